@@ -1,0 +1,69 @@
+"""Shared helpers for golden fixtures: a deterministic, construction-order-independent parameter
+fill (so the reference module in make_golden.py and our module in the tests get bit-identical
+weights from their *names and shapes alone*) and compact tensor digests."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def fill_params(module, seed=0):
+    """Overwrite every parameter/buffer of `module` from a per-name seeded CPU generator."""
+    sd = module.state_dict()
+    new = {}
+    for name in sorted(sd):
+        t = sd[name]
+        if not torch.is_floating_point(t):
+            new[name] = t.clone()
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if name.endswith("running_var"):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif name.endswith("running_mean"):
+            v = torch.randn(t.shape, generator=g) * 0.1
+        elif t.dim() == 1 and name.endswith(".weight"):  # norm scale
+            v = torch.rand(t.shape, generator=g) + 0.5
+        elif t.dim() == 1 or name.endswith(".bias"):
+            v = torch.randn(t.shape, generator=g) * 0.05
+        elif t.dim() == 3 and name.endswith(".weight"):  # LayerNorm([C,H,W]) scale
+            v = torch.rand(t.shape, generator=g) + 0.5
+        else:
+            fan_in = int(np.prod(t.shape[1:])) if t.dim() > 1 else t.numel()
+            v = torch.randn(t.shape, generator=g) * (1.5 / max(fan_in, 1)) ** 0.5
+        new[name] = v.to(t.dtype)
+    module.load_state_dict(new)
+    return module
+
+
+def seeded(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def digest(t, stride=None):
+    """Compact fingerprint of a tensor: shape, mean, abs-mean, per-channel means, strided sample."""
+    t = t.detach().double().cpu()
+    out = {"shape": np.asarray(t.shape, np.int64), "mean": np.float64(t.mean()), "absmean": np.float64(t.abs().mean())}
+    if t.dim() >= 2:
+        dims = [d for d in range(t.dim()) if d != 1]
+        out["chmean"] = t.mean(dim=dims).numpy()
+    flat = t.reshape(-1)
+    if stride is None:
+        stride = max(1, flat.numel() // 4096)
+    out["sample"] = flat[::stride].numpy().astype(np.float32)
+    out["stride"] = np.int64(stride)
+    return out
+
+
+def pack(prefix, d):
+    return {f"{prefix}.{k}": v for k, v in d.items()}
+
+
+def check_digest(t, npz, prefix, rtol, atol):
+    d = digest(t, int(npz[f"{prefix}.stride"]))
+    assert tuple(d["shape"]) == tuple(npz[f"{prefix}.shape"]), (prefix, d["shape"], npz[f"{prefix}.shape"])
+    np.testing.assert_allclose(d["sample"], npz[f"{prefix}.sample"], rtol=rtol, atol=atol, err_msg=prefix)
+    np.testing.assert_allclose(d["mean"], npz[f"{prefix}.mean"], rtol=rtol, atol=atol, err_msg=prefix)
+    np.testing.assert_allclose(d["absmean"], npz[f"{prefix}.absmean"], rtol=rtol, atol=atol, err_msg=prefix)
+    if f"{prefix}.chmean" in npz:
+        np.testing.assert_allclose(d["chmean"], npz[f"{prefix}.chmean"], rtol=rtol, atol=atol * 10, err_msg=prefix)
