@@ -1,0 +1,150 @@
+/*
+ * s2d.h — C-ABI of libs2d_hip.so: the MI355X (gfx950) hot path of Sparse2Dense / CenterPoint.
+ *
+ * One `extern "C"` shared object, plain pointers and sizes only (no torch / C++ types).  It
+ * replaces, for the voxel-backbone path, what the reference binds through numba and through the
+ * third-party `spconv` extension (reference = /root/reference, stevewongv/Sparse2Dense):
+ *
+ *   s2d_voxelize_*        <- det3d/ops/point_cloud/point_cloud_ops.py:7-55,112-184
+ *                            (points_to_voxel / _points_to_voxel_reverse_kernel) fused with
+ *                            det3d/models/readers/voxel_encoder.py:17-24 (per-voxel mean)
+ *   s2d_rulebook_subm_*   <- spconv.ops.get_indice_pairs(subm=True)  as called by SubMConv3d at
+ *                            det3d/models/backbones/scn.py:18-26,105,202-238
+ *   s2d_rulebook_conv_*   <- spconv.ops.get_indice_pairs(subm=False) as called by SparseConv3d at
+ *                            det3d/models/backbones/scn.py:116-118,126-128,136-138,147-149
+ *   s2d_spconv_fwd / _wgrad <- spconv.ops.indice_conv / indice_conv_backward (same call sites)
+ *   s2d_bn1d_*            <- nn.BatchNorm1d + ReLU + residual on `.features`, scn.py:69-85,104-152
+ *   s2d_densify_*         <- spconv.SparseConvTensor.dense(), scn.py:173-176, voxelnet.py:203-215
+ *
+ * Conventions
+ *   - every entry returns int: 0 = OK, <0 = invalid argument / unsupported shape / capacity,
+ *     >0 = hipError_t of a failed HIP call; text via s2d_last_error() (thread-local).
+ *   - all buffers are caller-owned DEVICE pointers (PyTorch caching allocator in our host code);
+ *     the library never allocates, frees or retains device memory.
+ *   - every entry is asynchronous on the caller's stream (`s2d_stream_t` = hipStream_t passed as
+ *     void*; NULL = the null stream) and never synchronises the device.
+ *   - variable-size results use a device scalar (`out_m`, `out_n`) that the HOST reads back only
+ *     where the reference API itself exposes a size.
+ *   - indices are int32, features fp32 (bf16 entry points carry the _bf16 suffix).
+ */
+#ifndef S2D_H_
+#define S2D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *s2d_stream_t;
+
+#define S2D_OK 0
+#define S2D_ERR_INVALID_ARG (-1)
+#define S2D_ERR_UNSUPPORTED (-2)
+#define S2D_ERR_CAPACITY (-3)
+#define S2D_ERR_WORKSPACE (-4)
+
+/* ---- library ------------------------------------------------------------------------------ */
+int s2d_version(void);
+/* copies the calling thread's last error text (NUL terminated) into buf; returns its length */
+int s2d_last_error(char *buf, size_t buf_len);
+
+/* ---- voxelization (hard voxelizer + fused reader mean) ------------------------------------ */
+/* workspace bytes for one call (hash table, per-point slots, scan scratch, k-smallest lists) */
+size_t s2d_voxelize_workspace_bytes(int64_t n_points, int max_points, int max_voxels);
+/*
+ * points[n_points][ndim] fp32 (x,y,z,...) ; coors_range = xmin,ymin,zmin,xmax,ymax,zmax ;
+ * voxel_size = (vx,vy,vz).  Outputs (rows >= *out_m are left untouched):
+ *   voxels[max_voxels][max_points][ndim] fp32 (zero padded), coors[max_voxels][3] int32 (z,y,x),
+ *   num_points[max_voxels] int32, mean[max_voxels][ndim] fp32 (may be NULL), out_m device int32.
+ * Voxel order = order of first appearance in `points`; slot order = point order; voxels whose
+ * first point comes after the max_voxels-th distinct voxel are dropped (reference semantics).
+ */
+int s2d_voxelize_run(const float *points, int64_t n_points, int ndim, const float coors_range[6],
+                     const float voxel_size[3], int max_points, int max_voxels, float *voxels,
+                     int32_t *coors, int32_t *num_points, float *mean, int32_t *out_m, void *ws,
+                     size_t ws_bytes, s2d_stream_t stream);
+
+/* ---- rulebooks ---------------------------------------------------------------------------- */
+/*
+ * A rulebook is a pair of dense gather maps (K = kD*kH*kW offsets, row-major over kz,ky,kx):
+ *   nbr_out[k][o] = input row j feeding output row o through offset k, or -1
+ *   nbr_in [k][j] = output row o fed by input row j through offset k, or -1   (transposed map,
+ *                   used by the data-gradient; for SubM it is nbr_out[K-1-k] and not stored)
+ * pair_count[k] = number of (j -> o) pairs of offset k (what spconv calls indice_pair_num).
+ * `shape` is the (D,H,W) extent the coordinates index; coors rows are (b,z,y,x).
+ */
+size_t s2d_rulebook_workspace_bytes(int batch, const int32_t shape[3], int64_t n_rows);
+
+/* SubM: output rows = input rows, same order; centred (pad = k/2, stride 1). */
+int s2d_rulebook_subm_build(const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                            const int32_t ksize[3], const int32_t dilation[3], int32_t *nbr_out,
+                            int32_t *pair_count, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/*
+ * Regular (strided) conv, two phases around the one host read of *out_n:
+ *   _count: marks every reachable output site, numbers them in sorted linear (b,z,y,x) order and
+ *           writes the count to the device scalar out_n (workspace keeps the occupancy index);
+ *   _fill : with n_out = *out_n known to the host, writes out_coors[n_out][4], nbr_out[K][n_out],
+ *           nbr_in[K][n] and pair_count[K].  Must reuse the same workspace, unchanged.
+ */
+int s2d_rulebook_conv_count(const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                            const int32_t ksize[3], const int32_t stride[3],
+                            const int32_t padding[3], const int32_t dilation[3], int32_t *out_n,
+                            void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_rulebook_conv_fill(const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                           const int32_t ksize[3], const int32_t stride[3],
+                           const int32_t padding[3], const int32_t dilation[3], int64_t n_out,
+                           int32_t *out_coors, int32_t *nbr_out, int32_t *nbr_in,
+                           int32_t *pair_count, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/* ---- sparse convolution (implicit GEMM on MFMA) ------------------------------------------- */
+/*
+ * out[o][:] = sum_k in[nbr[k][o]][:] * weight[k][:][:] (+ bias), fp32 in / fp32 accumulate on
+ * v_mfma_f32_16x16x4_f32.  weight is [K][cin][cout] (spconv v1.x layout [kD,kH,kW,Cin,Cout]).
+ * The same entry computes the data gradient when given nbr_in and the transposed weights.
+ * `nbr` has row stride n_out.
+ */
+int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const float *weight, const float *bias,
+                       const int32_t *nbr, int64_t n_out, int kvol, int cin, int cout,
+                       float *out_feat, s2d_stream_t stream);
+/* dweight[k] = sum_o in[nbr[k][o]]^T * dout[o]  ([K][cin][cout]); deterministic two-pass. */
+size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int cin, int cout);
+int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
+                         int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws,
+                         size_t ws_bytes, s2d_stream_t stream);
+
+/* ---- BatchNorm1d on features (+ReLU, +residual) ------------------------------------------- */
+/* stats[0..C) = sum_x, stats[C..2C) = sum_x^2 over the n rows (deterministic tree reduction) */
+size_t s2d_bn1d_workspace_bytes(int64_t n, int c);
+int s2d_bn1d_stats_f32(const float *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
+                       s2d_stream_t stream);
+/* y = relu?( (x - mean) * invstd * gamma + beta (+ residual) ); scale/shift precomputed [C] */
+int s2d_bn1d_apply_f32(const float *x, const float *scale, const float *shift,
+                       const float *residual, int relu, int64_t n, int c, float *y,
+                       s2d_stream_t stream);
+/*
+ * Backward of y = relu?(x*scale + shift (+res)):  g = dy * (y > 0 if relu);
+ * sums[0..C) = sum g, sums[C..2C) = sum g * x  (for dgamma/dbeta and the batch-stat terms);
+ * g is written to dres (may alias nothing; may be NULL when there is no residual and dx is
+ * produced by the second call).
+ */
+int s2d_bn1d_bwd_reduce_f32(const float *dy, const float *y, const float *x, int relu, int64_t n,
+                            int c, float *g_out, float *sums, void *ws, size_t ws_bytes,
+                            s2d_stream_t stream);
+/* dx = a[c]*g + b[c]*x + d[c]  (training-mode BN backward folded into three per-channel vectors) */
+int s2d_bn1d_bwd_apply_f32(const float *g, const float *x, const float *a, const float *b,
+                           const float *d, int64_t n, int c, float *dx, s2d_stream_t stream);
+
+/* ---- densify (SparseConvTensor.dense()) --------------------------------------------------- */
+/* out[B][C][D][H][W] (zero filled here) <- features[n][C] at coors[n][4]; bwd is the gather. */
+int s2d_densify_fwd_f32(const float *feat, const int32_t *coors, int64_t n, int batch,
+                        const int32_t shape[3], int c, float *out, s2d_stream_t stream);
+int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int64_t n, int batch,
+                        const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2D_H_ */

@@ -1,0 +1,107 @@
+"""ctypes binding of libs2d_hip.so (C-ABI declared in include/s2d.h).
+
+The product path has NO CPU fallback: if the shared object is missing or does not export a
+symbol, importing/using the ops raises immediately (build it with `python -m sparse2dense_amd.build`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libs2d_hip.so")
+
+c_i32p = ctypes.c_void_p
+c_f32p = ctypes.c_void_p
+_I3 = ctypes.c_int32 * 3
+_F3 = ctypes.c_float * 3
+_F6 = ctypes.c_float * 6
+
+# name -> (restype, argtypes); mirrors include/s2d.h one to one
+SIGNATURES = {
+    "s2d_version": (ctypes.c_int, []),
+    "s2d_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "s2d_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "s2d_voxelize_run": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, _F6, _F3, ctypes.c_int, ctypes.c_int,
+                                        c_f32p, c_i32p, c_i32p, c_f32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.c_void_p]),
+    "s2d_rulebook_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _I3, ctypes.c_int64]),
+    "s2d_rulebook_subm_build": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, c_i32p, c_i32p,
+                                               ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_rulebook_conv_count": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, _I3, _I3, c_i32p,
+                                               ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_rulebook_conv_fill": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, _I3, _I3,
+                                              ctypes.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_void_p,
+                                              ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_spconv_fwd_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_spconv_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "s2d_spconv_wgrad_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p]),
+    "s2d_bn1d_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "s2d_bn1d_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p,
+                                          ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bn1d_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                          c_f32p, ctypes.c_void_p]),
+    "s2d_bn1d_bwd_reduce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                               c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bn1d_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int,
+                                              c_f32p, ctypes.c_void_p]),
+    "s2d_densify_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
+                                           ctypes.c_void_p]),
+    "s2d_densify_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
+                                           ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class S2DError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libs2d_hip.so and type every entry point.  Raises if the build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise S2DError(
+            f"{LIB_PATH} not found: the HIP extension is not built (python -m sparse2dense_amd.build). "
+            "There is no CPU fallback for the sparse2dense_amd ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise S2DError(f"{LIB_PATH} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().s2d_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what=""):
+    """Mirror of the reference's AT_ERROR/TORCH_CHECK convention: non-zero -> RuntimeError."""
+    if rc != 0:
+        raise S2DError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def i3(v):
+    if isinstance(v, int):
+        v = (v, v, v)
+    v = [int(x) for x in v]
+    assert len(v) == 3
+    return _I3(*v)
+
+
+def f3(v):
+    return _F3(*[float(x) for x in v])
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])

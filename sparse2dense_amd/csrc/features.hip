@@ -1,0 +1,272 @@
+// Row-wise feature kernels of the sparse backbone on gfx950 (all HBM-bound, float4 vectorised):
+//   * BatchNorm1d statistics / apply(+ReLU,+residual) / backward on `.features` [N,C]
+//     (det3d/models/backbones/scn.py:69-85,104-152; BN1d eps=1e-3 momentum=0.01, scn.py:100-101)
+//   * SparseConvTensor.dense() scatter and its gather backward (scn.py:173-176)
+// Reductions are two-pass and order-fixed (deterministic; SyncBN all-reduces the [2C] vectors).
+#include "s2d_common.h"
+
+namespace s2d {
+
+constexpr int RED_THREADS = 256;
+
+// Each block reduces rows [blockIdx.x*rows_per_block, ...) for all channels; thread t owns the
+// 4-channel group (t % (C/4)) and the row lane (t / (C/4)).  C must be a multiple of 4, <= 1024.
+template <bool BWD>
+__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                                 const float *__restrict__ y, int relu, int64_t n, int c,
+                                                                 int rows_per_block, float *__restrict__ g_out,
+                                                                 float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [row_lanes][2][C]
+    const int c4 = c >> 2;
+    const int lanes = RED_THREADS / c4;  // row lanes per block (>= 1)
+    const int grp = threadIdx.x % c4, rl = threadIdx.x / c4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    float4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (rl < lanes) {
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const float4 xv = reinterpret_cast<const float4 *>(x + r * c)[grp];
+            if (BWD) {
+                float4 g = reinterpret_cast<const float4 *>(dy + r * c)[grp];
+                if (relu) {
+                    const float4 yv = reinterpret_cast<const float4 *>(y + r * c)[grp];
+                    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                    g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+                }
+                if (g_out) reinterpret_cast<float4 *>(g_out + r * c)[grp] = g;
+                s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+                s1.x += g.x * xv.x; s1.y += g.y * xv.y; s1.z += g.z * xv.z; s1.w += g.w * xv.w;
+            } else {
+                s0.x += xv.x; s0.y += xv.y; s0.z += xv.z; s0.w += xv.w;
+                s1.x += xv.x * xv.x; s1.y += xv.y * xv.y; s1.z += xv.z * xv.z; s1.w += xv.w * xv.w;
+            }
+        }
+        reinterpret_cast<float4 *>(lds + (size_t)rl * 2 * c)[grp] = s0;
+        reinterpret_cast<float4 *>(lds + (size_t)rl * 2 * c + c)[grp] = s1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * c; e += RED_THREADS) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += lds[(size_t)l * 2 * c + e];
+        partial[(size_t)blockIdx.x * 2 * c + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblocks, int width,
+                                                          float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * width + e];
+    out[e] = s;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                       const float *__restrict__ shift, const float *__restrict__ res,
+                                                       int relu, int64_t n4, int c4, float *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % c4);
+        float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const float4 a = reinterpret_cast<const float4 *>(scale)[g];
+        const float4 b = reinterpret_cast<const float4 *>(shift)[g];
+        v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y); v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
+        if (res) {
+            const float4 rr = reinterpret_cast<const float4 *>(res)[i];
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4 *>(y)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                           const float *__restrict__ a, const float *__restrict__ b,
+                                                           const float *__restrict__ d, int64_t n4, int c4,
+                                                           float *__restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int grp = (int)(i % c4);
+        const float4 gv = reinterpret_cast<const float4 *>(g)[i];
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        const float4 av = reinterpret_cast<const float4 *>(a)[grp];
+        const float4 bv = reinterpret_cast<const float4 *>(b)[grp];
+        const float4 dv = reinterpret_cast<const float4 *>(d)[grp];
+        float4 o;
+        o.x = fmaf(av.x, gv.x, fmaf(bv.x, xv.x, dv.x));
+        o.y = fmaf(av.y, gv.y, fmaf(bv.y, xv.y, dv.y));
+        o.z = fmaf(av.z, gv.z, fmaf(bv.z, xv.z, dv.z));
+        o.w = fmaf(av.w, gv.w, fmaf(bv.w, xv.w, dv.w));
+        reinterpret_cast<float4 *>(dx)[i] = o;
+    }
+}
+
+// dense(): one thread per (channel, row) with the row index fastest, so that x-adjacent sites of
+// the canonically ordered rows write adjacent addresses of the same channel plane.
+__global__ __launch_bounds__(256) void densify_fwd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ coors,
+                                                          int64_t n, int batch, int D, int H, int W, int c,
+                                                          float *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ch = t / n;
+    const int64_t i = t - ch * n;
+    if (ch >= c) return;
+    const int4 co = reinterpret_cast<const int4 *>(coors)[i];
+    if ((unsigned)co.x >= (unsigned)batch || (unsigned)co.y >= (unsigned)D || (unsigned)co.z >= (unsigned)H ||
+        (unsigned)co.w >= (unsigned)W)
+        return;
+    out[((((int64_t)co.x * c + ch) * D + co.y) * H + co.z) * W + co.w] = feat[i * c + ch];
+}
+
+__global__ __launch_bounds__(256) void densify_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ coors,
+                                                          int64_t n, int batch, int D, int H, int W, int c,
+                                                          float *__restrict__ dfeat) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, channel), channel fastest
+    const int64_t i = t / c;
+    const int ch = (int)(t - i * c);
+    if (i >= n) return;
+    const int4 co = reinterpret_cast<const int4 *>(coors)[i];
+    float v = 0.f;
+    if ((unsigned)co.x < (unsigned)batch && (unsigned)co.y < (unsigned)D && (unsigned)co.z < (unsigned)H &&
+        (unsigned)co.w < (unsigned)W)
+        v = dout[((((int64_t)co.x * c + ch) * D + co.y) * H + co.z) * W + co.w];
+    dfeat[t] = v;
+}
+
+struct RedPlan {
+    int nblocks;
+    int rows_per_block;
+    size_t lds;
+    size_t ws_bytes;
+};
+static RedPlan red_plan(int64_t n, int c) {
+    RedPlan p;
+    const int c4 = c / 4;
+    const int lanes = RED_THREADS / c4 > 0 ? RED_THREADS / c4 : 1;
+    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * 16);
+    if (nb > 1024) nb = 1024;
+    p.nblocks = (int)nb;
+    p.rows_per_block = (int)ceil_div(n > 0 ? n : 1, nb);
+    p.lds = (size_t)lanes * 2 * c * sizeof(float);
+    p.ws_bytes = align_up((size_t)nb * 2 * c * sizeof(float), 256);
+    return p;
+}
+
+static int check_c(int c, const char *who) {
+    if (c <= 0 || (c & 3) || c > 1024) {
+        set_error("%s: channel count %d must be a positive multiple of 4 (<=1024)", who, c);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" size_t s2d_bn1d_workspace_bytes(int64_t n, int c) {
+    if (n < 0 || c <= 0 || (c & 3) || c > 1024) return 0;
+    return red_plan(n, c).ws_bytes;
+}
+
+extern "C" int s2d_bn1d_stats_f32(const float *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
+                                  s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_stats");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n >= 0 && stats && (n == 0 || x), "bn1d_stats: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        S2D_HIP(hipMemsetAsync(stats, 0, 2 * c * sizeof(float), st));
+        return S2D_OK;
+    }
+    RedPlan p = red_plan(n, c);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("bn1d_stats: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(col_reduce_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, nullptr, nullptr, 0, n, c,
+                       p.rows_per_block, nullptr, (float *)ws);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
+                       stats);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_apply_f32(const float *x, const float *scale, const float *shift, const float *residual, int relu,
+                                  int64_t n, int c, float *y, s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_apply");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n >= 0 && scale && shift && (n == 0 || (x && y)), "bn1d_apply: bad argument");
+    if (n == 0) return S2D_OK;
+    const int64_t n4 = n * (c / 4);
+    int64_t blocks = ceil_div(n4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift, residual,
+                       relu, n4, c / 4, y);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_bwd_reduce_f32(const float *dy, const float *y, const float *x, int relu, int64_t n, int c,
+                                       float *g_out, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_bwd_reduce");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n >= 0 && sums && (n == 0 || (dy && x)) && (!relu || n == 0 || y), "bn1d_bwd_reduce: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        S2D_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(float), st));
+        return S2D_OK;
+    }
+    RedPlan p = red_plan(n, c);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("bn1d_bwd_reduce: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(col_reduce_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, dy, y, relu, n, c,
+                       p.rows_per_block, g_out, (float *)ws);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
+                       sums);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_bwd_apply_f32(const float *g, const float *x, const float *a, const float *b, const float *d,
+                                      int64_t n, int c, float *dx, s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_bwd_apply");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n >= 0 && a && b && d && (n == 0 || (g && x && dx)), "bn1d_bwd_apply: bad argument");
+    if (n == 0) return S2D_OK;
+    const int64_t n4 = n * (c / 4);
+    int64_t blocks = ceil_div(n4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, x, a, b, d, n4,
+                       c / 4, dx);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_densify_fwd_f32(const float *feat, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                                   int c, float *out, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0 && out, "densify_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * sizeof(float);
+    S2D_HIP(hipMemsetAsync(out, 0, bytes, st));
+    if (n == 0) return S2D_OK;
+    S2D_CHECK_ARG(feat && coors, "densify_fwd: null input");
+    const int64_t threads = n * c;
+    hipLaunchKernelGGL(densify_fwd_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, feat, coors, n, batch,
+                       shape[0], shape[1], shape[2], c, out);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                                   int c, float *dfeat, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0, "densify_bwd: bad argument");
+    if (n == 0) return S2D_OK;
+    S2D_CHECK_ARG(dout && coors && dfeat, "densify_bwd: null argument");
+    const int64_t threads = n * c;
+    hipLaunchKernelGGL(densify_bwd_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, dout,
+                       coors, n, batch, shape[0], shape[1], shape[2], c, dfeat);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

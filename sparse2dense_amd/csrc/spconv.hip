@@ -1,0 +1,432 @@
+// Sparse 3-D convolution (submanifold and strided) as an OUTPUT-STATIONARY implicit GEMM on the
+// gfx950 matrix cores.  Replaces spconv's indice_conv / indice_conv_backward (27x gather kernel +
+// cuBLAS mm + scatter-add kernel with HBM round trips between them) by one kernel per layer:
+//
+//   forward / data-gradient  (spconv_fwd_mfma)
+//     a wave owns 16*MT output rows and a 16*NT-wide slab of output channels; it walks the K
+//     kernel offsets, gathers the neighbour rows named by nbr[k][rows] straight into MFMA A
+//     fragments (float4 per lane, rows are L2/MALL resident), multiplies by W[k] staged per
+//     workgroup in LDS with global_load_lds (double buffered, one barrier per offset) and keeps
+//     the fp32 accumulators in registers until the single, vectorised store.  No atomics, no
+//     intermediate buffers, deterministic.  Offsets with no active row in the wave are skipped.
+//   weight-gradient (spconv_wgrad_mfma)
+//     grid = (offset k, row split); M = cin, N = cout, K = rows.  A/B fragments are float4 row
+//     segments of in[nbr[k][o]] and dout[o]; partial tiles go to a [split][K][cin][cout] slab
+//     that a second kernel reduces in a fixed order (deterministic).
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 — exact fp32 FMA chains (fp32 in, fp32 accumulate).
+// Channel counts that are not multiples of 16 (the 5-channel input layer) take the VALU kernels
+// at the bottom; they are bandwidth-trivial.
+#include "s2d_common.h"
+
+namespace s2d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+struct VecF;
+template <>
+struct VecF<1> { typedef float type; };
+template <>
+struct VecF<2> { typedef float2 type; };
+template <>
+struct VecF<4> { typedef float4 type; };
+
+__device__ __forceinline__ float vec_get(const float &v, int) { return v; }
+__device__ __forceinline__ float vec_get(const float2 &v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float vec_get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// Stage a [CIN][CT] fp32 slab of W[k] (row stride `cout` floats in global memory) into LDS,
+// lane-linear, with the LDS-DMA path (16 B per lane, 1 KiB per wave instruction).
+template <int CIN, int CT>
+__device__ __forceinline__ void stage_weights(float *lds, const float *__restrict__ wk, int cout, int wid, int lane) {
+    constexpr int UNITS = CIN * CT / 256;  // wave-instructions of 64 lanes x 4 floats
+#pragma unroll
+    for (int u = 0; u < (UNITS + 3) / 4; ++u) {
+        const int unit = u * 4 + wid;
+        if (unit < UNITS) {
+            const int chunk = unit * 64 + lane;  // 16-byte chunk id inside the slab
+            const int row = (chunk * 4) / CT;
+            const int col = (chunk * 4) % CT;
+            const float *src = wk + (int64_t)row * cout + col;
+            float *dst = lds + unit * 256;  // wave-uniform base; hardware adds lane*16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    }
+}
+
+template <int CIN, int NT, int MT>
+__global__ __launch_bounds__(256) void spconv_fwd_mfma(const float *__restrict__ in, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                                                       int n_out, int kvol, int cout, float *__restrict__ out) {
+    constexpr int CT = 16 * NT;   // output channels per workgroup
+    constexpr int KT = CIN / 16;  // float4 A loads per row
+    typedef typename VecF<NT>::type vecn;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *wbuf0 = reinterpret_cast<float *>(smem);
+    float *wbuf1 = wbuf0 + CIN * CT;
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int co0 = blockIdx.y * CT;
+    const int row0 = (blockIdx.x * 4 + wid) * (16 * MT);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_weights<CIN, CT>(wbuf0, w + co0, cout, wid, lane);
+
+    for (int k = 0; k < kvol; ++k) {
+        float *wb = (k & 1) ? wbuf1 : wbuf0;
+        if (k + 1 < kvol)
+            stage_weights<CIN, CT>((k & 1) ? wbuf0 : wbuf1, w + (int64_t)(k + 1) * CIN * cout + co0, cout, wid, lane);
+
+        int j[MT];
+        bool mine = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = row0 + 16 * m + r;
+            j[m] = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+            mine = mine || (j[m] >= 0);
+        }
+        const bool any = __ballot(mine) != 0ull;  // wave-uniform
+        float4 a[MT][KT];
+        if (any) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 *src = reinterpret_cast<const float4 *>(in + (int64_t)(j[m] >= 0 ? j[m] : 0) * CIN) + q;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    a[m][t] = j[m] >= 0 ? src[t * 4] : float4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (k == 0) __syncthreads();  // W[0] landed (the barrier's release drains the LDS-DMA)
+        if (any) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 16 * t + 4 * q + e;  // K index of this lane's A element
+                    const vecn b = *reinterpret_cast<const vecn *>(wb + kk * CT + r * NT);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float av = vec_get(a[m][t], e);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, vec_get(b, n), acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // everyone is done with wb; W[k+1] has landed
+    }
+
+    // C/D layout: column = lane&15 (-> channels r*NT .. r*NT+NT-1), row = (lane>>4)*4 + reg
+    vecn bv;
+    {
+        float tmp[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) tmp[n] = bias ? bias[co0 + r * NT + n] : 0.f;
+        bv = *reinterpret_cast<vecn *>(tmp);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + 16 * m + 4 * q + reg;
+            if (row < n_out) {
+                float tmp[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) tmp[n] = acc[m][n][reg] + vec_get(bv, n);
+                *reinterpret_cast<vecn *>(out + (int64_t)row * cout + co0 + r * NT) = *reinterpret_cast<vecn *>(tmp);
+            }
+        }
+    }
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct WgradCfg {
+    static constexpr int VA = CIN / 16 < 4 ? CIN / 16 : 4;     // floats per A load
+    static constexpr int LA = CIN / (16 * VA);                 // A loads per pair
+    static constexpr int VB = COUT >= 32 ? 2 : 1;              // floats per B load = N tiles per wave
+    static constexpr int WCO = COUT / (16 * VB);               // waves across cout
+    static constexpr int WROW = 4 / WCO;                       // waves across rows
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict__ in, const float *__restrict__ dout,
+                                                         const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                         int rows_per_split, float *__restrict__ partial) {
+    typedef WgradCfg<CIN, COUT> C;
+    typedef typename VecF<C::VA>::type veca;
+    typedef typename VecF<C::VB>::type vecb;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int k = blockIdx.x;
+    const int wco = wid % C::WCO, wrow = wid / C::WCO;
+    const int split = blockIdx.y * C::WROW + wrow;
+    const int co_base = wco * 16 * C::VB;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+
+    f32x4 acc[C::LA][C::VA][C::VB];
+#pragma unroll
+    for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+        for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+            for (int f = 0; f < C::VB; ++f) acc[la][e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = r_begin; base < r_end; base += 4) {
+        const int o = base + q;
+        const int j = o < r_end ? nk[o] : -1;
+        if (__ballot(j >= 0) == 0ull) continue;
+        veca av[C::LA];
+        vecb bv;
+        if (j >= 0) {
+#pragma unroll
+            for (int la = 0; la < C::LA; ++la)
+                av[la] = *reinterpret_cast<const veca *>(in + (int64_t)j * CIN + 64 * la + C::VA * i16);
+            bv = *reinterpret_cast<const vecb *>(dout + (int64_t)o * COUT + co_base + C::VB * i16);
+        } else {
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int la = 0; la < C::LA; ++la) av[la] = *reinterpret_cast<veca *>(z);
+            bv = *reinterpret_cast<vecb *>(z);
+        }
+#pragma unroll
+        for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+            for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+                for (int f = 0; f < C::VB; ++f)
+                    acc[la][e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(vec_get(av[la], e), vec_get(bv, f),
+                                                                          acc[la][e][f], 0, 0, 0);
+    }
+    // tile (la,e,f), reg: ci = 64*la + VA*(4*q+reg) + e ; co = co_base + VB*i16 + f
+    float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;
+#pragma unroll
+    for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+        for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = 64 * la + C::VA * (4 * q + reg) + e;
+                float tmp[C::VB];
+#pragma unroll
+                for (int f = 0; f < C::VB; ++f) tmp[f] = acc[la][e][f][reg];
+                *reinterpret_cast<vecb *>(dst + (int64_t)ci * COUT + co_base + C::VB * i16) = *reinterpret_cast<vecb *>(tmp);
+            }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int n_split, int64_t size,
+                                                           float *__restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    float s = 0.f;
+    for (int sp = 0; sp < n_split; ++sp) s += partial[(int64_t)sp * size + i];
+    dw[i] = s;
+}
+
+// ---- VALU fallbacks (channel counts not multiple of 16, e.g. the 5-channel input layer) ----------
+__global__ __launch_bounds__(256) void spconv_fwd_valu(const float *__restrict__ in, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                                                       int n_out, int kvol, int cin, int cout, float *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, co)
+    const int64_t o = t / cout;
+    const int co = (int)(t - o * cout);
+    if (o >= n_out) return;
+    float acc = bias ? bias[co] : 0.f;
+    for (int k = 0; k < kvol; ++k) {
+        const int j = nbr[(int64_t)k * n_out + o];
+        if (j < 0) continue;
+        const float *x = in + (int64_t)j * cin;
+        const float *wk = w + (int64_t)k * cin * cout + co;
+        for (int ci = 0; ci < cin; ++ci) acc = fmaf(x[ci], wk[(int64_t)ci * cout], acc);
+    }
+    out[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void spconv_wgrad_valu(const float *__restrict__ in, const float *__restrict__ dout,
+                                                         const int32_t *__restrict__ nbr, int n_out, int kvol, int cin,
+                                                         int cout, int rows_per_split, float *__restrict__ partial) {
+    const int k = blockIdx.x, split = blockIdx.y;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+    for (int e = threadIdx.x; e < cin * cout; e += blockDim.x) {
+        const int ci = e / cout, co = e - ci * cout;
+        float s = 0.f;
+        for (int o = r_begin; o < r_end; ++o) {
+            const int j = nk[o];
+            if (j >= 0) s = fmaf(in[(int64_t)j * cin + ci], dout[(int64_t)o * cout + co], s);
+        }
+        partial[(((int64_t)split * kvol + k) * cin + ci) * cout + co] = s;
+    }
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------
+template <int CIN, int NT>
+static int launch_fwd(const float *in, const float *w, const float *bias, const int32_t *nbr, int n_out, int kvol,
+                      int cout, float *out, hipStream_t st) {
+    constexpr int CT = 16 * NT;
+    const size_t lds = 2 * (size_t)CIN * CT * sizeof(float);
+    const int ytiles = cout / CT;
+    const bool small = ceil_div(n_out, 128) * ytiles < 512;  // keep >= 2 workgroups per CU in flight
+    if (small) {
+        auto kern = spconv_fwd_mfma<CIN, NT, 1>;
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n_out, 64), ytiles), dim3(256), lds, st, in, w, bias, nbr, n_out,
+                           kvol, cout, out);
+    } else {
+        auto kern = spconv_fwd_mfma<CIN, NT, 2>;
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(n_out, 128), ytiles), dim3(256), lds, st, in, w, bias, nbr,
+                           n_out, kvol, cout, out);
+    }
+    S2D_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int CIN>
+static int dispatch_fwd_cout(const float *in, const float *w, const float *bias, const int32_t *nbr, int n_out, int kvol,
+                             int cout, float *out, hipStream_t st) {
+    switch (cout) {
+        case 16: return launch_fwd<CIN, 1>(in, w, bias, nbr, n_out, kvol, cout, out, st);
+        case 32: return launch_fwd<CIN, 2>(in, w, bias, nbr, n_out, kvol, cout, out, st);
+        case 64: return launch_fwd<CIN, 4>(in, w, bias, nbr, n_out, kvol, cout, out, st);
+        case 128: return launch_fwd<CIN, 4>(in, w, bias, nbr, n_out, kvol, cout, out, st);
+        default: return -1;
+    }
+}
+
+struct WgradPlan {
+    int n_split;        // total row splits
+    int rows_per_split; // multiple of 4
+    int grid_y;
+    bool mfma;
+    int wrow;
+};
+
+static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
+    WgradPlan p;
+    p.mfma = (cin == 16 || cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
+    int vb = cout >= 32 ? 2 : 1;
+    int wco = p.mfma ? cout / (16 * vb) : 1;
+    p.wrow = p.mfma ? 4 / wco : 1;
+    // aim at ~2048 waves in flight, at least 256 rows per split
+    int64_t want_blocks_y = ceil_div(2048, (int64_t)kvol * 4);
+    int64_t max_split = ceil_div(n_out > 0 ? n_out : 1, 256);
+    int64_t splits = want_blocks_y * p.wrow;
+    if (splits > max_split) splits = max_split;
+    splits = ceil_div(splits, p.wrow) * p.wrow;
+    p.n_split = (int)splits;
+    p.grid_y = (int)(splits / p.wrow);
+    p.rows_per_split = (int)(ceil_div(ceil_div(n_out > 0 ? n_out : 1, splits), 4) * 4);
+    return p;
+}
+
+template <int CIN, int COUT>
+static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
+                         float *partial, hipStream_t st) {
+    hipLaunchKernelGGL((spconv_wgrad_mfma<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out, kvol,
+                       p.rows_per_split, partial);
+}
+
+template <int CIN>
+static bool dispatch_wgrad_cout(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, int cout,
+                                const WgradPlan &p, float *partial, hipStream_t st) {
+    switch (cout) {
+        case 16: launch_wgrad<CIN, 16>(in, dout, nbr, n_out, kvol, p, partial, st); return true;
+        case 32: launch_wgrad<CIN, 32>(in, dout, nbr, n_out, kvol, p, partial, st); return true;
+        case 64: launch_wgrad<CIN, 64>(in, dout, nbr, n_out, kvol, p, partial, st); return true;
+        case 128: launch_wgrad<CIN, 128>(in, dout, nbr, n_out, kvol, p, partial, st); return true;
+        default: return false;
+    }
+}
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const float *weight, const float *bias,
+                                  const int32_t *nbr, int64_t n_out, int kvol, int cin, int cout, float *out_feat,
+                                  s2d_stream_t stream) {
+    S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0 && cin > 0 && cout > 0, "spconv_fwd: bad sizes");
+    S2D_CHECK_ARG(weight && (n_out == 0 || (nbr && out_feat)) && (n_in == 0 || in_feat), "spconv_fwd: null argument");
+    if (n_out == 0) return S2D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = -1;
+    const bool cout_ok = cout == 16 || cout == 32 || cout == 64 || cout == 128;
+    if (cout_ok && n_in > 0) {
+        switch (cin) {
+            case 16: rc = dispatch_fwd_cout<16>(in_feat, weight, bias, nbr, (int)n_out, kvol, cout, out_feat, st); break;
+            case 32: rc = dispatch_fwd_cout<32>(in_feat, weight, bias, nbr, (int)n_out, kvol, cout, out_feat, st); break;
+            case 64: rc = dispatch_fwd_cout<64>(in_feat, weight, bias, nbr, (int)n_out, kvol, cout, out_feat, st); break;
+            case 128: rc = dispatch_fwd_cout<128>(in_feat, weight, bias, nbr, (int)n_out, kvol, cout, out_feat, st); break;
+            default: break;
+        }
+        if (rc > 0) return rc;
+    }
+    if (rc != 0) {
+        const int64_t threads = n_out * cout;
+        hipLaunchKernelGGL(spconv_fwd_valu, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, in_feat, weight, bias,
+                           nbr, (int)n_out, kvol, cin, cout, out_feat);
+        S2D_LAUNCH_CHECK();
+    }
+    return S2D_OK;
+}
+
+extern "C" size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int cin, int cout) {
+    if (n_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0) return 0;
+    WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
+    return align_up((size_t)p.n_split * kvol * cin * cout * sizeof(float), 256);
+}
+
+extern "C" int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
+                                    int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
+                                    s2d_stream_t stream) {
+    S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0 && cin > 0 && cout > 0, "spconv_wgrad: bad sizes");
+    S2D_CHECK_ARG(dweight, "spconv_wgrad: null dweight");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t size = (int64_t)kvol * cin * cout;
+    if (n_out == 0 || n_in == 0) {
+        S2D_HIP(hipMemsetAsync(dweight, 0, size * sizeof(float), st));
+        return S2D_OK;
+    }
+    S2D_CHECK_ARG(in_feat && dout && nbr, "spconv_wgrad: null argument");
+    WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
+    const size_t need = (size_t)p.n_split * size * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("spconv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    float *partial = (float *)ws;
+    bool done = false;
+    if (p.mfma) {
+        switch (cin) {
+            case 16: done = dispatch_wgrad_cout<16>(in_feat, dout, nbr, (int)n_out, kvol, cout, p, partial, st); break;
+            case 32: done = dispatch_wgrad_cout<32>(in_feat, dout, nbr, (int)n_out, kvol, cout, p, partial, st); break;
+            case 64: done = dispatch_wgrad_cout<64>(in_feat, dout, nbr, (int)n_out, kvol, cout, p, partial, st); break;
+            case 128: done = dispatch_wgrad_cout<128>(in_feat, dout, nbr, (int)n_out, kvol, cout, p, partial, st); break;
+            default: break;
+        }
+    }
+    if (!done) {
+        hipLaunchKernelGGL(spconv_wgrad_valu, dim3(kvol, p.n_split), dim3(128), 0, st, in_feat, dout, nbr, (int)n_out, kvol,
+                           cin, cout, p.rows_per_split, partial);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, p.n_split, size,
+                       dweight);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

@@ -1,0 +1,278 @@
+// Hard voxelization on gfx950, bit-compatible with the reference's sequential loop
+// (det3d/ops/point_cloud/point_cloud_ops.py:7-55) and fused with the mean reader
+// (det3d/models/readers/voxel_encoder.py:17-24).
+//
+// The reference is a first-come-first-served loop; the parallel restatement is
+//   1. vox_insert : per point, fp32 (p-lo)/vs with a correctly rounded divide + floor, range
+//                   test, linear cell key; open-addressing hash insert (L2-resident table, 8 B
+//                   per slot) and atomicMin of the point index  -> "first point of the cell"
+//   2. scan       : flag[i] = (first[slot(i)] == i); exclusive scan in point order = voxel id in
+//                   first-appearance order; ids >= max_voxels are dropped (cells that appear
+//                   after the table is full never enter it in the reference either)
+//   3. vox_ksmall : per point, cascade of atomicMin through the voxel's max_points-entry list =
+//                   the max_points smallest point indices in ascending order (slot order = point
+//                   order), independent of execution order
+//   4. vox_fill   : gather points into voxels[M][P][ndim] (zero padded), num_points, and the
+//                   per-voxel mean (slot-ordered fp32 sum / count)
+// HBM-bound integer/byte work: all tables are int32, reads of `points` are the only full-size
+// stream (20 B/point), everything else is L2-resident at 150 k points.
+#include <limits.h>
+
+#include "s2d_common.h"
+#include "scan.h"
+
+namespace s2d {
+
+constexpr uint32_t VOX_EMPTY = 0xFFFFFFFFu;
+constexpr int IDX_EMPTY = 0x7F7F7F7F;  // what hipMemsetAsync(.., 0x7F, ..) produces; > any point index
+
+struct VoxParams {
+    float lo[3];
+    float vs[3];
+    int grid[3];  // x, y, z
+    int ndim;
+    int max_points;
+    int max_voxels;
+    uint32_t table_mask;
+    int table_shift;  // 32 - log2(table size)
+};
+
+__device__ __forceinline__ uint32_t vox_hash(uint32_t key, int shift) { return (key * 2654435761u) >> shift; }
+
+__global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict__ points, int n, VoxParams p,
+                                                         uint32_t *__restrict__ keys, int *__restrict__ first,
+                                                         int *__restrict__ pt_slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *pt = points + (int64_t)i * p.ndim;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // point_cloud_ops.py:36 — IEEE fp32 subtract, correctly rounded divide, floor
+        float q = __fdiv_rn(__fsub_rn(pt[j], p.lo[j]), p.vs[j]);
+        float f = floorf(q);
+        ok = ok && (f >= 0.0f) && (f < (float)p.grid[j]);
+        c[j] = (int)f;
+    }
+    int slot = -1;
+    if (ok) {
+        const uint32_t key = ((uint32_t)c[2] * (uint32_t)p.grid[1] + (uint32_t)c[1]) * (uint32_t)p.grid[0] + (uint32_t)c[0];
+        uint32_t h = vox_hash(key, p.table_shift);
+        while (true) {
+            uint32_t old = atomicCAS(&keys[h], VOX_EMPTY, key);
+            if (old == VOX_EMPTY || old == key) break;
+            h = (h + 1) & p.table_mask;
+        }
+        atomicMin(&first[h], i);
+        slot = (int)h;
+    }
+    pt_slot[i] = slot;
+}
+
+struct FirstFlagIn {
+    const int *pt_slot;
+    const int *first;
+    __device__ int operator()(int64_t i) const {
+        int s = pt_slot[i];
+        return (s >= 0 && first[s] == (int)i) ? 1 : 0;
+    }
+};
+
+struct AssignVoxelOut {
+    const int *pt_slot;
+    const uint32_t *keys;
+    int *vid;          // per table slot
+    int32_t *coors;    // [max_voxels][3] z,y,x
+    VoxParams p;
+    __device__ void operator()(int64_t i, int flag, int rank) const {
+        if (!flag) return;
+        const int s = pt_slot[i];
+        if (rank < p.max_voxels) {
+            vid[s] = rank;
+            uint32_t key = keys[s];
+            int x = key % (uint32_t)p.grid[0];
+            key /= (uint32_t)p.grid[0];
+            int y = key % (uint32_t)p.grid[1];
+            int z = key / (uint32_t)p.grid[1];
+            coors[3 * rank + 0] = z;
+            coors[3 * rank + 1] = y;
+            coors[3 * rank + 2] = x;
+        } else {
+            vid[s] = -1;
+        }
+    }
+};
+
+__global__ void vox_finalize_count_kernel(const int *total, int max_voxels, int32_t *out_m) {
+    int t = *total;
+    *out_m = t < max_voxels ? t : max_voxels;
+}
+
+__global__ __launch_bounds__(256) void vox_ksmall_kernel(const int *__restrict__ pt_slot, const int *__restrict__ vid,
+                                                         int n, int max_points, int *__restrict__ ksmall) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = pt_slot[i];
+    if (s < 0) return;
+    const int v = vid[s];
+    if (v < 0) return;
+    int *list = ksmall + (int64_t)v * max_points;
+    int x = i;
+    // cheap early-out: already larger than the current last entry (entries only decrease)
+    if (__hip_atomic_load(&list[max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x) return;
+    for (int r = 0; r < max_points; ++r) {
+        int old = atomicMin(&list[r], x);
+        if (old == IDX_EMPTY) return;  // took an empty place, nothing displaced
+        x = old > x ? old : x;       // carry the larger one down the list
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_fill_kernel(const float *__restrict__ points, const int *__restrict__ ksmall,
+                                                       const int32_t *__restrict__ out_m, int ndim, int max_points,
+                                                       float *__restrict__ voxels, int32_t *__restrict__ num_points) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (voxel, slot)
+    const int m = *out_m;
+    const int64_t v = t / max_points;
+    const int r = (int)(t - v * max_points);
+    if (v >= m) return;
+    const int pid = ksmall[t];
+    float *dst = voxels + t * ndim;
+    if (pid != IDX_EMPTY) {
+        const float *src = points + (int64_t)pid * ndim;
+        for (int c = 0; c < ndim; ++c) dst[c] = src[c];
+    } else {
+        for (int c = 0; c < ndim; ++c) dst[c] = 0.0f;
+    }
+    if (r == 0) {
+        int cnt = 0;
+        for (int q = 0; q < max_points; ++q) cnt += (ksmall[v * max_points + q] != IDX_EMPTY) ? 1 : 0;
+        num_points[v] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_mean_kernel(const float *__restrict__ points, const int *__restrict__ ksmall,
+                                                       const int32_t *__restrict__ out_m, int ndim, int max_points,
+                                                       float *__restrict__ mean) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (voxel, channel)
+    const int m = *out_m;
+    const int64_t v = t / ndim;
+    const int c = (int)(t - v * ndim);
+    if (v >= m) return;
+    float s = 0.0f;
+    int cnt = 0;
+    for (int q = 0; q < max_points; ++q) {  // slot order, like features.sum(dim=1)
+        int pid = ksmall[v * max_points + q];
+        if (pid != IDX_EMPTY) {
+            s = __fadd_rn(s, points[(int64_t)pid * ndim + c]);
+            ++cnt;
+        }
+    }
+    mean[t] = __fdiv_rn(s, (float)cnt);
+}
+
+struct VoxWs {
+    uint32_t *keys;
+    int *first;
+    int *vid;
+    int *pt_slot;
+    int *block_sums;
+    int *total;
+    int *ksmall;
+    size_t table_size;
+    size_t bytes;
+};
+
+static VoxWs vox_carve(void *ws, int64_t n_points, int max_points, int max_voxels) {
+    VoxWs w;
+    size_t t = 1024;
+    while (t < (size_t)(2 * (n_points > 0 ? n_points : 1))) t <<= 1;
+    w.table_size = t;
+    Carver c(ws);
+    w.keys = c.take<uint32_t>(t);
+    w.first = c.take<int>(t);
+    w.vid = c.take<int>(t);
+    w.pt_slot = c.take<int>(n_points > 0 ? n_points : 1);
+    w.block_sums = c.take<int>(scan_num_blocks(n_points));
+    w.total = c.take<int>(1);
+    int64_t rows = n_points < max_voxels ? n_points : max_voxels;
+    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.bytes = c.total();
+    return w;
+}
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" size_t s2d_voxelize_workspace_bytes(int64_t n_points, int max_points, int max_voxels) {
+    if (n_points < 0 || max_points <= 0 || max_voxels <= 0) return 0;
+    return vox_carve(nullptr, n_points, max_points, max_voxels).bytes;
+}
+
+extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim, const float coors_range[6],
+                                const float voxel_size[3], int max_points, int max_voxels, float *voxels,
+                                int32_t *coors, int32_t *num_points, float *mean, int32_t *out_m, void *ws,
+                                size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n_points >= 0 && n_points < (int64_t)INT_MAX / 2, "voxelize: n_points=%lld out of range", (long long)n_points);
+    S2D_CHECK_ARG(ndim >= 3 && max_points > 0 && max_voxels > 0, "voxelize: bad ndim/max_points/max_voxels");
+    S2D_CHECK_ARG(coors_range && voxel_size && out_m && coors && voxels && num_points, "voxelize: null argument");
+    S2D_CHECK_ARG(n_points == 0 || points, "voxelize: null points");
+    hipStream_t st = (hipStream_t)stream;
+    VoxParams p;
+    double cells = 1.0;
+    for (int j = 0; j < 3; ++j) {
+        p.lo[j] = coors_range[j];
+        p.vs[j] = voxel_size[j];
+        // point_cloud_ops.py:24-27 and voxel_generator.py:10-11: fp32 divide, round half to even
+        float g = (coors_range[3 + j] - coors_range[j]) / voxel_size[j];
+        p.grid[j] = (int)nearbyintf(g);
+        S2D_CHECK_ARG(p.grid[j] > 0, "voxelize: empty grid on axis %d", j);
+        cells *= p.grid[j];
+    }
+    if (cells >= 4294967295.0) {
+        set_error("voxelize: grid of %.0f cells exceeds the 32-bit key space", cells);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    p.ndim = ndim;
+    p.max_points = max_points;
+    p.max_voxels = max_voxels;
+    VoxWs w = vox_carve(ws, n_points, max_points, max_voxels);
+    if (ws_bytes < w.bytes || !ws) {
+        set_error("voxelize: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    int lg = 0;
+    while (((size_t)1 << lg) < w.table_size) ++lg;
+    p.table_mask = (uint32_t)(w.table_size - 1);
+    p.table_shift = 32 - lg;
+
+    if (n_points == 0) {
+        S2D_HIP(hipMemsetAsync(out_m, 0, sizeof(int32_t), st));
+        return S2D_OK;
+    }
+    const int n = (int)n_points;
+    const int64_t rows = n_points < max_voxels ? n_points : max_voxels;
+    S2D_HIP(hipMemsetAsync(w.keys, 0xFF, w.table_size * sizeof(uint32_t), st));
+    S2D_HIP(hipMemsetAsync(w.first, 0x7F, w.table_size * sizeof(int), st));
+    S2D_HIP(hipMemsetAsync(w.ksmall, 0x7F, (size_t)rows * max_points * sizeof(int), st));
+    const dim3 blk(256);
+    hipLaunchKernelGGL(vox_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, w.keys, w.first, w.pt_slot);
+    S2D_LAUNCH_CHECK();
+    FirstFlagIn fin{w.pt_slot, w.first};
+    AssignVoxelOut fout{w.pt_slot, w.keys, w.vid, coors, p};
+    int rc = device_exclusive_scan(fin, fout, n_points, w.block_sums, w.total, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_finalize_count_kernel, dim3(1), dim3(1), 0, st, w.total, max_voxels, out_m);
+    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.vid, n, max_points, w.ksmall);
+    const int64_t fill_threads = rows * max_points;
+    hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)ceil_div(fill_threads, 256)), blk, 0, st, points, w.ksmall, out_m,
+                       ndim, max_points, voxels, num_points);
+    if (mean) {
+        const int64_t mean_threads = rows * ndim;
+        hipLaunchKernelGGL(vox_mean_kernel, dim3((unsigned)ceil_div(mean_threads, 256)), blk, 0, st, points, w.ksmall,
+                           out_m, ndim, max_points, mean);
+    }
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

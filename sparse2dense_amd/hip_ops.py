@@ -1,0 +1,276 @@
+"""Host-side launchers of the HIP kernels: torch tensors in, raw device pointers + the current
+HIP stream into the C-ABI (include/s2d.h).  No compute happens in Python and nothing here
+falls back to the CPU: tensors must live on a ROCm device.
+
+Reference interfaces these stand in for (file:line under /root/reference):
+  voxelize            det3d/ops/point_cloud/point_cloud_ops.py:112-184 + readers/voxel_encoder.py:17-24
+  subm/conv rulebook  spconv.ops.get_indice_pairs          (call sites det3d/models/backbones/scn.py:104-152)
+  spconv fwd/dgrad/wgrad  spconv.ops.indice_conv[_backward] (same call sites)
+  bn1d_*              nn.BatchNorm1d on .features           (scn.py:73-83)
+  densify             spconv.SparseConvTensor.dense()       (scn.py:173)
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, f3, f6, i3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.S2DError("sparse2dense_amd HIP op called with a CPU tensor: there is no CPU fallback")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# voxelization
+# ------------------------------------------------------------------------------------------------
+def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max_voxels: int, with_mean=True):
+    """Device hard-voxelizer.  points f32[N,ndim] (cuda).  Returns
+    (voxels f32[M,max_points,ndim], coors i32[M,3] (z,y,x), num_points i32[M], mean f32[M,ndim]|None).
+    One host read (M) — the same size the reference API returns."""
+    lib = _lib.load()
+    _need_gpu(points)
+    points = points.contiguous().float()
+    n, ndim = points.shape
+    dev = points.device
+    rows = max(min(n, max_voxels), 1)
+    voxels = torch.empty((rows, max_points, ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((rows, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((rows,), dtype=torch.int32, device=dev)
+    mean = torch.empty((rows, ndim), dtype=torch.float32, device=dev) if with_mean else None
+    out_m = torch.zeros((1,), dtype=torch.int32, device=dev)
+    wsb = lib.s2d_voxelize_workspace_bytes(n, max_points, max_voxels)
+    ws = _ws(wsb, dev)
+    # NB: the library sizes its outputs by max_voxels; we allocate min(n, max_voxels) rows, which is
+    # all it can ever write (ids are ranks of first points).
+    check(lib.s2d_voxelize_run(_ptr(points), n, ndim, f6(coors_range), f3(voxel_size), max_points, max_voxels,
+                               _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(out_m), _ptr(ws), ws.numel(),
+                               _stream()), "s2d_voxelize_run")
+    m = int(out_m.item())
+    return voxels[:m], coors[:m], num[:m], (mean[:m] if with_mean else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# rulebooks
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Rulebook:
+    """Dense gather maps of one sparse conv layer (see include/s2d.h)."""
+    subm: bool
+    kvol: int
+    n_in: int
+    n_out: int
+    nbr_out: torch.Tensor              # i32[K, n_out]: input row per (offset, output row) or -1
+    nbr_in: Optional[torch.Tensor]     # i32[K, n_in]: output row per (offset, input row) or -1 (None for subm)
+    pair_count: torch.Tensor           # i32[K]
+    out_coors: Optional[torch.Tensor]  # i32[n_out,4] (None for subm: same as input)
+    out_shape: Tuple[int, int, int]
+
+    def pairs(self):
+        """spconv-style per-offset (in_idx, out_idx) lists, on the host (tests / export only)."""
+        nb = self.nbr_out.cpu().numpy()
+        res = []
+        for k in range(self.kvol):
+            o = np.nonzero(nb[k] >= 0)[0]
+            res.append((nb[k][o].astype(np.int64), o.astype(np.int64)))
+        return res
+
+
+def conv_out_shape(shape, ksize, stride, padding, dilation=(1, 1, 1)):
+    return tuple((int(shape[i]) + 2 * padding[i] - dilation[i] * (ksize[i] - 1) - 1) // stride[i] + 1 for i in range(3))
+
+
+def build_subm_rulebook(coors: torch.Tensor, batch: int, shape, ksize, dilation=(1, 1, 1)) -> Rulebook:
+    lib = _lib.load()
+    _need_gpu(coors)
+    coors = coors.contiguous()
+    assert coors.dtype == torch.int32 and coors.dim() == 2 and coors.shape[1] == 4
+    n = coors.shape[0]
+    dev = coors.device
+    kvol = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+    cnt = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    ws = _ws(lib.s2d_rulebook_workspace_bytes(batch, i3(shape), n), dev)
+    check(lib.s2d_rulebook_subm_build(_ptr(coors), n, batch, i3(shape), i3(ksize), i3(dilation), _ptr(nbr), _ptr(cnt),
+                                      _ptr(ws), ws.numel(), _stream()), "s2d_rulebook_subm_build")
+    return Rulebook(True, kvol, n, n, nbr, None, cnt, None, tuple(int(s) for s in shape))
+
+
+class ConvRulebookJob:
+    """Two-phase strided-conv rulebook: `count()` launches the marking/numbering kernels and an
+    async copy of n_out into pinned host memory; `finish()` waits for it and fills the maps.  Several jobs
+    can be counted back to back before the first `finish()` so the host reads overlap."""
+
+    def __init__(self, coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)):
+        self.lib = _lib.load()
+        _need_gpu(coors)
+        self.coors = coors.contiguous()
+        assert self.coors.dtype == torch.int32 and self.coors.shape[1] == 4
+        self.batch, self.shape = int(batch), tuple(int(s) for s in shape)
+        self.ksize, self.stride = tuple(map(int, ksize)), tuple(map(int, stride))
+        self.padding, self.dilation = tuple(map(int, padding)), tuple(map(int, dilation))
+        self.out_shape = conv_out_shape(self.shape, self.ksize, self.stride, self.padding, self.dilation)
+        self.kvol = self.ksize[0] * self.ksize[1] * self.ksize[2]
+        dev = self.coors.device
+        self.ws = _ws(self.lib.s2d_rulebook_workspace_bytes(self.batch, i3(self.out_shape), 0), dev)
+        self.out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.host_n = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def count(self):
+        n = self.coors.shape[0]
+        check(self.lib.s2d_rulebook_conv_count(_ptr(self.coors), n, self.batch, i3(self.shape), i3(self.ksize),
+                                               i3(self.stride), i3(self.padding), i3(self.dilation), _ptr(self.out_n),
+                                               _ptr(self.ws), self.ws.numel(), _stream()), "s2d_rulebook_conv_count")
+        self.host_n.copy_(self.out_n, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        return self
+
+    def finish(self) -> Rulebook:
+        self.event.synchronize()
+        n_out = int(self.host_n[0])
+        n = self.coors.shape[0]
+        dev = self.coors.device
+        out_coors = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+        nbr_out = torch.empty((self.kvol, n_out), dtype=torch.int32, device=dev)
+        nbr_in = torch.empty((self.kvol, n), dtype=torch.int32, device=dev)
+        cnt = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+        check(self.lib.s2d_rulebook_conv_fill(_ptr(self.coors), n, self.batch, i3(self.shape), i3(self.ksize),
+                                              i3(self.stride), i3(self.padding), i3(self.dilation), n_out,
+                                              _ptr(out_coors), _ptr(nbr_out), _ptr(nbr_in), _ptr(cnt), _ptr(self.ws),
+                                              self.ws.numel(), _stream()), "s2d_rulebook_conv_fill")
+        return Rulebook(False, self.kvol, n, n_out, nbr_out, nbr_in, cnt, out_coors, self.out_shape)
+
+
+def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)) -> Rulebook:
+    return ConvRulebookJob(coors, batch, shape, ksize, stride, padding, dilation).count().finish()
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse conv arithmetic
+# ------------------------------------------------------------------------------------------------
+def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor,
+                       n_out: int) -> torch.Tensor:
+    """out[o] = sum_k feat[nbr[k][o]] @ weight_kio[k] (+bias).  weight_kio f32[K,Cin,Cout]."""
+    lib = _lib.load()
+    _need_gpu(feat, weight_kio, nbr)
+    feat = feat.contiguous()
+    weight_kio = weight_kio.contiguous()
+    kvol, cin, cout = weight_kio.shape
+    assert feat.dtype == torch.float32 and weight_kio.dtype == torch.float32
+    assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous()
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
+    b = bias.contiguous() if bias is not None else None
+    check(lib.s2d_spconv_fwd_f32(_ptr(feat), feat.shape[0], _ptr(weight_kio), _ptr(b), _ptr(nbr), n_out, kvol, cin, cout,
+                                 _ptr(out), _stream()), "s2d_spconv_fwd_f32")
+    return out
+
+
+def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol: int) -> torch.Tensor:
+    """dW[k] = sum_o feat[nbr[k][o]]^T dout[o]  ->  f32[K,Cin,Cout]."""
+    lib = _lib.load()
+    _need_gpu(feat, dout, nbr)
+    feat = feat.contiguous()
+    dout = dout.contiguous()
+    n_out, cout = dout.shape
+    cin = feat.shape[1]
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
+    ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
+    check(lib.s2d_spconv_wgrad_f32(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw),
+                                   _ptr(ws), ws.numel(), _stream()), "s2d_spconv_wgrad_f32")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm1d on features
+# ------------------------------------------------------------------------------------------------
+def bn1d_stats(x: torch.Tensor) -> torch.Tensor:
+    """[2C]: per-channel sum and sum of squares (deterministic)."""
+    lib = _lib.load()
+    _need_gpu(x)
+    x = x.contiguous()
+    n, c = x.shape
+    stats = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bn1d_stats_f32(_ptr(x), n, c, _ptr(stats), _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_f32")
+    return stats
+
+
+def bn1d_apply(x, scale, shift, residual=None, relu=False):
+    lib = _lib.load()
+    _need_gpu(x, scale, shift, residual)
+    x = x.contiguous()
+    n, c = x.shape
+    y = torch.empty_like(x)
+    r = residual.contiguous() if residual is not None else None
+    check(lib.s2d_bn1d_apply_f32(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), _ptr(r), int(relu), n, c,
+                                 _ptr(y), _stream()), "s2d_bn1d_apply_f32")
+    return y
+
+
+def bn1d_bwd_reduce(dy, y, x, relu, want_g=True):
+    """g = dy * (y>0 if relu); returns (g or None, sums[2C] = [sum g, sum g*x])."""
+    lib = _lib.load()
+    _need_gpu(dy, x)
+    dy = dy.contiguous()
+    x = x.contiguous()
+    n, c = x.shape
+    g = torch.empty_like(x) if want_g else None
+    sums = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bn1d_bwd_reduce_f32(_ptr(dy), _ptr(y), _ptr(x), int(relu), n, c, _ptr(g), _ptr(sums), _ptr(ws),
+                                      ws.numel(), _stream()), "s2d_bn1d_bwd_reduce_f32")
+    return g, sums
+
+
+def bn1d_bwd_apply(g, x, a, b, d):
+    lib = _lib.load()
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    check(lib.s2d_bn1d_bwd_apply_f32(_ptr(g), _ptr(x), _ptr(a.contiguous()), _ptr(b.contiguous()), _ptr(d.contiguous()),
+                                     n, c, _ptr(dx), _stream()), "s2d_bn1d_bwd_apply_f32")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# densify
+# ------------------------------------------------------------------------------------------------
+def densify(feat, coors, batch, shape):
+    lib = _lib.load()
+    _need_gpu(feat, coors)
+    feat = feat.contiguous()
+    n, c = feat.shape
+    out = torch.empty((batch, c, shape[0], shape[1], shape[2]), dtype=torch.float32, device=feat.device)
+    check(lib.s2d_densify_fwd_f32(_ptr(feat), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(out), _stream()),
+          "s2d_densify_fwd_f32")
+    return out
+
+
+def densify_bwd(dout, coors, batch, shape, c):
+    lib = _lib.load()
+    dout = dout.contiguous()
+    n = coors.shape[0]
+    dfeat = torch.empty((n, c), dtype=torch.float32, device=dout.device)
+    check(lib.s2d_densify_bwd_f32(_ptr(dout), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(dfeat), _stream()),
+          "s2d_densify_bwd_f32")
+    return dfeat
