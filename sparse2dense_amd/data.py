@@ -1,0 +1,62 @@
+"""Synthetic batches in the reference's `example` format, built on the device.
+
+Field names and dtypes follow `Voxelization.__call__` + `AssignLabel` + `Reformat` + `collate_kitti`
+(/root/reference/det3d/datasets/pipelines/preprocess.py:316-463,553-624,
+ /root/reference/det3d/torchie/parallel/collate.py:91-161) and `example_to_device`
+(/root/reference/det3d/torchie/trainer/trainer.py:78-124).  The voxel fields are produced by the
+HIP voxelizer from device-resident points; targets are CPU numpy (AssignLabel is CPU in the
+reference too) uploaded once.
+"""
+import numpy as np
+import torch
+
+from . import scene
+from .voxel_ops import VoxelGenerator, voxelize_batch
+
+WAYMO_TRAIN_MAX_VOXELS = 150000
+
+
+def waymo_generators(distill=False):
+    g = {"": VoxelGenerator(scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, WAYMO_TRAIN_MAX_VOXELS)}
+    if distill:  # preprocess.py:289-314: same grid for dense/reconstruction, 2x and 4x voxels for the PCR targets
+        vs = np.asarray(scene.WAYMO_VOXEL, np.float32)
+        g["_2"] = VoxelGenerator(vs * 2, scene.WAYMO_RANGE, 5, WAYMO_TRAIN_MAX_VOXELS)
+        g["_4"] = VoxelGenerator(vs * 4, scene.WAYMO_RANGE, 5, WAYMO_TRAIN_MAX_VOXELS)
+    return g
+
+
+class SyntheticFrames:
+    """Holds B seeded scenes on the device (points + targets); `example()` runs the device
+    voxelizer and returns the collated dict — i.e. the per-iteration data work of the hot path."""
+
+    def __init__(self, batch_size, n_points=150000, seed=20240928, distill=False, device="cuda"):
+        self.device = torch.device(device)
+        self.distill = distill
+        self.gens = waymo_generators(distill)
+        self.points, self.dense_points, self.recon_points = [], [], []
+        tg = {k: [] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+        for b in range(batch_size):
+            s = scene.make_scene(n_points, seed=seed + b)
+            self.points.append(torch.from_numpy(s["points"]).to(self.device))
+            if distill:
+                d, r = scene.make_distill_points(s, seed=seed + 100 + b)
+                self.dense_points.append(torch.from_numpy(d).to(self.device))
+                self.recon_points.append(torch.from_numpy(r).to(self.device))
+            t = scene.assign_targets(s["gt_boxes"], s["gt_classes"])
+            for k in tg:
+                tg[k].append(torch.from_numpy(t[k]))
+        self.targets = {k: [torch.stack(v).to(self.device)] for k, v in tg.items()}
+        self.grid_size = self.gens[""].grid_size
+
+    def example(self):
+        ex = voxelize_batch(self.gens[""], self.points)
+        if self.distill:
+            ex.update(voxelize_batch(self.gens[""], self.dense_points, prefix="dense_"))
+            ex.update(voxelize_batch(self.gens[""], self.recon_points, prefix="reconstruction_"))
+            for suf in ("_2", "_4"):
+                r = voxelize_batch(self.gens[suf], self.recon_points, prefix="reconstruction_")
+                for k, v in r.items():
+                    ex[k + suf] = v
+        ex["shape"] = np.stack([self.grid_size] * len(self.points))
+        ex.update(self.targets)
+        return ex

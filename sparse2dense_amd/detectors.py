@@ -1,0 +1,119 @@
+"""Detectors under the reference's registry keys.
+
+  DETECTORS["VoxelNet"]      /root/reference/det3d/models/detectors/voxelnet.py:21-105   (teacher,
+                             plain CenterPoint single stage, SECOND)
+  DETECTORS["KD_VoxelNet"]   /root/reference/det3d/models/detectors/voxelnet.py:144-265 (S2D student)
+  SingleStageDetector wiring /root/reference/det3d/models/detectors/single_stage.py:22-31
+
+`forward(example, return_loss=..., return_feature=..., return_recon_feature=...)` keeps the
+reference's argument meaning and return tuples.  Two deliberate device-side differences:
+  * the reader output may be supplied by the fused voxelizer (`example["voxel_mean"]`), which is
+    the same fp32 quantity (tests pin it to <= 2 ulp);
+  * KD_VoxelNet builds the reconstruction targets with the densify kernel instead of spconv's
+    scatter_nd (`SparseConvTensor(...).dense()`, voxelnet.py:203-215) — same tensor.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import registry
+from .heads import mask_offset_loss, metric_grid
+from .registry import DETECTORS
+from .spconv import SparseConvTensor
+
+
+class SingleStageDetector(nn.Module):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.reader = registry.build_reader(reader)
+        self.backbone = registry.build_backbone(backbone)
+        self.neck = registry.build_neck(neck) if neck is not None else None
+        self.bbox_head = registry.build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    def _read(self, example, prefix=""):
+        mean_key = prefix + "voxel_mean"
+        if mean_key in example:
+            return example[mean_key]
+        return self.reader(example[prefix + "voxels"], example[prefix + "num_points"])
+
+
+@DETECTORS.register_module
+class VoxelNet(SingleStageDetector):
+    def extract_feat(self, data):
+        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
+        neck = self.neck(x) if self.with_neck else x
+        return neck, voxel_feature, x
+
+    def forward(self, example, return_loss=True, return_feature=False, return_recon_feature=False, **kwargs):
+        prefix = "dense_" if "dense_voxels" in example else ""   # teacher sees the dense cloud (voxelnet.py:50-54)
+        batch_size = len(example[prefix + "num_voxels"])
+        data = dict(features=self._read(example, prefix), coors=example[prefix + "coordinates"], batch_size=batch_size,
+                    input_shape=example["shape"][0])
+        x, _, F_D_a = self.extract_feat(data)
+        F_D_b = None
+        if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)
+            F_D_b, _ = self.backbone(self._read(example, "reconstruction_"), example["reconstruction_coordinates"],
+                                     batch_size, example["shape"][0])
+        preds = self.bbox_head(x)
+        if return_loss:
+            losses = self.bbox_head.loss(example, preds)
+            return losses if not return_feature else (losses, F_D_a, F_D_b)
+        if return_feature and return_recon_feature:
+            return preds, F_D_a, F_D_b
+        boxes = self.bbox_head.predict(example, preds, self.test_cfg)
+        return boxes if not return_feature else (boxes, F_D_a, F_D_b)
+
+
+@DETECTORS.register_module
+class KD_VoxelNet(VoxelNet):
+    def extract_feat(self, data, train_pcm=True):
+        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self.neck(x)
+        return x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, voxel_feature
+
+    mask_offset_loss = staticmethod(mask_offset_loss)
+
+    def _recon_gt(self, example, scale, batch_size):
+        pre = f"reconstruction_"
+        feats = self._read_scaled(example, scale)
+        shape = np.array(example["shape"][0][::-1] / scale).astype("int64")   # voxelnet.py:199,210
+        coors = example[f"reconstruction_coordinates_{scale}"].int()
+        return SparseConvTensor(feats, coors, shape, batch_size).dense()
+
+    def _read_scaled(self, example, scale):
+        key = f"reconstruction_voxel_mean_{scale}"
+        if key in example:
+            return example[key]
+        return self.reader(example[f"reconstruction_voxels_{scale}"], example[f"reconstruction_num_points_{scale}"])
+
+    def forward(self, example, return_loss=True, return_feature=False, **kwargs):
+        batch_size = len(example["num_voxels"])
+        if return_loss:
+            recon_gt_2 = self._recon_gt(example, 2, batch_size)
+            recon_gt_4 = self._recon_gt(example, 4, batch_size)
+        data = dict(features=self._read(example), coors=example["coordinates"], batch_size=batch_size,
+                    input_shape=example["shape"][0])
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, _ = self.extract_feat(data)
+        mask_loss = comp_loss = 0
+        if self.training and return_loss:
+            n, _, d, h, w = recon_gt_4.shape
+            grid_4 = metric_grid(n, d, h, w, recon_gt_4)
+            m4, o4 = mask_offset_loss(gen_offset_4, gen_mask_4, recon_gt_4, grid_4)
+            n, _, d, h, w = gen_offset_2.shape
+            grid_2 = metric_grid(n, d, h, w, gen_offset_2)
+            m2, o2 = mask_offset_loss(gen_offset_2, gen_mask_2, recon_gt_2, grid_2)
+            mask_loss, comp_loss = m2 + m4, o2 + o4
+        preds = self.bbox_head(x)
+        if return_loss:
+            losses = self.bbox_head.loss(example, preds)
+            if not return_feature:
+                return losses, preds
+            return losses, F_S_a, F_S_b, preds, mask_loss, comp_loss
+        boxes = self.bbox_head.predict(example, preds, self.test_cfg)
+        return boxes if not return_feature else (boxes, F_S_a, F_S_b)

@@ -1,0 +1,66 @@
+"""Data parallelism: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on
+ROCm), frames sharded by rank, no data-path collective except
+  * the bucketed gradient all-reduce (DDP; overlaps the sparse-conv backward because head/neck
+    gradients are produced first), and
+  * SyncBN statistics (FeatureBatchNorm1d all-reduces its own [2C+1] vector; BatchNorm2d/3d layers
+    are converted to torch.nn.SyncBatchNorm).
+Reference: tools/train.py:86-96 (init_process_group), det3d/torchie/apis/train.py:360-391
+(apex convert_syncbn_model + DistributedDataParallel).  The redundant second gradient all-reduce
+of the reference's DistOptimizerHook (apis/train.py:313-316) is intentionally dropped: DDP has
+already averaged the gradients, so the result is identical.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .spconv import FeatureBatchNorm1d
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def convert_syncbn(module: nn.Module):
+    """BatchNorm2d/3d -> SyncBatchNorm; FeatureBatchNorm1d is left alone (it synchronises itself
+    inside its fused kernels' autograd function)."""
+    out = module
+    if isinstance(module, nn.modules.batchnorm._BatchNorm) and not isinstance(module, (FeatureBatchNorm1d, nn.SyncBatchNorm)):
+        out = nn.SyncBatchNorm(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats)
+        if module.affine:
+            with torch.no_grad():
+                out.weight = module.weight
+                out.bias = module.bias
+        out.running_mean = module.running_mean
+        out.running_var = module.running_var
+        out.num_batches_tracked = module.num_batches_tracked
+        out.training = module.training
+    for name, child in module.named_children():
+        out.add_module(name, convert_syncbn(child))
+    return out
+
+
+def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=25, find_unused_parameters=False):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return model
+    model = convert_syncbn(model)
+    kwargs = dict(bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters,
+                  gradient_as_bucket_view=True)
+    if next(model.parameters()).is_cuda:
+        dev = torch.cuda.current_device() if local_rank is None else local_rank
+        return nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev, **kwargs)
+    return nn.parallel.DistributedDataParallel(model, **kwargs)

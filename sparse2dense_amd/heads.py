@@ -1,0 +1,207 @@
+"""CenterHead and its losses under the reference's registry keys.
+
+  HEADS["CenterHead"], SepHead     /root/reference/det3d/models/bbox_heads/center_head.py:65-110,167-291
+  FastFocalLoss, RegLoss           /root/reference/det3d/models/losses/centernet_loss.py:6-54
+  _transpose_and_gather_feat       /root/reference/det3d/core/utils/center_utils.py:66-80
+  distillation losses              /root/reference/det3d/torchie/trainer/trainer.py:38-76,783-805
+  mask_offset_loss                 /root/reference/det3d/models/detectors/voxelnet.py:171-185
+
+`CenterHead.predict` (decode + rotated NMS) is inference post-processing and out of scope of the
+training hot path.
+"""
+import copy
+import logging
+from collections import defaultdict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .registry import HEADS, LOSSES
+
+
+def _gather_feat(feat, ind):
+    return feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2)))
+
+
+def _transpose_and_gather_feat(feat, ind):
+    b, c = feat.size(0), feat.size(1)
+    return _gather_feat(feat.permute(0, 2, 3, 1).reshape(b, -1, c), ind)
+
+
+@LOSSES.register_module
+class RegLoss(nn.Module):
+    """L1 of the gathered regression vector at <=max_objs centre indices, per output channel."""
+
+    def forward(self, output, mask, ind, target):
+        pred = _transpose_and_gather_feat(output, ind)
+        m = mask.float().unsqueeze(2)
+        loss = F.l1_loss(pred * m, target * m, reduction="none") / (m.sum() + 1e-4)
+        return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
+
+
+def fast_focal_loss(out, target, ind, mask, cat):
+    """CornerNet focal loss with gathered positives (centernet_loss.py:33-54)."""
+    mask = mask.float()
+    neg = (torch.log(1 - out) * out.pow(2) * (1 - target).pow(4)).sum()
+    pos_pix = _transpose_and_gather_feat(out, ind)           # B x M x C
+    pos_pred = pos_pix.gather(2, cat.unsqueeze(2))          # B x M x 1
+    num_pos = mask.sum()
+    pos = (torch.log(pos_pred) * (1 - pos_pred).pow(2) * mask.unsqueeze(2)).sum()
+    # num_pos == 0  =>  pos == 0 and the reference returns -neg: same value, without its host sync
+    return -(pos + neg) / num_pos.clamp(min=1.0)
+
+
+@LOSSES.register_module
+class FastFocalLoss(nn.Module):
+    def forward(self, out, target, ind, mask, cat):
+        return fast_focal_loss(out, target, ind, mask, cat)
+
+
+def distill_reg_loss(output, target, mask, ind):
+    """MSE between student and teacher box maps at the GT centres (trainer.py:68-76)."""
+    pred = _transpose_and_gather_feat(output, ind)
+    gt = _transpose_and_gather_feat(target, ind)
+    m = mask.float().unsqueeze(2)
+    loss = F.mse_loss(pred * m, gt * m, reduction="none") / (m.sum() + 1e-4)
+    return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
+
+
+def masked_mse_pair(student, teacher, w_pos, w_neg):
+    """w_pos*MSE over teacher>0 + w_neg*MSE over the rest (trainer.py:783-789), without
+    materialising boolean-indexed copies: two masked sums and two counts."""
+    pos = teacher > 0
+    d2 = (student - teacher) ** 2
+    n_pos = pos.sum()
+    n_neg = pos.numel() - n_pos
+    s_pos = (d2 * pos).sum()
+    s_neg = d2.sum() - s_pos
+    return w_pos * s_pos / n_pos + w_neg * s_neg / n_neg
+
+
+def sparse2dense_loss(F_S_a, F_D_a, F_S_b, F_D_b):
+    """CenterPoint branch weights 10/20 on (a), 5/20 on (b) (trainer.py:783-789)."""
+    return masked_mse_pair(F_S_a, F_D_a, 10.0, 20.0) + masked_mse_pair(F_S_b, F_D_b, 5.0, 20.0)
+
+
+def mask_offset_loss(gen_offset, gen_mask, gt, grid):
+    """PCR losses (voxelnet.py:171-185): BCE-with-logits on occupancy with pos_weight=neg/pos and L1
+    on offsets at the non-zero GT entries."""
+    gt_mask = gt.sum(1) != 0
+    count_pos = gt_mask.sum()
+    count_neg = (~gt_mask).sum()
+    beta = count_neg / count_pos
+    loss = F.binary_cross_entropy_with_logits(gen_mask[:, 0], gt_mask.float(), pos_weight=beta)
+    tgt = gt[:, :3] - grid * gt_mask[:, None]
+    sel = tgt != 0
+    n_sel = sel.sum()
+    com = ((gen_offset - tgt).abs() * sel).sum() / n_sel   # == F.l1_loss(gen_offset[sel], tgt[sel])
+    return loss, com
+
+
+def metric_grid(n, d, h, w, like):
+    """Cell-centre metric coordinates (x,y,z) of a [D,H,W] grid over the Waymo range
+    (voxelnet.py:232-236; the x step reuses 150.4/H exactly as the reference does)."""
+    zs, ys, xs = torch.meshgrid(torch.arange(d, device=like.device), torch.arange(h, device=like.device),
+                                torch.arange(w, device=like.device), indexing="ij")
+    ys = ys * (150.4 / h) - 75.2 + (150.4 / h) / 2
+    xs = xs * (150.4 / w) - 75.2 + (150.4 / h) / 2
+    zs = zs * (6 / d) - 2 + (6 / d) / 2
+    return torch.stack([xs, ys, zs], 0)[None].repeat(n, 1, 1, 1, 1).to(like)
+
+
+def _kaiming_normal_conv(m):
+    nn.init.kaiming_normal_(m.weight, a=0, mode="fan_out", nonlinearity="relu")
+    if m.bias is not None:
+        nn.init.constant_(m.bias, 0)
+
+
+class SepHead(nn.Module):
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, **kwargs):
+        super().__init__(**kwargs)
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            layers = []
+            for _ in range(num_conv - 1):
+                layers.append(nn.Conv2d(in_channels, head_conv, final_kernel, 1, final_kernel // 2, bias=True))
+                if bn:
+                    layers.append(nn.BatchNorm2d(head_conv))
+                layers.append(nn.ReLU())
+            layers.append(nn.Conv2d(head_conv, classes, final_kernel, 1, final_kernel // 2, bias=True))
+            fc = nn.Sequential(*layers)
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        _kaiming_normal_conv(m)
+            setattr(self, head, fc)
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+@HEADS.register_module
+class CenterHead(nn.Module):
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[],
+                 common_heads=dict(), logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2,
+                 dcn_head=False):
+        super().__init__()
+        if dcn_head:
+            raise NotImplementedError("dcn_head=True (nuScenes DCN configs) is outside the Waymo hot path")
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.code_weights = code_weights
+        self.weight = weight
+        self.dataset = dataset
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.crit = FastFocalLoss()
+        self.crit_reg = RegLoss()
+        self.box_n_dim = 9 if "vel" in common_heads else 7
+        self.use_direction_classifier = False
+        self.logger = logger or logging.getLogger("CenterHead")
+        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, 3, padding=1, bias=True),
+                                         nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
+        self.tasks = nn.ModuleList()
+        for num_cls in num_classes:
+            heads = copy.deepcopy(dict(common_heads))
+            heads.update(dict(hm=(num_cls, num_hm_conv)))
+            self.tasks.append(SepHead(share_conv_channel, heads, bn=True, init_bias=init_bias, final_kernel=3))
+
+    def forward(self, x, *kwargs):
+        x = self.shared_conv(x)
+        return [task(x) for task in self.tasks]
+
+    @staticmethod
+    def _sigmoid(x):
+        return torch.clamp(x.sigmoid_(), min=1e-4, max=1 - 1e-4)
+
+    def loss(self, example, preds_dicts, **kwargs):
+        merged = defaultdict(list)
+        for task_id, preds in enumerate(preds_dicts):
+            preds["hm"] = self._sigmoid(preds["hm"])
+            hm_loss = self.crit(preds["hm"], example["hm"][task_id], example["ind"][task_id], example["mask"][task_id],
+                                example["cat"][task_id])
+            target_box = example["anno_box"][task_id]
+            if self.dataset not in ("waymo", "nuscenes"):
+                raise NotImplementedError()
+            if "vel" in preds:
+                preds["anno_box"] = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["vel"], preds["rot"]), 1)
+            else:
+                preds["anno_box"] = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["rot"]), 1)
+                target_box = target_box[..., [0, 1, 2, 3, 4, 5, -2, -1]]  # drop the velocity target
+            box_loss = self.crit_reg(preds["anno_box"], example["mask"][task_id], example["ind"][task_id], target_box)
+            loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
+            loss = hm_loss + self.weight * loc_loss
+            # NB: the reference copies the logging scalars to the host here (.detach().cpu(), four
+            # blocking syncs per step, center_head.py:283); we keep them on the device.
+            ret = {"loss": loss, "hm_loss": hm_loss.detach(), "loc_loss": loc_loss, "loc_loss_elem": box_loss.detach(),
+                   "num_positive": example["mask"][task_id].float().sum()}
+            for k, v in ret.items():
+                merged[k].append(v)
+        return merged
+
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        raise NotImplementedError("CenterHead.predict (decode + rotated NMS) is inference post-processing; "
+                                  "out of scope of the training hot path (DESIGN.md, SURVEY.md §8(f))")

@@ -116,9 +116,8 @@ def build_subm_rulebook(coors: torch.Tensor, batch: int, shape, ksize, dilation=
 
 
 class ConvRulebookJob:
-    """Two-phase strided-conv rulebook: `count()` launches the marking/numbering kernels and an
-    async copy of n_out into pinned host memory; `finish()` waits for it and fills the maps.  Several jobs
-    can be counted back to back before the first `finish()` so the host reads overlap."""
+    """Two-phase strided-conv rulebook: `count()` launches the marking/numbering kernels,
+    `finish()` reads n_out back (one 4-byte D2H copy) and fills the maps."""
 
     def __init__(self, coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)):
         self.lib = _lib.load()
@@ -133,22 +132,16 @@ class ConvRulebookJob:
         dev = self.coors.device
         self.ws = _ws(self.lib.s2d_rulebook_workspace_bytes(self.batch, i3(self.out_shape), 0), dev)
         self.out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.host_n = torch.zeros((1,), dtype=torch.int32).pin_memory()
-        self.event = None
 
     def count(self):
         n = self.coors.shape[0]
         check(self.lib.s2d_rulebook_conv_count(_ptr(self.coors), n, self.batch, i3(self.shape), i3(self.ksize),
                                                i3(self.stride), i3(self.padding), i3(self.dilation), _ptr(self.out_n),
                                                _ptr(self.ws), self.ws.numel(), _stream()), "s2d_rulebook_conv_count")
-        self.host_n.copy_(self.out_n, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record()
         return self
 
     def finish(self) -> Rulebook:
-        self.event.synchronize()
-        n_out = int(self.host_n[0])
+        n_out = int(self.out_n.item())   # the one host read of this layer (spconv reads indice_pair_num here)
         n = self.coors.shape[0]
         dev = self.coors.device
         out_coors = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
@@ -169,8 +162,11 @@ def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1
 # ------------------------------------------------------------------------------------------------
 # sparse conv arithmetic
 # ------------------------------------------------------------------------------------------------
+PROFILE = None  # bench.py sets this to a list to collect per-launch HIP events (roofline pass)
+
+
 def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor,
-                       n_out: int) -> torch.Tensor:
+                       n_out: int, pair_count: Optional[torch.Tensor] = None, tag: str = "fwd") -> torch.Tensor:
     """out[o] = sum_k feat[nbr[k][o]] @ weight_kio[k] (+bias).  weight_kio f32[K,Cin,Cout]."""
     lib = _lib.load()
     _need_gpu(feat, weight_kio, nbr)
@@ -181,8 +177,17 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
     assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous()
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
     b = bias.contiguous() if bias is not None else None
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="spconv_fwd_mfma" if (cin % 16 == 0 and cout % 16 == 0) else "spconv_fwd_valu", tag=tag,
+                   cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_spconv_fwd_f32(_ptr(feat), feat.shape[0], _ptr(weight_kio), _ptr(b), _ptr(nbr), n_out, kvol, cin, cout,
                                  _ptr(out), _stream()), "s2d_spconv_fwd_f32")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
     return out
 
 

@@ -1,0 +1,161 @@
+"""BEV necks under the reference's registry keys.
+
+  NECKS["RPN"]      /root/reference/det3d/models/necks/rpn.py:24-162   (teacher / plain CenterPoint)
+  NECKS["S2D_RPN"]  /root/reference/det3d/models/necks/rpn.py:164-337  (S2D densify module + PCR head
+                                                                        + the RPN trunk on F_S_a)
+Module names / Sequential indices are the reference's, so state_dicts are interchangeable
+(`blocks.0.1.weight` — index 0 is the ZeroPad2d; `encoder_1.0.weight`; `generator_2.3.weight` ...).
+Round-1 status: these dense layers run on PyTorch-ROCm's conv/GEMM kernels (MIOpen / hipBLASLt);
+the hand-written MFMA dense-conv kernels are the next row of DESIGN.md §"what comes next".
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .backbones import build_norm_layer
+from .registry import NECKS
+
+
+def _xavier_uniform_convs(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+@NECKS.register_module
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super().__init__()
+        self._layer_strides = ds_layer_strides
+        self._num_filters = ds_num_filters
+        self._layer_nums = layer_nums
+        self._upsample_strides = us_layer_strides
+        self._num_upsample_filters = us_num_filters
+        self._num_input_features = num_input_features
+        self._norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN", eps=1e-3, momentum=0.01)
+        assert len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)
+        assert len(us_num_filters) == len(us_layer_strides)
+        self._upsample_start_idx = len(layer_nums) - len(us_layer_strides)
+        ratios = [us_layer_strides[i] / np.prod(ds_layer_strides[: i + self._upsample_start_idx + 1])
+                  for i in range(len(us_layer_strides))]
+        assert all(r == ratios[0] for r in ratios)
+
+        in_filters = [num_input_features, *ds_num_filters[:-1]]
+        blocks, deblocks = [], []
+        for i, depth in enumerate(layer_nums):
+            blocks.append(self._make_layer(in_filters[i], ds_num_filters[i], depth, stride=ds_layer_strides[i]))
+            j = i - self._upsample_start_idx
+            if j < 0:
+                continue
+            up = us_layer_strides[j]
+            if up > 1:
+                conv = nn.ConvTranspose2d(ds_num_filters[i], us_num_filters[j], up, stride=up, bias=False)
+            else:
+                down = int(np.round(1 / up))
+                conv = nn.Conv2d(ds_num_filters[i], us_num_filters[j], down, stride=down, bias=False)
+            deblocks.append(nn.Sequential(conv, build_norm_layer(self._norm_cfg, us_num_filters[j])[1], nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+        if logger is not None:
+            logger.info("Finish RPN Initialization")
+
+    @property
+    def downsample_factor(self):
+        factor = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            factor /= self._upsample_strides[-1]
+        return factor
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
+        layers = [nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+                  build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU()]
+        for j in range(num_blocks):
+            layers += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), build_norm_layer(self._norm_cfg, planes)[1]]
+            if j < num_blocks - 1:  # the last conv+BN of a block has no ReLU of its own (rpn.py:142-143)
+                layers.append(nn.ReLU())
+        return nn.Sequential(*layers)
+
+    def init_weights(self):
+        _xavier_uniform_convs(self)
+
+    def _trunk(self, x, relu_between):
+        ups = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if relu_between:
+                x = F.relu(x)
+            if i - self._upsample_start_idx >= 0:
+                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+        return torch.cat(ups, dim=1) if ups else x
+
+    def forward(self, x):
+        return self._trunk(x, relu_between=True)  # rpn.py:156
+
+
+def _cbg(*convs_and_channels):
+    layers = []
+    for conv, c in convs_and_channels:
+        layers += [conv, nn.BatchNorm2d(c), nn.GELU()]
+    return nn.Sequential(*layers)
+
+
+def _convnext(c, hw):
+    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), nn.LayerNorm([c, hw, hw], eps=1e-6),
+                         nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
+
+
+@NECKS.register_module
+class S2D_RPN(RPN):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super().__init__(layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                         num_input_features, norm_cfg, name, logger)
+        c = num_input_features
+        # ---- S2D module (rpn.py:186-253): 188 -> 94 -> 47 -> 3x ConvNeXt -> 94 -> 188 ----
+        self.encoder_1 = _cbg((nn.Conv2d(c, 256, 2, 2), 256), (nn.Conv2d(256, 256, 3, 1, 1), 256))
+        self.encoder_2 = _cbg((nn.Conv2d(256, 256, 3, 2, 1), 256), (nn.Conv2d(256, 256, 3, 1, 1), 256))
+        self.convnext_block_1 = _convnext(256, 47)
+        self.convnext_block_2 = _convnext(256, 47)
+        self.convnext_block_3 = _convnext(256, 47)
+        self.decoder_1 = _cbg((nn.ConvTranspose2d(256, 256, 4, 2, 1), 256))
+        self.decoder_2 = _cbg((nn.Conv2d(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
+        self.fusion_sparse = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
+        self.fusion_dense = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
+        self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
+        # ---- PCR point-cloud-reconstruction head (rpn.py:263-296) ----
+        self.generator_1 = nn.Sequential(nn.Conv3d(128, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.ReLU(),
+                                         nn.ConvTranspose3d(32, 32, 4, 2, 1), nn.BatchNorm3d(32), nn.ReLU())
+        self.gen_out_4 = nn.Sequential(nn.Conv3d(32, 3, 1, 1, 0))
+        self.gen_mask_4 = nn.Sequential(nn.Conv3d(32, 1, 1, 1, 0))
+        self.generator_2 = nn.Sequential(nn.Conv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.ReLU(),
+                                         nn.ConvTranspose3d(16, 3, 4, 2, 1), nn.BatchNorm3d(3), nn.ReLU())
+        self.gen_out_2 = nn.Sequential(nn.Conv3d(3, 3, 1, 1, 0))
+        self.gen_mask_2 = nn.Sequential(nn.Conv3d(3, 1, 1, 1, 0))
+
+    def forward(self, x):
+        y_1 = self.encoder_1(x)
+        y_2 = self.encoder_2(y_1)
+        att = self.convnext_block_1(y_2) + y_2
+        att = self.convnext_block_2(att) + att
+        att = F.gelu(self.convnext_block_3(att) + att)
+        y_3 = torch.cat([self.decoder_1(att), y_1], 1)
+        F_S_b = self.decoder_2(y_3)
+        F_S_a = self.fusion_dense(F_S_b) + self.fusion_sparse(x)
+        if self.training:
+            n, _, h, w = x.shape
+            gen = self.out_conv(F_S_b).view(n, 128, 5, h, w)
+            gen = self.generator_1(gen)
+            gen_offset_4 = self.gen_out_4(gen)
+            gen_mask_4 = self.gen_mask_4(gen)
+            gen = self.generator_2(gen)
+            gen_mask_2 = self.gen_mask_2(gen)
+            gen_offset_2 = self.gen_out_2(gen)
+        else:
+            gen_offset_2 = gen_mask_2 = gen_offset_4 = gen_mask_4 = None
+        # the trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)
+        out = self._trunk(F_S_a, relu_between=False)
+        return out, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b

@@ -1,0 +1,316 @@
+"""spconv-shaped module API on top of the HIP kernels.
+
+The reference backbones are written against spconv v1.x (`/root/reference/det3d/models/backbones/
+scn.py:2,8,18,104-152,162,173`); this module offers the same names, constructor arguments, weight
+layout `[kD,kH,kW,Cin,Cout]` and `.features`-assignable tensor so that those call sites read the
+same, while the arithmetic is ours:
+
+  SparseConvTensor / .dense()        -> hip_ops.densify           (scn.py:162,173)
+  SubMConv3d / SparseConv3d          -> rank/select rulebooks + MFMA implicit GEMM
+  SparseSequential / SparseModule    -> container semantics of spconv.SparseSequential
+  FeatureBatchNorm1d                 -> nn.BatchNorm1d drop-in (same state_dict) whose CUDA path
+                                        is the fused stats/apply(+ReLU,+residual) kernels and which
+                                        all-reduces its statistics when torch.distributed is up
+                                        (apex SyncBN in the reference, apis/train.py:360-362)
+There is no CPU path: every op raises on CPU tensors.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import hip_ops as H
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        assert len(v) == 3
+        return tuple(int(x) for x in v)
+    return (int(v),) * 3
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        return None if key is None else self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        out = _Densify.apply(self.features, self.indices, self.batch_size, tuple(self.spatial_shape))
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class _Densify(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, coors, batch, shape):
+        ctx.save_for_backward(coors)
+        ctx.meta = (batch, shape, feat.shape[1])
+        return H.densify(feat, coors, batch, shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coors,) = ctx.saved_tensors
+        batch, shape, c = ctx.meta
+        return H.densify_bwd(dout, coors, batch, shape, c), None, None, None
+
+
+class _SparseConvFn(torch.autograd.Function):
+    """out = sum_k gather(feat, nbr[k]) @ W[k] (+bias); spconv.ops.indice_conv + its backward."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, rb):
+        w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(feat, weight)
+        return H.spconv_gather_gemm(feat, w, bias, rb.nbr_out, rb.n_out, rb.pair_count, "fwd")
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, weight = ctx.saved_tensors
+        rb = ctx.rb
+        dout = dout.contiguous()
+        w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
+        dfeat = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if rb.subm:  # transposed map of a centred stencil = the same map with offsets mirrored
+                wt = w.flip(0).transpose(1, 2).contiguous()
+                dfeat = H.spconv_gather_gemm(dout, wt, None, rb.nbr_out, rb.n_in, rb.pair_count, "dgrad")
+            else:
+                wt = w.transpose(1, 2).contiguous()
+                dfeat = H.spconv_gather_gemm(dout, wt, None, rb.nbr_in, rb.n_in, rb.pair_count, "dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = H.spconv_wgrad(feat, dout, rb.nbr_out, rb.kvol).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0)
+        return dfeat, dw, db, None
+
+
+class SparseModule(nn.Module):
+    """marker base class: members of a SparseSequential that take the SparseConvTensor itself"""
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False, use_hash=False):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse, "only 3-D forward sparse convs on this path"
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.subm = subm
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv v1.x: kaiming_uniform(a=sqrt(5)) on the [k,k,k,Cin,Cout] tensor, bias U(+-1/sqrt(fan_in))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1.0 / fan_in ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def rulebook(self, x: SparseConvTensor):
+        if self.subm:
+            rb = x.find_indice_pair(self.indice_key)
+            if rb is None:
+                rb = H.build_subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+                if self.indice_key is not None:
+                    x.indice_dict[self.indice_key] = rb
+            return rb
+        key = ("conv", id(self))
+        rb = x.indice_dict.get(key)
+        if rb is None:
+            rb = H.build_conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
+                                       self.padding, self.dilation)
+        return rb
+
+    def forward(self, x: SparseConvTensor):
+        assert isinstance(x, SparseConvTensor)
+        rb = self.rulebook(x)
+        feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb)
+        if self.subm:
+            out = SparseConvTensor(feats, x.indices, x.spatial_shape, x.batch_size)
+        else:
+            out = SparseConvTensor(feats, rb.out_coors, rb.out_shape, x.batch_size)
+        out.indice_dict = x.indice_dict
+        out.grid = x.grid
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, use_hash=False):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, subm=True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, use_hash=False):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, subm=False,
+                         indice_key=indice_key)
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm1d on features
+# --------------------------------------------------------------------------------------------------
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _BNTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module):
+        n, c = x.shape
+        stats = H.bn1d_stats(x)
+        count = torch.full((1,), float(n), device=x.device)
+        if sync:
+            packed = torch.cat([stats, count])
+            dist.all_reduce(packed)
+            stats, count = packed[:-1], packed[-1:]
+        mean = stats[:c] / count
+        var = (stats[c:] / count - mean * mean).clamp_(min=0.0)
+        invstd = torch.rsqrt(var + eps)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        y = H.bn1d_apply(x, scale, shift, residual, relu)
+        if module is not None and module.track_running_stats:
+            with torch.no_grad():
+                m = module.momentum
+                unbiased = var * (count / (count - 1).clamp(min=1.0))
+                module.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                module.running_var.mul_(1 - m).add_(unbiased, alpha=m)
+                module.num_batches_tracked += 1
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, count)
+        ctx.relu, ctx.sync, ctx.has_res = relu, sync, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd, count = ctx.saved_tensors
+        c = x.shape[1]
+        g, sums = H.bn1d_bwd_reduce(dy.contiguous(), y, x, ctx.relu)
+        # parameter grads use the LOCAL sums (DDP averages them over ranks afterwards, exactly
+        # like torch.nn.SyncBatchNorm); the input grad needs the GLOBAL sums.
+        dbeta = sums[:c].clone()
+        dgamma = invstd * (sums[c:] - mean * sums[:c])
+        if ctx.sync:
+            dist.all_reduce(sums)
+        sg, sgx = sums[:c], sums[c:]
+        dgamma_all = invstd * (sgx - mean * sg)
+        a = gamma * invstd
+        b = -(a * invstd) * dgamma_all / count
+        d = -(a * sg) / count - b * mean
+        dx = H.bn1d_bwd_apply(g, x, a, b, d) if ctx.needs_input_grad[0] else None
+        return dx, dgamma, dbeta, (g if ctx.has_res else None), None, None, None, None
+
+
+class _BNEvalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, residual, relu, eps):
+        invstd = torch.rsqrt(rvar + eps)
+        scale = gamma * invstd
+        shift = beta - rmean * scale
+        y = H.bn1d_apply(x, scale, shift, residual, relu)
+        ctx.save_for_backward(x, y if relu else None, scale, rmean, invstd)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, scale, rmean, invstd = ctx.saved_tensors
+        c = x.shape[1]
+        g, sums = H.bn1d_bwd_reduce(dy.contiguous(), y, x, ctx.relu)
+        zero = torch.zeros_like(scale)
+        dx = H.bn1d_bwd_apply(g, x, scale, zero, zero) if ctx.needs_input_grad[0] else None
+        dbeta = sums[:c]
+        dgamma = invstd * (sums[c:] - rmean * sums[:c])
+        return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None), None, None
+
+
+class FeatureBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d with identical parameters/buffers; CUDA [N,C] inputs run the fused HIP path."""
+
+    def forward(self, x, residual=None, relu=False):
+        if not x.is_cuda or x.dim() != 2:
+            raise RuntimeError("FeatureBatchNorm1d: expected a CUDA [N,C] feature matrix (no CPU fallback)")
+        if x.shape[0] == 0:
+            return x
+        use_batch_stats = self.training or not self.track_running_stats
+        if use_batch_stats:
+            return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, _dist_on() and self.training, self)
+        return _BNEvalFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
+
+
+# --------------------------------------------------------------------------------------------------
+class SparseSequential(SparseModule):
+    """spconv.SparseSequential: sparse modules receive the tensor, plain modules its `.features`.
+    BN -> ReLU runs are fused into one kernel launch."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        name = str(len(self._modules)) if name is None else name
+        if name in self._modules:
+            raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.indices.shape[0] != 0:
+                    if isinstance(m, FeatureBatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                        x.features = m(x.features, relu=True)
+                        i += 1
+                    else:
+                        x.features = m(x.features)
+            else:
+                x = m(x)
+            i += 1
+        return x

@@ -1,0 +1,93 @@
+"""Drop-in for `det3d.ops.point_cloud.point_cloud_ops.points_to_voxel` and
+`det3d.core.input.voxel_generator.VoxelGenerator`
+(/root/reference/det3d/ops/point_cloud/point_cloud_ops.py:112-184,
+ /root/reference/det3d/core/input/voxel_generator.py:5-46), backed by the HIP voxelizer.
+
+numpy in -> numpy out keeps the reference contract; torch cuda in -> torch cuda out is the
+device overload the training step uses (no PCIe round trip).  `voxelize_batch` is the device-side
+counterpart of `Voxelization.__call__` + `collate_kitti` (preprocess.py:316-345,
+torchie/parallel/collate.py:105-144): per-sample voxelization, concatenation, batch index
+prepended to the (z,y,x) coordinates.
+"""
+import numpy as np
+import torch
+
+from . import hip_ops as H
+
+
+def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000,
+                    return_mean=False):
+    """Same signature and return layout as the reference function.  `reverse_index=False`
+    (xyz coordinate order) is served by flipping the columns."""
+    is_np = isinstance(points, np.ndarray)
+    if is_np:
+        if not torch.cuda.is_available():
+            raise RuntimeError("points_to_voxel: no ROCm device visible and there is no CPU fallback")
+        pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).cuda()
+    else:
+        pts = points
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    rng = np.asarray(coors_range, dtype=np.float32)
+    voxels, coors, num, mean = H.voxelize(pts, vs, rng, int(max_points), int(max_voxels), with_mean=return_mean)
+    if not reverse_index:
+        coors = coors.flip(1)
+    if is_np:
+        out = (voxels.cpu().numpy(), coors.cpu().numpy(), num.cpu().numpy())
+        return out + (mean.cpu().numpy(),) if return_mean else out
+    return (voxels, coors, num, mean) if return_mean else (voxels, coors, num)
+
+
+class VoxelGenerator:
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
+        self._grid_size = np.round(grid_size).astype(np.int64)  # voxel_generator.py:10-11
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._max_num_points = max_num_points
+        self._max_voxels = max_voxels
+
+    def generate(self, points, max_voxels=-1, return_mean=False):
+        if max_voxels == -1:
+            max_voxels = self._max_voxels
+        return points_to_voxel(points, self._voxel_size, self._point_cloud_range, self._max_num_points, True,
+                               max_voxels, return_mean=return_mean)
+
+    @property
+    def voxel_size(self):
+        return self._voxel_size
+
+    @property
+    def max_num_points_per_voxel(self):
+        return self._max_num_points
+
+    @property
+    def point_cloud_range(self):
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        return self._grid_size
+
+
+def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefix=""):
+    """List of per-sample cuda point tensors -> the collated example fields
+    `{prefix}voxels f32[sum M,P,C]`, `{prefix}coordinates i32[sum M,4] (b,z,y,x)`,
+    `{prefix}num_points i32[sum M]`, `{prefix}num_voxels i64[B]`, plus `{prefix}voxel_mean`
+    (the fused reader output).  Key names: collate.py:105-144 / trainer.py:78-124."""
+    vs, cs, ns, ms, counts = [], [], [], [], []
+    for b, pts in enumerate(point_clouds):
+        v, c, n, m = generator.generate(pts, max_voxels, return_mean=True)
+        cb = torch.empty((c.shape[0], 4), dtype=torch.int32, device=c.device)
+        cb[:, 0] = b
+        cb[:, 1:] = c
+        vs.append(v); cs.append(cb); ns.append(n); ms.append(m); counts.append(c.shape[0])
+    dev = vs[0].device
+    return {
+        prefix + "voxels": torch.cat(vs, 0),
+        prefix + "coordinates": torch.cat(cs, 0),
+        prefix + "num_points": torch.cat(ns, 0),
+        prefix + "num_voxels": torch.tensor(counts, dtype=torch.int64, device=dev),
+        prefix + "voxel_mean": torch.cat(ms, 0),
+    }

@@ -1,0 +1,161 @@
+"""Neck / head / loss parity against golden vectors produced by the reference's own nn.Modules
+(tests/golden/make_golden.py).  The deterministic name-seeded fill gives both sides identical
+weights, so the state_dict key/shape equality asserted here is also the checkpoint-compatibility
+contract.  CPU run = fp32 vs fp32 on the same backend (tight); the `gpu`
+variants re-run on the MI355X with the stated end-to-end tolerance."""
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_digest, fill_params, seeded
+from sparse2dense_amd import heads, necks
+from sparse2dense_amd.registry import HEADS, NECKS, build_from_cfg
+
+CFG = dict(layer_nums=[5, 5], ds_layer_strides=[1, 2], ds_num_filters=[128, 256], us_layer_strides=[1, 2],
+           us_num_filters=[256, 256], num_input_features=256, logger=logging.getLogger("t"))
+TASKS = [dict(num_class=3, class_names=["VEHICLE", "PEDESTRIAN", "CYCLIST"])]
+HEAD_CFG = dict(type="CenterHead", in_channels=512, tasks=TASKS, dataset="waymo", weight=2, code_weights=[1.0] * 8,
+                common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2)})
+
+
+def _grads(outputs, inputs, seed):
+    loss = 0
+    for i, o in enumerate(outputs):
+        loss = loss + (o * seeded(o.shape, seed + i).to(o.device)).sum()
+    return torch.autograd.grad(loss, inputs, allow_unused=True)
+
+
+def _run_rpn(golden_dir, dev, rtol, atol):
+    g = np.load(os.path.join(golden_dir, "rpn.npz"))
+    net = fill_params(build_from_cfg(dict(type="RPN", **CFG), NECKS)).train().to(dev)
+    assert sorted(net.state_dict().keys()) == list(g["state_keys"])
+    x = seeded((1, 256, 188, 188), 100).abs_().to(dev).requires_grad_(True)
+    y = net(x)
+    names = ["blocks.0.1.weight", "blocks.1.16.weight", "deblocks.1.0.weight", "blocks.0.2.bias"]
+    params = dict(net.named_parameters())
+    gr = _grads([y], [x] + [params[n] for n in names], 200)
+    check_digest(y, g, "y", rtol, atol)
+    check_digest(gr[0], g, "gx", rtol * 5, atol * 5)
+    for n, gi in zip(names, gr[1:]):
+        check_digest(gi, g, "g:" + n, rtol * 5, atol * 50)
+    net.eval()
+    check_digest(net(x), g, "y_eval", rtol, atol)
+
+
+def _run_s2d(golden_dir, dev, rtol, atol):
+    g = np.load(os.path.join(golden_dir, "s2d_rpn.npz"))
+    net = fill_params(build_from_cfg(dict(type="S2D_RPN", **CFG), NECKS)).train().to(dev)
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(v.shape)) for _, v in sorted(sd.items())] == list(g["state_shapes"])
+    x = seeded((1, 256, 188, 188), 101).abs_().to(dev).requires_grad_(True)
+    outs = net(x)
+    onames = ["x", "gen_offset_2", "gen_mask_2", "gen_offset_4", "gen_mask_4", "F_S_a", "F_S_b"]
+    names = ["encoder_1.0.weight", "convnext_block_2.1.weight", "decoder_2.3.weight", "generator_2.3.weight",
+             "fusion_sparse.0.weight", "blocks.0.1.weight", "gen_out_2.0.bias"]
+    params = dict(net.named_parameters())
+    gr = _grads(list(outs), [x] + [params[n] for n in names], 300)
+    for n, o in zip(onames, outs):
+        check_digest(o, g, n, rtol, atol)
+    check_digest(gr[0], g, "gx", rtol * 5, atol * 20)
+    for n, gi in zip(names, gr[1:]):
+        check_digest(gi, g, "g:" + n, rtol * 5, atol * 200)
+    net.eval()
+    oe = net(x)
+    assert oe[1] is None and oe[4] is None
+    check_digest(oe[0], g, "x_eval", rtol, atol)
+    check_digest(oe[5], g, "F_S_a_eval", rtol, atol)
+
+
+def _run_head(golden_dir, dev, rtol, atol):
+    g = np.load(os.path.join(golden_dir, "center_head.npz"))
+    head = fill_params(build_from_cfg(HEAD_CFG, HEADS)).train().to(dev)
+    assert sorted(head.state_dict().keys()) == list(g["state_keys"])
+    x = seeded((2, 512, 188, 188), 102, 0.5).to(dev).requires_grad_(True)
+    preds = head(x)
+    for k in ["reg", "height", "dim", "rot", "hm"]:
+        check_digest(preds[0][k], g, "pred." + k, rtol, atol)
+    example = {k: [torch.from_numpy(g["ex." + k]).to(dev)] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+    losses = head.loss(example, preds)
+    loss = losses["loss"][0]
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=rtol)
+    np.testing.assert_allclose(losses["hm_loss"][0].item(), g["hm_loss"], rtol=rtol)
+    np.testing.assert_allclose(losses["loc_loss"][0].item(), g["loc_loss"], rtol=rtol)
+    np.testing.assert_allclose(losses["loc_loss_elem"][0].cpu().numpy(), g["loc_loss_elem"], rtol=rtol, atol=atol)
+    assert float(losses["num_positive"][0]) == float(g["num_positive"])
+    names = ["shared_conv.0.weight", "tasks.0.hm.3.bias", "tasks.0.reg.0.weight"]
+    params = dict(head.named_parameters())
+    gr = torch.autograd.grad(loss, [x] + [params[n] for n in names])
+    check_digest(gr[0], g, "gx", rtol * 5, atol)
+    for n, gi in zip(names, gr[1:]):
+        check_digest(gi, g, "g:" + n, rtol * 5, atol * 10)
+    return example
+
+
+def test_rpn_cpu_matches_reference_golden(golden_dir):
+    _run_rpn(golden_dir, "cpu", 1e-4, 1e-5)
+
+
+def test_s2d_rpn_cpu_matches_reference_golden(golden_dir):
+    _run_s2d(golden_dir, "cpu", 1e-4, 1e-5)
+
+
+def test_center_head_and_loss_cpu_match_reference_golden(golden_dir):
+    _run_head(golden_dir, "cpu", 1e-4, 1e-5)
+
+
+@pytest.mark.gpu
+def test_rpn_gpu_matches_reference_golden(golden_dir):
+    _run_rpn(golden_dir, "cuda:0", 2e-3, 2e-4)
+
+
+@pytest.mark.gpu
+def test_s2d_rpn_gpu_matches_reference_golden(golden_dir):
+    _run_s2d(golden_dir, "cuda:0", 2e-3, 2e-4)
+
+
+@pytest.mark.gpu
+def test_center_head_gpu_matches_reference_golden(golden_dir):
+    _run_head(golden_dir, "cuda:0", 2e-3, 2e-4)
+
+
+def _loss_checks(golden_dir, dev):
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    h = np.load(os.path.join(golden_dir, "center_head.npz"))
+    ex = {k: torch.from_numpy(h["ex." + k]).to(dev) for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+    out = torch.sigmoid(seeded((2, 3, 188, 188), 500)).clamp(1e-4, 1 - 1e-4).to(dev)
+    rt = 2e-5 if dev == "cpu" else 2e-4
+    np.testing.assert_allclose(heads.FastFocalLoss()(out, ex["hm"], ex["ind"], ex["mask"], ex["cat"]).item(),
+                               g["fastfocal"], rtol=rt)
+    np.testing.assert_allclose(heads.fast_focal_loss(out, ex["hm"], ex["ind"], torch.zeros_like(ex["mask"]),
+                                                     ex["cat"]).item(), g["fastfocal_nopos"], rtol=rt)
+    box = seeded((2, 8, 188, 188), 501).to(dev)
+    tb = ex["anno_box"][..., [0, 1, 2, 3, 4, 5, -2, -1]]
+    np.testing.assert_allclose(heads.RegLoss()(box, ex["mask"], ex["ind"], tb).cpu().numpy(), g["regloss"], rtol=rt)
+    t_hm = seeded((2, 3, 188, 188), 502).to(dev)
+    np.testing.assert_allclose(heads.fast_focal_loss(out, torch.sigmoid(t_hm), ex["ind"], ex["mask"], ex["cat"]).item(),
+                               g["kd_hm"], rtol=rt)
+    t_box = seeded((2, 8, 188, 188), 503).to(dev)
+    np.testing.assert_allclose(heads.distill_reg_loss(box, t_box, ex["mask"], ex["ind"]).cpu().numpy(), g["kd_reg"],
+                               rtol=rt)
+    F_D_a = torch.relu(seeded((2, 256, 188, 188), 504)).to(dev); F_S_a = seeded((2, 256, 188, 188), 505).to(dev)
+    F_D_b = torch.relu(seeded((2, 256, 188, 188), 506)).to(dev); F_S_b = seeded((2, 256, 188, 188), 507).to(dev)
+    np.testing.assert_allclose(heads.sparse2dense_loss(F_S_a, F_D_a, F_S_b, F_D_b).item(), g["s2d_mse"], rtol=1e-4)
+    D, H, W = [int(v) for v in g["mol_shape"]]
+    gt = torch.from_numpy(g["mol_gt"]).to(dev)
+    grid = heads.metric_grid(2, D, H, W, gt)
+    ml, ol = heads.mask_offset_loss(seeded((2, 3, D, H, W), 510).to(dev), seeded((2, 1, D, H, W), 511).to(dev), gt, grid)
+    np.testing.assert_allclose(ml.item(), g["mask_loss"], rtol=rt)
+    np.testing.assert_allclose(ol.item(), g["offset_loss"], rtol=rt)
+
+
+def test_losses_cpu_match_reference_golden(golden_dir):
+    _loss_checks(golden_dir, "cpu")
+
+
+@pytest.mark.gpu
+def test_losses_gpu_match_reference_golden(golden_dir):
+    _loss_checks(golden_dir, "cuda:0")
