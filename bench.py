@@ -168,7 +168,7 @@ def main():
     if world > 1:
         dist.barrier()
     from sparse2dense_amd.data import SyntheticFrames
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = False   # MIOpen exhaustive find costs minutes on a fresh box
 
     model, teacher = build_models(args, dev)
     model = dp.wrap_ddp(model, local)

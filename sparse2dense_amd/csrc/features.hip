@@ -52,13 +52,17 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float *__
     }
 }
 
+// one wave per output element: lanes stride over the per-block partials, fixed-order butterfly
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblocks, int width,
                                                           float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (e >= width) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * width + e];
-    out[e] = s;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * width + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) out[e] = s;
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ scale,
@@ -185,7 +189,7 @@ extern "C" int s2d_bn1d_stats_f32(const float *x, int64_t n, int c, float *stats
     }
     hipLaunchKernelGGL(col_reduce_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, nullptr, nullptr, 0, n, c,
                        p.rows_per_block, nullptr, (float *)ws);
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
                        stats);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -223,7 +227,7 @@ extern "C" int s2d_bn1d_bwd_reduce_f32(const float *dy, const float *y, const fl
     }
     hipLaunchKernelGGL(col_reduce_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, dy, y, relu, n, c,
                        p.rows_per_block, g_out, (float *)ws);
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c,
                        sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
     typedef WgradCfg<CIN, COUT> C;
     typedef typename VecF<C::VA>::type veca;
     typedef typename VecF<C::VB>::type vecb;
+    constexpr int U = 4;  // pair groups (of 4 pairs) whose loads are in flight together
+    __shared__ int2 pair_lds[4][64];  // per wave: compacted (o, j) of the current 64-row window
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
     const int r_begin = split * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
     const int32_t *nk = nbr + (int64_t)k * n_out;
+    int2 *mypairs = pair_lds[wid];
 
     f32x4 acc[C::LA][C::VA][C::VB];
 #pragma unroll
@@ -186,31 +189,51 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
 #pragma unroll
             for (int f = 0; f < C::VB; ++f) acc[la][e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int base = r_begin; base < r_end; base += 4) {
-        const int o = base + q;
-        const int j = o < r_end ? nk[o] : -1;
-        if (__ballot(j >= 0) == 0ull) continue;
-        veca av[C::LA];
-        vecb bv;
-        if (j >= 0) {
+    for (int base = r_begin; base < r_end; base += 64) {
+        // 64-row window: coalesced read of the gather map, wave-level compaction of the active pairs
+        const int o_l = base + lane;
+        const int j_l = o_l < r_end ? nk[o_l] : -1;
+        const unsigned long long mask = __ballot(j_l >= 0);
+        const int cnt = __popcll(mask);
+        if (cnt == 0) continue;  // wave-uniform
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (j_l >= 0) mypairs[rank] = make_int2(o_l, j_l);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS ops are ordered, this pins the compiler
+        const int groups = (cnt + 3) >> 2;
+        for (int g0 = 0; g0 < groups; g0 += U) {
+            veca av[U][C::LA];
+            vecb bv[U];
 #pragma unroll
-            for (int la = 0; la < C::LA; ++la)
-                av[la] = *reinterpret_cast<const veca *>(in + (int64_t)j * CIN + 64 * la + C::VA * i16);
-            bv = *reinterpret_cast<const vecb *>(dout + (int64_t)o * COUT + co_base + C::VB * i16);
-        } else {
-            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < U; ++u) {
+                const int idx = 4 * (g0 + u) + q;
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (idx < cnt) {
+                    const int2 pr = mypairs[idx];
 #pragma unroll
-            for (int la = 0; la < C::LA; ++la) av[la] = *reinterpret_cast<veca *>(z);
-            bv = *reinterpret_cast<vecb *>(z);
+                    for (int la = 0; la < C::LA; ++la)
+                        av[u][la] = *reinterpret_cast<const veca *>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16);
+                    bv[u] = *reinterpret_cast<const vecb *>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16);
+                } else {
+#pragma unroll
+                    for (int la = 0; la < C::LA; ++la) av[u][la] = *reinterpret_cast<veca *>(z);
+                    bv[u] = *reinterpret_cast<vecb *>(z);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (4 * (g0 + u) < cnt) {  // wave-uniform
+#pragma unroll
+                    for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+                        for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+                            for (int f = 0; f < C::VB; ++f)
+                                acc[la][e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(vec_get(av[u][la], e), vec_get(bv[u], f),
+                                                                                      acc[la][e][f], 0, 0, 0);
+                }
+            }
         }
-#pragma unroll
-        for (int la = 0; la < C::LA; ++la)
-#pragma unroll
-            for (int e = 0; e < C::VA; ++e)
-#pragma unroll
-                for (int f = 0; f < C::VB; ++f)
-                    acc[la][e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(vec_get(av[la], e), vec_get(bv, f),
-                                                                          acc[la][e][f], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of this window done before the next overwrite
     }
     // tile (la,e,f), reg: ci = 64*la + VA*(4*q+reg) + e ; co = co_base + VB*i16 + f
     float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;

@@ -170,9 +170,14 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
     """out[o] = sum_k feat[nbr[k][o]] @ weight_kio[k] (+bias).  weight_kio f32[K,Cin,Cout]."""
     lib = _lib.load()
     _need_gpu(feat, weight_kio, nbr)
+    kvol, cin, cout = weight_kio.shape
+    if cin % 16 and cin < 16 and cout % 16 == 0:
+        # narrow input layer (5 point features): zero-pad K to one MFMA step so it rides the matrix path
+        feat = torch.nn.functional.pad(feat, (0, 16 - cin))
+        weight_kio = torch.nn.functional.pad(weight_kio, (0, 0, 0, 16 - cin))
+        cin = 16
     feat = feat.contiguous()
     weight_kio = weight_kio.contiguous()
-    kvol, cin, cout = weight_kio.shape
     assert feat.dtype == torch.float32 and weight_kio.dtype == torch.float32
     assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous()
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
@@ -195,15 +200,18 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol
     """dW[k] = sum_o feat[nbr[k][o]]^T dout[o]  ->  f32[K,Cin,Cout]."""
     lib = _lib.load()
     _need_gpu(feat, dout, nbr)
-    feat = feat.contiguous()
     dout = dout.contiguous()
     n_out, cout = dout.shape
+    cin_true = feat.shape[1]
+    if cin_true % 16 and cin_true < 16 and cout % 16 == 0:
+        feat = torch.nn.functional.pad(feat, (0, 16 - cin_true))
+    feat = feat.contiguous()
     cin = feat.shape[1]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
     ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
     check(lib.s2d_spconv_wgrad_f32(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw),
                                    _ptr(ws), ws.numel(), _stream()), "s2d_spconv_wgrad_f32")
-    return dw
+    return dw if cin == cin_true else dw[:, :cin_true].contiguous()
 
 
 # ------------------------------------------------------------------------------------------------

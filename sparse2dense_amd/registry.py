@@ -62,7 +62,13 @@ SECOND_STAGE = Registry("second_stage")
 ROI_HEAD = Registry("roi_head")
 
 
+def _ensure_registered():
+    """The model modules register themselves on import; make `build_*` usable on its own."""
+    from . import backbones, detectors, heads, necks  # noqa: F401
+
+
 def build(cfg, registry, default_args=None):
+    _ensure_registered()
     if isinstance(cfg, (list, tuple)):
         from torch import nn
         return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])

@@ -27,17 +27,41 @@ def _scene_voxels(n_points, seed, batch=1):
     return np.concatenate(feats), np.concatenate(coors)
 
 
-def _compare_grads(net, ref, rtol, atol, min_frac=0.999):
-    gp = dict(net.named_parameters()); rp = dict(ref.named_parameters())
-    assert set(gp) == set(rp)
-    for name in sorted(gp):
-        a, b = gp[name].grad, rp[name].grad
-        assert (a is None) == (b is None), name
-        if a is None:
+def _rel_errors(grads, exact):
+    out = {}
+    for name, b in exact.items():
+        a = grads[name]
+        if a is None or b is None:
+            assert a is None and b is None, name
             continue
-        a = a.cpu(); scale = b.abs().max().item() + 1e-12
-        close = ((a - b).abs() <= atol * max(scale, 1.0) + rtol * b.abs())
-        assert close.float().mean().item() >= min_frac, (name, (a - b).abs().max().item(), scale)
+        out[name] = ((a.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
+    return out
+
+
+def _grad_dict(module):
+    return {n: p.grad for n, p in module.named_parameters()}
+
+
+def _is_bn_fed_conv_bias(name):
+    # conv bias feeding a batch-statistics BN: the exact gradient is zero (BN removes the mean)
+    return name.endswith("conv1.bias") or name.endswith("conv2.bias")
+
+
+def _compare_grads(net, ref64, tol, ref32=None, slack=3.0):
+    """Norm-wise relative error of every parameter gradient against the float64 oracle.  Training-mode
+    BN makes the fp32 backward of this 21-layer stack ill-conditioned (the fp32 CPU oracle itself is
+    ~1e-2 off the fp64 one), so when `ref32` is given the bar is: the HIP path must be at most
+    `slack` x as far from exact arithmetic as the fp32 CPU restatement is, or within `tol`."""
+    exact = _grad_dict(ref64)
+    e_gpu = _rel_errors(_grad_dict(net), exact)
+    e_cpu = _rel_errors(_grad_dict(ref32), exact) if ref32 is not None else {}
+    for name, err in sorted(e_gpu.items()):
+        if _is_bn_fed_conv_bias(name) and net.training:
+            wn = exact[name[:-4] + "weight"].norm().item()
+            assert _grad_dict(net)[name].norm().item() <= 1e-3 * wn + 1e-6, name
+            continue
+        bar = max(tol, slack * e_cpu.get(name, 0.0))
+        assert err <= bar, (name, err, bar)
 
 
 @pytest.mark.parametrize("kind,ref_cls,channels", [("SpMiddleResNetFHD", R.RefSpMiddleResNetFHD, 256),
@@ -45,40 +69,47 @@ def _compare_grads(net, ref, rtol, atol, min_frac=0.999):
 def test_backbone_forward_backward_vs_oracle(kind, ref_cls, channels):
     feats, coors = _scene_voxels(8000, seed=7, batch=2)   # BASELINE config 1 scene ("second8k"), B=2
     net = fill_params(build_backbone(dict(type=kind, num_input_features=5, ds_factor=8))).train()
-    ref = fill_params(ref_cls(5)).train()
+    ref = fill_params(ref_cls(5)).double().train()   # float64 oracle = exact arithmetic for our purposes
+    ref32 = fill_params(ref_cls(5)).train()           # fp32 oracle: calibrates the conditioning of the backward
     assert sorted(net.state_dict()) == sorted(ref.state_dict())
     grid = np.array([1504, 1504, 40])
-    bev_ref, ms_ref = ref(torch.from_numpy(feats), coors, 2, grid)
+    bev_ref, ms_ref = ref(torch.from_numpy(feats).double(), coors, 2, grid)
+    bev32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
     net = net.to(DEV)
     bev, ms = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
     assert bev.shape == (2, channels, 188, 188) == bev_ref.shape
-    torch.testing.assert_close(bev.cpu(), bev_ref, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(bev.cpu().double(), bev_ref, rtol=1e-3, atol=1e-4)
     if kind == "SpMiddleResNetFHD":
         for k in ["conv1", "conv2", "conv3", "conv4"]:
             assert np.array_equal(ms[k].indices.cpu().numpy(), ms_ref[k].indices), k
-            torch.testing.assert_close(ms[k].features.cpu(), ms_ref[k].features, rtol=2e-3, atol=2e-4)
+            torch.testing.assert_close(ms[k].features.cpu().double(), ms_ref[k].features, rtol=1e-3, atol=1e-4)
     # running statistics updated identically (momentum 0.01, unbiased variance)
     sd, sr = net.state_dict(), ref.state_dict()
     for k in sd:
         if "running" in k:
-            torch.testing.assert_close(sd[k].cpu(), sr[k], rtol=1e-3, atol=1e-5)
+            torch.testing.assert_close(sd[k].cpu().double(), sr[k], rtol=1e-4, atol=1e-6)
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == int(sr[k]) == 1
     g = torch.randn(bev_ref.shape, generator=torch.Generator().manual_seed(5))
-    (bev_ref * g).sum().backward()
+    (bev_ref * g.double()).sum().backward()
+    (bev32 * g).sum().backward()
     (bev * g.to(DEV)).sum().backward()
-    _compare_grads(net, ref, rtol=5e-3, atol=5e-4)
+    _compare_grads(net, ref, tol=5e-3, ref32=ref32)
 
 
-def test_backbone_eval_mode_matches_oracle():
+def test_backbone_eval_mode_forward_backward_matches_oracle():
+    """Running-stat BN (the teacher's mode) is well conditioned: tight tolerance on every gradient."""
     feats, coors = _scene_voxels(8000, seed=11)
     net = fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).eval().to(DEV)
-    ref = fill_params(R.RefSpMiddleResNetFHD(5)).eval()
+    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().eval()
     grid = np.array([1504, 1504, 40])
-    with torch.no_grad():
-        a, _ = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 1, grid)
-        b, _ = ref(torch.from_numpy(feats), coors, 1, grid)
-    torch.testing.assert_close(a.cpu(), b, rtol=2e-3, atol=2e-4)
+    a, _ = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 1, grid)
+    b, _ = ref(torch.from_numpy(feats).double(), coors, 1, grid)
+    torch.testing.assert_close(a.cpu().double(), b, rtol=1e-3, atol=1e-4)
+    g = torch.randn(b.shape, generator=torch.Generator().manual_seed(6))
+    (b * g.double()).sum().backward()
+    (a * g.to(DEV)).sum().backward()
+    _compare_grads(net, ref, tol=5e-4)
 
 
 def test_detector_loss_vs_oracle_stack():
@@ -91,17 +122,18 @@ def test_detector_loss_vs_oracle_stack():
     model = fill_params(build_detector(waymo_configs.centerpoint_voxelnet())).train()
     ref_bb = R.RefSpMiddleResNetFHD(5)
     ref_bb.load_state_dict(model.backbone.state_dict())
-    ref_bb.train()
+    ref_bb.double().train()
     import copy
-    cpu_neck, cpu_head = copy.deepcopy(model.neck).train(), copy.deepcopy(model.bbox_head).train()
+    cpu_neck, cpu_head = copy.deepcopy(model.neck).double().train(), copy.deepcopy(model.bbox_head).double().train()
     # oracle side: CPU voxelizer + oracle backbone + torch-CPU neck/head
     pts = frames.points[0].cpu().numpy()
     v, c, n = OV.points_to_voxel(pts, scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
     assert np.array_equal(ex["coordinates"][:, 1:].cpu().numpy(), c)
     coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
-    bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)), coors, 1, np.array([1504, 1504, 40]))
+    bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double(), coors, 1, np.array([1504, 1504, 40]))
     preds = cpu_head(cpu_neck(bev))
-    ex_cpu = {k: [t.cpu() for t in ex[k]] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+    ex_cpu = {k: [t.cpu().double() if t.is_floating_point() else t.cpu() for t in ex[k]]
+              for k in ["hm", "anno_box", "ind", "mask", "cat"]}
     loss_ref = sum(cpu_head.loss(ex_cpu, preds)["loss"])
     loss_ref.backward()
     model = model.to(DEV)
@@ -109,4 +141,4 @@ def test_detector_loss_vs_oracle_stack():
     loss = sum(losses["loss"])
     loss.backward()
     np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-3)
-    _compare_grads(model.backbone, ref_bb, rtol=1e-2, atol=2e-3, min_frac=0.995)
+    _compare_grads(model.backbone, ref_bb, tol=5e-2)   # train-mode BN conditioning + MIOpen's fp32 conv algorithms in neck/head

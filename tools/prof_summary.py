@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Summarises a `rocprofv3 --kernel-trace --stats` run of bench.py:
+   python tools/prof_summary.py <dir-with-*_kernel_trace.csv> [frames_per_step]
+Prints (a) whole-run per-kernel stats and (b) the kernel breakdown of the LAST steady-state step
+(steps are delimited by the voxelizer's first kernel, one launch per frame)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+
+def main():
+    d = sys.argv[1]
+    frames = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    trace = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(trace)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "vox_insert" in r["Kernel_Name"]]
+    starts = idx[::frames]
+    a, b = starts[-2], starts[-1]
+    seg = rows[a:b]
+    t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in seg:
+        agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        agg[r["Kernel_Name"]][1] += 1
+    tot = sum(v[0] for v in agg.values())
+    print(f"# last steady-state step: wall {(t1 - t0) / 1e6:.3f} ms, {len(seg)} kernels, sum of kernel time {tot / 1e6:.3f} ms")
+    ours = sum(v[0] for k, v in agg.items() if "s2d::" in k)
+    print(f"# hand-written s2d:: kernels {ours / 1e6:.3f} ms ({100 * ours / tot:.1f} %)")
+    print("# share   total_ms  calls  avg_us   kernel")
+    for n, (dur, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+        print(f"{100 * dur / tot:6.2f}% {dur / 1e6:9.3f} {c:6d} {dur / c / 1e3:8.1f}   {n[:140]}")
+
+
+if __name__ == "__main__":
+    main()
