@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-points", type=int, default=150000)
+    p.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16"],
+                   help="compute dtype of the dense neck/head convs (autocast); the sparse stack is fp32")
     return p.parse_args()
 
 
@@ -62,6 +64,10 @@ def build_models(args, dev):
             teacher = build_detector(waymo_configs.centerpoint_voxelnet()).to(dev).eval()
             for p in teacher.parameters():
                 p.requires_grad = False
+    if args.dense_dtype == "bf16":
+        for m in (model, teacher):
+            if m is not None:
+                m.dense_dtype = torch.bfloat16
     return model.to(dev).train(), teacher
 
 
@@ -214,7 +220,9 @@ def main():
             "metric": "LiDAR frames/sec (fwd+bwd), 150k-pt 0.1m-voxel synthetic Waymo scene",
             "value": round(frames_total / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dense_dtype == "f32" else "f32 sparse stack / bf16 dense convs (fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": {"centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
                                     "s2d_student": "CenterPoint-voxelnet + S2D student (KD_VoxelNet) fwd+bwd",
                                     "s2d_distill": "CenterPoint-voxelnet + S2D distill, teacher+student dual forward "

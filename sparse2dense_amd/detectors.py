@@ -31,10 +31,22 @@ class SingleStageDetector(nn.Module):
         self.bbox_head = registry.build_head(bbox_head)
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
+        self.dense_dtype = torch.float32   # set to torch.bfloat16 to run neck + head under autocast
 
     @property
     def with_neck(self):
         return self.neck is not None
+
+    def _dense(self, module, x):
+        """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs)."""
+        if self.dense_dtype == torch.float32 or not x.is_cuda:
+            return module(x)
+        with torch.autocast("cuda", dtype=self.dense_dtype):
+            out = module(x)
+        f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+        if isinstance(out, (tuple, list)):
+            return type(out)(({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for o in out)
+        return f32(out)
 
     def _read(self, example, prefix=""):
         mean_key = prefix + "voxel_mean"
@@ -47,7 +59,7 @@ class SingleStageDetector(nn.Module):
 class VoxelNet(SingleStageDetector):
     def extract_feat(self, data):
         x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
-        neck = self.neck(x) if self.with_neck else x
+        neck = self._dense(self.neck, x) if self.with_neck else x
         return neck, voxel_feature, x
 
     def forward(self, example, return_loss=True, return_feature=False, return_recon_feature=False, **kwargs):
@@ -60,7 +72,7 @@ class VoxelNet(SingleStageDetector):
         if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)
             F_D_b, _ = self.backbone(self._read(example, "reconstruction_"), example["reconstruction_coordinates"],
                                      batch_size, example["shape"][0])
-        preds = self.bbox_head(x)
+        preds = self._dense(self.bbox_head, x)
         if return_loss:
             losses = self.bbox_head.loss(example, preds)
             return losses if not return_feature else (losses, F_D_a, F_D_b)
@@ -74,7 +86,7 @@ class VoxelNet(SingleStageDetector):
 class KD_VoxelNet(VoxelNet):
     def extract_feat(self, data, train_pcm=True):
         x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
-        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self.neck(x)
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x)
         return x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, voxel_feature
 
     mask_offset_loss = staticmethod(mask_offset_loss)
@@ -109,7 +121,7 @@ class KD_VoxelNet(VoxelNet):
             grid_2 = metric_grid(n, d, h, w, gen_offset_2)
             m2, o2 = mask_offset_loss(gen_offset_2, gen_mask_2, recon_gt_2, grid_2)
             mask_loss, comp_loss = m2 + m4, o2 + o4
-        preds = self.bbox_head(x)
+        preds = self._dense(self.bbox_head, x)
         if return_loss:
             losses = self.bbox_head.loss(example, preds)
             if not return_feature:

@@ -183,7 +183,7 @@ class _BNTrainFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module):
         n, c = x.shape
         stats = H.bn1d_stats(x)
-        count = torch.full((1,), float(n), device=x.device)
+        count = torch.full((1,), float(n), device=x.device, dtype=x.dtype)
         if sync:
             packed = torch.cat([stats, count])
             dist.all_reduce(packed)

@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE ONLY — an oracle-backed stand-in for `sparse2dense_amd.hip_ops`.
+
+`install(monkeypatch)` swaps every HIP launcher for a torch-CPU implementation built from
+`oracle/` so that the HOST logic of the product (module wiring, autograd functions, rulebook
+caching/planning, SyncBN + DDP data-parallel path over gloo) can be exercised by `-m "not gpu"`
+tests in a container without a GPU.  Nothing under sparse2dense_amd/ imports this file; the
+product path itself has no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from oracle import spconv_ref as R
+from oracle import voxelize as OV
+from sparse2dense_amd import hip_ops as H
+
+
+def _pairs_to_maps(pairs, n_in, n_out, want_in):
+    kvol = len(pairs)
+    nbr_out = np.full((kvol, n_out), -1, np.int32)
+    nbr_in = np.full((kvol, n_in), -1, np.int32) if want_in else None
+    cnt = np.zeros((kvol,), np.int32)
+    for k, (i_in, i_out) in enumerate(pairs):
+        nbr_out[k, i_out] = i_in
+        if want_in:
+            nbr_in[k, i_in] = i_out
+        cnt[k] = len(i_in)
+    return nbr_out, nbr_in, cnt
+
+
+def voxelize(points, voxel_size, coors_range, max_points, max_voxels, with_mean=True):
+    v, c, n = OV.points_to_voxel(points.numpy(), voxel_size, coors_range, max_points, max_voxels)
+    mean = torch.from_numpy(OV.voxel_mean(v, n)) if with_mean else None
+    return torch.from_numpy(v), torch.from_numpy(c), torch.from_numpy(n), mean
+
+
+def build_subm_rulebook(coors, batch, shape, ksize, dilation=(1, 1, 1)):
+    c = coors.numpy()
+    pairs = R.rulebook_subm(c, tuple(shape), ksize, dilation)
+    nbr_out, _, cnt = _pairs_to_maps(pairs, c.shape[0], c.shape[0], False)
+    return H.Rulebook(True, len(pairs), c.shape[0], c.shape[0], torch.from_numpy(nbr_out), None, torch.from_numpy(cnt),
+                      None, tuple(int(s) for s in shape))
+
+
+def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)):
+    c = coors.numpy()
+    oc, oshape, pairs = R.rulebook_conv(c, tuple(shape), ksize, stride, padding, dilation)
+    nbr_out, nbr_in, cnt = _pairs_to_maps(pairs, c.shape[0], oc.shape[0], True)
+    return H.Rulebook(False, len(pairs), c.shape[0], oc.shape[0], torch.from_numpy(nbr_out), torch.from_numpy(nbr_in),
+                      torch.from_numpy(cnt), torch.from_numpy(oc), oshape)
+
+
+def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag="fwd"):
+    out = feat.new_zeros((n_out, weight_kio.shape[2]))
+    for k in range(weight_kio.shape[0]):
+        o = (nbr[k] >= 0).nonzero().squeeze(1)
+        if o.numel():
+            out.index_add_(0, o, feat[nbr[k][o].long()] @ weight_kio[k])
+    return out + bias if bias is not None else out
+
+
+def spconv_wgrad(feat, dout, nbr, kvol):
+    dw = feat.new_zeros((kvol, feat.shape[1], dout.shape[1]))
+    for k in range(kvol):
+        o = (nbr[k] >= 0).nonzero().squeeze(1)
+        if o.numel():
+            dw[k] = feat[nbr[k][o].long()].t() @ dout[o]
+    return dw
+
+
+def bn1d_stats(x):
+    return torch.cat([x.sum(0), (x * x).sum(0)])
+
+
+def bn1d_apply(x, scale, shift, residual=None, relu=False):
+    y = x * scale + shift
+    if residual is not None:
+        y = y + residual
+    return y.relu() if relu else y
+
+
+def bn1d_bwd_reduce(dy, y, x, relu, want_g=True):
+    g = dy * (y > 0) if relu else dy.clone()
+    return g, torch.cat([g.sum(0), (g * x).sum(0)])
+
+
+def bn1d_bwd_apply(g, x, a, b, d):
+    return a * g + b * x + d
+
+
+def densify(feat, coors, batch, shape):
+    return R.densify(feat, coors.numpy(), tuple(shape), batch)
+
+
+def densify_bwd(dout, coors, batch, shape, c):
+    i = coors.long()
+    return dout[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
+
+
+_NAMES = ["voxelize", "build_subm_rulebook", "build_conv_rulebook", "spconv_gather_gemm", "spconv_wgrad", "bn1d_stats",
+          "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
+
+
+def install(monkeypatch=None):
+    """Patch sparse2dense_amd.hip_ops (and the CUDA-only guard of FeatureBatchNorm1d) in place."""
+    import sparse2dense_amd.spconv as sp
+    g = globals()
+    for n in _NAMES:
+        if monkeypatch is not None:
+            monkeypatch.setattr(H, n, g[n])
+        else:
+            setattr(H, n, g[n])
+    orig = sp.FeatureBatchNorm1d.forward
+
+    def forward(self, x, residual=None, relu=False):
+        if x.shape[0] == 0:
+            return x
+        if self.training or not self.track_running_stats:
+            return sp._BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, sp._dist_on() and self.training,
+                                       self)
+        return sp._BNEvalFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
+
+    if monkeypatch is not None:
+        monkeypatch.setattr(sp.FeatureBatchNorm1d, "forward", forward)
+    else:
+        sp.FeatureBatchNorm1d.forward = forward
+    return orig
