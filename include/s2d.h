@@ -120,6 +120,23 @@ int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, 
 size_t s2d_bn1d_workspace_bytes(int64_t n, int c);
 int s2d_bn1d_stats_f32(const float *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
                        s2d_stream_t stream);
+/*
+ * Per-channel finalisation, one launch each (replaces ~15 elementwise kernels per BN layer):
+ *  fwd: stats[2C] and the (possibly all-reduced) row count -> mean, invstd, scale = gamma*invstd,
+ *       shift = beta - mean*scale; running_mean/var (may both be NULL) updated with `momentum`
+ *       and the unbiased variance, exactly like nn.BatchNorm1d.
+ *  bwd: sums_local (this rank) and sums_global (all ranks; same pointer on one GPU) of
+ *       [sum g, sum g*x] -> dgamma, dbeta (local, DDP averages them) and the three vectors of
+ *       s2d_bn1d_bwd_apply_f32 (global).
+ */
+int s2d_bn1d_finalize_fwd_f32(const float *stats, const float *count, const float *gamma,
+                              const float *beta, float eps, float momentum, int c, float *mean,
+                              float *invstd, float *scale, float *shift, float *running_mean,
+                              float *running_var, s2d_stream_t stream);
+int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *sums_global, const float *count,
+                              const float *gamma, const float *mean, const float *invstd, int c,
+                              float *dgamma, float *dbeta, float *a, float *b, float *d,
+                              s2d_stream_t stream);
 /* y = relu?( (x - mean) * invstd * gamma + beta (+ residual) ); scale/shift precomputed [C] */
 int s2d_bn1d_apply_f32(const float *x, const float *scale, const float *shift,
                        const float *residual, int relu, int64_t n, int c, float *y,

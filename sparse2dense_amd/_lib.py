@@ -40,6 +40,10 @@ SIGNATURES = {
     "s2d_bn1d_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "s2d_bn1d_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bn1d_finalize_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                                 c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_bn1d_finalize_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p,
+                                                 c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_bn1d_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                           c_f32p, ctypes.c_void_p]),
     "s2d_bn1d_bwd_reduce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,

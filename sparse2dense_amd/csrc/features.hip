@@ -136,6 +136,55 @@ __global__ __launch_bounds__(256) void densify_bwd_kernel(const float *__restric
     dfeat[t] = v;
 }
 
+// ---- per-channel finalisation (one tiny launch instead of ~15 elementwise torch kernels) ---------
+// forward: stats[2C] (+count) -> mean, invstd, scale, shift; running stats updated in place.
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__restrict__ stats, const float *__restrict__ count_p,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              float eps, float momentum, int c, float *__restrict__ mean_out,
+                                                              float *__restrict__ invstd_out, float *__restrict__ scale,
+                                                              float *__restrict__ shift, float *__restrict__ running_mean,
+                                                              float *__restrict__ running_var) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float n = *count_p;
+    const float mean = stats[i] / n;
+    float var = stats[c + i] / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[i] * invstd;
+    mean_out[i] = mean;
+    invstd_out[i] = invstd;
+    scale[i] = sc;
+    shift[i] = beta[i] - mean * sc;
+    if (running_mean) {
+        const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
+        running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mean;
+        running_var[i] = (1.f - momentum) * running_var[i] + momentum * unbiased;
+    }
+}
+
+// backward: local sums (for dgamma/dbeta) and global sums (for dx) -> dgamma, dbeta, a, b, d
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__restrict__ sums_local,
+                                                              const float *__restrict__ sums_global,
+                                                              const float *__restrict__ count_p, const float *__restrict__ gamma,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              int c, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                              float *__restrict__ a, float *__restrict__ b, float *__restrict__ d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const float n = *count_p;
+    const float m = mean[i], is = invstd[i];
+    dbeta[i] = sums_local[i];
+    dgamma[i] = is * (sums_local[c + i] - m * sums_local[i]);
+    const float sg = sums_global[i];
+    const float dg_all = is * (sums_global[c + i] - m * sg);
+    const float av = gamma[i] * is;
+    const float bv = -(av * is) * dg_all / n;
+    a[i] = av;
+    b[i] = bv;
+    d[i] = -(av * sg) / n - bv * m;
+}
+
 struct RedPlan {
     int nblocks;
     int rows_per_block;
@@ -271,6 +320,28 @@ extern "C" int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int6
     const int64_t threads = n * c;
     hipLaunchKernelGGL(densify_bwd_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, dout,
                        coors, n, batch, shape[0], shape[1], shape[2], c, dfeat);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_finalize_fwd_f32(const float *stats, const float *count, const float *gamma, const float *beta,
+                                         float eps, float momentum, int c, float *mean, float *invstd, float *scale,
+                                         float *shift, float *running_mean, float *running_var, s2d_stream_t stream) {
+    S2D_CHECK_ARG(c > 0 && stats && count && gamma && beta && mean && invstd && scale && shift, "bn1d_finalize_fwd: null argument");
+    S2D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn1d_finalize_fwd: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, gamma,
+                       beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *sums_global, const float *count,
+                                         const float *gamma, const float *mean, const float *invstd, int c, float *dgamma,
+                                         float *dbeta, float *a, float *b, float *d, s2d_stream_t stream) {
+    S2D_CHECK_ARG(c > 0 && sums_local && sums_global && count && gamma && mean && invstd && dgamma && dbeta && a && b && d,
+                  "bn1d_finalize_bwd: null argument");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_local,
+                       sums_global, count, gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

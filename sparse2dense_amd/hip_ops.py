@@ -229,6 +229,28 @@ def bn1d_stats(x: torch.Tensor) -> torch.Tensor:
     return stats
 
 
+def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """-> packed f32[4,C]: rows mean, invstd, scale, shift (one launch; running stats updated in place)."""
+    lib = _lib.load()
+    c = gamma.shape[0]
+    out = torch.empty((4, c), dtype=torch.float32, device=stats.device)
+    check(lib.s2d_bn1d_finalize_fwd_f32(_ptr(stats), _ptr(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum), c,
+                                        _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(running_mean),
+                                        _ptr(running_var), _stream()), "s2d_bn1d_finalize_fwd_f32")
+    return out
+
+
+def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
+    """-> packed f32[5,C]: rows dgamma, dbeta, a, b, d."""
+    lib = _lib.load()
+    c = gamma.shape[0]
+    out = torch.empty((5, c), dtype=torch.float32, device=gamma.device)
+    check(lib.s2d_bn1d_finalize_bwd_f32(_ptr(sums_local), _ptr(sums_global), _ptr(count), _ptr(gamma), _ptr(mean),
+                                        _ptr(invstd), c, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                        _ptr(out[4]), _stream()), "s2d_bn1d_finalize_bwd_f32")
+    return out
+
+
 def bn1d_apply(x, scale, shift, residual=None, relu=False):
     lib = _lib.load()
     _need_gpu(x, scale, shift, residual)

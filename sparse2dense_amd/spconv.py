@@ -187,20 +187,14 @@ class _BNTrainFn(torch.autograd.Function):
         if sync:
             packed = torch.cat([stats, count])
             dist.all_reduce(packed)
-            stats, count = packed[:-1], packed[-1:]
-        mean = stats[:c] / count
-        var = (stats[c:] / count - mean * mean).clamp_(min=0.0)
-        invstd = torch.rsqrt(var + eps)
-        scale = gamma * invstd
-        shift = beta - mean * scale
+            stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+        track = module is not None and module.track_running_stats
+        fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
+                                  module.running_mean if track else None, module.running_var if track else None)
+        if track:
+            module.num_batches_tracked += 1
+        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         y = H.bn1d_apply(x, scale, shift, residual, relu)
-        if module is not None and module.track_running_stats:
-            with torch.no_grad():
-                m = module.momentum
-                unbiased = var * (count / (count - 1).clamp(min=1.0))
-                module.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                module.running_var.mul_(1 - m).add_(unbiased, alpha=m)
-                module.num_batches_tracked += 1
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, count)
         ctx.relu, ctx.sync, ctx.has_res = relu, sync, residual is not None
         return y
@@ -208,21 +202,16 @@ class _BNTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mean, invstd, count = ctx.saved_tensors
-        c = x.shape[1]
         g, sums = H.bn1d_bwd_reduce(dy.contiguous(), y, x, ctx.relu)
         # parameter grads use the LOCAL sums (DDP averages them over ranks afterwards, exactly
         # like torch.nn.SyncBatchNorm); the input grad needs the GLOBAL sums.
-        dbeta = sums[:c].clone()
-        dgamma = invstd * (sums[c:] - mean * sums[:c])
+        sums_all = sums
         if ctx.sync:
-            dist.all_reduce(sums)
-        sg, sgx = sums[:c], sums[c:]
-        dgamma_all = invstd * (sgx - mean * sg)
-        a = gamma * invstd
-        b = -(a * invstd) * dgamma_all / count
-        d = -(a * sg) / count - b * mean
-        dx = H.bn1d_bwd_apply(g, x, a, b, d) if ctx.needs_input_grad[0] else None
-        return dx, dgamma, dbeta, (g if ctx.has_res else None), None, None, None, None
+            sums_all = sums.clone()
+            dist.all_reduce(sums_all)
+        fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+        dx = H.bn1d_bwd_apply(g, x, fin[2], fin[3], fin[4]) if ctx.needs_input_grad[0] else None
+        return dx, fin[0], fin[1], (g if ctx.has_res else None), None, None, None, None
 
 
 class _BNEvalFn(torch.autograd.Function):

@@ -71,6 +71,33 @@ def bn1d_stats(x):
     return torch.cat([x.sum(0), (x * x).sum(0)])
 
 
+def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    c = gamma.shape[0]
+    mean = stats[:c] / count
+    var = (stats[c:] / count - mean * mean).clamp(min=0)
+    invstd = torch.rsqrt(var + eps)
+    scale = gamma.detach() * invstd
+    shift = beta.detach() - mean * scale
+    if running_mean is not None:
+        with torch.no_grad():
+            unbiased = var * (count / (count - 1).clamp(min=1))
+            running_mean.mul_(1 - momentum).add_(mean * momentum)
+            running_var.mul_(1 - momentum).add_(unbiased * momentum)
+    return torch.stack([mean, invstd, scale, shift])
+
+
+def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
+    c = gamma.shape[0]
+    dbeta = sums_local[:c]
+    dgamma = invstd * (sums_local[c:] - mean * sums_local[:c])
+    sg = sums_global[:c]
+    dg_all = invstd * (sums_global[c:] - mean * sg)
+    a = gamma.detach() * invstd
+    b = -(a * invstd) * dg_all / count
+    d = -(a * sg) / count - b * mean
+    return torch.stack([dgamma, dbeta, a, b, d])
+
+
 def bn1d_apply(x, scale, shift, residual=None, relu=False):
     y = x * scale + shift
     if residual is not None:
@@ -97,7 +124,7 @@ def densify_bwd(dout, coors, batch, shape, c):
 
 
 _NAMES = ["voxelize", "build_subm_rulebook", "build_conv_rulebook", "spconv_gather_gemm", "spconv_wgrad", "bn1d_stats",
-          "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
+          "bn1d_finalize_fwd", "bn1d_finalize_bwd", "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
 
 
 def install(monkeypatch=None):
