@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -46,13 +47,18 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-points", type=int, default=150000)
-    p.add_argument("--dense-dtype", default="f32", choices=["f32", "bf16"],
-                   help="compute dtype of the dense neck/head convs (autocast); the sparse stack is fp32")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                   help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
+    p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
+    p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16"], help="override for the sparse convs")
     return p.parse_args()
 
 
 def build_models(args, dev):
-    from sparse2dense_amd import waymo_configs
+    from sparse2dense_amd import hip_ops, waymo_configs
+    args.dense_dtype = args.dense_dtype or args.dtype
+    args.sparse_dtype = args.sparse_dtype or args.dtype
+    hip_ops.set_sparse_compute_dtype(args.sparse_dtype)
     from sparse2dense_amd.registry import build_detector
     torch.manual_seed(1234)
     teacher = None
@@ -117,12 +123,21 @@ def roofline_pass(step, n_steps=3):
                          gbs=a["bytes"] / a["n"] / (avg_ms * 1e-3) / 1e9))
     rows.sort(key=lambda r: -r["total_ms"])
     top = rows[0]
-    roof = dict(bound="mfma", achieved=round(top["tflops"], 3), peak=PEAK_F32_MATRIX_TFLOPS, unit="TFLOP/s",
-                frac=round(top["tflops"] / PEAK_F32_MATRIX_TFLOPS, 4), traffic=None,
-                kernel=f"{top['kernel']}<cin={top['cin']},cout={top['cout']}> n_out={top['n_out']}",
-                avg_launch_us=round(top["avg_us"], 2), launches_per_step=top["launches"] // n_steps,
-                algorithmic_gbs=round(top["gbs"], 1),
-                scope="dominant hand-written kernel; dense BEV convs run on MIOpen this round")
+    # which roof bounds it: arithmetic intensity of the algorithmic traffic against both peaks
+    peak_tf = PEAK_BF16_MATRIX_TFLOPS if top["kernel"].endswith("bf16") else PEAK_F32_MATRIX_TFLOPS
+    intensity = top["tflops"] * 1e3 / max(top["gbs"], 1e-9)          # FLOP per algorithmic byte
+    hbm_roof_tf = intensity * PEAK_HBM_GBS / 1e3
+    common = dict(traffic=None, kernel=f"{top['kernel']}<cin={top['cin']},cout={top['cout']}> n_out={top['n_out']}",
+                  avg_launch_us=round(top["avg_us"], 2), launches_per_step=top["launches"] // n_steps,
+                  algorithmic_tflops=round(top["tflops"], 2), algorithmic_gbs=round(top["gbs"], 1),
+                  flop_per_byte=round(intensity, 1), mfma_peak_tflops=peak_tf,
+                  scope="dominant hand-written kernel (sparse-conv implicit GEMM); dense BEV convs run on MIOpen this round")
+    if hbm_roof_tf < peak_tf:
+        roof = dict(bound="hbm", achieved=round(top["gbs"], 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(top["gbs"] / PEAK_HBM_GBS, 4), **common)
+    else:
+        roof = dict(bound="mfma", achieved=round(top["tflops"], 3), peak=peak_tf, unit="TFLOP/s",
+                    frac=round(top["tflops"] / peak_tf, 4), **common)
     return roof, rows
 
 
@@ -221,7 +236,8 @@ def main():
             "value": round(frames_total / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dense_dtype == "f32" else "f32 sparse stack / bf16 dense convs (fp32 accumulate)",
+            "dtype": "f32" if (args.dense_dtype, args.sparse_dtype) == ("f32", "f32") else
+                     f"sparse convs {args.sparse_dtype} / dense convs {args.dense_dtype} MFMA inputs, fp32 accumulate+storage",
             "data": "synthetic",
             "config": {"workload": {"centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
                                     "s2d_student": "CenterPoint-voxelnet + S2D student (KD_VoxelNet) fwd+bwd",

@@ -109,6 +109,18 @@ int s2d_rulebook_conv_fill(const int32_t *coors, int64_t n, int batch, const int
 int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const float *weight, const float *bias,
                        const int32_t *nbr, int64_t n_out, int kvol, int cin, int cout,
                        float *out_feat, s2d_stream_t stream);
+/*
+ * bf16-input / fp32-accumulate variant (v_mfma_f32_16x16x32_bf16).  Features and outputs stay
+ * fp32 in HBM; gathered rows are rounded to bf16 (RNE) in registers.  The weights are packed once
+ * per call into the LDS image the kernel stages linearly (kvol*cin*cout bf16 = 2 bytes each).
+ * Supported: cin in {32,64,128}, cout in {16,32,64,128} (s2d_spconv_bf16_supported).
+ */
+int s2d_spconv_bf16_supported(int cin, int cout);
+int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int cin, int cout, void *packed,
+                                 s2d_stream_t stream);
+int s2d_spconv_fwd_bf16(const float *in_feat, int64_t n_in, const void *packed_weight,
+                        const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
+                        int cout, float *out_feat, s2d_stream_t stream);
 /* dweight[k] = sum_o in[nbr[k][o]]^T * dout[o]  ([K][cin][cout]); deterministic two-pass. */
 size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int cin, int cout);
 int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,

@@ -163,6 +163,13 @@ def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1
 # sparse conv arithmetic
 # ------------------------------------------------------------------------------------------------
 PROFILE = None  # bench.py sets this to a list to collect per-launch HIP events (roofline pass)
+SPARSE_COMPUTE_DTYPE = "f32"  # "bf16": MFMA inputs rounded to bf16 (fp32 accumulate) where the kernel supports the shape
+
+
+def set_sparse_compute_dtype(name):
+    global SPARSE_COMPUTE_DTYPE
+    assert name in ("f32", "bf16")
+    SPARSE_COMPUTE_DTYPE = name
 
 
 def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor,
@@ -182,14 +189,23 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
     assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous()
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
     b = bias.contiguous() if bias is not None else None
+    use_bf16 = SPARSE_COMPUTE_DTYPE == "bf16" and lib.s2d_spconv_bf16_supported(cin, cout) and feat.shape[0] > 0
     rec = None
     if PROFILE is not None:
-        rec = dict(kernel="spconv_fwd_mfma" if (cin % 16 == 0 and cout % 16 == 0) else "spconv_fwd_valu", tag=tag,
+        rec = dict(kernel="spconv_fwd_bf16" if use_bf16 else
+                   ("spconv_fwd_mfma" if (cin % 16 == 0 and cout % 16 == 0) else "spconv_fwd_valu"), tag=tag,
                    cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
-    check(lib.s2d_spconv_fwd_f32(_ptr(feat), feat.shape[0], _ptr(weight_kio), _ptr(b), _ptr(nbr), n_out, kvol, cin, cout,
-                                 _ptr(out), _stream()), "s2d_spconv_fwd_f32")
+    if use_bf16:
+        packed = torch.empty((kvol * cin * cout,), dtype=torch.bfloat16, device=feat.device)
+        check(lib.s2d_spconv_pack_weights_bf16(_ptr(weight_kio), kvol, cin, cout, _ptr(packed), _stream()),
+              "s2d_spconv_pack_weights_bf16")
+        check(lib.s2d_spconv_fwd_bf16(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(b), _ptr(nbr), n_out, kvol, cin, cout,
+                                      _ptr(out), _stream()), "s2d_spconv_fwd_bf16")
+    else:
+        check(lib.s2d_spconv_fwd_f32(_ptr(feat), feat.shape[0], _ptr(weight_kio), _ptr(b), _ptr(nbr), n_out, kvol, cin,
+                                     cout, _ptr(out), _stream()), "s2d_spconv_fwd_f32")
     if rec is not None:
         rec["end"].record()
         PROFILE.append(rec)
