@@ -47,10 +47,11 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-points", type=int, default=150000)
-    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                    help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
     p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16"], help="override for the sparse convs")
+    p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
     return p.parse_args()
 
 
@@ -70,10 +71,12 @@ def build_models(args, dev):
             teacher = build_detector(waymo_configs.centerpoint_voxelnet()).to(dev).eval()
             for p in teacher.parameters():
                 p.requires_grad = False
-    if args.dense_dtype == "bf16":
-        for m in (model, teacher):
-            if m is not None:
+    for m in (model, teacher):
+        if m is not None:
+            if args.dense_dtype == "bf16":
                 m.dense_dtype = torch.bfloat16
+            if not args.nchw and args.dense_dtype == "bf16":   # fp32 MIOpen Winograd prefers NCHW (measured)
+                m.use_channels_last()
     return model.to(dev).train(), teacher
 
 

@@ -32,13 +32,26 @@ class SingleStageDetector(nn.Module):
         self.train_cfg = train_cfg
         self.test_cfg = test_cfg
         self.dense_dtype = torch.float32   # set to torch.bfloat16 to run neck + head under autocast
+        self.dense_channels_last = False    # set by use_channels_last()
 
     @property
     def with_neck(self):
         return self.neck is not None
 
+    def use_channels_last(self):
+        """NHWC activations/weights for the 2-D neck + head (avoids per-conv layout transposes)."""
+        for m in (self.neck, self.bbox_head):
+            if m is not None:
+                for mod in m.modules():
+                    if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                        mod.to(memory_format=torch.channels_last)
+        self.dense_channels_last = True
+        return self
+
     def _dense(self, module, x):
         """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs)."""
+        if self.dense_channels_last and x.is_cuda and x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)   # NHWC: what the bf16/fp32 MFMA conv kernels consume
         if self.dense_dtype == torch.float32 or not x.is_cuda:
             return module(x)
         with torch.autocast("cuda", dtype=self.dense_dtype):

@@ -43,28 +43,32 @@ def _ws(nbytes, device):
 # ------------------------------------------------------------------------------------------------
 # voxelization
 # ------------------------------------------------------------------------------------------------
-def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max_voxels: int, with_mean=True):
-    """Device hard-voxelizer.  points f32[N,ndim] (cuda).  Returns
-    (voxels f32[M,max_points,ndim], coors i32[M,3] (z,y,x), num_points i32[M], mean f32[M,ndim]|None).
-    One host read (M) — the same size the reference API returns."""
+def voxelize_async(points: torch.Tensor, voxel_size, coors_range, max_points: int, max_voxels: int, with_mean=True):
+    """Launches the device hard-voxelizer and returns UNTRIMMED buffers plus the device scalar M:
+    (voxels f32[rows,max_points,ndim], coors i32[rows,3], num_points i32[rows], mean|None, out_m i32[1])."""
     lib = _lib.load()
     _need_gpu(points)
     points = points.contiguous().float()
     n, ndim = points.shape
     dev = points.device
-    rows = max(min(n, max_voxels), 1)
+    rows = max(min(n, max_voxels), 1)   # ids are ranks of first points: never more rows than this
     voxels = torch.empty((rows, max_points, ndim), dtype=torch.float32, device=dev)
     coors = torch.empty((rows, 3), dtype=torch.int32, device=dev)
     num = torch.empty((rows,), dtype=torch.int32, device=dev)
     mean = torch.empty((rows, ndim), dtype=torch.float32, device=dev) if with_mean else None
     out_m = torch.zeros((1,), dtype=torch.int32, device=dev)
-    wsb = lib.s2d_voxelize_workspace_bytes(n, max_points, max_voxels)
-    ws = _ws(wsb, dev)
-    # NB: the library sizes its outputs by max_voxels; we allocate min(n, max_voxels) rows, which is
-    # all it can ever write (ids are ranks of first points).
+    ws = _ws(lib.s2d_voxelize_workspace_bytes(n, max_points, max_voxels), dev)
     check(lib.s2d_voxelize_run(_ptr(points), n, ndim, f6(coors_range), f3(voxel_size), max_points, max_voxels,
                                _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(out_m), _ptr(ws), ws.numel(),
                                _stream()), "s2d_voxelize_run")
+    return voxels, coors, num, mean, out_m
+
+
+def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max_voxels: int, with_mean=True):
+    """Device hard-voxelizer.  points f32[N,ndim] (cuda).  Returns
+    (voxels f32[M,max_points,ndim], coors i32[M,3] (z,y,x), num_points i32[M], mean f32[M,ndim]|None).
+    One host read (M) — the same size the reference API returns."""
+    voxels, coors, num, mean, out_m = voxelize_async(points, voxel_size, coors_range, max_points, max_voxels, with_mean)
     m = int(out_m.item())
     return voxels[:m], coors[:m], num[:m], (mean[:m] if with_mean else None)
 

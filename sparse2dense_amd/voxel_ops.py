@@ -76,13 +76,17 @@ def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefi
     `{prefix}voxels f32[sum M,P,C]`, `{prefix}coordinates i32[sum M,4] (b,z,y,x)`,
     `{prefix}num_points i32[sum M]`, `{prefix}num_voxels i64[B]`, plus `{prefix}voxel_mean`
     (the fused reader output).  Key names: collate.py:105-144 / trainer.py:78-124."""
-    vs, cs, ns, ms, counts = [], [], [], [], []
-    for b, pts in enumerate(point_clouds):
-        v, c, n, m = generator.generate(pts, max_voxels, return_mean=True)
-        cb = torch.empty((c.shape[0], 4), dtype=torch.int32, device=c.device)
+    # launch every frame's voxelizer first, then read the B voxel counts with ONE host sync
+    pend = [H.voxelize_async(pts, generator.voxel_size, generator.point_cloud_range, generator.max_num_points_per_voxel,
+                             generator._max_voxels if max_voxels == -1 else max_voxels, with_mean=True)
+            for pts in point_clouds]
+    counts = torch.cat([p[4] for p in pend]).cpu().tolist()
+    vs, cs, ns, ms = [], [], [], []
+    for b, ((v, c, n, m, _), k) in enumerate(zip(pend, counts)):
+        cb = torch.empty((k, 4), dtype=torch.int32, device=c.device)
         cb[:, 0] = b
-        cb[:, 1:] = c
-        vs.append(v); cs.append(cb); ns.append(n); ms.append(m); counts.append(c.shape[0])
+        cb[:, 1:] = c[:k]
+        vs.append(v[:k]); cs.append(cb); ns.append(n[:k]); ms.append(m[:k])
     dev = vs[0].device
     return {
         prefix + "voxels": torch.cat(vs, 0),

@@ -33,6 +33,11 @@ def voxelize(points, voxel_size, coors_range, max_points, max_voxels, with_mean=
     return torch.from_numpy(v), torch.from_numpy(c), torch.from_numpy(n), mean
 
 
+def voxelize_async(points, voxel_size, coors_range, max_points, max_voxels, with_mean=True):
+    v, c, n, m = voxelize(points, voxel_size, coors_range, max_points, max_voxels, with_mean)
+    return v, c, n, m, torch.tensor([c.shape[0]], dtype=torch.int32)
+
+
 def build_subm_rulebook(coors, batch, shape, ksize, dilation=(1, 1, 1)):
     c = coors.numpy()
     pairs = R.rulebook_subm(c, tuple(shape), ksize, dilation)
@@ -123,7 +128,7 @@ def densify_bwd(dout, coors, batch, shape, c):
     return dout[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
 
 
-_NAMES = ["voxelize", "build_subm_rulebook", "build_conv_rulebook", "spconv_gather_gemm", "spconv_wgrad", "bn1d_stats",
+_NAMES = ["voxelize", "voxelize_async", "build_subm_rulebook", "build_conv_rulebook", "spconv_gather_gemm", "spconv_wgrad", "bn1d_stats",
           "bn1d_finalize_fwd", "bn1d_finalize_bwd", "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
 
 

@@ -142,3 +142,36 @@ def test_detector_loss_vs_oracle_stack():
     loss.backward()
     np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-3)
     _compare_grads(model.backbone, ref_bb, tol=5e-2)   # train-mode BN conditioning + MIOpen's fp32 conv algorithms in neck/head
+
+
+def test_bf16_mode_within_stated_tolerance():
+    """BASELINE configs[1] names bf16: MFMA inputs rounded to bf16 (fp32 accumulate, fp32 storage /
+    statistics / master weights).  Stated tolerance vs the fp32/fp64 oracle:
+    2e-2 on features, 5e-2 on the loss."""
+    from sparse2dense_amd import hip_ops as H
+    from sparse2dense_amd.data import SyntheticFrames
+    feats, coors = _scene_voxels(8000, seed=7, batch=2)
+    net = fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).train().to(DEV)
+    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().train()
+    grid = np.array([1504, 1504, 40])
+    b, _ = ref(torch.from_numpy(feats).double(), coors, 2, grid)
+    H.set_sparse_compute_dtype("bf16")
+    try:
+        a, _ = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
+        err = ((a.cpu().double() - b).norm() / b.norm()).item()
+        assert err <= 2e-2, err
+        # whole detector, bf16 sparse + bf16 NHWC dense, against its own fp32 run
+        frames = SyntheticFrames(1, n_points=20000, seed=31)
+        ex = frames.example()
+        model = fill_params(build_detector(waymo_configs.centerpoint_voxelnet())).train().to(DEV)
+        H.set_sparse_compute_dtype("f32")
+        l32 = sum(model(ex, return_loss=True)["loss"]).item()
+        H.set_sparse_compute_dtype("bf16")
+        model.dense_dtype = torch.bfloat16
+        model.use_channels_last()
+        l16 = sum(model(ex, return_loss=True)["loss"])
+        l16.backward()
+        assert abs(l16.item() - l32) <= 5e-2 * abs(l32), (l16.item(), l32)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        H.set_sparse_compute_dtype("f32")
