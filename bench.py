@@ -51,6 +51,8 @@ def parse():
                    help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
     p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16"], help="override for the sparse convs")
+    p.add_argument("--prefetch", action="store_true",
+                   help="voxelize + plan the NEXT batch on a side stream during backward (measured neutral: the step is GPU-bound)")
     p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
     return p.parse_args()
 
@@ -85,7 +87,7 @@ def make_step(args, model, teacher, frames, optimizer):
     params = [p for p in model.parameters() if p.requires_grad]
 
     def step():
-        ex = frames.example()                       # device voxelization of the resident points
+        ex = frames.get()                           # device voxelization (+ geometry) of the resident points
         if teacher is not None:
             loss, _ = distill_loss(teacher, model, ex)
         else:
@@ -93,6 +95,7 @@ def make_step(args, model, teacher, frames, optimizer):
         backward_and_clip(loss, params, 35.0)
         if optimizer is not None:
             optimizer.step()
+        frames.start_next()                         # next batch's voxelizer + rulebooks on the side stream
         return loss
 
     return step
@@ -202,7 +205,15 @@ def main():
     if not args.no_optim:
         optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
                                       weight_decay=0.01, fused=True)
-    step = make_step(args, model, teacher, frames, optimizer)
+    if not args.prefetch:
+        class _Inline:   # voxelize + plan inline on the main stream
+            get = staticmethod(frames.example)
+            start_next = staticmethod(lambda: None)
+        source = _Inline
+    else:
+        from sparse2dense_amd.data import GeometryPrefetcher
+        source = GeometryPrefetcher(frames, [teacher, model])
+    step = make_step(args, model, teacher, source, optimizer)
 
     for _ in range(args.warmup):
         step()

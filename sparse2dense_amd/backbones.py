@@ -78,26 +78,60 @@ class SparseBasicBlock(SparseModule):
         return out
 
 
-def plan_geometry(x: SparseConvTensor, strided_convs, subm_keys):
-    """Builds every rulebook of a backbone pass up front.  `strided_convs` in network order;
-    `subm_keys[i]` = (indice_key, ksize) used at the resolution BEFORE strided_convs[i] (one extra
-    trailing entry allowed for the last resolution)."""
-    coors, shape = x.indices, x.spatial_shape
-    for i, conv in enumerate(strided_convs + [None]):
+def build_geometry(coors, batch_size, shape, strided_specs, subm_keys):
+    """Every rulebook of one backbone pass, from coordinates alone.  `strided_specs[i]` =
+    (plan_key, ksize, stride, padding); `subm_keys[i]` = (indice_key, ksize) at the resolution
+    before strided conv i.  Returns {indice_key: Rulebook, ("conv", plan_key): Rulebook}."""
+    plan = {}
+    for i in range(len(strided_specs) + 1):
         if i < len(subm_keys) and subm_keys[i] is not None:
             key, ksize = subm_keys[i]
-            if key not in x.indice_dict:
-                x.indice_dict[key] = H.build_subm_rulebook(coors, x.batch_size, shape, ksize)
-        if conv is None:
+            plan[key] = H.build_subm_rulebook(coors, batch_size, shape, ksize)
+        if i == len(strided_specs):
             break
-        rb = H.build_conv_rulebook(coors, x.batch_size, shape, conv.kernel_size, conv.stride, conv.padding,
-                                   conv.dilation)
-        x.indice_dict[("conv", id(conv))] = rb
+        pk, ksize, stride, padding = strided_specs[i]
+        rb = H.build_conv_rulebook(coors, batch_size, shape, ksize, stride, padding)
+        plan[("conv", pk)] = rb
         coors, shape = rb.out_coors, rb.out_shape
+    return plan
+
+
+def plan_geometry(x: SparseConvTensor, strided_specs, subm_keys):
+    """Attach the geometry plan to the tensor's indice_dict: reuse one pre-computed for exactly these
+    coordinates (data prefetcher, `tensor._s2d_plan`), else build it now — before the first feature
+    kernel, so that the four host reads of N_out happen while the device is otherwise idle."""
+    pre = getattr(x.indices, "_s2d_plan", None)
+    if pre is None:
+        pre = build_geometry(x.indices, x.batch_size, x.spatial_shape, strided_specs, subm_keys)
+    x.indice_dict.update(pre)
+
+
+class _PlannedBackbone(nn.Module):
+    """shared geometry planning of the two sparse middle extractors"""
+    SUBM_PREFIX = "res"
+
+    def _strided_convs(self):
+        raise NotImplementedError
+
+    def _specs(self):
+        convs = self._strided_convs()
+        for i, c in enumerate(convs):
+            c.plan_key = f"down{i}"
+        strided = [(c.plan_key, c.kernel_size, c.stride, c.padding) for c in convs]
+        subm = [(f"{self.SUBM_PREFIX}{i}", (3, 3, 3)) for i in range(4)]
+        return strided, subm
+
+    def precompute_geometry(self, coors, batch_size, input_shape):
+        """Geometry of a forward pass on `coors` (i32[N,4] cuda), attached to the tensor itself so
+        that a later `forward(…, coors, …)` picks it up.  Used by the side-stream prefetcher."""
+        sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
+        strided, subm = self._specs()
+        coors._s2d_plan = build_geometry(coors, batch_size, sparse_shape, strided, subm)
+        return coors._s2d_plan
 
 
 @BACKBONES.register_module
-class SpMiddleResNetFHD(nn.Module):
+class SpMiddleResNetFHD(_PlannedBackbone):
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", is_student=False, **kwargs):
         super().__init__()
         self.name = name
@@ -128,11 +162,13 @@ class SpMiddleResNetFHD(nn.Module):
         self.extra_conv = SparseSequential(
             SparseConv3d(128, 128, (3, 1, 1), (2, 1, 1), bias=False), norm(128), nn.ReLU())
 
+    def _strided_convs(self):
+        return [self.conv2[0], self.conv3[0], self.conv4[0], self.extra_conv[0]]
+
     def forward(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]  # (z+1, y, x), scn.py:159
-        ret = SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size)
-        plan_geometry(ret, [self.conv2[0], self.conv3[0], self.conv4[0], self.extra_conv[0]],
-                      [("res0", (3, 3, 3)), ("res1", (3, 3, 3)), ("res2", (3, 3, 3)), ("res3", (3, 3, 3))])
+        ret = SparseConvTensor(voxel_features, coors if coors.dtype == torch.int32 else coors.int(), sparse_shape, batch_size)
+        plan_geometry(ret, *self._specs())
         x = self.conv_input(ret)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
@@ -145,7 +181,9 @@ class SpMiddleResNetFHD(nn.Module):
 
 
 @BACKBONES.register_module
-class SpMiddleFHD(nn.Module):
+class SpMiddleFHD(_PlannedBackbone):
+    SUBM_PREFIX = "subm"
+
     """SECOND's plain (non-residual) middle extractor."""
 
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleFHD", **kwargs):
@@ -171,12 +209,13 @@ class SpMiddleFHD(nn.Module):
         self.extra_conv = SparseSequential(
             SparseConv3d(64, 64, (3, 1, 1), (2, 1, 1), bias=False), build_norm_layer(norm_cfg, 64)[1], nn.ReLU())
 
+    def _strided_convs(self):
+        return [m for m in self.middle_conv._modules.values() if isinstance(m, SparseConv3d)] + [self.extra_conv[0]]
+
     def forward(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
-        ret = SparseConvTensor(voxel_features, coors.int(), sparse_shape, batch_size)
-        strided = [m for m in self.middle_conv._modules.values() if isinstance(m, SparseConv3d)]
-        plan_geometry(ret, strided + [self.extra_conv[0]],
-                      [("subm0", (3, 3, 3)), ("subm1", (3, 3, 3)), ("subm2", (3, 3, 3)), ("subm3", (3, 3, 3))])
+        ret = SparseConvTensor(voxel_features, coors if coors.dtype == torch.int32 else coors.int(), sparse_shape, batch_size)
+        plan_geometry(ret, *self._specs())
         conv_4 = self.middle_conv(ret)
         ret = self.extra_conv(conv_4).dense()
         n, c, d, h, w = ret.shape

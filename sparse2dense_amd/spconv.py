@@ -114,6 +114,7 @@ class SparseConvolution(SparseModule):
         self.padding, self.dilation = _triple(padding), _triple(dilation)
         self.subm = subm
         self.indice_key = indice_key
+        self.plan_key = None   # set by a backbone: name under which a pre-planned strided rulebook is stored
         self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
         if bias:
             self.bias = nn.Parameter(torch.empty(out_channels))
@@ -137,7 +138,7 @@ class SparseConvolution(SparseModule):
                 if self.indice_key is not None:
                     x.indice_dict[self.indice_key] = rb
             return rb
-        key = ("conv", id(self))
+        key = ("conv", self.plan_key if self.plan_key is not None else id(self))
         rb = x.indice_dict.get(key)
         if rb is None:
             rb = H.build_conv_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride,
