@@ -39,19 +39,23 @@ class SingleStageDetector(nn.Module):
         return self.neck is not None
 
     def use_channels_last(self):
-        """NHWC activations/weights for the 2-D neck + head (avoids per-conv layout transposes)."""
-        for m in (self.neck, self.bbox_head):
-            if m is not None:
-                for mod in m.modules():
-                    if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
-                        mod.to(memory_format=torch.channels_last)
+        """NHWC activations/weights for the RPN trunk + head convs (avoids per-conv layout transposes
+        under bf16).  The S2D module and PCR head stay NCHW: MIOpen's NHWC bf16 BatchNorm segfaults on
+        their 47x47 maps (ROCm 7.2)."""
+        mods = list(self.bbox_head.modules())
+        if self.neck is not None:
+            mods += list(self.neck.blocks.modules()) + list(self.neck.deblocks.modules())
+            self.neck.trunk_channels_last = True
+        for mod in mods:
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                mod.to(memory_format=torch.channels_last)
         self.dense_channels_last = True
         return self
 
     def _dense(self, module, x):
         """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs)."""
-        if self.dense_channels_last and x.is_cuda and x.dim() == 4:
-            x = x.contiguous(memory_format=torch.channels_last)   # NHWC: what the bf16/fp32 MFMA conv kernels consume
+        if self.dense_channels_last and x.is_cuda and x.dim() == 4 and module is self.bbox_head:
+            x = x.contiguous(memory_format=torch.channels_last)   # NHWC: what the bf16 MFMA conv kernels consume
         if self.dense_dtype == torch.float32 or not x.is_cuda:
             return module(x)
         with torch.autocast("cuda", dtype=self.dense_dtype):

@@ -37,6 +37,7 @@ class RPN(nn.Module):
         self._num_upsample_filters = us_num_filters
         self._num_input_features = num_input_features
         self._norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN", eps=1e-3, momentum=0.01)
+        self.trunk_channels_last = False   # set by the detector: run blocks/deblocks on NHWC activations
         assert len(ds_layer_strides) == len(layer_nums) == len(ds_num_filters)
         assert len(us_num_filters) == len(us_layer_strides)
         self._upsample_start_idx = len(layer_nums) - len(us_layer_strides)
@@ -83,6 +84,8 @@ class RPN(nn.Module):
         _xavier_uniform_convs(self)
 
     def _trunk(self, x, relu_between):
+        if self.trunk_channels_last and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
         ups = []
         for i, blk in enumerate(self.blocks):
             x = blk(x)
@@ -147,13 +150,17 @@ class S2D_RPN(RPN):
         F_S_a = self.fusion_dense(F_S_b) + self.fusion_sparse(x)
         if self.training:
             n, _, h, w = x.shape
-            gen = self.out_conv(F_S_b).view(n, 128, 5, h, w)
-            gen = self.generator_1(gen)
-            gen_offset_4 = self.gen_out_4(gen)
-            gen_mask_4 = self.gen_mask_4(gen)
-            gen = self.generator_2(gen)
-            gen_mask_2 = self.gen_mask_2(gen)
-            gen_offset_2 = self.gen_out_2(gen)
+            gen = self.out_conv(F_S_b)
+            # PCR head in fp32 / standard layout: its 3-D convs are memory-bound, and MIOpen's
+            # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
+            with torch.autocast("cuda", enabled=False):
+                gen = gen.float().contiguous().view(n, 128, 5, h, w)
+                gen = self.generator_1(gen)
+                gen_offset_4 = self.gen_out_4(gen)
+                gen_mask_4 = self.gen_mask_4(gen)
+                gen = self.generator_2(gen)
+                gen_mask_2 = self.gen_mask_2(gen)
+                gen_offset_2 = self.gen_out_2(gen)
         else:
             gen_offset_2 = gen_mask_2 = gen_offset_4 = gen_mask_4 = None
         # the trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)
