@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-points", type=int, default=150000)
+    p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                    help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
@@ -147,13 +148,42 @@ def roofline_pass(step, n_steps=3):
     return roof, rows
 
 
+def effective_cpu_count():
+    """usable host cores: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_subprocess(args, timeout_s=240):
+    """Runs cpu_baseline() in a child process under a hard time limit so that a slow host can never
+    stall the bench; returns None (with the reason on stderr) if it does not finish."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-points", str(args.cpu_points)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        print("cpu_baseline: no result\n" + out.stderr[-2000:], file=sys.stderr)
+    except subprocess.TimeoutExpired:
+        print(f"cpu_baseline: exceeded {timeout_s}s, omitted", file=sys.stderr)
+    return None
+
+
 def cpu_baseline(args):
     """CPU oracle stack on ONE frame of the same workload (fwd+bwd, single iteration)."""
     from oracle import spconv_ref as R
     from oracle import voxelize as OV
     from sparse2dense_amd import scene, waymo_configs
     from sparse2dense_amd.registry import build_detector
-    cores = os.cpu_count() or 1
+    cores = effective_cpu_count()
     torch.set_num_threads(cores)
     s = scene.make_scene(args.cpu_points, seed=20240928)
     t = scene.assign_targets(s["gt_boxes"], s["gt_classes"])
@@ -181,6 +211,10 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
+    torch.set_num_threads(min(effective_cpu_count(), 16))
     from sparse2dense_amd import dp
     rank, local, world = dp.init_distributed()
     if world != max(args.gpus, 1):
@@ -241,7 +275,7 @@ def main():
         roof, rows = roofline_pass(step)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(args)
+        base = cpu_baseline_subprocess(args)
 
     if rank == 0:
         frames_total = args.batch * world * args.steps
