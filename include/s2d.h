@@ -127,6 +127,12 @@ int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, 
                          int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws,
                          size_t ws_bytes, s2d_stream_t stream);
 
+/* same contract, MFMA inputs rounded to bf16 (fp32 accumulate); channel counts that the matrix path
+ * does not cover fall back to the fp32 kernels inside. */
+int s2d_spconv_wgrad_bf16(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
+                          int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws,
+                          size_t ws_bytes, s2d_stream_t stream);
+
 /* ---- BatchNorm1d on features (+ReLU, +residual) ------------------------------------------- */
 /* stats[0..C) = sum_x, stats[C..2C) = sum_x^2 over the n rows (deterministic tree reduction) */
 size_t s2d_bn1d_workspace_bytes(int64_t n, int c);

@@ -42,6 +42,9 @@ SIGNATURES = {
     "s2d_spconv_wgrad_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_void_p]),
+    "s2d_spconv_wgrad_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p]),
     "s2d_bn1d_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "s2d_bn1d_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p]),

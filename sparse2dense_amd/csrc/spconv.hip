@@ -22,6 +22,7 @@
 namespace s2d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int N>
 struct VecF;
@@ -206,18 +207,17 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = 4 * (g0 + u) + q;
-                float z[4] = {0.f, 0.f, 0.f, 0.f};
-                if (idx < cnt) {
-                    const int2 pr = mypairs[idx];
+                const bool ok = idx < cnt;
+                const int2 pr = mypairs[min(idx, cnt - 1)];   // branch-free gather, zeroed by select below
 #pragma unroll
-                    for (int la = 0; la < C::LA; ++la)
-                        av[u][la] = *reinterpret_cast<const veca *>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16);
-                    bv[u] = *reinterpret_cast<const vecb *>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16);
-                } else {
+                for (int la = 0; la < C::LA; ++la) {
+                    veca v = *reinterpret_cast<const veca *>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16);
+                    float tmp[C::VA];
 #pragma unroll
-                    for (int la = 0; la < C::LA; ++la) av[u][la] = *reinterpret_cast<veca *>(z);
-                    bv[u] = *reinterpret_cast<vecb *>(z);
+                    for (int e = 0; e < C::VA; ++e) tmp[e] = ok ? vec_get(v, e) : 0.f;
+                    av[u][la] = *reinterpret_cast<veca *>(tmp);
                 }
+                bv[u] = *reinterpret_cast<const vecb *>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -236,6 +236,96 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads of this window done before the next overwrite
     }
     // tile (la,e,f), reg: ci = 64*la + VA*(4*q+reg) + e ; co = co_base + VB*i16 + f
+    float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;
+#pragma unroll
+    for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+        for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = 64 * la + C::VA * (4 * q + reg) + e;
+                float tmp[C::VB];
+#pragma unroll
+                for (int f = 0; f < C::VB; ++f) tmp[f] = acc[la][e][f][reg];
+                *reinterpret_cast<vecb *>(dst + (int64_t)ci * COUT + co_base + C::VB * i16) = *reinterpret_cast<vecb *>(tmp);
+            }
+}
+
+// bf16-input variant: same decomposition, but one v_mfma_f32_16x16x32_bf16 contracts 32 pairs.
+// Lane (i16, q) owns pairs 8q..8q+7 of a 32-pair group and loads, for each of them, its float4 /
+// float2 channel slice of in[j] and dout[o]; the k-contiguous bf16x8 fragments are assembled in
+// registers (the "transpose" costs nothing: every lane simply loads the elements it multiplies).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_bf16(const float *__restrict__ in, const float *__restrict__ dout,
+                                                         const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                         int rows_per_split, float *__restrict__ partial) {
+    typedef WgradCfg<CIN, COUT> C;
+    typedef typename VecF<C::VA>::type veca;
+    typedef typename VecF<C::VB>::type vecb;
+    __shared__ int2 pair_lds[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int k = blockIdx.x;
+    const int wco = wid % C::WCO, wrow = wid / C::WCO;
+    const int split = blockIdx.y * C::WROW + wrow;
+    const int co_base = wco * 16 * C::VB;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+    int2 *mypairs = pair_lds[wid];
+
+    f32x4 acc[C::LA][C::VA][C::VB];
+#pragma unroll
+    for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+        for (int e = 0; e < C::VA; ++e)
+#pragma unroll
+            for (int f = 0; f < C::VB; ++f) acc[la][e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = r_begin; base < r_end; base += 64) {
+        const int o_l = base + lane;
+        const int j_l = o_l < r_end ? nk[o_l] : -1;
+        const unsigned long long mask = __ballot(j_l >= 0);
+        const int cnt = __popcll(mask);
+        if (cnt == 0) continue;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (j_l >= 0) mypairs[rank] = make_int2(o_l, j_l);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int g = 0; 32 * g < cnt; ++g) {
+            veca av[8][C::LA];
+            vecb bv[8];
+            // branch-free: out-of-range slots re-load the last valid pair and are zeroed by a select
+            // (a branch around each load makes hipcc wait per element and serialises the gathers)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = 32 * g + 8 * q + e;
+                const int2 pr = mypairs[min(idx, cnt - 1)];
+#pragma unroll
+                for (int la = 0; la < C::LA; ++la)
+                    av[e][la] = *reinterpret_cast<const veca *>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16);
+                bv[e] = *reinterpret_cast<const vecb *>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16);
+            }
+            const int nvalid = cnt - 32 * g - 8 * q;  // this lane's valid slots: e < nvalid
+            bf16x8 bfr[C::VB];
+#pragma unroll
+            for (int f = 0; f < C::VB; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bfr[f][e] = (__bf16)(e < nvalid ? vec_get(bv[e], f) : 0.f);
+#pragma unroll
+            for (int la = 0; la < C::LA; ++la)
+#pragma unroll
+                for (int t = 0; t < C::VA; ++t) {
+                    bf16x8 afr;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) afr[e] = (__bf16)(e < nvalid ? vec_get(av[e][la], t) : 0.f);
+#pragma unroll
+                    for (int f = 0; f < C::VB; ++f)
+                        acc[la][t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[f], acc[la][t][f], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;
 #pragma unroll
     for (int la = 0; la < C::LA; ++la)
@@ -358,11 +448,17 @@ static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
     return p;
 }
 
+static bool g_wgrad_bf16 = false;  // set per call by the _bf16 entry point (host side, single-threaded per stream)
+
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
-    hipLaunchKernelGGL((spconv_wgrad_mfma<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out, kvol,
-                       p.rows_per_split, partial);
+    if (g_wgrad_bf16)
+        hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
+                           kvol, p.rows_per_split, partial);
+    else
+        hipLaunchKernelGGL((spconv_wgrad_mfma<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
+                           kvol, p.rows_per_split, partial);
 }
 
 template <int CIN>
@@ -415,9 +511,27 @@ extern "C" size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int 
     return align_up((size_t)p.n_split * kvol * cin * cout * sizeof(float), 256);
 }
 
+static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
+                      int cin, int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
 extern "C" int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
                                     int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
                                     s2d_stream_t stream) {
+    g_wgrad_bf16 = false;
+    return wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
+}
+
+extern "C" int s2d_spconv_wgrad_bf16(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
+                                     int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
+                                     s2d_stream_t stream) {
+    g_wgrad_bf16 = true;
+    int rc = wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
+    g_wgrad_bf16 = false;
+    return rc;
+}
+
+static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
+                      int cin, int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0 && cin > 0 && cout > 0, "spconv_wgrad: bad sizes");
     S2D_CHECK_ARG(dweight, "spconv_wgrad: null dweight");
     hipStream_t st = (hipStream_t)stream;

@@ -229,8 +229,9 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol
     cin = feat.shape[1]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
     ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
-    check(lib.s2d_spconv_wgrad_f32(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw),
-                                   _ptr(ws), ws.numel(), _stream()), "s2d_spconv_wgrad_f32")
+    fn = lib.s2d_spconv_wgrad_bf16 if SPARSE_COMPUTE_DTYPE == "bf16" else lib.s2d_spconv_wgrad_f32
+    check(fn(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw), _ptr(ws), ws.numel(),
+             _stream()), "s2d_spconv_wgrad")
     return dw if cin == cin_true else dw[:, :cin_true].contiguous()
 
 

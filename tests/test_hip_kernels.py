@@ -330,3 +330,32 @@ def test_spconv_bf16_vs_oracle(cin, cout, subm):
     torch.testing.assert_close(out, ref_r, rtol=1e-4, atol=1e-5)
     ref = R.sparse_conv(feats, w, b, pairs, n_out)
     assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (64, 64), (64, 128), (128, 128), (128, 64), (5, 16)])
+def test_spconv_wgrad_bf16_vs_oracle(cin, cout):
+    rs = np.random.RandomState(cin * 5 + cout)
+    torch.manual_seed(cin + cout)
+    shape = (11, 40, 36)
+    coors = _random_coors(rs, 2, shape, 0.12)
+    n = coors.shape[0]
+    feats = torch.randn(n, cin)
+    pairs = R.rulebook_subm(coors, shape, 3)
+    rb = H.build_subm_rulebook(_dev(coors), 2, shape, (3, 3, 3))
+    g = torch.randn(n, cout)
+    H.set_sparse_compute_dtype("bf16")
+    try:
+        gw = H.spconv_wgrad(feats.to(DEV), g.to(DEV), rb.nbr_out, 27).cpu()
+    finally:
+        H.set_sparse_compute_dtype("f32")
+
+    def ref_wgrad(f, d):
+        out = torch.zeros(27, cin, cout, dtype=torch.float64)
+        for k, (i_in, i_out) in enumerate(pairs):
+            if len(i_in):
+                out[k] = f[i_in].double().t() @ d[i_out].double()
+        return out
+    exact_rounded = ref_wgrad(feats.bfloat16().float(), g.bfloat16().float())
+    torch.testing.assert_close(gw.double(), exact_rounded, rtol=1e-4, atol=2e-4)
+    full = ref_wgrad(feats, g)
+    assert (gw.double() - full).abs().max().item() <= 2e-2 * full.abs().max().item()
