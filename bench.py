@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=4, help="frames per GPU (weak scaling; reference trains 3-4/GPU)")
     p.add_argument("--points", type=int, default=150000)
-    p.add_argument("--workload", default="centerpoint", choices=["centerpoint", "s2d_student", "s2d_distill"])
+    p.add_argument("--workload", default="centerpoint", choices=["centerpoint", "s2d_student", "s2d_distill", "pillar", "pillar_s2d"])
     p.add_argument("--no-optim", action="store_true", help="stop after backward + grad clip")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
@@ -68,6 +68,10 @@ def build_models(args, dev):
     teacher = None
     if args.workload == "centerpoint":
         model = build_detector(waymo_configs.centerpoint_voxelnet())
+    elif args.workload == "pillar":
+        model = build_detector(waymo_configs.centerpoint_pillar())
+    elif args.workload == "pillar_s2d":
+        model = build_detector(waymo_configs.pillar_s2d_student())
     else:
         model = build_detector(waymo_configs.s2d_student())
         if args.workload == "s2d_distill":
@@ -91,6 +95,9 @@ def make_step(args, model, teacher, frames, optimizer):
         ex = frames.get()                           # device voxelization (+ geometry) of the resident points
         if teacher is not None:
             loss, _ = distill_loss(teacher, model, ex)
+        elif args.workload == "pillar_s2d":
+            out = model(ex, return_loss=True)          # (losses, F_S_a, F_S_b, preds, mask_loss, offset_loss)
+            loss = sum(out[0]["loss"]) + (out[4] + out[5]) * 0.5   # trainer.py:766 weights for the PP branch
         else:
             loss, _ = single_stage_loss(model, ex)
         backward_and_clip(loss, params, 35.0)
@@ -233,8 +240,12 @@ def main():
 
     model, teacher = build_models(args, dev)
     model = dp.wrap_ddp(model, local)
-    frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
-                             distill=(args.workload != "centerpoint"), device=dev)
+    if args.workload.startswith("pillar"):
+        from sparse2dense_amd.data import SyntheticPillarFrames
+        frames = SyntheticPillarFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank, device=dev)
+    else:
+        frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
+                                 distill=(args.workload not in ("centerpoint",)), device=dev)
     optimizer = None
     if not args.no_optim:
         optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
@@ -290,7 +301,9 @@ def main():
             "config": {"workload": {"centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
                                     "s2d_student": "CenterPoint-voxelnet + S2D student (KD_VoxelNet) fwd+bwd",
                                     "s2d_distill": "CenterPoint-voxelnet + S2D distill, teacher+student dual forward "
-                                                   "(BASELINE configs[2])"}[args.workload],
+                                                   "(BASELINE configs[2])",
+                                    "pillar": "CenterPoint-Pillar single stage (PFN path)",
+                                    "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)"}[args.workload],
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
                        "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}",
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),

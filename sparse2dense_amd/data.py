@@ -80,6 +80,35 @@ def _walk_tensors(obj, fn):
             _walk_tensors(getattr(obj, f.name), fn)
 
 
+class SyntheticPillarFrames:
+    """Scene C: the same sweeps voxelized as pillars (0.32 m, 20 points, 32 000 pillars,
+    configs/waymo/pp/...:156-162) plus the object-only cloud for the PCR target; targets on the
+    468 x 468 map (out_size_factor 1)."""
+
+    def __init__(self, batch_size, n_points=150000, seed=20240928, device="cuda"):
+        self.device = torch.device(device)
+        self.gen = VoxelGenerator(scene.PILLAR_VOXEL, scene.PILLAR_RANGE, 20, 32000)
+        self.points, self.recon_points = [], []
+        tg = {k: [] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+        for b in range(batch_size):
+            s = scene.make_scene(n_points, seed=seed + b, pc_range=scene.PILLAR_RANGE)
+            self.points.append(torch.from_numpy(s["points"]).to(self.device))
+            self.recon_points.append(torch.from_numpy(s["object_points"]).to(self.device))
+            t = scene.assign_targets(s["gt_boxes"], s["gt_classes"], pc_range=scene.PILLAR_RANGE,
+                                     voxel_size=scene.PILLAR_VOXEL, out_size_factor=1, grid_xy=(468, 468))
+            for k in tg:
+                tg[k].append(torch.from_numpy(t[k]))
+        self.targets = {k: [torch.stack(v).to(self.device)] for k, v in tg.items()}
+        self.grid_size = self.gen.grid_size
+
+    def example(self):
+        ex = voxelize_batch(self.gen, self.points)
+        ex.update(voxelize_batch(self.gen, self.recon_points, prefix="reconstruction_"))
+        ex["shape"] = np.stack([self.grid_size] * len(self.points))
+        ex.update(self.targets)
+        return ex
+
+
 class GeometryPrefetcher:
     """Device-side counterpart of the reference's DataLoader workers (`workers_per_gpu=4`, config :182,
     which voxelize on the CPU while the GPU trains): the NEXT batch is voxelized and all of its

@@ -120,7 +120,7 @@ def install():
         return
     if "det3d" in sys.modules and not getattr(sys.modules["det3d"], "__s2d_shim__", False):
         raise RuntimeError("a real det3d package is already imported; the shim would shadow it")
-    from . import backbones, detectors, heads, necks, registry, spconv, voxel_ops  # noqa: F401 (registers keys)
+    from . import backbones, detectors, heads, necks, pillars, registry, spconv, voxel_ops  # noqa: F401 (registers keys)
 
     _module("det3d", __s2d_shim__=True)
     reg_attrs = {k: getattr(registry, k) for k in ["READERS", "BACKBONES", "NECKS", "HEADS", "LOSSES", "DETECTORS",

@@ -1,0 +1,224 @@
+"""PointPillars path (BASELINE config 5) under the reference's registry keys.
+
+  READERS["PillarFeatureNet"], PFNLayer     /root/reference/det3d/models/readers/pillar_encoder.py:16-154
+  BACKBONES["PointPillarsScatter"]          /root/reference/det3d/models/readers/pillar_encoder.py:157-217
+  BACKBONES["PointPillarsScatter_S2D"]      /root/reference/det3d/models/readers/pillar_encoder.py:219-394
+  DETECTORS["PointPillars"]                 /root/reference/det3d/models/detectors/point_pillars.py:10-125
+  DETECTORS["KD_PointPillars"]              /root/reference/det3d/models/detectors/point_pillars.py:127-215
+
+HIP pieces reused from the voxel path: the voxelizer (20 points/pillar, 32 000 pillars), the fused
+BatchNorm1d(+ReLU) kernels (the PFN's BN over [P,20,C] is the same per-channel statistic as over the
+flattened [P*20,C] rows, zero-padded slots included — exactly what the reference normalises), and
+the densify scatter (a pillar canvas is `SparseConvTensor.dense()` with D = 1).  The 2-D S2D module
+and the RPN/CenterHead run on PyTorch-ROCm like the voxel neck.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import registry
+from .backbones import build_norm_layer
+from .detectors import SingleStageDetector
+from .heads import mask_offset_loss, metric_grid
+from .registry import BACKBONES, DETECTORS, READERS
+from .spconv import FeatureBatchNorm1d, SparseConvTensor
+
+
+def get_paddings_indicator(actual_num, max_num, axis=0):
+    """[N, max_num] bool: slot index < actual_num (det3d/models/utils/misc.py:180-202)."""
+    actual_num = torch.unsqueeze(actual_num, axis + 1)
+    shape = [1] * len(actual_num.shape)
+    shape[axis + 1] = -1
+    idx = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(shape)
+    return actual_num.int() > idx
+
+
+class PFNLayer(nn.Module):
+    def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
+        super().__init__()
+        self.name = "PFNLayer"
+        self.last_vfe = last_layer
+        if not self.last_vfe:
+            out_channels = out_channels // 2
+        self.units = out_channels
+        self.norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN1d", eps=1e-3, momentum=0.01)
+        self.linear = nn.Linear(in_channels, self.units, bias=False)
+        self.norm = build_norm_layer(self.norm_cfg, self.units)[1]
+
+    def forward(self, inputs):
+        p, t, _ = inputs.shape
+        x = self.linear(inputs)
+        if isinstance(self.norm, FeatureBatchNorm1d):
+            x = self.norm(x.reshape(p * t, self.units), relu=True).view(p, t, self.units)   # fused BN + ReLU
+        else:
+            x = F.relu(self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous())
+        x_max = torch.max(x, dim=1, keepdim=True)[0]
+        if self.last_vfe:
+            return x_max
+        return torch.cat([x, x_max.repeat(1, t, 1)], dim=2)
+
+
+@READERS.register_module
+class PillarFeatureNet(nn.Module):
+    def __init__(self, num_input_features=4, num_filters=(64,), with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), norm_cfg=None):
+        super().__init__()
+        self.name = "PillarFeatureNet"
+        assert len(num_filters) > 0
+        self.num_input = num_input_features
+        num_input_features += 5 + (1 if with_distance else 0)
+        self._with_distance = with_distance
+        filters = [num_input_features] + list(num_filters)
+        self.pfn_layers = nn.ModuleList(
+            [PFNLayer(filters[i], filters[i + 1], norm_cfg=norm_cfg, last_layer=(i == len(filters) - 2))
+             for i in range(len(filters) - 1)])
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset = self.vx / 2 + pc_range[0]
+        self.y_offset = self.vy / 2 + pc_range[1]
+
+    def forward(self, features, num_voxels, coors):
+        dtype = features.dtype
+        mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_voxels.type_as(features).view(-1, 1, 1)
+        f_cluster = features[:, :, :3] - mean
+        f_center = torch.zeros_like(features[:, :, :2])
+        f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(dtype).unsqueeze(1) * self.vx + self.x_offset)
+        f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(dtype).unsqueeze(1) * self.vy + self.y_offset)
+        parts = [features, f_cluster, f_center]
+        if self._with_distance:
+            parts.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
+        feats = torch.cat(parts, dim=-1)
+        mask = get_paddings_indicator(num_voxels, feats.shape[1], axis=0)
+        feats = feats * mask.unsqueeze(-1).type_as(feats)   # decorations of empty slots back to zero
+        for pfn in self.pfn_layers:
+            feats = pfn(feats)
+        return feats.squeeze()
+
+
+def _scatter_canvas(voxel_features, coords, batch_size, input_shape):
+    """[P,C] pillar features -> [B,C,ny,nx] pseudo image (pillar_encoder.py:174-217)."""
+    nx, ny = int(input_shape[0]), int(input_shape[1])
+    coords = coords if coords.dtype == torch.int32 else coords.int()
+    canvas = SparseConvTensor(voxel_features, coords, (1, ny, nx), batch_size).dense()   # [B,C,1,ny,nx]
+    return canvas.view(batch_size, voxel_features.shape[1], ny, nx)
+
+
+@BACKBONES.register_module
+class PointPillarsScatter(nn.Module):
+    def __init__(self, num_input_features=64, norm_cfg=None, name="PointPillarsScatter", **kwargs):
+        super().__init__()
+        self.name = "PointPillarsScatter"
+        self.nchannels = num_input_features
+
+    def forward(self, voxel_features, coords, batch_size, input_shape):
+        return _scatter_canvas(voxel_features, coords, batch_size, input_shape)
+
+
+def _cbg(conv, c):
+    return [conv, nn.BatchNorm2d(c), nn.GELU()]
+
+
+def _convnext(c, hw):
+    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), nn.LayerNorm([c, hw, hw], eps=1e-6),
+                         nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
+
+
+@BACKBONES.register_module
+class PointPillarsScatter_S2D(nn.Module):
+    """scatter + the pillar flavour of the S2D module (468 -> 234 -> 117 -> 59 -> 3x ConvNeXt -> 117
+    -> 234 -> 468) + 1x1x1 PCR heads."""
+
+    def __init__(self, num_input_features=64, norm_cfg=None, name="PointPillarsScatter", **kwargs):
+        super().__init__()
+        self.name = "PointPillarsScatter"
+        self.nchannels = num_input_features
+        self.encoder_1 = nn.Sequential(nn.MaxPool2d(2, 2), *_cbg(nn.Conv2d(64, 32, 1, 1, 0), 32),
+                                       *_cbg(nn.Conv2d(32, 32, 2, 2), 32), *_cbg(nn.Conv2d(32, 128, 1, 1, 0), 128))
+        self.encoder_2 = nn.Sequential(*_cbg(nn.Conv2d(128, 128, 3, 2, 1), 128), *_cbg(nn.Conv2d(128, 256, 3, 1, 1), 256))
+        self.convnext_block_1 = _convnext(256, 59)
+        self.convnext_block_2 = _convnext(256, 59)
+        self.convnext_block_3 = _convnext(256, 59)
+        self.decoder_1 = nn.Sequential(*_cbg(nn.Conv2d(256, 128, 3, 1, 1), 128), nn.Upsample((117, 117)))
+        self.decoder_2 = nn.Sequential(*_cbg(nn.Conv2d(128 + 128, 64, 3, 1, 1), 64),
+                                       *_cbg(nn.ConvTranspose2d(64, 64, 4, 2, 1), 64),
+                                       *_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
+        self.fusion_sparse = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), num_input_features))
+        self.fusion_dense = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64))
+        self.generator = nn.Sequential(nn.Conv3d(64, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.GELU(),
+                                       nn.Conv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.GELU())
+        self.gen_out = nn.Sequential(nn.Conv3d(16, 3, 1, 1, 0))
+        self.gen_mask = nn.Sequential(nn.Conv3d(16, 8, 1, 1, 0), nn.BatchNorm3d(8), nn.GELU(), nn.Conv3d(8, 1, 1, 1, 0))
+
+    def forward(self, voxel_features, coords, batch_size, input_shape):
+        canvas = _scatter_canvas(voxel_features, coords, batch_size, input_shape)
+        y_1 = self.encoder_1(canvas)
+        y_2 = self.encoder_2(y_1)
+        att = self.convnext_block_1(y_2) + y_2
+        att = self.convnext_block_2(att) + att
+        att = self.convnext_block_3(att) + att
+        y_3 = torch.cat([self.decoder_1(att), y_1], 1)
+        F_S_b = self.decoder_2(y_3)
+        F_S_a = self.fusion_dense(F_S_b) + self.fusion_sparse(canvas)
+        gen_offset = gen_mask = None
+        if self.training:
+            n, c, h, w = canvas.shape
+            gen = self.generator(F_S_b.view(n, c, 1, h, w))
+            gen_mask = self.gen_mask(gen)
+            gen_offset = self.gen_out(gen)
+        return F_S_a, F_S_b, gen_offset, gen_mask
+
+
+@DETECTORS.register_module
+class PointPillars(SingleStageDetector):
+    def _features(self, example, prefix):
+        return self.reader(example[prefix + "voxels"], example[prefix + "num_points"], example[prefix + "coordinates"])
+
+    def extract_feat(self, data):
+        feats = self.reader(data["features"], data["num_voxels"], data["coors"])
+        x_fea = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
+        x = self._dense(self.neck, x_fea) if self.with_neck else x_fea
+        return x, x_fea
+
+    def forward(self, example, return_loss=True, **kwargs):
+        prefix = "dense_" if "dense_voxels" in example else ""
+        batch_size = len(example[prefix + "num_voxels"])
+        data = dict(features=example[prefix + "voxels"], num_voxels=example[prefix + "num_points"],
+                    coors=example[prefix + "coordinates"], batch_size=batch_size, input_shape=example["shape"][0])
+        x, F_D_a = self.extract_feat(data)
+        F_D_b = None
+        if not return_loss:   # teacher pass of the distillation step (point_pillars.py:62-85)
+            feats = self._features(example, "reconstruction_")
+            F_D_b = self.backbone(feats, example["reconstruction_coordinates"], batch_size, example["shape"][0])
+        preds = self._dense(self.bbox_head, x)
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        return preds, F_D_a, F_D_b
+
+
+@DETECTORS.register_module
+class KD_PointPillars(PointPillars):
+    mask_offset_loss = staticmethod(mask_offset_loss)
+
+    def extract_feat(self, data):
+        feats = self.reader(data["features"], data["num_voxels"], data["coors"])
+        F_S_a, F_S_b, gen_offset, gen_mask = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
+        x = self._dense(self.neck, F_S_a) if self.with_neck else F_S_a
+        return x, F_S_a, F_S_b, gen_offset, gen_mask
+
+    def forward(self, example, return_loss=True, **kwargs):
+        batch_size = len(example["num_voxels"])
+        if return_loss:   # dense reconstruction target from the object-only pillars (point_pillars.py:180-190)
+            rv, rn = example["reconstruction_voxels"], example["reconstruction_num_points"]
+            feat = (rv[:, :, :5].sum(dim=1) / rn.type_as(rv).view(-1, 1)).contiguous()
+            shape = np.array(example["shape"][0][::-1]).astype("int64")
+            recon_gt = SparseConvTensor(feat, example["reconstruction_coordinates"].int(), shape, batch_size).dense()
+        data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                    batch_size=batch_size, input_shape=example["shape"][0])
+        x, F_S_a, F_S_b, gen_offset, gen_mask = self.extract_feat(data)
+        preds = self._dense(self.bbox_head, x)
+        if not return_loss:
+            return self.bbox_head.predict(example, preds, self.test_cfg)
+        n, _, d, h, w = gen_offset.shape
+        grid = metric_grid(n, d, h, w, gen_offset)
+        mask_loss, offset_loss = mask_offset_loss(gen_offset, gen_mask, recon_gt, grid)
+        return self.bbox_head.loss(example, preds), F_S_a, F_S_b, preds, mask_loss, offset_loss

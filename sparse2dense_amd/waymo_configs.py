@@ -43,3 +43,32 @@ def second_voxelnet_parts():
                 backbone=dict(type="SpMiddleFHD", num_input_features=5, ds_factor=8),
                 neck=dict(type="RPN", layer_nums=[5], ds_layer_strides=[1], ds_num_filters=[128], us_layer_strides=[1],
                           us_num_filters=[128], num_input_features=128, logger=logging.getLogger("RPN")))
+
+
+def _pp_reader():
+    return dict(type="PillarFeatureNet", num_filters=[64, 64], num_input_features=5, with_distance=False,
+                voxel_size=(0.32, 0.32, 6.0), pc_range=(-74.88, -74.88, -2, 74.88, 74.88, 4.0))
+
+
+def _pp_neck():
+    return dict(type="RPN", layer_nums=[3, 5, 5], ds_layer_strides=[1, 2, 2], ds_num_filters=[64, 128, 256],
+                us_layer_strides=[1, 2, 4], us_num_filters=[128, 128, 128], num_input_features=64,
+                logger=logging.getLogger("RPN"))
+
+
+def _pp_head():
+    h = _head()
+    h["in_channels"] = 128 * 3
+    return h
+
+
+def centerpoint_pillar():
+    """configs/waymo/pp/waymo_centerpoint_pp_two_pfn_stride1_3x_distill_interval_5.py:18-51 (`model`)"""
+    return dict(type="PointPillars", pretrained=None, reader=_pp_reader(),
+                backbone=dict(type="PointPillarsScatter", ds_factor=1), neck=_pp_neck(), bbox_head=_pp_head())
+
+
+def pillar_s2d_student():
+    """same file :55-88 (`S_model`) — BASELINE config 5"""
+    return dict(type="KD_PointPillars", pretrained=None, reader=_pp_reader(),
+                backbone=dict(type="PointPillarsScatter_S2D", ds_factor=1), neck=_pp_neck(), bbox_head=_pp_head())

@@ -79,6 +79,7 @@ def install_reference_stubs():
     for k in ["Empty", "GroupNorm", "Sequential", "change_default_args"]:
         setattr(mu, k, getattr(misc, k))
     mu.build_norm_layer = norm.build_norm_layer
+    mu.get_paddings_indicator = misc.get_paddings_indicator
     importlib.import_module("det3d.models.registry")
     _ns("det3d.models.builder")
     # center_utils imports circle_nms_jit (numba) and cv2: both stubbed above
@@ -282,12 +283,56 @@ def gen_head_and_losses():
     save("losses.npz", **arrays)
 
 
+def gen_pillars():
+    """PointPillars reader + S2D scatter backbone (BASELINE config 5) from the reference modules."""
+    pe = importlib.import_module("det3d.models.readers.pillar_encoder")
+    from sparse2dense_amd import scene
+    g = np.load(os.path.join(HERE, "voxelize_pillar.npz"))
+    voxels = torch.from_numpy(g["voxels"]); num = torch.from_numpy(g["num_points"])
+    coors = torch.from_numpy(np.concatenate([np.zeros((g["coors"].shape[0], 1), np.int32), g["coors"]], 1))
+    pfn = pe.PillarFeatureNet(num_filters=[64, 64], num_input_features=5, with_distance=False,
+                              voxel_size=scene.PILLAR_VOXEL, pc_range=scene.PILLAR_RANGE)
+    fill_params(pfn).train()
+    vin = voxels.clone().requires_grad_(True)
+    feats = pfn(vin, num, coors)
+    names = ["pfn_layers.0.linear.weight", "pfn_layers.1.linear.weight", "pfn_layers.0.norm.weight"]
+    params = dict(pfn.named_parameters())
+    gr = _grads([feats], [vin] + [params[n] for n in names], 700)
+    arrays = dict(state_keys=np.asarray(sorted(pfn.state_dict().keys())))
+    arrays.update(pack("feats", digest(feats))); arrays.update(pack("gvox", digest(gr[0])))
+    for n, gi in zip(names, gr[1:]):
+        arrays.update(pack("g:" + n, digest(gi)))
+    # scatter (plain) on the PFN output
+    sc = pe.PointPillarsScatter(num_input_features=64)
+    canvas = sc(feats.detach(), coors, 1, np.array([468, 468, 1]))
+    arrays.update(pack("canvas", digest(canvas)))
+    save("pillar_pfn.npz", **arrays)
+
+    s2d = fill_params(pe.PointPillarsScatter_S2D(num_input_features=64)).train()
+    f = feats.detach().clone().requires_grad_(True)
+    outs = s2d(f, coors, 1, np.array([468, 468, 1]))
+    onames = ["F_S_a", "F_S_b", "gen_offset", "gen_mask"]
+    names = ["encoder_1.1.weight", "convnext_block_2.1.weight", "decoder_2.3.weight", "generator.3.weight", "gen_mask.3.bias"]
+    params = dict(s2d.named_parameters())
+    gr = _grads(list(outs), [f] + [params[n] for n in names], 800)
+    arrays = dict(state_keys=np.asarray(sorted(s2d.state_dict().keys())),
+                  state_shapes=np.asarray([str(tuple(v.shape)) for _, v in sorted(s2d.state_dict().items())]))
+    for n, o in zip(onames, outs):
+        arrays.update(pack(n, digest(o)))
+    arrays.update(pack("gf", digest(gr[0])))
+    for n, gi in zip(names, gr[1:]):
+        arrays.update(pack("g:" + n, digest(gi)))
+    save("pillar_s2d.npz", **arrays)
+
+
 if __name__ == "__main__":
     install_reference_stubs()
-    which = sys.argv[1:] or ["voxelize", "dense", "head"]
+    which = sys.argv[1:] or ["voxelize", "dense", "head", "pillars"]
     if "voxelize" in which:
         gen_voxelize()
     if "dense" in which:
         gen_dense_modules()
     if "head" in which:
         gen_head_and_losses()
+    if "pillars" in which:
+        gen_pillars()

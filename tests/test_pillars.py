@@ -1,0 +1,138 @@
+"""PointPillars path (BASELINE config 5): reader / scatter / pillar-S2D backbone against golden
+vectors produced by the reference modules (tests/golden/make_golden.py gen_pillars), plus the two
+detectors wired end to end.  CPU runs use the oracle-backed launchers (host logic + torch dense
+ops); `gpu` variants run the HIP voxelizer, fused BN and densify kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_backend
+from golden_util import check_digest, check_digest_norm, fill_params, seeded
+from sparse2dense_amd import scene
+from sparse2dense_amd.registry import BACKBONES, DETECTORS, READERS, build_detector, build_from_cfg, _ensure_registered
+
+_ensure_registered()
+READER_CFG = dict(type="PillarFeatureNet", num_filters=[64, 64], num_input_features=5, with_distance=False,
+                  voxel_size=scene.PILLAR_VOXEL, pc_range=scene.PILLAR_RANGE)
+
+
+def _grads(outputs, inputs, seed):
+    loss = 0
+    for i, o in enumerate(outputs):
+        loss = loss + (o * seeded(o.shape, seed + i).to(o.device)).sum()
+    return torch.autograd.grad(loss, inputs, allow_unused=True)
+
+
+def _pillar_inputs(golden_dir, dev):
+    g = np.load(os.path.join(golden_dir, "voxelize_pillar.npz"))
+    coors = np.concatenate([np.zeros((g["coors"].shape[0], 1), np.int32), g["coors"]], 1)
+    return (torch.from_numpy(g["voxels"]).to(dev), torch.from_numpy(g["num_points"]).to(dev),
+            torch.from_numpy(coors).to(dev))
+
+
+def _run(golden_dir, dev, chk, rt, at):
+    voxels, num, coors = _pillar_inputs(golden_dir, dev)
+    g = np.load(os.path.join(golden_dir, "pillar_pfn.npz"))
+    pfn = fill_params(build_from_cfg(READER_CFG, READERS)).train().to(dev)
+    assert sorted(pfn.state_dict().keys()) == list(g["state_keys"])
+    vin = voxels.clone().requires_grad_(True)
+    feats = pfn(vin, num, coors)
+    names = ["pfn_layers.0.linear.weight", "pfn_layers.1.linear.weight", "pfn_layers.0.norm.weight"]
+    params = dict(pfn.named_parameters())
+    gr = _grads([feats], [vin] + [params[n] for n in names], 700)
+    chk(feats, g, "feats", rt, at)
+    # max-over-points: a near-tie may pick another arg-max, moving single gradient entries -> norm-wise
+    check_digest_norm(gr[0], g, "gvox", max(rt * 5, 2e-3))
+    for n, gi in zip(names, gr[1:]):   # sums over ~1.4e5 rows in a different fp32 order
+        check_digest_norm(gi, g, "g:" + n, max(rt * 5, 2e-3))
+    sc = build_from_cfg(dict(type="PointPillarsScatter", num_input_features=64), BACKBONES)
+    canvas = sc(feats.detach(), coors, 1, np.array([468, 468, 1]))
+    assert canvas.shape == (1, 64, 468, 468)
+    chk(canvas, g, "canvas", rt, at)
+
+    g2 = np.load(os.path.join(golden_dir, "pillar_s2d.npz"))
+    s2d = fill_params(build_from_cfg(dict(type="PointPillarsScatter_S2D", num_input_features=64), BACKBONES)).train().to(dev)
+    sd = s2d.state_dict()
+    assert sorted(sd.keys()) == list(g2["state_keys"])
+    assert [str(tuple(v.shape)) for _, v in sorted(sd.items())] == list(g2["state_shapes"])
+    f = feats.detach().clone().requires_grad_(True)
+    outs = s2d(f, coors, 1, np.array([468, 468, 1]))
+    names = ["encoder_1.1.weight", "convnext_block_2.1.weight", "decoder_2.3.weight", "generator.3.weight", "gen_mask.3.bias"]
+    params = dict(s2d.named_parameters())
+    gr = _grads(list(outs), [f] + [params[n] for n in names], 800)
+    for n, o in zip(["F_S_a", "F_S_b", "gen_offset", "gen_mask"], outs):
+        chk(o, g2, n, rt, at)
+    check_digest_norm(gr[0], g2, "gf", max(rt * 5, 2e-3))   # MaxPool2d / max-over-points arg-max near-ties
+    for n, gi in zip(names, gr[1:]):
+        check_digest_norm(gi, g2, "g:" + n, max(rt * 5, 2e-3))
+
+
+def test_pillar_reader_scatter_s2d_cpu_match_reference_golden(golden_dir, monkeypatch):
+    cpu_backend.install(monkeypatch)
+    _run(golden_dir, "cpu", check_digest, 1e-4, 1e-5)
+
+
+@pytest.mark.gpu
+def test_pillar_reader_scatter_s2d_gpu_match_reference_golden(golden_dir):
+    _run(golden_dir, "cuda:0", lambda t, npz, p, rt, at: check_digest_norm(t, npz, p, rt), 5e-3, 0)
+
+
+def _pp_cfg(kind):
+    import logging
+    tasks = [dict(num_class=3, class_names=["VEHICLE", "PEDESTRIAN", "CYCLIST"])]
+    return dict(type=kind, pretrained=None, reader=READER_CFG,
+                backbone=dict(type="PointPillarsScatter" if kind == "PointPillars" else "PointPillarsScatter_S2D", ds_factor=1),
+                neck=dict(type="RPN", layer_nums=[3, 5, 5], ds_layer_strides=[1, 2, 2], ds_num_filters=[64, 128, 256],
+                          us_layer_strides=[1, 2, 4], us_num_filters=[128, 128, 128], num_input_features=64,
+                          logger=logging.getLogger("RPN")),
+                bbox_head=dict(type="CenterHead", in_channels=128 * 3, tasks=tasks, dataset="waymo", weight=2,
+                               code_weights=[1.0] * 8,
+                               common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2)}))
+
+
+def _pp_example(dev, n_points=3000):
+    from sparse2dense_amd.voxel_ops import VoxelGenerator, voxelize_batch
+    s = scene.make_scene(n_points, seed=77, n_cars=20, n_walls=3, n_peds=6)
+    gen = VoxelGenerator(scene.PILLAR_VOXEL, scene.PILLAR_RANGE, 20, 32000)
+    pts = torch.from_numpy(s["points"]).to(dev)
+    obj = torch.from_numpy(s["object_points"]).to(dev)
+    ex = voxelize_batch(gen, [pts])
+    ex.update(voxelize_batch(gen, [obj], prefix="reconstruction_"))
+    ex["shape"] = np.stack([gen.grid_size])
+    t = scene.assign_targets(s["gt_boxes"], s["gt_classes"], pc_range=scene.PILLAR_RANGE, voxel_size=scene.PILLAR_VOXEL,
+                             out_size_factor=1, grid_xy=(468, 468))
+    for k, v in t.items():
+        ex[k] = [torch.from_numpy(v)[None].to(dev)]
+    return ex
+
+
+def _detectors_step(dev):
+    torch.manual_seed(0)
+    ex = _pp_example(dev)
+    assert list(ex["shape"][0]) == [468, 468, 1]
+    teacher = build_detector(_pp_cfg("PointPillars")).to(dev).train()
+    losses = teacher(ex, return_loss=True)
+    sum(losses["loss"]).backward()
+    assert teacher.reader.pfn_layers[0].linear.weight.grad is not None
+    teacher.eval()
+    with torch.no_grad():
+        preds, F_D_a, F_D_b = teacher(ex, return_loss=False)
+    assert F_D_a.shape == (1, 64, 468, 468) == F_D_b.shape and preds[0]["hm"].shape == (1, 3, 468, 468)
+    student = build_detector(_pp_cfg("KD_PointPillars")).to(dev).train()
+    losses, F_S_a, F_S_b, S_preds, mask_loss, offset_loss = student(ex, return_loss=True)
+    total = sum(losses["loss"]) + mask_loss + offset_loss
+    total.backward()
+    assert torch.isfinite(total) and F_S_a.shape == (1, 64, 468, 468)
+    assert student.backbone.gen_mask[3].weight.grad is not None
+
+
+def test_pointpillars_detectors_cpu(monkeypatch):
+    cpu_backend.install(monkeypatch)
+    _detectors_step("cpu")
+
+
+@pytest.mark.gpu
+def test_pointpillars_detectors_gpu():
+    _detectors_step("cuda:0")

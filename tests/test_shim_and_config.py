@@ -80,6 +80,26 @@ def test_second_config_file_imports_and_backbone_builds():
     assert type(neck).__name__ == "RPN"
 
 
+@need_ref
+def test_pointpillars_config_file_loads_and_builds():
+    """BASELINE config 5: configs/waymo/pp/...distill...: teacher PointPillars + student KD_PointPillars."""
+    shim.install()
+    from det3d.models import build_detector
+    from det3d.torchie import Config
+    cfg = Config.fromfile(os.path.join(REF, "configs/waymo/pp/waymo_centerpoint_pp_two_pfn_stride1_3x_distill_interval_5.py"))
+    t = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    s = build_detector(cfg.S_model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert type(t).__name__ == "PointPillars" and type(s).__name__ == "KD_PointPillars"
+    for k in ["reader.pfn_layers.0.linear.weight", "reader.pfn_layers.1.norm.running_var", "neck.blocks.2.1.weight",
+              "bbox_head.shared_conv.0.weight"]:
+        assert k in t.state_dict(), k
+    assert "backbone.convnext_block_3.1.weight" in s.state_dict() and "backbone.gen_mask.3.bias" in s.state_dict()
+    assert tuple(s.state_dict()["backbone.convnext_block_1.1.weight"].shape) == (256, 59, 59)
+    lit = waymo_configs.pillar_s2d_student()
+    assert {k: v for k, v in dict(cfg.S_model.reader).items()} == lit["reader"]
+    assert cfg.assigner.out_size_factor == 1
+
+
 def test_param_counts_of_literal_configs():
     shim.install()
     from sparse2dense_amd.registry import build_detector
