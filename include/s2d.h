@@ -179,6 +179,24 @@ int s2d_densify_fwd_f32(const float *feat, const int32_t *coors, int64_t n, int 
 int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int64_t n, int batch,
                         const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
 
+/* ---- PCR head of the S2D neck (dense, NCDHW fp32, HBM-bound) -------------------------------- */
+/*
+ * 1x1x1 convolution = per-position channel mixing (nn.Conv3d(k=1) / nn.Conv2d(k=1),
+ * det3d/models/necks/rpn.py:263-296): out[n][co][p] = bias[co] + sum_ci weight[co][ci]*in[n][ci][p].
+ * The data gradient is the same entry with the transposed weight and bias = NULL.
+ */
+int s2d_pointwise_conv_f32(const float *in, const float *weight, const float *bias, int batch,
+                           int cin, int cout, int64_t positions, float *out, s2d_stream_t stream);
+/*
+ * nn.ConvTranspose3d(kernel 4, stride 2, padding 1) (rpn.py:267,284): in [n][cin][d][h][w] ->
+ * out [n][cout][2d][2h][2w]; weight [cin][cout][4][4][4].  _dgrad is its input gradient.
+ */
+int s2d_convt3d_k4s2p1_fwd_f32(const float *in, const float *weight, const float *bias, int batch,
+                               int cin, int cout, int d, int h, int w, float *out,
+                               s2d_stream_t stream);
+int s2d_convt3d_k4s2p1_dgrad_f32(const float *dout, const float *weight, int batch, int cin,
+                                 int cout, int d, int h, int w, float *din, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

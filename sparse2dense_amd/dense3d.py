@@ -1,0 +1,129 @@
+"""PCR-head layers on the hand-written streaming kernels (csrc/dense3d.hip).
+
+`PointwiseConv3d` / `ConvTranspose3dK4S2` are drop-in subclasses of `nn.Conv3d(k=1)` and
+`nn.ConvTranspose3d(4, 2, 1)` (same parameters, same state_dict keys) used by `S2D_RPN` and the
+pillar S2D backbone (/root/reference/det3d/models/necks/rpn.py:263-296,
+readers/pillar_encoder.py:304-323).  CUDA fp32 inputs take the HIP path; the weight gradients
+are plain GEMMs over the position axis (hipBLASLt through torch.matmul).  Other inputs (CPU
+goldens, non-contiguous exotic cases) fall through to the stock torch layer.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import check
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pointwise_conv(x, w2d, bias):
+    """x [N,Cin,*S] fp32 cuda contiguous; w2d [Cout,Cin]; -> [N,Cout,*S]"""
+    lib = _lib.load()
+    n, cin = x.shape[0], x.shape[1]
+    cout = w2d.shape[0]
+    pos = x[0, 0].numel()
+    out = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    check(lib.s2d_pointwise_conv_f32(_ptr(x), _ptr(w2d), _ptr(bias), n, cin, cout, pos, _ptr(out), _stream()),
+          "s2d_pointwise_conv_f32")
+    return out
+
+
+class _PwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w2d = weight.reshape(weight.shape[0], weight.shape[1]).contiguous()
+        ctx.save_for_backward(x, w2d)
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return pointwise_conv(x, w2d, bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w2d = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = pointwise_conv(dout, w2d.t().contiguous(), None)
+        if ctx.needs_input_grad[1]:
+            n, cout = dout.shape[0], dout.shape[1]
+            dw = torch.matmul(dout.reshape(n, cout, -1), x.reshape(n, x.shape[1], -1).transpose(1, 2)).sum(0)
+            dw = dw.reshape(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(dim=[0] + list(range(2, dout.dim())))
+        return dx, dw, db
+
+
+class _ConvT3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = x.contiguous()
+        weight = weight.contiguous()
+        n, cin, d, h, w = x.shape
+        cout = weight.shape[1]
+        out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        check(lib.s2d_convt3d_k4s2p1_fwd_f32(_ptr(x), _ptr(weight), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _stream()),
+              "s2d_convt3d_k4s2p1_fwd_f32")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        n, cin, d, h, w = x.shape
+        cout = weight.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.s2d_convt3d_k4s2p1_dgrad_f32(_ptr(dout), _ptr(weight), n, cin, cout, d, h, w, _ptr(dx), _stream()),
+                  "s2d_convt3d_k4s2p1_dgrad_f32")
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][k] = sum_{n,h} x[n,ci,h] * dout[n,co,2h-1+k]: 64 plain GEMMs over the positions
+            dp = F.pad(dout, (1, 1, 1, 1, 1, 1))
+            xf = x.reshape(n, cin, -1)
+            dw = torch.empty_like(weight)
+            for kz in range(4):
+                for ky in range(4):
+                    for kx in range(4):
+                        sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
+                        dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(dim=(0, 2, 3, 4))
+        return dx, dw, db
+
+
+def _hip_ok(x):
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+
+
+class PointwiseConv3d(nn.Conv3d):
+    """nn.Conv3d with kernel_size 1 (stride 1, no padding)."""
+
+    def forward(self, x):
+        if _hip_ok(x) and self.kernel_size == (1, 1, 1) and self.stride == (1, 1, 1) and self.padding == (0, 0, 0) \
+                and self.groups == 1:
+            return _PwConvFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+class ConvTranspose3dK4S2(nn.ConvTranspose3d):
+    """nn.ConvTranspose3d(cin, cout, 4, 2, 1)."""
+
+    def forward(self, x, output_size=None):
+        if _hip_ok(x) and self.kernel_size == (4, 4, 4) and self.stride == (2, 2, 2) and self.padding == (1, 1, 1) \
+                and self.output_padding == (0, 0, 0) and self.groups == 1 and self.dilation == (1, 1, 1):
+            return _ConvT3dFn.apply(x, self.weight, self.bias)
+        return super().forward(x, output_size)

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
+from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
 from .registry import NECKS
 
 
@@ -130,14 +131,15 @@ class S2D_RPN(RPN):
         self.fusion_dense = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
         self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
         # ---- PCR point-cloud-reconstruction head (rpn.py:263-296) ----
-        self.generator_1 = nn.Sequential(nn.Conv3d(128, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.ReLU(),
-                                         nn.ConvTranspose3d(32, 32, 4, 2, 1), nn.BatchNorm3d(32), nn.ReLU())
-        self.gen_out_4 = nn.Sequential(nn.Conv3d(32, 3, 1, 1, 0))
-        self.gen_mask_4 = nn.Sequential(nn.Conv3d(32, 1, 1, 1, 0))
-        self.generator_2 = nn.Sequential(nn.Conv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.ReLU(),
-                                         nn.ConvTranspose3d(16, 3, 4, 2, 1), nn.BatchNorm3d(3), nn.ReLU())
-        self.gen_out_2 = nn.Sequential(nn.Conv3d(3, 3, 1, 1, 0))
-        self.gen_mask_2 = nn.Sequential(nn.Conv3d(3, 1, 1, 1, 0))
+        # (nn.Conv3d / nn.ConvTranspose3d subclasses: same parameters, HIP streaming kernels on CUDA fp32)
+        self.generator_1 = nn.Sequential(PointwiseConv3d(128, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.ReLU(),
+                                         ConvTranspose3dK4S2(32, 32, 4, 2, 1), nn.BatchNorm3d(32), nn.ReLU())
+        self.gen_out_4 = nn.Sequential(PointwiseConv3d(32, 3, 1, 1, 0))
+        self.gen_mask_4 = nn.Sequential(PointwiseConv3d(32, 1, 1, 1, 0))
+        self.generator_2 = nn.Sequential(PointwiseConv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.ReLU(),
+                                         ConvTranspose3dK4S2(16, 3, 4, 2, 1), nn.BatchNorm3d(3), nn.ReLU())
+        self.gen_out_2 = nn.Sequential(PointwiseConv3d(3, 3, 1, 1, 0))
+        self.gen_mask_2 = nn.Sequential(PointwiseConv3d(3, 1, 1, 1, 0))
 
     def forward(self, x):
         y_1 = self.encoder_1(x)

@@ -1,0 +1,65 @@
+"""PCR-head streaming kernels (csrc/dense3d.hip) against torch's own Conv3d / ConvTranspose3d on the
+CPU in float64 (the reference uses exactly these nn layers, necks/rpn.py:263-296)."""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+from sparse2dense_amd.dense3d import ConvTranspose3dK4S2, PointwiseConv3d
+
+DEV = "cuda:0"
+
+
+def _compare(layer_hip, layer_ref, x, rtol=1e-4, atol=1e-4):
+    layer_ref.load_state_dict(layer_hip.state_dict())
+    layer_ref = layer_ref.double()
+    xr = x.double().requires_grad_(True)
+    yr = layer_ref(xr)
+    g = torch.randn(yr.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    gr = torch.autograd.grad(yr, [xr] + list(layer_ref.parameters()), g)
+    layer_hip = layer_hip.to(DEV)
+    xh = x.to(DEV).requires_grad_(True)
+    yh = layer_hip(xh)
+    gh = torch.autograd.grad(yh, [xh] + list(layer_hip.parameters()), g.float().to(DEV))
+    torch.testing.assert_close(yh.cpu().double(), yr, rtol=rtol, atol=atol)
+    for a, b in zip(gh, gr):
+        scale = b.abs().max().item() + 1e-12
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-4 * scale + atol, (a.shape, scale)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(128, 32, (2, 5, 12, 16)), (32, 3, (1, 4, 10, 12)), (32, 1, (2, 3, 8, 8)),
+                                            (32, 16, (2, 3, 8, 12)), (3, 3, (1, 6, 10, 8)), (3, 1, (2, 2, 6, 4)),
+                                            (16, 8, (1, 1, 20, 20)), (64, 32, (2, 1, 12, 12)), (5, 7, (1, 3, 5, 7))])
+def test_pointwise_conv3d(cin, cout, shape):
+    torch.manual_seed(cin + cout)
+    n, d, h, w = shape
+    x = torch.randn(n, cin, d, h, w)
+    _compare(PointwiseConv3d(cin, cout, 1, 1, 0), nn.Conv3d(cin, cout, 1, 1, 0), x)
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 8)), (16, 3, (1, 4, 7, 9)), (4, 5, (2, 2, 5, 6)), (1, 1, (1, 1, 1, 2))])
+def test_convtranspose3d_k4s2p1(cin, cout, shape):
+    torch.manual_seed(cin * 3 + cout)
+    n, d, h, w = shape
+    x = torch.randn(n, cin, d, h, w)
+    _compare(ConvTranspose3dK4S2(cin, cout, 4, 2, 1), nn.ConvTranspose3d(cin, cout, 4, 2, 1), x)
+
+
+def test_full_size_pcr_shapes_run():
+    """rpn.py:317-323 at the real extents: [1,128,5,188,188] -> [1,32,10,376,376] -> [1,3,20,752,752]"""
+    torch.manual_seed(0)
+    g1 = nn.Sequential(PointwiseConv3d(128, 32, 1, 1, 0), nn.ReLU(), ConvTranspose3dK4S2(32, 32, 4, 2, 1)).to(DEV)
+    g2 = nn.Sequential(PointwiseConv3d(32, 16, 1, 1, 0), nn.ReLU(), ConvTranspose3dK4S2(16, 3, 4, 2, 1)).to(DEV)
+    x = torch.randn(1, 128, 5, 188, 188, device=DEV, requires_grad=True)
+    y1 = g1(x)
+    y2 = g2(y1)
+    assert y1.shape == (1, 32, 10, 376, 376) and y2.shape == (1, 3, 20, 752, 752)
+    y2.mean().backward()
+    assert torch.isfinite(x.grad).all() and g1[2].weight.grad.abs().sum() > 0
+    # spot-check a strided sub-volume against torch on the CPU
+    ref = nn.ConvTranspose3d(16, 3, 4, 2, 1)
+    ref.load_state_dict(g2[2].state_dict())
+    z = g2[1](g2[0](y1)).detach()
+    sub = ref(z[:, :, :4, :8, :8].cpu())
+    torch.testing.assert_close(y2[:, :, :6, :14, :14].detach().cpu(), sub[:, :, :6, :14, :14], rtol=1e-4, atol=1e-4)
