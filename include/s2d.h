@@ -197,6 +197,24 @@ int s2d_convt3d_k4s2p1_fwd_f32(const float *in, const float *weight, const float
 int s2d_convt3d_k4s2p1_dgrad_f32(const float *dout, const float *weight, int batch, int cin,
                                  int cout, int d, int h, int w, float *din, s2d_stream_t stream);
 
+/*
+ * Channel-major batch norm (nn.BatchNorm3d / BatchNorm2d on NC[D]HW fp32 with few channels and
+ * ~1e7 positions per plane: the PCR head, rpn.py:266-289).  Same maths and the same per-channel
+ * finalisation entries as the row-major s2d_bn1d_* family; positions per plane must be a
+ * multiple of 4.  stats/sums are [2C]: (sum x, sum x^2) resp. (sum g, sum g*x), g = dy*(y>0 if relu).
+ */
+size_t s2d_bncm_workspace_bytes(int batch, int c, int64_t positions);
+int s2d_bncm_stats_f32(const float *x, int batch, int c, int64_t positions, float *stats, void *ws,
+                       size_t ws_bytes, s2d_stream_t stream);
+int s2d_bncm_apply_f32(const float *x, const float *scale, const float *shift, int relu, int batch,
+                       int c, int64_t positions, float *y, s2d_stream_t stream);
+int s2d_bncm_bwd_reduce_f32(const float *dy, const float *y, const float *x, int relu, int batch,
+                            int c, int64_t positions, float *sums, void *ws, size_t ws_bytes,
+                            s2d_stream_t stream);
+int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, const float *a,
+                           const float *b, const float *d, int relu, int batch, int c,
+                           int64_t positions, float *dx, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

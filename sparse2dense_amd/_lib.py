@@ -64,6 +64,15 @@ SIGNATURES = {
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_dgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_bncm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "s2d_bncm_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p,
+                                          ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bncm_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int64, c_f32p, ctypes.c_void_p]),
+    "s2d_bncm_bwd_reduce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int64, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bncm_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_densify_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
                                            ctypes.c_void_p]),
     "s2d_densify_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,

@@ -185,6 +185,100 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
     d[i] = -(av * sg) / n - bv * m;
 }
 
+
+// ---- channel-major (NC[D]HW) batch norm for the PCR head --------------------------------------
+// x[n][c][p], few channels (1..32) and up to 1.1e7 positions per plane.  MIOpen assigns one workgroup
+// per channel to such shapes (1.2 ms per call); here every (channel, position-chunk) gets a block.
+// grid (chunks, C); partial[chunk][2C] is reduced by partial_sum_kernel like the row-major case.
+template <bool BWD>
+__global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        const float *__restrict__ y, int relu, int n, int c, int64_t p4,
+                                                        int64_t chunk4, float *__restrict__ partial) {
+    __shared__ float lds[2][4];
+    const int ch = blockIdx.y;
+    const int64_t q0 = (int64_t)blockIdx.x * chunk4;
+    const int64_t q1 = q0 + chunk4 < p4 ? q0 + chunk4 : p4;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < n; ++b) {
+        const int64_t base = ((int64_t)b * c + ch) * p4;
+        for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
+            const float4 xv = reinterpret_cast<const float4 *>(x)[base + q];
+            if (BWD) {
+                float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
+                if (relu) {
+                    const float4 yv = reinterpret_cast<const float4 *>(y)[base + q];
+                    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                    g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+                }
+                s0 += (g.x + g.y) + (g.z + g.w);
+                s1 += (g.x * xv.x + g.y * xv.y) + (g.z * xv.z + g.w * xv.w);
+            } else {
+                s0 += (xv.x + xv.y) + (xv.z + xv.w);
+                s1 += (xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds[0][wid] = s0; lds[1][wid] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * 2 * c + ch] = (lds[0][0] + lds[0][1]) + (lds[0][2] + lds[0][3]);
+        partial[(size_t)blockIdx.x * 2 * c + c + ch] = (lds[1][0] + lds[1][1]) + (lds[1][2] + lds[1][3]);
+    }
+}
+
+// fwd: y = x*scale[c] + shift[c] (relu optional).  bwd (dy given): dx = a[c]*g + b[c]*x + d[c], g = dy*(y>0 if relu)
+template <bool BWD>
+__global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                       const float *__restrict__ y, const float *__restrict__ v0,
+                                                       const float *__restrict__ v1, const float *__restrict__ v2, int relu,
+                                                       int c, int64_t p4, float *__restrict__ out) {
+    // grid (position blocks, N*C)
+    const int plane = blockIdx.y, ch = plane % c;
+    const float a = v0[ch], b = v1[ch], d = BWD ? v2[ch] : 0.f;
+    const int64_t base = (int64_t)plane * p4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < p4; q += (int64_t)gridDim.x * 256) {
+        const float4 xv = reinterpret_cast<const float4 *>(x)[base + q];
+        float4 o;
+        if (BWD) {
+            float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
+            if (relu) {
+                const float4 yv = reinterpret_cast<const float4 *>(y)[base + q];
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            o.x = fmaf(a, g.x, fmaf(b, xv.x, d)); o.y = fmaf(a, g.y, fmaf(b, xv.y, d));
+            o.z = fmaf(a, g.z, fmaf(b, xv.z, d)); o.w = fmaf(a, g.w, fmaf(b, xv.w, d));
+        } else {
+            o.x = fmaf(xv.x, a, b); o.y = fmaf(xv.y, a, b); o.z = fmaf(xv.z, a, b); o.w = fmaf(xv.w, a, b);
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        }
+        reinterpret_cast<float4 *>(out)[base + q] = o;
+    }
+}
+
+struct CmPlan {
+    int chunks;
+    int64_t chunk4;
+    size_t ws_bytes;
+};
+static CmPlan cm_plan(int n, int c, int64_t p4) {
+    CmPlan pl;
+    int64_t want = ceil_div(2048, c > 0 ? c : 1);            // ~2048 blocks in total
+    int64_t maxc = ceil_div(p4, 1024);                         // at least 1024 float4 per block and sample
+    int64_t chunks = want < maxc ? want : maxc;
+    if (chunks < 1) chunks = 1;
+    pl.chunks = (int)chunks;
+    pl.chunk4 = ceil_div(p4, chunks);
+    pl.ws_bytes = align_up((size_t)chunks * 2 * c * sizeof(float), 256);
+    return pl;
+}
+
 struct RedPlan {
     int nblocks;
     int rows_per_block;
@@ -342,6 +436,73 @@ extern "C" int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *s
                   "bn1d_finalize_bwd: null argument");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_local,
                        sums_global, count, gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// ---- channel-major batch norm entry points -------------------------------------------------------
+extern "C" size_t s2d_bncm_workspace_bytes(int batch, int c, int64_t positions) {
+    if (batch <= 0 || c <= 0 || positions <= 0 || (positions & 3)) return 0;
+    return cm_plan(batch, c, positions / 4).ws_bytes;
+}
+
+static int bncm_reduce(bool bwd, const float *x, const float *dy, const float *y, int relu, int batch, int c,
+                       int64_t positions, float *sums, void *ws, size_t ws_bytes, hipStream_t st) {
+    S2D_CHECK_ARG(batch > 0 && c > 0 && c <= 65535 && positions > 0 && x && sums, "bncm: bad argument");
+    if (positions & 3) {
+        set_error("bncm: positions per plane (%lld) must be a multiple of 4", (long long)positions);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    CmPlan pl = cm_plan(batch, c, positions / 4);
+    if (!ws || ws_bytes < pl.ws_bytes) {
+        set_error("bncm: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    if (bwd)
+        hipLaunchKernelGGL(cm_reduce_kernel<true>, dim3(pl.chunks, c), dim3(256), 0, st, x, dy, y, relu, batch, c,
+                           positions / 4, pl.chunk4, (float *)ws);
+    else
+        hipLaunchKernelGGL(cm_reduce_kernel<false>, dim3(pl.chunks, c), dim3(256), 0, st, x, nullptr, nullptr, 0, batch, c,
+                           positions / 4, pl.chunk4, (float *)ws);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, pl.chunks, 2 * c, sums);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bncm_stats_f32(const float *x, int batch, int c, int64_t positions, float *stats, void *ws,
+                                  size_t ws_bytes, s2d_stream_t stream) {
+    return bncm_reduce(false, x, nullptr, nullptr, 0, batch, c, positions, stats, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int s2d_bncm_bwd_reduce_f32(const float *dy, const float *y, const float *x, int relu, int batch, int c,
+                                       int64_t positions, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(dy && (!relu || y), "bncm_bwd_reduce: null argument");
+    return bncm_reduce(true, x, dy, y, relu, batch, c, positions, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int s2d_bncm_apply_f32(const float *x, const float *scale, const float *shift, int relu, int batch, int c,
+                                  int64_t positions, float *y, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && scale && shift && y && batch > 0 && c > 0 && positions > 0 && !(positions & 3) &&
+                      (int64_t)batch * c <= 65535, "bncm_apply: bad argument");
+    const int64_t p4 = positions / 4;
+    int64_t bx = ceil_div(p4, 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(cm_apply_kernel<false>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                       nullptr, scale, shift, nullptr, relu, c, p4, y);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, const float *a, const float *b,
+                                      const float *d, int relu, int batch, int c, int64_t positions, float *dx,
+                                      s2d_stream_t stream) {
+    S2D_CHECK_ARG(dy && x && a && b && d && dx && (!relu || y) && batch > 0 && c > 0 && positions > 0 && !(positions & 3) &&
+                      (int64_t)batch * c <= 65535, "bncm_bwd_apply: bad argument");
+    const int64_t p4 = positions / 4;
+    int64_t bx = ceil_div(p4, 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(cm_apply_kernel<true>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, dy, y, a, b,
+                       d, relu, c, p4, dx);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

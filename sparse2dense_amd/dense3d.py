@@ -127,3 +127,102 @@ class ConvTranspose3dK4S2(nn.ConvTranspose3d):
                 and self.output_padding == (0, 0, 0) and self.groups == 1 and self.dilation == (1, 1, 1):
             return _ConvT3dFn.apply(x, self.weight, self.bias)
         return super().forward(x, output_size)
+
+
+# --------------------------------------------------------------------------------------------------
+# channel-major BatchNorm (NC[D]HW, few channels, ~1e7 positions per plane)
+# --------------------------------------------------------------------------------------------------
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _bncm_reduce(fn_name, args_front, n, c, pos, device):
+    lib = _lib.load()
+    out = torch.empty((2 * c,), dtype=torch.float32, device=device)
+    ws = _ws(lib.s2d_bncm_workspace_bytes(n, c, pos), device)
+    check(getattr(lib, fn_name)(*args_front, n, c, pos, _ptr(out), _ptr(ws), ws.numel(), _stream()), fn_name)
+    return out
+
+
+class _BNChannelMajorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, eps, sync, module, training):
+        import torch.distributed as dist
+        from . import hip_ops as H
+        lib = _lib.load()
+        x = x.contiguous()
+        n, c = x.shape[0], x.shape[1]
+        pos = x[0, 0].numel()
+        dev = x.device
+        if training:
+            stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(x),), n, c, pos, dev)
+            count = torch.full((1,), float(n * pos), device=dev)
+            if sync:
+                packed = torch.cat([stats, count])
+                dist.all_reduce(packed)
+                stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+            track = module.track_running_stats
+            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
+                                      module.running_mean if track else None, module.running_var if track else None)
+            if track:
+                module.num_batches_tracked += 1
+            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+        else:
+            invstd = torch.rsqrt(module.running_var + eps)
+            mean = module.running_mean
+            scale = gamma * invstd
+            shift = beta - mean * scale
+            count = torch.full((1,), float(n * pos), device=dev)
+        y = torch.empty_like(x)
+        check(lib.s2d_bncm_apply_f32(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), int(relu), n, c, pos,
+                                     _ptr(y), _stream()), "s2d_bncm_apply_f32")
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, count, scale)
+        ctx.relu, ctx.sync, ctx.training = relu, sync, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        from . import hip_ops as H
+        lib = _lib.load()
+        x, y, gamma, mean, invstd, count, scale = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape[0], x.shape[1]
+        pos = x[0, 0].numel()
+        sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), _ptr(y), _ptr(x), int(ctx.relu)), n, c, pos, x.device)
+        if ctx.training:
+            sums_all = sums
+            if ctx.sync:
+                sums_all = sums.clone()
+                dist.all_reduce(sums_all)
+            fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+            dgamma, dbeta, a, b, d = fin[0], fin[1], fin[2], fin[3], fin[4]
+        else:
+            dbeta = sums[:c]
+            dgamma = invstd * (sums[c:] - mean * sums[:c])
+            a, b, d = scale.contiguous(), torch.zeros_like(scale), torch.zeros_like(scale)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(a), _ptr(b), _ptr(d), int(ctx.relu), n, c, pos,
+                                             _ptr(dx), _stream()), "s2d_bncm_bwd_apply_f32")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class FastBatchNorm3d(nn.BatchNorm3d):
+    """nn.BatchNorm3d (same parameters / buffers) with an optional fused ReLU; CUDA fp32 inputs whose
+    plane size is a multiple of 4 run the channel-major HIP kernels and synchronise their statistics
+    across ranks themselves when torch.distributed is initialised."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, fused_relu=False):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.fused_relu = fused_relu
+
+    def forward(self, x):
+        if _hip_ok(x) and x.dim() >= 3 and x[0, 0].numel() % 4 == 0 and self.affine and x.shape[0] * x.shape[1] <= 65535:
+            import torch.distributed as dist
+            training = self.training or not self.track_running_stats
+            sync = training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            return _BNChannelMajorFn.apply(x, self.weight, self.bias, self.fused_relu, self.eps, sync, self, training)
+        y = super().forward(x)
+        return F.relu(y) if self.fused_relu else y

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
+from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .registry import NECKS
 
 
@@ -132,12 +132,16 @@ class S2D_RPN(RPN):
         self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
         # ---- PCR point-cloud-reconstruction head (rpn.py:263-296) ----
         # (nn.Conv3d / nn.ConvTranspose3d subclasses: same parameters, HIP streaming kernels on CUDA fp32)
-        self.generator_1 = nn.Sequential(PointwiseConv3d(128, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.ReLU(),
-                                         ConvTranspose3dK4S2(32, 32, 4, 2, 1), nn.BatchNorm3d(32), nn.ReLU())
+        # BN+ReLU pairs are fused in FastBatchNorm3d; an nn.Identity keeps the reference's Sequential indices
+        def bnr(c):
+            return FastBatchNorm3d(c, fused_relu=True)
+
+        self.generator_1 = nn.Sequential(PointwiseConv3d(128, 32, 1, 1, 0), bnr(32), nn.Identity(),
+                                         ConvTranspose3dK4S2(32, 32, 4, 2, 1), bnr(32), nn.Identity())
         self.gen_out_4 = nn.Sequential(PointwiseConv3d(32, 3, 1, 1, 0))
         self.gen_mask_4 = nn.Sequential(PointwiseConv3d(32, 1, 1, 1, 0))
-        self.generator_2 = nn.Sequential(PointwiseConv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.ReLU(),
-                                         ConvTranspose3dK4S2(16, 3, 4, 2, 1), nn.BatchNorm3d(3), nn.ReLU())
+        self.generator_2 = nn.Sequential(PointwiseConv3d(32, 16, 1, 1, 0), bnr(16), nn.Identity(),
+                                         ConvTranspose3dK4S2(16, 3, 4, 2, 1), bnr(3), nn.Identity())
         self.gen_out_2 = nn.Sequential(PointwiseConv3d(3, 3, 1, 1, 0))
         self.gen_mask_2 = nn.Sequential(PointwiseConv3d(3, 1, 1, 1, 0))
 

@@ -19,7 +19,7 @@ from torch import nn
 
 from . import registry
 from .backbones import build_norm_layer
-from .dense3d import PointwiseConv3d
+from .dense3d import FastBatchNorm3d, PointwiseConv3d
 from .detectors import SingleStageDetector
 from .heads import mask_offset_loss, metric_grid
 from .registry import BACKBONES, DETECTORS, READERS
@@ -145,10 +145,10 @@ class PointPillarsScatter_S2D(nn.Module):
                                        *_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
         self.fusion_sparse = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), num_input_features))
         self.fusion_dense = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64))
-        self.generator = nn.Sequential(PointwiseConv3d(64, 32, 1, 1, 0), nn.BatchNorm3d(32), nn.GELU(),
-                                       PointwiseConv3d(32, 16, 1, 1, 0), nn.BatchNorm3d(16), nn.GELU())
+        self.generator = nn.Sequential(PointwiseConv3d(64, 32, 1, 1, 0), FastBatchNorm3d(32), nn.GELU(),
+                                       PointwiseConv3d(32, 16, 1, 1, 0), FastBatchNorm3d(16), nn.GELU())
         self.gen_out = nn.Sequential(PointwiseConv3d(16, 3, 1, 1, 0))
-        self.gen_mask = nn.Sequential(PointwiseConv3d(16, 8, 1, 1, 0), nn.BatchNorm3d(8), nn.GELU(),
+        self.gen_mask = nn.Sequential(PointwiseConv3d(16, 8, 1, 1, 0), FastBatchNorm3d(8), nn.GELU(),
                                       PointwiseConv3d(8, 1, 1, 1, 0))
 
     def forward(self, voxel_features, coords, batch_size, input_shape):

@@ -63,3 +63,35 @@ def test_full_size_pcr_shapes_run():
     z = g2[1](g2[0](y1)).detach()
     sub = ref(z[:, :, :4, :8, :8].cpu())
     torch.testing.assert_close(y2[:, :, :6, :14, :14].detach().cpu(), sub[:, :, :6, :14, :14], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("c,shape,relu", [(32, (2, 5, 12, 16), True), (3, (2, 20, 24, 28), True), (16, (1, 10, 16, 12), False),
+                                          (8, (2, 1, 20, 20), False)])
+@pytest.mark.parametrize("train", [True, False])
+def test_channel_major_batchnorm3d(c, shape, relu, train):
+    from sparse2dense_amd.dense3d import FastBatchNorm3d
+    torch.manual_seed(c)
+    n, d, h, w = shape
+    x = torch.randn(n, c, d, h, w) * 2 + 0.3
+    bn = FastBatchNorm3d(c, eps=1e-5, momentum=0.1, fused_relu=relu)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2)
+    ref = nn.BatchNorm3d(c, eps=1e-5, momentum=0.1).double()
+    ref.load_state_dict(bn.state_dict())
+    bn.train(train); ref.train(train)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = yr.relu()
+    g = torch.randn(yr.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    gr = torch.autograd.grad(yr, [xr, ref.weight, ref.bias], g)
+    bn = bn.to(DEV)
+    xh = x.to(DEV).requires_grad_(True)
+    yh = bn(xh)
+    gh = torch.autograd.grad(yh, [xh, bn.weight, bn.bias], g.float().to(DEV))
+    torch.testing.assert_close(yh.cpu().double(), yr, rtol=1e-4, atol=1e-4)
+    for a, b in zip(gh, gr):
+        assert (a.cpu().double() - b).abs().max().item() <= 1e-3 * (b.abs().max().item() + 1e-9) + 1e-5
+    if train:
+        torch.testing.assert_close(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(bn.running_var.cpu().double(), ref.running_var, rtol=1e-4, atol=1e-5)
