@@ -146,6 +146,7 @@ def roofline_pass(step, n_steps=3):
                   algorithmic_tflops=round(top["tflops"], 2), algorithmic_gbs=round(top["gbs"], 1),
                   flop_per_byte=round(intensity, 1), mfma_peak_tflops=peak_tf,
                   scope="dominant hand-written kernel (sparse-conv implicit GEMM); dense BEV convs run on MIOpen this round")
+    common["traffic"], common["traffic_source"] = pmc_traffic(top)
     if hbm_roof_tf < peak_tf:
         roof = dict(bound="hbm", achieved=round(top["gbs"], 1), peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=round(top["gbs"] / PEAK_HBM_GBS, 4), **common)
@@ -166,6 +167,25 @@ def effective_cpu_count():
     except Exception:
         pass
     return max(1, n)
+
+
+def pmc_traffic(top):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/
+    r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs).  Only used when the
+    profiled instantiation and row count are the ones being benchmarked; otherwise null."""
+    try:
+        db = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+    except Exception:
+        return None, None
+    if top["n_out"] != 40644:      # the profile was taken on the default workload (B=4, seed 20240928)
+        return None, None
+    nt = {16: 1, 32: 2}.get(top["cout"], 4)
+    want = f"s2d::{top['kernel']}<{top['cin']}, {nt}, 2>"
+    for name, v in db.items():
+        if want in name and v["FETCH_SIZE_KiB"] and v["WRITE_SIZE_KiB"]:
+            b = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+            return round(b), "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB, per launch)"
+    return None, None
 
 
 def cpu_baseline_subprocess(args, timeout_s=240):
