@@ -334,7 +334,7 @@ def main():
             out["config"]["spconv_kernels"] = [
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

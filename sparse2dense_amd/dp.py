@@ -24,7 +24,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("S2D_FORCE_DDP", "0") == "1"   # exercise the N>1 code path with one rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -56,7 +57,8 @@ def convert_syncbn(module: nn.Module):
 
 
 def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=25, find_unused_parameters=False):
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    force = os.environ.get("S2D_FORCE_DDP", "0") == "1"
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return model
     model = convert_syncbn(model)
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters,

@@ -176,7 +176,10 @@ class SparseConv3d(SparseConvolution):
 # BatchNorm1d on features
 # --------------------------------------------------------------------------------------------------
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
 
 
 class _BNTrainFn(torch.autograd.Function):
