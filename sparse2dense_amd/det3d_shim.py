@@ -133,7 +133,8 @@ def install():
     _module("det3d.utils", Registry=registry.Registry, build_from_cfg=registry.build_from_cfg)
     _module("det3d.utils.registry", Registry=registry.Registry, build_from_cfg=registry.build_from_cfg)
     _module("det3d.utils.config_tool", get_downsample_factor=get_downsample_factor)
-    _module("det3d.builder", build_box_coder=lambda cfg, **kw: ConfigDict(dict(cfg, code_size=cfg.get("n_dim", 7))))
+    _module("det3d.builder", build_box_coder=lambda cfg, **kw: ConfigDict(
+        dict(cfg, code_size=cfg.get("n_dim", 7) + (1 if cfg.get("encode_angle_vector", False) else 0))))
     _module("det3d.torchie", Config=Config, ConfigDict=ConfigDict)
     _module("det3d.ops")
     _module("det3d.ops.point_cloud")

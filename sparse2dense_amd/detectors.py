@@ -95,6 +95,8 @@ class VoxelNet(SingleStageDetector):
             return losses if not return_feature else (losses, F_D_a, F_D_b)
         if return_feature and return_recon_feature:
             return preds, F_D_a, F_D_b
+        if kwargs.get("raw_preds", False):   # forward-only use (SECOND config 1: anchor decode is out of scope)
+            return preds
         boxes = self.bbox_head.predict(example, preds, self.test_cfg)
         return boxes if not return_feature else (boxes, F_D_a, F_D_b)
 

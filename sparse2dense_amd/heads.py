@@ -205,3 +205,69 @@ class CenterHead(nn.Module):
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         raise NotImplementedError("CenterHead.predict (decode + rotated NMS) is inference post-processing; "
                                   "out of scope of the training hot path (DESIGN.md, SURVEY.md §8(f))")
+
+
+# ----------------------------------------------------------------------------------------------
+# SECOND anchor head — forward only (BASELINE config 1)
+# ----------------------------------------------------------------------------------------------
+@HEADS.register_module
+class Head(nn.Module):
+    """three 1x1 convs + NHWC permute (/root/reference/det3d/models/bbox_heads/mg_head.py:199-232)"""
+
+    def __init__(self, num_input, num_pred, num_cls, use_dir=False, num_dir=0, header=True, name="",
+                 focal_loss_init=False, **kwargs):
+        super().__init__(**kwargs)
+        self.use_dir = use_dir
+        self.conv_box = nn.Conv2d(num_input, num_pred, 1)
+        self.conv_cls = nn.Conv2d(num_input, num_cls, 1)
+        if self.use_dir:
+            self.conv_dir = nn.Conv2d(num_input, num_dir, 1)
+
+    def forward(self, x):
+        ret = {"box_preds": self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
+               "cls_preds": self.conv_cls(x).permute(0, 2, 3, 1).contiguous()}
+        if self.use_dir:
+            ret["dir_cls_preds"] = self.conv_dir(x).permute(0, 2, 3, 1).contiguous()
+        return ret
+
+
+@HEADS.register_module
+class MultiGroupHead(nn.Module):
+    """Constructor signature and parameter names of the reference head
+    (/root/reference/det3d/models/bbox_heads/mg_head.py:386-533); `forward` is on the hot path of
+    config 1, the anchor loss / target assignment / NMS are out of scope."""
+
+    def __init__(self, mode="3d", in_channels=[128, ], norm_cfg=None, tasks=[], weights=[], num_classes=[1, ],
+                 box_coder=None, with_cls=True, with_reg=True, reg_class_agnostic=False, encode_background_as_zeros=True,
+                 loss_norm=None, loss_cls=None, use_sigmoid_score=True, loss_bbox=None, encode_rad_error_by_sin=True,
+                 loss_aux=None, direction_offset=0.0, name="rpn", logger=None):
+        super().__init__()
+        assert with_cls or with_reg
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.num_anchor_per_locs = [2 * n for n in num_classes]
+        self.box_coder = box_coder
+        code_size = box_coder["code_size"] if isinstance(box_coder, dict) else box_coder.code_size
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.encode_background_as_zeros = encode_background_as_zeros
+        self.use_sigmoid_score = use_sigmoid_score
+        self.box_n_dim = code_size
+        self.use_direction_classifier = loss_aux is not None
+        self.direction_offset = direction_offset
+        self.bev_only = mode == "bev"
+        self.tasks = nn.ModuleList()
+        for num_c, num_a in zip(num_classes, self.num_anchor_per_locs):
+            num_cls = num_a * num_c if encode_background_as_zeros else num_a * (num_c + 1)
+            num_pred = num_a * (code_size - 2) if self.bev_only else num_a * code_size
+            self.tasks.append(Head(in_channels, num_pred, num_cls, use_dir=self.use_direction_classifier,
+                                   num_dir=num_a * 2 if self.use_direction_classifier else None, header=False))
+
+    def forward(self, x):
+        return [task(x) for task in self.tasks]
+
+    def loss(self, example, preds_dicts, **kwargs):
+        raise NotImplementedError("MultiGroupHead.loss (anchor targets / box coders) is out of scope of the hot path")
+
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        raise NotImplementedError("MultiGroupHead.predict (anchor decode + NMS) is out of scope of the hot path")

@@ -38,6 +38,19 @@ def s2d_student():
                 neck=_neck("S2D_RPN"), bbox_head=_head())
 
 
+def second_voxelnet():
+    """configs/waymo/voxelnet/waymo_second_3x_interval_5.py:58-104 (BASELINE config 1); loss dictionaries of the
+    anchor head are omitted (forward only)."""
+    parts = second_voxelnet_parts()
+    return dict(type="VoxelNet", pretrained=None, **parts,
+                bbox_head=dict(type="MultiGroupHead", mode="3d", in_channels=sum([128, ]), tasks=TASKS, weights=[1, ],
+                               box_coder=dict(type="ground_box3d_coder", n_dim=7, linear_dim=False,
+                                              encode_angle_vector=False, code_size=7),
+                               encode_background_as_zeros=True, use_sigmoid_score=True, encode_rad_error_by_sin=True,
+                               loss_aux=dict(type="WeightedSoftmaxClassificationLoss", name="direction_classifier",
+                                             loss_weight=0.2), direction_offset=0.0))
+
+
 def second_voxelnet_parts():
     return dict(reader=dict(type="VoxelFeatureExtractorV3", num_input_features=5),
                 backbone=dict(type="SpMiddleFHD", num_input_features=5, ds_factor=8),

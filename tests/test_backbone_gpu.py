@@ -175,3 +175,29 @@ def test_bf16_mode_within_stated_tolerance():
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     finally:
         H.set_sparse_compute_dtype("f32")
+
+
+def test_second_config1_forward_vs_cpu_reference_path():
+    """BASELINE config 1: SECOND voxelnet on the 8k-pt cloud, batch 1 — HIP path vs the CPU reference
+    path (C voxelizer + oracle SpMiddleFHD + the same torch RPN / MultiGroupHead forward on CPU)."""
+    import copy
+    from sparse2dense_amd.data import SyntheticFrames
+    frames = SyntheticFrames(1, n_points=8000, seed=7)
+    ex = frames.example()
+    model = fill_params(build_detector(waymo_configs.second_voxelnet())).eval()
+    ref_bb = R.RefSpMiddleFHD(5)
+    ref_bb.load_state_dict(model.backbone.state_dict())
+    ref_bb.double().eval()
+    neck, head = copy.deepcopy(model.neck).double().eval(), copy.deepcopy(model.bbox_head).double().eval()
+    pts = frames.points[0].cpu().numpy()
+    v, c, n = OV.points_to_voxel(pts, scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
+    coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    with torch.no_grad():
+        bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double(), coors, 1, np.array([1504, 1504, 40]))
+        ref = head(neck(bev))[0]
+        out = model.to(DEV)(ex, return_loss=False, raw_preds=True)[0]
+    assert out["box_preds"].shape == (1, 188, 188, 42) and out["cls_preds"].shape == (1, 188, 188, 18)
+    assert out["dir_cls_preds"].shape == (1, 188, 188, 12)
+    for k in ["box_preds", "cls_preds", "dir_cls_preds"]:
+        err = ((out[k].cpu().double() - ref[k]).norm() / ref[k].norm()).item()
+        assert err <= 2e-3, (k, err)

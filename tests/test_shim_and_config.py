@@ -78,6 +78,12 @@ def test_second_config_file_imports_and_backbone_builds():
     assert "middle_conv.0.weight" in bb.state_dict() and "extra_conv.1.running_var" in bb.state_dict()
     neck = build_neck(cfg.S_model.neck)
     assert type(neck).__name__ == "RPN"
+    from det3d.models import build_detector
+    det = build_detector(cfg.S_model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    sd = det.state_dict()
+    assert tuple(sd["bbox_head.tasks.0.conv_box.weight"].shape) == (42, 128, 1, 1)     # 6 anchors x 7 (mg_head.py:460-478)
+    assert tuple(sd["bbox_head.tasks.0.conv_cls.weight"].shape) == (18, 128, 1, 1)
+    assert tuple(sd["bbox_head.tasks.0.conv_dir.weight"].shape) == (12, 128, 1, 1)
 
 
 @need_ref
