@@ -33,6 +33,7 @@ import torch.distributed as dist
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
+RULEBOOK_STATS = None
 
 
 def parse():
@@ -119,14 +120,27 @@ def roofline_pass(step, n_steps=3):
     torch.cuda.synchronize()
     recs, H.PROFILE = H.PROFILE, None
     agg = {}
+    rb = dict(ms=0.0, n=0, bytes=0.0)
     for r in recs:
+        ms = r["start"].elapsed_time(r["end"])
+        pairs = float(r["pairs"].sum().item()) if r["pairs"] is not None else 0.0
+        if r["kernel"] == "rulebook_subm":   # 16 N + 8 R + 4 K bytes
+            rb["ms"] += ms; rb["n"] += 1
+            rb["bytes"] += 16.0 * r["n_out"] + 8.0 * pairs + 4.0 * r["kvol"]
+            continue
         key = (r["kernel"], r["cin"], r["cout"], r["n_out"])
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
-        a["ms"] += r["start"].elapsed_time(r["end"])
+        a["ms"] += ms
         a["n"] += 1
-        pairs = float(r["pairs"].sum().item()) if r["pairs"] is not None else 0.0
         a["flops"] += 2.0 * pairs * r["cin"] * r["cout"]
         a["bytes"] += 4.0 * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + 4.0 * r["kvol"] * r["cin"] * r["cout"]
+    global RULEBOOK_STATS
+    RULEBOOK_STATS = None
+    if rb["n"]:
+        gbs = rb["bytes"] / (rb["ms"] * 1e-3) / 1e9
+        RULEBOOK_STATS = dict(kernel="s2d_rulebook_subm_build (6 launches: set, scan x3, perm, probe)", builds_per_step=rb["n"] // n_steps,
+                              avg_us=round(rb["ms"] / rb["n"] * 1e3, 1), algorithmic_gbs=round(gbs, 1),
+                              frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4))
     if not agg:
         return None, []
     rows = []
@@ -330,6 +344,8 @@ def main():
                        "loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": base,
         }
+        if RULEBOOK_STATS:
+            out["config"]["rulebook_stage"] = RULEBOOK_STATS
         if rows:
             out["config"]["spconv_kernels"] = [
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]

@@ -196,6 +196,11 @@ int s2d_convt3d_k4s2p1_fwd_f32(const float *in, const float *weight, const float
                                s2d_stream_t stream);
 int s2d_convt3d_k4s2p1_dgrad_f32(const float *dout, const float *weight, int batch, int cin,
                                  int cout, int d, int h, int w, float *din, s2d_stream_t stream);
+/* weight gradient [cin][cout][4][4][4] (cin, cout <= 32), fp32 matrix cores, deterministic */
+size_t s2d_convt3d_k4s2p1_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w);
+int s2d_convt3d_k4s2p1_wgrad_f32(const float *in, const float *dout, int batch, int cin, int cout,
+                                 int d, int h, int w, float *dweight, void *ws, size_t ws_bytes,
+                                 s2d_stream_t stream);
 
 /*
  * Channel-major batch norm (nn.BatchNorm3d / BatchNorm2d on NC[D]HW fp32 with few channels and

@@ -64,6 +64,10 @@ SIGNATURES = {
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_dgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_convt3d_k4s2p1_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "s2d_convt3d_k4s2p1_wgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                                    ctypes.c_void_p]),
     "s2d_bncm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "s2d_bncm_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p]),

@@ -14,7 +14,8 @@
 //                             wave-uniform.
 //   convt3d_dgrad_kernel<CI>  din[ci][h] = sum_co sum_{k in 4^3} dout[co][2h-1+k] * W[ci][co][k]
 //                             thread = one input cell, float4 loads of the 4 x-taps.
-// Weight gradients are plain GEMMs over the position axis and go through hipBLASLt (torch.matmul).
+//   convt3d_wgrad_kernel      LDS-staged rows contracted on the fp32 matrix cores (see below).
+// The 1x1x1 weight gradients are plain GEMMs over the position axis (hipBLASLt via torch.matmul).
 #include "s2d_common.h"
 
 namespace s2d {
@@ -188,6 +189,130 @@ __global__ __launch_bounds__(256) void convt3d_dgrad_kernel(const float *__restr
         if (ci0 + c < cin) dst[(int64_t)(ci0 + c) * cells] = acc[c];
 }
 
+// ---- ConvTranspose3d k4s2p1 weight gradient ------------------------------------------------------
+// dW[ci][co][kz][ky][kx] = sum_{n,h} x[n][ci][h] * dout[n][co][2h-1+k].  grid (row chunks, 16 (kz,ky) pairs);
+// a block walks input rows (n, hz, hy), stages x[ci][0..W) and dout[co][2hz-1+kz][2hy-1+ky][-1..2W]
+// in LDS with coalesced row loads, and contracts over the row's cells on the fp32 matrix cores
+// (A[i=ci][k=cell], B[k=cell][j=co] at stride 2, one accumulator set per kx).  Waves split the
+// cells; partial[chunk][ci][co][kz][ky][kx] is reduced by wgrad_reduce (fixed order).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CIT, int COT>  // number of 16-wide ci / co tiles (channels are zero padded in LDS)
+__global__ __launch_bounds__(256) void convt3d_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+                                                            Dims3 s, int batch, int cin, int cout, int rows_per_block,
+                                                            float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int W = s.w, W2 = 2 * s.w + 2;           // dout tile holds positions -1 .. 2W
+    const int xs_stride = W + 1, ds_stride = W2 + 1;   // +1: break power-of-two row strides
+    float *xs = lds;                                 // [CIT*16][xs_stride]
+    float *ds = lds + CIT * 16 * xs_stride;          // [COT*16][ds_stride]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int kz = blockIdx.y >> 2, ky = blockIdx.y & 3;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t total_rows = (int64_t)batch * s.d * s.h;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < total_rows ? r0 + rows_per_block : total_rows;
+
+    f32x4_t acc[CIT][COT][4];
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+        for (int b = 0; b < COT; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[a][b][k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t row = r0; row < r1; ++row) {
+        const int hy = (int)(row % s.h);
+        const int hz = (int)((row / s.h) % s.d);
+        const int n = (int)(row / ((int64_t)s.h * s.d));
+        const int z = 2 * hz - 1 + kz, y = 2 * hy - 1 + ky;
+        if ((unsigned)z >= (unsigned)od || (unsigned)y >= (unsigned)oh) continue;   // block-uniform
+        __syncthreads();   // previous row fully consumed
+        for (int e = threadIdx.x; e < CIT * 16 * W; e += 256) {
+            const int ci = e / W, c = e - ci * W;
+            xs[ci * xs_stride + c] = ci < cin ? x[(((int64_t)n * cin + ci) * s.d + hz) * s.h * (int64_t)W + (int64_t)hy * W + c] : 0.f;
+        }
+        for (int e = threadIdx.x; e < COT * 16 * W2; e += 256) {
+            const int co = e / W2, p = e - co * W2;       // p = position + 1
+            const int pos = p - 1;
+            float v = 0.f;
+            if (co < cout && (unsigned)pos < (unsigned)ow)
+                v = dout[((((int64_t)n * cout + co) * od + z) * oh + y) * (int64_t)ow + pos];
+            ds[co * ds_stride + p] = v;
+        }
+        __syncthreads();
+        for (int c0 = 4 * wid; c0 < W; c0 += 16) {   // 4 cells per MFMA k-step, waves interleaved
+            const int cell = c0 + q;
+            float av[CIT], bv[COT][4];
+#pragma unroll
+            for (int a = 0; a < CIT; ++a) av[a] = cell < W ? xs[(a * 16 + i16) * xs_stride + cell] : 0.f;
+#pragma unroll
+            for (int b = 0; b < COT; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bv[b][k] = cell < W ? ds[(b * 16 + i16) * ds_stride + 2 * cell + k] : 0.f;   // pos+1 = 2c-1+k+1
+#pragma unroll
+            for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                for (int b = 0; b < COT; ++b)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[a][b][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b][k], acc[a][b][k], 0, 0, 0);
+        }
+    }
+    // cross-wave reduction through LDS, then one partial slab per block
+    __syncthreads();
+    float *red = lds;   // [4 waves][CIT*COT*4 tiles][256]
+    constexpr int TILES = CIT * COT * 4;
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+        for (int b = 0; b < COT; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    red[((wid * TILES + (a * COT + b) * 4 + k) * 4 + reg) * 64 + lane] = acc[a][b][k][reg];
+    __syncthreads();
+    float *dst = partial + (int64_t)blockIdx.x * cin * cout * 64;
+    for (int e = threadIdx.x; e < TILES * 256; e += 256) {
+        const int t = e / 256, rl = e % 256, reg = rl / 64, ln = rl % 64;
+        const float v = (red[((0 * TILES + t) * 4 + reg) * 64 + ln] + red[((1 * TILES + t) * 4 + reg) * 64 + ln]) +
+                        (red[((2 * TILES + t) * 4 + reg) * 64 + ln] + red[((3 * TILES + t) * 4 + reg) * 64 + ln]);
+        const int k = t % 4, b = (t / 4) % COT, a = t / (4 * COT);
+        const int ci = a * 16 + 4 * (ln >> 4) + reg, co = b * 16 + (ln & 15);   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+        if (ci < cin && co < cout) dst[(((int64_t)ci * cout + co) * 4 + kz) * 16 + ky * 4 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ partial, int n_slabs, int64_t size,
+                                                          float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    float sum = 0.f;
+    for (int sidx = 0; sidx < n_slabs; ++sidx) sum += partial[(int64_t)sidx * size + i];
+    out[i] = sum;
+}
+
+struct CtWgradPlan {
+    int blocks_x, rows_per_block, cit, cot;
+    size_t lds, ws_bytes;
+};
+static CtWgradPlan ct_wgrad_plan(int batch, int cin, int cout, int d, int h, int w) {
+    CtWgradPlan p;
+    p.cit = (cin + 15) / 16;
+    p.cot = (cout + 15) / 16;
+    const int64_t rows = (int64_t)batch * d * h;
+    int64_t bx = rows < 128 ? rows : 128;
+    p.blocks_x = (int)bx;
+    p.rows_per_block = (int)ceil_div(rows, bx);
+    const size_t stage = ((size_t)p.cit * 16 * (w + 1) + (size_t)p.cot * 16 * (2 * w + 3)) * sizeof(float);
+    const size_t red = (size_t)4 * p.cit * p.cot * 4 * 256 * sizeof(float);
+    p.lds = stage > red ? stage : red;
+    p.ws_bytes = align_up((size_t)p.blocks_x * cin * cout * 64 * sizeof(float), 256);
+    return p;
+}
+
 static int pick_tile(int c) { return c >= 16 ? 16 : (c >= 8 ? 8 : (c >= 4 ? 4 : (c == 3 ? 3 : (c == 2 ? 2 : 1)))); }
 
 }  // namespace s2d
@@ -264,6 +389,49 @@ extern "C" int s2d_convt3d_k4s2p1_dgrad_f32(const float *dout, const float *weig
         default: S2D_CD(1); break;
     }
 #undef S2D_CD
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" size_t s2d_convt3d_k4s2p1_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w) {
+    if (batch <= 0 || cin <= 0 || cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+    return ct_wgrad_plan(batch, cin, cout, d, h, w).ws_bytes;
+}
+
+extern "C" int s2d_convt3d_k4s2p1_wgrad_f32(const float *in, const float *dout, int batch, int cin, int cout, int d, int h,
+                                            int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && dout && dweight && batch > 0 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, "convt3d_wgrad: bad argument");
+    if (cin > 32 || cout > 32) {
+        set_error("convt3d_wgrad: channel counts above 32 unsupported (%d -> %d)", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    CtWgradPlan p = ct_wgrad_plan(batch, cin, cout, d, h, w);
+    if (p.lds > 160 * 1024) {
+        set_error("convt3d_wgrad: row of %d cells does not fit the LDS staging (%zu bytes)", w, p.lds);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("convt3d_wgrad: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    Dims3 s{d, h, w};
+    float *partial = (float *)ws;
+    S2D_HIP(hipMemsetAsync(partial, 0, p.ws_bytes, st));   // (kz,ky) blocks whose rows are all out of range write nothing
+    const dim3 grid(p.blocks_x, 16), blk(256);
+#define S2D_CW(A, B)                                                                                          \
+    do {                                                                                                      \
+        auto kern = convt3d_wgrad_kernel<A, B>;                                                               \
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); \
+        hipLaunchKernelGGL(kern, grid, blk, p.lds, st, in, dout, s, batch, cin, cout, p.rows_per_block, partial); \
+    } while (0)
+    if (p.cit == 1 && p.cot == 1) S2D_CW(1, 1);
+    else if (p.cit == 1 && p.cot == 2) S2D_CW(1, 2);
+    else if (p.cit == 2 && p.cot == 1) S2D_CW(2, 1);
+    else S2D_CW(2, 2);
+#undef S2D_CW
+    const int64_t size = (int64_t)cin * cout * 64;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, p.blocks_x, size, dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

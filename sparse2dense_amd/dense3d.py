@@ -91,15 +91,20 @@ class _ConvT3dFn(torch.autograd.Function):
             check(lib.s2d_convt3d_k4s2p1_dgrad_f32(_ptr(dout), _ptr(weight), n, cin, cout, d, h, w, _ptr(dx), _stream()),
                   "s2d_convt3d_k4s2p1_dgrad_f32")
         if ctx.needs_input_grad[1]:
-            # dW[ci][co][k] = sum_{n,h} x[n,ci,h] * dout[n,co,2h-1+k]: 64 plain GEMMs over the positions
-            dp = F.pad(dout, (1, 1, 1, 1, 1, 1))
-            xf = x.reshape(n, cin, -1)
             dw = torch.empty_like(weight)
-            for kz in range(4):
-                for ky in range(4):
-                    for kx in range(4):
-                        sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
-                        dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
+            if cin <= 32 and cout <= 32:
+                ws = torch.empty(max(lib.s2d_convt3d_k4s2p1_wgrad_workspace_bytes(n, cin, cout, d, h, w), 256),
+                                 dtype=torch.uint8, device=x.device)
+                check(lib.s2d_convt3d_k4s2p1_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws),
+                                                       ws.numel(), _stream()), "s2d_convt3d_k4s2p1_wgrad_f32")
+            else:   # wide layers: 64 plain GEMMs over the positions (hipBLASLt)
+                dp = F.pad(dout, (1, 1, 1, 1, 1, 1))
+                xf = x.reshape(n, cin, -1)
+                for kz in range(4):
+                    for ky in range(4):
+                        for kx in range(4):
+                            sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
+                            dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(dim=(0, 2, 3, 4))
         return dx, dw, db

@@ -114,8 +114,16 @@ def build_subm_rulebook(coors: torch.Tensor, batch: int, shape, ksize, dilation=
     nbr = torch.empty((kvol, n), dtype=torch.int32, device=dev)
     cnt = torch.empty((kvol,), dtype=torch.int32, device=dev)
     ws = _ws(lib.s2d_rulebook_workspace_bytes(batch, i3(shape), n), dev)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="rulebook_subm", tag="rulebook", cin=0, cout=0, n_out=int(n), kvol=kvol, pairs=cnt,
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_rulebook_subm_build(_ptr(coors), n, batch, i3(shape), i3(ksize), i3(dilation), _ptr(nbr), _ptr(cnt),
                                       _ptr(ws), ws.numel(), _stream()), "s2d_rulebook_subm_build")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
     return Rulebook(True, kvol, n, n, nbr, None, cnt, None, tuple(int(s) for s in shape))
 
 
@@ -216,7 +224,8 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
     return out
 
 
-def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol: int) -> torch.Tensor:
+def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol: int,
+                 pair_count: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[k] = sum_o feat[nbr[k][o]]^T dout[o]  ->  f32[K,Cin,Cout]."""
     lib = _lib.load()
     _need_gpu(feat, dout, nbr)
@@ -229,9 +238,19 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol
     cin = feat.shape[1]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
     ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
-    fn = lib.s2d_spconv_wgrad_bf16 if SPARSE_COMPUTE_DTYPE == "bf16" else lib.s2d_spconv_wgrad_f32
+    bf = SPARSE_COMPUTE_DTYPE == "bf16"
+    fn = lib.s2d_spconv_wgrad_bf16 if bf else lib.s2d_spconv_wgrad_f32
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="spconv_wgrad_bf16" if (bf and cin % 16 == 0 and cout % 16 == 0) else "spconv_wgrad_mfma",
+                   tag="wgrad", cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(fn(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw), _ptr(ws), ws.numel(),
              _stream()), "s2d_spconv_wgrad")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
     return dw if cin == cin_true else dw[:, :cin_true].contiguous()
 
 

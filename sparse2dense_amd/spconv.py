@@ -92,7 +92,7 @@ class _SparseConvFn(torch.autograd.Function):
                 wt = w.transpose(1, 2).contiguous()
                 dfeat = H.spconv_gather_gemm(dout, wt, None, rb.nbr_in, rb.n_in, rb.pair_count, "dgrad")
         if ctx.needs_input_grad[1]:
-            dw = H.spconv_wgrad(feat, dout, rb.nbr_out, rb.kvol).view_as(weight)
+            dw = H.spconv_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0)
         return dfeat, dw, db, None

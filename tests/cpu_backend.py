@@ -63,7 +63,7 @@ def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag=
     return out + bias if bias is not None else out
 
 
-def spconv_wgrad(feat, dout, nbr, kvol):
+def spconv_wgrad(feat, dout, nbr, kvol, pair_count=None):
     dw = feat.new_zeros((kvol, feat.shape[1], dout.shape[1]))
     for k in range(kvol):
         o = (nbr[k] >= 0).nonzero().squeeze(1)
