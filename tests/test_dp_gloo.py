@@ -25,12 +25,12 @@ def _voxels(seed):
     return torch.from_numpy(OV.voxel_mean(v, n)).double(), c
 
 
-def _build():
+def _build(monkeypatch=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_backend
     from golden_util import fill_params
     from sparse2dense_amd.registry import build_backbone
-    cpu_backend.install()
+    cpu_backend.install(monkeypatch)   # worker processes patch globally; the pytest process via monkeypatch
     return fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).double().train()
 
 
@@ -64,14 +64,14 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_equals_single_process_batch():
+def test_two_rank_dp_equals_single_process_batch(monkeypatch):
     port = 29500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "rank0.pt"))
         r1 = torch.load(os.path.join(d, "rank1.pt"))
     # single process, both frames in one batch
-    net = _build()
+    net = _build(monkeypatch)
     f0, c0 = _voxels(0)
     f1, c1 = _voxels(1)
     coors = np.concatenate([np.concatenate([np.zeros((c0.shape[0], 1), np.int32), c0], 1),
