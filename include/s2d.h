@@ -116,8 +116,10 @@ int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const float *weight, 
  * Supported: cin in {32,64,128}, cout in {16,32,64,128} (s2d_spconv_bf16_supported).
  */
 int s2d_spconv_bf16_supported(int cin, int cout);
-int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int cin, int cout, void *packed,
-                                 s2d_stream_t stream);
+/* (cin, cout) describe the packed operand.  transpose=1: `weight` is stored [K][cout][cin] (the
+ * data gradient multiplies by W^T); flip=1: offsets mirrored, k -> K-1-k (SubM transposed map). */
+int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int cin, int cout, int transpose,
+                                 int flip, void *packed, s2d_stream_t stream);
 int s2d_spconv_fwd_bf16(const float *in_feat, int64_t n_in, const void *packed_weight,
                         const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
                         int cout, float *out_feat, s2d_stream_t stream);
@@ -155,6 +157,18 @@ int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *sums_global,
                               const float *gamma, const float *mean, const float *invstd, int c,
                               float *dgamma, float *dbeta, float *a, float *b, float *d,
                               s2d_stream_t stream);
+/* single-GPU fusions of {stats, finalize_fwd} and {bwd_reduce, finalize_bwd}: two launches each,
+ * no intermediate [2C] vector on the host side (the multi-rank path keeps the split entries so the
+ * sums can be all-reduced in between). */
+int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, const float *gamma,
+                                const float *beta, float eps, float momentum, float *mean,
+                                float *invstd, float *scale, float *shift, float *running_mean,
+                                float *running_var, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bn1d_bwd_reduce_finalize_f32(const float *dy, const float *y, const float *x, int relu,
+                                     int64_t n, int c, const float *gamma, const float *mean,
+                                     const float *invstd, float *g_out, float *dgamma, float *dbeta,
+                                     float *a, float *b, float *d, void *ws, size_t ws_bytes,
+                                     s2d_stream_t stream);
 /* y = relu?( (x - mean) * invstd * gamma + beta (+ residual) ); scale/shift precomputed [C] */
 int s2d_bn1d_apply_f32(const float *x, const float *scale, const float *shift,
                        const float *residual, int relu, int64_t n, int c, float *y,

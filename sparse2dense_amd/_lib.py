@@ -34,8 +34,8 @@ SIGNATURES = {
     "s2d_spconv_fwd_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_spconv_bf16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    "s2d_spconv_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                    ctypes.c_void_p]),
+    "s2d_spconv_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_spconv_fwd_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, ctypes.c_int64,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_spconv_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -52,6 +52,12 @@ SIGNATURES = {
                                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_bn1d_finalize_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p,
                                                  c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_bn1d_stats_finalize_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
+                                                   ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bn1d_bwd_reduce_finalize_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                                        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                        c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bn1d_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                           c_f32p, ctypes.c_void_p]),
     "s2d_bn1d_bwd_reduce_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,

@@ -279,6 +279,78 @@ static CmPlan cm_plan(int n, int c, int64_t p4) {
     return pl;
 }
 
+
+// ---- single-GPU fast path: reduction of the per-block partials fused with the finalisation ------
+// one wave per channel: lanes stride over the partials of (sum, sumsq) resp. (sum g, sum g*x).
+__global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float *__restrict__ partial, int nblocks, float n,
+                                                                     const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta, float eps, float momentum,
+                                                                     int c, float *__restrict__ mean_out,
+                                                                     float *__restrict__ invstd_out, float *__restrict__ scale,
+                                                                     float *__restrict__ shift, float *__restrict__ running_mean,
+                                                                     float *__restrict__ running_var) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= c) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = lane; b < nblocks; b += 64) {
+        s0 += partial[(size_t)b * 2 * c + i];
+        s1 += partial[(size_t)b * 2 * c + c + i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    if (lane != 0) return;
+    const float mean = s0 / n;
+    float var = s1 / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = rsqrtf(var + eps);
+    const float sc = gamma[i] * invstd;
+    mean_out[i] = mean;
+    invstd_out[i] = invstd;
+    scale[i] = sc;
+    shift[i] = beta[i] - mean * sc;
+    if (running_mean) {
+        const float unbiased = var * (n / fmaxf(n - 1.f, 1.f));
+        running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * mean;
+        running_var[i] = (1.f - momentum) * running_var[i] + momentum * unbiased;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_reduce_finalize_bwd_kernel(const float *__restrict__ partial, int nblocks, float n,
+                                                                     const float *__restrict__ gamma,
+                                                                     const float *__restrict__ mean,
+                                                                     const float *__restrict__ invstd, int c,
+                                                                     float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                     float *__restrict__ a, float *__restrict__ b,
+                                                                     float *__restrict__ d) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= c) return;
+    float sg = 0.f, sgx = 0.f;
+    for (int k = lane; k < nblocks; k += 64) {
+        sg += partial[(size_t)k * 2 * c + i];
+        sgx += partial[(size_t)k * 2 * c + c + i];
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        sg += __shfl_xor(sg, s, 64);
+        sgx += __shfl_xor(sgx, s, 64);
+    }
+    if (lane != 0) return;
+    const float m = mean[i], is = invstd[i];
+    const float dg = is * (sgx - m * sg);
+    dbeta[i] = sg;
+    dgamma[i] = dg;
+    const float av = gamma[i] * is;
+    const float bv = -(av * is) * dg / n;
+    a[i] = av;
+    b[i] = bv;
+    d[i] = -(av * sg) / n - bv * m;
+}
+
 struct RedPlan {
     int nblocks;
     int rows_per_block;
@@ -503,6 +575,50 @@ extern "C" int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const flo
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(cm_apply_kernel<true>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, dy, y, a, b,
                        d, relu, c, p4, dx);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// ---- fused single-GPU entry points (no cross-rank statistics exchange) -----------------------------
+extern "C" int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
+                                           float momentum, float *mean, float *invstd, float *scale, float *shift,
+                                           float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                           s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_stats_finalize");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n > 0 && x && gamma && beta && mean && invstd && scale && shift, "bn1d_stats_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p = red_plan(n, c);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("bn1d_stats_finalize: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(col_reduce_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, nullptr, nullptr, 0, n, c,
+                       p.rows_per_block, nullptr, (float *)ws);
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn1d_bwd_reduce_finalize_f32(const float *dy, const float *y, const float *x, int relu, int64_t n, int c,
+                                                const float *gamma, const float *mean, const float *invstd, float *g_out,
+                                                float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                                size_t ws_bytes, s2d_stream_t stream) {
+    int rc = check_c(c, "bn1d_bwd_reduce_finalize");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n > 0 && dy && x && (!relu || y) && gamma && mean && invstd && dgamma && dbeta && a && b && d,
+                  "bn1d_bwd_reduce_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p = red_plan(n, c);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("bn1d_bwd_reduce_finalize: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(col_reduce_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, dy, y, relu, n, c,
+                       p.rows_per_block, g_out, (float *)ws);
+    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+                       gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -17,7 +17,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // w[K][cin][cout] fp32 -> image[K][cout/CT][T][NT][4][16][8] bf16 with
 //   ci = 32 t + 8 q + e ,  co = y*CT + c*NT + n   (CT = 16*NT)
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__restrict__ w, int kvol, int cin, int cout,
-                                                                int nt, __bf16 *__restrict__ out) {
+                                                                int nt, int transpose, int flip, __bf16 *__restrict__ out) {
+    // (cin, cout) are the dimensions of the PACKED operand; with transpose=1 the source tensor is
+    // [K][cout][cin] (data gradient: W^T), with flip=1 offsets are mirrored (SubM transposed map).
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)kvol * cin * cout;
     if (i >= total) return;
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float *__r
     const int k = (int)r;
     const int ci = 32 * t + 8 * q + e;
     const int co = y * ct + c * nt + n;
-    out[i] = (__bf16)w[((int64_t)k * cin + ci) * cout + co];
+    const int ks = flip ? kvol - 1 - k : k;
+    const int64_t src = transpose ? ((int64_t)ks * cout + co) * cin + ci : ((int64_t)ks * cin + ci) * cout + co;
+    out[i] = (__bf16)w[src];
 }
 
 template <int BYTES>
@@ -212,8 +216,8 @@ extern "C" int s2d_spconv_bf16_supported(int cin, int cout) {
     return (cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
 }
 
-extern "C" int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int cin, int cout, void *packed,
-                                            s2d_stream_t stream) {
+extern "C" int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int cin, int cout, int transpose, int flip,
+                                            void *packed, s2d_stream_t stream) {
     S2D_CHECK_ARG(weight && packed && kvol > 0, "pack_weights_bf16: null argument");
     if (!s2d_spconv_bf16_supported(cin, cout)) {
         set_error("pack_weights_bf16: unsupported channels %d -> %d", cin, cout);
@@ -221,7 +225,7 @@ extern "C" int s2d_spconv_pack_weights_bf16(const float *weight, int kvol, int c
     }
     const int64_t total = (int64_t)kvol * cin * cout;
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, kvol, cin, cout, bf16_nt(cout), (__bf16 *)packed);
+                       weight, kvol, cin, cout, bf16_nt(cout), transpose, flip, (__bf16 *)packed);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

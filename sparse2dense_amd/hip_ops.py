@@ -185,11 +185,23 @@ def set_sparse_compute_dtype(name):
 
 
 def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optional[torch.Tensor], nbr: torch.Tensor,
-                       n_out: int, pair_count: Optional[torch.Tensor] = None, tag: str = "fwd") -> torch.Tensor:
-    """out[o] = sum_k feat[nbr[k][o]] @ weight_kio[k] (+bias).  weight_kio f32[K,Cin,Cout]."""
+                       n_out: int, pair_count: Optional[torch.Tensor] = None, tag: str = "fwd", transpose: bool = False,
+                       flip: bool = False) -> torch.Tensor:
+    """out[o] = sum_k feat[nbr[k][o]] @ W[k] (+bias), W = weight_kio f32[K,Cin,Cout].
+    transpose/flip: multiply by W[k]^T resp. W[K-1-k] instead (data gradient) — on the bf16 path this
+    is folded into the weight pre-pack, otherwise done with torch ops here."""
     lib = _lib.load()
     _need_gpu(feat, weight_kio, nbr)
-    kvol, cin, cout = weight_kio.shape
+    kvol = weight_kio.shape[0]
+    cin, cout = (weight_kio.shape[2], weight_kio.shape[1]) if transpose else (weight_kio.shape[1], weight_kio.shape[2])
+    fold = (SPARSE_COMPUTE_DTYPE == "bf16" and lib.s2d_spconv_bf16_supported(cin, cout) and feat.shape[0] > 0)
+    if (transpose or flip) and not fold:
+        if flip:
+            weight_kio = weight_kio.flip(0)
+        if transpose:
+            weight_kio = weight_kio.transpose(1, 2)
+        weight_kio = weight_kio.contiguous()
+        transpose = flip = False
     if cin % 16 and cin < 16 and cout % 16 == 0:
         # narrow input layer (5 point features): zero-pad K to one MFMA step so it rides the matrix path
         feat = torch.nn.functional.pad(feat, (0, 16 - cin))
@@ -198,7 +210,7 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
     feat = feat.contiguous()
     weight_kio = weight_kio.contiguous()
     assert feat.dtype == torch.float32 and weight_kio.dtype == torch.float32
-    assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous()
+    assert feat.shape[1] == cin and nbr.shape == (kvol, n_out) and nbr.is_contiguous(), (feat.shape, cin, nbr.shape)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feat.device)
     b = bias.contiguous() if bias is not None else None
     use_bf16 = SPARSE_COMPUTE_DTYPE == "bf16" and lib.s2d_spconv_bf16_supported(cin, cout) and feat.shape[0] > 0
@@ -211,8 +223,8 @@ def spconv_gather_gemm(feat: torch.Tensor, weight_kio: torch.Tensor, bias: Optio
         rec["start"].record()
     if use_bf16:
         packed = torch.empty((kvol * cin * cout,), dtype=torch.bfloat16, device=feat.device)
-        check(lib.s2d_spconv_pack_weights_bf16(_ptr(weight_kio), kvol, cin, cout, _ptr(packed), _stream()),
-              "s2d_spconv_pack_weights_bf16")
+        check(lib.s2d_spconv_pack_weights_bf16(_ptr(weight_kio), kvol, cin, cout, int(transpose), int(flip), _ptr(packed),
+                                               _stream()), "s2d_spconv_pack_weights_bf16")
         check(lib.s2d_spconv_fwd_bf16(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(b), _ptr(nbr), n_out, kvol, cin, cout,
                                       _ptr(out), _stream()), "s2d_spconv_fwd_bf16")
     else:
@@ -289,6 +301,36 @@ def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
                                         _ptr(invstd), c, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
                                         _ptr(out[4]), _stream()), "s2d_bn1d_finalize_bwd_f32")
     return out
+
+
+def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """single-GPU: batch statistics + finalisation in two launches -> packed f32[4,C] (mean, invstd, scale, shift)."""
+    lib = _lib.load()
+    _need_gpu(x)
+    x = x.contiguous()
+    n, c = x.shape
+    out = torch.empty((4, c), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bn1d_stats_finalize_f32(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(out[0]),
+                                          _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(running_mean), _ptr(running_var),
+                                          _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_finalize_f32")
+    return out
+
+
+def bn1d_bwd_reduce_finalize(dy, y, x, relu, gamma, mean, invstd):
+    """single-GPU: g = dy*(y>0 if relu), its sums and the finalisation -> (g, packed f32[5,C]: dgamma, dbeta, a, b, d)."""
+    lib = _lib.load()
+    dy = dy.contiguous()
+    x = x.contiguous()
+    n, c = x.shape
+    g = torch.empty_like(x)
+    out = torch.empty((5, c), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bn1d_bwd_reduce_finalize_f32(_ptr(dy), _ptr(y), _ptr(x), int(relu), n, c, _ptr(gamma), _ptr(mean),
+                                               _ptr(invstd), _ptr(g), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
+                                               _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
+          "s2d_bn1d_bwd_reduce_finalize_f32")
+    return g, out
 
 
 def bn1d_apply(x, scale, shift, residual=None, relu=False):

@@ -86,11 +86,10 @@ class _SparseConvFn(torch.autograd.Function):
         dfeat = dw = db = None
         if ctx.needs_input_grad[0]:
             if rb.subm:  # transposed map of a centred stencil = the same map with offsets mirrored
-                wt = w.flip(0).transpose(1, 2).contiguous()
-                dfeat = H.spconv_gather_gemm(dout, wt, None, rb.nbr_out, rb.n_in, rb.pair_count, "dgrad")
+                dfeat = H.spconv_gather_gemm(dout, w, None, rb.nbr_out, rb.n_in, rb.pair_count, "dgrad", transpose=True,
+                                             flip=True)
             else:
-                wt = w.transpose(1, 2).contiguous()
-                dfeat = H.spconv_gather_gemm(dout, wt, None, rb.nbr_in, rb.n_in, rb.pair_count, "dgrad")
+                dfeat = H.spconv_gather_gemm(dout, w, None, rb.nbr_in, rb.n_in, rb.pair_count, "dgrad", transpose=True)
         if ctx.needs_input_grad[1]:
             dw = H.spconv_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -186,15 +185,19 @@ class _BNTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module):
         n, c = x.shape
-        stats = H.bn1d_stats(x)
-        count = torch.full((1,), float(n), device=x.device, dtype=x.dtype)
-        if sync:
+        track = module is not None and module.track_running_stats
+        mom = module.momentum if track else 0.0
+        rm, rv = (module.running_mean, module.running_var) if track else (None, None)
+        count = None
+        if sync:   # statistics over the rows of ALL ranks: exchange [sum, sumsq, count] between the two kernels
+            stats = H.bn1d_stats(x)
+            count = torch.full((1,), float(n), device=x.device, dtype=x.dtype)
             packed = torch.cat([stats, count])
             dist.all_reduce(packed)
             stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
-        track = module is not None and module.track_running_stats
-        fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
-                                  module.running_mean if track else None, module.running_var if track else None)
+            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, mom, rm, rv)
+        else:
+            fin = H.bn1d_stats_finalize(x, gamma, beta, eps, mom, rm, rv)
         if track:
             module.num_batches_tracked += 1
         mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
@@ -206,14 +209,15 @@ class _BNTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mean, invstd, count = ctx.saved_tensors
-        g, sums = H.bn1d_bwd_reduce(dy.contiguous(), y, x, ctx.relu)
-        # parameter grads use the LOCAL sums (DDP averages them over ranks afterwards, exactly
-        # like torch.nn.SyncBatchNorm); the input grad needs the GLOBAL sums.
-        sums_all = sums
         if ctx.sync:
+            g, sums = H.bn1d_bwd_reduce(dy.contiguous(), y, x, ctx.relu)
+            # parameter grads use the LOCAL sums (DDP averages them over ranks afterwards, exactly
+            # like torch.nn.SyncBatchNorm); the input grad needs the GLOBAL sums.
             sums_all = sums.clone()
             dist.all_reduce(sums_all)
-        fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+            fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+        else:
+            g, fin = H.bn1d_bwd_reduce_finalize(dy, y, x, ctx.relu, gamma, mean, invstd)
         dx = H.bn1d_bwd_apply(g, x, fin[2], fin[3], fin[4]) if ctx.needs_input_grad[0] else None
         return dx, fin[0], fin[1], (g if ctx.has_res else None), None, None, None, None
 

@@ -54,7 +54,11 @@ def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1
                       torch.from_numpy(cnt), torch.from_numpy(oc), oshape)
 
 
-def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag="fwd"):
+def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag="fwd", transpose=False, flip=False):
+    if flip:
+        weight_kio = weight_kio.flip(0)
+    if transpose:
+        weight_kio = weight_kio.transpose(1, 2)
     out = feat.new_zeros((n_out, weight_kio.shape[2]))
     for k in range(weight_kio.shape[0]):
         o = (nbr[k] >= 0).nonzero().squeeze(1)
@@ -103,6 +107,17 @@ def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
     return torch.stack([dgamma, dbeta, a, b, d])
 
 
+def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype)
+    return bn1d_finalize_fwd(bn1d_stats(x), count, gamma, beta, eps, momentum, running_mean, running_var)
+
+
+def bn1d_bwd_reduce_finalize(dy, y, x, relu, gamma, mean, invstd):
+    g, sums = bn1d_bwd_reduce(dy, y, x, relu)
+    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype)
+    return g, bn1d_finalize_bwd(sums, sums, count, gamma, mean, invstd)
+
+
 def bn1d_apply(x, scale, shift, residual=None, relu=False):
     y = x * scale + shift
     if residual is not None:
@@ -129,7 +144,7 @@ def densify_bwd(dout, coors, batch, shape, c):
 
 
 _NAMES = ["voxelize", "voxelize_async", "build_subm_rulebook", "build_conv_rulebook", "spconv_gather_gemm", "spconv_wgrad", "bn1d_stats",
-          "bn1d_finalize_fwd", "bn1d_finalize_bwd", "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
+          "bn1d_finalize_fwd", "bn1d_finalize_bwd", "bn1d_stats_finalize", "bn1d_bwd_reduce_finalize", "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
 
 
 def install(monkeypatch=None):
