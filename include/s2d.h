@@ -234,6 +234,25 @@ int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, cons
                            const float *b, const float *d, int relu, int batch, int c,
                            int64_t positions, float *dx, s2d_stream_t stream);
 
+/*
+ * Dense 3x3 convolution, stride 1, padding 0 or 1, on NHWC bf16 activations (the BEV neck blocks
+ * and the CenterHead towers: det3d/models/necks/rpn.py:126-145, bbox_heads/center_head.py:209-232;
+ * replaces the cuDNN call behind nn.Conv2d there).  Implicit GEMM on v_mfma_f32_16x16x32_bf16,
+ * fp32 accumulate, bf16 output [N][Ho][Wo][cout].  cin and cout multiples of 64.
+ * The weight ([cout][cin][3][3] fp32, torch layout) is packed once per call into the kernel's
+ * LDS image (9*cin*cout bf16).  transpose_flip=1 packs the data-gradient operand: then (cin,cout)
+ * = (forward cout, forward cin) and the forward kernel run on dY with pad 1 yields dX (a pad-0
+ * forward first pads dY by one ring of zeros).  weight_nhwc=1: `weight` memory order is
+ * [cout][3][3][cin] (torch channels_last).  zero_page: >= 16 zero bytes of device memory
+ * (source of the border taps).
+ */
+int s2d_conv2d3x3_supported(int cin, int cout);
+int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int transpose_flip,
+                                    int weight_nhwc, void *packed, s2d_stream_t stream);
+int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias,
+                            const void *zero_page, int n_img, int h, int w, int cin, int cout,
+                            int pad, void *y, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

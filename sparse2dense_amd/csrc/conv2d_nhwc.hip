@@ -1,0 +1,221 @@
+// Dense 3x3 convolution (stride 1) for the BEV neck / head on the gfx950 matrix cores:
+// NHWC bf16 activations, bf16 weights, fp32 accumulate, bf16 output — an implicit GEMM with
+//   M = N*Ho*Wo output pixels, N = Cout, K = 9 taps x Cin.
+// (/root/reference/det3d/models/necks/rpn.py:126-145 `_make_layer`, bbox_heads/center_head.py:209-232.)
+//
+// Workgroup = 256 threads = 2(M) x 2(N) waves, tile 128 pixels x BN couts (BN = 128 or 64); each
+// wave owns 64 pixels x BN/2 couts = 4 x (BN/32) MFMA tiles of v_mfma_f32_16x16x32_bf16.  One K-step
+// = one tap x 64 input channels: the A tile (128 px x 64 ch) and the pre-packed B tile are brought
+// in with global_load_lds (16 B per lane, LDS image lane-linear = exactly the fragment order, so
+// every ds_read_b128 of a fragment is a conflict-free 1 KiB read), double buffered, one barrier
+// per K-step.  Border taps read a zero page instead of branching.  The data gradient is the same
+// kernel with the flipped / transposed weight image (conv2d_pack_weights_bf16).
+#include "s2d_common.h"
+
+namespace s2d {
+
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
+
+// weight image: [kstep = tap*(Cin/64)+chunk][co block (BN)][half h = k32 within the 64-chunk (2)][nt (BN/16)][q][c][8]
+//   ci = chunk*64 + h*32 + 8q + e ;  co = blk*BN + wn*(BN/2) + c*(BN/32) + n  with nt = wn*(BN/32) + n
+// source w[Cout][Cin][3][3] (torch layout).  transpose_flip=1 builds the data-gradient operand:
+//   packed "cin" runs over the source's Cout, packed "cout" over its Cin, taps mirrored.
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int bn,
+                                                          int transpose_flip, int w_nhwc, __bf16 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)9 * cin * cout;
+    if (i >= total) return;
+    const int ntile = bn / 16, per_wave = bn / 32;
+    int64_t r = i;
+    const int e = r % 8; r /= 8;
+    const int c = r % 16; r /= 16;
+    const int q = r % 4; r /= 4;
+    const int nt = r % ntile; r /= ntile;
+    const int h = r % 2; r /= 2;
+    const int blk = r % (cout / bn); r /= (cout / bn);
+    const int chunk = r % (cin / 64); r /= (cin / 64);
+    const int tap = (int)r;
+    const int ci = chunk * 64 + h * 32 + 8 * q + e;
+    const int co = blk * bn + (nt / per_wave) * (bn / 2) + c * per_wave + (nt % per_wave);
+    // source element (o, c, t) of the forward weight; w_nhwc: memory order [o][t][c] (torch channels_last) instead of [o][c][t]
+    const int so = transpose_flip ? ci : co, sc = transpose_flip ? co : ci, st = transpose_flip ? 8 - tap : tap;
+    const int src_c = transpose_flip ? cout : cin;
+    const float v = w_nhwc ? w[((int64_t)so * 9 + st) * src_c + sc] : w[((int64_t)so * src_c + sc) * 9 + st];
+    out[i] = (__bf16)v;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
+                                                                const float *__restrict__ bias,
+                                                                const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
+                                                                int cin, int cout, int pad, __bf16 *__restrict__ y) {
+    constexpr int NT = BN / 32;            // N tiles per wave
+    constexpr int A_BYTES = 128 * 64 * 2;  // 16 KiB: [128 px][64 ch]
+    constexpr int B_BYTES = 64 * BN * 2;   // [2][BN/16][64 lanes][8]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * A_BYTES; };
+    auto bbuf = [&](int b) -> char * { return smem + 2 * A_BYTES + b * B_BYTES; };
+
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int64_t m_total = (int64_t)n_img * Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int blk_n = blockIdx.y;
+    const int chunks = cin / 64;
+    const int ksteps = 9 * chunks;
+
+    // A staging: thread t moves 16-byte chunks t, t+256, t+512, t+768 of the [128][64ch] tile: pixel = id/8, part = id%8
+    int a_img[4], a_y[4], a_x[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int id = threadIdx.x + 256 * u;
+        const int64_t m = m0 + id / 8;
+        a_ok[u] = m < m_total;
+        const int64_t mm = a_ok[u] ? m : 0;
+        a_x[u] = (int)(mm % Wo);
+        a_y[u] = (int)((mm / Wo) % Ho);
+        a_img[u] = (int)(mm / ((int64_t)Wo * Ho));
+    }
+    const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * B_BYTES;
+    const int64_t wstep = (int64_t)(cout / BN) * B_BYTES;
+
+    auto stage = [&](int s, int buf) {
+        const int tap = s / chunks, chunk = s - tap * chunks;
+        const int dy = tap / 3 - pad, dx = tap % 3 - pad;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = threadIdx.x + 256 * u;
+            const int part = id & 7;
+            const int yy = a_y[u] + dy, xx = a_x[u] + dx;
+            const bool ok = a_ok[u] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const __bf16 *src = ok ? x + (((int64_t)a_img[u] * H + yy) * W + xx) * cin + chunk * 64 + part * 8 : zero_page;
+            // LDS destination is wave-uniform base + lane*16: chunk ids of a wave are consecutive (id = 64*w' + lane)
+            char *dst = abuf(buf) + (size_t)(id - lane) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+        constexpr int B_UNITS = B_BYTES / 1024;   // wave-instructions
+#pragma unroll
+        for (int u = 0; u < (B_UNITS + 3) / 4; ++u) {
+            const int unit = u * 4 + wid;
+            if (unit < B_UNITS) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(wsrc + (int64_t)s * wstep + unit * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4c acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < ksteps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < ksteps) stage(s + 1, cur ^ 1);
+        // A tile image: 16-byte chunk id = pixel*8 + part ; a lane's fragment for half h: pixel = 64*wm + 16*i + r, part = 4*h + q
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8c a[4], b[NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const bf16x8c *>(abuf(cur) + ((64 * wm + 16 * i + r) * 8 + 4 * h + q) * 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(cur) + ((h * (BN / 16) + wn * NT + j) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // tile s consumed by every wave; tile s+1 landed (the barrier's release drains the LDS-DMA)
+    }
+
+    // epilogue: C/D layout row = 4*(lane>>4)+reg (pixel), col = lane&15 -> couts co_base + r*NT + j  (NT consecutive)
+    const int co_base = blk_n * BN + wn * (BN / 2);
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
+            if (m < m_total) {
+                __bf16 *dst = y + m * cout + co_base + r * NT;
+                if (NT == 4) {
+                    bf16x4c v;
+                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
+                    v[2] = (__bf16)(acc[i][2 % NT][reg] + bv[2 % NT]); v[3] = (__bf16)(acc[i][3 % NT][reg] + bv[3 % NT]);
+                    *reinterpret_cast<bf16x4c *>(dst) = v;
+                } else {
+                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
+                    dst[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
+                }
+            }
+        }
+}
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" int s2d_conv2d3x3_supported(int cin, int cout) { return cin >= 64 && cin % 64 == 0 && cout >= 64 && cout % 64 == 0; }
+
+static int conv_bn(int cout) { return cout % 128 == 0 ? 128 : 64; }
+
+extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int transpose_flip, int weight_nhwc,
+                                               void *packed, s2d_stream_t stream) {
+    // (cin, cout) = dimensions of the PACKED operand; weight is torch [Cout][Cin][3][3] of the forward conv
+    S2D_CHECK_ARG(weight && packed, "conv2d_pack: null argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d_pack: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)9 * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin,
+                       cout, conv_bn(cout), transpose_flip, weight_nhwc, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
+                                       int n_img, int h, int w, int cin, int cout, int pad, void *y, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1),
+                  "conv2d3x3: bad argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d3x3: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    S2D_CHECK_ARG(ho > 0 && wo > 0, "conv2d3x3: empty output");
+    const int64_t m = (int64_t)n_img * ho * wo;
+    hipStream_t st = (hipStream_t)stream;
+    const int bn = conv_bn(cout);
+    const dim3 grid((unsigned)ceil_div(m, 128), cout / bn), blk(256);
+    if (bn == 128) {
+        const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 128 * 2);
+        auto kern = conv3x3_nhwc_bf16_kernel<128>;
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
+    } else {
+        const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 64 * 2);
+        auto kern = conv3x3_nhwc_bf16_kernel<64>;
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
+    }
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

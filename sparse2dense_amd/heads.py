@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .dense2d import Conv3x3
 from .registry import HEADS, LOSSES
 
 
@@ -123,7 +124,7 @@ class SepHead(nn.Module):
         for head, (classes, num_conv) in heads.items():
             layers = []
             for _ in range(num_conv - 1):
-                layers.append(nn.Conv2d(in_channels, head_conv, final_kernel, 1, final_kernel // 2, bias=True))
+                layers.append(Conv3x3(in_channels, head_conv, final_kernel, 1, final_kernel // 2, bias=True))
                 if bn:
                     layers.append(nn.BatchNorm2d(head_conv))
                 layers.append(nn.ReLU())
@@ -161,7 +162,7 @@ class CenterHead(nn.Module):
         self.box_n_dim = 9 if "vel" in common_heads else 7
         self.use_direction_classifier = False
         self.logger = logger or logging.getLogger("CenterHead")
-        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, 3, padding=1, bias=True),
+        self.shared_conv = nn.Sequential(Conv3x3(in_channels, share_conv_channel, 3, padding=1, bias=True),
                                          nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
         self.tasks = nn.ModuleList()
         for num_cls in num_classes:

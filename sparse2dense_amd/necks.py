@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
+from .dense2d import Conv3x3
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .registry import NECKS
 
@@ -73,10 +74,10 @@ class RPN(nn.Module):
         return factor
 
     def _make_layer(self, inplanes, planes, num_blocks, stride=1):
-        layers = [nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+        layers = [nn.ZeroPad2d(1), Conv3x3(inplanes, planes, 3, stride=stride, bias=False),
                   build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU()]
         for j in range(num_blocks):
-            layers += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), build_norm_layer(self._norm_cfg, planes)[1]]
+            layers += [Conv3x3(planes, planes, 3, padding=1, bias=False), build_norm_layer(self._norm_cfg, planes)[1]]
             if j < num_blocks - 1:  # the last conv+BN of a block has no ReLU of its own (rpn.py:142-143)
                 layers.append(nn.ReLU())
         return nn.Sequential(*layers)
