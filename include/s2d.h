@@ -253,6 +253,36 @@ int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const floa
                             const void *zero_page, int n_img, int h, int w, int cin, int cout,
                             int pad, void *y, s2d_stream_t stream);
 
+/*
+ * Row-major bf16 batch norm: nn.BatchNorm2d (+ the ReLU that follows it) on NHWC bf16 activations
+ * viewed as [n = N*H*W rows][c] (BEV neck and head: rpn.py:126-145, center_head.py:209-232;
+ * replaces the cuDNN batch-norm calls there).  c multiple of 8, <= 1024.  Statistics and all
+ * per-channel vectors are fp32 and use the same finalisation as the s2d_bn1d_* family
+ * (s2d_bn1d_finalize_fwd/bwd_f32 after an all-reduce of the split `stats` / `sums` vectors, or the
+ * fused *_finalize entries on one GPU).  The backward recomputes the ReLU mask from x, scale and
+ * shift (y > 0 <=> x*scale+shift > 0), so y is not an input.
+ */
+size_t s2d_bnrow_workspace_bytes(int64_t n, int c);
+int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
+                         s2d_stream_t stream);
+int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *gamma,
+                                  const float *beta, float eps, float momentum, float *mean,
+                                  float *invstd, float *scale, float *shift, float *running_mean,
+                                  float *running_var, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, int relu, int64_t n,
+                         int c, void *y, s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const float *scale, const float *shift,
+                              int relu, int64_t n, int c, float *sums, void *ws, size_t ws_bytes,
+                              s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const float *scale,
+                                       const float *shift, int relu, int64_t n, int c,
+                                       const float *gamma, const float *mean, const float *invstd,
+                                       float *dgamma, float *dbeta, float *a, float *b, float *d,
+                                       void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const float *scale, const float *shift,
+                             int relu, const float *a, const float *b, const float *d, int64_t n,
+                             int c, void *dx, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

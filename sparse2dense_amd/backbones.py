@@ -16,9 +16,10 @@ from torch import nn
 
 from . import hip_ops as H
 from .registry import BACKBONES, READERS
+from .dense2d import FastBatchNorm2d
 from .spconv import (FeatureBatchNorm1d, SparseConv3d, SparseConvTensor, SparseModule, SparseSequential, SubMConv3d)
 
-NORM_LAYERS = {"BN": ("bn", nn.BatchNorm2d), "BN1d": ("bn1d", FeatureBatchNorm1d), "GN": ("gn", nn.GroupNorm)}
+NORM_LAYERS = {"BN": ("bn", FastBatchNorm2d), "BN1d": ("bn1d", FeatureBatchNorm1d), "GN": ("gn", nn.GroupNorm)}
 
 
 def build_norm_layer(cfg, num_features, postfix=""):

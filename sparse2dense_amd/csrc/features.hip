@@ -378,6 +378,156 @@ static int check_c(int c, const char *who) {
     return 0;
 }
 
+// ---- row-major bf16 batch norm (BatchNorm2d on NHWC bf16 activations of the BEV neck / head) ------
+// x, y, dy, dx are [n rows = N*H*W][c] bf16; statistics, scale/shift and the reductions are fp32.
+// A thread owns 8 channels (one 16-byte access).  The ReLU mask of the backward is recomputed from
+// x (y > 0  <=>  fma(x, scale, shift) > 0), so the forward output need not be kept for it.
+typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+
+template <bool BWD>
+__global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
+                                                                      const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift, int relu, int64_t n, int c,
+                                                                      int rows_per_block, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [row_lanes][2][C]
+    const int c8 = c >> 3;
+    const int lanes = RED_THREADS / c8;
+    const int grp = threadIdx.x % c8, rl = threadIdx.x / c8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    float s0[8], s1[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s0[e] = 0.f; s1[e] = 0.f;
+        sc[e] = (BWD && relu) ? scale[grp * 8 + e] : 0.f;
+        sh[e] = (BWD && relu) ? shift[grp * 8 + e] : 0.f;
+    }
+    if (rl < lanes) {
+        for (int64_t r = r0 + rl; r < r1; r += lanes) {
+            const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x + r * c)[grp];
+            if (BWD) {
+                const bf16x8r gv = reinterpret_cast<const bf16x8r *>(dy + r * c)[grp];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)xv[e];
+                    float g = (float)gv[e];
+                    if (relu) g = fmaf(xf, sc[e], sh[e]) > 0.f ? g : 0.f;
+                    s0[e] += g;
+                    s1[e] += g * xf;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)xv[e];
+                    s0[e] += xf;
+                    s1[e] += xf * xf;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lds[(size_t)rl * 2 * c + grp * 8 + e] = s0[e];
+            lds[(size_t)rl * 2 * c + c + grp * 8 + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * c; e += RED_THREADS) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += lds[(size_t)l * 2 * c + e];
+        partial[(size_t)blockIdx.x * 2 * c + e] = s;
+    }
+}
+
+// apply kernels: blockDim.x = lanes*c8 (a multiple of c8), thread -> (row lane, 8-channel group); the per-channel constants
+// live in registers, rows are strided over the grid.
+__global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int relu, int64_t n, int c8,
+                                                             __bf16 *__restrict__ y) {
+    const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale[g * 8 + e];
+        sh[e] = shift[g * 8 + e];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n; r += (int64_t)gridDim.x * lanes) {
+        const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
+        bf16x8r o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = fmaf((float)xv[e], sc[e], sh[e]);
+            if (relu) v = fmaxf(v, 0.f);
+            o[e] = (__bf16)v;
+        }
+        reinterpret_cast<bf16x8r *>(y)[r * c8 + g] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ x,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 int relu, const float *__restrict__ a, const float *__restrict__ b,
+                                                                 const float *__restrict__ d, int64_t n, int c8,
+                                                                 __bf16 *__restrict__ dx) {
+    const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
+    float sc[8], sh[8], av[8], bv[8], dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = g * 8 + e;
+        sc[e] = relu ? scale[ch] : 0.f;
+        sh[e] = relu ? shift[ch] : 0.f;
+        av[e] = a[ch];
+        bv[e] = b[ch];
+        dv[e] = d[ch];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n; r += (int64_t)gridDim.x * lanes) {
+        const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
+        const bf16x8r gv = reinterpret_cast<const bf16x8r *>(dy)[r * c8 + g];
+        bf16x8r o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xf = (float)xv[e];
+            float gg = (float)gv[e];
+            if (relu) gg = fmaf(xf, sc[e], sh[e]) > 0.f ? gg : 0.f;
+            o[e] = (__bf16)fmaf(av[e], gg, fmaf(bv[e], xf, dv[e]));
+        }
+        reinterpret_cast<bf16x8r *>(dx)[r * c8 + g] = o;
+    }
+}
+
+struct RowLaunch {
+    unsigned blocks, threads;
+};
+static RowLaunch row_launch(int64_t n, int c8) {
+    const int lanes = 256 / c8 > 0 ? 256 / c8 : 1;
+    RowLaunch l;
+    l.threads = (unsigned)(lanes * c8);
+    int64_t blocks = ceil_div(n, (int64_t)lanes * 4);   // ~4 rows per thread
+    if (blocks > 16384) blocks = 16384;
+    l.blocks = (unsigned)blocks;
+    return l;
+}
+
+static RedPlan row_plan_bf16(int64_t n, int c) {
+    RedPlan p;
+    const int c8 = c / 8;
+    const int lanes = RED_THREADS / c8 > 0 ? RED_THREADS / c8 : 1;
+    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * 8);
+    if (nb > 2048) nb = 2048;
+    p.nblocks = (int)nb;
+    p.rows_per_block = (int)ceil_div(n > 0 ? n : 1, nb);
+    p.lds = (size_t)lanes * 2 * c * sizeof(float);
+    p.ws_bytes = align_up((size_t)nb * 2 * c * sizeof(float), 256);
+    return p;
+}
+
+static int check_c8(int c, const char *who) {
+    if (c <= 0 || (c & 7) || c > 1024) {
+        set_error("%s: channel count %d must be a positive multiple of 8 (<=1024)", who, c);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
 }  // namespace s2d
 
 using namespace s2d;
@@ -619,6 +769,114 @@ extern "C" int s2d_bn1d_bwd_reduce_finalize_f32(const float *dy, const float *y,
                        p.rows_per_block, g_out, (float *)ws);
     hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// ---- row-major bf16 batch norm entry points ---------------------------------------------------------
+extern "C" size_t s2d_bnrow_workspace_bytes(int64_t n, int c) {
+    if (n < 0 || c <= 0 || (c & 7) || c > 1024) return 0;
+    return row_plan_bf16(n, c).ws_bytes;
+}
+
+// fwd=1: x -> (sum x, sum x^2); fwd=0: (dy, x, scale, shift, relu) -> (sum g, sum g*x).  out: [2c] sums when
+// fin == nullptr-style split mode is wanted (stats != nullptr), else fused finalisation.
+static int bnrow_reduce(bool bwd, const void *x, const void *dy, const float *scale, const float *shift, int relu, int64_t n,
+                        int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who) {
+    int rc = check_c8(c, who);
+    if (rc) return rc;
+    S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || (scale && shift)), "bnrow reduce: bad argument");
+    RedPlan p = row_plan_bf16(n, c);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    if (bwd)
+        hipLaunchKernelGGL(row_reduce_bf16_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
+                           (const __bf16 *)dy, scale, shift, relu, n, c, p.rows_per_block, (float *)ws);
+    else
+        hipLaunchKernelGGL(row_reduce_bf16_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
+                           (const __bf16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, n, c, p.rows_per_block,
+                           (float *)ws);
+    *plan_out = p;
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
+                                    s2d_stream_t stream) {
+    S2D_CHECK_ARG(stats, "bnrow_stats: null stats");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p;
+    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, stats);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
+                                             float momentum, float *mean, float *invstd, float *scale, float *shift,
+                                             float *running_mean, float *running_var, void *ws, size_t ws_bytes,
+                                             s2d_stream_t stream) {
+    S2D_CHECK_ARG(gamma && beta && mean && invstd && scale && shift, "bnrow_stats_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p;
+    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats_finalize");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, int relu, int64_t n, int c, void *y,
+                                    s2d_stream_t stream) {
+    int rc = check_c8(c, "bnrow_apply");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n > 0 && x && y && scale && shift, "bnrow_apply: bad argument");
+    const RowLaunch l = row_launch(n, c / 8);
+    hipLaunchKernelGGL(row_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, scale,
+                       shift, relu, n, c / 8, (__bf16 *)y);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
+                                         int64_t n, int c, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(sums, "bnrow_bwd_reduce: null sums");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p;
+    int rc = bnrow_reduce(true, x, dy, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
+                                                  int64_t n, int c, const float *gamma, const float *mean, const float *invstd,
+                                                  float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                                  size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(gamma && mean && invstd && dgamma && dbeta && a && b && d, "bnrow_bwd_reduce_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    RedPlan p;
+    int rc = bnrow_reduce(true, x, dy, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+                       gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
+                                        const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
+                                        s2d_stream_t stream) {
+    int rc = check_c8(c, "bnrow_bwd_apply");
+    if (rc) return rc;
+    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || (scale && shift)), "bnrow_bwd_apply: bad argument");
+    const RowLaunch l = row_launch(n, c / 8);
+    hipLaunchKernelGGL(row_bwd_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)dy,
+                       (const __bf16 *)x, scale, shift, relu, a, b, d, n, c / 8, (__bf16 *)dx);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

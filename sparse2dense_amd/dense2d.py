@@ -121,3 +121,147 @@ class Conv3x3(nn.Conv2d):
         if self._hip_ok(x):
             return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0])
         return super().forward(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
+# --------------------------------------------------------------------------------------------------
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _dist_sync():
+    import torch.distributed as dist
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
+
+
+class _BNRowFn(torch.autograd.Function):
+    """x: bf16 channels_last [N,C,H,W].  Training statistics over N*H*W (all ranks when `sync`)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, eps, sync, module, training):
+        import torch.distributed as dist
+        from . import hip_ops as H
+        lib = _lib.load()
+        n_img, c, h, w = x.shape
+        rows = n_img * h * w
+        dev = x.device
+        gamma = gamma.float().contiguous()
+        beta = beta.float().contiguous()
+        track = module.track_running_stats
+        ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
+        count = None
+        if training and not sync:
+            fin = torch.empty((4, c), dtype=torch.float32, device=dev)
+            check(lib.s2d_bnrow_stats_finalize_bf16(_ptr(x), rows, c, _ptr(gamma), _ptr(beta), float(eps),
+                                                    float(module.momentum if track else 0.0), _ptr(fin[0]), _ptr(fin[1]),
+                                                    _ptr(fin[2]), _ptr(fin[3]), _ptr(module.running_mean if track else None),
+                                                    _ptr(module.running_var if track else None), _ptr(ws), ws.numel(),
+                                                    _stream()), "s2d_bnrow_stats_finalize_bf16")
+        elif training:
+            packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)
+            check(lib.s2d_bnrow_stats_bf16(_ptr(x), rows, c, _ptr(packed), _ptr(ws), ws.numel(), _stream()),
+                  "s2d_bnrow_stats_bf16")
+            packed[-1] = float(rows)
+            dist.all_reduce(packed)
+            count = packed[-1:].contiguous()
+            fin = H.bn1d_finalize_fwd(packed[:-1].contiguous(), count, gamma, beta, eps, module.momentum if track else 0.0,
+                                      module.running_mean if track else None, module.running_var if track else None)
+        else:
+            invstd = torch.rsqrt(module.running_var.float() + eps)
+            scale = gamma * invstd
+            fin = torch.stack([module.running_mean.float(), invstd, scale, beta - module.running_mean.float() * scale])
+        if training and track:
+            module.num_batches_tracked += 1
+        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+        y = torch.empty_like(x)   # preserves channels_last
+        check(lib.s2d_bnrow_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), int(relu), rows, c, _ptr(y), _stream()),
+              "s2d_bnrow_apply_bf16")
+        ctx.save_for_backward(x, gamma, fin, count)
+        ctx.relu, ctx.sync, ctx.training = relu, sync, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        from . import hip_ops as H
+        lib = _lib.load()
+        x, gamma, fin, count = ctx.saved_tensors
+        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+        n_img, c, h, w = x.shape
+        rows = n_img * h * w
+        dev = x.device
+        dy = _nhwc_bf16(dy)
+        relu = int(ctx.relu)
+        ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
+        if ctx.training and not ctx.sync:
+            out = torch.empty((5, c), dtype=torch.float32, device=dev)
+            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(gamma),
+                                                         _ptr(mean), _ptr(invstd), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                         _ptr(out[3]), _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
+                  "s2d_bnrow_bwd_reduce_finalize_bf16")
+        else:
+            sums = torch.empty((2 * c,), dtype=torch.float32, device=dev)
+            check(lib.s2d_bnrow_bwd_reduce_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(sums), _ptr(ws),
+                                                ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
+            if ctx.training:
+                sums_all = sums.clone()
+                dist.all_reduce(sums_all)
+                out = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+            else:   # eval: y = x*scale + shift with constant scale
+                zeros = torch.zeros_like(scale)
+                out = torch.stack([invstd * (sums[c:] - mean * sums[:c]), sums[:c], scale, zeros, zeros])
+        dgamma, dbeta = out[0], out[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.s2d_bnrow_bwd_apply_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, _ptr(out[2]), _ptr(out[3]),
+                                               _ptr(out[4]), rows, c, _ptr(dx), _stream()), "s2d_bnrow_bwd_apply_bf16")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class FastBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters / buffers / state_dict keys) with an optional fused ReLU.  bf16 channels_last
+    CUDA inputs run the row-major HIP kernels, which synchronise their statistics across ranks themselves when
+    torch.distributed is initialised (so dp.convert_syncbn leaves this class alone).  Other inputs take the stock
+    batch norm — torch's SyncBatchNorm function when a process group is up — followed by the ReLU."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, fused_relu=False):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.fused_relu = fused_relu
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and self.affine
+                and self.num_features % 8 == 0 and self.num_features <= 1024 and x.numel() > 0
+                and x.is_contiguous(memory_format=torch.channels_last) and self.momentum is not None)
+
+    def forward(self, x, relu=None):
+        relu = self.fused_relu if relu is None else relu
+        training = self.training or not self.track_running_stats
+        sync = training and _dist_sync()
+        if self._hip_ok(x):
+            return _BNRowFn.apply(x, self.weight, self.bias, relu, self.eps, sync, self, training)
+        if sync and x.is_cuda:
+            import torch.distributed as dist
+            from torch.nn.modules._functions import SyncBatchNorm as _SyncFn
+            if self.track_running_stats:
+                self.num_batches_tracked += 1
+            y = _SyncFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                              dist.group.WORLD, dist.get_world_size())
+        else:
+            y = super().forward(x)
+        return torch.relu(y) if relu else y
+
+
+def fuse_bn_relu(layers):
+    """[.., FastBatchNorm2d, nn.ReLU, ..] -> [.., FastBatchNorm2d(fused_relu), nn.Identity, ..]: same indices (state_dict
+    keys of the reference checkpoints), one kernel instead of two."""
+    layers = list(layers)
+    for i in range(len(layers) - 1):
+        if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.ReLU):
+            layers[i].fused_relu = True
+            layers[i + 1] = nn.Identity()
+    return layers

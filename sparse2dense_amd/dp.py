@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from .dense2d import FastBatchNorm2d
 from .dense3d import FastBatchNorm3d
 from .spconv import FeatureBatchNorm1d
 
@@ -38,10 +39,10 @@ def init_distributed(backend=None):
 
 
 def convert_syncbn(module: nn.Module):
-    """BatchNorm2d/3d -> SyncBatchNorm; FeatureBatchNorm1d and FastBatchNorm3d are left alone (they
+    """BatchNorm2d/3d -> SyncBatchNorm; FeatureBatchNorm1d, FastBatchNorm2d and FastBatchNorm3d are left alone (they
     synchronise themselves inside their fused kernels' autograd functions)."""
     out = module
-    if isinstance(module, nn.modules.batchnorm._BatchNorm) and not isinstance(module, (FeatureBatchNorm1d, FastBatchNorm3d, nn.SyncBatchNorm)):
+    if isinstance(module, nn.modules.batchnorm._BatchNorm) and not isinstance(module, (FeatureBatchNorm1d, FastBatchNorm3d, FastBatchNorm2d, nn.SyncBatchNorm)):
         out = nn.SyncBatchNorm(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats)
         if module.affine:
             with torch.no_grad():

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense2d import Conv3x3
+from .dense2d import Conv3x3, FastBatchNorm2d, fuse_bn_relu
 from .registry import HEADS, LOSSES
 
 
@@ -126,10 +126,10 @@ class SepHead(nn.Module):
             for _ in range(num_conv - 1):
                 layers.append(Conv3x3(in_channels, head_conv, final_kernel, 1, final_kernel // 2, bias=True))
                 if bn:
-                    layers.append(nn.BatchNorm2d(head_conv))
+                    layers.append(FastBatchNorm2d(head_conv))
                 layers.append(nn.ReLU())
             layers.append(nn.Conv2d(head_conv, classes, final_kernel, 1, final_kernel // 2, bias=True))
-            fc = nn.Sequential(*layers)
+            fc = nn.Sequential(*fuse_bn_relu(layers))
             if "hm" in head:
                 fc[-1].bias.data.fill_(init_bias)
             else:
@@ -162,8 +162,8 @@ class CenterHead(nn.Module):
         self.box_n_dim = 9 if "vel" in common_heads else 7
         self.use_direction_classifier = False
         self.logger = logger or logging.getLogger("CenterHead")
-        self.shared_conv = nn.Sequential(Conv3x3(in_channels, share_conv_channel, 3, padding=1, bias=True),
-                                         nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
+        self.shared_conv = nn.Sequential(*fuse_bn_relu([Conv3x3(in_channels, share_conv_channel, 3, padding=1, bias=True),
+                                                        FastBatchNorm2d(share_conv_channel), nn.ReLU(inplace=True)]))
         self.tasks = nn.ModuleList()
         for num_cls in num_classes:
             heads = copy.deepcopy(dict(common_heads))

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv3x3
+from .dense2d import Conv3x3, FastBatchNorm2d, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .registry import NECKS
 
@@ -60,7 +60,7 @@ class RPN(nn.Module):
             else:
                 down = int(np.round(1 / up))
                 conv = nn.Conv2d(ds_num_filters[i], us_num_filters[j], down, stride=down, bias=False)
-            deblocks.append(nn.Sequential(conv, build_norm_layer(self._norm_cfg, us_num_filters[j])[1], nn.ReLU()))
+            deblocks.append(nn.Sequential(*fuse_bn_relu([conv, build_norm_layer(self._norm_cfg, us_num_filters[j])[1], nn.ReLU()])))
         self.blocks = nn.ModuleList(blocks)
         self.deblocks = nn.ModuleList(deblocks)
         if logger is not None:
@@ -80,7 +80,7 @@ class RPN(nn.Module):
             layers += [Conv3x3(planes, planes, 3, padding=1, bias=False), build_norm_layer(self._norm_cfg, planes)[1]]
             if j < num_blocks - 1:  # the last conv+BN of a block has no ReLU of its own (rpn.py:142-143)
                 layers.append(nn.ReLU())
-        return nn.Sequential(*layers)
+        return nn.Sequential(*fuse_bn_relu(layers))
 
     def init_weights(self):
         _xavier_uniform_convs(self)
@@ -90,9 +90,14 @@ class RPN(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         ups = []
         for i, blk in enumerate(self.blocks):
-            x = blk(x)
-            if relu_between:
-                x = F.relu(x)
+            if relu_between and isinstance(blk[-1], FastBatchNorm2d):   # F.relu(block(x)) with the ReLU fused into the last BN
+                for layer in blk[:-1]:
+                    x = layer(x)
+                x = blk[-1](x, relu=True)
+            else:
+                x = blk(x)
+                if relu_between:
+                    x = F.relu(x)
             if i - self._upsample_start_idx >= 0:
                 ups.append(self.deblocks[i - self._upsample_start_idx](x))
         return torch.cat(ups, dim=1) if ups else x

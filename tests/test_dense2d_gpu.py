@@ -80,3 +80,63 @@ def test_module_autograd_matches_stock_conv(pad, bias):
     # fp32 (no autocast) and CPU inputs take the stock layer
     y32 = m(x)
     assert y32.dtype == torch.float32
+
+
+# ---------------------------------------------------------------------------------------------------
+# FastBatchNorm2d: row-major bf16 kernels vs torch fp32 batch norm on the same bf16-rounded input.
+# Tolerance: outputs/gradients are rounded to bf16 (2^-8 relative) -> 1e-2 of the tensor's max; fp32 per-channel
+# quantities (running stats, dgamma, dbeta) 2e-3 relative to their max (bf16 dy/x products, fp32 sums).
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 20, 24), (4, 128, 47, 47), (1, 256, 33, 9), (2, 8, 5, 7), (1, 512, 16, 16)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_fast_batchnorm2d_training(n, c, h, w, relu):
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(2)
+    m = D.FastBatchNorm2d(c, eps=1e-3, momentum=0.01, fused_relu=relu).cuda()
+    ref = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).double()   # float64 on the CPU: an oracle, not MIOpen
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    x = (torch.randn(n, c, h, w, device="cuda") * 2 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, c, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    ya = m(xa)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy)
+    xr = x.double().cpu().contiguous().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double().cpu().contiguous())
+
+    def close(what, a, r, tol):
+        err = (a.double().cpu() - r).abs().max() / r.abs().max().clamp(min=1e-6)
+        assert err <= tol, (what, float(err))
+    close("y", ya, yr, 1e-2)
+    close("dx", xa.grad, xr.grad, 1.5e-2)
+    close("dgamma", m.weight.grad, ref.weight.grad, 2e-3)
+    close("dbeta", m.bias.grad, ref.bias.grad, 2e-3)
+    close("running_mean", m.running_mean, ref.running_mean, 1e-4)
+    close("running_var", m.running_var, ref.running_var, 1e-4)
+    assert int(m.num_batches_tracked) == 1
+
+
+def test_fast_batchnorm2d_eval_and_fallbacks():
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(3)
+    m = D.FastBatchNorm2d(64, fused_relu=True).cuda()
+    with torch.no_grad():
+        m.running_mean.uniform_(-1, 1); m.running_var.uniform_(0.5, 2)
+    m.eval()
+    x = torch.randn(2, 64, 12, 10, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    y = m(xa)
+    y.backward(torch.ones_like(y))
+    xr = x.float().contiguous().requires_grad_(True)
+    yr = torch.relu(F.batch_norm(xr, m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps))
+    yr.backward(torch.ones_like(yr))
+    assert (y.float() - yr).abs().max() <= 1e-2 * yr.abs().max()
+    assert (xa.grad.float() - xr.grad).abs().max() <= 1e-2 * xr.grad.abs().max()
+    # fp32 / NCHW inputs: stock path, same fused-ReLU semantics
+    x32 = torch.randn(2, 64, 12, 10, device="cuda")
+    assert (m(x32) - torch.relu(F.batch_norm(x32, m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps))).abs().max() < 1e-5
