@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-points", type=int, default=150000)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--torch-profile", action="store_true", help="after the timed region: torch.profiler table of 2 steps "
+                   "(ops with input shapes -> stderr); diagnostic only")
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                    help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
@@ -312,6 +314,16 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70,
+                                                                 max_name_column_width=48, max_shapes_column_width=70),
+              file=sys.stderr)
 
     ex = frames.example()
     n_vox = int(ex["coordinates"].shape[0])

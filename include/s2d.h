@@ -152,7 +152,7 @@ int s2d_bn1d_stats_f32(const float *x, int64_t n, int c, float *stats, void *ws,
 int s2d_bn1d_finalize_fwd_f32(const float *stats, const float *count, const float *gamma,
                               const float *beta, float eps, float momentum, int c, float *mean,
                               float *invstd, float *scale, float *shift, float *running_mean,
-                              float *running_var, s2d_stream_t stream);
+                              float *running_var, int64_t *batches_tracked, s2d_stream_t stream);
 int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *sums_global, const float *count,
                               const float *gamma, const float *mean, const float *invstd, int c,
                               float *dgamma, float *dbeta, float *a, float *b, float *d,
@@ -163,7 +163,8 @@ int s2d_bn1d_finalize_bwd_f32(const float *sums_local, const float *sums_global,
 int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, const float *gamma,
                                 const float *beta, float eps, float momentum, float *mean,
                                 float *invstd, float *scale, float *shift, float *running_mean,
-                                float *running_var, void *ws, size_t ws_bytes, s2d_stream_t stream);
+                                float *running_var, int64_t *batches_tracked, void *ws,
+                                size_t ws_bytes, s2d_stream_t stream);
 int s2d_bn1d_bwd_reduce_finalize_f32(const float *dy, const float *y, const float *x, int relu,
                                      int64_t n, int c, const float *gamma, const float *mean,
                                      const float *invstd, float *g_out, float *dgamma, float *dbeta,
@@ -192,6 +193,13 @@ int s2d_densify_fwd_f32(const float *feat, const int32_t *coors, int64_t n, int 
                         const int32_t shape[3], int c, float *out, s2d_stream_t stream);
 int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int64_t n, int batch,
                         const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
+/* dense() + view(N, C*D, H, W) written directly in the layout the bf16 BEV neck consumes:
+ * out / dout are [batch][H][W][c*D] bf16 (torch channels_last of [batch][c*D][H][W]), BEV channel
+ * = ch*D + z (scn.py:173-176).  feat / dfeat stay fp32 [n][c]. */
+int s2d_densify_bev_fwd_bf16(const float *feat, const int32_t *coors, int64_t n, int batch,
+                             const int32_t shape[3], int c, void *out, s2d_stream_t stream);
+int s2d_densify_bev_bwd_bf16(const void *dout, const int32_t *coors, int64_t n, int batch,
+                             const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
 
 /* ---- PCR head of the S2D neck (dense, NCDHW fp32, HBM-bound) -------------------------------- */
 /*
@@ -268,7 +276,8 @@ int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws
 int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *gamma,
                                   const float *beta, float eps, float momentum, float *mean,
                                   float *invstd, float *scale, float *shift, float *running_mean,
-                                  float *running_var, void *ws, size_t ws_bytes, s2d_stream_t stream);
+                                  float *running_var, int64_t *batches_tracked, void *ws,
+                                  size_t ws_bytes, s2d_stream_t stream);
 int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, int relu, int64_t n,
                          int c, void *y, s2d_stream_t stream);
 int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const float *scale, const float *shift,

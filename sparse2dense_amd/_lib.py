@@ -49,12 +49,13 @@ SIGNATURES = {
     "s2d_bn1d_stats_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bn1d_finalize_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, ctypes.c_int,
-                                                 c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+                                                 c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p,
+                                                 ctypes.c_void_p]),
     "s2d_bn1d_finalize_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p,
                                                  c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_bn1d_stats_finalize_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
                                                    ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bn1d_bwd_reduce_finalize_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                                         c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                                         c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -73,7 +74,7 @@ SIGNATURES = {
                                 [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_bnrow_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "s2d_bnrow_stats_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "s2d_bnrow_stats_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bnrow_stats_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bnrow_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_bnrow_bwd_reduce_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bnrow_bwd_reduce_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -95,6 +96,10 @@ SIGNATURES = {
                                                ctypes.c_int64, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bncm_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
+    "s2d_densify_bev_fwd_bf16": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "s2d_densify_bev_bwd_bf16": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
+                                                ctypes.c_void_p]),
     "s2d_densify_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
                                            ctypes.c_void_p]),
     "s2d_densify_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,

@@ -166,7 +166,7 @@ class SpMiddleResNetFHD(_PlannedBackbone):
     def _strided_convs(self):
         return [self.conv2[0], self.conv3[0], self.conv4[0], self.extra_conv[0]]
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
+    def forward(self, voxel_features, coors, batch_size, input_shape, bev_nhwc_bf16=False):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]  # (z+1, y, x), scn.py:159
         ret = SparseConvTensor(voxel_features, coors if coors.dtype == torch.int32 else coors.int(), sparse_shape, batch_size)
         plan_geometry(ret, *self._specs())
@@ -175,9 +175,7 @@ class SpMiddleResNetFHD(_PlannedBackbone):
         x_conv2 = self.conv2(x_conv1)
         x_conv3 = self.conv3(x_conv2)
         x_conv4 = self.conv4(x_conv3)
-        ret = self.extra_conv(x_conv4).dense()
-        n, c, d, h, w = ret.shape
-        ret = ret.view(n, c * d, h, w)
+        ret = self.extra_conv(x_conv4).dense_bev(nhwc_bf16=bev_nhwc_bf16)
         return ret, {"conv1": x_conv1, "conv2": x_conv2, "conv3": x_conv3, "conv4": x_conv4}
 
 
@@ -213,11 +211,9 @@ class SpMiddleFHD(_PlannedBackbone):
     def _strided_convs(self):
         return [m for m in self.middle_conv._modules.values() if isinstance(m, SparseConv3d)] + [self.extra_conv[0]]
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
+    def forward(self, voxel_features, coors, batch_size, input_shape, bev_nhwc_bf16=False):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
         ret = SparseConvTensor(voxel_features, coors if coors.dtype == torch.int32 else coors.int(), sparse_shape, batch_size)
         plan_geometry(ret, *self._specs())
         conv_4 = self.middle_conv(ret)
-        ret = self.extra_conv(conv_4).dense()
-        n, c, d, h, w = ret.shape
-        return ret.view(n, c * d, h, w), conv_4
+        return self.extra_conv(conv_4).dense_bev(nhwc_bf16=bev_nhwc_bf16), conv_4

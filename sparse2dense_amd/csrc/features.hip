@@ -136,6 +136,38 @@ __global__ __launch_bounds__(256) void densify_bwd_kernel(const float *__restric
     dfeat[t] = v;
 }
 
+
+// dense() straight into the BEV layout the bf16 neck consumes: [B][H][W][c*D] bf16 (channels_last view of
+// ret.view(N, C*D, H, W), scn.py:173-176); BEV channel = ch*D + z.  Thread per (row, channel), channel fastest.
+__global__ __launch_bounds__(256) void densify_bev_fwd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ coors,
+                                                              int64_t n, int batch, int D, int H, int W, int c,
+                                                              __bf16 *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / c;
+    const int ch = (int)(t - i * c);
+    if (i >= n) return;
+    const int4 co = reinterpret_cast<const int4 *>(coors)[i];
+    if ((unsigned)co.x >= (unsigned)batch || (unsigned)co.y >= (unsigned)D || (unsigned)co.z >= (unsigned)H ||
+        (unsigned)co.w >= (unsigned)W)
+        return;
+    out[((((int64_t)co.x * H + co.z) * W + co.w) * c + ch) * D + co.y] = (__bf16)feat[t];
+}
+
+__global__ __launch_bounds__(256) void densify_bev_bwd_kernel(const __bf16 *__restrict__ dout, const int32_t *__restrict__ coors,
+                                                              int64_t n, int batch, int D, int H, int W, int c,
+                                                              float *__restrict__ dfeat) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / c;
+    const int ch = (int)(t - i * c);
+    if (i >= n) return;
+    const int4 co = reinterpret_cast<const int4 *>(coors)[i];
+    float v = 0.f;
+    if ((unsigned)co.x < (unsigned)batch && (unsigned)co.y < (unsigned)D && (unsigned)co.z < (unsigned)H &&
+        (unsigned)co.w < (unsigned)W)
+        v = (float)dout[((((int64_t)co.x * H + co.z) * W + co.w) * c + ch) * D + co.y];
+    dfeat[t] = v;
+}
+
 // ---- per-channel finalisation (one tiny launch instead of ~15 elementwise torch kernels) ---------
 // forward: stats[2C] (+count) -> mean, invstd, scale, shift; running stats updated in place.
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__restrict__ stats, const float *__restrict__ count_p,
@@ -143,9 +175,11 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
                                                               float eps, float momentum, int c, float *__restrict__ mean_out,
                                                               float *__restrict__ invstd_out, float *__restrict__ scale,
                                                               float *__restrict__ shift, float *__restrict__ running_mean,
-                                                              float *__restrict__ running_var) {
+                                                              float *__restrict__ running_var,
+                                                              long long *__restrict__ batches_tracked) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
+    if (i == 0 && batches_tracked) *batches_tracked += 1;   // nn.BatchNorm's num_batches_tracked, no extra launch
     const float n = *count_p;
     const float mean = stats[i] / n;
     float var = stats[c + i] / n - mean * mean;
@@ -288,10 +322,12 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float
                                                                      int c, float *__restrict__ mean_out,
                                                                      float *__restrict__ invstd_out, float *__restrict__ scale,
                                                                      float *__restrict__ shift, float *__restrict__ running_mean,
-                                                                     float *__restrict__ running_var) {
+                                                                     float *__restrict__ running_var,
+                                                                     long long *__restrict__ batches_tracked) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= c) return;
+    if (i == 0 && lane == 0 && batches_tracked) *batches_tracked += 1;
     float s0 = 0.f, s1 = 0.f;
     for (int b = lane; b < nblocks; b += 64) {
         s0 += partial[(size_t)b * 2 * c + i];
@@ -640,13 +676,41 @@ extern "C" int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int6
     return S2D_OK;
 }
 
+
+extern "C" int s2d_densify_bev_fwd_bf16(const float *feat, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                                        int c, void *out, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0 && out, "densify_bev_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 2;
+    S2D_HIP(hipMemsetAsync(out, 0, bytes, st));
+    if (n == 0) return S2D_OK;
+    S2D_CHECK_ARG(feat && coors, "densify_bev_fwd: null input");
+    hipLaunchKernelGGL(densify_bev_fwd_kernel, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, st, feat, coors, n, batch,
+                       shape[0], shape[1], shape[2], c, (__bf16 *)out);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_densify_bev_bwd_bf16(const void *dout, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
+                                        int c, float *dfeat, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0, "densify_bev_bwd: bad argument");
+    if (n == 0) return S2D_OK;
+    S2D_CHECK_ARG(dout && coors && dfeat, "densify_bev_bwd: null argument");
+    hipLaunchKernelGGL(densify_bev_bwd_kernel, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)dout, coors, n, batch, shape[0], shape[1], shape[2], c, dfeat);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
 extern "C" int s2d_bn1d_finalize_fwd_f32(const float *stats, const float *count, const float *gamma, const float *beta,
                                          float eps, float momentum, int c, float *mean, float *invstd, float *scale,
-                                         float *shift, float *running_mean, float *running_var, s2d_stream_t stream) {
+                                         float *shift, float *running_mean, float *running_var, int64_t *batches_tracked,
+                                         s2d_stream_t stream) {
     S2D_CHECK_ARG(c > 0 && stats && count && gamma && beta && mean && invstd && scale && shift, "bn1d_finalize_fwd: null argument");
     S2D_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn1d_finalize_fwd: running stats must come in pairs");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, count, gamma,
-                       beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+                       beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
+                       (long long *)batches_tracked);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -732,8 +796,8 @@ extern "C" int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const flo
 // ---- fused single-GPU entry points (no cross-rank statistics exchange) -----------------------------
 extern "C" int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                                            float momentum, float *mean, float *invstd, float *scale, float *shift,
-                                           float *running_mean, float *running_var, void *ws, size_t ws_bytes,
-                                           s2d_stream_t stream) {
+                                           float *running_mean, float *running_var, int64_t *batches_tracked, void *ws,
+                                           size_t ws_bytes, s2d_stream_t stream) {
     int rc = check_c(c, "bn1d_stats_finalize");
     if (rc) return rc;
     S2D_CHECK_ARG(n > 0 && x && gamma && beta && mean && invstd && scale && shift, "bn1d_stats_finalize: bad argument");
@@ -746,7 +810,8 @@ extern "C" int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, con
     hipLaunchKernelGGL(col_reduce_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, nullptr, nullptr, 0, n, c,
                        p.rows_per_block, nullptr, (float *)ws);
     hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
-                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
+                       (long long *)batches_tracked);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -816,15 +881,16 @@ extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stat
 
 extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *gamma, const float *beta, float eps,
                                              float momentum, float *mean, float *invstd, float *scale, float *shift,
-                                             float *running_mean, float *running_var, void *ws, size_t ws_bytes,
-                                             s2d_stream_t stream) {
+                                             float *running_mean, float *running_var, int64_t *batches_tracked, void *ws,
+                                             size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(gamma && beta && mean && invstd && scale && shift, "bnrow_stats_finalize: bad argument");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
     int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats_finalize");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
-                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var);
+                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
+                       (long long *)batches_tracked);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -104,8 +104,14 @@ class _Conv3x3Fn(torch.autograd.Function):
             _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                             [False, True, False])
             dw = dwb.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dyb.float().sum(dim=(0, 2, 3))
+        if ctx.has_bias and ctx.needs_input_grad[2]:   # per-channel sum of dY: the row-reduce kernel's first output half
+            lib = _lib.load()
+            rows = dyb.shape[0] * dyb.shape[2] * dyb.shape[3]
+            stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
+            ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)
+            check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), _ptr(ws), ws.numel(), _stream()),
+                  "s2d_bnrow_stats_bf16")
+            db = stats[:cout]
         return dx, dw, db, None
 
 
@@ -159,7 +165,8 @@ class _BNRowFn(torch.autograd.Function):
             check(lib.s2d_bnrow_stats_finalize_bf16(_ptr(x), rows, c, _ptr(gamma), _ptr(beta), float(eps),
                                                     float(module.momentum if track else 0.0), _ptr(fin[0]), _ptr(fin[1]),
                                                     _ptr(fin[2]), _ptr(fin[3]), _ptr(module.running_mean if track else None),
-                                                    _ptr(module.running_var if track else None), _ptr(ws), ws.numel(),
+                                                    _ptr(module.running_var if track else None),
+                                                    _ptr(module.num_batches_tracked if track else None), _ptr(ws), ws.numel(),
                                                     _stream()), "s2d_bnrow_stats_finalize_bf16")
         elif training:
             packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)
@@ -169,13 +176,12 @@ class _BNRowFn(torch.autograd.Function):
             dist.all_reduce(packed)
             count = packed[-1:].contiguous()
             fin = H.bn1d_finalize_fwd(packed[:-1].contiguous(), count, gamma, beta, eps, module.momentum if track else 0.0,
-                                      module.running_mean if track else None, module.running_var if track else None)
+                                      module.running_mean if track else None, module.running_var if track else None,
+                                      module.num_batches_tracked if track else None)
         else:
             invstd = torch.rsqrt(module.running_var.float() + eps)
             scale = gamma * invstd
             fin = torch.stack([module.running_mean.float(), invstd, scale, beta - module.running_mean.float() * scale])
-        if training and track:
-            module.num_batches_tracked += 1
         mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         y = torch.empty_like(x)   # preserves channels_last
         check(lib.s2d_bnrow_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), int(relu), rows, c, _ptr(y), _stream()),

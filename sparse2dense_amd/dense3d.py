@@ -168,9 +168,8 @@ class _BNChannelMajorFn(torch.autograd.Function):
                 stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
             track = module.track_running_stats
             fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
-                                      module.running_mean if track else None, module.running_var if track else None)
-            if track:
-                module.num_batches_tracked += 1
+                                      module.running_mean if track else None, module.running_var if track else None,
+                                      module.num_batches_tracked if track else None)
             mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         else:
             invstd = torch.rsqrt(module.running_var + eps)

@@ -52,8 +52,9 @@ class SingleStageDetector(nn.Module):
         self.dense_channels_last = True
         return self
 
-    def _dense(self, module, x):
-        """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs)."""
+    def _dense(self, module, x, keep_first=False):
+        """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs).  keep_first: the first
+        (or only) output stays in the compute dtype — the neck map that only feeds the head."""
         if self.dense_channels_last and x.is_cuda and x.dim() == 4 and module is self.bbox_head:
             x = x.contiguous(memory_format=torch.channels_last)   # NHWC: what the bf16 MFMA conv kernels consume
         if self.dense_dtype == torch.float32 or not x.is_cuda:
@@ -62,8 +63,11 @@ class SingleStageDetector(nn.Module):
             out = module(x)
         f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
         if isinstance(out, (tuple, list)):
-            return type(out)(({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for o in out)
-        return f32(out)
+            conv = [({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for o in out]
+            if keep_first and torch.is_tensor(out[0]):
+                conv[0] = out[0]
+            return type(out)(conv)
+        return out if keep_first and torch.is_tensor(out) else f32(out)
 
     def _read(self, example, prefix=""):
         mean_key = prefix + "voxel_mean"
@@ -75,15 +79,19 @@ class SingleStageDetector(nn.Module):
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
     def extract_feat(self, data):
-        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
-        neck = self._dense(self.neck, x) if self.with_neck else x
+        # the BEV map goes straight to NHWC bf16 when nobody but the bf16 neck reads it
+        bev = bool(data.get("bev_private", False) and self.dense_channels_last and self.dense_dtype == torch.bfloat16
+                   and self.with_neck and data["features"].is_cuda)
+        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"],
+                                         bev_nhwc_bf16=bev)
+        neck = self._dense(self.neck, x, keep_first=True) if self.with_neck else x
         return neck, voxel_feature, x
 
     def forward(self, example, return_loss=True, return_feature=False, return_recon_feature=False, **kwargs):
         prefix = "dense_" if "dense_voxels" in example else ""   # teacher sees the dense cloud (voxelnet.py:50-54)
         batch_size = len(example[prefix + "num_voxels"])
         data = dict(features=self._read(example, prefix), coors=example[prefix + "coordinates"], batch_size=batch_size,
-                    input_shape=example["shape"][0])
+                    input_shape=example["shape"][0], bev_private=not return_feature)
         x, _, F_D_a = self.extract_feat(data)
         F_D_b = None
         if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)
@@ -105,7 +113,7 @@ class VoxelNet(SingleStageDetector):
 class KD_VoxelNet(VoxelNet):
     def extract_feat(self, data, train_pcm=True):
         x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
-        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x)
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True)
         return x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, voxel_feature
 
     mask_offset_loss = staticmethod(mask_offset_loss)

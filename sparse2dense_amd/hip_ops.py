@@ -281,14 +281,15 @@ def bn1d_stats(x: torch.Tensor) -> torch.Tensor:
     return stats
 
 
-def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
-    """-> packed f32[4,C]: rows mean, invstd, scale, shift (one launch; running stats updated in place)."""
+def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, batches_tracked=None):
+    """-> packed f32[4,C]: rows mean, invstd, scale, shift (one launch; running stats and the int64
+    num_batches_tracked counter updated in place)."""
     lib = _lib.load()
     c = gamma.shape[0]
     out = torch.empty((4, c), dtype=torch.float32, device=stats.device)
     check(lib.s2d_bn1d_finalize_fwd_f32(_ptr(stats), _ptr(count), _ptr(gamma), _ptr(beta), float(eps), float(momentum), c,
                                         _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(running_mean),
-                                        _ptr(running_var), _stream()), "s2d_bn1d_finalize_fwd_f32")
+                                        _ptr(running_var), _ptr(batches_tracked), _stream()), "s2d_bn1d_finalize_fwd_f32")
     return out
 
 
@@ -303,7 +304,7 @@ def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
     return out
 
 
-def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None, batches_tracked=None):
     """single-GPU: batch statistics + finalisation in two launches -> packed f32[4,C] (mean, invstd, scale, shift)."""
     lib = _lib.load()
     _need_gpu(x)
@@ -313,7 +314,7 @@ def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, runnin
     ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
     check(lib.s2d_bn1d_stats_finalize_f32(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(out[0]),
                                           _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(running_mean), _ptr(running_var),
-                                          _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_finalize_f32")
+                                          _ptr(batches_tracked), _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_finalize_f32")
     return out
 
 
@@ -390,4 +391,27 @@ def densify_bwd(dout, coors, batch, shape, c):
     dfeat = torch.empty((n, c), dtype=torch.float32, device=dout.device)
     check(lib.s2d_densify_bwd_f32(_ptr(dout), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(dfeat), _stream()),
           "s2d_densify_bwd_f32")
+    return dfeat
+
+
+def densify_bev_bf16(feat, coors, batch, shape):
+    """-> bf16 [batch, C*D, H, W] in channels_last memory (== dense().view(N, C*D, H, W) cast to bf16, NHWC)"""
+    lib = _lib.load()
+    _need_gpu(feat, coors)
+    feat = feat.contiguous()
+    n, c = feat.shape
+    out = torch.empty((batch, c * shape[0], shape[1], shape[2]), dtype=torch.bfloat16, device=feat.device,
+                      memory_format=torch.channels_last)
+    check(lib.s2d_densify_bev_fwd_bf16(_ptr(feat), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(out), _stream()),
+          "s2d_densify_bev_fwd_bf16")
+    return out
+
+
+def densify_bev_bf16_bwd(dout, coors, batch, shape, c):
+    lib = _lib.load()
+    dout = dout.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    n = coors.shape[0]
+    dfeat = torch.empty((n, c), dtype=torch.float32, device=dout.device)
+    check(lib.s2d_densify_bev_bwd_bf16(_ptr(dout), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(dfeat), _stream()),
+          "s2d_densify_bev_bwd_bf16")
     return dfeat

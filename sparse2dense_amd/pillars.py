@@ -178,7 +178,7 @@ class PointPillars(SingleStageDetector):
     def extract_feat(self, data):
         feats = self.reader(data["features"], data["num_voxels"], data["coors"])
         x_fea = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
-        x = self._dense(self.neck, x_fea) if self.with_neck else x_fea
+        x = self._dense(self.neck, x_fea, keep_first=True) if self.with_neck else x_fea
         return x, x_fea
 
     def forward(self, example, return_loss=True, **kwargs):
@@ -204,7 +204,7 @@ class KD_PointPillars(PointPillars):
     def extract_feat(self, data):
         feats = self.reader(data["features"], data["num_voxels"], data["coors"])
         F_S_a, F_S_b, gen_offset, gen_mask = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
-        x = self._dense(self.neck, F_S_a) if self.with_neck else F_S_a
+        x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
         return x, F_S_a, F_S_b, gen_offset, gen_mask
 
     def forward(self, example, return_loss=True, **kwargs):

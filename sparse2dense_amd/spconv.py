@@ -51,6 +51,30 @@ class SparseConvTensor:
         out = _Densify.apply(self.features, self.indices, self.batch_size, tuple(self.spatial_shape))
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
+    def dense_bev(self, nhwc_bf16=False):
+        """dense() folded to the BEV map [N, C*D, H, W] (scn.py:173-176); nhwc_bf16: channels_last bf16 output."""
+        if nhwc_bf16 and self.features.is_cuda:
+            return _DensifyBev.apply(self.features, self.indices, self.batch_size, tuple(self.spatial_shape))
+        ret = self.dense()
+        n, c, d, h, w = ret.shape
+        return ret.view(n, c * d, h, w)
+
+
+class _DensifyBev(torch.autograd.Function):
+    """dense().view(N, C*D, H, W) emitted as NHWC bf16 for the bf16 BEV neck (no fp32 volume, no layout copy)."""
+
+    @staticmethod
+    def forward(ctx, feat, coors, batch, shape):
+        ctx.save_for_backward(coors)
+        ctx.meta = (batch, shape, feat.shape[1])
+        return H.densify_bev_bf16(feat, coors, batch, shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coors,) = ctx.saved_tensors
+        batch, shape, c = ctx.meta
+        return H.densify_bev_bf16_bwd(dout, coors, batch, shape, c), None, None, None
+
 
 class _Densify(torch.autograd.Function):
     @staticmethod
@@ -188,6 +212,7 @@ class _BNTrainFn(torch.autograd.Function):
         track = module is not None and module.track_running_stats
         mom = module.momentum if track else 0.0
         rm, rv = (module.running_mean, module.running_var) if track else (None, None)
+        nbt = module.num_batches_tracked if track else None   # bumped inside the finalize kernel
         count = None
         if sync:   # statistics over the rows of ALL ranks: exchange [sum, sumsq, count] between the two kernels
             stats = H.bn1d_stats(x)
@@ -195,11 +220,9 @@ class _BNTrainFn(torch.autograd.Function):
             packed = torch.cat([stats, count])
             dist.all_reduce(packed)
             stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
-            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, mom, rm, rv)
+            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, mom, rm, rv, nbt)
         else:
-            fin = H.bn1d_stats_finalize(x, gamma, beta, eps, mom, rm, rv)
-        if track:
-            module.num_batches_tracked += 1
+            fin = H.bn1d_stats_finalize(x, gamma, beta, eps, mom, rm, rv, nbt)
         mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         y = H.bn1d_apply(x, scale, shift, residual, relu)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, count)

@@ -80,7 +80,9 @@ def bn1d_stats(x):
     return torch.cat([x.sum(0), (x * x).sum(0)])
 
 
-def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn1d_finalize_fwd(stats, count, gamma, beta, eps, momentum, running_mean=None, running_var=None, batches_tracked=None):
+    if batches_tracked is not None:
+        batches_tracked += 1
     c = gamma.shape[0]
     mean = stats[:c] / count
     var = (stats[c:] / count - mean * mean).clamp(min=0)
@@ -107,9 +109,9 @@ def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
     return torch.stack([dgamma, dbeta, a, b, d])
 
 
-def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None, batches_tracked=None):
     count = torch.full((1,), float(x.shape[0]), dtype=x.dtype)
-    return bn1d_finalize_fwd(bn1d_stats(x), count, gamma, beta, eps, momentum, running_mean, running_var)
+    return bn1d_finalize_fwd(bn1d_stats(x), count, gamma, beta, eps, momentum, running_mean, running_var, batches_tracked)
 
 
 def bn1d_bwd_reduce_finalize(dy, y, x, relu, gamma, mean, invstd):

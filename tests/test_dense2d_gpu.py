@@ -140,3 +140,23 @@ def test_fast_batchnorm2d_eval_and_fallbacks():
     # fp32 / NCHW inputs: stock path, same fused-ReLU semantics
     x32 = torch.randn(2, 64, 12, 10, device="cuda")
     assert (m(x32) - torch.relu(F.batch_norm(x32, m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps))).abs().max() < 1e-5
+
+
+def test_densify_bev_nhwc_bf16_matches_dense_view():
+    """dense_bev(nhwc_bf16=True) == dense().view(N, C*D, H, W) rounded to bf16 (bit-exact), gradient = the gather."""
+    from sparse2dense_amd.spconv import SparseConvTensor
+    g = torch.Generator().manual_seed(5)
+    batch, d, h, w, c = 3, 2, 23, 17, 128
+    cells = torch.randperm(batch * d * h * w, generator=g)[:700]
+    coors = torch.stack([cells // (d * h * w), (cells // (h * w)) % d, (cells // w) % h, cells % w], 1).int().cuda()
+    feat = torch.randn(700, c, generator=g).cuda()
+    fa = feat.clone().requires_grad_(True)
+    fb = feat.clone().requires_grad_(True)
+    a = SparseConvTensor(fa, coors, [d, h, w], batch).dense_bev(nhwc_bf16=True)
+    b = SparseConvTensor(fb, coors, [d, h, w], batch).dense_bev(nhwc_bf16=False)
+    assert a.shape == b.shape and a.dtype == torch.bfloat16 and a.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(a.float(), b.to(torch.bfloat16).float())
+    dy = torch.randn(b.shape, device="cuda").to(torch.bfloat16)
+    a.backward(dy.contiguous(memory_format=torch.channels_last))
+    b.backward(dy.float())
+    assert torch.equal(fa.grad, fb.grad)
