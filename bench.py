@@ -54,17 +54,20 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
                    help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
-    p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16"], help="override for the sparse convs")
+    p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16", "s16"],
+                   help="override for the sparse stack: bf16 = fp32 storage / bf16 MFMA inputs, s16 = bf16 storage (default with --dtype bf16)")
     p.add_argument("--prefetch", action="store_true",
                    help="voxelize + plan the NEXT batch on a side stream during backward (measured neutral: the step is GPU-bound)")
     p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
+    p.add_argument("--graph", action="store_true", help="replay the static-shape neck+head section (fwd+bwd) as HIP graphs; "
+                   "single-GPU CenterPoint bf16 only.  Off by default: the step is GPU-bound, measured 216.9 (graph) vs 223.3 frames/s")
     return p.parse_args()
 
 
 def build_models(args, dev):
     from sparse2dense_amd import hip_ops, waymo_configs
     args.dense_dtype = args.dense_dtype or args.dtype
-    args.sparse_dtype = args.sparse_dtype or args.dtype
+    args.sparse_dtype = args.sparse_dtype or ("s16" if args.dtype == "bf16" else args.dtype)
     hip_ops.set_sparse_compute_dtype(args.sparse_dtype)
     from sparse2dense_amd.registry import build_detector
     torch.manual_seed(1234)
@@ -87,6 +90,10 @@ def build_models(args, dev):
                 m.dense_dtype = torch.bfloat16
             if not args.nchw and args.dense_dtype == "bf16":   # fp32 MIOpen Winograd prefers NCHW (measured)
                 m.use_channels_last()
+    args.graph = bool(args.graph and args.workload == "centerpoint" and args.dense_dtype == "bf16" and not args.nchw
+                      and int(os.environ.get("WORLD_SIZE", "1")) == 1)
+    if args.graph:
+        model.use_dense_graph()
     return model.to(dev).train(), teacher
 
 
@@ -135,7 +142,8 @@ def roofline_pass(step, n_steps=3):
         a["ms"] += ms
         a["n"] += 1
         a["flops"] += 2.0 * pairs * r["cin"] * r["cout"]
-        a["bytes"] += 4.0 * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + 4.0 * r["kvol"] * r["cin"] * r["cout"]
+        eb = float(r.get("elem_bytes", 4))   # feature storage: fp32, or bf16 on the s16 path (its weight image is bf16 too)
+        a["bytes"] += eb * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + eb * r["kvol"] * r["cin"] * r["cout"]
     global RULEBOOK_STATS
     RULEBOOK_STATS = None
     if rb["n"]:
@@ -154,7 +162,7 @@ def roofline_pass(step, n_steps=3):
     rows.sort(key=lambda r: -r["total_ms"])
     top = rows[0]
     # which roof bounds it: arithmetic intensity of the algorithmic traffic against both peaks
-    peak_tf = PEAK_BF16_MATRIX_TFLOPS if top["kernel"].endswith("bf16") else PEAK_F32_MATRIX_TFLOPS
+    peak_tf = PEAK_BF16_MATRIX_TFLOPS if top["kernel"].endswith(("bf16", "s16")) else PEAK_F32_MATRIX_TFLOPS
     intensity = top["tflops"] * 1e3 / max(top["gbs"], 1e-9)          # FLOP per algorithmic byte
     hbm_roof_tf = intensity * PEAK_HBM_GBS / 1e3
     common = dict(traffic=None, kernel=f"{top['kernel']}<cin={top['cin']},cout={top['cout']}> n_out={top['n_out']}",
@@ -342,7 +350,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if (args.dense_dtype, args.sparse_dtype) == ("f32", "f32") else
-                     f"sparse convs {args.sparse_dtype} / dense convs {args.dense_dtype} MFMA inputs, fp32 accumulate+storage",
+                     ("bf16 (sparse stack: " + {"f32": "fp32", "bf16": "fp32 storage, bf16 MFMA inputs", "s16": "bf16 storage"}[args.sparse_dtype]
+                      + "; dense neck/head: " + ("bf16 NHWC activations" if args.dense_dtype == "bf16" else "fp32")
+                      + "; fp32 accumulate, statistics, master weights, optimizer)"),
             "data": "synthetic",
             "config": {"workload": {"centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
                                     "s2d_student": "CenterPoint-voxelnet + S2D student (KD_VoxelNet) fwd+bwd",
@@ -351,7 +361,7 @@ def main():
                                     "pillar": "CenterPoint-Pillar single stage (PFN path)",
                                     "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)"}[args.workload],
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}",
+                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "hip_graph_dense_section": bool(getattr(args, "graph", False)),
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),
                        "loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": base,

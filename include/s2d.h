@@ -195,11 +195,13 @@ int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int64_t n, int 
                         const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
 /* dense() + view(N, C*D, H, W) written directly in the layout the bf16 BEV neck consumes:
  * out / dout are [batch][H][W][c*D] bf16 (torch channels_last of [batch][c*D][H][W]), BEV channel
- * = ch*D + z (scn.py:173-176).  feat / dfeat stay fp32 [n][c]. */
-int s2d_densify_bev_fwd_bf16(const float *feat, const int32_t *coors, int64_t n, int batch,
-                             const int32_t shape[3], int c, void *out, s2d_stream_t stream);
+ * = ch*D + z (scn.py:173-176).  feat / dfeat are [n][c], fp32 or (feat_bf16=1) bf16. */
+int s2d_densify_bev_fwd_bf16(const void *feat, int feat_bf16, const int32_t *coors, int64_t n,
+                             int batch, const int32_t shape[3], int c, void *out,
+                             s2d_stream_t stream);
 int s2d_densify_bev_bwd_bf16(const void *dout, const int32_t *coors, int64_t n, int batch,
-                             const int32_t shape[3], int c, float *dfeat, s2d_stream_t stream);
+                             const int32_t shape[3], int c, void *dfeat, int feat_bf16,
+                             s2d_stream_t stream);
 
 /* ---- PCR head of the S2D neck (dense, NCDHW fp32, HBM-bound) -------------------------------- */
 /*
@@ -267,8 +269,11 @@ int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const floa
  * replaces the cuDNN batch-norm calls there).  c multiple of 8, <= 1024.  Statistics and all
  * per-channel vectors are fp32 and use the same finalisation as the s2d_bn1d_* family
  * (s2d_bn1d_finalize_fwd/bwd_f32 after an all-reduce of the split `stats` / `sums` vectors, or the
- * fused *_finalize entries on one GPU).  The backward recomputes the ReLU mask from x, scale and
- * shift (y > 0 <=> x*scale+shift > 0), so y is not an input.
+ * fused *_finalize entries on one GPU).  Also the batch norm of the bf16-storage sparse stack
+ * ([n sites][c], scn.py:73-83) with `residual` added before the ReLU.  Backward: with y == NULL the
+ * ReLU mask is recomputed from x, scale and shift (y > 0 <=> x*scale+shift > 0; only valid without a
+ * residual), otherwise taken from y; dres (optional) receives the masked dy, i.e. the gradient of
+ * the residual branch.
  */
 size_t s2d_bnrow_workspace_bytes(int64_t n, int c);
 int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
@@ -278,19 +283,42 @@ int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *
                                   float *invstd, float *scale, float *shift, float *running_mean,
                                   float *running_var, int64_t *batches_tracked, void *ws,
                                   size_t ws_bytes, s2d_stream_t stream);
-int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, int relu, int64_t n,
-                         int c, void *y, s2d_stream_t stream);
-int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const float *scale, const float *shift,
-                              int relu, int64_t n, int c, float *sums, void *ws, size_t ws_bytes,
-                              s2d_stream_t stream);
-int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const float *scale,
-                                       const float *shift, int relu, int64_t n, int c,
+int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, const void *residual,
+                         int relu, int64_t n, int c, void *y, s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const void *y, const float *scale,
+                              const float *shift, int relu, int64_t n, int c, float *sums, void *ws,
+                              size_t ws_bytes, s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const void *y,
+                                       const float *scale, const float *shift, int relu, int64_t n, int c,
                                        const float *gamma, const float *mean, const float *invstd,
                                        float *dgamma, float *dbeta, float *a, float *b, float *d,
                                        void *ws, size_t ws_bytes, s2d_stream_t stream);
-int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const float *scale, const float *shift,
-                             int relu, const float *a, const float *b, const float *d, int64_t n,
-                             int c, void *dx, s2d_stream_t stream);
+int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const void *y, const float *scale,
+                             const float *shift, int relu, const float *a, const float *b,
+                             const float *d, int64_t n, int c, void *dx, void *dres,
+                             s2d_stream_t stream);
+
+/*
+ * bf16-storage sparse convolution ("s16" path): features and outputs are bf16 [n][c] in HBM,
+ * fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Same gather-map contract as s2d_spconv_fwd_f32
+ * (nbr[k][o] = input row feeding output row o through kernel offset k, or -1); the data gradient is
+ * the same entry run on dout with nbr_in (or the SubM map with flip=1) and the weight image packed
+ * with transpose=1.  cin, cout in {16, 32, 64, 128}.  The weight image depends on the launch tiling
+ * chosen from n_out, so pack and fwd must be given the same n_out.  zero_page: >= 16 zero bytes of
+ * device memory (what a missing neighbour reads).
+ */
+int s2d_spconv_s16_supported(int cin, int cout);
+size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout);
+int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int cin, int cout, int transpose,
+                                int flip, int64_t n_out, void *packed, s2d_stream_t stream);
+/* weight gradient of the s16 path (in_feat, dout bf16; dweight fp32 [kvol][cin][cout]); workspace from
+ * s2d_spconv_wgrad_workspace_bytes */
+int s2d_spconv_s16_wgrad(const void *in_feat, int64_t n_in, const void *dout, const int32_t *nbr,
+                         int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws,
+                         size_t ws_bytes, s2d_stream_t stream);
+int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_weight,
+                       const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
+                       int cout, const void *zero_page, void *out_feat, s2d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -75,10 +75,17 @@ SIGNATURES = {
     "s2d_bnrow_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "s2d_bnrow_stats_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bnrow_stats_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "s2d_bnrow_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
-    "s2d_bnrow_bwd_reduce_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "s2d_bnrow_bwd_reduce_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
-    "s2d_bnrow_bwd_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_bnrow_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_bnrow_bwd_reduce_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bnrow_bwd_reduce_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bnrow_bwd_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_spconv_s16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "s2d_spconv_s16_packed_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "s2d_spconv_s16_pack_weights": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_spconv_s16_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, ctypes.c_int64,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_dgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -96,10 +103,12 @@ SIGNATURES = {
                                                ctypes.c_int64, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bncm_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
-    "s2d_densify_bev_fwd_bf16": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p,
-                                                ctypes.c_void_p]),
-    "s2d_densify_bev_bwd_bf16": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
-                                                ctypes.c_void_p]),
+    "s2d_densify_bev_fwd_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_int64, ctypes.c_int, _I3,
+                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_densify_bev_bwd_bf16": (ctypes.c_int, [ctypes.c_void_p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "s2d_spconv_s16_wgrad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_i32p, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_densify_fwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,
                                            ctypes.c_void_p]),
     "s2d_densify_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, c_f32p,

@@ -6,9 +6,11 @@
 // Workgroup = 256 threads = 2(M) x 2(N) waves, tile 128 pixels x BN couts (BN = 128 or 64); each
 // wave owns 64 pixels x BN/2 couts = 4 x (BN/32) MFMA tiles of v_mfma_f32_16x16x32_bf16.  One K-step
 // = one tap x 64 input channels: the A tile (128 px x 64 ch) and the pre-packed B tile are brought
-// in with global_load_lds (16 B per lane, LDS image lane-linear = exactly the fragment order, so
-// every ds_read_b128 of a fragment is a conflict-free 1 KiB read), double buffered, one barrier
-// per K-step.  Border taps read a zero page instead of branching.  The data gradient is the same
+// in with global_load_lds (16 B per lane, lane-linear LDS image), double buffered, one barrier per
+// K-step.  B fragments are contiguous 1 KiB reads; the A image is [pixel][8 parts of 16 B] with the
+// part index XOR-swizzled by (pixel & 7) — chosen by which global chunk each lane fetches — so that
+// the 16-lane groups of a ds_read_b128 fragment read hit 16 distinct bank slots (unswizzled rows
+// 128 B apart are 4-way conflicted and the kernel becomes LDS-bound).  Border taps read a zero page instead of branching.  The data gradient is the same
 // kernel with the flipped / transposed weight image (conv2d_pack_weights_bf16).
 #include "s2d_common.h"
 
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 128;
+    if (m0 >= m_total) return;
     const int blk_n = blockIdx.y;
     const int chunks = cin / 64;
     const int ksteps = 9 * chunks;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = threadIdx.x + 256 * u;
-            const int part = id & 7;
+            const int part = (id & 7) ^ ((id >> 3) & 7);   // XOR swizzle: LDS slot (row, s) holds channel part s ^ (row & 7)
             const int yy = a_y[u] + dy, xx = a_x[u] + dx;
             const bool ok = a_ok[u] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             const __bf16 *src = ok ? x + (((int64_t)a_img[u] * H + yy) * W + xx) * cin + chunk * 64 + part * 8 : zero_page;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
             bf16x8c a[4], b[NT];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const bf16x8c *>(abuf(cur) + ((64 * wm + 16 * i + r) * 8 + 4 * h + q) * 16);
+                a[i] = *reinterpret_cast<const bf16x8c *>(abuf(cur) + ((64 * wm + 16 * i + r) * 8 + ((4 * h + q) ^ (r & 7))) * 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(cur) + ((h * (BN / 16) + wn * NT + j) * 64 + lane) * 16);
@@ -202,17 +205,25 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     const int64_t m = (int64_t)n_img * ho * wo;
     hipStream_t st = (hipStream_t)stream;
     const int bn = conv_bn(cout);
-    const dim3 grid((unsigned)ceil_div(m, 128), cout / bn), blk(256);
+    const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
     if (bn == 128) {
         const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 128 * 2);
         auto kern = conv3x3_nhwc_bf16_kernel<128>;
-        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool attr_set = false;   // once per process (idempotent if raced); also keeps the call out of graph captures
+        if (!attr_set) {
+            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
                            (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
     } else {
         const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 64 * 2);
         auto kern = conv3x3_nhwc_bf16_kernel<64>;
-        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool attr_set = false;
+        if (!attr_set) {
+            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
                            (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
     }

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void densify_bwd_kernel(const float *__restric
 
 // dense() straight into the BEV layout the bf16 neck consumes: [B][H][W][c*D] bf16 (channels_last view of
 // ret.view(N, C*D, H, W), scn.py:173-176); BEV channel = ch*D + z.  Thread per (row, channel), channel fastest.
-__global__ __launch_bounds__(256) void densify_bev_fwd_kernel(const float *__restrict__ feat, const int32_t *__restrict__ coors,
+template <typename T>
+__global__ __launch_bounds__(256) void densify_bev_fwd_kernel(const T *__restrict__ feat, const int32_t *__restrict__ coors,
                                                               int64_t n, int batch, int D, int H, int W, int c,
                                                               __bf16 *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,12 +151,13 @@ __global__ __launch_bounds__(256) void densify_bev_fwd_kernel(const float *__res
     if ((unsigned)co.x >= (unsigned)batch || (unsigned)co.y >= (unsigned)D || (unsigned)co.z >= (unsigned)H ||
         (unsigned)co.w >= (unsigned)W)
         return;
-    out[((((int64_t)co.x * H + co.z) * W + co.w) * c + ch) * D + co.y] = (__bf16)feat[t];
+    out[((((int64_t)co.x * H + co.z) * W + co.w) * c + ch) * D + co.y] = (__bf16)(float)feat[t];
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void densify_bev_bwd_kernel(const __bf16 *__restrict__ dout, const int32_t *__restrict__ coors,
                                                               int64_t n, int batch, int D, int H, int W, int c,
-                                                              float *__restrict__ dfeat) {
+                                                              T *__restrict__ dfeat) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = t / c;
     const int ch = (int)(t - i * c);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void densify_bev_bwd_kernel(const __bf16 *__re
     if ((unsigned)co.x < (unsigned)batch && (unsigned)co.y < (unsigned)D && (unsigned)co.z < (unsigned)H &&
         (unsigned)co.w < (unsigned)W)
         v = (float)dout[((((int64_t)co.x * H + co.z) * W + co.w) * c + ch) * D + co.y];
-    dfeat[t] = v;
+    dfeat[t] = (T)v;
 }
 
 // ---- per-channel finalisation (one tiny launch instead of ~15 elementwise torch kernels) ---------
@@ -419,9 +421,11 @@ static int check_c(int c, const char *who) {
 // A thread owns 8 channels (one 16-byte access).  The ReLU mask of the backward is recomputed from
 // x (y > 0  <=>  fma(x, scale, shift) > 0), so the forward output need not be kept for it.
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
+constexpr int ROW_UNROLL = 4;   // rows per thread and trip in the row-major bf16 kernels
 
 template <bool BWD>
 __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
+                                                                      const __bf16 *__restrict__ y,
                                                                       const float *__restrict__ scale,
                                                                       const float *__restrict__ shift, int relu, int64_t n, int c,
                                                                       int rows_per_block, float *__restrict__ partial) {
@@ -435,28 +439,40 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
-        sc[e] = (BWD && relu) ? scale[grp * 8 + e] : 0.f;
-        sh[e] = (BWD && relu) ? shift[grp * 8 + e] : 0.f;
+        sc[e] = (BWD && relu && !y) ? scale[grp * 8 + e] : 0.f;
+        sh[e] = (BWD && relu && !y) ? shift[grp * 8 + e] : 0.f;
     }
     if (rl < lanes) {
-        for (int64_t r = r0 + rl; r < r1; r += lanes) {
-            const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x + r * c)[grp];
-            if (BWD) {
-                const bf16x8r gv = reinterpret_cast<const bf16x8r *>(dy + r * c)[grp];
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)ROW_UNROLL * lanes) {
+            bf16x8r xv[ROW_UNROLL], gv[ROW_UNROLL], yv[ROW_UNROLL];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xf = (float)xv[e];
-                    float g = (float)gv[e];
-                    if (relu) g = fmaf(xf, sc[e], sh[e]) > 0.f ? g : 0.f;
-                    s0[e] += g;
-                    s1[e] += g * xf;
+            for (int u = 0; u < ROW_UNROLL; ++u) {   // all loads of the trip first; rows past the end re-read row rb
+                const int64_t r = rb + (int64_t)u * lanes < r1 ? rb + (int64_t)u * lanes : rb;
+                xv[u] = reinterpret_cast<const bf16x8r *>(x + r * c)[grp];
+                if (BWD) {
+                    gv[u] = reinterpret_cast<const bf16x8r *>(dy + r * c)[grp];
+                    if (relu && y) yv[u] = reinterpret_cast<const bf16x8r *>(y + r * c)[grp];
                 }
-            } else {
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xf = (float)xv[e];
-                    s0[e] += xf;
-                    s1[e] += xf * xf;
+            for (int u = 0; u < ROW_UNROLL; ++u) {
+                if (rb + (int64_t)u * lanes >= r1) break;
+                if (BWD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xf = (float)xv[u][e];
+                        float g = (float)gv[u][e];
+                        if (relu) g = (y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? g : 0.f;
+                        s0[e] += g;
+                        s1[e] += g * xf;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xf = (float)xv[u][e];
+                        s0[e] += xf;
+                        s1[e] += xf * xf;
+                    }
                 }
             }
         }
@@ -477,8 +493,8 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 // apply kernels: blockDim.x = lanes*c8 (a multiple of c8), thread -> (row lane, 8-channel group); the per-channel constants
 // live in registers, rows are strided over the grid.
 __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
-                                                             const float *__restrict__ shift, int relu, int64_t n, int c8,
-                                                             __bf16 *__restrict__ y) {
+                                                             const float *__restrict__ shift, const __bf16 *__restrict__ res,
+                                                             int relu, int64_t n, int c8, __bf16 *__restrict__ y) {
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8];
 #pragma unroll
@@ -486,47 +502,77 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
         sc[e] = scale[g * 8 + e];
         sh[e] = shift[g * 8 + e];
     }
-    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n; r += (int64_t)gridDim.x * lanes) {
-        const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
-        bf16x8r o;
+    // ROW_UNROLL rows per trip with every load issued before the first use (the kernel is a pure HBM stream: what
+    // matters is bytes in flight per wave); rows past the end re-read the trip's first row and are not stored
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    for (int64_t r0 = (int64_t)blockIdx.x * lanes + rl; r0 < n; r0 += ROW_UNROLL * stride) {
+        bf16x8r xv[ROW_UNROLL], rv[ROW_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = fmaf((float)xv[e], sc[e], sh[e]);
-            if (relu) v = fmaxf(v, 0.f);
-            o[e] = (__bf16)v;
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            const int64_t r = r0 + u * stride < n ? r0 + u * stride : r0;
+            xv[u] = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
+            if (res) rv[u] = reinterpret_cast<const bf16x8r *>(res)[r * c8 + g];
         }
-        reinterpret_cast<bf16x8r *>(y)[r * c8 + g] = o;
+#pragma unroll
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            const int64_t r = r0 + u * stride;
+            if (r >= n) break;
+            bf16x8r o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = fmaf((float)xv[u][e], sc[e], sh[e]);
+                if (res) v += (float)rv[u][e];
+                if (relu) v = fmaxf(v, 0.f);
+                o[e] = (__bf16)v;
+            }
+            reinterpret_cast<bf16x8r *>(y)[r * c8 + g] = o;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ x,
+                                                                 const __bf16 *__restrict__ y,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  int relu, const float *__restrict__ a, const float *__restrict__ b,
                                                                  const float *__restrict__ d, int64_t n, int c8,
-                                                                 __bf16 *__restrict__ dx) {
+                                                                 __bf16 *__restrict__ dx, __bf16 *__restrict__ dres) {
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8], av[8], bv[8], dv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = g * 8 + e;
-        sc[e] = relu ? scale[ch] : 0.f;
-        sh[e] = relu ? shift[ch] : 0.f;
+        sc[e] = (relu && !y) ? scale[ch] : 0.f;
+        sh[e] = (relu && !y) ? shift[ch] : 0.f;
         av[e] = a[ch];
         bv[e] = b[ch];
         dv[e] = d[ch];
     }
-    for (int64_t r = (int64_t)blockIdx.x * lanes + rl; r < n; r += (int64_t)gridDim.x * lanes) {
-        const bf16x8r xv = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
-        const bf16x8r gv = reinterpret_cast<const bf16x8r *>(dy)[r * c8 + g];
-        bf16x8r o;
+    const int64_t stride = (int64_t)gridDim.x * lanes;
+    for (int64_t r0 = (int64_t)blockIdx.x * lanes + rl; r0 < n; r0 += ROW_UNROLL * stride) {
+        bf16x8r xv[ROW_UNROLL], gv[ROW_UNROLL], yv[ROW_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xf = (float)xv[e];
-            float gg = (float)gv[e];
-            if (relu) gg = fmaf(xf, sc[e], sh[e]) > 0.f ? gg : 0.f;
-            o[e] = (__bf16)fmaf(av[e], gg, fmaf(bv[e], xf, dv[e]));
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            const int64_t r = r0 + u * stride < n ? r0 + u * stride : r0;
+            xv[u] = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
+            gv[u] = reinterpret_cast<const bf16x8r *>(dy)[r * c8 + g];
+            if (relu && y) yv[u] = reinterpret_cast<const bf16x8r *>(y)[r * c8 + g];
         }
-        reinterpret_cast<bf16x8r *>(dx)[r * c8 + g] = o;
+#pragma unroll
+        for (int u = 0; u < ROW_UNROLL; ++u) {
+            const int64_t r = r0 + u * stride;
+            if (r >= n) break;
+            bf16x8r o, gm;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xf = (float)xv[u][e];
+                float gg = (float)gv[u][e];
+                if (relu) gg = (y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? gg : 0.f;
+                gm[e] = (__bf16)gg;
+                o[e] = (__bf16)fmaf(av[e], gg, fmaf(bv[e], xf, dv[e]));
+            }
+            reinterpret_cast<bf16x8r *>(dx)[r * c8 + g] = o;
+            if (dres) reinterpret_cast<bf16x8r *>(dres)[r * c8 + g] = gm;   // gradient of the residual branch: masked dy
+        }
     }
 }
 
@@ -677,27 +723,35 @@ extern "C" int s2d_densify_bwd_f32(const float *dout, const int32_t *coors, int6
 }
 
 
-extern "C" int s2d_densify_bev_fwd_bf16(const float *feat, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
-                                        int c, void *out, s2d_stream_t stream) {
+extern "C" int s2d_densify_bev_fwd_bf16(const void *feat, int feat_bf16, const int32_t *coors, int64_t n, int batch,
+                                        const int32_t shape[3], int c, void *out, s2d_stream_t stream) {
     S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0 && out, "densify_bev_fwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 2;
     S2D_HIP(hipMemsetAsync(out, 0, bytes, st));
     if (n == 0) return S2D_OK;
     S2D_CHECK_ARG(feat && coors, "densify_bev_fwd: null input");
-    hipLaunchKernelGGL(densify_bev_fwd_kernel, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, st, feat, coors, n, batch,
-                       shape[0], shape[1], shape[2], c, (__bf16 *)out);
+    if (feat_bf16)
+        hipLaunchKernelGGL(densify_bev_fwd_kernel<__bf16>, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, st,
+                           (const __bf16 *)feat, coors, n, batch, shape[0], shape[1], shape[2], c, (__bf16 *)out);
+    else
+        hipLaunchKernelGGL(densify_bev_fwd_kernel<float>, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, st,
+                           (const float *)feat, coors, n, batch, shape[0], shape[1], shape[2], c, (__bf16 *)out);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
 extern "C" int s2d_densify_bev_bwd_bf16(const void *dout, const int32_t *coors, int64_t n, int batch, const int32_t shape[3],
-                                        int c, float *dfeat, s2d_stream_t stream) {
+                                        int c, void *dfeat, int feat_bf16, s2d_stream_t stream) {
     S2D_CHECK_ARG(n >= 0 && batch > 0 && shape && c > 0, "densify_bev_bwd: bad argument");
     if (n == 0) return S2D_OK;
     S2D_CHECK_ARG(dout && coors && dfeat, "densify_bev_bwd: null argument");
-    hipLaunchKernelGGL(densify_bev_bwd_kernel, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16 *)dout, coors, n, batch, shape[0], shape[1], shape[2], c, dfeat);
+    if (feat_bf16)
+        hipLaunchKernelGGL(densify_bev_bwd_kernel<__bf16>, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16 *)dout, coors, n, batch, shape[0], shape[1], shape[2], c, (__bf16 *)dfeat);
+    else
+        hipLaunchKernelGGL(densify_bev_bwd_kernel<float>, dim3((unsigned)ceil_div(n * c, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16 *)dout, coors, n, batch, shape[0], shape[1], shape[2], c, (float *)dfeat);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -846,11 +900,11 @@ extern "C" size_t s2d_bnrow_workspace_bytes(int64_t n, int c) {
 
 // fwd=1: x -> (sum x, sum x^2); fwd=0: (dy, x, scale, shift, relu) -> (sum g, sum g*x).  out: [2c] sums when
 // fin == nullptr-style split mode is wanted (stats != nullptr), else fused finalisation.
-static int bnrow_reduce(bool bwd, const void *x, const void *dy, const float *scale, const float *shift, int relu, int64_t n,
-                        int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who) {
+static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, const float *scale, const float *shift, int relu,
+                        int64_t n, int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who) {
     int rc = check_c8(c, who);
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || (scale && shift)), "bnrow reduce: bad argument");
+    S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || y || (scale && shift)), "bnrow reduce: bad argument");
     RedPlan p = row_plan_bf16(n, c);
     if (!ws || ws_bytes < p.ws_bytes) {
         set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, p.ws_bytes);
@@ -858,11 +912,11 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const float *sc
     }
     if (bwd)
         hipLaunchKernelGGL(row_reduce_bf16_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
-                           (const __bf16 *)dy, scale, shift, relu, n, c, p.rows_per_block, (float *)ws);
+                           (const __bf16 *)dy, (const __bf16 *)y, scale, shift, relu, n, c, p.rows_per_block, (float *)ws);
     else
         hipLaunchKernelGGL(row_reduce_bf16_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
-                           (const __bf16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, n, c, p.rows_per_block,
-                           (float *)ws);
+                           (const __bf16 *)nullptr, (const __bf16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, n, c,
+                           p.rows_per_block, (float *)ws);
     *plan_out = p;
     return S2D_OK;
 }
@@ -872,7 +926,7 @@ extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stat
     S2D_CHECK_ARG(stats, "bnrow_stats: null stats");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats");
+    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, stats);
     S2D_LAUNCH_CHECK();
@@ -886,7 +940,7 @@ extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, co
     S2D_CHECK_ARG(gamma && beta && mean && invstd && scale && shift, "bnrow_stats_finalize: bad argument");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats_finalize");
+    int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats_finalize");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
@@ -895,38 +949,39 @@ extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, co
     return S2D_OK;
 }
 
-extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, int relu, int64_t n, int c, void *y,
-                                    s2d_stream_t stream) {
+extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, const void *residual, int relu,
+                                    int64_t n, int c, void *y, s2d_stream_t stream) {
     int rc = check_c8(c, "bnrow_apply");
     if (rc) return rc;
     S2D_CHECK_ARG(n > 0 && x && y && scale && shift, "bnrow_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
     hipLaunchKernelGGL(row_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, scale,
-                       shift, relu, n, c / 8, (__bf16 *)y);
+                       shift, (const __bf16 *)residual, relu, n, c / 8, (__bf16 *)y);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
-extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
-                                         int64_t n, int c, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const void *y, const float *scale, const float *shift,
+                                         int relu, int64_t n, int c, float *sums, void *ws, size_t ws_bytes,
+                                         s2d_stream_t stream) {
     S2D_CHECK_ARG(sums, "bnrow_bwd_reduce: null sums");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(true, x, dy, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
+    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
-extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
-                                                  int64_t n, int c, const float *gamma, const float *mean, const float *invstd,
+extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const void *y, const float *scale,
+                                                  const float *shift, int relu, int64_t n, int c, const float *gamma, const float *mean, const float *invstd,
                                                   float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
                                                   size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(gamma && mean && invstd && dgamma && dbeta && a && b && d, "bnrow_bwd_reduce_finalize: bad argument");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(true, x, dy, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize");
+    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
@@ -934,15 +989,15 @@ extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x,
     return S2D_OK;
 }
 
-extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const float *scale, const float *shift, int relu,
-                                        const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
-                                        s2d_stream_t stream) {
+extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const void *y, const float *scale, const float *shift,
+                                        int relu, const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
+                                        void *dres, s2d_stream_t stream) {
     int rc = check_c8(c, "bnrow_bwd_apply");
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || (scale && shift)), "bnrow_bwd_apply: bad argument");
+    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || y || (scale && shift)), "bnrow_bwd_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
     hipLaunchKernelGGL(row_bwd_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)dy,
-                       (const __bf16 *)x, scale, shift, relu, a, b, d, n, c / 8, (__bf16 *)dx);
+                       (const __bf16 *)x, (const __bf16 *)y, scale, shift, relu, a, b, d, n, c / 8, (__bf16 *)dx, (__bf16 *)dres);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -35,6 +35,15 @@ void set_error(const char *fmt, ...);
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with a private 4 MiB L2.
+// Launch xcd_grid(tiles) workgroups and map id -> xcd_tile(id, grid): every XCD then works on one contiguous
+// eighth of the tiles, so neighbouring tiles (which share gathered rows / halo pixels) hit the same L2.
+constexpr int S2D_XCDS = 8;
+static inline unsigned xcd_grid(int64_t tiles) { return (unsigned)(ceil_div(tiles, S2D_XCDS) * S2D_XCDS); }
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_tile(int block_id, int grid) { return (block_id % S2D_XCDS) * (grid / S2D_XCDS) + block_id / S2D_XCDS; }
+#endif
+
 // carve aligned sub-buffers out of a caller workspace
 struct Carver {
     char *base;

@@ -33,6 +33,35 @@ struct VecF<2> { typedef float2 type; };
 template <>
 struct VecF<4> { typedef float4 type; };
 
+// bf16 bit patterns (low 16 bits of a 32-bit value) of N consecutive elements at p; T = float (rounded here) or __bf16
+typedef unsigned u32v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bf16_bits(float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); }
+template <typename T, int N>
+__device__ __forceinline__ void load_bf16_bits(const T *__restrict__ p, unsigned (&out)[N]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (N == 1) {
+            out[0] = bf16_bits(*reinterpret_cast<const float *>(p));
+        } else if constexpr (N == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(p);
+            out[0] = bf16_bits(v.x); out[1] = bf16_bits(v.y);
+        } else {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            out[0] = bf16_bits(v.x); out[1] = bf16_bits(v.y); out[2] = bf16_bits(v.z); out[3] = bf16_bits(v.w);
+        }
+    } else {
+        if constexpr (N == 1) {   // the aligned 32-bit word holding the element, then a shift (no 16-bit loads)
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+            const unsigned w = *reinterpret_cast<const unsigned *>(a & ~(uintptr_t)3);
+            out[0] = (a & 2) ? (w >> 16) : (w & 0xffffu);
+        } else if constexpr (N == 2) {
+            const unsigned w = *reinterpret_cast<const unsigned *>(p);
+            out[0] = w & 0xffffu; out[1] = w >> 16;
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2 *>(p);
+            out[0] = w.x & 0xffffu; out[1] = w.x >> 16; out[2] = w.y & 0xffffu; out[3] = w.y >> 16;
+        }
+    }
+}
 __device__ __forceinline__ float vec_get(const float &v, int) { return v; }
 __device__ __forceinline__ float vec_get(const float2 &v, int i) { return i == 0 ? v.x : v.y; }
 __device__ __forceinline__ float vec_get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -255,13 +284,12 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
 // Lane (i16, q) owns pairs 8q..8q+7 of a 32-pair group and loads, for each of them, its float4 /
 // float2 channel slice of in[j] and dout[o]; the k-contiguous bf16x8 fragments are assembled in
 // registers (the "transpose" costs nothing: every lane simply loads the elements it multiplies).
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void spconv_wgrad_bf16(const float *__restrict__ in, const float *__restrict__ dout,
+template <int CIN, int COUT, typename T>
+__global__ __launch_bounds__(256) void spconv_wgrad_bf16(const T *__restrict__ in, const T *__restrict__ dout,
                                                          const int32_t *__restrict__ nbr, int n_out, int kvol,
                                                          int rows_per_split, float *__restrict__ partial) {
     typedef WgradCfg<CIN, COUT> C;
-    typedef typename VecF<C::VA>::type veca;
-    typedef typename VecF<C::VB>::type vecb;
+    typedef typename VecF<C::VB>::type vecb_out;
     __shared__ int2 pair_lds[4][64];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,8 +321,9 @@ __global__ __launch_bounds__(256) void spconv_wgrad_bf16(const float *__restrict
         if (j_l >= 0) mypairs[rank] = make_int2(o_l, j_l);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int g = 0; 32 * g < cnt; ++g) {
-            veca av[8][C::LA];
-            vecb bv[8];
+            // elements are carried as bf16 bit patterns in the low half of a 32-bit register; the k-contiguous MFMA
+            // fragments are assembled with 32-bit selects/shifts/ors
+            unsigned abits[8][C::LA][C::VA], bbits[8][C::VB];
             // branch-free: out-of-range slots re-load the last valid pair and are zeroed by a select
             // (a branch around each load makes hipcc wait per element and serialises the gathers)
 #pragma unroll
@@ -302,23 +331,28 @@ __global__ __launch_bounds__(256) void spconv_wgrad_bf16(const float *__restrict
                 const int idx = 32 * g + 8 * q + e;
                 const int2 pr = mypairs[min(idx, cnt - 1)];
 #pragma unroll
-                for (int la = 0; la < C::LA; ++la)
-                    av[e][la] = *reinterpret_cast<const veca *>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16);
-                bv[e] = *reinterpret_cast<const vecb *>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16);
+                for (int la = 0; la < C::LA; ++la) load_bf16_bits<T, C::VA>(in + (int64_t)pr.y * CIN + 64 * la + C::VA * i16, abits[e][la]);
+                load_bf16_bits<T, C::VB>(dout + (int64_t)pr.x * COUT + co_base + C::VB * i16, bbits[e]);
             }
             const int nvalid = cnt - 32 * g - 8 * q;  // this lane's valid slots: e < nvalid
             bf16x8 bfr[C::VB];
 #pragma unroll
-            for (int f = 0; f < C::VB; ++f)
+            for (int f = 0; f < C::VB; ++f) {
+                u32v4 w;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bfr[f][e] = (__bf16)(e < nvalid ? vec_get(bv[e], f) : 0.f);
+                for (int h = 0; h < 4; ++h)
+                    w[h] = (2 * h < nvalid ? bbits[2 * h][f] : 0u) | ((2 * h + 1 < nvalid ? bbits[2 * h + 1][f] : 0u) << 16);
+                bfr[f] = __builtin_bit_cast(bf16x8, w);
+            }
 #pragma unroll
             for (int la = 0; la < C::LA; ++la)
 #pragma unroll
                 for (int t = 0; t < C::VA; ++t) {
-                    bf16x8 afr;
+                    u32v4 w;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) afr[e] = (__bf16)(e < nvalid ? vec_get(av[e][la], t) : 0.f);
+                    for (int h = 0; h < 4; ++h)
+                        w[h] = (2 * h < nvalid ? abits[2 * h][la][t] : 0u) | ((2 * h + 1 < nvalid ? abits[2 * h + 1][la][t] : 0u) << 16);
+                    const bf16x8 afr = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
                     for (int f = 0; f < C::VB; ++f)
                         acc[la][t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[f], acc[la][t][f], 0, 0, 0);
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_bf16(const float *__restrict
                 float tmp[C::VB];
 #pragma unroll
                 for (int f = 0; f < C::VB; ++f) tmp[f] = acc[la][e][f][reg];
-                *reinterpret_cast<vecb *>(dst + (int64_t)ci * COUT + co_base + C::VB * i16) = *reinterpret_cast<vecb *>(tmp);
+                *reinterpret_cast<vecb_out *>(dst + (int64_t)ci * COUT + co_base + C::VB * i16) = *reinterpret_cast<vecb_out *>(tmp);
             }
 }
 
@@ -448,13 +482,16 @@ static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
     return p;
 }
 
-static bool g_wgrad_bf16 = false;  // set per call by the _bf16 entry point (host side, single-threaded per stream)
+static int g_wgrad_mode = 0;  // 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf16 MFMA on bf16 storage (set per call by the entry points)
 
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
-    if (g_wgrad_bf16)
-        hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
+    if (g_wgrad_mode == 2)
+        hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, __bf16>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
+                           (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
+    else if (g_wgrad_mode == 1)
+        hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, float>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
                            kvol, p.rows_per_split, partial);
     else
         hipLaunchKernelGGL((spconv_wgrad_mfma<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
@@ -517,16 +554,31 @@ static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, con
 extern "C" int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
                                     int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
                                     s2d_stream_t stream) {
-    g_wgrad_bf16 = false;
+    g_wgrad_mode = 0;
     return wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
 }
 
 extern "C" int s2d_spconv_wgrad_bf16(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
                                      int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
                                      s2d_stream_t stream) {
-    g_wgrad_bf16 = true;
+    g_wgrad_mode = 1;
     int rc = wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
-    g_wgrad_bf16 = false;
+    g_wgrad_mode = 0;
+    return rc;
+}
+
+// bf16-storage ("s16") weight gradient: in_feat / dout are bf16 [n][c]; cin, cout in {16,32,64,128}
+extern "C" int s2d_spconv_s16_wgrad(const void *in_feat, int64_t n_in, const void *dout, const int32_t *nbr, int64_t n_out,
+                                    int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    const bool ok = (cin == 16 || cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
+    if (!ok) {
+        set_error("spconv_s16_wgrad: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    g_wgrad_mode = 2;
+    int rc = wgrad_impl((const float *)in_feat, n_in, (const float *)dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes,
+                        stream);
+    g_wgrad_mode = 0;
     return rc;
 }
 

@@ -1,0 +1,338 @@
+// Sparse-conv implicit GEMM with bf16 feature storage ("s16" path): features, gathered rows and the
+// output are bf16 [n][C] in HBM, weights a pre-packed bf16 LDS image, accumulation fp32 on
+// v_mfma_f32_16x16x32_bf16.  Used for the forward (nbr = output->input map) and, with the
+// transposed / mirrored weight image, for the data gradient
+// (spconv.ops.indice_conv / indice_conv_backward; call sites det3d/models/backbones/scn.py:104-152).
+//
+// The GEMM's K axis is the concatenation over kernel offsets of the input channels.  One K-step is
+// 64 K-elements: 64/CIN offsets when CIN < 64, one offset's 64-channel chunk otherwise.  A workgroup
+// (4 waves) owns BM output rows x all COUT columns.  Per K-step the A tile [BM rows][64] is gathered
+// row by row with global_load_lds (16 B per lane; a missing neighbour reads a zero page) and the B
+// tile (64 x COUT, pre-packed in fragment order) is a linear global_load_lds copy; both are double
+// buffered with one barrier per K-step.  The workgroup's slice of the gather map (all offsets x BM rows)
+// is copied to LDS once up front, so a step's gathers hang off an LDS read, not a second global trip.  The A image
+// is [row][8 parts of 16 B] with the part index XOR-swizzled by (row & 7) so that the 16-lane groups
+// of a ds_read_b128 fragment read touch 16 distinct bank slots.  Each stager marks the 16-row MFMA
+// tile it found a neighbour for; waves skip the MFMAs of tiles with no valid row at this K-step.
+#include "s2d_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace s2d {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+
+__host__ __device__ inline int s16_steps(int cin, int kvol) { return cin < 64 ? (kvol + 64 / cin - 1) / (64 / cin) : kvol * (cin / 64); }
+// kernel-offset slots covered by the K-steps (>= kvol; the phantom slots read zero rows and zero weights)
+__host__ __device__ inline int s16_kslots(int cin, int kvol) { return cin < 64 ? s16_steps(cin, kvol) * (64 / cin) : kvol; }
+
+template <int CIN, int COUT, int BM>
+struct S16Cfg {
+    static constexpr int OPS = CIN < 64 ? 64 / CIN : 1;   // kernel offsets per K-step
+    static constexpr int CPO = CIN > 64 ? CIN / 64 : 1;   // K-steps per kernel offset
+    static constexpr int PPO = CIN < 64 ? CIN / 8 : 8;    // 16-byte parts per offset inside a K-step
+    static constexpr int WN = COUT == 128 ? 2 : ((COUT == 64 && BM == 64) ? 2 : 1);
+    static constexpr int WM = 4 / WN;
+    static constexpr int MI = BM / WM / 16;               // 16-row MFMA tiles per wave
+    static constexpr int NJ = COUT / WN / 16;             // 16-col MFMA tiles per wave
+    static constexpr int A_BYTES = BM * 64 * 2;
+    static constexpr int B_BYTES = 64 * COUT * 2;
+    static constexpr int A_LOADS = BM * 8 / 256;          // 16-byte chunks per thread per K-step
+    static constexpr int TILES = BM / 16;
+    static constexpr size_t LDS_FIXED = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES + 3 * 16 * sizeof(int);
+    static size_t lds_bytes(int kvol) { return LDS_FIXED + (size_t)s16_kslots(CIN, kvol) * BM * sizeof(int); }
+    static_assert(MI >= 1 && NJ >= 1, "bad tiling");
+};
+
+// packed image: [step][h (2)][nt = cout/16][q (4)][c (16)][e (8)]   (one K-step = 64*cout bf16, contiguous)
+//   K element kk = 32 h + 8 q + e ;  column co = wn*(cout/WN) + c*NJ + n  with nt = wn*NJ + n
+// source w: [K][cin][cout] fp32, or [K][cout][cin] when transpose (data gradient), offsets mirrored when flip.
+__global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int wn_count,
+                                                       int transpose, int flip, __bf16 *__restrict__ out) {
+    const int steps = s16_steps(cin, kvol);
+    const int64_t total = (int64_t)steps * 64 * cout;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ntile = cout / 16, nj = ntile / wn_count;
+    int64_t r = i;
+    const int e = r % 8; r /= 8;
+    const int c = r % 16; r /= 16;
+    const int q = r % 4; r /= 4;
+    const int nt = r % ntile; r /= ntile;
+    const int h = r % 2; r /= 2;
+    const int step = (int)r;
+    const int kk = 32 * h + 8 * q + e;
+    int k, ch;
+    if (cin < 64) {
+        k = step * (64 / cin) + kk / cin;
+        ch = kk % cin;
+    } else {
+        k = step / (cin / 64);
+        ch = (step % (cin / 64)) * 64 + kk;
+    }
+    const int co = (nt / nj) * (cout / wn_count) + c * nj + (nt % nj);
+    float v = 0.f;
+    if (k < kvol) {
+        const int ks = flip ? kvol - 1 - k : k;
+        v = transpose ? w[((int64_t)ks * cout + co) * cin + ch] : w[((int64_t)ks * cin + ch) * cout + co];
+    }
+    out[i] = (__bf16)v;
+}
+
+template <int CIN, int COUT, int BM>
+__global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__restrict__ in, const __bf16 *__restrict__ wpack,
+                                                             const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                                                             const __bf16 *__restrict__ zero_page, int n_out, int kvol,
+                                                             int rows_per_block, __bf16 *__restrict__ out) {
+    // rows_per_block <= BM (multiple of 16): the launcher shrinks it so that the grid fills whole rounds of resident
+    // workgroups; the tiles past it stay unmarked and are skipped.
+    typedef S16Cfg<CIN, COUT, BM> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * C::A_BYTES; };
+    auto bbuf = [&](int b) -> char * { return smem + 2 * C::A_BYTES + b * C::B_BYTES; };
+    volatile int *flags = reinterpret_cast<volatile int *>(smem + 2 * C::A_BYTES + 2 * C::B_BYTES);   // [3][16]
+    int *idx_lds = reinterpret_cast<int *>(smem + 2 * C::A_BYTES + 2 * C::B_BYTES + 3 * 16 * sizeof(int));   // [kslots][BM]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid / C::WN, wn = wid % C::WN;
+    const int r = lane & 15, q = lane >> 4;
+    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * rows_per_block;
+    if (row0 >= n_out) return;
+    const int row_end = min(n_out, row0 + rows_per_block);
+    const int steps = s16_steps(CIN, kvol);
+
+    // staging role of this thread: LDS slot (row = id>>3, s = id&7) of chunk ids id = t + 256u holds part s ^ (row&7)
+    const int prt = (t & 7) ^ ((t >> 3) & 7);
+    const int oslot = CIN < 64 ? prt / C::PPO : 0;
+    const int choff = (CIN < 64 ? prt % C::PPO : prt) * 8;
+
+    // the block's whole gather-map slice lives in LDS (one coalesced pass up front): the per-step gathers then
+    // depend on an LDS read, not on a second global round trip
+    auto load_idx = [&](int s, int (&j)[C::A_LOADS]) {
+        const int k = CIN < 64 ? s * C::OPS + oslot : s / C::CPO;
+#pragma unroll
+        for (int u = 0; u < C::A_LOADS; ++u) j[u] = idx_lds[k * BM + (t >> 3) + 32 * u];
+    };
+    auto stage = [&](int s, int buf, const int (&j)[C::A_LOADS]) {
+        const int chunk = CIN > 64 ? (s % C::CPO) * 64 : 0;
+        volatile int *fl = flags + (s % 3) * 16;
+#pragma unroll
+        for (int u = 0; u < C::A_LOADS; ++u) {
+            const __bf16 *src = j[u] >= 0 ? in + (int64_t)j[u] * CIN + chunk + choff : zero_page;
+            char *dst = abuf(buf) + (size_t)(t - lane + 256 * u) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            if (j[u] >= 0) fl[(t >> 7) + 2 * u] = 1;   // 16-row tile of row (t>>3) + 32u
+        }
+        constexpr int B_UNITS = C::B_BYTES / 1024;
+        const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)s * C::B_BYTES;
+#pragma unroll
+        for (int u = 0; u < (B_UNITS + 3) / 4; ++u) {
+            const int unit = u * 4 + wid;
+            if (unit < B_UNITS) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + unit * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4s acc[C::MI][C::NJ];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < C::NJ; ++jn) acc[i][jn] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+    if (t < 48) flags[t] = 0;
+    {
+        const int kslots = s16_kslots(CIN, kvol);
+        for (int e = t; e < kslots * BM; e += 256) {
+            const int k = e / BM, row = row0 + (e - k * BM);
+            idx_lds[e] = (k < kvol && row < row_end) ? nbr[(int64_t)k * n_out + row] : -1;
+        }
+    }
+    int jn_[C::A_LOADS];
+    __syncthreads();
+    load_idx(0, jn_);
+    stage(0, 0, jn_);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (t < 16) flags[((s + 2) % 3) * 16 + t] = 0;   // last read in step s-1, next set while staging step s+2
+        if (s + 1 < steps) {
+            load_idx(s + 1, jn_);
+            stage(s + 1, cur ^ 1, jn_);
+        }
+        int on[C::MI];
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) on[i] = __builtin_amdgcn_readfirstlane(flags[(s % 3) * 16 + wm * C::MI + i]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8s b[C::NJ];
+#pragma unroll
+            for (int jn = 0; jn < C::NJ; ++jn)
+                b[jn] = *reinterpret_cast<const bf16x8s *>(bbuf(cur) + ((h * (COUT / 16) + wn * C::NJ + jn) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                if (on[i]) {
+                    const bf16x8s a = *reinterpret_cast<const bf16x8s *>(
+                        abuf(cur) + ((wm * 16 * C::MI + 16 * i + r) * 8 + ((4 * h + q) ^ (r & 7))) * 16);
+#pragma unroll
+                    for (int jn = 0; jn < C::NJ; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout row = 4*(lane>>4)+reg, col = lane&15 -> columns co_base + r*NJ + jn (NJ consecutive)
+    const int co_base = wn * (COUT / C::WN);
+    float bv[C::NJ];
+#pragma unroll
+    for (int jn = 0; jn < C::NJ; ++jn) bv[jn] = bias ? bias[co_base + r * C::NJ + jn] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + wm * 16 * C::MI + 16 * i + 4 * q + reg;
+            if (row < row_end) {
+                __bf16 *dst = out + (int64_t)row * COUT + co_base + r * C::NJ;
+                if (C::NJ == 4) {
+                    bf16x4s v;
+                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % C::NJ][reg] + bv[1 % C::NJ]);
+                    v[2] = (__bf16)(acc[i][2 % C::NJ][reg] + bv[2 % C::NJ]); v[3] = (__bf16)(acc[i][3 % C::NJ][reg] + bv[3 % C::NJ]);
+                    *reinterpret_cast<bf16x4s *>(dst) = v;
+                } else if (C::NJ == 2) {
+                    bf16x2s v;
+                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % C::NJ][reg] + bv[1 % C::NJ]);
+                    *reinterpret_cast<bf16x2s *>(dst) = v;
+                } else {
+                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
+                }
+            }
+        }
+}
+
+static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
+
+// Launch plan (tile template height and rows per workgroup).
+struct S16Plan {
+    int bm, rows_per_block;
+    unsigned grid;
+};
+static S16Plan s16_plan(int64_t n_out, int kvol, int cin, int cout) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    if (const char *ov = getenv("S2D_S16_PLAN")) {   // tuning hook: "bm,rows_per_block"
+        int bm = 0, rpb = 0;
+        if (sscanf(ov, "%d,%d", &bm, &rpb) == 2 && (bm == 64 || bm == 128 || (bm == 256 && cout != 128)) && rpb >= 16 && rpb <= bm &&
+            rpb % 16 == 0)
+            return S16Plan{bm, rpb, (unsigned)ceil_div(n_out, rpb)};
+    }
+    // measured on MI355X over the stages of the 150k-point scene (scratch sweep, r01): the K loop is bound by gather
+    // round trips, so what counts is rows resident per CU; 64-row tiles (3-4 workgroups per CU) win everywhere except
+    // at 128 output channels, where the 16 KiB weight tile per step makes 128-row tiles cheaper per row.  Shrinking the
+    // rows per workgroup below the template height never paid.
+    (void)cus; (void)kvol; (void)cin;
+    const int bm = cout == 128 ? 128 : 64;
+    S16Plan best{bm, bm, (unsigned)ceil_div(n_out, bm)};
+    return best;
+}
+
+template <int CIN, int COUT, int BM>
+static int s16_launch(const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias, const int32_t *nbr,
+                      const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
+    typedef S16Cfg<CIN, COUT, BM> C;
+    auto kern = spconv_fwd_s16_kernel<CIN, COUT, BM>;
+    static size_t attr_bytes = 48 * 1024;   // per instantiation; raising the limit is idempotent if raced
+    const size_t lds = C::lds_bytes(kvol);
+    if (lds > attr_bytes) {
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(p.grid)), dim3(256), lds, st, in, wpack, bias, nbr, zero_page, n_out, kvol,
+                       p.rows_per_block, out);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+template <int CIN, int COUT>
+static int s16_dispatch_bm(const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias, const int32_t *nbr,
+                           const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
+    if (p.bm == 64) return s16_launch<CIN, COUT, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+    if (p.bm == 128) return s16_launch<CIN, COUT, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+    if constexpr (COUT != 128) return s16_launch<CIN, COUT, 256>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+    return S2D_ERR_UNSUPPORTED;
+}
+
+template <int CIN>
+static int s16_dispatch_cout(int cout, const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias,
+                             const int32_t *nbr, const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
+    switch (cout) {
+        case 16: return s16_dispatch_bm<CIN, 16>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+        case 32: return s16_dispatch_bm<CIN, 32>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+        case 64: return s16_dispatch_bm<CIN, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+        case 128: return s16_dispatch_bm<CIN, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+    }
+    return S2D_ERR_UNSUPPORTED;
+}
+
+static bool s16_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" int s2d_spconv_s16_supported(int cin, int cout) { return s16_ok(cin) && s16_ok(cout); }
+
+extern "C" size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout) {
+    if (!s2d_spconv_s16_supported(cin, cout) || kvol <= 0) return 0;
+    return (size_t)s16_steps(cin, kvol) * 64 * cout;
+}
+
+extern "C" int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int cin, int cout, int transpose, int flip,
+                                           int64_t n_out, void *packed, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed && kvol > 0 && n_out >= 0, "spconv_s16_pack: bad argument");
+    if (!s2d_spconv_s16_supported(cin, cout)) {
+        set_error("spconv_s16_pack: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)s2d_spconv_s16_packed_elems(kvol, cin, cout);
+    hipLaunchKernelGGL(s16_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, kvol, cin,
+                       cout, s16_wn(cout, s16_plan(n_out, kvol, cin, cout).bm), transpose, flip, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias,
+                                  const int32_t *nbr, int64_t n_out, int kvol, int cin, int cout, const void *zero_page,
+                                  void *out_feat, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0, "spconv_s16_fwd: bad sizes");
+    if (!s2d_spconv_s16_supported(cin, cout)) {
+        set_error("spconv_s16_fwd: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (n_out == 0) return S2D_OK;
+    S2D_CHECK_ARG(in_feat && packed_weight && nbr && out_feat && zero_page && n_in > 0, "spconv_s16_fwd: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *in = (const __bf16 *)in_feat, *wp = (const __bf16 *)packed_weight, *zp = (const __bf16 *)zero_page;
+    __bf16 *out = (__bf16 *)out_feat;
+    const S16Plan plan = s16_plan(n_out, kvol, cin, cout);
+    switch (cin) {
+        case 16: return s16_dispatch_cout<16>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
+        case 32: return s16_dispatch_cout<32>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
+        case 64: return s16_dispatch_cout<64>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
+        case 128: return s16_dispatch_cout<128>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
+    }
+    return S2D_ERR_UNSUPPORTED;
+}

@@ -145,29 +145,30 @@ def _dist_sync():
 
 
 class _BNRowFn(torch.autograd.Function):
-    """x: bf16 channels_last [N,C,H,W].  Training statistics over N*H*W (all ranks when `sync`)."""
+    """Batch norm over the rows of a row-major bf16 matrix: x is bf16 channels_last [N,C,H,W] (rows = N*H*W) or a
+    sparse feature matrix [n,C].  y = relu?(bn(x) + residual?).  Training statistics over all rows (of all ranks when
+    `sync`)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, relu, eps, sync, module, training):
+    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training):
         import torch.distributed as dist
         from . import hip_ops as H
         lib = _lib.load()
-        n_img, c, h, w = x.shape
-        rows = n_img * h * w
+        c = x.shape[1]
+        rows = x.numel() // c
         dev = x.device
         gamma = gamma.float().contiguous()
         beta = beta.float().contiguous()
         track = module.track_running_stats
         ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
         count = None
+        rm, rv, nbt = (module.running_mean, module.running_var, module.num_batches_tracked) if track else (None, None, None)
         if training and not sync:
             fin = torch.empty((4, c), dtype=torch.float32, device=dev)
             check(lib.s2d_bnrow_stats_finalize_bf16(_ptr(x), rows, c, _ptr(gamma), _ptr(beta), float(eps),
                                                     float(module.momentum if track else 0.0), _ptr(fin[0]), _ptr(fin[1]),
-                                                    _ptr(fin[2]), _ptr(fin[3]), _ptr(module.running_mean if track else None),
-                                                    _ptr(module.running_var if track else None),
-                                                    _ptr(module.num_batches_tracked if track else None), _ptr(ws), ws.numel(),
-                                                    _stream()), "s2d_bnrow_stats_finalize_bf16")
+                                                    _ptr(fin[2]), _ptr(fin[3]), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(ws),
+                                                    ws.numel(), _stream()), "s2d_bnrow_stats_finalize_bf16")
         elif training:
             packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)
             check(lib.s2d_bnrow_stats_bf16(_ptr(x), rows, c, _ptr(packed), _ptr(ws), ws.numel(), _stream()),
@@ -176,18 +177,19 @@ class _BNRowFn(torch.autograd.Function):
             dist.all_reduce(packed)
             count = packed[-1:].contiguous()
             fin = H.bn1d_finalize_fwd(packed[:-1].contiguous(), count, gamma, beta, eps, module.momentum if track else 0.0,
-                                      module.running_mean if track else None, module.running_var if track else None,
-                                      module.num_batches_tracked if track else None)
+                                      rm, rv, nbt)
         else:
             invstd = torch.rsqrt(module.running_var.float() + eps)
             scale = gamma * invstd
             fin = torch.stack([module.running_mean.float(), invstd, scale, beta - module.running_mean.float() * scale])
-        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+        scale, shift = fin[2], fin[3]
         y = torch.empty_like(x)   # preserves channels_last
-        check(lib.s2d_bnrow_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), int(relu), rows, c, _ptr(y), _stream()),
+        check(lib.s2d_bnrow_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), rows, c, _ptr(y), _stream()),
               "s2d_bnrow_apply_bf16")
-        ctx.save_for_backward(x, gamma, fin, count)
-        ctx.relu, ctx.sync, ctx.training = relu, sync, training
+        has_res = residual is not None
+        # with a residual the ReLU mask cannot be recomputed from x alone: keep y
+        ctx.save_for_backward(x, gamma, fin, count, y if (has_res and relu) else None)
+        ctx.relu, ctx.sync, ctx.training, ctx.has_res = relu, sync, training, has_res
         return y
 
     @staticmethod
@@ -195,24 +197,24 @@ class _BNRowFn(torch.autograd.Function):
         import torch.distributed as dist
         from . import hip_ops as H
         lib = _lib.load()
-        x, gamma, fin, count = ctx.saved_tensors
+        x, gamma, fin, count, y = ctx.saved_tensors
         mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
-        n_img, c, h, w = x.shape
-        rows = n_img * h * w
+        c = x.shape[1]
+        rows = x.numel() // c
         dev = x.device
-        dy = _nhwc_bf16(dy)
+        dy = _nhwc_bf16(dy) if x.dim() == 4 else dy.to(torch.bfloat16).contiguous()
         relu = int(ctx.relu)
         ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
         if ctx.training and not ctx.sync:
             out = torch.empty((5, c), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(gamma),
-                                                         _ptr(mean), _ptr(invstd), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
-                                                         _ptr(out[3]), _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
+            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, rows, c,
+                                                         _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(out[0]), _ptr(out[1]),
+                                                         _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_bwd_reduce_finalize_bf16")
         else:
             sums = torch.empty((2 * c,), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_bwd_reduce_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(sums), _ptr(ws),
-                                                ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
+            check(lib.s2d_bnrow_bwd_reduce_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(sums),
+                                                _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
             if ctx.training:
                 sums_all = sums.clone()
                 dist.all_reduce(sums_all)
@@ -221,12 +223,16 @@ class _BNRowFn(torch.autograd.Function):
                 zeros = torch.zeros_like(scale)
                 out = torch.stack([invstd * (sums[c:] - mean * sums[:c]), sums[:c], scale, zeros, zeros])
         dgamma, dbeta = out[0], out[1]
-        dx = None
-        if ctx.needs_input_grad[0]:
+        dx = dres = None
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[0] or want_res:
             dx = torch.empty_like(x)
-            check(lib.s2d_bnrow_bwd_apply_bf16(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), relu, _ptr(out[2]), _ptr(out[3]),
-                                               _ptr(out[4]), rows, c, _ptr(dx), _stream()), "s2d_bnrow_bwd_apply_bf16")
-        return dx, dgamma, dbeta, None, None, None, None, None
+            if want_res:
+                dres = torch.empty_like(x) if relu else dy   # without a ReLU the residual gradient is dy itself
+            check(lib.s2d_bnrow_bwd_apply_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, _ptr(out[2]),
+                                               _ptr(out[3]), _ptr(out[4]), rows, c, _ptr(dx),
+                                               _ptr(dres) if (want_res and relu) else None, _stream()), "s2d_bnrow_bwd_apply_bf16")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):
@@ -249,7 +255,7 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         training = self.training or not self.track_running_stats
         sync = training and _dist_sync()
         if self._hip_ok(x):
-            return _BNRowFn.apply(x, self.weight, self.bias, relu, self.eps, sync, self, training)
+            return _BNRowFn.apply(x, self.weight, self.bias, None, relu, self.eps, sync, self, training)
         if sync and x.is_cuda:
             import torch.distributed as dist
             from torch.nn.modules._functions import SyncBatchNorm as _SyncFn

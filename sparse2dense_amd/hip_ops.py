@@ -175,12 +175,14 @@ def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1
 # sparse conv arithmetic
 # ------------------------------------------------------------------------------------------------
 PROFILE = None  # bench.py sets this to a list to collect per-launch HIP events (roofline pass)
-SPARSE_COMPUTE_DTYPE = "f32"  # "bf16": MFMA inputs rounded to bf16 (fp32 accumulate) where the kernel supports the shape
+# "f32": fp32 storage, fp32 MFMA (the parity mode).  "bf16": fp32 storage, MFMA inputs rounded to bf16 in the kernels.
+# "s16": bf16 feature storage end to end (csrc/spconv_s16.hip + the row-major bf16 batch norm), fp32 accumulate/statistics.
+SPARSE_COMPUTE_DTYPE = "f32"
 
 
 def set_sparse_compute_dtype(name):
     global SPARSE_COMPUTE_DTYPE
-    assert name in ("f32", "bf16")
+    assert name in ("f32", "bf16", "s16")
     SPARSE_COMPUTE_DTYPE = name
 
 
@@ -402,16 +404,101 @@ def densify_bev_bf16(feat, coors, batch, shape):
     n, c = feat.shape
     out = torch.empty((batch, c * shape[0], shape[1], shape[2]), dtype=torch.bfloat16, device=feat.device,
                       memory_format=torch.channels_last)
-    check(lib.s2d_densify_bev_fwd_bf16(_ptr(feat), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(out), _stream()),
-          "s2d_densify_bev_fwd_bf16")
+    assert feat.dtype in (torch.float32, torch.bfloat16)
+    check(lib.s2d_densify_bev_fwd_bf16(_ptr(feat), int(feat.dtype == torch.bfloat16), _ptr(coors.contiguous()), n, batch,
+                                       i3(shape), c, _ptr(out), _stream()), "s2d_densify_bev_fwd_bf16")
     return out
 
 
-def densify_bev_bf16_bwd(dout, coors, batch, shape, c):
+def densify_bev_bf16_bwd(dout, coors, batch, shape, c, feat_dtype=torch.float32):
     lib = _lib.load()
     dout = dout.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     n = coors.shape[0]
-    dfeat = torch.empty((n, c), dtype=torch.float32, device=dout.device)
-    check(lib.s2d_densify_bev_bwd_bf16(_ptr(dout), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(dfeat), _stream()),
-          "s2d_densify_bev_bwd_bf16")
+    dfeat = torch.empty((n, c), dtype=feat_dtype, device=dout.device)
+    check(lib.s2d_densify_bev_bwd_bf16(_ptr(dout), _ptr(coors.contiguous()), n, batch, i3(shape), c, _ptr(dfeat),
+                                       int(feat_dtype == torch.bfloat16), _stream()), "s2d_densify_bev_bwd_bf16")
     return dfeat
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16-storage sparse conv ("s16" path, csrc/spconv_s16.hip)
+# ------------------------------------------------------------------------------------------------
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.uint8, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def spconv_s16_pack(weight_kio, n_out, transpose=False, flip=False):
+    """fp32 [K, cin, cout] (or the forward layer's [K, cout, cin] with transpose) -> the kernel's bf16 weight image
+    for a launch over n_out rows; returns (packed, kvol, cin, cout) of the packed operand."""
+    lib = _lib.load()
+    kvol = weight_kio.shape[0]
+    cin, cout = (weight_kio.shape[2], weight_kio.shape[1]) if transpose else (weight_kio.shape[1], weight_kio.shape[2])
+    w = weight_kio.detach().float().contiguous()
+    packed = torch.empty(lib.s2d_spconv_s16_packed_elems(kvol, cin, cout), dtype=torch.bfloat16, device=w.device)
+    check(lib.s2d_spconv_s16_pack_weights(_ptr(w), kvol, cin, cout, int(transpose), int(flip), int(n_out), _ptr(packed),
+                                          _stream()), "s2d_spconv_s16_pack_weights")
+    return packed, kvol, cin, cout
+
+
+def spconv_s16_run(feat, packed, kvol, cin, cout, bias, nbr, n_out, pair_count=None, tag="fwd"):
+    lib = _lib.load()
+    assert feat.dtype == torch.bfloat16 and feat.shape[1] == cin and feat.is_contiguous()
+    out = torch.empty((n_out, cout), dtype=torch.bfloat16, device=feat.device)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="spconv_fwd_s16", tag=tag, cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
+                   elem_bytes=2, start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
+    check(lib.s2d_spconv_s16_fwd(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(bias), _ptr(nbr), int(n_out), kvol, cin, cout,
+                                 _ptr(zero_page(feat.device)), _ptr(out), _stream()), "s2d_spconv_s16_fwd")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
+    return out
+
+
+def col_sums_bf16(x):
+    """per-column fp32 sums of a row-major bf16 matrix [n, c] (c % 8 == 0): bias gradients"""
+    lib = _lib.load()
+    n, c = x.shape
+    stats = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_bnrow_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bnrow_stats_bf16(_ptr(x), n, c, _ptr(stats), _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
+    return stats[:c]
+
+
+def spconv_s16(feat, weight_kio, bias, nbr, n_out, transpose=False, flip=False, pair_count=None, tag="fwd"):
+    """feat bf16 [n_in, cin]; weight_kio fp32 [K, cin, cout] (or [K, cout, cin] of the forward layer when transpose:
+    then the result is the data gradient w.r.t. that layer's input); -> bf16 [n_out, cout of the packed operand]."""
+    _need_gpu(feat, weight_kio, nbr)
+    packed, kvol, cin, cout = spconv_s16_pack(weight_kio, n_out, transpose, flip)
+    b = None if bias is None else bias.detach().float().contiguous()
+    return spconv_s16_run(feat.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, pair_count, tag)
+
+
+def spconv_s16_wgrad(feat, dout, nbr, kvol, pair_count=None):
+    """dW[k] = gather(feat, nbr[k])^T @ dout for bf16 feat [n_in, cin], dout [n_out, cout] -> fp32 [K, cin, cout]"""
+    lib = _lib.load()
+    assert feat.dtype == torch.bfloat16 and dout.dtype == torch.bfloat16
+    feat, dout = feat.contiguous(), dout.contiguous()
+    cin, cout, n_out = feat.shape[1], dout.shape[1], dout.shape[0]
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
+    ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="spconv_wgrad_s16", tag="wgrad", cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
+                   elem_bytes=2, start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
+    check(lib.s2d_spconv_s16_wgrad(_ptr(feat), feat.shape[0], _ptr(dout), _ptr(nbr), n_out, kvol, cin, cout, _ptr(dw), _ptr(ws),
+                                   ws.numel(), _stream()), "s2d_spconv_s16_wgrad")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
+    return dw

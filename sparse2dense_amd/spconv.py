@@ -48,7 +48,8 @@ class SparseConvTensor:
         return None if key is None else self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        out = _Densify.apply(self.features, self.indices, self.batch_size, tuple(self.spatial_shape))
+        feats = self.features.float() if self.features.dtype == torch.bfloat16 else self.features   # bf16-storage stack
+        out = _Densify.apply(feats, self.indices, self.batch_size, tuple(self.spatial_shape))
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
     def dense_bev(self, nhwc_bf16=False):
@@ -66,14 +67,14 @@ class _DensifyBev(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, coors, batch, shape):
         ctx.save_for_backward(coors)
-        ctx.meta = (batch, shape, feat.shape[1])
+        ctx.meta = (batch, shape, feat.shape[1], feat.dtype)
         return H.densify_bev_bf16(feat, coors, batch, shape)
 
     @staticmethod
     def backward(ctx, dout):
         (coors,) = ctx.saved_tensors
-        batch, shape, c = ctx.meta
-        return H.densify_bev_bf16_bwd(dout, coors, batch, shape, c), None, None, None
+        batch, shape, c, dt = ctx.meta
+        return H.densify_bev_bf16_bwd(dout, coors, batch, shape, c, dt), None, None, None
 
 
 class _Densify(torch.autograd.Function):
@@ -94,17 +95,43 @@ class _SparseConvFn(torch.autograd.Function):
     """out = sum_k gather(feat, nbr[k]) @ W[k] (+bias); spconv.ops.indice_conv + its backward."""
 
     @staticmethod
+    def _w_s16(weight, rb, cin_feat):
+        """[kz,ky,kx,cin,cout] -> [K, cin_feat, cout]; the 5-channel input layer is zero-padded to the 16 stored channels"""
+        w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
+        if w.shape[1] < cin_feat:
+            w = torch.nn.functional.pad(w, (0, 0, 0, cin_feat - w.shape[1]))
+        return w
+
+    @staticmethod
     def forward(ctx, feat, weight, bias, rb):
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         ctx.rb = rb
         ctx.has_bias = bias is not None
         ctx.save_for_backward(feat, weight)
+        ctx.s16 = feat.dtype == torch.bfloat16
+        if ctx.s16:   # bf16 feature storage: gather -> LDS -> MFMA, bf16 out
+            return H.spconv_s16(feat, _SparseConvFn._w_s16(weight, rb, feat.shape[1]), bias, rb.nbr_out, rb.n_out,
+                                pair_count=rb.pair_count, tag="fwd")
         return H.spconv_gather_gemm(feat, w, bias, rb.nbr_out, rb.n_out, rb.pair_count, "fwd")
 
     @staticmethod
     def backward(ctx, dout):
         feat, weight = ctx.saved_tensors
         rb = ctx.rb
+        if ctx.s16:
+            dout = dout.to(torch.bfloat16).contiguous()
+            w = _SparseConvFn._w_s16(weight, rb, feat.shape[1])
+            dfeat = dw = db = None
+            if ctx.needs_input_grad[0]:
+                nbr = rb.nbr_out if rb.subm else rb.nbr_in
+                dfeat = H.spconv_s16(dout, w, None, nbr, rb.n_in, transpose=True, flip=rb.subm, pair_count=rb.pair_count,
+                                     tag="dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
+                dw = dw[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = H.col_sums_bf16(dout)
+            return dfeat, dw, db, None
         dout = dout.contiguous()
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         dfeat = dw = db = None
@@ -171,7 +198,14 @@ class SparseConvolution(SparseModule):
     def forward(self, x: SparseConvTensor):
         assert isinstance(x, SparseConvTensor)
         rb = self.rulebook(x)
-        feats = _SparseConvFn.apply(x.features, self.weight, self.bias, rb)
+        feats = x.features
+        if H.SPARSE_COMPUTE_DTYPE == "s16" and feats.is_cuda and feats.dtype != torch.bfloat16 \
+                and self.out_channels in (16, 32, 64, 128) and (feats.shape[1] <= 16 or feats.shape[1] in (32, 64, 128)):
+            # entry of the bf16-storage stack: the 5 point features are zero-padded to 16 stored channels
+            if feats.shape[1] < 16:
+                feats = torch.nn.functional.pad(feats, (0, 16 - feats.shape[1]))
+            feats = feats.to(torch.bfloat16)
+        feats = _SparseConvFn.apply(feats, self.weight, self.bias, rb)
         if self.subm:
             out = SparseConvTensor(feats, x.indices, x.spatial_shape, x.batch_size)
         else:
@@ -277,6 +311,12 @@ class FeatureBatchNorm1d(nn.BatchNorm1d):
         if x.shape[0] == 0:
             return x
         use_batch_stats = self.training or not self.track_running_stats
+        if x.dtype == torch.bfloat16:   # bf16-storage stack: the row-major bf16 kernels (also used by the BEV neck)
+            from .dense2d import _BNRowFn
+            if self.num_features % 8:
+                raise RuntimeError("FeatureBatchNorm1d: bf16 features need a channel count that is a multiple of 8")
+            return _BNRowFn.apply(x.contiguous(), self.weight, self.bias, None if residual is None else residual.contiguous(),
+                                  relu, self.eps, _dist_on() and use_batch_stats, self, use_batch_stats)
         if use_batch_stats:
             return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, _dist_on() and self.training, self)
         return _BNEvalFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)

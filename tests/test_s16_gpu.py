@@ -1,0 +1,129 @@
+"""bf16-storage sparse stack ("s16" path): gather/implicit-GEMM forward, data gradient, weight gradient and the row-major
+bf16 batch norm with residual, against fp32/fp64 torch restatements evaluated on the same bf16-rounded operands.
+
+Tolerances: operands are rounded to bf16 once and seen identically by both sides; products accumulate in fp32; the
+kernels round their bf16 outputs once (2^-8 relative) -> 8e-3 of max|ref| for bf16 outputs, 2e-3 for fp32 outputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref_conv(feat, w, bias, nbr, n_out):
+    out = torch.zeros(n_out, w.shape[2], device=feat.device, dtype=torch.float64)
+    fr, wr = feat.double(), w.to(torch.bfloat16).double()
+    for k in range(w.shape[0]):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        if o.numel():
+            out[o] += fr[nbr[k][o].long()] @ wr[k]
+    return out + (bias.double() if bias is not None else 0)
+
+
+def _random_map(kvol, n_in, n_out, p_empty=0.6, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    nbr = torch.randint(0, n_in, (kvol, n_out), device=DEV, dtype=torch.int32, generator=g)
+    nbr[torch.rand(kvol, n_out, device=DEV, generator=g) < p_empty] = -1
+    if n_out > 64:
+        nbr[:, 16:64] = -1   # whole 16-row tiles without a neighbour (the skipped-MFMA path)
+    return nbr
+
+
+@pytest.mark.parametrize("cin", [16, 32, 64, 128])
+@pytest.mark.parametrize("cout", [16, 32, 64, 128])
+@pytest.mark.parametrize("n_in,n_out,kvol", [(500, 333, 27), (257, 130, 3), (3000, 100000, 27), (40, 1, 27)])
+def test_s16_forward_and_transposed(cin, cout, n_in, n_out, kvol):
+    from sparse2dense_amd import hip_ops as H
+    if n_out > 50000 and cin * cout > 32 * 64:
+        n_out = 9100   # keep the float64 reference quick; the 64-/128-row tile templates are still both exercised
+    torch.manual_seed(cin * 131 + cout)
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    w = torch.randn(kvol, cin, cout, device=DEV) * 0.1
+    b = torch.randn(cout, device=DEV)
+    nbr = _random_map(kvol, n_in, n_out)
+    out = H.spconv_s16(feat, w, b, nbr, n_out)
+    ref = _ref_conv(feat, w, b, nbr, n_out)
+    assert out.dtype == torch.bfloat16 and out.shape == (n_out, cout)
+    assert (out.double() - ref).abs().max() <= 8e-3 * ref.abs().max()
+    # the data-gradient operand: weight stored [K, cout_fwd, cin_fwd] -> W^T, offsets mirrored
+    out2 = H.spconv_s16(feat, w.transpose(1, 2).contiguous(), None, nbr, n_out, transpose=True, flip=True)
+    ref2 = _ref_conv(feat, w.flip(0), None, nbr, n_out)
+    assert (out2.double() - ref2).abs().max() <= 8e-3 * ref2.abs().max()
+
+
+def test_s16_empty_and_unsupported():
+    from sparse2dense_amd import _lib, hip_ops as H
+    feat = torch.randn(10, 16, device=DEV).to(torch.bfloat16)
+    w = torch.randn(27, 16, 16, device=DEV)
+    out = H.spconv_s16(feat, w, None, torch.empty((27, 0), dtype=torch.int32, device=DEV), 0)
+    assert out.shape == (0, 16)
+    all_empty = torch.full((27, 70), -1, dtype=torch.int32, device=DEV)
+    out = H.spconv_s16(feat, w, None, all_empty, 70)
+    assert torch.count_nonzero(out) == 0
+    with pytest.raises(_lib.S2DError):
+        H.spconv_s16(torch.randn(10, 24, device=DEV).to(torch.bfloat16), torch.randn(27, 24, 16, device=DEV), None, all_empty, 70)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (64, 64), (64, 128), (128, 128), (128, 64)])
+def test_s16_wgrad(cin, cout):
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(7)
+    n_in, n_out, kvol = 2000, 3100, 27
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(n_out, cout, device=DEV).to(torch.bfloat16)
+    nbr = _random_map(kvol, n_in, n_out, p_empty=0.7, seed=3)
+    dw = H.spconv_s16_wgrad(feat, dout, nbr, kvol)
+    ref = torch.zeros(kvol, cin, cout, device=DEV, dtype=torch.float64)
+    for k in range(kvol):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        ref[k] = feat[nbr[k][o].long()].double().t() @ dout[o].double()
+    assert dw.dtype == torch.float32
+    assert (dw.double() - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("relu,with_res", [(True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("n,c", [(5000, 16), (777, 128), (33, 32)])
+def test_feature_bn_bf16_rows_with_residual(n, c, relu, with_res):
+    """FeatureBatchNorm1d on bf16 [n, c] features (+residual, +ReLU) vs a float64 CPU batch norm."""
+    from sparse2dense_amd.spconv import FeatureBatchNorm1d
+    torch.manual_seed(11)
+    m = FeatureBatchNorm1d(c, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    x = (torch.randn(n, c, device=DEV) * 2 + 0.3).to(torch.bfloat16)
+    res = torch.randn(n, c, device=DEV).to(torch.bfloat16) if with_res else None
+    dy = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+    xa = x.clone().requires_grad_(True)
+    ra = res.clone().requires_grad_(True) if with_res else None
+    y = m(xa, residual=ra, relu=relu)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy)
+    xr = x.double().cpu().requires_grad_(True)
+    rr = res.double().cpu().requires_grad_(True) if with_res else None
+    yr = ref(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.double().cpu())
+
+    def close(what, a, r, tol):
+        err = (a.double().cpu() - r).abs().max() / r.abs().max().clamp(min=1e-9)
+        assert err <= tol, (what, float(err))
+    # y itself is compared away from the ReLU kink: a bf16-rounded y that is exactly 0 vs a tiny positive reference
+    close("y", y, yr, 1e-2)
+    close("dx", xa.grad, xr.grad, 2e-2)
+    if with_res:
+        # masked dy; rows where the fp64 reference and the bf16 kernel disagree on the sign of a ~0 pre-activation excluded
+        stable = (yr.detach().abs() > 1e-2) | (not relu)
+        diff = ((ra.grad.double().cpu() - rr.grad) * stable).abs().max()
+        assert diff <= 1e-2 * rr.grad.abs().max(), float(diff)
+    close("dgamma", m.weight.grad, ref.weight.grad, 5e-3)
+    close("dbeta", m.bias.grad, ref.bias.grad, 5e-3)
+    close("running_mean", m.running_mean, ref.running_mean, 1e-4)
+    close("running_var", m.running_var, ref.running_var, 1e-4)
+    assert int(m.num_batches_tracked) == 1
