@@ -423,12 +423,14 @@ static int check_c(int c, const char *who) {
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 constexpr int ROW_UNROLL = 4;   // rows per thread and trip in the row-major bf16 kernels
 
-template <bool BWD>
+// RELU / HAS_Y are compile-time: with run-time flags hipcc keeps a uniform branch per element in the unrolled bodies
+template <bool BWD, bool RELU, bool HAS_Y>
 __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                                       const __bf16 *__restrict__ y,
                                                                       const float *__restrict__ scale,
-                                                                      const float *__restrict__ shift, int relu, int64_t n, int c,
+                                                                      const float *__restrict__ shift, int64_t n, int c,
                                                                       int rows_per_block, float *__restrict__ partial) {
+    constexpr bool relu = RELU;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [row_lanes][2][C]
     const int c8 = c >> 3;
     const int lanes = RED_THREADS / c8;
@@ -439,30 +441,32 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
-        sc[e] = (BWD && relu && !y) ? scale[grp * 8 + e] : 0.f;
-        sh[e] = (BWD && relu && !y) ? shift[grp * 8 + e] : 0.f;
+        sc[e] = (BWD && relu && !HAS_Y) ? scale[grp * 8 + e] : 0.f;
+        sh[e] = (BWD && relu && !HAS_Y) ? shift[grp * 8 + e] : 0.f;
     }
     if (rl < lanes) {
-        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)ROW_UNROLL * lanes) {
-            bf16x8r xv[ROW_UNROLL], gv[ROW_UNROLL], yv[ROW_UNROLL];
+        constexpr int RU = BWD ? ROW_UNROLL : 2 * ROW_UNROLL;   // the statistics pass carries one tensor: twice the rows in flight
+        for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)RU * lanes) {
+            bf16x8r xv[RU], gv[BWD ? RU : 1], yv[(BWD && HAS_Y) ? RU : 1];
 #pragma unroll
-            for (int u = 0; u < ROW_UNROLL; ++u) {   // all loads of the trip first; rows past the end re-read row rb
+            for (int u = 0; u < RU; ++u) {   // all loads of the trip first; rows past the end re-read row rb
                 const int64_t r = rb + (int64_t)u * lanes < r1 ? rb + (int64_t)u * lanes : rb;
                 xv[u] = reinterpret_cast<const bf16x8r *>(x + r * c)[grp];
-                if (BWD) {
+                if constexpr (BWD) {
                     gv[u] = reinterpret_cast<const bf16x8r *>(dy + r * c)[grp];
-                    if (relu && y) yv[u] = reinterpret_cast<const bf16x8r *>(y + r * c)[grp];
+                    if constexpr (relu && HAS_Y) yv[u] = reinterpret_cast<const bf16x8r *>(y + r * c)[grp];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < ROW_UNROLL; ++u) {
+            for (int u = 0; u < RU; ++u) {
                 if (rb + (int64_t)u * lanes >= r1) break;
-                if (BWD) {
+                if constexpr (BWD) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float xf = (float)xv[u][e];
                         float g = (float)gv[u][e];
-                        if (relu) g = (y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? g : 0.f;
+                        if constexpr (relu && HAS_Y) g = (float)yv[u][e] > 0.f ? g : 0.f;
+                        else if constexpr (relu) g = fmaf(xf, sc[e], sh[e]) > 0.f ? g : 0.f;
                         s0[e] += g;
                         s1[e] += g * xf;
                     }
@@ -492,9 +496,12 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 
 // apply kernels: blockDim.x = lanes*c8 (a multiple of c8), thread -> (row lane, 8-channel group); the per-channel constants
 // live in registers, rows are strided over the grid.
+template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
-                                                             const float *__restrict__ shift, const __bf16 *__restrict__ res,
-                                                             int relu, int64_t n, int c8, __bf16 *__restrict__ y) {
+                                                             const float *__restrict__ shift, const __bf16 *__restrict__ res_p,
+                                                             int64_t n, int c8, __bf16 *__restrict__ y) {
+    constexpr bool relu = RELU;
+    const __bf16 *__restrict__ res = RES ? res_p : nullptr;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8];
 #pragma unroll
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
         for (int u = 0; u < ROW_UNROLL; ++u) {
             const int64_t r = r0 + u * stride < n ? r0 + u * stride : r0;
             xv[u] = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
-            if (res) rv[u] = reinterpret_cast<const bf16x8r *>(res)[r * c8 + g];
+            if (RES) rv[u] = reinterpret_cast<const bf16x8r *>(res)[r * c8 + g];
         }
 #pragma unroll
         for (int u = 0; u < ROW_UNROLL; ++u) {
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = fmaf((float)xv[u][e], sc[e], sh[e]);
-                if (res) v += (float)rv[u][e];
+                if (RES) v += (float)rv[u][e];
                 if (relu) v = fmaxf(v, 0.f);
                 o[e] = (__bf16)v;
             }
@@ -530,19 +537,21 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
     }
 }
 
+template <bool RELU, bool HAS_Y, bool HAS_DRES>
 __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ x,
                                                                  const __bf16 *__restrict__ y,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                 int relu, const float *__restrict__ a, const float *__restrict__ b,
+                                                                 const float *__restrict__ a, const float *__restrict__ b,
                                                                  const float *__restrict__ d, int64_t n, int c8,
                                                                  __bf16 *__restrict__ dx, __bf16 *__restrict__ dres) {
+    constexpr bool relu = RELU;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8], av[8], bv[8], dv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = g * 8 + e;
-        sc[e] = (relu && !y) ? scale[ch] : 0.f;
-        sh[e] = (relu && !y) ? shift[ch] : 0.f;
+        sc[e] = (relu && !HAS_Y) ? scale[ch] : 0.f;
+        sh[e] = (relu && !HAS_Y) ? shift[ch] : 0.f;
         av[e] = a[ch];
         bv[e] = b[ch];
         dv[e] = d[ch];
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *_
             const int64_t r = r0 + u * stride < n ? r0 + u * stride : r0;
             xv[u] = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
             gv[u] = reinterpret_cast<const bf16x8r *>(dy)[r * c8 + g];
-            if (relu && y) yv[u] = reinterpret_cast<const bf16x8r *>(y)[r * c8 + g];
+            if (relu && HAS_Y) yv[u] = reinterpret_cast<const bf16x8r *>(y)[r * c8 + g];
         }
 #pragma unroll
         for (int u = 0; u < ROW_UNROLL; ++u) {
@@ -566,12 +575,12 @@ __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *_
             for (int e = 0; e < 8; ++e) {
                 const float xf = (float)xv[u][e];
                 float gg = (float)gv[u][e];
-                if (relu) gg = (y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? gg : 0.f;
-                gm[e] = (__bf16)gg;
+                if (relu) gg = (HAS_Y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? gg : 0.f;
+                if (HAS_DRES) gm[e] = (__bf16)gg;
                 o[e] = (__bf16)fmaf(av[e], gg, fmaf(bv[e], xf, dv[e]));
             }
             reinterpret_cast<bf16x8r *>(dx)[r * c8 + g] = o;
-            if (dres) reinterpret_cast<bf16x8r *>(dres)[r * c8 + g] = gm;   // gradient of the residual branch: masked dy
+            if (HAS_DRES) reinterpret_cast<bf16x8r *>(dres)[r * c8 + g] = gm;   // gradient of the residual branch: masked dy
         }
     }
 }
@@ -593,8 +602,8 @@ static RedPlan row_plan_bf16(int64_t n, int c) {
     RedPlan p;
     const int c8 = c / 8;
     const int lanes = RED_THREADS / c8 > 0 ? RED_THREADS / c8 : 1;
-    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * 8);
-    if (nb > 2048) nb = 2048;
+    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * 16);
+    if (nb > 1024) nb = 1024;   // ~4 resident workgroups per CU, each streaming >= 16 rows per thread
     p.nblocks = (int)nb;
     p.rows_per_block = (int)ceil_div(n > 0 ? n : 1, nb);
     p.lds = (size_t)lanes * 2 * c * sizeof(float);
@@ -910,13 +919,14 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, 
         set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, p.ws_bytes);
         return S2D_ERR_WORKSPACE;
     }
-    if (bwd)
-        hipLaunchKernelGGL(row_reduce_bf16_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
-                           (const __bf16 *)dy, (const __bf16 *)y, scale, shift, relu, n, c, p.rows_per_block, (float *)ws);
-    else
-        hipLaunchKernelGGL(row_reduce_bf16_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x,
-                           (const __bf16 *)nullptr, (const __bf16 *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, n, c,
-                           p.rows_per_block, (float *)ws);
+#define S2D_ROW_REDUCE(B, R, Y)                                                                                              \
+    hipLaunchKernelGGL((row_reduce_bf16_kernel<B, R, Y>), dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x, \
+                       (const __bf16 *)dy, (const __bf16 *)y, scale, shift, n, c, p.rows_per_block, (float *)ws)
+    if (!bwd) S2D_ROW_REDUCE(false, false, false);
+    else if (!relu) S2D_ROW_REDUCE(true, false, false);
+    else if (y) S2D_ROW_REDUCE(true, true, true);
+    else S2D_ROW_REDUCE(true, true, false);
+#undef S2D_ROW_REDUCE
     *plan_out = p;
     return S2D_OK;
 }
@@ -955,8 +965,15 @@ extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const flo
     if (rc) return rc;
     S2D_CHECK_ARG(n > 0 && x && y && scale && shift, "bnrow_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
-    hipLaunchKernelGGL(row_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, scale,
-                       shift, (const __bf16 *)residual, relu, n, c / 8, (__bf16 *)y);
+#define S2D_ROW_APPLY(RS, RL)                                                                                                   \
+    hipLaunchKernelGGL((row_apply_bf16_kernel<RS, RL>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, \
+                       scale, shift, (const __bf16 *)residual, n, c / 8, (__bf16 *)y)
+    if (residual) {
+        if (relu) S2D_ROW_APPLY(true, true); else S2D_ROW_APPLY(true, false);
+    } else {
+        if (relu) S2D_ROW_APPLY(false, true); else S2D_ROW_APPLY(false, false);
+    }
+#undef S2D_ROW_APPLY
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -996,8 +1013,19 @@ extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const voi
     if (rc) return rc;
     S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || y || (scale && shift)), "bnrow_bwd_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
-    hipLaunchKernelGGL(row_bwd_apply_bf16_kernel, dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)dy,
-                       (const __bf16 *)x, (const __bf16 *)y, scale, shift, relu, a, b, d, n, c / 8, (__bf16 *)dx, (__bf16 *)dres);
+#define S2D_ROW_BWD(RL, Y, DR)                                                                                                     \
+    hipLaunchKernelGGL((row_bwd_apply_bf16_kernel<RL, Y, DR>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream,         \
+                       (const __bf16 *)dy, (const __bf16 *)x, (const __bf16 *)y, scale, shift, a, b, d, n, c / 8, (__bf16 *)dx,    \
+                       (__bf16 *)dres)
+    const bool use_y = relu && y;
+    if (!relu) {
+        if (dres) S2D_ROW_BWD(false, false, true); else S2D_ROW_BWD(false, false, false);
+    } else if (use_y) {
+        if (dres) S2D_ROW_BWD(true, true, true); else S2D_ROW_BWD(true, true, false);
+    } else {
+        if (dres) S2D_ROW_BWD(true, false, true); else S2D_ROW_BWD(true, false, false);
+    }
+#undef S2D_ROW_BWD
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
