@@ -276,8 +276,9 @@ int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const floa
  * the residual branch.
  */
 size_t s2d_bnrow_workspace_bytes(int64_t n, int c);
-int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
-                         s2d_stream_t stream);
+/* stats: [2c] sums, plus the row count at stats[2c] when write_count (the [2c+1] vector SyncBN all-reduces) */
+int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, int write_count, void *ws,
+                         size_t ws_bytes, s2d_stream_t stream);
 int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *gamma,
                                   const float *beta, float eps, float momentum, float *mean,
                                   float *invstd, float *scale, float *shift, float *running_mean,
@@ -285,9 +286,10 @@ int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, const float *
                                   size_t ws_bytes, s2d_stream_t stream);
 int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, const void *residual,
                          int relu, int64_t n, int c, void *y, s2d_stream_t stream);
+/* sums_copy (optional): second copy of the [2c] sums — the local one feeds dgamma/dbeta, the copy is all-reduced */
 int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const void *y, const float *scale,
-                              const float *shift, int relu, int64_t n, int c, float *sums, void *ws,
-                              size_t ws_bytes, s2d_stream_t stream);
+                              const float *shift, int relu, int64_t n, int c, float *sums,
+                              float *sums_copy, void *ws, size_t ws_bytes, s2d_stream_t stream);
 int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const void *y,
                                        const float *scale, const float *shift, int relu, int64_t n, int c,
                                        const float *gamma, const float *mean, const float *invstd,

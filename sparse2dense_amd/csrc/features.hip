@@ -53,16 +53,22 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float *__
 }
 
 // one wave per output element: lanes stride over the per-block partials, fixed-order butterfly
+// out2 (optional): a second copy of the sums (the one that gets all-reduced); count >= 0: also written to out[width]
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblocks, int width,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, float *__restrict__ out2 = nullptr,
+                                                          float count = -1.f) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (e == 0 && lane == 0 && count >= 0.f) out[width] = count;
     if (e >= width) return;
     float s = 0.f;
     for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * width + e];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if (lane == 0) out[e] = s;
+    if (lane == 0) {
+        out[e] = s;
+        if (out2) out2[e] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ scale,
@@ -931,14 +937,15 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, 
     return S2D_OK;
 }
 
-extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, void *ws, size_t ws_bytes,
+extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stats, int write_count, void *ws, size_t ws_bytes,
                                     s2d_stream_t stream) {
     S2D_CHECK_ARG(stats, "bnrow_stats: null stats");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
     int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, stats);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, stats,
+                       (float *)nullptr, write_count ? (float)n : -1.f);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -979,14 +986,15 @@ extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const flo
 }
 
 extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const void *y, const float *scale, const float *shift,
-                                         int relu, int64_t n, int c, float *sums, void *ws, size_t ws_bytes,
+                                         int relu, int64_t n, int c, float *sums, float *sums_copy, void *ws, size_t ws_bytes,
                                          s2d_stream_t stream) {
     S2D_CHECK_ARG(sums, "bnrow_bwd_reduce: null sums");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
     int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums,
+                       sums_copy, -1.f);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

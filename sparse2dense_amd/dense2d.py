@@ -30,11 +30,12 @@ def _zero_page(device):
 
 
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    # a plain int: ctypes converts it for the c_void_p parameters (cheaper than building a c_void_p per argument)
+    return None if t is None else t.data_ptr()
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def supported(cin, cout):
@@ -109,7 +110,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             rows = dyb.shape[0] * dyb.shape[2] * dyb.shape[3]
             stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
             ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)
-            check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), _ptr(ws), ws.numel(), _stream()),
+            check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_stats_bf16")
             db = stats[:cout]
         return dx, dw, db, None
@@ -132,15 +133,27 @@ class Conv3x3(nn.Conv2d):
 # --------------------------------------------------------------------------------------------------
 # BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
 # --------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """reduction workspace: one grow-only buffer per device and stream.  Every user writes it before reading it inside
+    one entry point, and launches on a stream are ordered, so consecutive calls can share it."""
+    if torch.cuda.is_current_stream_capturing():   # graph capture: a private allocation from the graph's pool
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
 
 
 def _dist_sync():
     import torch.distributed as dist
     import os
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("S2D_DEBUG_NO_SYNCBN", "0") == "1":
+        return False   # (S2D_DEBUG_NO_SYNCBN: measurement hook, splits DDP overhead from SyncBN overhead)
     return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
 
 
@@ -171,9 +184,8 @@ class _BNRowFn(torch.autograd.Function):
                                                     ws.numel(), _stream()), "s2d_bnrow_stats_finalize_bf16")
         elif training:
             packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_stats_bf16(_ptr(x), rows, c, _ptr(packed), _ptr(ws), ws.numel(), _stream()),
-                  "s2d_bnrow_stats_bf16")
-            packed[-1] = float(rows)
+            check(lib.s2d_bnrow_stats_bf16(_ptr(x), rows, c, _ptr(packed), 1, _ptr(ws), ws.numel(), _stream()),
+                  "s2d_bnrow_stats_bf16")   # [sum, sumsq, row count] in one vector
             dist.all_reduce(packed)
             count = packed[-1:].contiguous()
             fin = H.bn1d_finalize_fwd(packed[:-1].contiguous(), count, gamma, beta, eps, module.momentum if track else 0.0,
@@ -213,10 +225,10 @@ class _BNRowFn(torch.autograd.Function):
                   "s2d_bnrow_bwd_reduce_finalize_bf16")
         else:
             sums = torch.empty((2 * c,), dtype=torch.float32, device=dev)
+            sums_all = torch.empty_like(sums) if ctx.training else None
             check(lib.s2d_bnrow_bwd_reduce_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(sums),
-                                                _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
+                                                _ptr(sums_all), _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
             if ctx.training:
-                sums_all = sums.clone()
                 dist.all_reduce(sums_all)
                 out = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
             else:   # eval: y = x*scale + shift with constant scale

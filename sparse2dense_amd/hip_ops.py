@@ -21,13 +21,13 @@ from ._lib import check, f3, f6, i3
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t: Optional[torch.Tensor]):
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()   # a plain int: ctypes converts it for the c_void_p parameters
 
 
 def _need_gpu(*ts):
@@ -37,7 +37,13 @@ def _need_gpu(*ts):
 
 
 def _ws(nbytes, device):
+    """private workspace (rulebook / voxelizer jobs keep state in it between their two calls)"""
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _ws_shared(nbytes, device):
+    from .dense2d import _ws as shared_ws   # one grow-only scratch buffer per (device, stream), see there
+    return shared_ws(nbytes, device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -251,7 +257,7 @@ def spconv_wgrad(feat: torch.Tensor, dout: torch.Tensor, nbr: torch.Tensor, kvol
     feat = feat.contiguous()
     cin = feat.shape[1]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
-    ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
+    ws = _ws_shared(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
     bf = SPARSE_COMPUTE_DTYPE == "bf16"
     fn = lib.s2d_spconv_wgrad_bf16 if bf else lib.s2d_spconv_wgrad_f32
     rec = None
@@ -278,7 +284,7 @@ def bn1d_stats(x: torch.Tensor) -> torch.Tensor:
     x = x.contiguous()
     n, c = x.shape
     stats = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
-    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    ws = _ws_shared(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
     check(lib.s2d_bn1d_stats_f32(_ptr(x), n, c, _ptr(stats), _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_f32")
     return stats
 
@@ -313,7 +319,7 @@ def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, runnin
     x = x.contiguous()
     n, c = x.shape
     out = torch.empty((4, c), dtype=torch.float32, device=x.device)
-    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    ws = _ws_shared(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
     check(lib.s2d_bn1d_stats_finalize_f32(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(out[0]),
                                           _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(running_mean), _ptr(running_var),
                                           _ptr(batches_tracked), _ptr(ws), ws.numel(), _stream()), "s2d_bn1d_stats_finalize_f32")
@@ -328,7 +334,7 @@ def bn1d_bwd_reduce_finalize(dy, y, x, relu, gamma, mean, invstd):
     n, c = x.shape
     g = torch.empty_like(x)
     out = torch.empty((5, c), dtype=torch.float32, device=x.device)
-    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    ws = _ws_shared(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
     check(lib.s2d_bn1d_bwd_reduce_finalize_f32(_ptr(dy), _ptr(y), _ptr(x), int(relu), n, c, _ptr(gamma), _ptr(mean),
                                                _ptr(invstd), _ptr(g), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]),
                                                _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
@@ -357,7 +363,7 @@ def bn1d_bwd_reduce(dy, y, x, relu, want_g=True):
     n, c = x.shape
     g = torch.empty_like(x) if want_g else None
     sums = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
-    ws = _ws(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
+    ws = _ws_shared(lib.s2d_bn1d_workspace_bytes(n, c), x.device)
     check(lib.s2d_bn1d_bwd_reduce_f32(_ptr(dy), _ptr(y), _ptr(x), int(relu), n, c, _ptr(g), _ptr(sums), _ptr(ws),
                                       ws.numel(), _stream()), "s2d_bn1d_bwd_reduce_f32")
     return g, sums
@@ -469,8 +475,8 @@ def col_sums_bf16(x):
     lib = _lib.load()
     n, c = x.shape
     stats = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
-    ws = _ws(lib.s2d_bnrow_workspace_bytes(n, c), x.device)
-    check(lib.s2d_bnrow_stats_bf16(_ptr(x), n, c, _ptr(stats), _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
+    ws = _ws_shared(lib.s2d_bnrow_workspace_bytes(n, c), x.device)
+    check(lib.s2d_bnrow_stats_bf16(_ptr(x), n, c, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
     return stats[:c]
 
 
@@ -490,7 +496,7 @@ def spconv_s16_wgrad(feat, dout, nbr, kvol, pair_count=None):
     feat, dout = feat.contiguous(), dout.contiguous()
     cin, cout, n_out = feat.shape[1], dout.shape[1], dout.shape[0]
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
-    ws = _ws(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
+    ws = _ws_shared(lib.s2d_spconv_wgrad_workspace_bytes(n_out, kvol, cin, cout), feat.device)
     rec = None
     if PROFILE is not None:
         rec = dict(kernel="spconv_wgrad_s16", tag="wgrad", cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,

@@ -234,8 +234,8 @@ class SparseConv3d(SparseConvolution):
 # --------------------------------------------------------------------------------------------------
 def _dist_on():
     import os
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("S2D_DEBUG_NO_SYNCBN", "0") == "1":
+        return False   # (S2D_DEBUG_NO_SYNCBN: measurement hook, splits DDP overhead from SyncBN overhead)
     return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
 
 

@@ -160,3 +160,35 @@ def test_densify_bev_nhwc_bf16_matches_dense_view():
     a.backward(dy.contiguous(memory_format=torch.channels_last))
     b.backward(dy.float())
     assert torch.equal(fa.grad, fb.grad)
+
+
+def test_bn_rows_sync_path_equals_local_path_on_one_rank(monkeypatch):
+    """The SyncBN route (split statistics kernels -> all-reduce of [sum, sumsq, count] -> finalize; backward likewise)
+    must reproduce the fused single-GPU route when the world has one rank (RCCL all-reduce of one contribution)."""
+    import torch.distributed as dist
+    from sparse2dense_amd import dense2d as D
+    from sparse2dense_amd.spconv import FeatureBatchNorm1d
+    if dist.is_initialized():
+        pytest.skip("a process group is already up")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        torch.manual_seed(4)
+        for make, shape in [(lambda: D.FastBatchNorm2d(64, eps=1e-3, momentum=0.01, fused_relu=True), (2, 64, 30, 26)),
+                            (lambda: FeatureBatchNorm1d(32, eps=1e-3, momentum=0.01), (3000, 32))]:
+            a, b = make().cuda(), make().cuda()
+            b.load_state_dict(a.state_dict())
+            x = torch.randn(*shape, device="cuda").to(torch.bfloat16)
+            if len(shape) == 4:
+                x = x.contiguous(memory_format=torch.channels_last)
+            dy = torch.randn_like(x)
+            outs = []
+            for m, force in ((a, "0"), (b, "1")):
+                monkeypatch.setenv("S2D_FORCE_DDP", force)
+                xi = x.clone().requires_grad_(True)
+                y = m(xi)
+                y.backward(dy)
+                outs.append((y, xi.grad, m.weight.grad, m.bias.grad, m.running_mean, m.running_var, m.num_batches_tracked))
+            for u, v in zip(*outs):
+                assert torch.allclose(u.float(), v.float(), rtol=1e-5, atol=1e-6), (u.float() - v.float()).abs().max()
+    finally:
+        dist.destroy_process_group()
