@@ -141,6 +141,10 @@ def roofline_pass(step, n_steps=3):
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
         a["ms"] += ms
         a["n"] += 1
+        if r.get("dense"):   # dense 3x3 conv, NHWC bf16: 2*M*9*cin*cout flops; every input / output / weight byte once
+            a["flops"] += 2.0 * r["n_out"] * 9 * r["cin"] * r["cout"]
+            a["bytes"] += 2.0 * (r["in_pixels"] * r["cin"] + r["n_out"] * r["cout"] + 9 * r["cin"] * r["cout"])
+            continue
         a["flops"] += 2.0 * pairs * r["cin"] * r["cout"]
         eb = float(r.get("elem_bytes", 4))   # feature storage: fp32, or bf16 on the s16 path (its weight image is bf16 too)
         a["bytes"] += eb * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + eb * r["kvol"] * r["cin"] * r["cout"]
@@ -160,23 +164,50 @@ def roofline_pass(step, n_steps=3):
                          total_ms=a["ms"], tflops=a["flops"] / a["n"] / (avg_ms * 1e-3) / 1e12,
                          gbs=a["bytes"] / a["n"] / (avg_ms * 1e-3) / 1e9))
     rows.sort(key=lambda r: -r["total_ms"])
-    top = rows[0]
-    # which roof bounds it: arithmetic intensity of the algorithmic traffic against both peaks
-    peak_tf = PEAK_BF16_MATRIX_TFLOPS if top["kernel"].endswith(("bf16", "s16")) else PEAK_F32_MATRIX_TFLOPS
-    intensity = top["tflops"] * 1e3 / max(top["gbs"], 1e-9)          # FLOP per algorithmic byte
+
+    # the dominant KERNEL is a device function (what rocprofv3 --stats lists); one template instantiation serves several
+    # tensor shapes, so group the per-shape rows by instantiation before ranking
+    def template_of(r):
+        if r["kernel"] == "conv3x3_nhwc_bf16":
+            return f"conv3x3_nhwc_bf16_kernel<{128 if r['cout'] % 128 == 0 else 64}>"
+        if r["kernel"] == "spconv_fwd_s16":
+            return f"spconv_fwd_s16_kernel<{r['cin']}, {r['cout']}, {128 if r['cout'] == 128 else 64}>"
+        return f"{r['kernel']}<{r['cin']}, {r['cout']}>"
+    groups = {}
+    for r in rows:
+        g = groups.setdefault(template_of(r), dict(rows=[], ms=0.0, n=0, flops=0.0, bytes=0.0))
+        g["rows"].append(r)
+        g["ms"] += r["total_ms"]; g["n"] += r["launches"]
+        g["flops"] += r["tflops"] * 1e12 * r["total_ms"] * 1e-3
+        g["bytes"] += r["gbs"] * 1e9 * r["total_ms"] * 1e-3
+    name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    avg_us = g["ms"] / g["n"] * 1e3
+    tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+    lead = g["rows"][0]["kernel"]
+    peak_tf = PEAK_BF16_MATRIX_TFLOPS if lead.endswith(("bf16", "s16")) else PEAK_F32_MATRIX_TFLOPS
+    dense = lead.startswith("conv3x3")
+    intensity = tflops * 1e3 / max(gbs, 1e-9)          # FLOP per algorithmic byte
     hbm_roof_tf = intensity * PEAK_HBM_GBS / 1e3
-    common = dict(traffic=None, kernel=f"{top['kernel']}<cin={top['cin']},cout={top['cout']}> n_out={top['n_out']}",
-                  avg_launch_us=round(top["avg_us"], 2), launches_per_step=top["launches"] // n_steps,
-                  algorithmic_tflops=round(top["tflops"], 2), algorithmic_gbs=round(top["gbs"], 1),
-                  flop_per_byte=round(intensity, 1), mfma_peak_tflops=peak_tf,
-                  scope="dominant hand-written kernel (sparse-conv implicit GEMM); dense BEV convs run on MIOpen this round")
-    common["traffic"], common["traffic_source"] = pmc_traffic(top)
-    if hbm_roof_tf < peak_tf:
-        roof = dict(bound="hbm", achieved=round(top["gbs"], 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                    frac=round(top["gbs"] / PEAK_HBM_GBS, 4), **common)
+    shapes = [dict(cin=r["cin"], cout=r["cout"], rows_out=r["n_out"], launches_per_step=r["launches"] // n_steps,
+                   avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1)) for r in g["rows"]]
+    common = dict(traffic=None, kernel=f"s2d::{name}", avg_launch_us=round(avg_us, 2), launches_per_step=g["n"] // n_steps,
+                  algorithmic_tflops=round(tflops, 2), algorithmic_gbs=round(gbs, 1), flop_per_byte=round(intensity, 1),
+                  mfma_peak_tflops=peak_tf, shapes=shapes,
+                  scope=("dominant hand-written kernel of the step by total time (rocprofv3 --stats agrees, profiles/): "
+                         + ("dense 3x3 NHWC bf16 implicit GEMM of the BEV neck/head, forward + data-gradient launches"
+                            if dense else "sparse-conv gather implicit GEMM, forward + data-gradient launches")))
+    # measured HBM bytes per launch: launch-weighted mean over the shapes, only if every shape has a PMC entry
+    per = [(pmc_traffic(r), r["launches"]) for r in g["rows"]]
+    if all(tr[0] is not None for tr, _ in per):
+        common["traffic"] = round(sum(tr[0] * n for tr, n in per) / g["n"])
+        common["traffic_source"] = per[0][0][1]
     else:
-        roof = dict(bound="mfma", achieved=round(top["tflops"], 3), peak=peak_tf, unit="TFLOP/s",
-                    frac=round(top["tflops"] / peak_tf, 4), **common)
+        common["traffic_source"] = None
+    if hbm_roof_tf < peak_tf:
+        roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), **common)
+    else:
+        roof = dict(bound="mfma", achieved=round(tflops, 3), peak=peak_tf, unit="TFLOP/s", frac=round(tflops / peak_tf, 4), **common)
     return roof, rows
 
 
@@ -194,21 +225,26 @@ def effective_cpu_count():
 
 
 def pmc_traffic(top):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/
-    r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs).  Only used when the
-    profiled instantiation and row count are the ones being benchmarked; otherwise null."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, keyed by kernel name and launch grid).  The launch grid is a
+    function of the tensor shape, so an entry is only found when the profiled shape is the one being benchmarked."""
     try:
-        db = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        db = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
     except Exception:
         return None, None
-    if top["n_out"] != 40644:      # the profile was taken on the default workload (B=4, seed 20240928)
+    xcd = lambda tiles: -(-tiles // 8) * 8
+    if top["kernel"] == "conv3x3_nhwc_bf16":
+        bn = 128 if top["cout"] % 128 == 0 else 64
+        want, grid = f"conv3x3_nhwc_bf16_kernel<{bn}>", xcd(-(-top["n_out"] // 128)) * (top["cout"] // bn) * 256
+    elif top["kernel"] == "spconv_fwd_s16":
+        bm = 128 if top["cout"] == 128 else 64
+        want, grid = f"spconv_fwd_s16_kernel<{top['cin']}, {top['cout']}, {bm}>", xcd(-(-top["n_out"] // bm)) * 256
+    else:
         return None, None
-    nt = {16: 1, 32: 2}.get(top["cout"], 4)
-    want = f"s2d::{top['kernel']}<{top['cin']}, {nt}, 2>"
     for name, v in db.items():
-        if want in name and v["FETCH_SIZE_KiB"] and v["WRITE_SIZE_KiB"]:
+        if want in name and name.endswith(f"grid={grid}") and v["FETCH_SIZE_KiB"] and v["WRITE_SIZE_KiB"]:
             b = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
-            return round(b), "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB, per launch)"
+            return round(b), "profiles/r01_final_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB, per launch of this shape)"
     return None, None
 
 

@@ -64,8 +64,18 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad):
     n, _, h, w = x.shape
     ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    from . import hip_ops as H
+    rec = None
+    if H.PROFILE is not None:   # bench.py roofline pass: HIP events on the launch stream
+        rec = dict(kernel="conv3x3_nhwc_bf16", tag="dense", cin=cin, cout=cout, n_out=n * ho * wo, kvol=9, pairs=None,
+                   dense=True, in_pixels=n * h * w, start=torch.cuda.Event(enable_timing=True),
+                   end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
                                       pad, _ptr(y), _stream()), "s2d_conv2d3x3_nhwc_bf16")
+    if rec is not None:
+        rec["end"].record()
+        H.PROFILE.append(rec)
     return y
 
 
