@@ -322,6 +322,18 @@ int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_wei
                        const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
                        int cout, const void *zero_page, void *out_feat, s2d_stream_t stream);
 
+/*
+ * Weight gradient of the dense 3x3 stride-1 convolution above (replaces the cuDNN backward-filter call):
+ * x [n][h][w][cin] bf16 (the forward input), dy [n][ho][wo][cout] bf16, dweight fp32 in the torch layout
+ * [cout][cin][3][3].  cin, cout multiples of 64.  Pixels are contracted on v_mfma_f32_16x16x32_bf16 through LDS
+ * transpose reads; split partial sums are reduced in a fixed order (deterministic).
+ */
+int s2d_conv2d3x3_wgrad_supported(int cin, int cout);
+size_t s2d_conv2d3x3_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout, int pad);
+int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img,
+                                  int h, int w, int cin, int cout, int pad, float *dweight, void *ws,
+                                  size_t ws_bytes, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,33 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad):
     return y
 
 
+# which weight gradients take the hand-written transpose-read kernel (csrc/conv2d_wgrad.hip) instead of MIOpen:
+# "auto" = where it measured faster on MI355X (r01: only cin >= 512, i.e. the head's 512->64 conv), True / False = all / none
+import os as _os
+WGRAD_HIP = {"0": False, "1": True}.get(_os.environ.get("S2D_WGRAD_HIP", ""), "auto")
+
+
+def _wgrad_hip(cin, cout):
+    if WGRAD_HIP == "auto":
+        return cin >= 512
+    return bool(WGRAD_HIP)
+
+
+def conv3x3_wgrad(x, dy, pad):
+    """x bf16 NHWC [N,cin,H,W] (forward input), dy bf16 NHWC [N,cout,Ho,Wo] -> fp32 [cout,cin,3,3]"""
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
+    assert dy.shape[2] == h + 2 * pad - 2 and dy.shape[3] == w + 2 * pad - 2
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.s2d_conv2d3x3_wgrad_workspace_bytes(n, h, w, cin, cout, pad), x.device)
+    check(lib.s2d_conv2d3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(_zero_page(x.device)), n, h, w, cin, cout, pad, _ptr(dw), _ptr(ws),
+                                            ws.numel(), _stream()), "s2d_conv2d3x3_wgrad_nhwc_bf16")
+    return dw
+
+
 def _nhwc_bf16(t):
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
@@ -110,7 +137,9 @@ class _Conv3x3Fn(torch.autograd.Function):
             else:
                 src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
             dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):
+            dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
+        elif ctx.needs_input_grad[1]:
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                             [False, True, False])
