@@ -135,6 +135,9 @@ def load():
         raise S2DError(
             f"{LIB_PATH} not found: the HIP extension is not built (python -m sparse2dense_amd.build). "
             "There is no CPU fallback for the sparse2dense_amd ops.")
+    # torch first: PyTorch-ROCm ships its own libamdhip64; the process must hold ONE HIP runtime (the one that owns the
+    # tensors' memory and streams), and the loader binds us to whichever copy of that SONAME is already mapped.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name, None)
