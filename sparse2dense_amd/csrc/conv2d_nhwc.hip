@@ -13,6 +13,7 @@
 // 128 B apart are 4-way conflicted and the kernel becomes LDS-bound).  Border taps read a zero page instead of branching.  The data gradient is the same
 // kernel with the flipped / transposed weight image (conv2d_pack_weights_bf16).
 #include "s2d_common.h"
+#include <cstdlib>
 
 namespace s2d {
 
@@ -169,6 +170,157 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
         }
 }
 
+
+// ---- pad = 1 variant with the A tile shared by the three kx taps ------------------------------------------------------
+// With padding 1 the input pixel of output pixel m at tap (ky, kx) is the ky-row centre
+// pixel of output pixel m + kx - 1, so one [130 px][64 ch] tile per (ky, channel chunk) serves all three kx taps: the tap
+// is a row offset of the fragment read, and the two pixels per image row whose neighbour falls off the row are zeroed
+// in the fragment (they would otherwise pick up the previous / next image row).  Staged bytes per three taps drop from
+// 96 KiB to 64.6 KiB.  K order: (ky, chunk, kx); the weight image is the one of the kernel above (step = tap*chunks+chunk).
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_p1_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
+                                                                   const float *__restrict__ bias,
+                                                                   const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
+                                                                   int cin, int cout, __bf16 *__restrict__ y) {
+    constexpr int NT = BN / 32;
+    constexpr int A_ROWS = 136;                  // 130 used: output pixels m0-1 .. m0+128
+    constexpr int A_BYTES = A_ROWS * 64 * 2;
+    constexpr int A_CHUNKS = A_ROWS * 8;
+    constexpr int A_LOADS = (A_CHUNKS + 255) / 256;
+    constexpr int B_BYTES = 64 * BN * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * A_BYTES; };
+    auto bbuf = [&](int b) -> char * { return smem + 2 * A_BYTES + b * B_BYTES; };
+
+    const int64_t m_total = (int64_t)n_img * H * W;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 128;
+    if (m0 >= m_total) return;
+    const int blk_n = blockIdx.y;
+    const int chunks = cin / 64;
+    const int T = 9 * chunks;
+
+    // staging roles: chunk id = threadIdx.x + 256u -> tile row j = id/8 (output pixel m0 - 1 + j), LDS slot id%8
+    int a_img[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
+    bool a_ok[A_LOADS];
+#pragma unroll
+    for (int u = 0; u < A_LOADS; ++u) {
+        const int id = threadIdx.x + 256 * u;
+        const int64_t m = m0 - 1 + id / 8;
+        a_ok[u] = id < 130 * 8 && m >= 0 && m < m_total;
+        const int64_t mm = a_ok[u] ? m : 0;
+        a_x[u] = (int)(mm % W);
+        a_y[u] = (int)((mm / W) % H);
+        a_img[u] = (int)(mm / ((int64_t)W * H));
+    }
+    const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * B_BYTES;
+    const int64_t wstep = (int64_t)(cout / BN) * B_BYTES;
+
+    auto stage_a = [&](int g, int buf) {   // g = ky*chunks + chunk
+        const int ky = g / chunks, chunk = g - ky * chunks;
+#pragma unroll
+        for (int u = 0; u < A_LOADS; ++u) {
+            const int id = threadIdx.x + 256 * u;
+            if (id < A_CHUNKS) {   // wave-uniform (A_CHUNKS is a multiple of 64)
+                const int part = (id & 7) ^ ((id >> 3) & 7);
+                const int yy = a_y[u] + ky - 1;
+                const bool ok = a_ok[u] && (unsigned)yy < (unsigned)H;
+                const __bf16 *src = ok ? x + (((int64_t)a_img[u] * H + yy) * W + a_x[u]) * cin + chunk * 64 + part * 8 : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(abuf(buf) + (size_t)(id - lane) * 16), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_b = [&](int t, int buf) {   // t = (ky*chunks + chunk)*3 + kx  ->  packed step (ky*3+kx)*chunks + chunk
+        const int g = t / 3, kx = t - 3 * g;
+        const int ky = g / chunks, chunk = g - ky * chunks;
+        const int s = (ky * 3 + kx) * chunks + chunk;
+        constexpr int B_UNITS = B_BYTES / 1024;
+#pragma unroll
+        for (int u = 0; u < (B_UNITS + 3) / 4; ++u) {
+            const int unit = u * 4 + wid;
+            if (unit < B_UNITS) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(wsrc + (int64_t)s * wstep + unit * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // per-lane border flags of the 4 M tiles: bit i of edge_l / edge_r = this lane's pixel of tile i sits at x == 0 / x == W-1
+    unsigned edge_l = 0, edge_r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + 64 * wm + 16 * i + r;
+        const int xx = (int)((m < m_total ? m : 0) % W);
+        edge_l |= (xx == 0 ? 1u : 0u) << i;
+        edge_r |= (xx == W - 1 ? 1u : 0u) << i;
+    }
+
+    f32x4c acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+
+    stage_a(0, 0);
+    stage_b(0, 0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int g = t / 3, kx = t - 3 * g;
+        if (t + 1 < T) {
+            stage_b(t + 1, (t + 1) & 1);
+            if (kx == 2) stage_a(g + 1, (g + 1) & 1);   // buffer last read in group g-1
+        }
+        const char *ab = abuf(g & 1), *bb = bbuf(t & 1);
+        const unsigned dead = kx == 0 ? edge_l : (kx == 2 ? edge_r : 0u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8c a[4], b[NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 64 * wm + 16 * i + r + kx;   // tile row of output pixel (64wm+16i+r) shifted by kx-1, +1 halo
+                a[i] = *reinterpret_cast<const bf16x8c *>(ab + (row * 8 + ((4 * h + q) ^ (row & 7))) * 16);
+                if ((dead >> i) & 1u) a[i] = bf16x8c{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[j] = *reinterpret_cast<const bf16x8c *>(bb + ((h * (BN / 16) + wn * NT + j) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int co_base = blk_n * BN + wn * (BN / 2);
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
+            if (m < m_total) {
+                __bf16 *dst = y + m * cout + co_base + r * NT;
+                if (NT == 4) {
+                    bf16x4c v;
+                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
+                    v[2] = (__bf16)(acc[i][2 % NT][reg] + bv[2 % NT]); v[3] = (__bf16)(acc[i][3 % NT][reg] + bv[3 % NT]);
+                    *reinterpret_cast<bf16x4c *>(dst) = v;
+                } else {
+                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
+                    dst[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
+                }
+            }
+        }
+}
+
 }  // namespace s2d
 
 using namespace s2d;
@@ -206,6 +358,36 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     hipStream_t st = (hipStream_t)stream;
     const int bn = conv_bn(cout);
     const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
+    // tap-shared A tile: measured on MI355X (r01) it wins where the A tile dominates the staged bytes (64-wide column
+    // blocks with many input channels: 512->64 196 -> 141 us) and is neutral-to-slightly-slower at 128-wide blocks
+    // (128->128 71 vs 74 us: those launches are bound by the per-K-step load round trip, not by staged bytes).
+    // S2D_CONV_SHARED_A=0/1 forces the choice for A/B runs.
+    const char *force = getenv("S2D_CONV_SHARED_A");
+    const bool shared_a = pad == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
+    if (shared_a) {
+        const size_t lds = 2 * (136 * 64 * 2) + 2 * (size_t)(64 * bn * 2);
+        if (bn == 128) {
+            auto kern = conv3x3_p1_nhwc_bf16_kernel<128>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y);
+        } else {
+            auto kern = conv3x3_p1_nhwc_bf16_kernel<64>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y);
+        }
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     if (bn == 128) {
         const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 128 * 2);
         auto kern = conv3x3_nhwc_bf16_kernel<128>;
