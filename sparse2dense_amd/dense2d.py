@@ -196,47 +196,55 @@ def _dist_sync():
     return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
 
 
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
 class _BNRowFn(torch.autograd.Function):
     """Batch norm over the rows of a row-major bf16 matrix: x is bf16 channels_last [N,C,H,W] (rows = N*H*W) or a
     sparse feature matrix [n,C].  y = relu?(bn(x) + residual?).  Training statistics over all rows (of all ranks when
-    `sync`)."""
+    `sync`).  This runs ~80 times per training step: per-channel vectors live in one [4,C] / [5,C] buffer each and are
+    passed as base pointer + offset (no tensor views on the hot path)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training):
-        import torch.distributed as dist
-        from . import hip_ops as H
         lib = _lib.load()
         c = x.shape[1]
         rows = x.numel() // c
         dev = x.device
-        gamma = gamma.float().contiguous()
-        beta = beta.float().contiguous()
+        gamma, beta = _f32c(gamma), _f32c(beta)
         track = module.track_running_stats
         ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
+        stream = _stream()
         count = None
         rm, rv, nbt = (module.running_mean, module.running_var, module.num_batches_tracked) if track else (None, None, None)
-        if training and not sync:
-            fin = torch.empty((4, c), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_stats_finalize_bf16(_ptr(x), rows, c, _ptr(gamma), _ptr(beta), float(eps),
-                                                    float(module.momentum if track else 0.0), _ptr(fin[0]), _ptr(fin[1]),
-                                                    _ptr(fin[2]), _ptr(fin[3]), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(ws),
-                                                    ws.numel(), _stream()), "s2d_bnrow_stats_finalize_bf16")
-        elif training:
-            packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_stats_bf16(_ptr(x), rows, c, _ptr(packed), 1, _ptr(ws), ws.numel(), _stream()),
-                  "s2d_bnrow_stats_bf16")   # [sum, sumsq, row count] in one vector
-            dist.all_reduce(packed)
-            count = packed[-1:].contiguous()
-            fin = H.bn1d_finalize_fwd(packed[:-1].contiguous(), count, gamma, beta, eps, module.momentum if track else 0.0,
-                                      rm, rv, nbt)
+        mom = float(module.momentum if track else 0.0)
+        if training:
+            fin = torch.empty((4, c), dtype=torch.float32, device=dev)   # rows: mean, invstd, scale, shift
+            fp, rb = fin.data_ptr(), 4 * c
+            if not sync:
+                check(lib.s2d_bnrow_stats_finalize_bf16(x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), mom,
+                                                        fp, fp + rb, fp + 2 * rb, fp + 3 * rb, _ptr(rm), _ptr(rv), _ptr(nbt),
+                                                        ws.data_ptr(), ws.numel(), stream), "s2d_bnrow_stats_finalize_bf16")
+            else:
+                import torch.distributed as dist
+                packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)   # [sum, sumsq, row count]
+                check(lib.s2d_bnrow_stats_bf16(x.data_ptr(), rows, c, packed.data_ptr(), 1, ws.data_ptr(), ws.numel(), stream),
+                      "s2d_bnrow_stats_bf16")
+                dist.all_reduce(packed)
+                count = packed   # kept alive for the backward: the count is its last element
+                pp = packed.data_ptr()
+                check(lib.s2d_bn1d_finalize_fwd_f32(pp, pp + 8 * c, gamma.data_ptr(), beta.data_ptr(), float(eps), mom, c, fp,
+                                                    fp + rb, fp + 2 * rb, fp + 3 * rb, _ptr(rm), _ptr(rv), _ptr(nbt), stream),
+                      "s2d_bn1d_finalize_fwd_f32")
         else:
             invstd = torch.rsqrt(module.running_var.float() + eps)
             scale = gamma * invstd
             fin = torch.stack([module.running_mean.float(), invstd, scale, beta - module.running_mean.float() * scale])
-        scale, shift = fin[2], fin[3]
+            fp, rb = fin.data_ptr(), 4 * c
         y = torch.empty_like(x)   # preserves channels_last
-        check(lib.s2d_bnrow_apply_bf16(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), rows, c, _ptr(y), _stream()),
-              "s2d_bnrow_apply_bf16")
+        check(lib.s2d_bnrow_apply_bf16(x.data_ptr(), fp + 2 * rb, fp + 3 * rb, _ptr(residual), int(relu), rows, c, y.data_ptr(),
+                                       stream), "s2d_bnrow_apply_bf16")
         has_res = residual is not None
         # with a residual the ReLU mask cannot be recomputed from x alone: keep y
         ctx.save_for_backward(x, gamma, fin, count, y if (has_res and relu) else None)
@@ -245,45 +253,52 @@ class _BNRowFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        import torch.distributed as dist
-        from . import hip_ops as H
         lib = _lib.load()
         x, gamma, fin, count, y = ctx.saved_tensors
-        mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
         c = x.shape[1]
         rows = x.numel() // c
         dev = x.device
-        dy = _nhwc_bf16(dy) if x.dim() == 4 else dy.to(torch.bfloat16).contiguous()
+        fp, rb = fin.data_ptr(), 4 * c          # mean, invstd, scale, shift
+        if dy.dtype != torch.bfloat16 or not (dy.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4
+                                              else dy.is_contiguous()):
+            dy = _nhwc_bf16(dy) if x.dim() == 4 else dy.to(torch.bfloat16).contiguous()
         relu = int(ctx.relu)
         ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
+        stream = _stream()
+        out = torch.empty((5, c), dtype=torch.float32, device=dev)   # rows: dgamma, dbeta, a, b, d
+        op = out.data_ptr()
         if ctx.training and not ctx.sync:
-            out = torch.empty((5, c), dtype=torch.float32, device=dev)
-            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, rows, c,
-                                                         _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(out[0]), _ptr(out[1]),
-                                                         _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), _ptr(ws), ws.numel(), _stream()),
+            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows,
+                                                         c, gamma.data_ptr(), fp, fp + rb, op, op + rb, op + 2 * rb, op + 3 * rb,
+                                                         op + 4 * rb, ws.data_ptr(), ws.numel(), stream),
                   "s2d_bnrow_bwd_reduce_finalize_bf16")
         else:
-            sums = torch.empty((2 * c,), dtype=torch.float32, device=dev)
-            sums_all = torch.empty_like(sums) if ctx.training else None
-            check(lib.s2d_bnrow_bwd_reduce_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, rows, c, _ptr(sums),
-                                                _ptr(sums_all), _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_bwd_reduce_bf16")
+            sums = torch.empty((2, 2 * c), dtype=torch.float32, device=dev)   # row 0: local sums, row 1: the copy that is all-reduced
+            sp = sums.data_ptr()
+            check(lib.s2d_bnrow_bwd_reduce_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows, c, sp,
+                                                sp + 8 * c if ctx.training else None, ws.data_ptr(), ws.numel(), stream),
+                  "s2d_bnrow_bwd_reduce_bf16")
             if ctx.training:
-                dist.all_reduce(sums_all)
-                out = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+                import torch.distributed as dist
+                dist.all_reduce(sums[1])
+                check(lib.s2d_bn1d_finalize_bwd_f32(sp, sp + 8 * c, count.data_ptr() + 8 * c, gamma.data_ptr(), fp, fp + rb, c, op,
+                                                    op + rb, op + 2 * rb, op + 3 * rb, op + 4 * rb, stream),
+                      "s2d_bn1d_finalize_bwd_f32")
             else:   # eval: y = x*scale + shift with constant scale
+                mean, invstd, scale = fin[0], fin[1], fin[2]
                 zeros = torch.zeros_like(scale)
-                out = torch.stack([invstd * (sums[c:] - mean * sums[:c]), sums[:c], scale, zeros, zeros])
-        dgamma, dbeta = out[0], out[1]
+                out = torch.stack([invstd * (sums[0, c:] - mean * sums[0, :c]), sums[0, :c], scale, zeros, zeros])
+                op = out.data_ptr()
         dx = dres = None
         want_res = ctx.has_res and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[0] or want_res:
             dx = torch.empty_like(x)
             if want_res:
                 dres = torch.empty_like(x) if relu else dy   # without a ReLU the residual gradient is dy itself
-            check(lib.s2d_bnrow_bwd_apply_bf16(_ptr(dy), _ptr(x), _ptr(y), _ptr(scale), _ptr(shift), relu, _ptr(out[2]),
-                                               _ptr(out[3]), _ptr(out[4]), rows, c, _ptr(dx),
-                                               _ptr(dres) if (want_res and relu) else None, _stream()), "s2d_bnrow_bwd_apply_bf16")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None
+            check(lib.s2d_bnrow_bwd_apply_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, op + 2 * rb,
+                                               op + 3 * rb, op + 4 * rb, rows, c, dx.data_ptr(),
+                                               dres.data_ptr() if (want_res and relu) else None, stream), "s2d_bnrow_bwd_apply_bf16")
+        return dx, out[0], out[1], dres, None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):

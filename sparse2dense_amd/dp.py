@@ -57,13 +57,14 @@ def convert_syncbn(module: nn.Module):
     return out
 
 
-def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=25, find_unused_parameters=False):
+def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=40, find_unused_parameters=False):
     force = os.environ.get("S2D_FORCE_DDP", "0") == "1"
     if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return model
     model = convert_syncbn(model)
+    bucket_cap_mb = float(os.environ.get("S2D_DDP_BUCKET_MB", bucket_cap_mb))
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters,
-                  gradient_as_bucket_view=True)
+                  gradient_as_bucket_view=True, static_graph=os.environ.get("S2D_DDP_STATIC_GRAPH", "0") == "1")
     if next(model.parameters()).is_cuda:
         dev = torch.cuda.current_device() if local_rank is None else local_rank
         return nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev, **kwargs)
