@@ -245,7 +245,7 @@ int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, cons
                            int64_t positions, float *dx, s2d_stream_t stream);
 
 /*
- * Dense 3x3 convolution, stride 1, padding 0 or 1, on NHWC bf16 activations (the BEV neck blocks
+ * Dense 3x3 convolution, stride 1 (or 2: forward only), padding 0 or 1, on NHWC bf16 activations (the BEV neck blocks
  * and the CenterHead towers: det3d/models/necks/rpn.py:126-145, bbox_heads/center_head.py:209-232;
  * replaces the cuDNN call behind nn.Conv2d there).  Implicit GEMM on v_mfma_f32_16x16x32_bf16,
  * fp32 accumulate, bf16 output [N][Ho][Wo][cout].  cin and cout multiples of 64.
@@ -261,7 +261,7 @@ int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int 
                                     int weight_nhwc, void *packed, s2d_stream_t stream);
 int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias,
                             const void *zero_page, int n_img, int h, int w, int cin, int cout,
-                            int pad, void *y, s2d_stream_t stream);
+                            int pad, int stride, void *y, s2d_stream_t stream);
 
 /*
  * Row-major bf16 batch norm: nn.BatchNorm2d (+ the ReLU that follows it) on NHWC bf16 activations

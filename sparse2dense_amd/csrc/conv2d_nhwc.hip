@@ -53,7 +53,7 @@ template <int BN>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                 const float *__restrict__ bias,
                                                                 const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
-                                                                int cin, int cout, int pad, __bf16 *__restrict__ y) {
+                                                                int cin, int cout, int pad, int stride, __bf16 *__restrict__ y) {
     constexpr int NT = BN / 32;            // N tiles per wave
     constexpr int A_BYTES = 128 * 64 * 2;  // 16 KiB: [128 px][64 ch]
     constexpr int B_BYTES = 64 * BN * 2;   // [2][BN/16][64 lanes][8]
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
     auto abuf = [&](int b) -> char * { return smem + b * A_BYTES; };
     auto bbuf = [&](int b) -> char * { return smem + 2 * A_BYTES + b * B_BYTES; };
 
-    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int Ho = (H + 2 * pad - 3) / stride + 1, Wo = (W + 2 * pad - 3) / stride + 1;
     const int64_t m_total = (int64_t)n_img * Ho * Wo;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
         const int64_t m = m0 + id / 8;
         a_ok[u] = m < m_total;
         const int64_t mm = a_ok[u] ? m : 0;
-        a_x[u] = (int)(mm % Wo);
-        a_y[u] = (int)((mm / Wo) % Ho);
+        a_x[u] = (int)(mm % Wo) * stride;            // input coordinates of tap (0,0) + pad
+        a_y[u] = (int)((mm / Wo) % Ho) * stride;
         a_img[u] = (int)(mm / ((int64_t)Wo * Ho));
     }
     const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * B_BYTES;
@@ -345,15 +345,16 @@ extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int
 }
 
 extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
-                                       int n_img, int h, int w, int cin, int cout, int pad, void *y, s2d_stream_t stream) {
-    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1),
-                  "conv2d3x3: bad argument");
+                                       int n_img, int h, int w, int cin, int cout, int pad, int stride, void *y,
+                                       s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1) &&
+                      (stride == 1 || stride == 2), "conv2d3x3: bad argument");
     if (!s2d_conv2d3x3_supported(cin, cout)) {
         set_error("conv2d3x3: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
-    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
-    S2D_CHECK_ARG(ho > 0 && wo > 0, "conv2d3x3: empty output");
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    S2D_CHECK_ARG(h + 2 * pad >= 3 && w + 2 * pad >= 3, "conv2d3x3: empty output");
     const int64_t m = (int64_t)n_img * ho * wo;
     hipStream_t st = (hipStream_t)stream;
     const int bn = conv_bn(cout);
@@ -363,7 +364,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     // (128->128 71 vs 74 us: those launches are bound by the per-K-step load round trip, not by staged bytes).
     // S2D_CONV_SHARED_A=0/1 forces the choice for A/B runs.
     const char *force = getenv("S2D_CONV_SHARED_A");
-    const bool shared_a = pad == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
+    const bool shared_a = pad == 1 && stride == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
     if (shared_a) {
         const size_t lds = 2 * (136 * 64 * 2) + 2 * (size_t)(64 * bn * 2);
         if (bn == 128) {
@@ -397,7 +398,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y);
     } else {
         const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 64 * 2);
         auto kern = conv3x3_nhwc_bf16_kernel<64>;
@@ -407,7 +408,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, (__bf16 *)y);
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y);
     }
     S2D_LAUNCH_CHECK();
     return S2D_OK;

@@ -5,7 +5,8 @@ reference's checkpoints and our golden fixtures load unchanged
 (/root/reference/det3d/models/necks/rpn.py:126-145, bbox_heads/center_head.py:209-232).
 The HIP path is taken for CUDA inputs under bf16 autocast when the layer is 3x3 / stride 1 /
 padding 0|1 / no groups / no dilation and both channel counts are multiples of 64; forward and
-data gradient run on the kernel, the weight gradient is MIOpen's (aten.convolution_backward).
+data gradient run on the kernel, the weight gradient on MIOpen (aten.convolution_backward) or, where it measured
+faster, on csrc/conv2d_wgrad.hip.  The stride-2 layer of a block runs its forward on the kernel too.
 Everything else (fp32 runs, CPU goldens, the 2-channel output convs) is the stock layer.
 """
 import ctypes
@@ -57,12 +58,12 @@ def pack_weights(weight, transpose_flip=False):
     return packed
 
 
-def conv3x3_nhwc(x, packed, bias, cin, cout, pad):
+def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1):
     """x: bf16 [N,cin,H,W] in channels_last memory -> bf16 [N,cout,Ho,Wo] channels_last"""
     lib = _lib.load()
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
     n, _, h, w = x.shape
-    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    ho, wo = (h + 2 * pad - 3) // stride + 1, (w + 2 * pad - 3) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     from . import hip_ops as H
     rec = None
@@ -72,7 +73,7 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad):
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
-                                      pad, _ptr(y), _stream()), "s2d_conv2d3x3_nhwc_bf16")
+                                      pad, stride, _ptr(y), _stream()), "s2d_conv2d3x3_nhwc_bf16")
     if rec is not None:
         rec["end"].record()
         H.PROFILE.append(rec)
@@ -112,38 +113,43 @@ def _nhwc_bf16(t):
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad):
+    def forward(ctx, x, weight, bias, pad, stride):
         xb = _nhwc_bf16(x)
         cout, cin = weight.shape[0], weight.shape[1]
         ctx.save_for_backward(xb, weight)
-        ctx.pad = pad
+        ctx.pad, ctx.stride = pad, stride
         ctx.has_bias = bias is not None
         b = None if bias is None else bias.detach().float().contiguous()
-        return conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad)
+        return conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride)
 
     @staticmethod
     def backward(ctx, dy):
         xb, weight = ctx.saved_tensors
-        pad = ctx.pad
+        pad, stride = ctx.pad, ctx.stride
         cout, cin = weight.shape[0], weight.shape[1]
         dyb = _nhwc_bf16(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            # dX = conv(dY, flip(W)^T) with padding 2 - pad_fwd - ... : for a 3x3 stride-1 conv the data gradient is a
-            # "full" correlation with padding (2 - pad); pad=1 -> 1.  pad=0 -> 2 is not a kernel mode: pad dY by one
-            # ring of zeros and run pad=1.
-            if pad == 1:
-                src = dyb
-            else:
-                src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
-            dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
-        if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):
-            dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
-        elif ctx.needs_input_grad[1]:
+        if stride != 1:   # the strided layer (one per RPN block): forward on the kernel above, both gradients through MIOpen
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                            [False, True, False])
-            dw = dwb.to(weight.dtype)
+            dx, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [stride, stride], [pad, pad], [1, 1], False,
+                                                             [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+            dw = None if dwb is None else dwb.to(weight.dtype)
+        else:
+            if ctx.needs_input_grad[0]:
+                # for a 3x3 stride-1 conv the data gradient is the correlation of dY with flip(W)^T at padding 2 - pad:
+                # pad=1 -> 1; pad=0 -> 2 is not a kernel mode: pad dY by one ring of zeros and run pad=1.
+                if pad == 1:
+                    src = dyb
+                else:
+                    src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+                dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
+            if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):
+                dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
+            elif ctx.needs_input_grad[1]:
+                wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                                [False, True, False])
+                dw = dwb.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:   # per-channel sum of dY: the row-reduce kernel's first output half
             lib = _lib.load()
             rows = dyb.shape[0] * dyb.shape[2] * dyb.shape[3]
@@ -152,20 +158,20 @@ class _Conv3x3Fn(torch.autograd.Function):
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class Conv3x3(nn.Conv2d):
     def _hip_ok(self, x):
         return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
                 and torch.get_autocast_gpu_dtype() == torch.bfloat16
-                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.dilation == (1, 1) and self.groups == 1
+                and self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.dilation == (1, 1) and self.groups == 1
                 and self.padding in ((0, 0), (1, 1)) and self.padding_mode == "zeros"
                 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0)
 
     def forward(self, x):
         if self._hip_ok(x):
-            return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0])
+            return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0])
         return super().forward(x)
 
 

@@ -211,3 +211,24 @@ def test_conv3x3_wgrad_matches_float64(n, cin, cout, h, w, pad):
     assert dw.shape == wr.grad.shape and dw.dtype == torch.float32
     err = (dw.double() - wr.grad).abs().max() / wr.grad.abs().max()
     assert err <= 1e-3, float(err)
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+def test_stride2_forward_and_module_backward(pad):
+    """stride-2 3x3 conv (first layer of the second RPN block, rpn.py:126-131): forward on the HIP kernel, gradients via MIOpen."""
+    from sparse2dense_amd import dense2d as D
+    x, wt, b = _mk(2, 128, 256, 41, 38, seed=5)
+    y = D.conv3x3_nhwc(x, D.pack_weights(wt), b, 128, 256, pad, stride=2)
+    ref = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), b, padding=pad, stride=2)
+    assert y.shape == ref.shape
+    assert (y.float() - ref).abs().max() <= 6e-3 * ref.abs().max()
+    m = D.Conv3x3(128, 256, 3, stride=2, padding=pad, bias=False).cuda()
+    xa = x.float().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = m(xa)
+    ya.float().sum().backward()
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(xr, m.weight.detach().to(torch.bfloat16).float(), None, padding=pad, stride=2)
+    yr.sum().backward()
+    assert (ya.float() - yr).abs().max() <= 6e-3 * yr.abs().max()
+    assert (xa.grad - xr.grad).abs().max() <= 1e-2 * xr.grad.abs().max()
