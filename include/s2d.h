@@ -259,9 +259,20 @@ int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, cons
 int s2d_conv2d3x3_supported(int cin, int cout);
 int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int transpose_flip,
                                     int weight_nhwc, void *packed, s2d_stream_t stream);
+/* stats_partial (optional, fp32 [ceil(n*ho*wo/128)][2][cout]): per 128-pixel tile (sum, sum of squares) of the stored
+ * outputs per channel — the statistics pass of a following batch norm, produced in the conv epilogue; finish it with
+ * s2d_bn_partials_finalize_f32 (or s2d_bn_partials_sum_f32 -> all-reduce -> s2d_bn1d_finalize_fwd_f32). */
 int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias,
                             const void *zero_page, int n_img, int h, int w, int cin, int cout,
-                            int pad, int stride, void *y, s2d_stream_t stream);
+                            int pad, int stride, void *y, float *stats_partial, s2d_stream_t stream);
+/* batch-norm statistics from per-tile partial sums [nblocks][2][c] (a conv epilogue's stats_partial) over n rows:
+ * fused finalize (mean, invstd, scale, shift, running stats, batches_tracked) or the plain [2c](+count) sums */
+int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma,
+                                 const float *beta, float eps, float momentum, float *mean,
+                                 float *invstd, float *scale, float *shift, float *running_mean,
+                                 float *running_var, int64_t *batches_tracked, s2d_stream_t stream);
+int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c, float *stats,
+                            int write_count, s2d_stream_t stream);
 
 /*
  * Row-major bf16 batch norm: nn.BatchNorm2d (+ the ReLU that follows it) on NHWC bf16 activations

@@ -49,11 +49,77 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
     out[i] = (__bf16)v;
 }
 
+// Shared epilogue.  C/D layout: row = 4*(lane>>4)+reg (pixel), col = lane&15 -> couts co_base + r*NT + j (NT consecutive).
+// stats_partial (optional): per-tile (sum, sum of squares) of the STORED bf16 outputs per output channel, laid out
+// [tile][2][cout] — exactly the partial-sum slabs the batch-norm finalize kernel consumes, so the BatchNorm that
+// follows this conv skips its statistics pass over the tensor.  Fixed summation order (deterministic).
+template <int BN>
+__device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[4][BN / 32], const float *__restrict__ bias, __bf16 *__restrict__ y,
+                                              int64_t m0, int64_t m_total, int cout, int blk_n, int wm, int wn, int r, int q,
+                                              char *smem, float *__restrict__ stats_partial, int tile) {
+    constexpr int NT = BN / 32;
+    const int co_base = blk_n * BN + wn * (BN / 2);
+    float bv[NT], s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
+        s1[j] = 0.f;
+        s2[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
+            if (m < m_total) {
+                __bf16 v[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    v[j] = (__bf16)(acc[i][j][reg] + bv[j]);
+                    const float f = (float)v[j];
+                    s1[j] += f;
+                    s2[j] += f * f;
+                }
+                __bf16 *dst = y + m * cout + co_base + r * NT;
+                if (NT == 4) {
+                    bf16x4c o;
+                    o[0] = v[0]; o[1] = v[1 % NT]; o[2] = v[2 % NT]; o[3] = v[3 % NT];
+                    *reinterpret_cast<bf16x4c *>(dst) = o;
+                } else {
+                    dst[0] = v[0];
+                    dst[1] = v[1 % NT];
+                }
+            }
+        }
+    if (stats_partial) {   // block-uniform
+        // lanes with the same r hold the same columns: fold the four q groups, then the two M waves through LDS
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
+        }
+        float *red = reinterpret_cast<float *>(smem);   // [wm][2][BN]; the K loop ended with a barrier, its buffers are free
+        if (q == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                red[(wm * 2 + 0) * BN + wn * (BN / 2) + r * NT + j] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * (BN / 2) + r * NT + j] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * BN; e += 256) {
+            const int which = e / BN, col = e - which * BN;
+            stats_partial[((int64_t)tile * 2 + which) * cout + blk_n * BN + col] = red[which * BN + col] + red[(2 + which) * BN + col];
+        }
+    }
+}
+
 template <int BN>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                 const float *__restrict__ bias,
                                                                 const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
-                                                                int cin, int cout, int pad, int stride, __bf16 *__restrict__ y) {
+                                                                int cin, int cout, int pad, int stride, __bf16 *__restrict__ y,
+                                                                float *__restrict__ stats_partial) {
     constexpr int NT = BN / 32;            // N tiles per wave
     constexpr int A_BYTES = 128 * 64 * 2;  // 16 KiB: [128 px][64 ch]
     constexpr int B_BYTES = 64 * BN * 2;   // [2][BN/16][64 lanes][8]
@@ -145,29 +211,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
         __syncthreads();   // tile s consumed by every wave; tile s+1 landed (the barrier's release drains the LDS-DMA)
     }
 
-    // epilogue: C/D layout row = 4*(lane>>4)+reg (pixel), col = lane&15 -> couts co_base + r*NT + j  (NT consecutive)
-    const int co_base = blk_n * BN + wn * (BN / 2);
-    float bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
-            if (m < m_total) {
-                __bf16 *dst = y + m * cout + co_base + r * NT;
-                if (NT == 4) {
-                    bf16x4c v;
-                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
-                    v[2] = (__bf16)(acc[i][2 % NT][reg] + bv[2 % NT]); v[3] = (__bf16)(acc[i][3 % NT][reg] + bv[3 % NT]);
-                    *reinterpret_cast<bf16x4c *>(dst) = v;
-                } else {
-                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
-                    dst[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
-                }
-            }
-        }
+    conv_epilogue<BN>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / 128));
 }
 
 
@@ -181,7 +225,8 @@ template <int BN>
 __global__ __launch_bounds__(256) void conv3x3_p1_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                    const float *__restrict__ bias,
                                                                    const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
-                                                                   int cin, int cout, __bf16 *__restrict__ y) {
+                                                                   int cin, int cout, __bf16 *__restrict__ y,
+                                                                   float *__restrict__ stats_partial) {
     constexpr int NT = BN / 32;
     constexpr int A_ROWS = 136;                  // 130 used: output pixels m0-1 .. m0+128
     constexpr int A_BYTES = A_ROWS * 64 * 2;
@@ -297,28 +342,7 @@ __global__ __launch_bounds__(256) void conv3x3_p1_nhwc_bf16_kernel(const __bf16 
         __syncthreads();
     }
 
-    const int co_base = blk_n * BN + wn * (BN / 2);
-    float bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
-            if (m < m_total) {
-                __bf16 *dst = y + m * cout + co_base + r * NT;
-                if (NT == 4) {
-                    bf16x4c v;
-                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
-                    v[2] = (__bf16)(acc[i][2 % NT][reg] + bv[2 % NT]); v[3] = (__bf16)(acc[i][3 % NT][reg] + bv[3 % NT]);
-                    *reinterpret_cast<bf16x4c *>(dst) = v;
-                } else {
-                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
-                    dst[1] = (__bf16)(acc[i][1 % NT][reg] + bv[1 % NT]);
-                }
-            }
-        }
+    conv_epilogue<BN>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / 128));
 }
 
 }  // namespace s2d
@@ -346,7 +370,7 @@ extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int
 
 extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
                                        int n_img, int h, int w, int cin, int cout, int pad, int stride, void *y,
-                                       s2d_stream_t stream) {
+                                       float *stats_partial, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1) &&
                       (stride == 1 || stride == 2), "conv2d3x3: bad argument");
     if (!s2d_conv2d3x3_supported(cin, cout)) {
@@ -375,7 +399,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
                 attr_set = true;
             }
             hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y);
+                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y, stats_partial);
         } else {
             auto kern = conv3x3_p1_nhwc_bf16_kernel<64>;
             static bool attr_set = false;
@@ -384,7 +408,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
                 attr_set = true;
             }
             hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y);
+                               (const __bf16 *)zero_page, n_img, h, w, cin, cout, (__bf16 *)y, stats_partial);
         }
         S2D_LAUNCH_CHECK();
         return S2D_OK;
@@ -398,7 +422,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y);
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
     } else {
         const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 64 * 2);
         auto kern = conv3x3_nhwc_bf16_kernel<64>;
@@ -408,7 +432,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
             attr_set = true;
         }
         hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y);
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
     }
     S2D_LAUNCH_CHECK();
     return S2D_OK;

@@ -1037,3 +1037,26 @@ extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const voi
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
+
+// ---- batch-norm statistics whose reduction pass ran in a producer's epilogue -----------------------------------------
+extern "C" int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta,
+                                            float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
+                                            float *running_mean, float *running_var, int64_t *batches_tracked,
+                                            s2d_stream_t stream) {
+    S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && gamma && beta && mean && invstd && scale && shift,
+                  "bn_partials_finalize: bad argument");
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, (float)n,
+                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
+                       (long long *)batches_tracked);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c, float *stats, int write_count,
+                                       s2d_stream_t stream) {
+    S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && stats, "bn_partials_sum: bad argument");
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, 2 * c, stats,
+                       (float *)nullptr, write_count ? (float)n : -1.f);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

@@ -58,8 +58,9 @@ def pack_weights(weight, transpose_flip=False):
     return packed
 
 
-def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1):
-    """x: bf16 [N,cin,H,W] in channels_last memory -> bf16 [N,cout,Ho,Wo] channels_last"""
+def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
+    """x: bf16 [N,cin,H,W] in channels_last memory -> bf16 [N,cout,Ho,Wo] channels_last.  bn_stats: also returns the
+    per-tile (sum, sumsq) slabs [tiles, 2, cout] of the output (the statistics pass of a following batch norm)."""
     lib = _lib.load()
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
     n, _, h, w = x.shape
@@ -72,12 +73,13 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1):
                    dense=True, in_pixels=n * h * w, start=torch.cuda.Event(enable_timing=True),
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
+    partial = torch.empty(((n * ho * wo + 127) // 128, 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
     check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
-                                      pad, stride, _ptr(y), _stream()), "s2d_conv2d3x3_nhwc_bf16")
+                                      pad, stride, _ptr(y), _ptr(partial), _stream()), "s2d_conv2d3x3_nhwc_bf16")
     if rec is not None:
         rec["end"].record()
         H.PROFILE.append(rec)
-    return y
+    return (y, partial) if bn_stats else y
 
 
 # which weight gradients take the hand-written transpose-read kernel (csrc/conv2d_wgrad.hip) instead of MIOpen:
@@ -113,17 +115,21 @@ def _nhwc_bf16(t):
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, stride):
+    def forward(ctx, x, weight, bias, pad, stride, bn_stats):
         xb = _nhwc_bf16(x)
         cout, cin = weight.shape[0], weight.shape[1]
         ctx.save_for_backward(xb, weight)
         ctx.pad, ctx.stride = pad, stride
         ctx.has_bias = bias is not None
         b = None if bias is None else bias.detach().float().contiguous()
+        if bn_stats:
+            y, partial = conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride, bn_stats=True)
+            ctx.mark_non_differentiable(partial)
+            return y, partial
         return conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         xb, weight = ctx.saved_tensors
         pad, stride = ctx.pad, ctx.stride
         cout, cin = weight.shape[0], weight.shape[1]
@@ -158,7 +164,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class Conv3x3(nn.Conv2d):
@@ -169,9 +175,15 @@ class Conv3x3(nn.Conv2d):
                 and self.padding in ((0, 0), (1, 1)) and self.padding_mode == "zeros"
                 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0)
 
+    emit_bn_stats = False   # set by fuse_bn_relu() when a FastBatchNorm2d follows: its statistics come out of our epilogue
+
     def forward(self, x):
         if self._hip_ok(x):
-            return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0])
+            if self.emit_bn_stats and self.training and torch.is_grad_enabled():
+                y, partial = _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0], True)
+                y._s2d_bn_partial = partial   # read (forward pass only) by the FastBatchNorm2d that follows
+                return y
+            return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0], False)
         return super().forward(x)
 
 
@@ -213,7 +225,7 @@ class _BNRowFn(torch.autograd.Function):
     passed as base pointer + offset (no tensor views on the hot path)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training):
+    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training, partial=None):
         lib = _lib.load()
         c = x.shape[1]
         rows = x.numel() // c
@@ -228,15 +240,23 @@ class _BNRowFn(torch.autograd.Function):
         if training:
             fin = torch.empty((4, c), dtype=torch.float32, device=dev)   # rows: mean, invstd, scale, shift
             fp, rb = fin.data_ptr(), 4 * c
-            if not sync:
+            if partial is not None and not sync:   # statistics pass already done in the producing conv's epilogue
+                check(lib.s2d_bn_partials_finalize_f32(partial.data_ptr(), partial.shape[0], rows, c, gamma.data_ptr(),
+                                                       beta.data_ptr(), float(eps), mom, fp, fp + rb, fp + 2 * rb, fp + 3 * rb,
+                                                       _ptr(rm), _ptr(rv), _ptr(nbt), stream), "s2d_bn_partials_finalize_f32")
+            elif not sync:
                 check(lib.s2d_bnrow_stats_finalize_bf16(x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), mom,
                                                         fp, fp + rb, fp + 2 * rb, fp + 3 * rb, _ptr(rm), _ptr(rv), _ptr(nbt),
                                                         ws.data_ptr(), ws.numel(), stream), "s2d_bnrow_stats_finalize_bf16")
             else:
                 import torch.distributed as dist
                 packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)   # [sum, sumsq, row count]
-                check(lib.s2d_bnrow_stats_bf16(x.data_ptr(), rows, c, packed.data_ptr(), 1, ws.data_ptr(), ws.numel(), stream),
-                      "s2d_bnrow_stats_bf16")
+                if partial is not None:
+                    check(lib.s2d_bn_partials_sum_f32(partial.data_ptr(), partial.shape[0], rows, c, packed.data_ptr(), 1, stream),
+                          "s2d_bn_partials_sum_f32")
+                else:
+                    check(lib.s2d_bnrow_stats_bf16(x.data_ptr(), rows, c, packed.data_ptr(), 1, ws.data_ptr(), ws.numel(), stream),
+                          "s2d_bnrow_stats_bf16")
                 dist.all_reduce(packed)
                 count = packed   # kept alive for the backward: the count is its last element
                 pp = packed.data_ptr()
@@ -304,7 +324,7 @@ class _BNRowFn(torch.autograd.Function):
             check(lib.s2d_bnrow_bwd_apply_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, op + 2 * rb,
                                                op + 3 * rb, op + 4 * rb, rows, c, dx.data_ptr(),
                                                dres.data_ptr() if (want_res and relu) else None, stream), "s2d_bnrow_bwd_apply_bf16")
-        return dx, out[0], out[1], dres, None, None, None, None, None
+        return dx, out[0], out[1], dres, None, None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):
@@ -327,7 +347,10 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         training = self.training or not self.track_running_stats
         sync = training and _dist_sync()
         if self._hip_ok(x):
-            return _BNRowFn.apply(x, self.weight, self.bias, None, relu, self.eps, sync, self, training)
+            partial = getattr(x, "_s2d_bn_partial", None) if training else None
+            if partial is not None and partial.shape[2] != self.num_features:
+                partial = None
+            return _BNRowFn.apply(x, self.weight, self.bias, None, relu, self.eps, sync, self, training, partial)
         if sync and x.is_cuda:
             import torch.distributed as dist
             from torch.nn.modules._functions import SyncBatchNorm as _SyncFn
@@ -348,4 +371,6 @@ def fuse_bn_relu(layers):
         if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.ReLU):
             layers[i].fused_relu = True
             layers[i + 1] = nn.Identity()
+        if isinstance(layers[i], Conv3x3) and isinstance(layers[i + 1], FastBatchNorm2d):
+            layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials
     return layers

@@ -232,3 +232,28 @@ def test_stride2_forward_and_module_backward(pad):
     yr.sum().backward()
     assert (ya.float() - yr).abs().max() <= 6e-3 * yr.abs().max()
     assert (xa.grad - xr.grad).abs().max() <= 1e-2 * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,pad,stride", [(64, 128, 1, 1), (128, 64, 0, 1), (128, 256, 0, 2), (512, 64, 1, 1)])
+def test_conv_epilogue_bn_statistics_match_the_reduction_kernel(cin, cout, pad, stride):
+    """Conv3x3 -> FastBatchNorm2d(+ReLU): batch statistics produced in the conv epilogue (per-tile partial sums) must give
+    the same normalisation as the stand-alone statistics pass over the stored bf16 tensor (different fp32 summation order)."""
+    import copy
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(9)
+    fused = torch.nn.Sequential(*D.fuse_bn_relu([D.Conv3x3(cin, cout, 3, stride=stride, padding=pad, bias=False),
+                                                 D.FastBatchNorm2d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU()])).cuda().train()
+    assert fused[0].emit_bn_stats and fused[1].fused_relu
+    plain = copy.deepcopy(fused)
+    plain[0].emit_bn_stats = False
+    x = torch.randn(3, cin, 37, 29, device="cuda")
+    outs = []
+    for m in (fused, plain):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        y.float().square().sum().backward()
+        outs.append((y, xi.grad, m[0].weight.grad, m[1].weight.grad, m[1].bias.grad, m[1].running_mean, m[1].running_var))
+    for name, u, v in zip(["y", "dx", "dw", "dgamma", "dbeta", "rmean", "rvar"], *outs):
+        err = (u.float() - v.float()).abs().max() / v.float().abs().max().clamp(min=1e-9)
+        assert err <= (1e-2 if name in ("y", "dx", "dw") else 1e-4), (name, float(err))   # bf16 tensors may flip one rounding
