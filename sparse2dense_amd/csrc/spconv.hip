@@ -456,6 +456,109 @@ static int dispatch_fwd_cout(const float *in, const float *w, const float *bias,
     }
 }
 
+// bf16-storage weight gradient for the narrow stages (CIN, COUT in {16, 32}): with 2-byte elements the kernel above
+// issues one 2- or 4-byte load per lane and pair, which leaves the stage-0/1 launches (most pairs, fewest FLOPs) bound by
+// load instructions.  Here every lane fetches 16 bytes of a gathered row, the wave parks the 32-pair tile in its
+// private LDS slice as [pair][channels] and the MFMA fragments come back through the gfx950 transpose read
+// (ds_read_b64_tr_b16: a 16-lane group reads a [4 pair][16 ch] block, each lane gets the 4 pairs of its channel; lane
+// group g therefore holds pairs {4g..4g+3, 16+4g..16+4g+3} of the 32-pair K-step for A and B alike).  One wave = one
+// row split; no workgroup barrier (LDS operations of a wave execute in order).
+typedef int wg_i32x2 __attribute__((ext_vector_type(2)));
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+template <int HI_OFF>
+__device__ __forceinline__ bf16x8 wg_tr_read(unsigned lds_addr) {
+    wg_i32x2 lo, hi;   // early-clobber: the address register is read again by the second instruction
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(lds_addr), "n"(HI_OFF) : "memory");
+    wg_i32x4 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_s16_small(const __bf16 *__restrict__ in, const __bf16 *__restrict__ dout,
+                                                              const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                              int rows_per_split, float *__restrict__ partial) {
+    constexpr int MA = CIN / 16, NB = COUT / 16;          // 16-channel tiles
+    constexpr int RS_A = CIN * 2, RS_B = COUT * 2;        // row strides of the LDS tiles in bytes
+    constexpr int LPR_A = CIN / 8, LPR_B = COUT / 8;      // lanes (16-byte pieces) per gathered row
+    constexpr int TILE_A = 32 * RS_A, TILE_B = 32 * RS_B;
+    __shared__ int2 pair_lds[4][64];
+    __shared__ __attribute__((aligned(16))) char tile_lds[4][TILE_A + TILE_B];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    const int k = blockIdx.x;
+    const int split = blockIdx.y * 4 + wid;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+    int2 *mypairs = pair_lds[wid];
+    char *ta = tile_lds[wid], *tb = tile_lds[wid] + TILE_A;
+    const unsigned ta_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)ta);
+    const unsigned tb_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)tb);
+    const int tr_off_a = (4 * g + (c16 >> 2)) * RS_A + (c16 & 3) * 8;
+    const int tr_off_b = (4 * g + (c16 >> 2)) * RS_B + (c16 & 3) * 8;
+
+    f32x4 acc[MA][NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = r_begin; base < r_end; base += 64) {
+        const int o_l = base + lane;
+        const int j_l = o_l < r_end ? nk[o_l] : -1;
+        const unsigned long long mask = __ballot(j_l >= 0);
+        const int cnt = __popcll(mask);
+        if (cnt == 0) continue;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (j_l >= 0) mypairs[rank] = make_int2(o_l, j_l);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int p0 = 0; p0 < cnt; p0 += 32) {
+            // gather: 16 bytes per lane; rows past the window's pair count are zero
+            uint4 va[(32 * LPR_A + 63) / 64], vb[(32 * LPR_B + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (32 * LPR_A + 63) / 64; ++u) {
+                const int c = lane + 64 * u, pr = c / LPR_A, part = c % LPR_A;
+                const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
+                va[u] = *reinterpret_cast<const uint4 *>(in + (int64_t)pp.y * CIN + part * 8);
+                if (p0 + pr >= cnt) va[u] = uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < (32 * LPR_B + 63) / 64; ++u) {
+                const int c = lane + 64 * u, pr = c / LPR_B, part = c % LPR_B;
+                const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
+                vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + part * 8);
+                if (p0 + pr >= cnt) vb[u] = uint4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < (32 * LPR_A + 63) / 64; ++u) *reinterpret_cast<uint4 *>(ta + (lane + 64 * u) * 16) = va[u];
+#pragma unroll
+            for (int u = 0; u < (32 * LPR_B + 63) / 64; ++u) *reinterpret_cast<uint4 *>(tb + (lane + 64 * u) * 16) = vb[u];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bf16x8 a[MA], b[NB];
+#pragma unroll
+            for (int m = 0; m < MA; ++m) a[m] = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) b[n] = wg_tr_read<16 * RS_B>(tb_addr + tr_off_b + n * 32);
+#pragma unroll
+            for (int m = 0; m < MA; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // C/D layout: row (ci within tile) = 4*(lane>>4)+reg, col (co within tile) = lane&15
+    float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dst[(int64_t)(16 * m + 4 * g + reg) * COUT + 16 * n + c16] = acc[m][n][reg];
+}
+
 struct WgradPlan {
     int n_split;        // total row splits
     int rows_per_split; // multiple of 4
@@ -487,6 +590,13 @@ static int g_wgrad_mode = 0;  // 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf1
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
+    if constexpr (CIN <= 32 && COUT <= 32) {
+        if (g_wgrad_mode == 2) {   // narrow stages on bf16 storage: 16-byte gathers + LDS transpose reads
+            hipLaunchKernelGGL((spconv_wgrad_s16_small<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
+                               (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
+            return;
+        }
+    }
     if (g_wgrad_mode == 2)
         hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, __bf16>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
                            (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
