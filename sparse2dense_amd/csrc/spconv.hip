@@ -18,6 +18,7 @@
 // Channel counts that are not multiples of 16 (the 5-channel input layer) take the VALU kernels
 // at the bottom; they are bandwidth-trivial.
 #include "s2d_common.h"
+#include <cstdlib>
 
 namespace s2d {
 
@@ -456,9 +457,8 @@ static int dispatch_fwd_cout(const float *in, const float *w, const float *bias,
     }
 }
 
-// bf16-storage weight gradient for the narrow stages (CIN, COUT in {16, 32}): with 2-byte elements the kernel above
-// issues one 2- or 4-byte load per lane and pair, which leaves the stage-0/1 launches (most pairs, fewest FLOPs) bound by
-// load instructions.  Here every lane fetches 16 bytes of a gathered row, the wave parks the 32-pair tile in its
+// bf16-storage weight gradient through LDS transpose reads: with 2-byte elements the kernel above issues one 2- to
+// 8-byte load per lane and pair, which leaves the launches with many pairs and few FLOPs bound by load instructions.  Here every lane fetches 16 bytes of a gathered row, the wave parks the 32-pair tile in its
 // private LDS slice as [pair][channels] and the MFMA fragments come back through the gfx950 transpose read
 // (ds_read_b64_tr_b16: a 16-lane group reads a [4 pair][16 ch] block, each lane gets the 4 pairs of its channel; lane
 // group g therefore holds pairs {4g..4g+3, 16+4g..16+4g+3} of the 32-pair K-step for A and B alike).  One wave = one
@@ -476,20 +476,34 @@ __device__ __forceinline__ bf16x8 wg_tr_read(unsigned lds_addr) {
 }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void spconv_wgrad_s16_small(const __bf16 *__restrict__ in, const __bf16 *__restrict__ dout,
-                                                              const int32_t *__restrict__ nbr, int n_out, int kvol,
-                                                              int rows_per_split, float *__restrict__ partial) {
-    constexpr int MA = CIN / 16, NB = COUT / 16;          // 16-channel tiles
-    constexpr int RS_A = CIN * 2, RS_B = COUT * 2;        // row strides of the LDS tiles in bytes
-    constexpr int LPR_A = CIN / 8, LPR_B = COUT / 8;      // lanes (16-byte pieces) per gathered row
+struct WgS16Cfg {
+    static constexpr int NBMAX = CIN == 128 ? 2 : 4;
+    static constexpr int NB = COUT / 16 < NBMAX ? COUT / 16 : NBMAX;              // 16-column tiles per wave
+    static constexpr int WCO = COUT / (16 * NB);                                  // waves across the output channels
+    static constexpr int WROW = 4 / WCO;                                          // row splits per workgroup
+    static constexpr int MA = CIN / 16;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restrict__ in, const __bf16 *__restrict__ dout,
+                                                           const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                           int rows_per_split, float *__restrict__ partial) {
+    typedef WgS16Cfg<CIN, COUT> C;
+    constexpr int MA = C::MA, NB = C::NB;
+    constexpr int CB = 16 * NB;                           // output channels of this wave
+    constexpr int RS_A = CIN * 2, RS_B = CB * 2;          // row strides of the LDS tiles in bytes
+    constexpr int LPR_A = CIN / 8, LPR_B = CB / 8;        // lanes (16-byte pieces) per gathered row
     constexpr int TILE_A = 32 * RS_A, TILE_B = 32 * RS_B;
+    constexpr int LA = (32 * LPR_A + 63) / 64, LB = (32 * LPR_B + 63) / 64;
     __shared__ int2 pair_lds[4][64];
     __shared__ __attribute__((aligned(16))) char tile_lds[4][TILE_A + TILE_B];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wco = wid % C::WCO, wrow = wid / C::WCO;
     const int g = lane >> 4, c16 = lane & 15;
     const int k = blockIdx.x;
-    const int split = blockIdx.y * 4 + wid;
+    const int split = blockIdx.y * C::WROW + wrow;
+    const int co_base = wco * CB;
     const int r_begin = split * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
     const int32_t *nk = nbr + (int64_t)k * n_out;
@@ -517,35 +531,35 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_small(const __bf16 *__re
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int p0 = 0; p0 < cnt; p0 += 32) {
             // gather: 16 bytes per lane; rows past the window's pair count are zero
-            uint4 va[(32 * LPR_A + 63) / 64], vb[(32 * LPR_B + 63) / 64];
+            uint4 va[LA], vb[LB];
 #pragma unroll
-            for (int u = 0; u < (32 * LPR_A + 63) / 64; ++u) {
+            for (int u = 0; u < LA; ++u) {
                 const int c = lane + 64 * u, pr = c / LPR_A, part = c % LPR_A;
                 const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
                 va[u] = *reinterpret_cast<const uint4 *>(in + (int64_t)pp.y * CIN + part * 8);
                 if (p0 + pr >= cnt) va[u] = uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
-            for (int u = 0; u < (32 * LPR_B + 63) / 64; ++u) {
+            for (int u = 0; u < LB; ++u) {
                 const int c = lane + 64 * u, pr = c / LPR_B, part = c % LPR_B;
                 const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
-                vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + part * 8);
+                vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + co_base + part * 8);
                 if (p0 + pr >= cnt) vb[u] = uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
-            for (int u = 0; u < (32 * LPR_A + 63) / 64; ++u) *reinterpret_cast<uint4 *>(ta + (lane + 64 * u) * 16) = va[u];
+            for (int u = 0; u < LA; ++u) *reinterpret_cast<uint4 *>(ta + (lane + 64 * u) * 16) = va[u];
 #pragma unroll
-            for (int u = 0; u < (32 * LPR_B + 63) / 64; ++u) *reinterpret_cast<uint4 *>(tb + (lane + 64 * u) * 16) = vb[u];
+            for (int u = 0; u < LB; ++u) *reinterpret_cast<uint4 *>(tb + (lane + 64 * u) * 16) = vb[u];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bf16x8 a[MA], b[NB];
-#pragma unroll
-            for (int m = 0; m < MA; ++m) a[m] = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
+            bf16x8 b[NB];
 #pragma unroll
             for (int n = 0; n < NB; ++n) b[n] = wg_tr_read<16 * RS_B>(tb_addr + tr_off_b + n * 32);
 #pragma unroll
-            for (int m = 0; m < MA; ++m)
+            for (int m = 0; m < MA; ++m) {
+                const bf16x8 a = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -556,10 +570,11 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_small(const __bf16 *__re
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) dst[(int64_t)(16 * m + 4 * g + reg) * COUT + 16 * n + c16] = acc[m][n][reg];
+            for (int reg = 0; reg < 4; ++reg) dst[(int64_t)(16 * m + 4 * g + reg) * COUT + co_base + 16 * n + c16] = acc[m][n][reg];
 }
 
 struct WgradPlan {
+    bool tr;            // bf16-storage transpose-read kernel (its wave layout differs)
     int n_split;        // total row splits
     int rows_per_split; // multiple of 4
     int grid_y;
@@ -567,11 +582,26 @@ struct WgradPlan {
     int wrow;
 };
 
+static int g_wgrad_mode = 0;  // 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf16 MFMA on bf16 storage (set per call by the entry points)
+static int g_wgrad_tr = -1;   // S2D_WGRAD_TR=0/1 forces the register-assembled / transpose-read bf16-storage kernel (A/B runs)
+
 static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
     WgradPlan p;
     p.mfma = (cin == 16 || cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
+    if (g_wgrad_tr < 0) {
+        const char *e = getenv("S2D_WGRAD_TR");
+        g_wgrad_tr = e ? (e[0] == '1' ? 1 : 0) : 2;
+    }
+    // measured (r01, bench scene): the transpose-read kernel wins for cin <= 64 (16->16 144 -> 97 us ... 64->128 81 -> 58 us,
+    // launch + reduce included) and loses at cin = 128 (120 -> 131 us: four waves each re-gather the 256-byte rows)
+    p.tr = g_wgrad_mode == 2 && p.mfma && (g_wgrad_tr == 1 || (g_wgrad_tr == 2 && cin <= 64));
     int vb = cout >= 32 ? 2 : 1;
     int wco = p.mfma ? cout / (16 * vb) : 1;
+    if (p.tr) {
+        const int nbmax = cin == 128 ? 2 : 4;
+        const int nb = cout / 16 < nbmax ? cout / 16 : nbmax;
+        wco = cout / (16 * nb);
+    }
     p.wrow = p.mfma ? 4 / wco : 1;
     // aim at ~2048 waves in flight, at least 256 rows per split
     int64_t want_blocks_y = ceil_div(2048, (int64_t)kvol * 4);
@@ -585,17 +615,13 @@ static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
     return p;
 }
 
-static int g_wgrad_mode = 0;  // 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf16 MFMA on bf16 storage (set per call by the entry points)
-
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
-    if constexpr (CIN <= 32 && COUT <= 32) {
-        if (g_wgrad_mode == 2) {   // narrow stages on bf16 storage: 16-byte gathers + LDS transpose reads
-            hipLaunchKernelGGL((spconv_wgrad_s16_small<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
-                               (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
-            return;
-        }
+    if (g_wgrad_mode == 2 && p.tr) {   // bf16 storage: 16-byte gathers + per-wave LDS tile + transpose reads
+        hipLaunchKernelGGL((spconv_wgrad_s16_tr<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
+                           (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
+        return;
     }
     if (g_wgrad_mode == 2)
         hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, __bf16>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
@@ -654,8 +680,17 @@ extern "C" int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const floa
 
 extern "C" size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int cin, int cout) {
     if (n_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0) return 0;
-    WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
-    return align_up((size_t)p.n_split * kvol * cin * cout * sizeof(float), 256);
+    // one size for every entry point: the bf16-storage kernels split the rows differently from the fp32-storage ones
+    const int saved = g_wgrad_mode;
+    size_t need = 0;
+    for (int mode = 0; mode <= 2; mode += 2) {
+        g_wgrad_mode = mode;
+        const WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
+        const size_t b = (size_t)p.n_split * kvol * cin * cout * sizeof(float);
+        need = b > need ? b : need;
+    }
+    g_wgrad_mode = saved;
+    return align_up(need, 256);
 }
 
 static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
