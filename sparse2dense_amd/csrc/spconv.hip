@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
 }
 
 struct WgradPlan {
+    int mode;           // storage / MFMA variant, see wgrad_plan
     bool tr;            // bf16-storage transpose-read kernel (its wave layout differs)
     int n_split;        // total row splits
     int rows_per_split; // multiple of 4
@@ -582,19 +583,23 @@ struct WgradPlan {
     int wrow;
 };
 
-static int g_wgrad_mode = 0;  // 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf16 MFMA on bf16 storage (set per call by the entry points)
-static int g_wgrad_tr = -1;   // S2D_WGRAD_TR=0/1 forces the register-assembled / transpose-read bf16-storage kernel (A/B runs)
-
-static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
-    WgradPlan p;
-    p.mfma = (cin == 16 || cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
-    if (g_wgrad_tr < 0) {
+// mode: 0 fp32 MFMA, 1 bf16 MFMA on fp32 storage, 2 bf16 MFMA on bf16 storage (one per C-ABI entry point)
+static int wgrad_tr_override() {   // S2D_WGRAD_TR=0/1 forces the register-assembled / transpose-read bf16-storage kernel (A/B runs)
+    static const int v = [] {
         const char *e = getenv("S2D_WGRAD_TR");
-        g_wgrad_tr = e ? (e[0] == '1' ? 1 : 0) : 2;
-    }
+        return e ? (e[0] == '1' ? 1 : 0) : 2;
+    }();
+    return v;
+}
+
+static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout) {
+    WgradPlan p;
+    p.mode = mode;
+    const int tr_pref = wgrad_tr_override();
+    p.mfma = (cin == 16 || cin == 32 || cin == 64 || cin == 128) && (cout == 16 || cout == 32 || cout == 64 || cout == 128);
     // measured (r01, bench scene): the transpose-read kernel wins for cin <= 64 (16->16 144 -> 97 us ... 64->128 81 -> 58 us,
     // launch + reduce included) and loses at cin = 128 (120 -> 131 us: four waves each re-gather the 256-byte rows)
-    p.tr = g_wgrad_mode == 2 && p.mfma && (g_wgrad_tr == 1 || (g_wgrad_tr == 2 && cin <= 64));
+    p.tr = mode == 2 && p.mfma && (tr_pref == 1 || (tr_pref == 2 && cin <= 64));
     int vb = cout >= 32 ? 2 : 1;
     int wco = p.mfma ? cout / (16 * vb) : 1;
     if (p.tr) {
@@ -618,15 +623,15 @@ static WgradPlan wgrad_plan(int64_t n_out, int kvol, int cin, int cout) {
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
-    if (g_wgrad_mode == 2 && p.tr) {   // bf16 storage: 16-byte gathers + per-wave LDS tile + transpose reads
+    if (p.mode == 2 && p.tr) {   // bf16 storage: 16-byte gathers + per-wave LDS tile + transpose reads
         hipLaunchKernelGGL((spconv_wgrad_s16_tr<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
                            (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
         return;
     }
-    if (g_wgrad_mode == 2)
+    if (p.mode == 2)
         hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, __bf16>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
                            (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
-    else if (g_wgrad_mode == 1)
+    else if (p.mode == 1)
         hipLaunchKernelGGL((spconv_wgrad_bf16<CIN, COUT, float>), dim3(kvol, p.grid_y), dim3(256), 0, st, in, dout, nbr, n_out,
                            kvol, p.rows_per_split, partial);
     else
@@ -681,35 +686,28 @@ extern "C" int s2d_spconv_fwd_f32(const float *in_feat, int64_t n_in, const floa
 extern "C" size_t s2d_spconv_wgrad_workspace_bytes(int64_t n_out, int kvol, int cin, int cout) {
     if (n_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0) return 0;
     // one size for every entry point: the bf16-storage kernels split the rows differently from the fp32-storage ones
-    const int saved = g_wgrad_mode;
     size_t need = 0;
     for (int mode = 0; mode <= 2; mode += 2) {
-        g_wgrad_mode = mode;
-        const WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
+        const WgradPlan p = wgrad_plan(mode, n_out, kvol, cin, cout);
         const size_t b = (size_t)p.n_split * kvol * cin * cout * sizeof(float);
         need = b > need ? b : need;
     }
-    g_wgrad_mode = saved;
     return align_up(need, 256);
 }
 
-static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
+static int wgrad_impl(int mode, const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
                       int cin, int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 extern "C" int s2d_spconv_wgrad_f32(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
                                     int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
                                     s2d_stream_t stream) {
-    g_wgrad_mode = 0;
-    return wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
+    return wgrad_impl(0, in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
 }
 
 extern "C" int s2d_spconv_wgrad_bf16(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr,
                                      int64_t n_out, int kvol, int cin, int cout, float *dweight, void *ws, size_t ws_bytes,
                                      s2d_stream_t stream) {
-    g_wgrad_mode = 1;
-    int rc = wgrad_impl(in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
-    g_wgrad_mode = 0;
-    return rc;
+    return wgrad_impl(1, in_feat, n_in, dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes, stream);
 }
 
 // bf16-storage ("s16") weight gradient: in_feat / dout are bf16 [n][c]; cin, cout in {16,32,64,128}
@@ -720,14 +718,11 @@ extern "C" int s2d_spconv_s16_wgrad(const void *in_feat, int64_t n_in, const voi
         set_error("spconv_s16_wgrad: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
-    g_wgrad_mode = 2;
-    int rc = wgrad_impl((const float *)in_feat, n_in, (const float *)dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes,
-                        stream);
-    g_wgrad_mode = 0;
-    return rc;
+    return wgrad_impl(2, (const float *)in_feat, n_in, (const float *)dout, nbr, n_out, kvol, cin, cout, dweight, ws, ws_bytes,
+                      stream);
 }
 
-static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
+static int wgrad_impl(int mode, const float *in_feat, int64_t n_in, const float *dout, const int32_t *nbr, int64_t n_out, int kvol,
                       int cin, int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0 && cin > 0 && cout > 0, "spconv_wgrad: bad sizes");
     S2D_CHECK_ARG(dweight, "spconv_wgrad: null dweight");
@@ -738,7 +733,7 @@ static int wgrad_impl(const float *in_feat, int64_t n_in, const float *dout, con
         return S2D_OK;
     }
     S2D_CHECK_ARG(in_feat && dout && nbr, "spconv_wgrad: null argument");
-    WgradPlan p = wgrad_plan(n_out, kvol, cin, cout);
+    WgradPlan p = wgrad_plan(mode, n_out, kvol, cin, cout);
     const size_t need = (size_t)p.n_split * size * sizeof(float);
     if (!ws || ws_bytes < need) {
         set_error("spconv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
