@@ -21,10 +21,10 @@
 //
 // Status (r01, MI355X, 4x188x188): 128->128 133 us and 256->256@94 123 us against MIOpen's 118 / 115 us; 512->64
 // 187 us against 226 us, so the host side (dense2d.py) only routes cin >= 512 here for now.  Measured split of the
-// 128->128 case: K loop 79 us (loads alone 32, transpose reads + MFMA alone 44: they do not overlap yet — all 20
-// transpose reads of a K-step are waited for before its first MFMA and a CU holds one 8-wave workgroup), partial-slab
-// stores 37 us (4-byte stores of 50 MB), reduce 19 us.  Next: interleave reads of tap kx+1 with the MFMAs of kx,
-// 16-byte slab stores through an LDS transpose, fewer/larger splits.
+// 128->128 case before the last two changes: K loop 79 us (loads alone 32, transpose reads + MFMA alone 44, not
+// overlapping), partial-slab stores 37 us (4-byte stores of 50 MB), reduce 19 us.  Since then the X reads of tap kx+1
+// are issued ahead of the MFMAs of tap kx, and the operands are swapped (D[ci][co]) so that a lane's four results are
+// consecutive ci = one 16-byte slab store.
 #include "s2d_common.h"
 
 namespace s2d {
@@ -170,25 +170,35 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
             advance();
         }
         if (row_ok) {
-            i32x2w alo[C::MI], ahi[C::MI], blo[C::NJ][3], bhi[C::NJ][3];
+            // dY fragments and the kx = 0 X fragments first; then the X reads of tap kx+1 are issued ahead of the MFMAs of
+            // tap kx (LDS returns in order: "lgkmcnt(2*NJ)" = everything but the youngest tap's reads has arrived)
+            i32x2w alo[C::MI], ahi[C::MI], blo[3][C::NJ], bhi[3][C::NJ];
             const unsigned abase = smem_addr + cur * (C::A_BYTES + C::B_BYTES) + tr_row * C::RS_A + wco * C::MI * 32 + tr_col;
             const unsigned bbase = smem_addr + cur * (C::A_BYTES + C::B_BYTES) + C::A_BYTES + tr_row * C::RS_B + wci * C::NJ * 32 + tr_col;
 #pragma unroll
             for (int i = 0; i < C::MI; ++i) tr_issue<16 * C::RS_A>(alo[i], ahi[i], abase + i * 32);
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j)
+            for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(blo[0][j], bhi[0][j], bbase + j * 32);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) tr_issue<16 * C::RS_B>(blo[j][kx], bhi[j][kx], bbase + j * 32 + kx * C::RS_B);
-            tr_wait();
+            for (int kx = 0; kx < 3; ++kx) {
+                if (kx < 2) {
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16x8w b = tr_pack(blo[j][kx], bhi[j][kx]);
-#pragma unroll
-                    for (int i = 0; i < C::MI; ++i)
-                        acc[i][j][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pack(alo[i], ahi[i]), b, acc[i][j][kx], 0, 0, 0);
+                    for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(blo[kx + 1][j], bhi[kx + 1][j], bbase + j * 32 + (kx + 1) * C::RS_B);
+                    if (C::NJ == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < C::NJ; ++j) {
+                    const bf16x8w xf = tr_pack(blo[kx][j], bhi[kx][j]);
+#pragma unroll
+                    for (int i = 0; i < C::MI; ++i)   // D[ci][co]: the X fragment is the row operand, so a lane's 4 results are 4 consecutive ci
+                        acc[i][j][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, tr_pack(alo[i], ahi[i]), acc[i][j][kx], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // next step's tiles must have landed (in every wave) before anyone reads them; the two younger steps stay in flight
         if (more) {
@@ -201,20 +211,18 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         __builtin_amdgcn_s_barrier();
     }
 
-    // partial[split][ky][kx][co][ci] ; C/D layout: row (co) = 4*(lane>>4)+reg, col (ci) = lane&15
+    // partial[split][ky][kx][co][ci] ; C/D layout: row (ci) = 4*(lane>>4)+reg -> one 16-byte store, col (co) = lane&15
     float *dst = partial + ((int64_t)blockIdx.x * 9 + ky * 3) * (int64_t)cout * cin;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int co = cot * TCO + (wco * C::MI + i) * 16 + 4 * g + reg;
-                    const int ci = cit * TCI + (wci * C::NJ + j) * 16 + c16;
-                    dst[((int64_t)kx * cout + co) * cin + ci] = acc[i][j][kx][reg];
-                }
+            for (int j = 0; j < C::NJ; ++j) {
+                const int co = cot * TCO + (wco * C::MI + i) * 16 + c16;
+                const int ci = cit * TCI + (wci * C::NJ + j) * 16 + 4 * g;
+                *reinterpret_cast<f32x4w *>(dst + ((int64_t)kx * cout + co) * cin + ci) = acc[i][j][kx];
+            }
 }
 
 // dw[co][ci][ky][kx] = sum_split partial[split][ky*3+kx][co][ci]   (fixed order -> deterministic)
