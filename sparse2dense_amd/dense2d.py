@@ -36,15 +36,46 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # raw hipStream_t of torch's current stream on the current device (the private accessor is ~5x cheaper than
+    # torch.cuda.current_stream().cuda_stream, and this runs once per kernel launch, ~500 times a step)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def supported(cin, cout):
     return bool(_lib.load().s2d_conv2d3x3_supported(int(cin), int(cout)))
 
 
+import weakref
+
+_pack_cache = {}   # id(weight) -> [weakref(weight), data_ptr, version, {variant: packed}]
+
+
+def cached_pack(weight, variant, build):
+    """Packed-weight images are rebuilt when the parameter changes (its autograd version counter moves on every in-place
+    update such as an optimizer step or load_state_dict, its data_ptr on re-assignment), not on every call.  In-place
+    edits through `weight.data` do not move the counter: call clear_pack_cache() after such surgery."""
+    key = id(weight)
+    ent = _pack_cache.get(key)
+    if ent is None or ent[0]() is not weight or ent[1] != weight.data_ptr() or ent[2] != weight._version:
+        ent = [weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)), weight.data_ptr(), weight._version, {}]
+        _pack_cache[key] = ent
+    hit = ent[3].get(variant)
+    if hit is None:
+        hit = build()
+        ent[3][variant] = hit
+    return hit
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
 def pack_weights(weight, transpose_flip=False):
-    """weight fp32 [Cout,Cin,3,3] -> bf16 LDS image of the forward (or data-gradient) operand"""
+    """weight fp32 [Cout,Cin,3,3] -> bf16 LDS image of the forward (or data-gradient) operand (cached, see cached_pack)"""
+    return cached_pack(weight, ("conv3x3", bool(transpose_flip)), lambda: _pack_weights(weight, transpose_flip))
+
+
+def _pack_weights(weight, transpose_flip):
     lib = _lib.load()
     cout, cin = weight.shape[0], weight.shape[1]
     w = weight.detach().float()
@@ -191,14 +222,15 @@ class Conv3x3(nn.Conv2d):
 # BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
 # --------------------------------------------------------------------------------------------------
 _ws_cache = {}
+GRAPH_CAPTURE_POSSIBLE = False   # set by SingleStageDetector.use_dense_graph(): only then is stream capture checked per call
 
 
 def _ws(nbytes, device):
     """reduction workspace: one grow-only buffer per device and stream.  Every user writes it before reading it inside
     one entry point, and launches on a stream are ordered, so consecutive calls can share it."""
-    if torch.cuda.is_current_stream_capturing():   # graph capture: a private allocation from the graph's pool
+    if GRAPH_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing():   # a private allocation from the graph's pool
         return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -22,7 +22,7 @@ def _ptr(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def pointwise_conv(x, w2d, bias):

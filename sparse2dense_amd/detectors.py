@@ -80,6 +80,9 @@ class SingleStageDetector(nn.Module):
         """Training-time option: replay the neck + head forward/backward as HIP graphs (one capture per input shape).
         Needs the bf16 NHWC dense mode and a single process (no SyncBN collectives inside the captured section)."""
         self.dense_graph = bool(on)
+        if on:
+            from . import dense2d
+            dense2d.GRAPH_CAPTURE_POSSIBLE = True
         return self
 
     def _graph_ok(self, x):

@@ -21,7 +21,7 @@ from ._lib import check, f3, f6, i3
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())   # raw hipStream_t (cheap accessor, see dense2d._stream)
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -103,6 +103,17 @@ class _SparseConvFn(torch.autograd.Function):
         return w
 
     @staticmethod
+    def _s16(x, weight, bias, rb, nbr, n_out, transpose, flip, tag, cin_feat=None):
+        """bf16-storage conv / data gradient with the weight image cached per parameter version (dense2d.cached_pack)"""
+        from .dense2d import cached_pack
+        cin_feat = x.shape[1] if cin_feat is None else cin_feat
+        packed, kvol, cin, cout = cached_pack(
+            weight, ("s16", bool(transpose), bool(flip), int(cin_feat)),
+            lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
+        b = None if bias is None else bias.detach().float().contiguous()
+        return H.spconv_s16_run(x.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, rb.pair_count, tag)
+
+    @staticmethod
     def forward(ctx, feat, weight, bias, rb):
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         ctx.rb = rb
@@ -110,8 +121,7 @@ class _SparseConvFn(torch.autograd.Function):
         ctx.save_for_backward(feat, weight)
         ctx.s16 = feat.dtype == torch.bfloat16
         if ctx.s16:   # bf16 feature storage: gather -> LDS -> MFMA, bf16 out
-            return H.spconv_s16(feat, _SparseConvFn._w_s16(weight, rb, feat.shape[1]), bias, rb.nbr_out, rb.n_out,
-                                pair_count=rb.pair_count, tag="fwd")
+            return _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd")
         return H.spconv_gather_gemm(feat, w, bias, rb.nbr_out, rb.n_out, rb.pair_count, "fwd")
 
     @staticmethod
@@ -120,12 +130,10 @@ class _SparseConvFn(torch.autograd.Function):
         rb = ctx.rb
         if ctx.s16:
             dout = dout.to(torch.bfloat16).contiguous()
-            w = _SparseConvFn._w_s16(weight, rb, feat.shape[1])
             dfeat = dw = db = None
             if ctx.needs_input_grad[0]:
                 nbr = rb.nbr_out if rb.subm else rb.nbr_in
-                dfeat = H.spconv_s16(dout, w, None, nbr, rb.n_in, transpose=True, flip=rb.subm, pair_count=rb.pair_count,
-                                     tag="dgrad")
+                dfeat = _SparseConvFn._s16(dout, weight, None, rb, nbr, rb.n_in, True, rb.subm, "dgrad", cin_feat=feat.shape[1])
             if ctx.needs_input_grad[1]:
                 dw = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
                 dw = dw[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
