@@ -207,15 +207,27 @@ class Conv3x3(nn.Conv2d):
                 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0)
 
     emit_bn_stats = False   # set by fuse_bn_relu() when a FastBatchNorm2d follows: its statistics come out of our epilogue
+    absorbed_pad = 0        # set by fuse_bn_relu(): an nn.ZeroPad2d(1) in front of this padding-0 conv is folded into the kernel
 
     def forward(self, x):
         if self._hip_ok(x):
+            pad = self.padding[0] + self.absorbed_pad
             if self.emit_bn_stats and self.training and torch.is_grad_enabled():
-                y, partial = _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0], True)
+                y, partial = _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], True)
                 y._s2d_bn_partial = partial   # read (forward pass only) by the FastBatchNorm2d that follows
                 return y
-            return _Conv3x3Fn.apply(x, self.weight, self.bias, self.padding[0], self.stride[0], False)
+            return _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], False)
+        if self.absorbed_pad:
+            x = torch.nn.functional.pad(x, (self.absorbed_pad,) * 4)
         return super().forward(x)
+
+
+class AbsorbedZeroPad2d(nn.ZeroPad2d):
+    """nn.ZeroPad2d(1) whose zero border is produced inside the 3x3 conv that follows it (ZeroPad2d(1) + conv(padding=0)
+    == conv(padding=1), rpn.py:129-131): keeps the reference's Sequential slot, moves no data."""
+
+    def forward(self, x):
+        return x
 
 
 # --------------------------------------------------------------------------------------------------
@@ -405,4 +417,8 @@ def fuse_bn_relu(layers):
             layers[i + 1] = nn.Identity()
         if isinstance(layers[i], Conv3x3) and isinstance(layers[i + 1], FastBatchNorm2d):
             layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials
+        if type(layers[i]) is nn.ZeroPad2d and tuple(layers[i].padding) == (1, 1, 1, 1) and isinstance(layers[i + 1], Conv3x3) \
+                and layers[i + 1].padding == (0, 0) and layers[i + 1].kernel_size == (3, 3):
+            layers[i] = AbsorbedZeroPad2d(1)
+            layers[i + 1].absorbed_pad = 1
     return layers
