@@ -422,3 +422,26 @@ def fuse_bn_relu(layers):
             layers[i] = AbsorbedZeroPad2d(1)
             layers[i + 1].absorbed_pad = 1
     return layers
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm over a whole [C,H,W] map (ConvNeXt blocks of the S2D module, rpn.py:186-259)
+# --------------------------------------------------------------------------------------------------
+class WideLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict keys).  The S2D blocks normalise over the whole [C, 47, 47] map, i.e.
+    a few rows of ~5e5 elements: torch's row-per-workgroup kernels then run on B (= 2-4) workgroups of a 256-CU GPU
+    (measured 0.44 ms forward + 1.13 ms backward per layer).  For that shape the statistics are taken with torch's
+    multi-workgroup reductions and the rest is elementwise (autograd differentiates it); anything else is the stock path."""
+
+    def forward(self, x):
+        nd = len(self.normalized_shape)
+        row = 1
+        for d in self.normalized_shape:
+            row *= int(d)
+        if x.is_cuda and row >= (1 << 16) and x.numel() // row <= 64 and self.elementwise_affine:
+            dims = tuple(range(x.dim() - nd, x.dim()))
+            xf = x.float()
+            var, mean = torch.var_mean(xf, dim=dims, unbiased=False, keepdim=True)
+            y = (xf - mean) * torch.rsqrt(var + self.eps) * self.weight.float() + self.bias.float()
+            return y.to(x.dtype)
+        return super().forward(x)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv3x3, FastBatchNorm2d, fuse_bn_relu
+from .dense2d import Conv3x3, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .registry import NECKS
 
@@ -114,7 +114,7 @@ def _cbg(*convs_and_channels):
 
 
 def _convnext(c, hw):
-    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), nn.LayerNorm([c, hw, hw], eps=1e-6),
+    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
                          nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
 
 

@@ -19,6 +19,7 @@ from torch import nn
 
 from . import registry
 from .backbones import build_norm_layer
+from .dense2d import WideLayerNorm
 from .dense3d import FastBatchNorm3d, PointwiseConv3d
 from .detectors import SingleStageDetector
 from .heads import mask_offset_loss, metric_grid
@@ -120,7 +121,7 @@ def _cbg(conv, c):
 
 
 def _convnext(c, hw):
-    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), nn.LayerNorm([c, hw, hw], eps=1e-6),
+    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
                          nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
 
 

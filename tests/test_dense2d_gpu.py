@@ -257,3 +257,21 @@ def test_conv_epilogue_bn_statistics_match_the_reduction_kernel(cin, cout, pad, 
     for name, u, v in zip(["y", "dx", "dw", "dgamma", "dbeta", "rmean", "rvar"], *outs):
         err = (u.float() - v.float()).abs().max() / v.float().abs().max().clamp(min=1e-9)
         assert err <= (1e-2 if name in ("y", "dx", "dw") else 1e-4), (name, float(err))   # bf16 tensors may flip one rounding
+
+
+def test_wide_layernorm_matches_stock():
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(0)
+    m = D.WideLayerNorm([64, 47, 47], eps=1e-6).cuda()
+    ref = torch.nn.LayerNorm([64, 47, 47], eps=1e-6).cuda()
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-1, 1)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(2, 64, 47, 47, device="cuda") * 3 + 1
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = m(xa), ref(xb)
+    g = torch.randn_like(x)
+    ya.backward(g); yb.backward(g)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(m.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5) and torch.allclose(m.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5)
