@@ -63,12 +63,12 @@ class SingleStageDetector(nn.Module):
         return self.neck is not None
 
     def use_channels_last(self):
-        """NHWC activations/weights for the RPN trunk + head convs (avoids per-conv layout transposes
-        under bf16).  The S2D module and PCR head stay NCHW: MIOpen's NHWC bf16 BatchNorm segfaults on
-        their 47x47 maps (ROCm 7.2)."""
+        """NHWC activations/weights for the whole 2-D neck + head (avoids per-conv layout transposes under bf16).  Every
+        BatchNorm2d on that path is a FastBatchNorm2d (own row-major kernels): MIOpen's NHWC bf16 batch norm, which
+        segfaults on the 47x47 maps of the S2D module (ROCm 7.2), is never reached.  The PCR head (3-D) stays NCDHW fp32."""
         mods = list(self.bbox_head.modules())
         if self.neck is not None:
-            mods += list(self.neck.blocks.modules()) + list(self.neck.deblocks.modules())
+            mods += list(self.neck.modules())
             self.neck.trunk_channels_last = True
         for mod in mods:
             if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):

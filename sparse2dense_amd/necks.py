@@ -107,10 +107,12 @@ class RPN(nn.Module):
 
 
 def _cbg(*convs_and_channels):
+    """conv -> BatchNorm2d -> GELU groups of the S2D module (rpn.py:186-253); the drop-in layer classes take the HIP
+    kernels on NHWC bf16 inputs and are the stock layers otherwise"""
     layers = []
     for conv, c in convs_and_channels:
-        layers += [conv, nn.BatchNorm2d(c), nn.GELU()]
-    return nn.Sequential(*layers)
+        layers += [conv, FastBatchNorm2d(c), nn.GELU()]
+    return nn.Sequential(*fuse_bn_relu(layers))
 
 
 def _convnext(c, hw):
@@ -126,13 +128,13 @@ class S2D_RPN(RPN):
                          num_input_features, norm_cfg, name, logger)
         c = num_input_features
         # ---- S2D module (rpn.py:186-253): 188 -> 94 -> 47 -> 3x ConvNeXt -> 94 -> 188 ----
-        self.encoder_1 = _cbg((nn.Conv2d(c, 256, 2, 2), 256), (nn.Conv2d(256, 256, 3, 1, 1), 256))
-        self.encoder_2 = _cbg((nn.Conv2d(256, 256, 3, 2, 1), 256), (nn.Conv2d(256, 256, 3, 1, 1), 256))
+        self.encoder_1 = _cbg((nn.Conv2d(c, 256, 2, 2), 256), (Conv3x3(256, 256, 3, 1, 1), 256))
+        self.encoder_2 = _cbg((Conv3x3(256, 256, 3, 2, 1), 256), (Conv3x3(256, 256, 3, 1, 1), 256))
         self.convnext_block_1 = _convnext(256, 47)
         self.convnext_block_2 = _convnext(256, 47)
         self.convnext_block_3 = _convnext(256, 47)
         self.decoder_1 = _cbg((nn.ConvTranspose2d(256, 256, 4, 2, 1), 256))
-        self.decoder_2 = _cbg((nn.Conv2d(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
+        self.decoder_2 = _cbg((Conv3x3(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
         self.fusion_sparse = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
         self.fusion_dense = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
         self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
@@ -152,6 +154,8 @@ class S2D_RPN(RPN):
         self.gen_mask_2 = nn.Sequential(PointwiseConv3d(3, 1, 1, 1, 0))
 
     def forward(self, x):
+        if self.trunk_channels_last and x.is_cuda:   # NHWC end to end: conv, batch norm and GELU all keep the layout
+            x = x.contiguous(memory_format=torch.channels_last)
         y_1 = self.encoder_1(x)
         y_2 = self.encoder_2(y_1)
         att = self.convnext_block_1(y_2) + y_2
