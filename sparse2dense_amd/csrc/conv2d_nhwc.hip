@@ -114,7 +114,18 @@ __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[4][BN / 32], const f
     }
 }
 
-template <int BN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = depth of the LDS ring.  NS = 2: double buffer, one __syncthreads() per K-step (whose release waits for every
+// outstanding load).  NS >= 3: the loads of K-step s+NS-1 are issued while step s is computed and only the NEXT step's
+// loads are waited for (s_waitcnt vmcnt(N) with N = the younger steps' load count, then a raw s_barrier), so NS-2
+// K-steps of LDS-DMA stay in flight across the barrier.  Measured (r01, MI355X, 128->128 @ 4x188x188): NS=2 563 TFLOP/s,
+// NS=3 360, NS=4 365 — the deeper rings cost the second resident workgroup per CU (96 / 128 KiB of LDS), and the four
+// extra waves hide more latency than the extra K-steps in flight; the host launches NS=2 unless S2D_CONV_NS says otherwise.
+template <int BN, int NS>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                 const float *__restrict__ bias,
                                                                 const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
@@ -124,8 +135,9 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
     constexpr int A_BYTES = 128 * 64 * 2;  // 16 KiB: [128 px][64 ch]
     constexpr int B_BYTES = 64 * BN * 2;   // [2][BN/16][64 lanes][8]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto abuf = [&](int b) -> char * { return smem + b * A_BYTES; };
-    auto bbuf = [&](int b) -> char * { return smem + 2 * A_BYTES + b * B_BYTES; };
+    auto abuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_BYTES); };
+    auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
+    constexpr int LPS = 4 + (B_BYTES / 1024) / 4;   // global_load_lds instructions per wave and K-step (A: 4, B: 4 or 2)
 
     const int Ho = (H + 2 * pad - 3) / stride + 1, Wo = (W + 2 * pad - 3) / stride + 1;
     const int64_t m_total = (int64_t)n_img * Ho * Wo;
@@ -188,11 +200,24 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    __syncthreads();
+    if (NS == 2) {
+        stage(0, 0);
+        __syncthreads();
+    } else {
+        const int npre = ksteps < NS - 1 ? ksteps : NS - 1;
+        for (int p = 0; p < npre; ++p) stage(p, p);
+        if (npre >= 3) wait_vmcnt<2 * LPS>();
+        else if (npre == 2) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+    }
     for (int s = 0; s < ksteps; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < ksteps) stage(s + 1, cur ^ 1);
+        const int cur = NS == 2 ? (s & 1) : s % NS;
+        if (NS == 2) {
+            if (s + 1 < ksteps) stage(s + 1, cur ^ 1);
+        } else if (s + NS - 1 < ksteps) {
+            stage(s + NS - 1, (s + NS - 1) % NS);   // the slot read in iteration s-1
+        }
         // A tile image: 16-byte chunk id = pixel*8 + part ; a lane's fragment for half h: pixel = 64*wm + 16*i + r, part = 4*h + q
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -208,7 +233,17 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();   // tile s consumed by every wave; tile s+1 landed (the barrier's release drains the LDS-DMA)
+        if (NS == 2) {
+            __syncthreads();   // tile s consumed by every wave; tile s+1 landed (the barrier's release drains the LDS-DMA)
+        } else {
+            if (s + 1 < ksteps) {   // step s+1 must have landed; the younger steps (at most NS-2) stay in flight
+                const int ahead = ksteps - 2 - s < NS - 2 ? ksteps - 2 - s : NS - 2;
+                if (ahead >= 2) wait_vmcnt<2 * LPS>();
+                else if (ahead == 1) wait_vmcnt<LPS>();
+                else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     conv_epilogue<BN>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / 128));
@@ -413,27 +448,27 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
         S2D_LAUNCH_CHECK();
         return S2D_OK;
     }
+    // ring depth of the LDS-DMA pipeline (S2D_CONV_NS=2/3/4 forces it for A/B runs)
+    static const int ns_env = [] { const char *e = getenv("S2D_CONV_NS"); return e ? atoi(e) : 0; }();
+    const int ns = (ns_env >= 2 && ns_env <= 4) ? ns_env : 2;
+    const size_t lds = (size_t)ns * (128 * 64 * 2 + 64 * bn * 2);
+#define S2D_CONV_LAUNCH(BN_, NS_)                                                                                         \
+    do {                                                                                                                  \
+        auto kern = conv3x3_nhwc_bf16_kernel<BN_, NS_>;                                                                   \
+        static bool attr_set = false; /* once per instantiation; also keeps the call out of graph captures */            \
+        if (!attr_set) {                                                                                                  \
+            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,              \
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);   \
+    } while (0)
     if (bn == 128) {
-        const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 128 * 2);
-        auto kern = conv3x3_nhwc_bf16_kernel<128>;
-        static bool attr_set = false;   // once per process (idempotent if raced); also keeps the call out of graph captures
-        if (!attr_set) {
-            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
+        if (ns == 4) S2D_CONV_LAUNCH(128, 4); else if (ns == 3) S2D_CONV_LAUNCH(128, 3); else S2D_CONV_LAUNCH(128, 2);
     } else {
-        const size_t lds = 2 * (128 * 64 * 2) + 2 * (64 * 64 * 2);
-        auto kern = conv3x3_nhwc_bf16_kernel<64>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
+        if (ns == 4) S2D_CONV_LAUNCH(64, 4); else if (ns == 3) S2D_CONV_LAUNCH(64, 3); else S2D_CONV_LAUNCH(64, 2);
     }
+#undef S2D_CONV_LAUNCH
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
