@@ -148,7 +148,15 @@ def roofline_pass(step, n_steps=3):
             rb["ms"] += ms; rb["n"] += 1
             rb["bytes"] += 16.0 * r["n_out"] + 8.0 * pairs + 4.0 * r["kvol"]
             continue
-        key = (r["kernel"], r["cin"], r["cout"], r["n_out"])
+        kname = r["kernel"]
+        if r.get("dense"):   # mirror of the dispatch in csrc/conv2d_nhwc.hip (which device function serves this launch)
+            if r["cout"] % 128 == 0:
+                kname = "conv3x3_k32_nhwc_bf16_kernel<128>"
+            elif r.get("pad") == 1 and r.get("stride") == 1 and r["cin"] >= 128:
+                kname = "conv3x3_p1_nhwc_bf16_kernel<64>"
+            else:
+                kname = "conv3x3_nhwc_bf16_kernel<64, 2>"
+        key = (kname, r["cin"], r["cout"], r["n_out"])
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
         a["ms"] += ms
         a["n"] += 1
@@ -179,8 +187,8 @@ def roofline_pass(step, n_steps=3):
     # the dominant KERNEL is a device function (what rocprofv3 --stats lists); one template instantiation serves several
     # tensor shapes, so group the per-shape rows by instantiation before ranking
     def template_of(r):
-        if r["kernel"] == "conv3x3_nhwc_bf16":
-            return f"conv3x3_nhwc_bf16_kernel<{128 if r['cout'] % 128 == 0 else 64}>"
+        if r["kernel"].startswith("conv3x3_"):
+            return r["kernel"]
         if r["kernel"] == "spconv_fwd_s16":
             return f"spconv_fwd_s16_kernel<{r['cin']}, {r['cout']}, {128 if r['cout'] == 128 else 64}>"
         return f"{r['kernel']}<{r['cin']}, {r['cout']}>"
@@ -196,7 +204,7 @@ def roofline_pass(step, n_steps=3):
     tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12
     gbs = g["bytes"] / (g["ms"] * 1e-3) / 1e9
     lead = g["rows"][0]["kernel"]
-    peak_tf = PEAK_BF16_MATRIX_TFLOPS if lead.endswith(("bf16", "s16")) else PEAK_F32_MATRIX_TFLOPS
+    peak_tf = PEAK_BF16_MATRIX_TFLOPS if (lead.endswith(("bf16", "s16")) or "bf16" in lead) else PEAK_F32_MATRIX_TFLOPS
     dense = lead.startswith("conv3x3")
     intensity = tflops * 1e3 / max(gbs, 1e-9)          # FLOP per algorithmic byte
     hbm_roof_tf = intensity * PEAK_HBM_GBS / 1e3
@@ -244,9 +252,9 @@ def pmc_traffic(top):
     except Exception:
         return None, None
     xcd = lambda tiles: -(-tiles // 8) * 8
-    if top["kernel"] == "conv3x3_nhwc_bf16":
+    if top["kernel"].startswith("conv3x3_"):
         bn = 128 if top["cout"] % 128 == 0 else 64
-        want, grid = f"conv3x3_nhwc_bf16_kernel<{bn}>", xcd(-(-top["n_out"] // 128)) * (top["cout"] // bn) * 256
+        want, grid = top["kernel"], xcd(-(-top["n_out"] // 128)) * (top["cout"] // bn) * 256
     elif top["kernel"] == "spconv_fwd_s16":
         bm = 128 if top["cout"] == 128 else 64
         want, grid = f"spconv_fwd_s16_kernel<{top['cin']}, {top['cout']}, {bm}>", xcd(-(-top["n_out"] // bm)) * 256

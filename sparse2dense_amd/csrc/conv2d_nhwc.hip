@@ -250,6 +250,116 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 }
 
 
+// ---- 32-deep K-steps on a 3-slot ring -------------------------------------------------------------------------------
+// The kernels above are bound by the load -> barrier round trip of a K-step, and what hides it is resident waves, not
+// ring depth (see the NS note).  Halving the K-step (one tap x 32 channels: A 8 KiB + B 8 KiB) makes a 3-slot ring cost
+// 48 KiB, so three workgroups (12 waves) stay resident per CU, each with two K-steps of LDS-DMA in flight across its
+// barrier.  A image: [128 px][4 parts of 16 B], part index XOR-swizzled by (row >> 1) & 3 (checked against the
+// ds_read_b128 lane groups: 16 distinct bank slots).  B = the h-th half of the 64-deep packed slab (same weight image).
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
+                                                                    const float *__restrict__ bias,
+                                                                    const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
+                                                                    int cin, int cout, int pad, int stride, __bf16 *__restrict__ y,
+                                                                    float *__restrict__ stats_partial) {
+    constexpr int NS = 3;
+    constexpr int NT = BN / 32;
+    constexpr int A_BYTES = 128 * 32 * 2;      // 8 KiB
+    constexpr int B_HALF = 32 * BN * 2;        // half of a packed K-step slab: [BN/16][64 lanes][8]
+    constexpr int LPS = 2 + (B_HALF / 1024) / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF); };
+    auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF) + A_BYTES; };
+
+    const int Ho = (H + 2 * pad - 3) / stride + 1, Wo = (W + 2 * pad - 3) / stride + 1;
+    const int64_t m_total = (int64_t)n_img * Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 128;
+    if (m0 >= m_total) return;
+    const int blk_n = blockIdx.y;
+    const int chunks = cin / 64;
+    const int T = 18 * chunks;   // sub-steps: (tap, 64-channel chunk, half)
+
+    // A staging: thread t moves the 16-byte chunks t and t+256 of the [128][32 ch] tile: row = id/4, slot = id%4
+    int a_img[2], a_y[2], a_x[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int id = threadIdx.x + 256 * u;
+        const int64_t m = m0 + id / 4;
+        a_ok[u] = m < m_total;
+        const int64_t mm = a_ok[u] ? m : 0;
+        a_x[u] = (int)(mm % Wo) * stride;
+        a_y[u] = (int)((mm / Wo) % Ho) * stride;
+        a_img[u] = (int)(mm / ((int64_t)Wo * Ho));
+    }
+    const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * (2 * B_HALF);
+    const int64_t wstep = (int64_t)(cout / BN) * (2 * B_HALF);
+
+    auto stage = [&](int t, int buf) {
+        const int s = t >> 1, h = t & 1;
+        const int tap = s / chunks, chunk = s - tap * chunks;
+        const int dy = tap / 3 - pad, dx = tap % 3 - pad;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = threadIdx.x + 256 * u;
+            const int row = id >> 2;
+            const int part = (id & 3) ^ ((row >> 1) & 3);
+            const int yy = a_y[u] + dy, xx = a_x[u] + dx;
+            const bool ok = a_ok[u] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const __bf16 *src = ok ? x + (((int64_t)a_img[u] * H + yy) * W + xx) * cin + chunk * 64 + h * 32 + part * 8 : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(abuf(buf) + (size_t)(id - lane) * 16), 16, 0, 0);
+        }
+        constexpr int B_UNITS = B_HALF / 1024;
+#pragma unroll
+        for (int u = 0; u < B_UNITS / 4; ++u) {
+            const int unit = u * 4 + wid;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(wsrc + (int64_t)s * wstep + h * B_HALF + unit * 1024 + lane * 16),
+                (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4c acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    stage(1, 1);
+    wait_vmcnt<LPS>();
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+        const int cur = t % NS;
+        if (t + 2 < T) stage(t + 2, (t + 2) % NS);   // the slot read in iteration t-1
+        bf16x8c a[4], b[NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 64 * wm + 16 * i + r;
+            a[i] = *reinterpret_cast<const bf16x8c *>(abuf(cur) + (row * 4 + (q ^ ((row >> 1) & 3))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(cur) + ((wn * NT + j) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (t + 1 < T) {   // sub-step t+1 must have landed; t+2 (if issued) stays in flight
+            if (t + 2 < T) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+
+    conv_epilogue<BN>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / 128));
+}
+
 // ---- pad = 1 variant with the A tile shared by the three kx taps ------------------------------------------------------
 // With padding 1 the input pixel of output pixel m at tap (ky, kx) is the ky-row centre
 // pixel of output pixel m + kx - 1, so one [130 px][64 ch] tile per (ky, channel chunk) serves all three kx taps: the tap
@@ -451,6 +561,19 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     // ring depth of the LDS-DMA pipeline (S2D_CONV_NS=2/3/4 forces it for A/B runs)
     static const int ns_env = [] { const char *e = getenv("S2D_CONV_NS"); return e ? atoi(e) : 0; }();
     const int ns = (ns_env >= 2 && ns_env <= 4) ? ns_env : 2;
+    // default: 128-wide column blocks take the 32-deep / 3-slot-ring kernel (measured r01: 128->128 556 -> 589, 256->256@94
+    // 510 -> 577 TFLOP/s), 64-wide blocks the 64-deep double buffer (359 vs 335); S2D_CONV_NS=2/3/4/32 forces a variant
+    if (ns_env == 32 || (ns_env == 0 && bn == 128)) {   // 32-deep K-steps, 3-slot ring
+        const size_t lds32 = 3 * (size_t)(128 * 32 * 2 + 32 * bn * 2);
+        if (bn == 128)
+            hipLaunchKernelGGL(conv3x3_k32_nhwc_bf16_kernel<128>, grid, blk, lds32, st, (const __bf16 *)x, (const __bf16 *)packed_weight,
+                               bias, (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
+        else
+            hipLaunchKernelGGL(conv3x3_k32_nhwc_bf16_kernel<64>, grid, blk, lds32, st, (const __bf16 *)x, (const __bf16 *)packed_weight,
+                               bias, (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     const size_t lds = (size_t)ns * (128 * 64 * 2 + 64 * bn * 2);
 #define S2D_CONV_LAUNCH(BN_, NS_)                                                                                         \
     do {                                                                                                                  \

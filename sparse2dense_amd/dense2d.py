@@ -101,7 +101,7 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
     rec = None
     if H.PROFILE is not None:   # bench.py roofline pass: HIP events on the launch stream
         rec = dict(kernel="conv3x3_nhwc_bf16", tag="dense", cin=cin, cout=cout, n_out=n * ho * wo, kvol=9, pairs=None,
-                   dense=True, in_pixels=n * h * w, start=torch.cuda.Event(enable_timing=True),
+                   dense=True, in_pixels=n * h * w, pad=pad, stride=stride, start=torch.cuda.Event(enable_timing=True),
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     partial = torch.empty(((n * ho * wo + 127) // 128, 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
