@@ -12,8 +12,9 @@
 // buffered with one barrier per K-step.  The workgroup's slice of the gather map (all offsets x BM rows)
 // is copied to LDS once up front, so a step's gathers hang off an LDS read, not a second global trip.  The A image
 // is [row][8 parts of 16 B] with the part index XOR-swizzled by (row & 7) so that the 16-lane groups
-// of a ds_read_b128 fragment read touch 16 distinct bank slots.  Each stager marks the 16-row MFMA
-// tile it found a neighbour for; waves skip the MFMAs of tiles with no valid row at this K-step.
+// of a ds_read_b128 fragment read touch 16 distinct bank slots.  A table built in the prologue says which
+// 16-row MFMA tiles have a neighbour at which K-step; waves skip the MFMAs of the others.  Nothing is stored to
+// LDS with ds_write inside the K loop (see s16_fill_maps).
 #include "s2d_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -42,8 +43,9 @@ struct S16Cfg {
     static constexpr int B_BYTES = 64 * COUT * 2;
     static constexpr int A_LOADS = BM * 8 / 256;          // 16-byte chunks per thread per K-step
     static constexpr int TILES = BM / 16;
-    static constexpr size_t LDS_FIXED = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES + 3 * 16 * sizeof(int);
-    static size_t lds_bytes(int kvol) { return LDS_FIXED + (size_t)s16_kslots(CIN, kvol) * BM * sizeof(int); }
+    static constexpr size_t LDS_FIXED = 2 * (size_t)A_BYTES + 2 * (size_t)B_BYTES;
+    // + the gather-map slice [kslots][BM] and the tile-skip table [kslots][TILES]
+    static size_t lds_bytes(int kvol) { return LDS_FIXED + (size_t)s16_kslots(CIN, kvol) * (BM + TILES) * sizeof(int); }
     static_assert(MI >= 1 && NJ >= 1, "bad tiling");
 };
 
@@ -82,114 +84,11 @@ __global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__
     out[i] = (__bf16)v;
 }
 
-template <int CIN, int COUT, int BM>
-__global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__restrict__ in, const __bf16 *__restrict__ wpack,
-                                                             const float *__restrict__ bias, const int32_t *__restrict__ nbr,
-                                                             const __bf16 *__restrict__ zero_page, int n_out, int kvol,
-                                                             int rows_per_block, __bf16 *__restrict__ out) {
-    // rows_per_block <= BM (multiple of 16): the launcher shrinks it so that the grid fills whole rounds of resident
-    // workgroups; the tiles past it stay unmarked and are skipped.
+template <int CIN, int COUT, int BM, int MI_, int NJ_>
+__device__ __forceinline__ void s16_epilogue(f32x4s (&acc)[MI_][NJ_], const float *__restrict__ bias, __bf16 *__restrict__ out,
+                                             int row0, int row_end, int wm, int wn, int r, int q) {
     typedef S16Cfg<CIN, COUT, BM> C;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto abuf = [&](int b) -> char * { return smem + b * C::A_BYTES; };
-    auto bbuf = [&](int b) -> char * { return smem + 2 * C::A_BYTES + b * C::B_BYTES; };
-    volatile int *flags = reinterpret_cast<volatile int *>(smem + 2 * C::A_BYTES + 2 * C::B_BYTES);   // [3][16]
-    int *idx_lds = reinterpret_cast<int *>(smem + 2 * C::A_BYTES + 2 * C::B_BYTES + 3 * 16 * sizeof(int));   // [kslots][BM]
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wid / C::WN, wn = wid % C::WN;
-    const int r = lane & 15, q = lane >> 4;
-    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * rows_per_block;
-    if (row0 >= n_out) return;
-    const int row_end = min(n_out, row0 + rows_per_block);
-    const int steps = s16_steps(CIN, kvol);
-
-    // staging role of this thread: LDS slot (row = id>>3, s = id&7) of chunk ids id = t + 256u holds part s ^ (row&7)
-    const int prt = (t & 7) ^ ((t >> 3) & 7);
-    const int oslot = CIN < 64 ? prt / C::PPO : 0;
-    const int choff = (CIN < 64 ? prt % C::PPO : prt) * 8;
-
-    // the block's whole gather-map slice lives in LDS (one coalesced pass up front): the per-step gathers then
-    // depend on an LDS read, not on a second global round trip
-    auto load_idx = [&](int s, int (&j)[C::A_LOADS]) {
-        const int k = CIN < 64 ? s * C::OPS + oslot : s / C::CPO;
-#pragma unroll
-        for (int u = 0; u < C::A_LOADS; ++u) j[u] = idx_lds[k * BM + (t >> 3) + 32 * u];
-    };
-    auto stage = [&](int s, int buf, const int (&j)[C::A_LOADS]) {
-        const int chunk = CIN > 64 ? (s % C::CPO) * 64 : 0;
-        volatile int *fl = flags + (s % 3) * 16;
-#pragma unroll
-        for (int u = 0; u < C::A_LOADS; ++u) {
-            const __bf16 *src = j[u] >= 0 ? in + (int64_t)j[u] * CIN + chunk + choff : zero_page;
-            char *dst = abuf(buf) + (size_t)(t - lane + 256 * u) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            if (j[u] >= 0) fl[(t >> 7) + 2 * u] = 1;   // 16-row tile of row (t>>3) + 32u
-        }
-        constexpr int B_UNITS = C::B_BYTES / 1024;
-        const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)s * C::B_BYTES;
-#pragma unroll
-        for (int u = 0; u < (B_UNITS + 3) / 4; ++u) {
-            const int unit = u * 4 + wid;
-            if (unit < B_UNITS) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + unit * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
-            }
-        }
-    };
-
-    f32x4s acc[C::MI][C::NJ];
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < C::NJ; ++jn) acc[i][jn] = f32x4s{0.f, 0.f, 0.f, 0.f};
-
-    if (t < 48) flags[t] = 0;
-    {
-        const int kslots = s16_kslots(CIN, kvol);
-        for (int e = t; e < kslots * BM; e += 256) {
-            const int k = e / BM, row = row0 + (e - k * BM);
-            idx_lds[e] = (k < kvol && row < row_end) ? nbr[(int64_t)k * n_out + row] : -1;
-        }
-    }
-    int jn_[C::A_LOADS];
-    __syncthreads();
-    load_idx(0, jn_);
-    stage(0, 0, jn_);
-    __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-        const int cur = s & 1;
-        if (t < 16) flags[((s + 2) % 3) * 16 + t] = 0;   // last read in step s-1, next set while staging step s+2
-        if (s + 1 < steps) {
-            load_idx(s + 1, jn_);
-            stage(s + 1, cur ^ 1, jn_);
-        }
-        int on[C::MI];
-#pragma unroll
-        for (int i = 0; i < C::MI; ++i) on[i] = __builtin_amdgcn_readfirstlane(flags[(s % 3) * 16 + wm * C::MI + i]);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            bf16x8s b[C::NJ];
-#pragma unroll
-            for (int jn = 0; jn < C::NJ; ++jn)
-                b[jn] = *reinterpret_cast<const bf16x8s *>(bbuf(cur) + ((h * (COUT / 16) + wn * C::NJ + jn) * 64 + lane) * 16);
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i) {
-                if (on[i]) {
-                    const bf16x8s a = *reinterpret_cast<const bf16x8s *>(
-                        abuf(cur) + ((wm * 16 * C::MI + 16 * i + r) * 8 + ((4 * h + q) ^ (r & 7))) * 16);
-#pragma unroll
-                    for (int jn = 0; jn < C::NJ; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[jn], acc[i][jn], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
+    static_assert(MI_ == C::MI && NJ_ == C::NJ, "tile shape");
     // epilogue: C/D layout row = 4*(lane>>4)+reg, col = lane&15 -> columns co_base + r*NJ + jn (NJ consecutive)
     const int co_base = wn * (COUT / C::WN);
     float bv[C::NJ];
@@ -217,6 +116,139 @@ __global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__res
             }
         }
 }
+
+// Prologue shared by the forward kernels: the workgroup's slice of the gather map -> idx_lds [kslots][BM] (one coalesced
+// pass; -1 for rows past the block and phantom offsets), then the tile-skip table skip_lds [steps or kvol][BM/16]
+// (1 = some row of that 16-row MFMA tile has a neighbour at that K-step).  The table is written here, before the first
+// LDS-DMA: a ds_write after a global_load_lds makes the compiler drain vmcnt(0) first (it cannot tell the DMA's
+// destination from the store's), which serialised the gathers of a step in the first version of these kernels.
+template <int CIN, int BM>
+__device__ __forceinline__ void s16_fill_maps(const int32_t *__restrict__ nbr, int n_out, int kvol, int row0, int row_end,
+                                              int *idx_lds, int *skip_lds) {
+    constexpr int OPS = CIN < 64 ? 64 / CIN : 1, TILES = BM / 16;
+    const int t = threadIdx.x;
+    const int kslots = s16_kslots(CIN, kvol);
+    for (int e = t; e < kslots * BM; e += 256) {
+        const int k = e / BM, row = row0 + (e - k * BM);
+        idx_lds[e] = (k < kvol && row < row_end) ? nbr[(int64_t)k * n_out + row] : -1;
+    }
+    __syncthreads();
+    const int groups = kslots / OPS;
+    for (int e = t; e < groups * TILES; e += 256) {
+        const int g = e / TILES, i = e - g * TILES;
+        int any = 0;
+        for (int o = 0; o < OPS; ++o)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) any |= idx_lds[(g * OPS + o) * BM + 16 * i + rr] >= 0;
+        skip_lds[e] = any;
+    }
+    __syncthreads();
+}
+
+template <int CIN, int COUT, int BM>
+__global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__restrict__ in, const __bf16 *__restrict__ wpack,
+                                                             const float *__restrict__ bias, const int32_t *__restrict__ nbr,
+                                                             const __bf16 *__restrict__ zero_page, int n_out, int kvol,
+                                                             int rows_per_block, __bf16 *__restrict__ out) {
+    // rows_per_block <= BM (multiple of 16): the launcher shrinks it so that the grid fills whole rounds of resident
+    // workgroups; the tiles past it stay unmarked and are skipped.
+    typedef S16Cfg<CIN, COUT, BM> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * C::A_BYTES; };
+    auto bbuf = [&](int b) -> char * { return smem + 2 * C::A_BYTES + b * C::B_BYTES; };
+    int *idx_lds = reinterpret_cast<int *>(smem + 2 * C::A_BYTES + 2 * C::B_BYTES);   // [kslots][BM]
+    int *skip_lds = idx_lds + s16_kslots(CIN, kvol) * BM;                              // [steps or kvol][TILES]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wid / C::WN, wn = wid % C::WN;
+    const int r = lane & 15, q = lane >> 4;
+    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * rows_per_block;
+    if (row0 >= n_out) return;
+    const int row_end = min(n_out, row0 + rows_per_block);
+    const int steps = s16_steps(CIN, kvol);
+
+    // staging role of this thread: LDS slot (row = id>>3, s = id&7) of chunk ids id = t + 256u holds part s ^ (row&7)
+    const int prt = (t & 7) ^ ((t >> 3) & 7);
+    const int oslot = CIN < 64 ? prt / C::PPO : 0;
+    const int choff = (CIN < 64 ? prt % C::PPO : prt) * 8;
+
+    // the block's whole gather-map slice lives in LDS (one coalesced pass up front): the per-step gathers then
+    // depend on an LDS read, not on a second global round trip
+    auto load_idx = [&](int s, int (&j)[C::A_LOADS]) {
+        const int k = CIN < 64 ? s * C::OPS + oslot : s / C::CPO;
+#pragma unroll
+        for (int u = 0; u < C::A_LOADS; ++u) j[u] = idx_lds[k * BM + (t >> 3) + 32 * u];
+    };
+    auto stage = [&](int s, int buf, const int (&j)[C::A_LOADS]) {
+        const int chunk = CIN > 64 ? (s % C::CPO) * 64 : 0;
+#pragma unroll
+        for (int u = 0; u < C::A_LOADS; ++u) {
+            const __bf16 *src = j[u] >= 0 ? in + (int64_t)j[u] * CIN + chunk + choff : zero_page;
+            char *dst = abuf(buf) + (size_t)(t - lane + 256 * u) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+        constexpr int B_UNITS = C::B_BYTES / 1024;
+        const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)s * C::B_BYTES;
+#pragma unroll
+        for (int u = 0; u < (B_UNITS + 3) / 4; ++u) {
+            const int unit = u * 4 + wid;
+            if (unit < B_UNITS) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + unit * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4s acc[C::MI][C::NJ];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < C::NJ; ++jn) acc[i][jn] = f32x4s{0.f, 0.f, 0.f, 0.f};
+
+    s16_fill_maps<CIN, BM>(nbr, n_out, kvol, row0, row_end, idx_lds, skip_lds);
+    int jn_[C::A_LOADS];
+    load_idx(0, jn_);
+    stage(0, 0, jn_);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < steps) {
+            load_idx(s + 1, jn_);
+            stage(s + 1, cur ^ 1, jn_);
+        }
+        int on[C::MI];
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+            on[i] = __builtin_amdgcn_readfirstlane(skip_lds[(CIN < 64 ? s : s / C::CPO) * C::TILES + wm * C::MI + i]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8s b[C::NJ];
+#pragma unroll
+            for (int jn = 0; jn < C::NJ; ++jn)
+                b[jn] = *reinterpret_cast<const bf16x8s *>(bbuf(cur) + ((h * (COUT / 16) + wn * C::NJ + jn) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                if (on[i]) {
+                    const bf16x8s a = *reinterpret_cast<const bf16x8s *>(
+                        abuf(cur) + ((wm * 16 * C::MI + 16 * i + r) * 8 + ((4 * h + q) ^ (r & 7))) * 16);
+#pragma unroll
+                    for (int jn = 0; jn < C::NJ; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    s16_epilogue<CIN, COUT, BM, C::MI, C::NJ>(acc, bias, out, row0, row_end, wm, wn, r, q);
+}
+
+// Measured and dropped (r01): a variant with 32-channel K-steps on a 3-slot ring (manual vmcnt waits, three workgroups
+// per CU - what won for the dense 3x3 kernel) is 30-55 % slower here: the gather then moves 64 B per row and request
+// instead of 128 B, and the gather rate, not the barrier round trip, is what bounds this kernel.
 
 static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
 
