@@ -151,13 +151,13 @@ def roofline_pass(step, n_steps=3):
         kname = r["kernel"]
         if r.get("dense"):   # mirror of the dispatch in csrc/conv2d_nhwc.hip (which device function serves this launch)
             if r["cout"] % 128 == 0:
-                kname = "conv3x3_k32_nhwc_bf16_kernel<128>"
+                kname = f"conv3x3_k32_nhwc_bf16_kernel<128, {r.get('tile_rows', 128) // 32}>"
             elif r.get("pad") == 1 and r.get("stride") == 1 and r["cin"] >= 128:
                 kname = "conv3x3_p1_nhwc_bf16_kernel<64>"
             else:
                 kname = "conv3x3_nhwc_bf16_kernel<64, 2>"
         key = (kname, r["cin"], r["cout"], r["n_out"])
-        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, tile_rows=r.get("tile_rows", 128)))
         a["ms"] += ms
         a["n"] += 1
         if r.get("dense"):   # dense 3x3 conv, NHWC bf16: 2*M*9*cin*cout flops; every input / output / weight byte once
@@ -179,7 +179,7 @@ def roofline_pass(step, n_steps=3):
     rows = []
     for (kern, cin, cout, n_out), a in agg.items():
         avg_ms = a["ms"] / a["n"]
-        rows.append(dict(kernel=kern, cin=cin, cout=cout, n_out=n_out, launches=a["n"], avg_us=avg_ms * 1e3,
+        rows.append(dict(kernel=kern, cin=cin, cout=cout, n_out=n_out, tile_rows=a["tile_rows"], launches=a["n"], avg_us=avg_ms * 1e3,
                          total_ms=a["ms"], tflops=a["flops"] / a["n"] / (avg_ms * 1e-3) / 1e12,
                          gbs=a["bytes"] / a["n"] / (avg_ms * 1e-3) / 1e9))
     rows.sort(key=lambda r: -r["total_ms"])
@@ -254,7 +254,7 @@ def pmc_traffic(top):
     xcd = lambda tiles: -(-tiles // 8) * 8
     if top["kernel"].startswith("conv3x3_"):
         bn = 128 if top["cout"] % 128 == 0 else 64
-        want, grid = top["kernel"], xcd(-(-top["n_out"] // 128)) * (top["cout"] // bn) * 256
+        want, grid = top["kernel"], xcd(-(-top["n_out"] // top.get("tile_rows", 128))) * (top["cout"] // bn) * 256
     elif top["kernel"] == "spconv_fwd_s16":
         bm = 128 if top["cout"] == 128 else 64
         want, grid = f"spconv_fwd_s16_kernel<{top['cin']}, {top['cout']}, {bm}>", xcd(-(-top["n_out"] // bm)) * 256

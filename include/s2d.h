@@ -259,9 +259,11 @@ int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, cons
 int s2d_conv2d3x3_supported(int cin, int cout);
 int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int transpose_flip,
                                     int weight_nhwc, void *packed, s2d_stream_t stream);
-/* stats_partial (optional, fp32 [ceil(n*ho*wo/128)][2][cout]): per 128-pixel tile (sum, sum of squares) of the stored
+/* stats_partial (optional, fp32 [tiles][2][cout], tiles = s2d_conv2d3x3_stats_tiles(...) for the same shape - the
+ * pixel-tile height is chosen per launch): per pixel tile (sum, sum of squares) of the stored
  * outputs per channel — the statistics pass of a following batch norm, produced in the conv epilogue; finish it with
  * s2d_bn_partials_finalize_f32 (or s2d_bn_partials_sum_f32 -> all-reduce -> s2d_bn1d_finalize_fwd_f32). */
+int64_t s2d_conv2d3x3_stats_tiles(int n_img, int h, int w, int cin, int cout, int pad, int stride);
 int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias,
                             const void *zero_page, int n_img, int h, int w, int cin, int cout,
                             int pad, int stride, void *y, float *stats_partial, s2d_stream_t stream);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "s2d_pointwise_conv_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_conv2d3x3_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "s2d_conv2d3x3_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 7),
     "s2d_conv2d3x3_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_conv2d3x3_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p] +

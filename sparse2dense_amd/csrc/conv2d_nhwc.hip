@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
 // stats_partial (optional): per-tile (sum, sum of squares) of the STORED bf16 outputs per output channel, laid out
 // [tile][2][cout] — exactly the partial-sum slabs the batch-norm finalize kernel consumes, so the BatchNorm that
 // follows this conv skips its statistics pass over the tensor.  Fixed summation order (deterministic).
-template <int BN>
-__device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[4][BN / 32], const float *__restrict__ bias, __bf16 *__restrict__ y,
+template <int BN, int MI = 4>
+__device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[MI][BN / 32], const float *__restrict__ bias, __bf16 *__restrict__ y,
                                               int64_t m0, int64_t m_total, int cout, int blk_n, int wm, int wn, int r, int q,
                                               char *smem, float *__restrict__ stats_partial, int tile) {
     constexpr int NT = BN / 32;
@@ -67,10 +67,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[4][BN / 32], const f
         s2[j] = 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int64_t m = m0 + 64 * wm + 16 * i + 4 * q + reg;
+            const int64_t m = m0 + 16 * MI * wm + 16 * i + 4 * q + reg;
             if (m < m_total) {
                 __bf16 v[NT];
 #pragma unroll
@@ -98,7 +98,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[4][BN / 32], const f
             s1[j] += __shfl_xor(s1[j], 16, 64); s1[j] += __shfl_xor(s1[j], 32, 64);
             s2[j] += __shfl_xor(s2[j], 16, 64); s2[j] += __shfl_xor(s2[j], 32, 64);
         }
-        float *red = reinterpret_cast<float *>(smem);   // [wm][2][BN]; the K loop ended with a barrier, its buffers are free
+        float *red = reinterpret_cast<float *>(smem);   // [wm][2][BN]
+        __syncthreads();                                // every wave is out of the K loop: its buffers are free
         if (q == 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -256,17 +257,19 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 // 48 KiB, so three workgroups (12 waves) stay resident per CU, each with two K-steps of LDS-DMA in flight across its
 // barrier.  A image: [128 px][4 parts of 16 B], part index XOR-swizzled by (row >> 1) & 3 (checked against the
 // ds_read_b128 lane groups: 16 distinct bank slots).  B = the h-th half of the 64-deep packed slab (same weight image).
-template <int BN>
-__global__ __launch_bounds__(256) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
+template <int BN, int MI>
+__global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                     const float *__restrict__ bias,
                                                                     const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
                                                                     int cin, int cout, int pad, int stride, __bf16 *__restrict__ y,
                                                                     float *__restrict__ stats_partial) {
     constexpr int NS = 3;
     constexpr int NT = BN / 32;
-    constexpr int A_BYTES = 128 * 32 * 2;      // 8 KiB
+    constexpr int BM = 32 * MI;                // output pixels per workgroup (2 x 2 waves, MI 16-row tiles per wave)
+    constexpr int A_BYTES = BM * 32 * 2;       // 8 KiB at MI = 4
+    constexpr int A_LOADS = (BM * 4 + 255) / 256;
     constexpr int B_HALF = 32 * BN * 2;        // half of a packed K-step slab: [BN/16][64 lanes][8]
-    constexpr int LPS = 2 + (B_HALF / 1024) / 4;
+    constexpr int LPS = A_LOADS + (B_HALF / 1024) / 4;   // LDS-DMA instructions per wave and sub-step (waves 2, 3: one less at MI = 3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto abuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF); };
     auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF) + A_BYTES; };
@@ -277,87 +280,163 @@ __global__ __launch_bounds__(256) void conv3x3_k32_nhwc_bf16_kernel(const __bf16
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 15, q = lane >> 4;
-    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * 128;
+    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * BM;
     if (m0 >= m_total) return;
     const int blk_n = blockIdx.y;
     const int chunks = cin / 64;
     const int T = 18 * chunks;   // sub-steps: (tap, 64-channel chunk, half)
 
-    // A staging: thread t moves the 16-byte chunks t and t+256 of the [128][32 ch] tile: row = id/4, slot = id%4
-    int a_img[2], a_y[2], a_x[2];
-    bool a_ok[2];
+    // A staging: thread t moves the 16-byte chunks t and t+256 of the [128][32 ch] tile: row = id/4, slot = id%4.
+    // Everything that depends on the thread is computed once: the address of the window's corner pixel (tap 0) and a
+    // 9-bit mask of the taps that fall inside the image.  The K loop then only adds wave-uniform offsets kept by a
+    // scalar cursor (tap, channel offset, weight pointer) - the first version recomputed tap / chunk / bounds with
+    // divisions in every sub-step and spent 190 instructions per 16 MFMAs, i.e. ~760 issue cycles per wave and
+    // sub-step against 256 MFMA cycles (rocprofv3 SQ_ACTIVE_INST_ANY vs SQ_VALU_MFMA_BUSY_CYCLES, profiles/).
+    const bool short_wave = MI == 3 && wid >= 2;   // 384 chunks: the second A load only exists for waves 0, 1
+    const __bf16 *a_base[A_LOADS];
+    unsigned a_mask[A_LOADS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < A_LOADS; ++u) {
         const int id = threadIdx.x + 256 * u;
-        const int64_t m = m0 + id / 4;
-        a_ok[u] = m < m_total;
-        const int64_t mm = a_ok[u] ? m : 0;
-        a_x[u] = (int)(mm % Wo) * stride;
-        a_y[u] = (int)((mm / Wo) % Ho) * stride;
-        a_img[u] = (int)(mm / ((int64_t)Wo * Ho));
-    }
-    const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * (2 * B_HALF);
-    const int64_t wstep = (int64_t)(cout / BN) * (2 * B_HALF);
-
-    auto stage = [&](int t, int buf) {
-        const int s = t >> 1, h = t & 1;
-        const int tap = s / chunks, chunk = s - tap * chunks;
-        const int dy = tap / 3 - pad, dx = tap % 3 - pad;
+        const int row = id >> 2;
+        const int part = (id & 3) ^ ((row >> 1) & 3);
+        const int64_t m = m0 + row;
+        const bool ok = m < m_total;
+        const int64_t mm = ok ? m : 0;
+        const int ix0 = (int)(mm % Wo) * stride - pad;
+        const int iy0 = (int)((mm / Wo) % Ho) * stride - pad;
+        const int img = (int)(mm / ((int64_t)Wo * Ho));
+        a_base[u] = x + (((int64_t)img * H + iy0) * W + ix0) * cin + part * 8;
+        unsigned mask = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int tap = 0; tap < 9; ++tap)
+            if (ok && (unsigned)(iy0 + tap / 3) < (unsigned)H && (unsigned)(ix0 + tap % 3) < (unsigned)W) mask |= 1u << tap;
+        a_mask[u] = mask;
+    }
+    const int64_t wstep = (int64_t)(cout / BN) * (2 * B_HALF);
+    // stage cursor (wave-uniform)
+    const char *st_w = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * (2 * B_HALF) + wid * 1024;
+    int st_tap = 0, st_kx = 0, st_coff = 0, st_off = 0, st_h = 0;
+
+    auto stage_next = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < A_LOADS; ++u) {
+            if (u == 1 && short_wave) break;
             const int id = threadIdx.x + 256 * u;
-            const int row = id >> 2;
-            const int part = (id & 3) ^ ((row >> 1) & 3);
-            const int yy = a_y[u] + dy, xx = a_x[u] + dx;
-            const bool ok = a_ok[u] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const __bf16 *src = ok ? x + (((int64_t)a_img[u] * H + yy) * W + xx) * cin + chunk * 64 + h * 32 + part * 8 : zero_page;
+            const bool ok = (a_mask[u] >> st_tap) & 1u;
+            const __bf16 *src = ok ? a_base[u] + (st_off + st_coff) : zero_page;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(abuf(buf) + (size_t)(id - lane) * 16), 16, 0, 0);
         }
         constexpr int B_UNITS = B_HALF / 1024;
 #pragma unroll
         for (int u = 0; u < B_UNITS / 4; ++u) {
-            const int unit = u * 4 + wid;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(wsrc + (int64_t)s * wstep + h * B_HALF + unit * 1024 + lane * 16),
-                (__attribute__((address_space(3))) void *)(bbuf(buf) + unit * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st_w + u * 4096 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(bbuf(buf) + (u * 4 + wid) * 1024), 16, 0, 0);
+        }
+        // advance: (tap, chunk, half) order, the half is the fast index
+        st_w += st_h ? wstep - B_HALF : (int64_t)B_HALF;
+        st_h ^= 1;
+        st_coff += 32;
+        if (st_coff == cin) {
+            st_coff = 0;
+            ++st_tap;
+            ++st_kx;
+            st_off += cin;
+            if (st_kx == 3) {
+                st_kx = 0;
+                st_off += (W - 3) * cin;
+            }
         }
     };
 
-    f32x4c acc[4][NT];
+    f32x4c acc[MI][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    stage(1, 1);
-    wait_vmcnt<LPS>();
-    __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < T; ++t) {
-        const int cur = t % NS;
-        if (t + 2 < T) stage(t + 2, (t + 2) % NS);   // the slot read in iteration t-1
-        bf16x8c a[4], b[NT];
+    // Fragments are double buffered in registers: the ds_reads of sub-step t+1 are issued right after the barrier and
+    // fly under the 16 MFMAs of sub-step t, and so does the staging of sub-step t+3, so a wave's MFMA stream is only
+    // interrupted by the barrier itself.  Ring protocol (slot of sub-step k = k % 3), iteration t:
+    //   wait: own loads of t+1 landed (those of t+2 stay in flight), own fragment reads of t done;  barrier
+    //   read fragments of t+1;  stage t+3 into the slot of t (its fragments are in registers);  MFMAs of t.
+    const int a_rd = ((16 * MI * wm + r) * 4 + (q ^ ((r >> 1) & 3))) * 16;   // rows 16 MI wm + 16 i + r: + 1024 i bytes
+    const int b_rd = (wn * NT * 64 + lane) * 16;
+    auto read_frags = [&](int slot, bf16x8c (&a)[MI], bf16x8c (&b)[NT]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 64 * wm + 16 * i + r;
-            a[i] = *reinterpret_cast<const bf16x8c *>(abuf(cur) + (row * 4 + (q ^ ((row >> 1) & 3))) * 16);
-        }
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8c *>(abuf(slot) + a_rd + i * 1024);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(cur) + ((wn * NT + j) * 64 + lane) * 16);
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(slot) + b_rd + j * 1024);
+    };
+    auto mfmas = [&](const bf16x8c (&a)[MI], const bf16x8c (&b)[NT]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (t + 1 < T) {   // sub-step t+1 must have landed; t+2 (if issued) stays in flight
-            if (t + 2 < T) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-        }
+    };
+    // the waits are the builtin, not inline asm: the compiler's own waitcnt bookkeeping then knows the fragment reads
+    // are done and does not put a second lgkmcnt(0) between the next reads and the MFMAs
+    auto sync_in_flight = [&]() {   // vmcnt(one sub-step of this wave's loads) lgkmcnt(0)
+        if (short_wave) __builtin_amdgcn_s_waitcnt(((LPS - 1) & 15) | 0x70 | (((LPS - 1) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt((LPS & 15) | 0x70 | ((LPS >> 4) << 14));
         __builtin_amdgcn_s_barrier();
+    };
+    auto sync_all = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x70);   // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    };
+    int rd = 1, st = 0;   // slots of sub-steps t+1 and t+3 (= t)
+    auto rot = [&]() {
+        rd = rd == 2 ? 0 : rd + 1;
+        st = st == 2 ? 0 : st + 1;
+    };
+    bf16x8c fa[2][MI], fb[2][NT];
+    stage_next(0);
+    stage_next(1);
+    stage_next(2);
+    if (short_wave) __builtin_amdgcn_s_waitcnt(((2 * LPS - 2) & 15) | 0x70 | (((2 * LPS - 2) >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(((2 * LPS) & 15) | 0x70 | (((2 * LPS) >> 4) << 14));   // sub-step 0 landed
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, fa[0], fb[0]);
+    int t = 0;
+    for (; t + 4 < T; t += 2) {   // T = 18 * chunks is even; no conditional waits inside the loop
+        sync_in_flight();
+        read_frags(rd, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_next(st);
+        mfmas(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rot();
+        sync_in_flight();
+        read_frags(rd, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_next(st);
+        mfmas(fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rot();
     }
+    // t = T-4 .. T-1
+    sync_in_flight();
+    read_frags(rd, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_next(st);   // sub-step T-1
+    mfmas(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    rot();
+    sync_in_flight();   // T-2 landed, T-1 in flight
+    read_frags(rd, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    rot();
+    sync_all();
+    read_frags(rd, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(fa[0], fb[0]);
+    mfmas(fa[1], fb[1]);
 
-    conv_epilogue<BN>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / 128));
+    conv_epilogue<BN, MI>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / BM));
 }
 
 // ---- pad = 1 variant with the A tile shared by the three kx taps ------------------------------------------------------
@@ -513,6 +592,64 @@ extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int
     return S2D_OK;
 }
 
+// ---- launch plan --------------------------------------------------------------------------------------------------
+static int conv_env_int(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+static bool conv_use_shared_a(int cin, int bn, int pad, int stride) {
+    // tap-shared A tile: measured on MI355X (r01) it wins where the A tile dominates the staged bytes (64-wide column
+    // blocks with many input channels: 512->64 196 -> 141 us) and is neutral-to-slightly-slower at 128-wide blocks.
+    // S2D_CONV_SHARED_A=0/1 forces the choice for A/B runs.
+    const char *force = getenv("S2D_CONV_SHARED_A");
+    return pad == 1 && stride == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
+}
+static bool conv_use_k32(int bn) {
+    // 128-wide column blocks take the 32-deep / 3-slot-ring kernel, 64-wide blocks the 64-deep double buffer;
+    // S2D_CONV_NS=2/3/4/32 forces a variant
+    static const int ns_env = conv_env_int("S2D_CONV_NS");
+    return ns_env == 32 || (ns_env == 0 && bn == 128);
+}
+// Output pixels per workgroup of the k32 kernel (128, 96 or 64).  The BEV launches are small against the chip (a
+// 256->256 conv on 4 x 94 x 94 pixels is 552 tiles of 128 x 128 for 768 resident workgroups).  Fitted to the measured
+// launch times (r01, 10 shapes x 3 tile heights): time ~ max(1, workgroups / resident slots) x (tile rows + 48), i.e.
+// shorter tiles pay while the launch is below one round of resident workgroups, taller ones amortise the per-step
+// overhead once it is above.
+static int conv_k32_rows(int64_t m, int col_blocks) {
+    static const int force = conv_env_int("S2D_CONV_BM");
+    if (force == 64 || force == 96 || force == 128) return force;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        slots = 3 * n;
+    }
+    int best = 128;
+    int64_t best_cost = -1;
+    for (int bm : {128, 96, 64}) {
+        const int64_t blocks = ceil_div(m, bm) * col_blocks;
+        const int64_t cost = (blocks > slots ? blocks : slots) * (bm + 48);
+        if (best_cost < 0 || cost < best_cost) {
+            best = bm;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+static int conv_tile_rows(int64_t m, int cin, int cout, int pad, int stride) {
+    const int bn = conv_bn(cout);
+    if (conv_use_shared_a(cin, bn, pad, stride) || !conv_use_k32(bn)) return 128;
+    return bn == 128 ? conv_k32_rows(m, cout / bn) : 128;
+}
+
+extern "C" int64_t s2d_conv2d3x3_stats_tiles(int n_img, int h, int w, int cin, int cout, int pad, int stride) {
+    if (!s2d_conv2d3x3_supported(cin, cout) || n_img <= 0 || h + 2 * pad < 3 || w + 2 * pad < 3 || stride < 1) return 0;
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    const int64_t m = (int64_t)n_img * ho * wo;
+    return ceil_div(m, conv_tile_rows(m, cin, cout, pad, stride));
+}
+
 extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
                                        int n_img, int h, int w, int cin, int cout, int pad, int stride, void *y,
                                        float *stats_partial, s2d_stream_t stream) {
@@ -528,12 +665,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     hipStream_t st = (hipStream_t)stream;
     const int bn = conv_bn(cout);
     const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
-    // tap-shared A tile: measured on MI355X (r01) it wins where the A tile dominates the staged bytes (64-wide column
-    // blocks with many input channels: 512->64 196 -> 141 us) and is neutral-to-slightly-slower at 128-wide blocks
-    // (128->128 71 vs 74 us: those launches are bound by the per-K-step load round trip, not by staged bytes).
-    // S2D_CONV_SHARED_A=0/1 forces the choice for A/B runs.
-    const char *force = getenv("S2D_CONV_SHARED_A");
-    const bool shared_a = pad == 1 && stride == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
+    const bool shared_a = conv_use_shared_a(cin, bn, pad, stride);
     if (shared_a) {
         const size_t lds = 2 * (136 * 64 * 2) + 2 * (size_t)(64 * bn * 2);
         if (bn == 128) {
@@ -561,16 +693,20 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     // ring depth of the LDS-DMA pipeline (S2D_CONV_NS=2/3/4 forces it for A/B runs)
     static const int ns_env = [] { const char *e = getenv("S2D_CONV_NS"); return e ? atoi(e) : 0; }();
     const int ns = (ns_env >= 2 && ns_env <= 4) ? ns_env : 2;
-    // default: 128-wide column blocks take the 32-deep / 3-slot-ring kernel (measured r01: 128->128 556 -> 589, 256->256@94
-    // 510 -> 577 TFLOP/s), 64-wide blocks the 64-deep double buffer (359 vs 335); S2D_CONV_NS=2/3/4/32 forces a variant
-    if (ns_env == 32 || (ns_env == 0 && bn == 128)) {   // 32-deep K-steps, 3-slot ring
-        const size_t lds32 = 3 * (size_t)(128 * 32 * 2 + 32 * bn * 2);
-        if (bn == 128)
-            hipLaunchKernelGGL(conv3x3_k32_nhwc_bf16_kernel<128>, grid, blk, lds32, st, (const __bf16 *)x, (const __bf16 *)packed_weight,
-                               bias, (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
-        else
-            hipLaunchKernelGGL(conv3x3_k32_nhwc_bf16_kernel<64>, grid, blk, lds32, st, (const __bf16 *)x, (const __bf16 *)packed_weight,
-                               bias, (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial);
+    if (conv_use_k32(bn)) {   // 32-deep K-steps, 3-slot ring
+#define S2D_CONV_K32(BN_, MI_)                                                                                                  \
+    hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<BN_, MI_>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn), blk,         \
+                       3 * (size_t)(32 * MI_ * 64 + 64 * BN_), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,      \
+                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial)
+        if (bn == 128) {
+            const int rows = conv_k32_rows(m, cout / bn);
+            if (rows == 128) S2D_CONV_K32(128, 4);
+            else if (rows == 96) S2D_CONV_K32(128, 3);
+            else S2D_CONV_K32(128, 2);
+        } else {
+            S2D_CONV_K32(64, 4);
+        }
+#undef S2D_CONV_K32
         S2D_LAUNCH_CHECK();
         return S2D_OK;
     }

@@ -101,10 +101,14 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
     rec = None
     if H.PROFILE is not None:   # bench.py roofline pass: HIP events on the launch stream
         rec = dict(kernel="conv3x3_nhwc_bf16", tag="dense", cin=cin, cout=cout, n_out=n * ho * wo, kvol=9, pairs=None,
-                   dense=True, in_pixels=n * h * w, pad=pad, stride=stride, start=torch.cuda.Event(enable_timing=True),
+                   dense=True, in_pixels=n * h * w, pad=pad, stride=stride,
+                   tile_rows=next(bm for bm in (128, 96, 64)
+                                  if -(-n * ho * wo // bm) == lib.s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, stride)),
+                   start=torch.cuda.Event(enable_timing=True),
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
-    partial = torch.empty(((n * ho * wo + 127) // 128, 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
+    partial = (torch.empty((lib.s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, stride), 2, cout), dtype=torch.float32,
+                           device=x.device) if bn_stats else None)
     check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
                                       pad, stride, _ptr(y), _ptr(partial), _stream()), "s2d_conv2d3x3_nhwc_bf16")
     if rec is not None:
