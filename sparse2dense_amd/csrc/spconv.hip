@@ -312,9 +312,13 @@ __global__ __launch_bounds__(256) void spconv_wgrad_bf16(const T *__restrict__ i
 #pragma unroll
             for (int f = 0; f < C::VB; ++f) acc[la][e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // the neighbour indices of the next 64-row window are fetched while this one is processed (one of the serial
+    // memory round trips of a window: index -> pair list -> gathers)
+    int j_next = r_begin + lane < r_end ? nk[r_begin + lane] : -1;
     for (int base = r_begin; base < r_end; base += 64) {
         const int o_l = base + lane;
-        const int j_l = o_l < r_end ? nk[o_l] : -1;
+        const int j_l = j_next;
+        j_next = o_l + 64 < r_end ? nk[o_l + 64] : -1;
         const unsigned long long mask = __ballot(j_l >= 0);
         const int cnt = __popcll(mask);
         if (cnt == 0) continue;
@@ -383,6 +387,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     float s = 0.f;
     for (int sp = 0; sp < n_split; ++sp) s += partial[(int64_t)sp * size + i];
     dw[i] = s;
+}
+
+// size % 4 == 0: a workgroup owns 16 float4 columns; 16 thread rows stride over the splits (the small layers have ~7k
+// elements and ~76 splits: one thread per element walked the splits as a serial chain of loads and took longer than
+// the gather kernel's tail), then a fixed-order fold through LDS (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4 *__restrict__ partial, int n_split, int64_t size4,
+                                                            float4 *__restrict__ dw) {
+    __shared__ float4 red[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + col;
+    float4 s = float4{0.f, 0.f, 0.f, 0.f};
+    if (i < size4) {
+        for (int sp = sl; sp < n_split; sp += 16) {
+            const float4 v = partial[(int64_t)sp * size4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && i < size4) {
+        float4 t = red[0][col];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            const float4 v = red[r][col];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        dw[i] = t;
+    }
 }
 
 // ---- VALU fallbacks (channel counts not multiple of 16, e.g. the 5-channel input layer) ----------
@@ -520,9 +552,13 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // the neighbour indices of the next 64-row window are fetched while this one is processed (one of the serial
+    // memory round trips of a window: index -> pair list -> gathers)
+    int j_next = r_begin + lane < r_end ? nk[r_begin + lane] : -1;
     for (int base = r_begin; base < r_end; base += 64) {
         const int o_l = base + lane;
-        const int j_l = o_l < r_end ? nk[o_l] : -1;
+        const int j_l = j_next;
+        j_next = o_l + 64 < r_end ? nk[o_l + 64] : -1;
         const unsigned long long mask = __ballot(j_l >= 0);
         const int cnt = __popcll(mask);
         if (cnt == 0) continue;
@@ -609,7 +645,9 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
     }
     p.wrow = p.mfma ? 4 / wco : 1;
     // aim at ~2048 waves in flight, at least 256 rows per split
-    int64_t want_blocks_y = ceil_div(2048, (int64_t)kvol * 4);
+    static const int waves_env = [] { const char *e = getenv("S2D_WGRAD_WAVES"); return e ? atoi(e) : 0; }();
+    const int want_waves = waves_env > 0 ? waves_env : 2048;
+    int64_t want_blocks_y = ceil_div(want_waves, (int64_t)kvol * 4);
     int64_t max_split = ceil_div(n_out > 0 ? n_out : 1, 256);
     int64_t splits = want_blocks_y * p.wrow;
     if (splits > max_split) splits = max_split;
@@ -754,8 +792,12 @@ static int wgrad_impl(int mode, const float *in_feat, int64_t n_in, const float 
         hipLaunchKernelGGL(spconv_wgrad_valu, dim3(kvol, p.n_split), dim3(128), 0, st, in_feat, dout, nbr, (int)n_out, kvol,
                            cin, cout, p.rows_per_split, partial);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, p.n_split, size,
-                       dweight);
+    if (size % 4 == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)ceil_div(size / 4, 16)), dim3(256), 0, st, (const float4 *)partial,
+                           p.n_split, size / 4, (float4 *)dweight);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, p.n_split, size,
+                           dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

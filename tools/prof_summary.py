@@ -34,5 +34,21 @@ def main():
         print(f"{100 * dur / tot:6.2f}% {dur / 1e6:9.3f} {c:6d} {dur / c / 1e3:8.1f}   {n[:140]}")
 
 
+    # GPU idle time inside the step, attributed to the kernel that ends the gap (what the host was late to launch)
+    gaps = collections.defaultdict(lambda: [0, 0])
+    idle = 0
+    end = int(seg[0]["End_Timestamp"])
+    for r in seg[1:]:
+        g = int(r["Start_Timestamp"]) - end
+        if g > 0:
+            idle += g
+            gaps[r["Kernel_Name"]][0] += g
+            gaps[r["Kernel_Name"]][1] += 1
+        end = max(end, int(r["End_Timestamp"]))
+    print(f"# GPU idle inside the step: {idle / 1e6:.3f} ms; largest contributors (gap before the kernel):")
+    for n, (dur, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+        print(f"#   {dur / 1e3:8.1f} us over {c:4d} gaps   {n[:110]}")
+
+
 if __name__ == "__main__":
     main()
