@@ -112,27 +112,48 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
             if (++sy == Ho) { sy = 0; ++sn; }
         }
     };
-    auto stage = [&](int buf) {   // stages the tiles of step (sn, sy, sxc): chunk c of the slot = A chunks, then B chunks
+    // Staging roles are fixed per thread: chunk c = t + 512 u of the slot is an A (dY) chunk or a B (X) chunk (wave-uniform,
+    // the chunk counts are multiples of 64) at a fixed (pixel row, 16-byte column) of its tile.  Everything that depends
+    // on the thread is computed once - the source pointer at step origin and the pixel row (a huge value for pad columns
+    // and filler rows, which then always fail the range test and read the zero page); per K-step only wave-uniform
+    // offsets and limits change.  (The first version redid the chunk -> (row, col) division and the address products
+    // in every K-step: ~200 staging instructions per 24 MFMAs.)
+    constexpr int NU = (C::CHUNKS + 511) / 512;
+    const __bf16 *ptr_u[NU];
+    int row_u[NU];
+    bool isa_u[NU], has_u[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int c = t + 512 * u;
+        has_u[u] = __builtin_amdgcn_readfirstlane(c < C::CHUNKS ? 1 : 0) != 0;
+        isa_u[u] = __builtin_amdgcn_readfirstlane(c < C::A_CHUNKS ? 1 : 0) != 0;
+        if (c < C::A_CHUNKS) {
+            const int row = c / C::CPR_A, col = c % C::CPR_A;
+            row_u[u] = (col < TCO / 8 && row < 32) ? row : 0x40000000;
+            ptr_u[u] = dy + (int64_t)row * cout + cot * TCO + col * 8;
+        } else {
+            const int q = c - C::A_CHUNKS;
+            const int row = q / C::CPR_B, col = q % C::CPR_B;
+            row_u[u] = (col < TCI / 8 && row < 34) ? row : 0x40000000;
+            ptr_u[u] = x + (int64_t)row * cin + cit * TCI + col * 8;
+        }
+    }
+    auto stage = [&](int buf) {   // stages the tiles of step (sn, sy, sxc)
         const int x0 = sxc * 32;
         const int yin = sy + ky - pad;
+        const int64_t ua = (((int64_t)sn * Ho + sy) * Wo + x0) * cout;          // element offset of dY[sn][sy][x0][0]
+        const int64_t ub = (((int64_t)sn * H + yin) * W + x0 - pad) * cin;      // of X[sn][yin][x0 - pad][0]
+        const unsigned lim_b = (unsigned)yin < (unsigned)H ? (unsigned)W : 0u;  // a kernel row outside the image: all zero
         char *slot = abuf(buf);
 #pragma unroll
-        for (int u = 0; u < (C::CHUNKS + 511) / 512; ++u) {
-            const int c = t + 512 * u;
-            if (c < C::CHUNKS) {   // wave-uniform: chunk counts are multiples of 64
-                const __bf16 *src = zero_page;
-                if (c < C::A_CHUNKS) {   // wave-uniform
-                    const int row = c / C::CPR_A, col = c % C::CPR_A, xo = x0 + row;
-                    if (col < TCO / 8 && row < 32 && xo < Wo)
-                        src = dy + ((int64_t)(sn * Ho + sy) * Wo + xo) * cout + cot * TCO + col * 8;
-                } else {
-                    const int q = c - C::A_CHUNKS;
-                    const int row = q / C::CPR_B, col = q % C::CPR_B, xin = x0 - pad + row;
-                    if (col < TCI / 8 && row < 34 && (unsigned)yin < (unsigned)H && (unsigned)xin < (unsigned)W)
-                        src = x + ((int64_t)(sn * H + yin) * W + xin) * cin + cit * TCI + col * 8;
-                }
+        for (int u = 0; u < NU; ++u) {
+            if (has_u[u]) {   // wave-uniform
+                const int64_t uo = isa_u[u] ? ua : ub;
+                const unsigned lim = isa_u[u] ? (unsigned)Wo : lim_b;
+                const unsigned xv = (unsigned)(x0 - (isa_u[u] ? 0 : pad) + row_u[u]);
+                const __bf16 *src = xv < lim ? ptr_u[u] + uo : zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(slot + (size_t)(c - lane) * 16), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(slot + (size_t)(t + 512 * u - lane) * 16), 16, 0, 0);
             }
         }
     };
@@ -141,101 +162,145 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     // "s_waitcnt vmcnt(2 * nl)" = the two youngest K-steps may stay in flight
     int nl = 0;
 #pragma unroll
-    for (int u = 0; u < (C::CHUNKS + 511) / 512; ++u) nl += (t + 512 * u < C::CHUNKS) ? 1 : 0;
-    nl = __builtin_amdgcn_readfirstlane(nl);
+    for (int u = 0; u < NU; ++u) nl += has_u[u] ? 1 : 0;
 
     // per-lane position of the transpose reads inside a tile: pixel row 4g + c16/4 (+16 for the second read), 8-byte column c16 % 4
     const int tr_row = 4 * g + (c16 >> 2), tr_col = (c16 & 3) * 8;
-    // prologue: fill the ring (the staging cursor runs ahead of the compute cursor; rows are tracked separately)
-    int cy = sy;                                  // image row of the step being computed
-    int cxc = sxc;
-    const int n_pre = min(C::NS - 1, s1 - s0);
+    // Fragments are double buffered in registers: iteration i issues the transpose reads of step i+1 and then runs the
+    // MFMAs of step i, whose fragments were read during iteration i-1 (three LDS round trips per K-step - one per kx tap -
+    // used to sit in front of the MFMAs).  Ring protocol (slot of step i = i % NS), iteration i:
+    //   stage step i+NS-1 into the slot of step i-1 (its fragment reads were waited for before the last barrier);
+    //   wait: own loads of step i+1 landed, own fragment reads of step i done;  barrier;
+    //   issue the reads of step i+1;  MFMAs of step i.
+    // A kernel row outside the image stages zero tiles (lim_b = 0), so no step is skipped.
+    struct Frags {
+        i32x2w alo[C::MI], ahi[C::MI], blo[3][C::NJ], bhi[3][C::NJ];
+    };
+    const unsigned a_off = tr_row * C::RS_A + wco * C::MI * 32 + tr_col;
+    const unsigned b_off = C::A_BYTES + tr_row * C::RS_B + wci * C::NJ * 32 + tr_col;
+    auto read_frags = [&](int slot, Frags &f) {
+        const unsigned base = smem_addr + slot * (C::A_BYTES + C::B_BYTES);
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) tr_issue<16 * C::RS_A>(f.alo[i], f.ahi[i], base + a_off + i * 32);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(f.blo[kx][j], f.bhi[kx][j], base + b_off + j * 32 + kx * C::RS_B);
+    };
+    auto mfmas = [&](const Frags &f) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < C::NJ; ++j) {
+                const bf16x8w xf = tr_pack(f.blo[kx][j], f.bhi[kx][j]);
+#pragma unroll
+                for (int i = 0; i < C::MI; ++i)   // D[ci][co]: the X fragment is the row operand, so a lane's 4 results are 4 consecutive ci
+                    acc[i][j][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, tr_pack(f.alo[i], f.ahi[i]), acc[i][j][kx], 0, 0, 0);
+            }
+    };
+    const int n = s1 - s0;
+    const int n_pre = min(C::NS - 1, n);
     for (int p = 0; p < n_pre; ++p) {
         stage(p);
         advance();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (simple: the whole prologue lands before the first step)
     __builtin_amdgcn_s_barrier();
-    for (int s = s0; s < s1; ++s) {
-        const int cur = (s - s0) % C::NS;
-        const int yin = cy + ky - pad;
-        const bool row_ok = (unsigned)yin < (unsigned)H;   // block-uniform: a kernel row outside the image adds nothing
-        if (++cxc == XC) {
-            cxc = 0;
-            if (++cy == Ho) cy = 0;
-        }
-        const bool more = s + C::NS - 1 < s1;
-        if (more) {   // slot (s-1) % NS was last read in the previous iteration, before its barrier
-            stage((s - s0 + C::NS - 1) % C::NS);
+    Frags f0, f1;
+    read_frags(0, f0);
+    int slot_next = 1, slot_stage = C::NS - 1;   // slots of steps i+1 and i+NS-1
+    auto iteration = [&](int i, const Frags &cur, Frags &nxt) {
+        const bool more = i + C::NS - 1 < n;
+        if (more) {
+            stage(slot_stage);
             advance();
         }
-        if (row_ok) {
-            // dY fragments and the kx = 0 X fragments first; then the X reads of tap kx+1 are issued ahead of the MFMAs of
-            // tap kx (LDS returns in order: "lgkmcnt(2*NJ)" = everything but the youngest tap's reads has arrived)
-            i32x2w alo[C::MI], ahi[C::MI], blo[3][C::NJ], bhi[3][C::NJ];
-            const unsigned abase = smem_addr + cur * (C::A_BYTES + C::B_BYTES) + tr_row * C::RS_A + wco * C::MI * 32 + tr_col;
-            const unsigned bbase = smem_addr + cur * (C::A_BYTES + C::B_BYTES) + C::A_BYTES + tr_row * C::RS_B + wci * C::NJ * 32 + tr_col;
-#pragma unroll
-            for (int i = 0; i < C::MI; ++i) tr_issue<16 * C::RS_A>(alo[i], ahi[i], abase + i * 32);
-#pragma unroll
-            for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(blo[0][j], bhi[0][j], bbase + j * 32);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                if (kx < 2) {
-#pragma unroll
-                    for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(blo[kx + 1][j], bhi[kx + 1][j], bbase + j * 32 + (kx + 1) * C::RS_B);
-                    if (C::NJ == 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < C::NJ; ++j) {
-                    const bf16x8w xf = tr_pack(blo[kx][j], bhi[kx][j]);
-#pragma unroll
-                    for (int i = 0; i < C::MI; ++i)   // D[ci][co]: the X fragment is the row operand, so a lane's 4 results are 4 consecutive ci
-                        acc[i][j][kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, tr_pack(alo[i], ahi[i]), acc[i][j][kx], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // next step's tiles must have landed (in every wave) before anyone reads them; the two younger steps stay in flight
+        // step i+1 landed (in every wave after the barrier); the two younger steps stay in flight
         if (more) {
-            if (nl == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (nl == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (nl == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (nl == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (nl == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < n) read_frags(slot_next, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        slot_next = slot_next == C::NS - 1 ? 0 : slot_next + 1;
+        slot_stage = slot_stage == C::NS - 1 ? 0 : slot_stage + 1;
+    };
+    for (int i = 0; i < n; i += 2) {
+        iteration(i, f0, f1);
+        if (i + 1 < n) iteration(i + 1, f1, f0);
     }
 
-    // partial[split][ky][kx][co][ci] ; C/D layout: row (ci) = 4*(lane>>4)+reg -> one 16-byte store, col (co) = lane&15
+    // partial[split][ky][kx][co][ci].  C/D layout: row (ci) = 4*(lane>>4)+reg, col (co) = lane&15: a direct store writes
+    // 64-byte pieces of 16 different co rows per instruction (measured: 37 us for the 50 MB of slabs of a 128->128 layer).
+    // Each wave instead passes its [MI*16 co][NJ*16 ci] tile of one kx through LDS (the ring is free now) and stores it
+    // as whole NJ*64-byte row segments, 16 bytes per lane.
+    constexpr int EP_ROWB = C::NJ * 64 + 16;              // padded LDS row (bytes)
+    constexpr int EP_BYTES = C::MI * 16 * EP_ROWB;
+    static_assert(8 * EP_BYTES <= (int)C::LDS, "epilogue tiles exceed the ring");
+    __syncthreads();   // every wave is out of the K loop
+    char *ep = smem + wid * EP_BYTES;
     float *dst = partial + ((int64_t)blockIdx.x * 9 + ky * 3) * (int64_t)cout * cin;
+    const int co0 = cot * TCO + wco * C::MI * 16, ci0 = cit * TCI + wci * C::NJ * 16;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j) {
-                const int co = cot * TCO + (wco * C::MI + i) * 16 + c16;
-                const int ci = cit * TCI + (wci * C::NJ + j) * 16 + 4 * g;
-                *reinterpret_cast<f32x4w *>(dst + ((int64_t)kx * cout + co) * cin + ci) = acc[i][j][kx];
-            }
+            for (int j = 0; j < C::NJ; ++j)
+                *reinterpret_cast<f32x4w *>(ep + (16 * i + c16) * EP_ROWB + (16 * j + 4 * g) * 4) = acc[i][j][kx];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: its LDS ops are ordered, this pins the compiler
+        constexpr int CPRW = C::NJ * 4;                       // 16-byte chunks per row
+#pragma unroll
+        for (int it = 0; it < C::MI * 16 * CPRW / 64; ++it) {
+            const int id = lane + 64 * it, row = id / CPRW, ch = id % CPRW;
+            const f32x4w v = *reinterpret_cast<const f32x4w *>(ep + row * EP_ROWB + ch * 16);
+            *reinterpret_cast<f32x4w *>(dst + ((int64_t)kx * cout + co0 + row) * cin + ci0 + ch * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next kx overwrites the tile
+    }
 }
 
 // dw[co][ci][ky][kx] = sum_split partial[split][ky*3+kx][co][ci]   (fixed order -> deterministic)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int cin, int cout,
+// A workgroup owns 64 float4 columns of the [tap][co][ci] plane; 4 thread rows stride over the splits (more loads in
+// flight than one thread per element walking all splits), fixed-order fold through LDS.  cin % 4 == 0.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float4 *__restrict__ partial, int splits, int cin, int cout,
                                                                    float *__restrict__ dw) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [tap][co][ci], ci fastest (coalesced reads)
-    const int64_t plane = (int64_t)cout * cin;
-    if (i >= 9 * plane) return;
-    const int tap = (int)(i / plane);
-    const int64_t r = i - tap * plane;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[(int64_t)k * 9 * plane + i];
-    dw[r * 9 + tap] = s;
+    __shared__ float4 red[4][64];
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t plane = (int64_t)cout * cin;          // floats per tap
+    const int64_t size4 = 9 * plane / 4;
+    const int64_t i4 = (int64_t)blockIdx.x * 64 + col;  // float4 index over [tap][co][ci]
+    float4 s = float4{0.f, 0.f, 0.f, 0.f};
+    if (i4 < size4) {
+        for (int k = sl; k < splits; k += 4) {
+            const float4 v = partial[(int64_t)k * size4 + i4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && i4 < size4) {
+        float4 t = red[0][col];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            const float4 v = red[r][col];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const int64_t i = i4 * 4;
+        const int tap = (int)(i / plane);
+        const int64_t r = i - tap * plane;               // co * cin + ci, 4 consecutive ci
+        dw[r * 9 + tap] = t.x;
+        dw[(r + 1) * 9 + tap] = t.y;
+        dw[(r + 2) * 9 + tap] = t.z;
+        dw[(r + 3) * 9 + tap] = t.w;
+    }
 }
 
 struct WgPlan {
@@ -309,7 +374,7 @@ extern "C" int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, cons
     else rc = wg_launch<64, 64>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st);
     if (rc) return rc;
     const int64_t total = (int64_t)9 * cin * cout;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, (const float *)partial,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
                        p.splits, cin, cout, dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;

@@ -118,14 +118,16 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
 
 
 # which weight gradients take the hand-written transpose-read kernel (csrc/conv2d_wgrad.hip) instead of MIOpen:
-# "auto" = where it measured faster on MI355X (r01: only cin >= 512, i.e. the head's 512->64 conv), True / False = all / none
+# "auto" = every stride-1 3x3 conv the kernel supports (r01 end state: 111-116 us against MIOpen's 114-120 us on the
+# 128->128 / 256->256 BEV layers, 181 vs 224 us on 512->64 - and no SubTensorOp / cast launches or MIOpen host-side
+# solver lookup around it); True / False = all / none
 import os as _os
 WGRAD_HIP = {"0": False, "1": True}.get(_os.environ.get("S2D_WGRAD_HIP", ""), "auto")
 
 
 def _wgrad_hip(cin, cout):
     if WGRAD_HIP == "auto":
-        return cin >= 512
+        return True
     return bool(WGRAD_HIP)
 
 
