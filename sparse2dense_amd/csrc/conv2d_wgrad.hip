@@ -315,7 +315,16 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad) {
     const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
     const int64_t total = (int64_t)n_img * ho * ((wo + 31) / 32);
     const int tiles = (cout / p.tco) * (cin / p.tci);
-    int64_t splits = ceil_div(256, 3 * tiles);   // one 8-wave workgroup per CU
+    // one 8-wave workgroup per CU (203 VGPRs: a second one does not fit), and never more workgroups than CUs: 258
+    // workgroups on 256 CUs ran as two rounds (rocprofv3: SQ busy 51 us of a 103 us launch) - round DOWN
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    int64_t splits = cus / (3 * tiles);
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.steps_per_block = (int)ceil_div(total, splits);
