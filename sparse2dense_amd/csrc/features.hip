@@ -56,13 +56,15 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float *__
 // out2 (optional): a second copy of the sums (the one that gets all-reduced); count >= 0: also written to out[width]
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblocks, int width,
                                                           float *__restrict__ out, float *__restrict__ out2 = nullptr,
-                                                          float count = -1.f) {
+                                                          float count = -1.f, bool cm = false) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (e == 0 && lane == 0 && count >= 0.f) out[width] = count;
     if (e >= width) return;
     float s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * width + e];
+    // cm: partials stored element-major [width][nblocks] (the row-major bf16 reduce kernels): the lanes' loads are then
+    // one contiguous run instead of 64 sectors
+    for (int b = lane; b < nblocks; b += 64) s += cm ? partial[(size_t)e * nblocks + b] : partial[(size_t)b * width + e];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
     if (lane == 0) {
@@ -331,15 +333,15 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float
                                                                      float *__restrict__ invstd_out, float *__restrict__ scale,
                                                                      float *__restrict__ shift, float *__restrict__ running_mean,
                                                                      float *__restrict__ running_var,
-                                                                     long long *__restrict__ batches_tracked) {
+                                                                     long long *__restrict__ batches_tracked, bool cm = false) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= c) return;
     if (i == 0 && lane == 0 && batches_tracked) *batches_tracked += 1;
     float s0 = 0.f, s1 = 0.f;
     for (int b = lane; b < nblocks; b += 64) {
-        s0 += partial[(size_t)b * 2 * c + i];
-        s1 += partial[(size_t)b * 2 * c + c + i];
+        s0 += cm ? partial[(size_t)i * nblocks + b] : partial[(size_t)b * 2 * c + i];
+        s1 += cm ? partial[(size_t)(c + i) * nblocks + b] : partial[(size_t)b * 2 * c + c + i];
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -369,14 +371,14 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_bwd_kernel(const float
                                                                      const float *__restrict__ invstd, int c,
                                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                                      float *__restrict__ a, float *__restrict__ b,
-                                                                     float *__restrict__ d) {
+                                                                     float *__restrict__ d, bool cm = false) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= c) return;
     float sg = 0.f, sgx = 0.f;
     for (int k = lane; k < nblocks; k += 64) {
-        sg += partial[(size_t)k * 2 * c + i];
-        sgx += partial[(size_t)k * 2 * c + c + i];
+        sg += cm ? partial[(size_t)i * nblocks + k] : partial[(size_t)k * 2 * c + i];
+        sgx += cm ? partial[(size_t)(c + i) * nblocks + k] : partial[(size_t)k * 2 * c + c + i];
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
     for (int e = threadIdx.x; e < 2 * c; e += RED_THREADS) {
         float s = 0.f;
         for (int l = 0; l < lanes; ++l) s += lds[(size_t)l * 2 * c + e];
-        partial[(size_t)blockIdx.x * 2 * c + e] = s;
+        partial[(size_t)e * gridDim.x + blockIdx.x] = s;   // element-major: the finalize kernels' lanes stride over the blocks
     }
 }
 
@@ -945,7 +947,7 @@ extern "C" int s2d_bnrow_stats_bf16(const void *x, int64_t n, int c, float *stat
     int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, stats,
-                       (float *)nullptr, write_count ? (float)n : -1.f);
+                       (float *)nullptr, write_count ? (float)n : -1.f, true);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -961,7 +963,7 @@ extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, co
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
-                       (long long *)batches_tracked);
+                       (long long *)batches_tracked, true);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -994,7 +996,7 @@ extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const vo
     int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums,
-                       sums_copy, -1.f);
+                       sums_copy, -1.f, true);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -1009,7 +1011,7 @@ extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x,
     int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
-                       gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
+                       gamma, mean, invstd, c, dgamma, dbeta, a, b, d, true);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

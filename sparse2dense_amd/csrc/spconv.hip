@@ -647,7 +647,10 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
     // aim at ~2048 waves in flight, at least 256 rows per split
     static const int waves_env = [] { const char *e = getenv("S2D_WGRAD_WAVES"); return e ? atoi(e) : 0; }();
     const int want_waves = waves_env > 0 ? waves_env : 2048;
-    int64_t want_blocks_y = ceil_div(want_waves, (int64_t)kvol * 4);
+    // rounded DOWN: the 128-channel kernel (174 VGPRs) fits two workgroups per CU = 512 on the chip, and 27 x 19 = 513
+    // workgroups ran as two rounds
+    int64_t want_blocks_y = want_waves / ((int64_t)kvol * 4);
+    if (want_blocks_y < 1) want_blocks_y = 1;
     int64_t max_split = ceil_div(n_out > 0 ? n_out : 1, 256);
     int64_t splits = want_blocks_y * p.wrow;
     if (splits > max_split) splits = max_split;
