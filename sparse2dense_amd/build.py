@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
         if force or _stale(o, [s] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
-                print(" ".join(cmd), flush=True)
+                print(" ".join(cmd), file=sys.stderr, flush=True)
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
-            print(" ".join(cmd), flush=True)
+            print(" ".join(cmd), file=sys.stderr, flush=True)
         subprocess.check_call(cmd)
     return LIB
 
