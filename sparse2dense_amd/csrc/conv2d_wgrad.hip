@@ -19,12 +19,14 @@
 // [split][ky][kx][co][ci]; a second kernel reduces the splits in a fixed order (deterministic) into the
 // torch layout [cout][cin][3][3].
 //
-// Status (r01, MI355X, 4x188x188): 128->128 133 us and 256->256@94 123 us against MIOpen's 118 / 115 us; 512->64
-// 187 us against 226 us, so the host side (dense2d.py) only routes cin >= 512 here for now.  Measured split of the
-// 128->128 case before the last two changes: K loop 79 us (loads alone 32, transpose reads + MFMA alone 44, not
-// overlapping), partial-slab stores 37 us (4-byte stores of 50 MB), reduce 19 us.  Since then the X reads of tap kx+1
-// are issued ahead of the MFMAs of tap kx, and the operands are swapped (D[ci][co]) so that a lane's four results are
-// consecutive ci = one 16-byte slab store.
+// Status (r01, MI355X, 4x188x188, reduce included): 128->128 69 us and 256->256@94 71 us against MIOpen's 119 / 114 us
+// (plus its zeroing / cast launches), 512->64 146 us against 227 us: every stride-1 3x3 weight gradient runs here.
+// History of the 128->128 case: 133 us with the K loop at 79 us (loads alone 32, transpose reads + MFMA alone 44, not
+// overlapping), partial-slab stores 37 us (4-byte stores of 50 MB), reduce 19 us.  Then: operands swapped (D[ci][co], a
+// lane's four results are consecutive ci), staging roles hoisted out of the K loop, fragments double buffered in
+// registers, slabs stored through LDS as whole row segments, split-parallel float4 reduce -> 116 us; and the one that
+// mattered most: the grid was 258 workgroups for 256 CUs with one resident workgroup per CU (203 VGPRs), i.e. two
+// rounds - rounding the split count down gave 69 us.
 #include "s2d_common.h"
 
 namespace s2d {
