@@ -191,6 +191,22 @@ struct WgradCfg {
     static constexpr int WROW = 4 / WCO;                       // waves across rows
 };
 
+// (kernel offset, row-split block) of this workgroup.  Workgroups go to the 8 XCDs round-robin in launch order; when the
+// number of row-split blocks is a multiple of 8, XCD x gets every offset of the row blocks = x (mod 8), so that the rows
+// its L2 sees are 1/8 of the tensor (the 27 offsets of a row block re-read the same input / gradient rows; spread
+// over all XCDs each 4 MB L2 streamed the whole tensor).
+__device__ __forceinline__ void wgrad_block(int kvol, int &k, int &by) {
+    const int gy = gridDim.y, b = blockIdx.x + kvol * blockIdx.y;
+    if ((gy & 7) == 0) {
+        const int xcd = b & 7, q = b >> 3;
+        k = q % kvol;
+        by = (q / kvol) * 8 + xcd;
+    } else {
+        k = blockIdx.x;
+        by = blockIdx.y;
+    }
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict__ in, const float *__restrict__ dout,
                                                          const int32_t *__restrict__ nbr, int n_out, int kvol,
@@ -203,9 +219,10 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma(const float *__restrict
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int k = blockIdx.x;
+    int k, by;
+    wgrad_block(kvol, k, by);
     const int wco = wid % C::WCO, wrow = wid / C::WCO;
-    const int split = blockIdx.y * C::WROW + wrow;
+    const int split = by * C::WROW + wrow;
     const int co_base = wco * 16 * C::VB;
     const int r_begin = split * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
@@ -295,9 +312,10 @@ __global__ __launch_bounds__(256) void spconv_wgrad_bf16(const T *__restrict__ i
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, q = lane >> 4;
-    const int k = blockIdx.x;
+    int k, by;
+    wgrad_block(kvol, k, by);
     const int wco = wid % C::WCO, wrow = wid / C::WCO;
-    const int split = blockIdx.y * C::WROW + wrow;
+    const int split = by * C::WROW + wrow;
     const int co_base = wco * 16 * C::VB;
     const int r_begin = split * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
@@ -527,19 +545,20 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
     constexpr int LPR_A = CIN / 8, LPR_B = CB / 8;        // lanes (16-byte pieces) per gathered row
     constexpr int TILE_A = 32 * RS_A, TILE_B = 32 * RS_B;
     constexpr int LA = (32 * LPR_A + 63) / 64, LB = (32 * LPR_B + 63) / 64;
-    __shared__ int2 pair_lds[4][64];
+    constexpr int RING = 256;   // pair ring per wave (at most 64 pending + 64 being appended)
+    __shared__ int2 pair_lds[4][RING];
     __shared__ __attribute__((aligned(16))) char tile_lds[4][TILE_A + TILE_B];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wco = wid % C::WCO, wrow = wid / C::WCO;
     const int g = lane >> 4, c16 = lane & 15;
-    const int k = blockIdx.x;
-    const int split = blockIdx.y * C::WROW + wrow;
+    int k, by;
+    wgrad_block(kvol, k, by);
+    const int split = by * C::WROW + wrow;
     const int co_base = wco * CB;
     const int r_begin = split * rows_per_split;
     const int r_end = min(n_out, r_begin + rows_per_split);
     const int32_t *nk = nbr + (int64_t)k * n_out;
-    int2 *mypairs = pair_lds[wid];
     char *ta = tile_lds[wid], *tb = tile_lds[wid] + TILE_A;
     const unsigned ta_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)ta);
     const unsigned tb_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)tb);
@@ -552,52 +571,95 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // the neighbour indices of the next 64-row window are fetched while this one is processed (one of the serial
-    // memory round trips of a window: index -> pair list -> gathers)
-    int j_next = r_begin + lane < r_end ? nk[r_begin + lane] : -1;
-    for (int base = r_begin; base < r_end; base += 64) {
-        const int o_l = base + lane;
-        const int j_l = j_next;
-        j_next = o_l + 64 < r_end ? nk[o_l + 64] : -1;
-        const unsigned long long mask = __ballot(j_l >= 0);
-        const int cnt = __popcll(mask);
-        if (cnt == 0) continue;
-        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-        if (j_l >= 0) mypairs[rank] = make_int2(o_l, j_l);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int p0 = 0; p0 < cnt; p0 += 32) {
-            // gather: 16 bytes per lane; rows past the window's pair count are zero
-            uint4 va[LA], vb[LB];
-#pragma unroll
-            for (int u = 0; u < LA; ++u) {
-                const int c = lane + 64 * u, pr = c / LPR_A, part = c % LPR_A;
-                const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
-                va[u] = *reinterpret_cast<const uint4 *>(in + (int64_t)pp.y * CIN + part * 8);
-                if (p0 + pr >= cnt) va[u] = uint4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int u = 0; u < LB; ++u) {
-                const int c = lane + 64 * u, pr = c / LPR_B, part = c % LPR_B;
-                const int2 pp = mypairs[min(p0 + pr, cnt - 1)];
-                vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + co_base + part * 8);
-                if (p0 + pr >= cnt) vb[u] = uint4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int u = 0; u < LA; ++u) *reinterpret_cast<uint4 *>(ta + (lane + 64 * u) * 16) = va[u];
-#pragma unroll
-            for (int u = 0; u < LB; ++u) *reinterpret_cast<uint4 *>(tb + (lane + 64 * u) * 16) = vb[u];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bf16x8 b[NB];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) b[n] = wg_tr_read<16 * RS_B>(tb_addr + tr_off_b + n * 32);
-#pragma unroll
-            for (int m = 0; m < MA; ++m) {
-                const bf16x8 a = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
-#pragma unroll
-                for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
-            }
+    // The rows of this wave are a chain of dependent round trips: neighbour index -> compacted pair list (LDS) -> row
+    // gathers -> LDS tile -> transpose reads -> MFMA.  It is software pipelined over CHUNKS of 32 pairs: pairs of as many
+    // 64-row windows as needed are appended to a ring (indices prefetched two windows ahead), chunks are cut from the
+    // ring independent of window boundaries (only the last chunk of the wave is partial - cutting per window left the
+    // typical 36-pair window with a 4-pair second chunk), and the gathers of chunk c+1 are issued before chunk c is
+    // consumed.  The gather is unconditional straight-line code (clamped indices) so that hipcc's vmcnt bookkeeping stays
+    // exact: with a branch around it the merge of the two paths made every consume wait for the next chunk's loads too.
+    // The loop is unrolled by two: copying registers that have loads in flight would wait for them.
+    struct Gather {
+        uint4 va[LA], vb[LB];
+    };
+    int2 *ring = pair_lds[wid];
+    int tail = 0;                    // pairs appended so far (wave-uniform)
+    int nbase = r_begin;             // first row of the next window to append
+    auto load_idx = [&](int base) -> int { return base + lane < r_end ? nk[min(base + lane, n_out - 1)] : -1; };
+    int jp0 = load_idx(nbase), jp1 = load_idx(nbase + 64);
+    if (lane == 0) ring[0] = make_int2(0, 0);   // clamped gathers of an empty ring read row 0
+    auto top_up = [&](int need) {    // append windows until `need` pairs exist or the rows are exhausted
+        while (tail < need && nbase < r_end) {
+            const int j_l = jp0;
+            jp0 = jp1;
+            jp1 = load_idx(nbase + 128);
+            const unsigned long long mask = __ballot(j_l >= 0);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (j_l >= 0) ring[(tail + rank) & (RING - 1)] = make_int2(nbase + lane, j_l);
+            tail += __popcll(mask);
+            nbase += 64;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto gather = [&](int start, int cnt, Gather &gt) {   // 16 bytes per lane; rows past cnt re-read the chunk's last pair
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < LA; ++u) {
+            const int c = lane + 64 * u, pr = c / LPR_A, part = c % LPR_A;
+            const int2 pp = ring[(start + min(pr, last)) & (RING - 1)];
+            gt.va[u] = *reinterpret_cast<const uint4 *>(in + (int64_t)pp.y * CIN + part * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int c = lane + 64 * u, pr = c / LPR_B, part = c % LPR_B;
+            const int2 pp = ring[(start + min(pr, last)) & (RING - 1)];
+            gt.vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + co_base + part * 8);
+        }
+    };
+    auto consume = [&](Gather &gt, int cnt) {   // rows past the pair count are zeroed; LDS tile; transpose reads; MFMAs
+#pragma unroll
+        for (int u = 0; u < LA; ++u) {
+            const int c = lane + 64 * u;
+            const uint4 v = c / LPR_A < cnt ? gt.va[u] : uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4 *>(ta + c * 16) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int c = lane + 64 * u;
+            const uint4 v = c / LPR_B < cnt ? gt.vb[u] : uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4 *>(tb + c * 16) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bf16x8 b[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) b[n] = wg_tr_read<16 * RS_B>(tb_addr + tr_off_b + n * 32);
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            const bf16x8 a = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
+        }
+    };
+    // chunk (start, cnt) is in flight in `cur`; stage the next chunk into `nxt`, then consume `cur`
+    int start = 0, cnt = 0;
+    auto step = [&](Gather &cur, Gather &nxt) {
+        const int nstart = start + cnt;
+        top_up(nstart + 32);
+        const int ncnt = min(32, tail - nstart);
+        gather(ncnt > 0 ? nstart : max(tail - 1, 0), ncnt, nxt);   // nothing left: re-read the last valid pair (never consumed)
+        __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks the gather below the MFMAs of `cur`
+        consume(cur, cnt);
+        __builtin_amdgcn_sched_barrier(0);
+        start = nstart;
+        cnt = ncnt;
+    };
+    Gather g0, g1;
+    top_up(32);
+    cnt = min(32, tail);
+    gather(0, cnt, g0);   // tail == 0: ring[0] = (0, 0)
+    while (cnt > 0) {   // no exit between the two steps: an empty chunk (cnt = 0) is a zero tile, consumed once at most
+        step(g0, g1);
+        step(g1, g0);
     }
     // C/D layout: row (ci within tile) = 4*(lane>>4)+reg, col (co within tile) = lane&15
     float *dst = partial + ((int64_t)split * kvol + k) * CIN * COUT;
@@ -652,6 +714,11 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
     int64_t want_blocks_y = want_waves / ((int64_t)kvol * 4);
     if (want_blocks_y < 1) want_blocks_y = 1;
     int64_t max_split = ceil_div(n_out > 0 ? n_out : 1, 256);
+    if (p.tr && cin * cout <= 32 * 32) want_blocks_y *= 2;   // small register footprint: more resident workgroups
+    if (want_blocks_y * p.wrow > max_split) want_blocks_y = max_split / p.wrow > 0 ? max_split / p.wrow : 1;
+    // multiple of 8: XCD-local row blocks (wgrad_block); measured r01: 16->16 61 -> 40 us, 32->32 73 -> 50 us, neutral at
+    // 64 channels, and the 128-channel register-assembled kernel prefers its 18 blocks (125 vs 132 us)
+    if (p.tr && want_blocks_y >= 8) want_blocks_y &= ~(int64_t)7;
     int64_t splits = want_blocks_y * p.wrow;
     if (splits > max_split) splits = max_split;
     splits = ceil_div(splits, p.wrow) * p.wrow;

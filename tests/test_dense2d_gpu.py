@@ -42,6 +42,28 @@ def test_forward_and_dgrad(n, cin, cout, h, w, pad, w_nhwc):
     assert (dx.float() - xr.grad).abs().max() <= 6e-3 * xr.grad.abs().max()
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,pad,rows", [(4, 128, 128, 188, 188, 1, 128), (4, 256, 256, 94, 94, 1, 96),
+                                                     (1, 128, 128, 188, 188, 1, 64), (4, 128, 256, 95, 93, 0, None)])
+def test_bev_sized_launches_cover_every_tile_height(n, cin, cout, h, w, pad, rows):
+    """The k32 kernel picks 128-, 96- or 64-pixel tiles per launch (csrc/conv2d_nhwc.hip conv_k32_rows); the BASELINE
+    BEV shapes exercise all three.  Checks the output, the tile count the host allocates the statistics slabs for, and the
+    epilogue statistics (sum over tiles == column sums of the stored output)."""
+    from sparse2dense_amd import _lib, dense2d as D
+    x, wt, b = _mk(n, cin, cout, h, w, seed=11)
+    y, part = D.conv3x3_nhwc(x, D.pack_weights(wt), b, cin, cout, pad, bn_stats=True)
+    ref = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), b, padding=pad)
+    assert (y.float() - ref).abs().max() <= 6e-3 * ref.abs().max()
+    m = n * ref.shape[2] * ref.shape[3]
+    tiles = _lib.load().s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, 1)
+    assert part.shape == (tiles, 2, cout) and tiles in [-(-m // r) for r in (128, 96, 64)]
+    if rows is not None and torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert tiles == -(-m // rows)
+    yf = y.float()
+    s1, s2 = yf.sum((0, 2, 3)), (yf * yf).sum((0, 2, 3))
+    assert (part[:, 0].sum(0) - s1).abs().max() <= 1e-3 * s1.abs().max() + 1e-2
+    assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
+
+
 def test_unsupported_channels_raise():
     from sparse2dense_amd import _lib, dense2d as D
     w = torch.randn(3, 64, 3, 3, device="cuda")
