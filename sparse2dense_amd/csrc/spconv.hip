@@ -525,6 +525,17 @@ __device__ __forceinline__ bf16x8 wg_tr_read(unsigned lds_addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// issue only (no wait): the caller batches all fragment reads of a chunk and waits once
+template <int HI_OFF>
+__device__ __forceinline__ void wg_tr_issue(wg_i32x2 &lo, wg_i32x2 &hi, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(lds_addr), "n"(HI_OFF) : "memory");
+}
+__device__ __forceinline__ bf16x8 wg_tr_pack(const wg_i32x2 &lo, const wg_i32x2 &hi) {
+    wg_i32x4 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int CIN, int COUT>
 struct WgS16Cfg {
     static constexpr int NBMAX = CIN == 128 ? 2 : 4;
@@ -630,14 +641,18 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
             *reinterpret_cast<uint4 *>(tb + c * 16) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bf16x8 b[NB];
+        wg_i32x2 blo[NB], bhi[NB], alo[MA], ahi[MA];   // all fragment reads of the chunk, one wait
 #pragma unroll
-        for (int n = 0; n < NB; ++n) b[n] = wg_tr_read<16 * RS_B>(tb_addr + tr_off_b + n * 32);
+        for (int n = 0; n < NB; ++n) wg_tr_issue<16 * RS_B>(blo[n], bhi[n], tb_addr + tr_off_b + n * 32);
+#pragma unroll
+        for (int m = 0; m < MA; ++m) wg_tr_issue<16 * RS_A>(alo[m], ahi[m], ta_addr + tr_off_a + m * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MA; ++m) {
-            const bf16x8 a = wg_tr_read<16 * RS_A>(ta_addr + tr_off_a + m * 32);
+            const bf16x8 a = wg_tr_pack(alo[m], ahi[m]);
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wg_tr_pack(blo[n], bhi[n]), acc[m][n], 0, 0, 0);
         }
     };
     // chunk (start, cnt) is in flight in `cur`; stage the next chunk into `nxt`, then consume `cur`
@@ -671,9 +686,143 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_tr(const __bf16 *__restr
             for (int reg = 0; reg < 4; ++reg) dst[(int64_t)(16 * m + 4 * g + reg) * COUT + co_base + 16 * n + c16] = acc[m][n][reg];
 }
 
+// ---- 128 input channels, bf16 storage: workgroup-cooperative variant ------------------------------------------------
+// At 128 input channels a wave of the kernel above owns all 128 ci x 32 co, so the four waves of a workgroup each
+// gathered the same 256-byte input rows.  Here the workgroup gathers a chunk of 32 pairs ONCE (16 bytes per thread and
+// piece: A [32][128] and B [32][128] into double-buffered LDS tiles, one barrier per chunk) and every wave takes its
+// 32-column slice of B with transpose reads.  The pair ring / chunk pipeline is the one of spconv_wgrad_s16_tr; all four
+// waves run the (identical) index bookkeeping redundantly, so the ring needs no synchronisation of its own.
+template <int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_s16_coop128(const __bf16 *__restrict__ in, const __bf16 *__restrict__ dout,
+                                                                const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                                int rows_per_split, float *__restrict__ partial) {
+    constexpr int CIN = 128, MA = CIN / 16, NB = COUT / 64;   // a wave: 128 ci x COUT/4 co
+    constexpr int RS_A = CIN * 2 + 32, RS_B = COUT * 2 + 32;   // padded pixel-major rows (conflict-free transpose reads)
+    constexpr int TILE_A = 32 * RS_A, TILE_B = 32 * RS_B;
+    constexpr int PA = 32 * (CIN / 8) / 256, PB = 32 * (COUT / 8) / 256;   // 16-byte pieces per thread
+    static_assert(PA >= 1 && PB >= 1 && NB >= 1, "tile shape");
+    constexpr int RING = 256;
+    __shared__ int2 ring[RING];
+    __shared__ __attribute__((aligned(16))) char tiles[2][TILE_A + TILE_B];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = lane >> 4, c16 = lane & 15;
+    int k, by;
+    wgrad_block(kvol, k, by);
+    const int r_begin = by * rows_per_split;
+    const int r_end = min(n_out, r_begin + rows_per_split);
+    const int32_t *nk = nbr + (int64_t)k * n_out;
+    const unsigned tiles_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)&tiles[0][0]);
+    const int tr_off_a = (4 * g + (c16 >> 2)) * RS_A + (c16 & 3) * 8;
+    const int tr_off_b = TILE_A + (4 * g + (c16 >> 2)) * RS_B + (c16 & 3) * 8 + wid * (COUT / 4) * 2;
+
+    f32x4 acc[MA][NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Gather {
+        uint4 va[PA], vb[PB];
+    };
+    int tail = 0, nbase = r_begin;
+    auto load_idx = [&](int base) -> int { return base + lane < r_end ? nk[min(base + lane, n_out - 1)] : -1; };
+    int jp0 = load_idx(nbase), jp1 = load_idx(nbase + 64);
+    if (lane == 0) ring[0] = make_int2(0, 0);
+    auto top_up = [&](int need) {   // every wave appends the same pairs to the same slots
+        while (tail < need && nbase < r_end) {
+            const int j_l = jp0;
+            jp0 = jp1;
+            jp1 = load_idx(nbase + 128);
+            const unsigned long long mask = __ballot(j_l >= 0);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (j_l >= 0) ring[(tail + rank) & (RING - 1)] = make_int2(nbase + lane, j_l);
+            tail += __popcll(mask);
+            nbase += 64;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto gather = [&](int start, int cnt, Gather &gt) {
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            const int c = t + 256 * u, pr = c / (CIN / 8), part = c % (CIN / 8);
+            const int2 pp = ring[(start + min(pr, last)) & (RING - 1)];
+            gt.va[u] = *reinterpret_cast<const uint4 *>(in + (int64_t)pp.y * CIN + part * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int c = t + 256 * u, pr = c / (COUT / 8), part = c % (COUT / 8);
+            const int2 pp = ring[(start + min(pr, last)) & (RING - 1)];
+            gt.vb[u] = *reinterpret_cast<const uint4 *>(dout + (int64_t)pp.x * COUT + part * 8);
+        }
+    };
+    int parity = 0;
+    auto consume = [&](Gather &gt, int cnt) {
+        char *tl = tiles[parity];
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            const int c = t + 256 * u, pr = c / (CIN / 8), part = c % (CIN / 8);
+            const uint4 v = pr < cnt ? gt.va[u] : uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4 *>(tl + pr * RS_A + part * 16) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int c = t + 256 * u, pr = c / (COUT / 8), part = c % (COUT / 8);
+            const uint4 v = pr < cnt ? gt.vb[u] : uint4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4 *>(tl + TILE_A + pr * RS_B + part * 16) = v;
+        }
+        __syncthreads();   // tile complete; also: every wave is done reading the other tile (it is overwritten next)
+        const unsigned base = tiles_addr + parity * (TILE_A + TILE_B);
+        wg_i32x2 blo[NB], bhi[NB], alo[MA], ahi[MA];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) wg_tr_issue<16 * RS_B>(blo[n], bhi[n], base + tr_off_b + n * 32);
+#pragma unroll
+        for (int m = 0; m < MA; ++m) wg_tr_issue<16 * RS_A>(alo[m], ahi[m], base + tr_off_a + m * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            const bf16x8 a = wg_tr_pack(alo[m], ahi[m]);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wg_tr_pack(blo[n], bhi[n]), acc[m][n], 0, 0, 0);
+        }
+        parity ^= 1;
+    };
+    int start = 0, cnt = 0;
+    auto step = [&](Gather &cur, Gather &nxt) {
+        const int nstart = start + cnt;
+        top_up(nstart + 32);
+        const int ncnt = min(32, tail - nstart);
+        gather(ncnt > 0 ? nstart : max(tail - 1, 0), ncnt, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(cur, cnt);
+        __builtin_amdgcn_sched_barrier(0);
+        start = nstart;
+        cnt = ncnt;
+    };
+    Gather g0, g1;
+    top_up(32);
+    cnt = min(32, tail);
+    gather(0, cnt, g0);
+    while (cnt > 0) {   // wave-uniform AND identical in the four waves (same indices): the barriers inside match
+        step(g0, g1);
+        step(g1, g0);
+    }
+    float *dst = partial + ((int64_t)by * kvol + k) * CIN * COUT;
+    const int co_base = wid * (COUT / 4);
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dst[(int64_t)(16 * m + 4 * g + reg) * COUT + co_base + 16 * n + c16] = acc[m][n][reg];
+}
+
 struct WgradPlan {
     int mode;           // storage / MFMA variant, see wgrad_plan
     bool tr;            // bf16-storage transpose-read kernel (its wave layout differs)
+    bool coop;          // bf16 storage, 128 input channels: workgroup-cooperative gather (one row split per workgroup)
     int n_split;        // total row splits
     int rows_per_split; // multiple of 4
     int grid_y;
@@ -698,6 +847,8 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
     // measured (r01, bench scene): the transpose-read kernel wins for cin <= 64 (16->16 144 -> 97 us ... 64->128 81 -> 58 us,
     // launch + reduce included) and loses at cin = 128 (120 -> 131 us: four waves each re-gather the 256-byte rows)
     p.tr = mode == 2 && p.mfma && (tr_pref == 1 || (tr_pref == 2 && cin <= 64));
+    static const int coop_env = [] { const char *e = getenv("S2D_WGRAD_COOP"); return e ? atoi(e) : 1; }();
+    p.coop = mode == 2 && !p.tr && coop_env && cin == 128 && (cout == 128 || cout == 64);
     int vb = cout >= 32 ? 2 : 1;
     int wco = p.mfma ? cout / (16 * vb) : 1;
     if (p.tr) {
@@ -706,6 +857,7 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
         wco = cout / (16 * nb);
     }
     p.wrow = p.mfma ? 4 / wco : 1;
+    if (p.coop) p.wrow = 1;
     // aim at ~2048 waves in flight, at least 256 rows per split
     static const int waves_env = [] { const char *e = getenv("S2D_WGRAD_WAVES"); return e ? atoi(e) : 0; }();
     const int want_waves = waves_env > 0 ? waves_env : 2048;
@@ -731,6 +883,13 @@ static WgradPlan wgrad_plan(int mode, int64_t n_out, int kvol, int cin, int cout
 template <int CIN, int COUT>
 static void launch_wgrad(const float *in, const float *dout, const int32_t *nbr, int n_out, int kvol, const WgradPlan &p,
                          float *partial, hipStream_t st) {
+    if (p.mode == 2 && p.coop) {
+        if constexpr (CIN == 128 && (COUT == 128 || COUT == 64)) {
+            hipLaunchKernelGGL((spconv_wgrad_s16_coop128<COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
+                               (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
+            return;
+        }
+    }
     if (p.mode == 2 && p.tr) {   // bf16 storage: 16-byte gathers + per-wave LDS tile + transpose reads
         hipLaunchKernelGGL((spconv_wgrad_s16_tr<CIN, COUT>), dim3(kvol, p.grid_y), dim3(256), 0, st, (const __bf16 *)in,
                            (const __bf16 *)dout, nbr, n_out, kvol, p.rows_per_split, partial);
