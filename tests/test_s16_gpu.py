@@ -83,6 +83,27 @@ def test_s16_wgrad(cin, cout):
     assert (dw.double() - ref).abs().max() <= 2e-3 * ref.abs().max()
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 64), (128, 128)])
+@pytest.mark.parametrize("n_out,p_empty", [(1, 0.0), (63, 0.5), (4097, 0.0), (4097, 0.97), (20000, 1.0), (20000, 0.6)])
+def test_s16_wgrad_pair_ring_edges(cin, cout, n_out, p_empty):
+    """The weight-gradient kernels cut chunks of 32 (output row, neighbour) pairs from a ring that is filled 64 rows at a
+    time: dense maps (64 pairs per window), nearly empty and empty maps, a single row, row counts off the window size."""
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(11)
+    n_in, kvol = 1500, 27
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(n_out, cout, device=DEV).to(torch.bfloat16)
+    nbr = _random_map(kvol, n_in, n_out, p_empty=p_empty, seed=5)
+    dw = H.spconv_s16_wgrad(feat, dout, nbr, kvol)
+    ref = torch.zeros(kvol, cin, cout, device=DEV, dtype=torch.float64)
+    for k in range(kvol):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        if o.numel():
+            ref[k] = feat[nbr[k][o].long()].double().t() @ dout[o].double()
+    assert torch.isfinite(dw).all()
+    assert (dw.double() - ref).abs().max() <= 2e-3 * max(ref.abs().max().item(), 1e-6)
+
+
 @pytest.mark.parametrize("relu,with_res", [(True, True), (False, True), (True, False)])
 @pytest.mark.parametrize("n,c", [(5000, 16), (777, 128), (33, 32)])
 def test_feature_bn_bf16_rows_with_residual(n, c, relu, with_res):
