@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
                                                                     const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
                                                                     int cin, int cout, int pad, int stride, __bf16 *__restrict__ y,
                                                                     float *__restrict__ stats_partial) {
-    constexpr int NS = 3;
     constexpr int NT = BN / 32;
     constexpr int BM = 32 * MI;                // output pixels per workgroup (2 x 2 waves, MI 16-row tiles per wave)
     constexpr int A_BYTES = BM * 32 * 2;       // 8 KiB at MI = 4

@@ -82,7 +82,6 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     typedef WgCfg<TCO, TCI> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto abuf = [&](int b) -> char * { return smem + b * (C::A_BYTES + C::B_BYTES); };
-    auto bbuf = [&](int b) -> char * { return smem + b * (C::A_BYTES + C::B_BYTES) + C::A_BYTES; };
     const unsigned smem_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
 
     const int t = threadIdx.x, lane = t & 63;
