@@ -416,7 +416,7 @@ def main():
                                     "pillar": "CenterPoint-Pillar single stage (PFN path)",
                                     "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)"}[args.workload],
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "hip_graph_dense_section": bool(getattr(args, "graph", False)),
+                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"), "hip_graph_dense_section": bool(getattr(args, "graph", False)),
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),
                        "loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": base,

@@ -57,11 +57,48 @@ def convert_syncbn(module: nn.Module):
     return out
 
 
+def dp_mode():
+    """"flat" (default): no wrapper; the gradients are flattened into one buffer after the backward and all-reduced in one
+    call (allreduce_grads).  "ddp": torch DistributedDataParallel (bucketed all-reduce overlapped with the backward).
+    Measured on MI355X (r01, 1 rank, SyncBN route on): 15.4 ms/step flat against 17.1 ms/step DDP - with ~300 parameters
+    and a step whose N>1 route is host-bound, DDP's per-parameter hooks and bucket bookkeeping cost 1.6 ms, more than
+    overlapping a 36 MB all-reduce (~0.2-0.3 ms over xGMI) can buy.  S2D_DP_MODE selects."""
+    return os.environ.get("S2D_DP_MODE", "flat")
+
+
+def flat_enabled(model=None):
+    return dist.is_initialized() and dp_mode() == "flat" and (model is None or getattr(model, "_s2d_flat_allreduce", False))
+
+
+def allreduce_grads(params):
+    """Average the gradients over the ranks: one flatten, one all-reduce, one scatter back (every rank must hold a
+    gradient for the same parameters - true for this path: DDP runs it with find_unused_parameters=False)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not dist.is_initialized():
+        return
+    world = dist.get_world_size()
+    by_dtype = {}
+    for g in grads:
+        by_dtype.setdefault(g.dtype, []).append(g)
+    for gs in by_dtype.values():
+        flat = torch._utils._flatten_dense_tensors(gs)
+        dist.all_reduce(flat)
+        if world > 1:
+            flat.div_(world)
+        torch._foreach_copy_(gs, list(torch._utils._unflatten_dense_tensors(flat, gs)))
+
+
 def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=40, find_unused_parameters=False):
     force = os.environ.get("S2D_FORCE_DDP", "0") == "1"
     if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return model
     model = convert_syncbn(model)
+    if dp_mode() == "flat":
+        with torch.no_grad():   # what the DDP constructor does: every rank starts from rank 0's parameters and buffers
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t, 0)
+        model._s2d_flat_allreduce = True
+        return model
     bucket_cap_mb = float(os.environ.get("S2D_DDP_BUCKET_MB", bucket_cap_mb))
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters,
                   gradient_as_bucket_view=True, static_graph=os.environ.get("S2D_DDP_STATIC_GRAPH", "0") == "1")

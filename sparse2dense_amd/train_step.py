@@ -56,4 +56,7 @@ def backward_and_clip(loss, params, max_norm=35.0):
     for p in params:
         p.grad = None
     loss.backward()
+    from . import dp
+    if dp.flat_enabled():   # S2D_DP_MODE=flat: gradients averaged here instead of in DDP's backward hooks
+        dp.allreduce_grads(params)
     return torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm)

@@ -38,9 +38,9 @@ def _weights(shape):
     return torch.randn(shape, dtype=torch.float64, generator=torch.Generator().manual_seed(9))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="ddp"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), S2D_DP_MODE=mode)
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)
     from sparse2dense_amd import dp
@@ -52,11 +52,14 @@ def _worker(rank, world, port, out_dir):
     conv = dp.convert_syncbn(probe)
     assert isinstance(conv[1], torch.nn.SyncBatchNorm) and type(conv[2]) is FeatureBatchNorm1d
     ddp = dp.wrap_ddp(net)
-    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) == (mode == "ddp")
     feats, c = _voxels(rank)
     coors = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
     bev, _ = ddp(feats, coors, 1, np.array([1504, 1504, 40]))
     (bev * _weights((2,) + bev.shape[1:])[rank:rank + 1]).sum().backward()
+    if mode == "flat":
+        assert dp.flat_enabled(ddp)
+        dp.allreduce_grads(list(net.parameters()))
     torch.save({"grads": {n: p.grad.clone() for n, p in net.named_parameters()},
                 "buffers": {k: v.clone() for k, v in net.state_dict().items() if "running" in k}},
                os.path.join(out_dir, f"rank{rank}.pt"))
@@ -64,10 +67,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_equals_single_process_batch(monkeypatch):
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("mode", ["ddp", "flat"])
+def test_two_rank_dp_equals_single_process_batch(monkeypatch, mode):
+    port = 29500 + (os.getpid() % 2000) + (7 if mode == "flat" else 0)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, d, mode), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "rank0.pt"))
         r1 = torch.load(os.path.join(d, "rank1.pt"))
     # single process, both frames in one batch
