@@ -44,6 +44,7 @@ typedef void *s2d_stream_t;
 #define S2D_ERR_UNSUPPORTED (-2)
 #define S2D_ERR_CAPACITY (-3)
 #define S2D_ERR_WORKSPACE (-4)
+#define S2D_ERR_COMM (-5)
 
 /* ---- library ------------------------------------------------------------------------------ */
 int s2d_version(void);
@@ -346,6 +347,21 @@ size_t s2d_conv2d3x3_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int
 int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img,
                                   int h, int w, int cin, int cout, int pad, float *dweight, void *ws,
                                   size_t ws_bytes, s2d_stream_t stream);
+
+/*
+ * SyncBN statistics all-reduce on the compute stream (det3d/torchie/apis/train.py:281-300: apex SyncBatchNorm + DDP when
+ * training distributed).  The RCCL already loaded in the process is resolved at run time; s2d_comm_available() == 0 means
+ * the host keeps using its own collective.  Bootstrap: rank 0 calls s2d_comm_unique_id (128 bytes), the host broadcasts
+ * them, every rank calls s2d_comm_init (collective).  s2d_comm_allreduce_sum_f32: in-place sum of `count` floats over the
+ * ranks, enqueued on `stream` (between a batch-norm reduction kernel and its finalize kernel).
+ */
+int s2d_comm_load_library(const char *path); /* optional: the RCCL shared object the host framework has loaded */
+int s2d_comm_available(void);
+int s2d_comm_unique_id(void *id128);
+int s2d_comm_init(const void *id128, int nranks, int rank);
+int s2d_comm_ranks(void);
+int s2d_comm_shutdown(void);
+int s2d_comm_allreduce_sum_f32(float *buf, int64_t count, s2d_stream_t stream);
 
 #ifdef __cplusplus
 }

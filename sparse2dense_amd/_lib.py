@@ -67,6 +67,13 @@ SIGNATURES = {
                                               c_f32p, ctypes.c_void_p]),
     "s2d_pointwise_conv_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int64, c_f32p, ctypes.c_void_p]),
+    "s2d_comm_load_library": (ctypes.c_int, [ctypes.c_char_p]),
+    "s2d_comm_available": (ctypes.c_int, []),
+    "s2d_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "s2d_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "s2d_comm_ranks": (ctypes.c_int, []),
+    "s2d_comm_shutdown": (ctypes.c_int, []),
+    "s2d_comm_allreduce_sum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "s2d_conv2d3x3_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_conv2d3x3_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 7),
     "s2d_conv2d3x3_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

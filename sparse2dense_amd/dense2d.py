@@ -12,6 +12,8 @@ Everything else (fp32 runs, CPU goldens, the 2-channel output convs) is the stoc
 import ctypes
 
 import torch
+
+from . import collective as _collective
 from torch import nn
 
 from . import _lib
@@ -307,7 +309,7 @@ class _BNRowFn(torch.autograd.Function):
                 else:
                     check(lib.s2d_bnrow_stats_bf16(x.data_ptr(), rows, c, packed.data_ptr(), 1, ws.data_ptr(), ws.numel(), stream),
                           "s2d_bnrow_stats_bf16")
-                dist.all_reduce(packed)
+                _collective.allreduce_sum_(packed)
                 count = packed   # kept alive for the backward: the count is its last element
                 pp = packed.data_ptr()
                 check(lib.s2d_bn1d_finalize_fwd_f32(pp, pp + 8 * c, gamma.data_ptr(), beta.data_ptr(), float(eps), mom, c, fp,
@@ -356,7 +358,7 @@ class _BNRowFn(torch.autograd.Function):
                   "s2d_bnrow_bwd_reduce_bf16")
             if ctx.training:
                 import torch.distributed as dist
-                dist.all_reduce(sums[1])
+                _collective.allreduce_sum_(sums[1])
                 check(lib.s2d_bn1d_finalize_bwd_f32(sp, sp + 8 * c, count.data_ptr() + 8 * c, gamma.data_ptr(), fp, fp + rb, c, op,
                                                     op + rb, op + 2 * rb, op + 3 * rb, op + 4 * rb, stream),
                       "s2d_bn1d_finalize_bwd_f32")

@@ -10,6 +10,8 @@ goldens, non-contiguous exotic cases) fall through to the stock torch layer.
 import ctypes
 
 import torch
+
+from . import collective as _collective
 import torch.nn.functional as F
 from torch import nn
 
@@ -164,7 +166,7 @@ class _BNChannelMajorFn(torch.autograd.Function):
             count = torch.full((1,), float(n * pos), device=dev)
             if sync:
                 packed = torch.cat([stats, count])
-                dist.all_reduce(packed)
+                _collective.allreduce_sum_(packed)
                 stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
             track = module.track_running_stats
             fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
@@ -198,7 +200,7 @@ class _BNChannelMajorFn(torch.autograd.Function):
             sums_all = sums
             if ctx.sync:
                 sums_all = sums.clone()
-                dist.all_reduce(sums_all)
+                _collective.allreduce_sum_(sums_all)
             fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
             dgamma, dbeta, a, b, d = fin[0], fin[1], fin[2], fin[3], fin[4]
         else:

@@ -82,7 +82,8 @@ def allreduce_grads(params):
         by_dtype.setdefault(g.dtype, []).append(g)
     for gs in by_dtype.values():
         flat = torch._utils._flatten_dense_tensors(gs)
-        dist.all_reduce(flat)
+        from . import collective
+        collective.allreduce_sum_(flat)   # direct RCCL route for fp32 on the GPU, torch.distributed otherwise
         if world > 1:
             flat.div_(world)
         torch._foreach_copy_(gs, list(torch._utils._unflatten_dense_tensors(flat, gs)))
@@ -93,6 +94,13 @@ def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=40, find_unused_pa
     if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return model
     model = convert_syncbn(model)
+    if next(model.parameters()).is_cuda and dp_mode() == "flat":
+        # SyncBN vectors (and the flat gradient buffer): RCCL on the compute stream (collective.py).  Only with the flat
+        # gradient all-reduce: every collective of a step is then issued in program order on one stream; DDP's bucket
+        # all-reduces run concurrently on c10d's own communicator, and two communicators used concurrently in an order
+        # that may differ between ranks can deadlock.
+        from . import collective
+        collective.init_direct(torch.cuda.current_device() if local_rank is None else local_rank)
     if dp_mode() == "flat":
         with torch.no_grad():   # what the DDP constructor does: every rank starts from rank 0's parameters and buffers
             for t in list(model.parameters()) + list(model.buffers()):

@@ -18,6 +18,8 @@ from collections import OrderedDict
 
 import numpy as np
 import torch
+
+from . import collective as _collective
 import torch.distributed as dist
 from torch import nn
 
@@ -260,7 +262,7 @@ class _BNTrainFn(torch.autograd.Function):
             stats = H.bn1d_stats(x)
             count = torch.full((1,), float(n), device=x.device, dtype=x.dtype)
             packed = torch.cat([stats, count])
-            dist.all_reduce(packed)
+            _collective.allreduce_sum_(packed)
             stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
             fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, mom, rm, rv, nbt)
         else:
@@ -279,7 +281,7 @@ class _BNTrainFn(torch.autograd.Function):
             # parameter grads use the LOCAL sums (DDP averages them over ranks afterwards, exactly
             # like torch.nn.SyncBatchNorm); the input grad needs the GLOBAL sums.
             sums_all = sums.clone()
-            dist.all_reduce(sums_all)
+            _collective.allreduce_sum_(sums_all)
             fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
         else:
             g, fin = H.bn1d_bwd_reduce_finalize(dy, y, x, ctx.relu, gamma, mean, invstd)

@@ -186,16 +186,23 @@ def test_densify_bev_nhwc_bf16_matches_dense_view():
     assert torch.equal(fa.grad, fb.grad)
 
 
-def test_bn_rows_sync_path_equals_local_path_on_one_rank(monkeypatch):
+@pytest.mark.parametrize("route", ["torch", "direct"])
+def test_bn_rows_sync_path_equals_local_path_on_one_rank(monkeypatch, route):
     """The SyncBN route (split statistics kernels -> all-reduce of [sum, sumsq, count] -> finalize; backward likewise)
-    must reproduce the fused single-GPU route when the world has one rank (RCCL all-reduce of one contribution)."""
+    must reproduce the fused single-GPU route when the world has one rank (RCCL all-reduce of one contribution), both
+    through torch.distributed and through the communicator of csrc/comm.hip on the compute stream."""
     import torch.distributed as dist
-    from sparse2dense_amd import dense2d as D
+    from sparse2dense_amd import _lib, collective, dense2d as D
     from sparse2dense_amd.spconv import FeatureBatchNorm1d
     if dist.is_initialized():
         pytest.skip("a process group is already up")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29577 + (route == 'direct')}", rank=0, world_size=1)
     try:
+        if route == "direct":
+            assert collective.init_direct(torch.cuda.current_device()) and collective.direct_enabled()
+            t = torch.arange(5, dtype=torch.float32, device="cuda")
+            collective.allreduce_sum_(t)
+            assert t.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0] and _lib.load().s2d_comm_ranks() == 1
         torch.manual_seed(4)
         for make, shape in [(lambda: D.FastBatchNorm2d(64, eps=1e-3, momentum=0.01, fused_relu=True), (2, 64, 30, 26)),
                             (lambda: FeatureBatchNorm1d(32, eps=1e-3, momentum=0.01), (3000, 32))]:
@@ -215,6 +222,8 @@ def test_bn_rows_sync_path_equals_local_path_on_one_rank(monkeypatch):
             for u, v in zip(*outs):
                 assert torch.allclose(u.float(), v.float(), rtol=1e-5, atol=1e-6), (u.float() - v.float()).abs().max()
     finally:
+        collective._DIRECT = False
+        _lib.load().s2d_comm_shutdown()
         dist.destroy_process_group()
 
 
