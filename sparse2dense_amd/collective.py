@@ -31,7 +31,7 @@ def allreduce_sum_(t: torch.Tensor):
     return t
 
 
-def init_direct(device_index, timeout_s=60.0):
+def init_direct(device_index, timeout_s=120.0):
     """Collective over the default process group (call it on every rank, after torch.cuda.set_device).  Returns True when
     the direct route is on.  Every step that can block runs in a helper thread under a time limit, and the outcome is
     agreed on with a torch.distributed all-reduce, so the ranks never end up on different routes."""
