@@ -36,6 +36,8 @@ def init_direct(device_index, timeout_s=120.0):
     the direct route is on.  Every step that can block runs in a helper thread under a time limit, and the outcome is
     agreed on with a torch.distributed all-reduce, so the ranks never end up on different routes."""
     global _DIRECT
+    if _DIRECT and dist.is_initialized():   # a second model wrapped in the same process: the communicator is up already
+        return True
     _DIRECT = False
     if os.environ.get("S2D_RCCL_DIRECT", "1") == "0" or not dist.is_initialized() or dist.get_backend() != "nccl":
         return False
