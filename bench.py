@@ -155,7 +155,7 @@ def roofline_pass(step, n_steps=3):
             elif r.get("pad") == 1 and r.get("stride") == 1 and r["cin"] >= 128:
                 kname = "conv3x3_p1_nhwc_bf16_kernel<64>"
             else:
-                kname = "conv3x3_nhwc_bf16_kernel<64, 2>"
+                kname = "conv3x3_k32_nhwc_bf16_kernel<64, 4>"
         key = (kname, r["cin"], r["cout"], r["n_out"])
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, tile_rows=r.get("tile_rows", 128)))
         a["ms"] += ms

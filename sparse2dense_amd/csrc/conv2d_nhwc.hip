@@ -604,10 +604,11 @@ static bool conv_use_shared_a(int cin, int bn, int pad, int stride) {
     return pad == 1 && stride == 1 && (force ? force[0] == '1' : (bn == 64 && cin >= 128));
 }
 static bool conv_use_k32(int bn) {
-    // 128-wide column blocks take the 32-deep / 3-slot-ring kernel, 64-wide blocks the 64-deep double buffer;
-    // S2D_CONV_NS=2/3/4/32 forces a variant
+    // the 32-deep / 3-slot-ring kernel is the default for both column-block widths (64-wide blocks: 64->64@4x188^2 26 us
+    // against 30 us on the 64-deep double buffer since the cursor rewrite); S2D_CONV_NS=2/3/4 forces the 64-deep variants
     static const int ns_env = conv_env_int("S2D_CONV_NS");
-    return ns_env == 32 || (ns_env == 0 && bn == 128);
+    (void)bn;
+    return ns_env == 32 || ns_env == 0;
 }
 // Output pixels per workgroup of the k32 kernel (128, 96 or 64).  The BEV launches are small against the chip (a
 // 256->256 conv on 4 x 94 x 94 pixels is 552 tiles of 128 x 128 for 768 resident workgroups).  Fitted to the measured
