@@ -52,6 +52,26 @@ def test_workspace_queries(lib):
     assert lib.s2d_bn1d_workspace_bytes(1000, 5) == 0   # unsupported channel count
 
 
+def test_launch_plans_of_the_dense_conv_kernels(lib):
+    """Host-side launch plans (no device work): the pixel-tile height of the 3x3 conv is picked per launch and sizes the
+    BN-statistics slabs; the weight-gradient kernel never launches more workgroups than CUs (256 assumed without a GPU)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("plan constants below are for 256 CUs")
+    tiles = lib.s2d_conv2d3x3_stats_tiles
+    m = 4 * 188 * 188
+    assert tiles(4, 188, 188, 128, 128, 1, 1) == -(-m // 128)          # 1.44 rounds of resident workgroups: tall tiles
+    assert tiles(4, 94, 94, 256, 256, 1, 1) == -(-(m // 4) // 96)       # below one round: 96-row tiles
+    assert tiles(1, 188, 188, 128, 128, 1, 1) == -(-(m // 4) // 64)     # a quarter of a round: 64-row tiles
+    assert tiles(4, 188, 188, 512, 64, 1, 1) == -(-m // 128)            # 64-wide column blocks: tap-shared kernel, 128 rows
+    assert tiles(4, 190, 190, 128, 256, 0, 2) == -(-(4 * 94 * 94) // 96)
+    assert tiles(4, 188, 188, 100, 128, 1, 1) == 0                       # unsupported channel count
+    for shape, tiles_ in (((4, 188, 188, 128, 128, 1), 1), ((4, 94, 94, 256, 256, 1), 4), ((4, 188, 188, 512, 64, 1), 4)):
+        splits = lib.s2d_conv2d3x3_wgrad_workspace_bytes(*shape) // (9 * shape[3] * shape[4] * 4)
+        assert 0.9 * (256 // (3 * tiles_)) <= splits <= 256 // (3 * tiles_), (shape, splits)   # 3 kernel rows x tiles x splits <= 256
+    assert lib.s2d_comm_ranks() == 0                                       # no communicator without a process group
+
+
 def test_ops_fail_loudly_on_cpu_tensors():
     import torch
     from sparse2dense_amd import hip_ops
