@@ -56,11 +56,7 @@ def parse():
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
     p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16", "s16"],
                    help="override for the sparse stack: bf16 = fp32 storage / bf16 MFMA inputs, s16 = bf16 storage (default with --dtype bf16)")
-    p.add_argument("--prefetch", action="store_true",
-                   help="voxelize + plan the NEXT batch on a side stream during backward (measured neutral: the step is GPU-bound)")
     p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
-    p.add_argument("--graph", action="store_true", help="replay the static-shape neck+head section (fwd+bwd) as HIP graphs; "
-                   "single-GPU CenterPoint bf16 only.  Off by default: the step is GPU-bound, measured 216.9 (graph) vs 223.3 frames/s")
     return p.parse_args()
 
 
@@ -90,10 +86,6 @@ def build_models(args, dev):
                 m.dense_dtype = torch.bfloat16
             if not args.nchw and args.dense_dtype == "bf16":   # fp32 MIOpen Winograd prefers NCHW (measured)
                 m.use_channels_last()
-    args.graph = bool(args.graph and args.workload == "centerpoint" and args.dense_dtype == "bf16" and not args.nchw
-                      and int(os.environ.get("WORLD_SIZE", "1")) == 1)
-    if args.graph:
-        model.use_dense_graph()
     return model.to(dev).train(), teacher
 
 
@@ -102,7 +94,7 @@ def make_step(args, model, teacher, frames, optimizer):
     params = [p for p in model.parameters() if p.requires_grad]
 
     def step():
-        ex = frames.get()                           # device voxelization (+ geometry) of the resident points
+        ex = frames.example()                       # device voxelization of the resident points
         if teacher is not None:
             loss, _ = distill_loss(teacher, model, ex)
         elif args.workload == "pillar_s2d":
@@ -113,7 +105,6 @@ def make_step(args, model, teacher, frames, optimizer):
         backward_and_clip(loss, params, 35.0)
         if optimizer is not None:
             optimizer.step()
-        frames.start_next()                         # next batch's voxelizer + rulebooks on the side stream
         return loss
 
     return step
@@ -349,15 +340,7 @@ def main():
     if not args.no_optim:
         optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
                                       weight_decay=0.01, fused=True)
-    if not args.prefetch:
-        class _Inline:   # voxelize + plan inline on the main stream
-            get = staticmethod(frames.example)
-            start_next = staticmethod(lambda: None)
-        source = _Inline
-    else:
-        from sparse2dense_amd.data import GeometryPrefetcher
-        source = GeometryPrefetcher(frames, [teacher, model])
-    step = make_step(args, model, teacher, source, optimizer)
+    step = make_step(args, model, teacher, frames, optimizer)
 
     for _ in range(args.warmup):
         step()
@@ -416,7 +399,7 @@ def main():
                                     "pillar": "CenterPoint-Pillar single stage (PFN path)",
                                     "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)"}[args.workload],
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"), "hip_graph_dense_section": bool(getattr(args, "graph", False)),
+                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"),
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),
                        "loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": base,

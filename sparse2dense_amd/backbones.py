@@ -98,13 +98,9 @@ def build_geometry(coors, batch_size, shape, strided_specs, subm_keys):
 
 
 def plan_geometry(x: SparseConvTensor, strided_specs, subm_keys):
-    """Attach the geometry plan to the tensor's indice_dict: reuse one pre-computed for exactly these
-    coordinates (data prefetcher, `tensor._s2d_plan`), else build it now — before the first feature
-    kernel, so that the four host reads of N_out happen while the device is otherwise idle."""
-    pre = getattr(x.indices, "_s2d_plan", None)
-    if pre is None:
-        pre = build_geometry(x.indices, x.batch_size, x.spatial_shape, strided_specs, subm_keys)
-    x.indice_dict.update(pre)
+    """Attach the geometry plan to the tensor's indice_dict — built before the first feature kernel, so that the
+    host reads of N_out happen while the device is otherwise idle."""
+    x.indice_dict.update(build_geometry(x.indices, x.batch_size, x.spatial_shape, strided_specs, subm_keys))
 
 
 class _PlannedBackbone(nn.Module):
@@ -121,14 +117,6 @@ class _PlannedBackbone(nn.Module):
         strided = [(c.plan_key, c.kernel_size, c.stride, c.padding) for c in convs]
         subm = [(f"{self.SUBM_PREFIX}{i}", (3, 3, 3)) for i in range(4)]
         return strided, subm
-
-    def precompute_geometry(self, coors, batch_size, input_shape):
-        """Geometry of a forward pass on `coors` (i32[N,4] cuda), attached to the tensor itself so
-        that a later `forward(…, coors, …)` picks it up.  Used by the side-stream prefetcher."""
-        sparse_shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
-        strided, subm = self._specs()
-        coors._s2d_plan = build_geometry(coors, batch_size, sparse_shape, strided, subm)
-        return coors._s2d_plan
 
 
 @BACKBONES.register_module

@@ -12,15 +12,26 @@ import torch
 import torch.distributed as dist
 
 _DIRECT = False
+_DIRECT_PG = None      # the process group the direct communicator was bootstrapped over
+_CANCEL = threading.Event()   # set when a bootstrap timed out: the helper thread then tears its communicator down
+
+
+def sync_on():
+    """One predicate for every self-synchronising batch norm of the path (FeatureBatchNorm1d, FastBatchNorm2d/3d): a
+    process group is up and there is more than one rank (S2D_FORCE_DDP=1 exercises the route with one rank;
+    S2D_DEBUG_NO_SYNCBN=1 is a measurement hook that splits gradient all-reduce cost from SyncBN cost)."""
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("S2D_DEBUG_NO_SYNCBN", "0") == "1":
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
 
 
 def direct_enabled():
-    return _DIRECT
+    return _DIRECT and dist.is_initialized() and _DIRECT_PG is dist.group.WORLD
 
 
 def allreduce_sum_(t: torch.Tensor):
     """In-place sum of `t` over the ranks, ordered on the current stream."""
-    if _DIRECT and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+    if direct_enabled() and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
         from . import _lib
         lib = _lib.load()
         rc = lib.s2d_comm_allreduce_sum_f32(t.data_ptr(), t.numel(), torch._C._cuda_getCurrentRawStream(t.device.index))
@@ -35,10 +46,11 @@ def init_direct(device_index, timeout_s=120.0):
     """Collective over the default process group (call it on every rank, after torch.cuda.set_device).  Returns True when
     the direct route is on.  Every step that can block runs in a helper thread under a time limit, and the outcome is
     agreed on with a torch.distributed all-reduce, so the ranks never end up on different routes."""
-    global _DIRECT
-    if _DIRECT and dist.is_initialized():   # a second model wrapped in the same process: the communicator is up already
+    global _DIRECT, _DIRECT_PG
+    if direct_enabled():   # a second model wrapped in the same process group: the communicator is up already
         return True
-    _DIRECT = False
+    _DIRECT, _DIRECT_PG = False, None   # (a destroyed and re-created process group starts over)
+    _CANCEL.clear()
     if os.environ.get("S2D_RCCL_DIRECT", "1") == "0" or not dist.is_initialized() or dist.get_backend() != "nccl":
         return False
     from . import _lib
@@ -63,6 +75,9 @@ def init_direct(device_index, timeout_s=120.0):
             if lib.s2d_comm_init(ident[0], world, rank) != 0:
                 result["why"] = "comm_init: " + _lib.last_error()
                 return
+            if _CANCEL.is_set():   # the caller gave up while ncclCommInitRank was blocked: no probe, no stray communicator
+                lib.s2d_comm_shutdown()
+                return
             probe = torch.ones(8, dtype=torch.float32, device=torch.device("cuda", device_index))
             if lib.s2d_comm_allreduce_sum_f32(probe.data_ptr(), probe.numel(), torch._C._cuda_getCurrentRawStream(device_index)) != 0:
                 result["why"] = "probe all-reduce: " + _lib.last_error()
@@ -79,6 +94,7 @@ def init_direct(device_index, timeout_s=120.0):
         th.start()
         th.join(timeout_s)
         if th.is_alive():
+            _CANCEL.set()
             result["why"] = f"bootstrap did not finish within {timeout_s:.0f} s"
         ok = (not th.is_alive()) and result["ok"]
     if not ok:
@@ -87,4 +103,7 @@ def init_direct(device_index, timeout_s=120.0):
     flag = torch.tensor([1.0 if ok else 0.0], device=torch.device("cuda", device_index))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     _DIRECT = bool(flag.item() > 0.5)
+    _DIRECT_PG = dist.group.WORLD if _DIRECT else None
+    if not _DIRECT and ok:   # this rank's communicator came up but another rank's did not: drop it, all ranks use c10d
+        lib.s2d_comm_shutdown()
     return _DIRECT

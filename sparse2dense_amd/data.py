@@ -62,24 +62,6 @@ class SyntheticFrames:
         return ex
 
 
-def _walk_tensors(obj, fn):
-    import dataclasses
-    if torch.is_tensor(obj):
-        fn(obj)
-        plan = getattr(obj, "_s2d_plan", None)
-        if plan is not None:
-            _walk_tensors(plan, fn)
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            _walk_tensors(v, fn)
-    elif isinstance(obj, (list, tuple)):
-        for v in obj:
-            _walk_tensors(v, fn)
-    elif dataclasses.is_dataclass(obj):
-        for f in dataclasses.fields(obj):
-            _walk_tensors(getattr(obj, f.name), fn)
-
-
 class SyntheticPillarFrames:
     """Scene C: the same sweeps voxelized as pillars (0.32 m, 20 points, 32 000 pillars,
     configs/waymo/pp/...:156-162) plus the object-only cloud for the PCR target; targets on the
@@ -106,59 +88,4 @@ class SyntheticPillarFrames:
         ex.update(voxelize_batch(self.gen, self.recon_points, prefix="reconstruction_"))
         ex["shape"] = np.stack([self.grid_size] * len(self.points))
         ex.update(self.targets)
-        return ex
-
-
-class GeometryPrefetcher:
-    """Device-side counterpart of the reference's DataLoader workers (`workers_per_gpu=4`, config :182,
-    which voxelize on the CPU while the GPU trains): the NEXT batch is voxelized and all of its
-    rulebooks are built on a side HIP stream while the current step's backward runs on the main
-    stream.  Every host read (voxel counts, N_out of the strided layers) therefore waits on the side
-    stream only and the main stream never drains."""
-
-    def __init__(self, frames: SyntheticFrames, models=()):
-        self.frames = frames
-        self.models = [m for m in models if m is not None]
-        self.stream = torch.cuda.Stream(device=frames.device)
-        self.pending = None
-
-    def _produce(self):
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            ex = self.frames.example()
-            shape = ex["shape"][0]
-            for prefix, model in self._passes(ex):
-                coors = ex[prefix + "coordinates"]
-                model.backbone.precompute_geometry(coors, len(ex[prefix + "num_voxels"]), shape)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        return ex, ev
-
-    def _passes(self, ex):
-        """(prefix, model) for every backbone forward the step will run (voxelnet.py:50-54,73-89)."""
-        out = []
-        for m in self.models:
-            kind = type(getattr(m, "module", m)).__name__
-            mm = getattr(m, "module", m)
-            if kind == "KD_VoxelNet":
-                out.append(("", mm))
-            else:
-                out.append(("dense_" if "dense_voxels" in ex else "", mm))
-                if "reconstruction_coordinates" in ex and len(self.models) > 1:
-                    out.append(("reconstruction_", mm))
-        return out
-
-    def start_next(self):
-        """call after the current step has been enqueued"""
-        if self.pending is None:
-            self.pending = self._produce()
-
-    def get(self):
-        if self.pending is None:
-            self.pending = self._produce()
-        ex, ev = self.pending
-        self.pending = None
-        main = torch.cuda.current_stream()
-        main.wait_event(ev)
-        _walk_tensors(ex, lambda t: t.record_stream(main) if t.is_cuda else None)
         return ex

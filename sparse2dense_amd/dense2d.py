@@ -242,14 +242,11 @@ class AbsorbedZeroPad2d(nn.ZeroPad2d):
 # BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
 # --------------------------------------------------------------------------------------------------
 _ws_cache = {}
-GRAPH_CAPTURE_POSSIBLE = False   # set by SingleStageDetector.use_dense_graph(): only then is stream capture checked per call
 
 
 def _ws(nbytes, device):
     """reduction workspace: one grow-only buffer per device and stream.  Every user writes it before reading it inside
     one entry point, and launches on a stream are ordered, so consecutive calls can share it."""
-    if GRAPH_CAPTURE_POSSIBLE and torch.cuda.is_current_stream_capturing():   # a private allocation from the graph's pool
-        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index, _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -258,12 +255,7 @@ def _ws(nbytes, device):
     return buf
 
 
-def _dist_sync():
-    import torch.distributed as dist
-    import os
-    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("S2D_DEBUG_NO_SYNCBN", "0") == "1":
-        return False   # (S2D_DEBUG_NO_SYNCBN: measurement hook, splits DDP overhead from SyncBN overhead)
-    return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
+_dist_sync = _collective.sync_on
 
 
 def _f32c(t):

@@ -225,10 +225,18 @@ class FastBatchNorm3d(nn.BatchNorm3d):
         self.fused_relu = fused_relu
 
     def forward(self, x):
-        if _hip_ok(x) and x.dim() >= 3 and x[0, 0].numel() % 4 == 0 and self.affine and x.shape[0] * x.shape[1] <= 65535:
-            import torch.distributed as dist
-            training = self.training or not self.track_running_stats
-            sync = training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        training = self.training or not self.track_running_stats
+        sync = training and _collective.sync_on()
+        if _hip_ok(x) and x.dim() >= 3 and x[0, 0].numel() % 4 == 0 and self.affine and x.shape[0] * x.shape[1] <= 65535 \
+                and self.momentum is not None:
             return _BNChannelMajorFn.apply(x, self.weight, self.bias, self.fused_relu, self.eps, sync, self, training)
-        y = super().forward(x)
+        if sync and x.is_cuda:   # inputs the channel-major kernels do not cover still synchronise (as FastBatchNorm2d does)
+            import torch.distributed as dist
+            from torch.nn.modules._functions import SyncBatchNorm as _SyncFn
+            if self.track_running_stats:
+                self.num_batches_tracked += 1
+            y = _SyncFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, self.momentum,
+                              dist.group.WORLD, dist.get_world_size())
+        else:
+            y = super().forward(x)
         return F.relu(y) if self.fused_relu else y

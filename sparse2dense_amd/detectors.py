@@ -22,28 +22,6 @@ from .registry import DETECTORS
 from .spconv import SparseConvTensor
 
 
-class _DenseSection(nn.Module):
-    """neck + head as one callable with tensor-only inputs/outputs, so that its forward AND backward can be captured
-    into HIP graphs (torch.cuda.make_graphed_callables): the BEV maps have static shapes, and at ~450 launches per step
-    this section is otherwise bound by host launch overhead, not by the GPU."""
-
-    def __init__(self, neck, head, dtype):
-        super().__init__()
-        self.neck, self.head, self.dtype = neck, head, dtype
-        self.keys = None
-
-    def forward(self, x):
-        with torch.autocast("cuda", dtype=self.dtype, cache_enabled=False):
-            preds = self.head(self.neck(x))
-        if self.keys is None:
-            self.keys = [sorted(p.keys()) for p in preds]
-        return tuple(p[k] for p, ks in zip(preds, self.keys) for k in ks)
-
-    def unflatten(self, outs):
-        it = iter(outs)
-        return [{k: next(it).float() for k in ks} for ks in self.keys]
-
-
 class SingleStageDetector(nn.Module):
     def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__()
@@ -55,8 +33,6 @@ class SingleStageDetector(nn.Module):
         self.test_cfg = test_cfg
         self.dense_dtype = torch.float32   # set to torch.bfloat16 to run neck + head under autocast
         self.dense_channels_last = False    # set by use_channels_last()
-        self.dense_graph = False            # set by use_dense_graph(): capture neck+head fwd/bwd into HIP graphs
-        self._graphed = {}                  # (shape, dtype) -> (graphed callable, _DenseSection); not part of the module tree
 
     @property
     def with_neck(self):
@@ -75,36 +51,6 @@ class SingleStageDetector(nn.Module):
                 mod.to(memory_format=torch.channels_last)
         self.dense_channels_last = True
         return self
-
-    def use_dense_graph(self, on=True):
-        """Training-time option: replay the neck + head forward/backward as HIP graphs (one capture per input shape).
-        Needs the bf16 NHWC dense mode and a single process (no SyncBN collectives inside the captured section)."""
-        self.dense_graph = bool(on)
-        if on:
-            from . import dense2d
-            dense2d.GRAPH_CAPTURE_POSSIBLE = True
-        return self
-
-    def _graph_ok(self, x):
-        import torch.distributed as dist
-        import os
-        return (self.dense_graph and self.training and torch.is_grad_enabled() and x.is_cuda and self.with_neck
-                and self.dense_dtype == torch.bfloat16 and self.dense_channels_last and x.dtype == torch.bfloat16
-                and not (dist.is_available() and dist.is_initialized()
-                         and (dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1")))
-
-    def _dense_section_graphed(self, x):
-        """neck + head through the captured graphs -> list of per-task prediction dicts (fp32)"""
-        key = (tuple(x.shape), x.dtype)
-        entry = self._graphed.get(key)
-        if entry is None:
-            section = _DenseSection(self.neck, self.bbox_head, self.dense_dtype)
-            sample = x.detach().clone().requires_grad_(True)
-            fn = torch.cuda.make_graphed_callables(section, (sample,), num_warmup_iters=3)
-            entry = (fn, section)
-            self._graphed[key] = entry
-        fn, section = entry
-        return section.unflatten(fn(x))
 
     def _dense(self, module, x, keep_first=False):
         """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs).  keep_first: the first
@@ -132,10 +78,6 @@ class SingleStageDetector(nn.Module):
 
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
-    def _graph_ok_for(self, data):
-        return (self.dense_graph and self.training and data["features"].is_cuda and self.with_neck
-                and self._graph_ok(torch.empty(0, dtype=torch.bfloat16, device=data["features"].device)))
-
     def extract_feat(self, data):
         # the BEV map goes straight to NHWC bf16 when nobody but the bf16 neck reads it
         bev = bool(data.get("bev_private", False) and self.dense_channels_last and self.dense_dtype == torch.bfloat16
@@ -150,12 +92,6 @@ class VoxelNet(SingleStageDetector):
         batch_size = len(example[prefix + "num_voxels"])
         data = dict(features=self._read(example, prefix), coors=example[prefix + "coordinates"], batch_size=batch_size,
                     input_shape=example["shape"][0], bev_private=not return_feature)
-        if return_loss and not return_feature and not return_recon_feature and self._graph_ok_for(data):
-            bev, _ = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"], bev_nhwc_bf16=True)
-            if not bev.requires_grad:
-                bev.requires_grad_(True)
-            preds = self._dense_section_graphed(bev)
-            return self.bbox_head.loss(example, preds)
         x, _, F_D_a = self.extract_feat(data)
         F_D_b = None
         if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)

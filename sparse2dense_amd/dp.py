@@ -1,13 +1,15 @@
 """Data parallelism: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on
 ROCm), frames sharded by rank, no data-path collective except
-  * the bucketed gradient all-reduce (DDP; overlaps the sparse-conv backward because head/neck
-    gradients are produced first), and
-  * SyncBN statistics (FeatureBatchNorm1d all-reduces its own [2C+1] vector; BatchNorm2d/3d layers
-    are converted to torch.nn.SyncBatchNorm).
+  * the bucketed gradient all-reduce (`GradBuckets`, default route "overlap": parameters are grouped
+    in reverse registration order - the order the backward produces their gradients, head and neck
+    first - and a bucket's all-reduce is launched asynchronously from the gradient hook of its last
+    parameter, so it flies while the sparse-conv backward still runs); and
+  * SyncBN statistics (FeatureBatchNorm1d / FastBatchNorm2d / FastBatchNorm3d all-reduce their own
+    [2C+1] vectors; other BatchNorm2d/3d layers are converted to torch.nn.SyncBatchNorm).
 Reference: tools/train.py:86-96 (init_process_group), det3d/torchie/apis/train.py:360-391
 (apex convert_syncbn_model + DistributedDataParallel).  The redundant second gradient all-reduce
-of the reference's DistOptimizerHook (apis/train.py:313-316) is intentionally dropped: DDP has
-already averaged the gradients, so the result is identical.
+of the reference's DistOptimizerHook (apis/train.py:313-316) is intentionally dropped: the
+gradients have already been averaged, so the result is identical.
 """
 import os
 
@@ -58,35 +60,108 @@ def convert_syncbn(module: nn.Module):
 
 
 def dp_mode():
-    """"flat" (default): no wrapper; the gradients are flattened into one buffer after the backward and all-reduced in one
-    call (allreduce_grads).  "ddp": torch DistributedDataParallel (bucketed all-reduce overlapped with the backward).
-    Measured on MI355X (r01, 1 rank, SyncBN route on): 15.4 ms/step flat against 17.1 ms/step DDP - with ~300 parameters
-    and a step whose N>1 route is host-bound, DDP's per-parameter hooks and bucket bookkeeping cost 1.6 ms, more than
-    overlapping a 36 MB all-reduce (~0.2-0.3 ms over xGMI) can buy.  S2D_DP_MODE selects."""
-    return os.environ.get("S2D_DP_MODE", "flat")
+    """S2D_DP_MODE selects the gradient route:
+      "overlap" (default)  GradBuckets, all-reduce of a bucket launched from the backward hooks (overlaps the backward);
+      "flat"               GradBuckets, every bucket launched after the backward (no overlap; A/B reference);
+      "ddp"                torch DistributedDataParallel."""
+    return os.environ.get("S2D_DP_MODE", "overlap")
 
 
-def flat_enabled(model=None):
-    return dist.is_initialized() and dp_mode() == "flat" and (model is None or getattr(model, "_s2d_flat_allreduce", False))
+_BUCKETERS = {}   # id(parameter) -> GradBuckets that owns it
 
 
-def allreduce_grads(params):
-    """Average the gradients over the ranks: one flatten, one all-reduce, one scatter back (every rank must hold a
-    gradient for the same parameters - true for this path: DDP runs it with find_unused_parameters=False)."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized():
-        return
-    world = dist.get_world_size()
-    by_dtype = {}
-    for g in grads:
-        by_dtype.setdefault(g.dtype, []).append(g)
-    for gs in by_dtype.values():
-        flat = torch._utils._flatten_dense_tensors(gs)
-        from . import collective
-        collective.allreduce_sum_(flat)   # direct RCCL route for fp32 on the GPU, torch.distributed otherwise
-        if world > 1:
-            flat.div_(world)
-        torch._foreach_copy_(gs, list(torch._utils._unflatten_dense_tensors(flat, gs)))
+class GradBuckets:
+    """Bucketed gradient averaging without DDP's bookkeeping.  The bucket layout is static (every parameter that
+    requires a gradient, whether or not this step produces one on this rank: a missing gradient is sent as zeros, so
+    ranks can never disagree on message sizes).  Per step: `prepare()` -> backward -> `finish()`; afterwards every
+    `p.grad` is a view into its bucket's flat buffer holding the average over the ranks."""
+
+    def __init__(self, params, bucket_bytes=None, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.overlap = overlap
+        cap = int(float(os.environ.get("S2D_BUCKET_MB", 16)) * (1 << 20)) if bucket_bytes is None else int(bucket_bytes)
+        self.buckets = []     # dicts: params, flat, views, pending, work
+        cur, cur_bytes, cur_key = [], 0, None
+        for p in reversed(self.params):   # reverse registration order = (approximately) gradient production order
+            key = (p.dtype, p.device)
+            nb = p.numel() * p.element_size()
+            if cur and (key != cur_key or cur_bytes + nb > cap):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p); cur_bytes += nb; cur_key = key
+        if cur:
+            self._close(cur)
+        self._handles = []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                _BUCKETERS[id(p)] = self
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self._armed = False
+
+    def _close(self, ps):
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        views, off = [], 0
+        for p in ps:
+            views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+        self.buckets.append(dict(params=ps, flat=flat, views=views, pending=len(ps), work=None, launched=False))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            if not self._armed:
+                return
+            b = self.buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0 and self.overlap:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        src, dst = [], []
+        for p, v in zip(b["params"], b["views"]):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad); dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        b["work"] = dist.all_reduce(b["flat"], async_op=True)   # c10d: ordered after the copies, runs on its own stream
+        b["launched"] = True
+
+    def prepare(self):
+        for b in self.buckets:
+            b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
+            for p in b["params"]:
+                p.grad = None
+        self._armed = True
+
+    def finish(self):
+        self._armed = False
+        world = dist.get_world_size()
+        for b in self.buckets:   # buckets whose hooks did not all fire (unused parameters) or the "flat" route
+            if not b["launched"]:
+                self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()     # NCCL: the current stream waits for the collective, the host does not block
+            if world > 1:
+                b["flat"].div_(world)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        for b in self.buckets:
+            for p in b["params"]:
+                _BUCKETERS.pop(id(p), None)
+
+
+def bucketers_of(params):
+    seen, out = set(), []
+    for p in params:
+        g = _BUCKETERS.get(id(p))
+        if g is not None and id(g) not in seen:
+            seen.add(id(g)); out.append(g)
+    return out
 
 
 def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=40, find_unused_parameters=False):
@@ -94,18 +169,18 @@ def wrap_ddp(model: nn.Module, local_rank=None, bucket_cap_mb=40, find_unused_pa
     if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return model
     model = convert_syncbn(model)
-    if next(model.parameters()).is_cuda and dp_mode() == "flat":
-        # SyncBN vectors (and the flat gradient buffer): RCCL on the compute stream (collective.py).  Only with the flat
-        # gradient all-reduce: every collective of a step is then issued in program order on one stream; DDP's bucket
-        # all-reduces run concurrently on c10d's own communicator, and two communicators used concurrently in an order
-        # that may differ between ranks can deadlock.
-        from . import collective
-        collective.init_direct(torch.cuda.current_device() if local_rank is None else local_rank)
-    if dp_mode() == "flat":
+    mode = dp_mode()
+    if mode in ("overlap", "flat"):
+        if next(model.parameters()).is_cuda:
+            # SyncBN vectors: RCCL on the compute stream through the C library's own communicator (collective.py); the
+            # gradient buckets go through torch.distributed (c10d's communicator and stream).  Both kinds of collective
+            # are issued from the host in program / autograd order, which is the same on every rank.
+            from . import collective
+            collective.init_direct(torch.cuda.current_device() if local_rank is None else local_rank)
         with torch.no_grad():   # what the DDP constructor does: every rank starts from rank 0's parameters and buffers
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t, 0)
-        model._s2d_flat_allreduce = True
+        model._s2d_grad_buckets = GradBuckets(list(model.parameters()), overlap=(mode == "overlap"))
         return model
     bucket_cap_mb = float(os.environ.get("S2D_DDP_BUCKET_MB", bucket_cap_mb))
     kwargs = dict(bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters,

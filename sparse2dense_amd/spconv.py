@@ -242,11 +242,7 @@ class SparseConv3d(SparseConvolution):
 # --------------------------------------------------------------------------------------------------
 # BatchNorm1d on features
 # --------------------------------------------------------------------------------------------------
-def _dist_on():
-    import os
-    if not (dist.is_available() and dist.is_initialized()) or os.environ.get("S2D_DEBUG_NO_SYNCBN", "0") == "1":
-        return False   # (S2D_DEBUG_NO_SYNCBN: measurement hook, splits DDP overhead from SyncBN overhead)
-    return dist.get_world_size() > 1 or os.environ.get("S2D_FORCE_DDP", "0") == "1"
+_dist_on = _collective.sync_on
 
 
 class _BNTrainFn(torch.autograd.Function):
@@ -312,15 +308,40 @@ class _BNEvalFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, (g if ctx.has_res else None), None, None
 
 
+class _EmptySyncFn(torch.autograd.Function):
+    """Statistics exchange of a batch norm whose local feature matrix is empty: contributes zeros to the forward
+    [sum, sumsq, count] and to the backward [sum g, sum g*x] all-reduces so that the collectives of all ranks match."""
+
+    @staticmethod
+    def forward(ctx, x, n_fwd, n_bwd):
+        ctx.n_bwd = n_bwd
+        ctx.dt = torch.float32 if x.dtype == torch.bfloat16 else x.dtype   # the statistics dtype of the other ranks
+        _collective.allreduce_sum_(torch.zeros(n_fwd, dtype=ctx.dt, device=x.device))
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _collective.allreduce_sum_(torch.zeros(ctx.n_bwd, dtype=ctx.dt, device=dy.device))
+        return dy, None, None
+
+
 class FeatureBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d with identical parameters/buffers; CUDA [N,C] inputs run the fused HIP path."""
 
+    _REQUIRE_CUDA = True   # tests/cpu_backend.py clears it together with swapping the HIP launchers for the oracle
+
     def forward(self, x, residual=None, relu=False):
-        if not x.is_cuda or x.dim() != 2:
+        if (self._REQUIRE_CUDA and not x.is_cuda) or x.dim() != 2:
             raise RuntimeError("FeatureBatchNorm1d: expected a CUDA [N,C] feature matrix (no CPU fallback)")
-        if x.shape[0] == 0:
-            return x
+        if self.momentum is None:
+            raise RuntimeError("FeatureBatchNorm1d: momentum=None (cumulative average) is not supported by the fused kernels")
         use_batch_stats = self.training or not self.track_running_stats
+        if x.shape[0] == 0:
+            if use_batch_stats and _dist_on():
+                # a rank without active sites still takes part in the statistics exchange of the other ranks (forward:
+                # zero sums and a zero count; the backward collective is matched by _EmptySyncFn)
+                return _EmptySyncFn.apply(x, 2 * self.num_features + 1, 2 * self.num_features)
+            return x
         if x.dtype == torch.bfloat16:   # bf16-storage stack: the row-major bf16 kernels (also used by the BEV neck)
             from .dense2d import _BNRowFn
             if self.num_features % 8:

@@ -52,11 +52,17 @@ def distill_loss(T_model, S_model, example):
 
 
 def backward_and_clip(loss, params, max_norm=35.0):
-    """zero_grad -> backward -> clip_grad_norm_(35) (hooks/optimizer.py:15-21, config :216)."""
+    """zero_grad -> backward -> clip_grad_norm_(35) (hooks/optimizer.py:15-21, config :216).  Under data parallelism
+    (dp.wrap_ddp, routes "overlap"/"flat") the gradients are averaged over the ranks by the model's GradBuckets: its
+    all-reduces are launched from gradient hooks during the backward and awaited here, before the clip."""
+    from . import dp
+    params = list(params)
+    syncs = dp.bucketers_of(params)
+    for g in syncs:
+        g.prepare()
     for p in params:
         p.grad = None
     loss.backward()
-    from . import dp
-    if dp.flat_enabled():   # S2D_DP_MODE=flat: gradients averaged here instead of in DDP's backward hooks
-        dp.allreduce_grads(params)
+    for g in syncs:
+        g.finish()
     return torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm)

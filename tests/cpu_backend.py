@@ -158,18 +158,7 @@ def install(monkeypatch=None):
             monkeypatch.setattr(H, n, g[n])
         else:
             setattr(H, n, g[n])
-    orig = sp.FeatureBatchNorm1d.forward
-
-    def forward(self, x, residual=None, relu=False):
-        if x.shape[0] == 0:
-            return x
-        if self.training or not self.track_running_stats:
-            return sp._BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, sp._dist_on() and self.training,
-                                       self)
-        return sp._BNEvalFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
-
     if monkeypatch is not None:
-        monkeypatch.setattr(sp.FeatureBatchNorm1d, "forward", forward)
+        monkeypatch.setattr(sp.FeatureBatchNorm1d, "_REQUIRE_CUDA", False)
     else:
-        sp.FeatureBatchNorm1d.forward = forward
-    return orig
+        sp.FeatureBatchNorm1d._REQUIRE_CUDA = False

@@ -2,8 +2,11 @@
 launchers swapped for tests/cpu_backend.py) on its own frame under sparse2dense_amd.dp.wrap_ddp:
   * FeatureBatchNorm1d statistics are global (all-reduced sums + counts, different N per rank);
   * BatchNorm2d layers are converted to SyncBatchNorm, FeatureBatchNorm1d is left in place;
-  * after DDP's bucketed all-reduce every rank holds the gradient of the mean-of-ranks loss, equal
-    to the single-process gradient on the concatenated 2-frame batch (x 1/2 for the sum loss)."""
+  * after the bucketed all-reduce (routes "overlap": launched from the backward hooks, "flat": after
+    the backward, "ddp": torch DDP) every rank holds the gradient of the mean-of-ranks loss, equal
+    to the single-process gradient on the concatenated 2-frame batch (x 1/2 for the sum loss);
+  * a parameter that gets no gradient on one rank, and a rank whose sparse tensor is empty, do not
+    unbalance the collectives."""
 import os
 import sys
 import tempfile
@@ -40,7 +43,7 @@ def _weights(shape):
 
 def _worker(rank, world, port, out_dir, mode="ddp"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), S2D_DP_MODE=mode)
+                      LOCAL_RANK=str(rank), S2D_DP_MODE=mode, S2D_BUCKET_MB="1")
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)
     from sparse2dense_amd import dp
@@ -56,10 +59,15 @@ def _worker(rank, world, port, out_dir, mode="ddp"):
     feats, c = _voxels(rank)
     coors = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
     bev, _ = ddp(feats, coors, 1, np.array([1504, 1504, 40]))
-    (bev * _weights((2,) + bev.shape[1:])[rank:rank + 1]).sum().backward()
-    if mode == "flat":
-        assert dp.flat_enabled(ddp)
-        dp.allreduce_grads(list(net.parameters()))
+    loss = (bev * _weights((2,) + bev.shape[1:])[rank:rank + 1]).sum()
+    if mode == "ddp":
+        loss.backward()
+    else:
+        from sparse2dense_amd.train_step import backward_and_clip
+        gb = net._s2d_grad_buckets
+        assert gb.overlap == (mode == "overlap") and len(gb.buckets) >= 2   # S2D_BUCKET_MB below: several buckets
+        backward_and_clip(loss, list(net.parameters()), max_norm=1e30)
+        assert all(b["launched"] for b in gb.buckets)
     torch.save({"grads": {n: p.grad.clone() for n, p in net.named_parameters()},
                 "buffers": {k: v.clone() for k, v in net.state_dict().items() if "running" in k}},
                os.path.join(out_dir, f"rank{rank}.pt"))
@@ -67,9 +75,9 @@ def _worker(rank, world, port, out_dir, mode="ddp"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ddp", "flat"])
+@pytest.mark.parametrize("mode", ["overlap", "ddp", "flat"])
 def test_two_rank_dp_equals_single_process_batch(monkeypatch, mode):
-    port = 29500 + (os.getpid() % 2000) + (7 if mode == "flat" else 0)
+    port = 29500 + (os.getpid() % 2000) + {"overlap": 0, "ddp": 3, "flat": 7}[mode]
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, port, d, mode), nprocs=2, join=True)
         r0 = torch.load(os.path.join(d, "rank0.pt"))
@@ -89,3 +97,75 @@ def test_two_rank_dp_equals_single_process_batch(monkeypatch, mode):
         if "running" in k:   # SyncBN: statistics over the voxels of BOTH ranks
             torch.testing.assert_close(r0["buffers"][k], v, rtol=1e-8, atol=1e-11, msg=k)
             torch.testing.assert_close(r1["buffers"][k], v, rtol=1e-8, atol=1e-11, msg=k)
+
+
+def _worker_uneven(rank, world, port, out_dir):
+    """rank 1 has an EMPTY sparse tensor in front of a SyncBN'd FeatureBatchNorm1d and produces no gradient for one
+    parameter: the forward/backward statistics exchanges and the bucket all-reduces must still pair up."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), S2D_DP_MODE="overlap")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    import cpu_backend
+    cpu_backend.install(None)
+    from sparse2dense_amd import dp
+    from sparse2dense_amd.spconv import FeatureBatchNorm1d
+    from sparse2dense_amd.train_step import backward_and_clip
+    dp.init_distributed("gloo")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(4, 8)
+            self.bn = FeatureBatchNorm1d(8, eps=1e-3, momentum=0.01)
+            self.only_rank0 = torch.nn.Parameter(torch.ones(8))
+
+        def forward(self, x, use_extra):
+            y = self.bn(self.lin(x))
+            return (y * self.only_rank0).sum() if use_extra else y.sum() * 1.0
+
+    torch.manual_seed(3)
+    net = dp.wrap_ddp(Net().double())
+    x = torch.randn(6 if rank == 0 else 0, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    loss = net(x, use_extra=(rank == 0))
+    backward_and_clip(loss, list(net.parameters()), max_norm=1e30)
+    torch.save({n: p.grad.clone() for n, p in net.named_parameters()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_empty_rank_and_unused_parameter_do_not_unbalance_collectives():
+    port = 31700 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_uneven, args=(2, port, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    for n in r0:
+        torch.testing.assert_close(r0[n], r1[n], rtol=1e-12, atol=1e-14, msg=n)
+    # reference: the 6 rows in one process (rank 1 contributed nothing); averaged over 2 ranks -> x 1/2
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(4, 8).double()
+    bn = torch.nn.BatchNorm1d(8, eps=1e-3, momentum=0.01).double()
+    extra = torch.ones(8, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(6, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    (bn(lin(x)) * extra).sum().backward()
+    torch.testing.assert_close(r0["only_rank0"] * 2, extra.grad, rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(r0["lin.weight"] * 2, lin.weight.grad, rtol=1e-7, atol=1e-10)
+    torch.testing.assert_close(r0["bn.weight"] * 2, bn.weight.grad, rtol=1e-7, atol=1e-10)
+
+
+def test_direct_rccl_route_falls_back_on_every_rank_when_unavailable():
+    """collective.init_direct on a non-NCCL process group: returns False and leaves the torch.distributed route on
+    (the agreement all-reduce itself needs a GPU; on gloo the early exit is what every rank takes)."""
+    port = 33100 + (os.getpid() % 2000)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from sparse2dense_amd import collective
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        assert collective.init_direct(0) is False and not collective.direct_enabled()
+        t = torch.ones(4)
+        assert collective.allreduce_sum_(t) is t and float(t.sum()) == 4.0
+    finally:
+        dist.destroy_process_group()
+    assert not collective.direct_enabled() and not collective.sync_on()

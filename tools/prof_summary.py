@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Summarises a `rocprofv3 --kernel-trace --stats` run of bench.py:
-   python tools/prof_summary.py <dir-with-*_kernel_trace.csv> [frames_per_step]
+   python tools/prof_summary.py <dir-with-*_kernel_trace.csv> [voxelizer_launches_per_step]
 Prints (a) whole-run per-kernel stats and (b) the kernel breakdown of the LAST steady-state step
-(steps are delimited by the voxelizer's first kernel, one launch per frame)."""
+(steps are delimited by the voxelizer's first kernel; launches per step = frames for the single-stage workloads,
+5 x frames for the S2D workloads, whose frames are voxelized as points / dense / reconstruction at three scales - or 1
+with the batched voxelizer)."""
 import collections
 import csv
 import glob
