@@ -5,16 +5,21 @@
 
 One step = one pass of the hot path over one batch of synthetic frames that are already resident
 in HBM as raw points: device voxelization (+fused reader) -> 8 rulebooks -> SpMiddleResNetFHD
-(MFMA sparse convs, fused BN) -> densify -> RPN neck -> CenterHead -> CenterPoint loss ->
-backward -> grad-clip(35) -> AdamW step; DDP all-reduce overlapped with backward when N>1.
-Default workload = BASELINE.json configs[1] (CenterPoint-voxelnet single stage, 150k-pt 0.1 m
-Waymo scene); `--workload s2d_student|s2d_distill` run configs[2].
+(MFMA sparse convs, fused BN) -> densify -> neck -> CenterHead -> losses -> backward ->
+grad-clip(35) -> AdamW step; bucketed gradient all-reduce overlapped with the backward when N>1.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     : the dominant hand-written kernel (sparse-conv implicit GEMM instantiation with
-                 the largest total time), algorithmic FLOPs / HIP-event-timed launches
-  cpu_baseline : the CPU oracle stack (C voxelizer + per-offset gather-mm-scatter backbone + torch
-                 CPU neck/head) on a bounded sample of the same workload, host cores stated
+Default workload = north_star's target: CenterPoint-voxelnet + S2D (`KD_VoxelNet` student: S2D
+densify module + PCR head + RPN trunk + CenterHead), forward + backward, B=4 frames per GPU of the
+150k-point 0.1 m-voxel synthetic Waymo scene.  `--workload centerpoint` = BASELINE configs[1],
+`--workload s2d_distill` = configs[2] (teacher + student dual forward); at N=1 both are also timed
+(short) and reported under `other_workloads` of the same JSON line.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+  roofline     : the dominant hand-written kernel of the step by total time (per-launch HIP events)
+  sparse_gemm  : MFMA fraction of the sparse implicit GEMM at C >= 64 (forward + data gradient)
+  rulebook     : HBM fraction of the rulebook stage (4 SubM + 4 strided builds per backbone pass)
+  cpu_baseline : the CPU oracle stack on a bounded sample (150k-pt frame, and BASELINE configs[0]:
+                 SECOND on the 8k-pt cloud, 3 warm-up + 10 timed iterations, median), host cores stated
 """
 import argparse
 import json
@@ -30,10 +35,18 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-RULEBOOK_STATS = None
+PMC_TRAFFIC_FILES = ["r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
+
+WORKLOAD_NAMES = {
+    "centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
+    "s2d_student": "CenterPoint-voxelnet + S2D (KD_VoxelNet student: S2D module + PCR head + RPN trunk + CenterHead), forward+backward",
+    "s2d_distill": "CenterPoint-voxelnet + S2D distill, teacher+student dual forward (BASELINE configs[2])",
+    "pillar": "CenterPoint-Pillar single stage (PFN path)",
+    "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)",
+}
 
 
 def parse():
@@ -43,16 +56,18 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=4, help="frames per GPU (weak scaling; reference trains 3-4/GPU)")
     p.add_argument("--points", type=int, default=150000)
-    p.add_argument("--workload", default="centerpoint", choices=["centerpoint", "s2d_student", "s2d_distill", "pillar", "pillar_s2d"])
+    p.add_argument("--workload", default="s2d_student", choices=list(WORKLOAD_NAMES))
     p.add_argument("--no-optim", action="store_true", help="stop after backward + grad clip")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="do not time the other workloads (other_workloads)")
     p.add_argument("--cpu-points", type=int, default=150000)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--beam-jitter", type=float, default=None, help="scene.make_scene(beam_jitter=...); default scene.WAYMO_BEAM_JITTER")
     p.add_argument("--torch-profile", action="store_true", help="after the timed region: torch.profiler table of 2 steps "
                    "(ops with input shapes -> stderr); diagnostic only")
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
-                   help="MFMA input dtype of the conv path (fp32 accumulate, fp32 storage/statistics/master weights)")
+                   help="MFMA input dtype of the conv path (fp32 accumulate, fp32 statistics/master weights)")
     p.add_argument("--dense-dtype", default=None, choices=["f32", "bf16"], help="override for the dense neck/head convs")
     p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16", "s16"],
                    help="override for the sparse stack: bf16 = fp32 storage / bf16 MFMA inputs, s16 = bf16 storage (default with --dtype bf16)")
@@ -60,7 +75,7 @@ def parse():
     return p.parse_args()
 
 
-def build_models(args, dev):
+def build_models(args, workload, dev):
     from sparse2dense_amd import hip_ops, waymo_configs
     args.dense_dtype = args.dense_dtype or args.dtype
     args.sparse_dtype = args.sparse_dtype or ("s16" if args.dtype == "bf16" else args.dtype)
@@ -68,15 +83,15 @@ def build_models(args, dev):
     from sparse2dense_amd.registry import build_detector
     torch.manual_seed(1234)
     teacher = None
-    if args.workload == "centerpoint":
+    if workload == "centerpoint":
         model = build_detector(waymo_configs.centerpoint_voxelnet())
-    elif args.workload == "pillar":
+    elif workload == "pillar":
         model = build_detector(waymo_configs.centerpoint_pillar())
-    elif args.workload == "pillar_s2d":
+    elif workload == "pillar_s2d":
         model = build_detector(waymo_configs.pillar_s2d_student())
     else:
         model = build_detector(waymo_configs.s2d_student())
-        if args.workload == "s2d_distill":
+        if workload == "s2d_distill":
             teacher = build_detector(waymo_configs.centerpoint_voxelnet()).to(dev).eval()
             for p in teacher.parameters():
                 p.requires_grad = False
@@ -89,7 +104,7 @@ def build_models(args, dev):
     return model.to(dev).train(), teacher
 
 
-def make_step(args, model, teacher, frames, optimizer):
+def make_step(workload, model, teacher, frames, optimizer):
     from sparse2dense_amd.train_step import backward_and_clip, distill_loss, single_stage_loss
     params = [p for p in model.parameters() if p.requires_grad]
 
@@ -97,9 +112,14 @@ def make_step(args, model, teacher, frames, optimizer):
         ex = frames.example()                       # device voxelization of the resident points
         if teacher is not None:
             loss, _ = distill_loss(teacher, model, ex)
-        elif args.workload == "pillar_s2d":
+        elif workload == "pillar_s2d":
             out = model(ex, return_loss=True)          # (losses, F_S_a, F_S_b, preds, mask_loss, offset_loss)
             loss = sum(out[0]["loss"]) + (out[4] + out[5]) * 0.5   # trainer.py:766 weights for the PP branch
+        elif workload == "s2d_student":
+            # the student's own terms of the distillation step (trainer.py:781,804-805 without the teacher-dependent ones):
+            # detection losses + PCR mask / offset losses
+            losses, _, _, _, mask_loss, offset_loss = model(ex, return_loss=True, return_feature=True)
+            loss = sum(losses["loss"]) + (mask_loss + offset_loss)
         else:
             loss, _ = single_stage_loss(model, ex)
         backward_and_clip(loss, params, 35.0)
@@ -110,35 +130,86 @@ def make_step(args, model, teacher, frames, optimizer):
     return step
 
 
-EVENT_OVERHEAD_US = 0.0
+def setup_workload(args, workload, dev, rank):
+    """model(s), resident frames, optimizer and the step closure of one workload"""
+    from sparse2dense_amd import dp, scene
+    from sparse2dense_amd.data import SyntheticFrames
+    model, teacher = build_models(args, workload, dev)
+    model = dp.wrap_ddp(model, dev.index)
+    jitter = scene.WAYMO_BEAM_JITTER if args.beam_jitter is None else args.beam_jitter
+    if workload.startswith("pillar"):
+        from sparse2dense_amd.data import SyntheticPillarFrames
+        frames = SyntheticPillarFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank, device=dev)
+    else:
+        frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
+                                 distill=(workload != "centerpoint"), device=dev, beam_jitter=jitter)
+    optimizer = None
+    if not args.no_optim:
+        optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
+                                      weight_decay=0.01, fused=True)
+    return model, teacher, frames, make_step(workload, model, teacher, frames, optimizer)
+
+
+def timed(step, steps, warmup, world, dev):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks"""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, loss
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline pass: per-launch HIP events on the stream the kernels are launched on
+# ------------------------------------------------------------------------------------------------
+def _event_overhead_us():
+    """an event pair around NOTHING still measures a few microseconds (the two record operations): calibrate it"""
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in pairs:
+        a.record(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
 
 
 def roofline_pass(step, n_steps=3):
-    """Re-runs a few steps with per-launch HIP events around the sparse-conv kernels (on the
-    stream they are launched on) and returns the roofline object of the dominant instantiation."""
     from sparse2dense_amd import hip_ops as H
     H.PROFILE = []
     for _ in range(n_steps):
         step()
     torch.cuda.synchronize()
     recs, H.PROFILE = H.PROFILE, None
-    # an event pair around NOTHING still measures a few microseconds (the two record operations); calibrate and
-    # subtract it, so that the per-launch durations are the kernels' own (rocprofv3 --stats agrees within a few %)
-    pairs_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for a_, b_ in pairs_:
-        a_.record(); b_.record()
-    torch.cuda.synchronize()
-    global EVENT_OVERHEAD_US
-    EVENT_OVERHEAD_US = sorted(a_.elapsed_time(b_) for a_, b_ in pairs_)[len(pairs_) // 2] * 1e3
-    agg = {}
-    rb = dict(ms=0.0, n=0, bytes=0.0)
+    over = _event_overhead_us()
+    agg, rb = {}, dict(ms=0.0, n=0, bytes=0.0, subm=0, conv=0)
     for r in recs:
-        ms = max(r["start"].elapsed_time(r["end"]) - (0.0 if r["kernel"] == "rulebook_subm" else EVENT_OVERHEAD_US * 1e-3), 1e-4)
-        pairs = float(r["pairs"].sum().item()) if r["pairs"] is not None else 0.0
-        if r["kernel"] == "rulebook_subm":   # BASELINE.md §3: 16 N + 8 R + 4 K bytes
-            rb["ms"] += ms; rb["n"] += 1
-            rb["bytes"] += 16.0 * r["n_out"] + 8.0 * pairs + 4.0 * r["kvol"]
+        pairs = float(r["pairs"].sum().item()) if r.get("pairs") is not None else 0.0
+        if r["kernel"] in ("rulebook_subm", "rulebook_conv"):
+            # launch chains (several kernels inside one event pair): the event overhead is not subtracted
+            ms = r["start"].elapsed_time(r["end"])
+            if r["kernel"] == "rulebook_conv":   # count phase + fill phase (the host read of N_out between them is not GPU time)
+                ms += r["start2"].elapsed_time(r["end2"])
+                rb["bytes"] += 16.0 * r["n_in"] + 16.0 * r["n_out"] + 8.0 * pairs + 4.0 * r["kvol"]   # SURVEY 8(d)
+                rb["conv"] += 1
+            else:
+                rb["bytes"] += 16.0 * r["n_out"] + 8.0 * pairs + 4.0 * r["kvol"]
+                rb["subm"] += 1
+            rb["ms"] += ms
+            rb["n"] += 1
             continue
+        ms = max(r["start"].elapsed_time(r["end"]) - over * 1e-3, 1e-4)
         kname = r["kernel"]
         if r.get("dense"):   # mirror of the dispatch in csrc/conv2d_nhwc.hip (which device function serves this launch)
             if r["cout"] % 128 == 0:
@@ -147,7 +218,7 @@ def roofline_pass(step, n_steps=3):
                 kname = "conv3x3_p1_nhwc_bf16_kernel<64>"
             else:
                 kname = "conv3x3_k32_nhwc_bf16_kernel<64, 4>"
-        key = (kname, r["cin"], r["cout"], r["n_out"])
+        key = (kname, r["cin"], r["cout"], r["n_out"], r.get("tag", ""))
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, tile_rows=r.get("tile_rows", 128)))
         a["ms"] += ms
         a["n"] += 1
@@ -158,30 +229,43 @@ def roofline_pass(step, n_steps=3):
         a["flops"] += 2.0 * pairs * r["cin"] * r["cout"]
         eb = float(r.get("elem_bytes", 4))   # feature storage: fp32, or bf16 on the s16 path (its weight image is bf16 too)
         a["bytes"] += eb * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + eb * r["kvol"] * r["cin"] * r["cout"]
-    global RULEBOOK_STATS
-    RULEBOOK_STATS = None
+    rulebook = None
     if rb["n"]:
         gbs = rb["bytes"] / (rb["ms"] * 1e-3) / 1e9
-        RULEBOOK_STATS = dict(kernel="s2d_rulebook_subm_build (6 launches: set, scan x3, perm, probe)", builds_per_step=rb["n"] // n_steps,
-                              avg_us=round(rb["ms"] / rb["n"] * 1e3, 1), algorithmic_gbs=round(gbs, 1),
-                              frac_of_hbm_peak=round(gbs / PEAK_HBM_GBS, 4))
-    if not agg:
-        return None, []
+        rulebook = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                        builds_per_step=rb["n"] // n_steps, subm_builds=rb["subm"] // n_steps, strided_builds=rb["conv"] // n_steps,
+                        avg_build_us=round(rb["ms"] / rb["n"] * 1e3, 1), total_ms_per_step=round(rb["ms"] / n_steps, 3),
+                        algorithmic_mb_per_step=round(rb["bytes"] / n_steps / 1e6, 2),
+                        algorithmic_bytes="SubM 16 N + 8 R + 4 K; strided 16 N_in + 16 N_out + 8 R + 4 K (SURVEY 8(d))")
     rows = []
-    for (kern, cin, cout, n_out), a in agg.items():
+    for (kern, cin, cout, n_out, tag), a in agg.items():
         avg_ms = a["ms"] / a["n"]
-        rows.append(dict(kernel=kern, cin=cin, cout=cout, n_out=n_out, tile_rows=a["tile_rows"], launches=a["n"], avg_us=avg_ms * 1e3,
-                         total_ms=a["ms"], tflops=a["flops"] / a["n"] / (avg_ms * 1e-3) / 1e12,
+        rows.append(dict(kernel=kern, tag=tag, cin=cin, cout=cout, n_out=n_out, tile_rows=a["tile_rows"], launches=a["n"],
+                         avg_us=avg_ms * 1e3, total_ms=a["ms"], tflops=a["flops"] / a["n"] / (avg_ms * 1e-3) / 1e12,
                          gbs=a["bytes"] / a["n"] / (avg_ms * 1e-3) / 1e9))
     rows.sort(key=lambda r: -r["total_ms"])
+
+    # sparse implicit GEMM, C >= 64 (north_star: ">= 50 % MFMA utilisation for the sparse-conv implicit GEMM")
+    sg_rows = [r for r in rows if r["kernel"].startswith("spconv_fwd") and min(r["cin"], r["cout"]) >= 64]
+    sparse_gemm = None
+    if sg_rows:
+        ms = sum(r["total_ms"] for r in sg_rows)
+        fl = sum(r["tflops"] * 1e12 * r["total_ms"] * 1e-3 for r in sg_rows)
+        tf = fl / (ms * 1e-3) / 1e12
+        sparse_gemm = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_MATRIX_TFLOPS, unit="TFLOP/s",
+                           frac=round(tf / PEAK_BF16_MATRIX_TFLOPS, 4), scope="sparse-conv gather implicit GEMM launches with "
+                           "Cin, Cout >= 64 (forward + data gradient), algorithmic FLOPs 2 R Cin Cout",
+                           shapes=[dict(cin=r["cin"], cout=r["cout"], rows_out=r["n_out"], pass_=r["tag"], launches_per_step=r["launches"] // n_steps,
+                                        avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1),
+                                        frac=round(r["tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4)) for r in sg_rows])
+    if not rows:
+        return None, [], rulebook, sparse_gemm
 
     # the dominant KERNEL is a device function (what rocprofv3 --stats lists); one template instantiation serves several
     # tensor shapes, so group the per-shape rows by instantiation before ranking
     def template_of(r):
         if r["kernel"].startswith("conv3x3_"):
             return r["kernel"]
-        if r["kernel"] == "spconv_fwd_s16":
-            return f"spconv_fwd_s16_kernel<{r['cin']}, {r['cout']}, {128 if r['cout'] == 128 else 64}>"
         return f"{r['kernel']}<{r['cin']}, {r['cout']}>"
     groups = {}
     for r in rows:
@@ -203,10 +287,10 @@ def roofline_pass(step, n_steps=3):
                    avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1)) for r in g["rows"]]
     common = dict(traffic=None, kernel=f"s2d::{name}", avg_launch_us=round(avg_us, 2), launches_per_step=g["n"] // n_steps,
                   algorithmic_tflops=round(tflops, 2), algorithmic_gbs=round(gbs, 1), flop_per_byte=round(intensity, 1),
-                  mfma_peak_tflops=peak_tf, shapes=shapes, event_pair_overhead_us_subtracted=round(EVENT_OVERHEAD_US, 2),
-                  scope=("dominant hand-written kernel of the step by total time (rocprofv3 --stats agrees, profiles/): "
-                         + ("dense 3x3 NHWC bf16 implicit GEMM of the BEV neck/head, forward + data-gradient launches"
-                            if dense else "sparse-conv gather implicit GEMM, forward + data-gradient launches")))
+                  mfma_peak_tflops=peak_tf, shapes=shapes, event_pair_overhead_us_subtracted=round(over, 2),
+                  scope=("dominant hand-written kernel of the step by total time among the event-timed ones (rocprofv3 --stats "
+                         "agrees, profiles/): " + ("dense 3x3 NHWC bf16 implicit GEMM of the BEV neck/head, forward + data-gradient launches"
+                                                  if dense else "sparse-conv gather implicit GEMM, forward + data-gradient launches")))
     # measured HBM bytes per launch: launch-weighted mean over the shapes, only if every shape has a PMC entry
     per = [(pmc_traffic(r), r["launches"]) for r in g["rows"]]
     if all(tr[0] is not None for tr, _ in per):
@@ -218,7 +302,7 @@ def roofline_pass(step, n_steps=3):
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), **common)
     else:
         roof = dict(bound="mfma", achieved=round(tflops, 3), peak=peak_tf, unit="TFLOP/s", frac=round(tflops / peak_tf, 4), **common)
-    return roof, rows
+    return roof, rows, rulebook, sparse_gemm
 
 
 def effective_cpu_count():
@@ -235,13 +319,9 @@ def effective_cpu_count():
 
 
 def pmc_traffic(top):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_final_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, keyed by kernel name and launch grid).  The launch grid is a
-    function of the tensor shape, so an entry is only found when the profiled shape is the one being benchmarked."""
-    try:
-        db = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
-    except Exception:
-        return None, None
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/*_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs, keyed by kernel name and launch grid).  The launch grid is a function of the
+    tensor shape, so an entry is only found when the profiled shape is the one being benchmarked."""
     xcd = lambda tiles: -(-tiles // 8) * 8
     if top["kernel"].startswith("conv3x3_"):
         bn = 128 if top["cout"] % 128 == 0 else 64
@@ -251,16 +331,22 @@ def pmc_traffic(top):
         want, grid = f"spconv_fwd_s16_kernel<{top['cin']}, {top['cout']}, {bm}>", xcd(-(-top["n_out"] // bm)) * 256
     else:
         return None, None
-    for name, v in db.items():
-        if want in name and name.endswith(f"grid={grid}") and v["FETCH_SIZE_KiB"] and v["WRITE_SIZE_KiB"]:
-            b = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
-            return round(b), "profiles/r01_final_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB, per launch of this shape)"
+    for fname in PMC_TRAFFIC_FILES:
+        try:
+            db = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+        except Exception:
+            continue
+        for name, v in db.items():
+            if want in name and name.endswith(f"grid={grid}") and v["FETCH_SIZE_KiB"] and v["WRITE_SIZE_KiB"]:
+                b = (2.0 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024.0
+                return round(b), f"profiles/{fname} (2*FETCH_SIZE + WRITE_SIZE, KiB, per launch of this shape)"
     return None, None
 
 
-def cpu_baseline_subprocess(args, timeout_s=240):
-    """Runs cpu_baseline() in a child process under a hard time limit so that a slow host can never
-    stall the bench; returns None (with the reason on stderr) if it does not finish."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (oracle stack on the host cores; runs in a child process under a time limit)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline_subprocess(args, timeout_s=300):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-points", str(args.cpu_points)]
     try:
@@ -275,14 +361,38 @@ def cpu_baseline_subprocess(args, timeout_s=240):
 
 
 def cpu_baseline(args):
-    """CPU oracle stack on ONE frame of the same workload (fwd+bwd, single iteration)."""
+    """CPU oracle stack (C voxelizer + per-offset gather-mm-scatter backbone + torch-CPU neck/head):
+    (a) ONE 150k-point frame of the CenterPoint-voxelnet step, fwd+bwd, single iteration;
+    (b) BASELINE configs[0]: SECOND voxelnet on the 8k-point cloud, batch 1, forward (its anchor loss is out of scope),
+        3 warm-up + 10 timed iterations, median."""
     from oracle import spconv_ref as R
     from oracle import voxelize as OV
     from sparse2dense_amd import scene, waymo_configs
     from sparse2dense_amd.registry import build_detector
     cores = effective_cpu_count()
     torch.set_num_threads(cores)
-    s = scene.make_scene(args.cpu_points, seed=20240928)
+    grid = np.array([1504, 1504, 40])
+    # (b) first: short and always finishes
+    s8 = scene.make_scene(8000, seed=7)
+    torch.manual_seed(1234)
+    det8 = build_detector(waymo_configs.second_voxelnet())
+    bb8, neck8, head8 = R.RefSpMiddleFHD(5).eval(), det8.neck.eval(), det8.bbox_head.eval()
+
+    def second_once():
+        t0 = time.perf_counter()
+        v, c, n = OV.points_to_voxel(s8["points"], scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
+        coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+        with torch.no_grad():
+            bev, _ = bb8(torch.from_numpy(OV.voxel_mean(v, n)), coors, 1, grid)
+            head8(neck8(bev))
+        return time.perf_counter() - t0, c.shape[0]
+    for _ in range(3):
+        second_once()
+    ts = sorted(second_once()[0] for _ in range(10))
+    second = dict(value=round(1.0 / ts[len(ts) // 2], 3), unit="frames/s", sample=f"SECOND voxelnet forward, 8000 pts ({second_once()[1]} voxels), "
+                  "batch 1, 3 warm-up + 10 timed, median")
+    # (a)
+    s = scene.make_scene(args.cpu_points, seed=20240928, beam_jitter=scene.WAYMO_BEAM_JITTER)
     t = scene.assign_targets(s["gt_boxes"], s["gt_classes"])
     ex = {k: [torch.from_numpy(v)[None]] for k, v in t.items()}
     torch.manual_seed(1234)
@@ -294,7 +404,7 @@ def cpu_baseline(args):
     feats = torch.from_numpy(OV.voxel_mean(v, n))
     coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
     t1 = time.perf_counter()
-    bev, _ = bb(feats, coors, 1, np.array([1504, 1504, 40]))
+    bev, _ = bb(feats, coors, 1, grid)
     t2 = time.perf_counter()
     loss = sum(head.loss(ex, head(neck(bev)))["loss"])
     t3 = time.perf_counter()
@@ -302,8 +412,31 @@ def cpu_baseline(args):
     t4 = time.perf_counter()
     total = t4 - t0
     return dict(value=round(1.0 / total, 4), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 frame ({args.cpu_points} pts, {c.shape[0]} voxels), fwd+bwd, 1 iteration, no warm-up; "
-                       f"voxelize {t1 - t0:.2f}s backbone-fwd {t2 - t1:.2f}s dense-fwd+loss {t3 - t2:.2f}s bwd {t4 - t3:.2f}s")
+                sample=f"CenterPoint-voxelnet, 1 frame ({args.cpu_points} pts, {c.shape[0]} voxels), fwd+bwd, 1 iteration, no warm-up; "
+                       f"voxelize {t1 - t0:.2f}s backbone-fwd {t2 - t1:.2f}s dense-fwd+loss {t3 - t2:.2f}s bwd {t4 - t3:.2f}s",
+                config0_second_8k=second)
+
+
+def scene_stats(model, frames):
+    """measured sizes of the benchmark scene: voxels per batch, active sites N_l and SubM pairs R_l per stage"""
+    ex = frames.example()
+    out = dict(voxels_per_gpu_batch=int(ex["coordinates"].shape[0]))
+    bb = getattr(getattr(model, "module", model), "backbone", None)
+    if bb is None or not hasattr(bb, "_specs"):
+        return out
+    try:
+        from sparse2dense_amd.backbones import build_geometry
+        shape = [int(v) for v in (np.array(ex["shape"][0][::-1]) + [1, 0, 0])]
+        plan = build_geometry(ex["coordinates"], len(ex["num_voxels"]), shape, *bb._specs())
+        n_l, r_l = [], []
+        for k, rb in plan.items():
+            if isinstance(k, str):
+                n_l.append(int(rb.n_out)); r_l.append(int(rb.pair_count.sum().item()))
+        out.update(sites_per_stage=n_l, subm_pairs_per_stage=r_l,
+                   strided_pairs=[int(rb.pair_count.sum().item()) for k, rb in plan.items() if not isinstance(k, str)])
+    except Exception as e:   # diagnostic only
+        out["stats_error"] = repr(e)
+    return out
 
 
 def main():
@@ -325,41 +458,10 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from sparse2dense_amd.data import SyntheticFrames
     torch.backends.cudnn.benchmark = False   # MIOpen exhaustive find costs minutes on a fresh box
 
-    model, teacher = build_models(args, dev)
-    model = dp.wrap_ddp(model, local)
-    if args.workload.startswith("pillar"):
-        from sparse2dense_amd.data import SyntheticPillarFrames
-        frames = SyntheticPillarFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank, device=dev)
-    else:
-        frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
-                                 distill=(args.workload not in ("centerpoint",)), device=dev)
-    optimizer = None
-    if not args.no_optim:
-        optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
-                                      weight_decay=0.01, fused=True)
-    step = make_step(args, model, teacher, frames, optimizer)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    model, teacher, frames, step = setup_workload(args, args.workload, dev, rank)
+    elapsed, loss = timed(step, args.steps, args.warmup, world, dev)
 
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
@@ -371,13 +473,32 @@ def main():
                                                                  max_name_column_width=48, max_shapes_column_width=70),
               file=sys.stderr)
 
-    ex = frames.example()
-    n_vox = int(ex["coordinates"].shape[0])
-    roof, rows = (None, [])
-    if rank == 0 and world == 1 and not args.no_roofline:
-        roof, rows = roofline_pass(step)
+    single = rank == 0 and world == 1
+    stats = scene_stats(model, frames) if rank == 0 else {}
+    roof, rows, rulebook, sparse_gemm = (None, [], None, None)
+    if single and not args.no_roofline:
+        roof, rows, rulebook, sparse_gemm = roofline_pass(step)
+    loss_value = round(float(loss.item()), 4)
+
+    others = {}
+    if single and not args.no_extras and not args.workload.startswith("pillar"):
+        del model, teacher, frames, step
+        torch.cuda.empty_cache()
+        for wl in ("centerpoint", "s2d_student", "s2d_distill"):
+            if wl == args.workload:
+                continue
+            try:
+                m2, t2, f2, st2 = setup_workload(args, wl, dev, rank)
+                k = max(5, min(args.steps, 10))
+                el, _ = timed(st2, k, 3, 1, dev)
+                others[wl] = dict(workload=WORKLOAD_NAMES[wl], value=round(args.batch * k / el, 3), unit="frames/s",
+                                  ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=3, frames_per_gpu=args.batch)
+                del m2, t2, f2, st2
+                torch.cuda.empty_cache()
+            except Exception as e:   # an extra must never take the headline number down
+                others[wl] = dict(error=repr(e))
     base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         base = cpu_baseline_subprocess(args)
 
     if rank == 0:
@@ -392,23 +513,19 @@ def main():
                       + "; dense neck/head: " + ("bf16 NHWC activations" if args.dense_dtype == "bf16" else "fp32")
                       + "; fp32 accumulate, statistics, master weights, optimizer)"),
             "data": "synthetic",
-            "config": {"workload": {"centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
-                                    "s2d_student": "CenterPoint-voxelnet + S2D student (KD_VoxelNet) fwd+bwd",
-                                    "s2d_distill": "CenterPoint-voxelnet + S2D distill, teacher+student dual forward "
-                                                   "(BASELINE configs[2])",
-                                    "pillar": "CenterPoint-Pillar single stage (PFN path)",
-                                    "pillar_s2d": "CenterPoint-Pillar + S2D student (BASELINE configs[4], PFN path)"}[args.workload],
+            "config": {"workload": WORKLOAD_NAMES[args.workload],
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "voxels_per_gpu_batch": n_vox, "parallelism": f"dp{world}", "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"),
+                       "parallelism": f"dp{world}",
+                       "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"),
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),
-                       "loss": round(float(loss.item()), 4)},
-            "roofline": roof, "cpu_baseline": base,
+                       "loss": loss_value, "scene": stats},
+            "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "cpu_baseline": base,
         }
-        if RULEBOOK_STATS:
-            out["config"]["rulebook_stage"] = RULEBOOK_STATS
+        if others:
+            out["other_workloads"] = others
         if rows:
-            out["config"]["spconv_kernels"] = [
-                {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
+            out["config"]["event_timed_kernels"] = [
+                {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

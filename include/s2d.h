@@ -349,6 +349,39 @@ int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zer
                                   size_t ws_bytes, s2d_stream_t stream);
 
 /*
+ * Depth-wise 7x7 convolution, padding 3, stride 1 (nn.Conv2d(C, C, 7, padding=3, groups=C): first layer of the three
+ * ConvNeXt blocks of the S2D module, det3d/models/necks/rpn.py:204-225) on NHWC bf16 maps.  x, y [n][h][w][c] bf16;
+ * weight fp32 [c][49] (the torch layout [c][1][7][7]); bias fp32 [c] or NULL; fp32 accumulation.  flip=1 mirrors the taps:
+ * the data gradient is the same stencil applied to dy.  c must be a multiple of 8.  The weight gradient returns dweight
+ * fp32 [c][49] and (optionally) dbias [c]; its partial sums are folded in a fixed order (deterministic).
+ */
+int s2d_dwconv7_supported(int channels);
+int s2d_dwconv7_nhwc_bf16(const void *x, const float *weight, const float *bias, int n_img, int h, int w,
+                          int c, int flip, void *y, s2d_stream_t stream);
+size_t s2d_dwconv7_wgrad_workspace_bytes(int n_img, int h, int w, int c);
+int s2d_dwconv7_wgrad_nhwc_bf16(const void *x, const void *dy, int n_img, int h, int w, int c,
+                                float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                s2d_stream_t stream);
+
+/*
+ * PCR (point-cloud reconstruction) losses of the S2D student, det3d/models/detectors/voxelnet.py:171-185,203-249
+ * (`mask_offset_loss` on the dense reconstruction target), computed from the SPARSE recon voxels instead of the dense
+ * [B,5,D,H,W] target: gen_offset fp32 [B][3][D][H][W], gen_mask fp32 [B][1][D][H][W] (logits), coors int32 [m][4] (b,z,y,x)
+ * and feats fp32 [m][5] = the reader output of the recon voxels at this scale.  out8 (device, 8 floats):
+ * [0] mask_loss (BCE-with-logits, pos_weight = #neg/#pos, mean over all cells)  [1] offset_loss (L1 at the non-zero target
+ * entries)  [2] beta  [3] n_sel  [4] N  [5] n_pos.  The backward takes out8 and the two upstream scalar gradients (device)
+ * and writes d/d gen_mask (every cell) and d/d gen_offset (only the selected entries: the caller passes a zeroed buffer).
+ */
+size_t s2d_pcr_loss_workspace_bytes(void);
+int s2d_pcr_loss_fwd_f32(const float *gen_offset, const float *gen_mask, const int32_t *coors,
+                         const float *feats, int64_t m, int batch, int d, int h, int w, float *out8,
+                         void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const int32_t *coors,
+                         const float *feats, int64_t m, int batch, int d, int h, int w,
+                         const float *fwd_out8, const float *go_mask, const float *go_offset,
+                         float *g_gen_mask, float *g_gen_offset_zeroed, s2d_stream_t stream);
+
+/*
  * SyncBN statistics all-reduce on the compute stream (det3d/torchie/apis/train.py:281-300: apex SyncBatchNorm + DDP when
  * training distributed).  The RCCL already loaded in the process is resolved at run time; s2d_comm_available() == 0 means
  * the host keeps using its own collective.  Bootstrap: rank 0 calls s2d_comm_unique_id (128 bytes), the host broadcasts

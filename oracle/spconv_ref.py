@@ -150,6 +150,40 @@ def pairs_to_set(pairs):
     return s
 
 
+# ----------------------------------------------------------------------------------------------
+# bf16-STORAGE emulation (the product's "s16" mode keeps sparse features in bf16 between kernels,
+# fp32 accumulation / statistics).  `with bf16_storage():` makes the module-level restatement below
+# round features to bf16 at exactly the points where the product writes a bf16 tensor - the backbone
+# input, every conv output, every fused BN(+residual)(+ReLU) output - and round the gradients
+# flowing back through those points the same way, in whatever dtype (fp32 / fp64) the oracle runs.
+# ----------------------------------------------------------------------------------------------
+_STORAGE_BF16 = False
+
+
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _store(x):
+    return _RoundBf16.apply(x) if _STORAGE_BF16 else x
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _STORAGE_BF16
+        self.prev, _STORAGE_BF16 = _STORAGE_BF16, True
+
+    def __exit__(self, *a):
+        global _STORAGE_BF16
+        _STORAGE_BF16 = self.prev
+
+
 def sparse_conv(features, weight, bias, pairs, n_out):
     """spconv 'Native' algorithm: per offset gather -> mm -> scatter-add.  Differentiable (torch)."""
     kvol = weight.shape[0] * weight.shape[1] * weight.shape[2]
@@ -212,12 +246,12 @@ class RefSparseConv(nn.Module):
                 pairs = rulebook_subm(x.indices, x.spatial_shape, self.ksize, self.dilation)
                 if key is not None:
                     x.indice_dict[key] = pairs
-            out = RefSparseTensor(sparse_conv(x.features, self.weight, self.bias, pairs, x.indices.shape[0]),
+            out = RefSparseTensor(_store(sparse_conv(x.features, self.weight, self.bias, pairs, x.indices.shape[0])),
                                   x.indices, x.spatial_shape, x.batch_size)
         else:
             oc, oshape, pairs = rulebook_conv(x.indices, x.spatial_shape, self.ksize, self.stride, self.padding,
                                               self.dilation)
-            out = RefSparseTensor(sparse_conv(x.features, self.weight, self.bias, pairs, oc.shape[0]),
+            out = RefSparseTensor(_store(sparse_conv(x.features, self.weight, self.bias, pairs, oc.shape[0])),
                                   oc, oshape, x.batch_size)
         out.indice_dict = x.indice_dict
         return out
@@ -235,11 +269,15 @@ class RefSparseSequential(nn.Sequential):
     """spconv.SparseSequential: sparse modules take the tensor, plain modules its features."""
 
     def forward(self, x):
-        for m in self:
+        mods = list(self)
+        for i, m in enumerate(mods):
             if isinstance(m, (RefSparseConv, RefBasicBlock, RefSparseSequential)):
                 x = m(x)
             else:
                 x.features = m(x.features)
+                # the product fuses BN + ReLU into one kernel with one bf16 store: round after the ReLU only
+                if not (isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)):
+                    x.features = _store(x.features)
         return x
 
 
@@ -260,10 +298,10 @@ class RefBasicBlock(nn.Module):
 
     def forward(self, x):
         out = self.conv1(x)
-        out.features = self.relu(self.bn1(out.features))
+        out.features = _store(self.relu(self.bn1(out.features)))
         out = self.conv2(out)
         out.features = self.bn2(out.features)
-        out.features = self.relu(out.features + x.features)
+        out.features = _store(self.relu(out.features + x.features))
         return out
 
 
@@ -285,7 +323,7 @@ class RefSpMiddleResNetFHD(nn.Module):
 
     def forward(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]  # scn.py:159
-        x = RefSparseTensor(voxel_features, coors, sparse_shape, batch_size)
+        x = RefSparseTensor(_store(voxel_features), coors, sparse_shape, batch_size)
         x = self.conv_input(x)
         c1 = self.conv1(x)
         c2 = self.conv2(c1)
@@ -319,7 +357,7 @@ class RefSpMiddleFHD(nn.Module):
 
     def forward(self, voxel_features, coors, batch_size, input_shape):
         sparse_shape = np.array(input_shape[::-1]) + [1, 0, 0]
-        x = RefSparseTensor(voxel_features, coors, sparse_shape, batch_size)
+        x = RefSparseTensor(_store(voxel_features), coors, sparse_shape, batch_size)
         c4 = self.middle_conv(x)
         ret = self.extra_conv(c4).dense()
         n, c, d, h, w = ret.shape

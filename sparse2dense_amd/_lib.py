@@ -73,6 +73,16 @@ SIGNATURES = {
     "s2d_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "s2d_comm_ranks": (ctypes.c_int, []),
     "s2d_comm_shutdown": (ctypes.c_int, []),
+    "s2d_pcr_loss_workspace_bytes": (ctypes.c_size_t, []),
+    "s2d_pcr_loss_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 4 +
+                             [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_loss_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 4 +
+                             [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_dwconv7_supported": (ctypes.c_int, [ctypes.c_int]),
+    "s2d_dwconv7_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_dwconv7_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "s2d_dwconv7_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 +
+                                    [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_comm_allreduce_sum_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "s2d_conv2d3x3_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_conv2d3x3_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 7),

@@ -29,14 +29,14 @@ class SyntheticFrames:
     """Holds B seeded scenes on the device (points + targets); `example()` runs the device
     voxelizer and returns the collated dict — i.e. the per-iteration data work of the hot path."""
 
-    def __init__(self, batch_size, n_points=150000, seed=20240928, distill=False, device="cuda"):
+    def __init__(self, batch_size, n_points=150000, seed=20240928, distill=False, device="cuda", beam_jitter=2e-4):
         self.device = torch.device(device)
         self.distill = distill
         self.gens = waymo_generators(distill)
         self.points, self.dense_points, self.recon_points = [], [], []
         tg = {k: [] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
         for b in range(batch_size):
-            s = scene.make_scene(n_points, seed=seed + b)
+            s = scene.make_scene(n_points, seed=seed + b, beam_jitter=beam_jitter)
             self.points.append(torch.from_numpy(s["points"]).to(self.device))
             if distill:
                 d, r = scene.make_distill_points(s, seed=seed + 100 + b)

@@ -230,6 +230,62 @@ class Conv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+# --------------------------------------------------------------------------------------------------
+# depth-wise 7x7 convolution of the S2D ConvNeXt blocks (csrc/dwconv.hip)
+# --------------------------------------------------------------------------------------------------
+class _DwConv7Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        xb = _nhwc_bf16(x)
+        n, c, h, w = xb.shape
+        wf = weight.detach().float().contiguous()
+        y = torch.empty_like(xb)
+        check(lib.s2d_dwconv7_nhwc_bf16(_ptr(xb), _ptr(wf), _ptr(None if bias is None else bias.detach().float().contiguous()),
+                                        n, h, w, c, 0, _ptr(y), _stream()), "s2d_dwconv7_nhwc_bf16")
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xb, weight = ctx.saved_tensors
+        n, c, h, w = xb.shape
+        dyb = _nhwc_bf16(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xb)
+            check(lib.s2d_dwconv7_nhwc_bf16(_ptr(dyb), _ptr(weight.detach().float().contiguous()), None, n, h, w, c, 1, _ptr(dx),
+                                            _stream()), "s2d_dwconv7_nhwc_bf16 (data gradient)")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dwf = torch.empty((c, 1, 7, 7), dtype=torch.float32, device=xb.device)
+            dbf = torch.empty((c,), dtype=torch.float32, device=xb.device) if ctx.has_bias else None
+            ws = _ws(lib.s2d_dwconv7_wgrad_workspace_bytes(n, h, w, c), xb.device)
+            check(lib.s2d_dwconv7_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), n, h, w, c, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(),
+                                                  _stream()), "s2d_dwconv7_wgrad_nhwc_bf16")
+            dw = dwf.to(weight.dtype)
+            db = dbf
+        return dx, dw, db
+
+
+class DepthwiseConv7(nn.Conv2d):
+    """nn.Conv2d(C, C, 7, padding=3, groups=C) (same parameters / state_dict keys).  CUDA inputs under bf16 autocast run
+    the NHWC stencil kernels; anything else is the stock layer."""
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.dilation == (1, 1)
+                and self.groups == self.in_channels == self.out_channels and self.padding_mode == "zeros"
+                and self.in_channels % 8 == 0 and self.in_channels <= 640)
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            return _DwConv7Fn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class AbsorbedZeroPad2d(nn.ZeroPad2d):
     """nn.ZeroPad2d(1) whose zero border is produced inside the 3x3 conv that follows it (ZeroPad2d(1) + conv(padding=0)
     == conv(padding=1), rpn.py:129-131): keeps the reference's Sequential slot, moves no data."""

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import registry
-from .heads import mask_offset_loss, metric_grid
+from .heads import mask_offset_loss, mask_offset_loss_sparse, metric_grid
 from .registry import DETECTORS
 from .spconv import SparseConvTensor
 
@@ -133,20 +133,27 @@ class KD_VoxelNet(VoxelNet):
 
     def forward(self, example, return_loss=True, return_feature=False, **kwargs):
         batch_size = len(example["num_voxels"])
-        if return_loss:
-            recon_gt_2 = self._recon_gt(example, 2, batch_size)
-            recon_gt_4 = self._recon_gt(example, 4, batch_size)
         data = dict(features=self._read(example), coors=example["coordinates"], batch_size=batch_size,
                     input_shape=example["shape"][0])
         x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, _ = self.extract_feat(data)
         mask_loss = comp_loss = 0
         if self.training and return_loss:
-            n, _, d, h, w = recon_gt_4.shape
-            grid_4 = metric_grid(n, d, h, w, recon_gt_4)
-            m4, o4 = mask_offset_loss(gen_offset_4, gen_mask_4, recon_gt_4, grid_4)
-            n, _, d, h, w = gen_offset_2.shape
-            grid_2 = metric_grid(n, d, h, w, gen_offset_2)
-            m2, o2 = mask_offset_loss(gen_offset_2, gen_mask_2, recon_gt_2, grid_2)
+            if gen_offset_2.is_cuda and gen_offset_2.dtype == torch.float32:
+                # the reconstruction targets stay sparse: both PCR losses are evaluated at the recon voxels plus one dense
+                # reduction over the occupancy logits (csrc/losses.hip) - no [B,5,20,752,752] / [B,5,10,376,376] volumes
+                m4, o4 = mask_offset_loss_sparse(gen_offset_4, gen_mask_4, example["reconstruction_coordinates_4"],
+                                                 self._read_scaled(example, 4))
+                m2, o2 = mask_offset_loss_sparse(gen_offset_2, gen_mask_2, example["reconstruction_coordinates_2"],
+                                                 self._read_scaled(example, 2))
+            else:   # the reference's formulation (voxelnet.py:194-215,230-249), used by the CPU oracle stack
+                recon_gt_2 = self._recon_gt(example, 2, batch_size)
+                recon_gt_4 = self._recon_gt(example, 4, batch_size)
+                n, _, d, h, w = recon_gt_4.shape
+                grid_4 = metric_grid(n, d, h, w, recon_gt_4)
+                m4, o4 = mask_offset_loss(gen_offset_4, gen_mask_4, recon_gt_4, grid_4)
+                n, _, d, h, w = gen_offset_2.shape
+                grid_2 = metric_grid(n, d, h, w, gen_offset_2)
+                m2, o2 = mask_offset_loss(gen_offset_2, gen_mask_2, recon_gt_2, grid_2)
             mask_loss, comp_loss = m2 + m4, o2 + o4
         preds = self._dense(self.bbox_head, x)
         if return_loss:

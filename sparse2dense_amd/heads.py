@@ -100,6 +100,46 @@ def mask_offset_loss(gen_offset, gen_mask, gt, grid):
     return loss, com
 
 
+class _PcrLossFn(torch.autograd.Function):
+    """mask_offset_loss from the sparse recon voxels (csrc/losses.hip): no dense target, no metric grid tensor"""
+
+    @staticmethod
+    def forward(ctx, gen_offset, gen_mask, coors, feats):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        lib = _lib.load()
+        gen_offset, gen_mask = gen_offset.contiguous(), gen_mask.contiguous()
+        coors, feats = coors.contiguous(), feats.contiguous()
+        b, _, d, h, w = gen_offset.shape
+        assert gen_mask.shape == (b, 1, d, h, w) and gen_offset.shape[1] == 3 and feats.shape[1] == 5
+        out = torch.empty(8, dtype=torch.float32, device=gen_offset.device)
+        ws = _ws(lib.s2d_pcr_loss_workspace_bytes(), gen_offset.device)
+        _lib.check(lib.s2d_pcr_loss_fwd_f32(_ptr(gen_offset), _ptr(gen_mask), _ptr(coors), _ptr(feats), coors.shape[0], b, d, h, w,
+                                            _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_loss_fwd_f32")
+        ctx.save_for_backward(gen_offset, gen_mask, coors, feats, out)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, go_mask, go_off):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        lib = _lib.load()
+        gen_offset, gen_mask, coors, feats, out = ctx.saved_tensors
+        b, _, d, h, w = gen_offset.shape
+        g_mask = torch.empty_like(gen_mask) if ctx.needs_input_grad[1] else None
+        g_off = torch.zeros_like(gen_offset) if ctx.needs_input_grad[0] else None
+        _lib.check(lib.s2d_pcr_loss_bwd_f32(_ptr(gen_offset), _ptr(gen_mask), _ptr(coors), _ptr(feats), coors.shape[0], b, d, h, w,
+                                            _ptr(out), _ptr(go_mask.float().contiguous()), _ptr(go_off.float().contiguous()),
+                                            _ptr(g_mask), _ptr(g_off), _stream()), "s2d_pcr_loss_bwd_f32")
+        return g_off, g_mask, None, None
+
+
+def mask_offset_loss_sparse(gen_offset, gen_mask, coors, feats):
+    """`mask_offset_loss(gen_offset, gen_mask, SparseConvTensor(feats, coors, [D,H,W]).dense(), metric_grid(...))`
+    (voxelnet.py:171-185,203-249) without the dense target: CUDA fp32 only."""
+    return _PcrLossFn.apply(gen_offset, gen_mask, coors if coors.dtype == torch.int32 else coors.int(), feats.float())
+
+
 def metric_grid(n, d, h, w, like):
     """Cell-centre metric coordinates (x,y,z) of a [D,H,W] grid over the Waymo range
     (voxelnet.py:232-236; the x step reuses 150.4/H exactly as the reference does)."""

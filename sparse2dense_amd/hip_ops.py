@@ -153,9 +153,17 @@ class ConvRulebookJob:
 
     def count(self):
         n = self.coors.shape[0]
+        self._rec = None
+        if PROFILE is not None:
+            self._rec = dict(kernel="rulebook_conv", tag="rulebook", cin=0, cout=0, n_in=int(n), kvol=self.kvol,
+                             start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
+                             start2=torch.cuda.Event(enable_timing=True), end2=torch.cuda.Event(enable_timing=True))
+            self._rec["start"].record()
         check(self.lib.s2d_rulebook_conv_count(_ptr(self.coors), n, self.batch, i3(self.shape), i3(self.ksize),
                                                i3(self.stride), i3(self.padding), i3(self.dilation), _ptr(self.out_n),
                                                _ptr(self.ws), self.ws.numel(), _stream()), "s2d_rulebook_conv_count")
+        if self._rec is not None:
+            self._rec["end"].record()
         return self
 
     def finish(self) -> Rulebook:
@@ -166,10 +174,17 @@ class ConvRulebookJob:
         nbr_out = torch.empty((self.kvol, n_out), dtype=torch.int32, device=dev)
         nbr_in = torch.empty((self.kvol, n), dtype=torch.int32, device=dev)
         cnt = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+        rec = getattr(self, "_rec", None)
+        if rec is not None:
+            rec["start2"].record()
         check(self.lib.s2d_rulebook_conv_fill(_ptr(self.coors), n, self.batch, i3(self.shape), i3(self.ksize),
                                               i3(self.stride), i3(self.padding), i3(self.dilation), n_out,
                                               _ptr(out_coors), _ptr(nbr_out), _ptr(nbr_in), _ptr(cnt), _ptr(self.ws),
                                               self.ws.numel(), _stream()), "s2d_rulebook_conv_fill")
+        if rec is not None and PROFILE is not None:
+            rec["end2"].record()
+            rec.update(n_out=int(n_out), pairs=cnt)
+            PROFILE.append(rec)
         return Rulebook(False, self.kvol, n, n_out, nbr_out, nbr_in, cnt, out_coors, self.out_shape)
 
 

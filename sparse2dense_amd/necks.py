@@ -5,8 +5,9 @@
                                                                         + the RPN trunk on F_S_a)
 Module names / Sequential indices are the reference's, so state_dicts are interchangeable
 (`blocks.0.1.weight` — index 0 is the ZeroPad2d; `encoder_1.0.weight`; `generator_2.3.weight` ...).
-Round-1 status: these dense layers run on PyTorch-ROCm's conv/GEMM kernels (MIOpen / hipBLASLt);
-the hand-written MFMA dense-conv kernels are the next row of DESIGN.md §"what comes next".
+Under bf16 autocast on NHWC inputs the layers run on the hand-written kernels behind `dense2d` / `dense3d`
+(3x3 convs, depth-wise 7x7, batch norms, the PCR head); layers without a kernel of ours, fp32 runs and CPU
+inputs take the stock torch layer (DESIGN.md section 3 lists which).
 """
 import numpy as np
 import torch
@@ -14,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv3x3, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .registry import NECKS
 
@@ -116,7 +117,7 @@ def _cbg(*convs_and_channels):
 
 
 def _convnext(c, hw):
-    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
+    return nn.Sequential(DepthwiseConv7(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
                          nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
 
 
@@ -170,7 +171,9 @@ class S2D_RPN(RPN):
             # PCR head in fp32 / standard layout: its 3-D convs are memory-bound, and MIOpen's
             # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
             with torch.autocast("cuda", enabled=False):
-                gen = gen.float().contiguous().view(n, 128, 5, h, w)
+                if gen.dtype in (torch.bfloat16, torch.float16):
+                    gen = gen.float()
+                gen = gen.contiguous().view(n, 128, 5, h, w)
                 gen = self.generator_1(gen)
                 gen_offset_4 = self.gen_out_4(gen)
                 gen_mask_4 = self.gen_mask_4(gen)

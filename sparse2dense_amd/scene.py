@@ -15,6 +15,7 @@ WAYMO_RANGE = (-75.2, -75.2, -2.0, 75.2, 75.2, 4.0)
 WAYMO_VOXEL = (0.1, 0.1, 0.15)
 PILLAR_RANGE = (-74.88, -74.88, -2.0, 74.88, 74.88, 4.0)
 PILLAR_VOXEL = (0.32, 0.32, 6.0)
+WAYMO_BEAM_JITTER = 2.5e-3   # see make_scene(beam_jitter=...)
 
 
 def _ray_box(origin, dirs, center, size, yaw):
@@ -39,7 +40,7 @@ def _ground(x, y):
 
 
 def make_scene(n_points=150000, seed=20240928, n_cars=100, n_walls=25, n_peds=40,
-               pc_range=WAYMO_RANGE, return_objects=True):
+               pc_range=WAYMO_RANGE, return_objects=True, beam_jitter=2e-4):
     """One LiDAR sweep: 64 beams x 2650 azimuths ray-cast against an undulating ground, walls,
     car-sized boxes and pedestrian-sized posts; cropped to `pc_range`, resampled to exactly
     `n_points` rows and shuffled (the reference shuffles too, preprocess.py:257-260).
@@ -52,8 +53,11 @@ def make_scene(n_points=150000, seed=20240928, n_cars=100, n_walls=25, n_peds=40
     elev = np.deg2rad(-17.6 + 20.0 * np.linspace(0.0, 1.0, 64) ** 0.7)  # denser near the horizon
     azim = np.linspace(-math.pi, math.pi, 2650, endpoint=False)
     ee, aa = np.meshgrid(elev, azim, indexing="ij")
-    ee = ee.ravel() + rs.normal(0, 2e-4, ee.size)
-    aa = aa.ravel() + rs.normal(0, 2e-4, aa.size)
+    # beam_jitter (rad): per-return pointing noise.  2e-4 keeps the 64 rings razor thin (M ~ 65-70 k voxels per 150 k
+    # points: the sparse end of Waymo); WAYMO_BEAM_JITTER spreads them over neighbouring cells the way ego-motion
+    # compensation and the four short-range lidars do in real sweeps (M ~ 100 k, SURVEY 8(d)'s 90-130 k bracket).
+    ee = ee.ravel() + rs.normal(0, beam_jitter, ee.size)
+    aa = aa.ravel() + rs.normal(0, beam_jitter, aa.size)
     dirs = np.stack([np.cos(ee) * np.cos(aa), np.cos(ee) * np.sin(aa), np.sin(ee)], axis=1)
 
     # ground: flat-plane hit refined twice against the height field

@@ -79,3 +79,43 @@ def check_digest_norm(t, npz, prefix, tol):
     err = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
     assert err <= tol, (prefix, err)
     assert abs(d["absmean"] - npz[f"{prefix}.absmean"]) <= tol * abs(npz[f"{prefix}.absmean"]) + 1e-12, prefix
+
+
+class _RoundBf16STE(torch.autograd.Function):
+    """x -> bf16 -> x.dtype in the forward, the same rounding on the gradient in the backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def bf16_emulation_copy(module):
+    """Float64 host copy of a 2-D neck / head whose leaf layers (convs, transposed convs, batch norms incl. their fused
+    ReLU, activations, layer norms) round their OUTPUT - and the gradient flowing back through it - to bf16, and whose
+    conv weights are rounded to bf16: the storage roundings of the product's bf16 NHWC mode with exact accumulation in
+    between.  3-D (PCR) layers stay unrounded: the product runs them in fp32."""
+    import copy
+    from torch import nn
+    m = copy.deepcopy(module).cpu().double()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (nn.Conv2d, nn.ConvTranspose2d)):
+                mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
+    leaf2d = (nn.Conv2d, nn.ConvTranspose2d, nn.BatchNorm2d, nn.GELU, nn.ReLU, nn.LayerNorm)
+
+    def hook(_mod, _inp, out):
+        return _RoundBf16STE.apply(out) if torch.is_tensor(out) and out.dim() == 4 else out
+
+    for mod in m.modules():
+        if isinstance(mod, leaf2d):
+            mod.register_forward_hook(hook)
+    return m
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()

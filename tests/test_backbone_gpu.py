@@ -210,13 +210,59 @@ def test_s16_storage_mode_within_stated_tolerance():
         l16.backward()
         assert abs(l16.item() - l32.item()) <= 5e-2 * abs(l32.item()), (l16.item(), l32.item())
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
-        # gradient direction of the sparse stack agrees with the fp32 run (norm-wise, the big conv weights)
-        for n, p in model.named_parameters():
-            if n.startswith("backbone.") and n.endswith("weight") and p.dim() == 5 and n in g32:
-                cos = torch.nn.functional.cosine_similarity(p.grad.flatten(), g32[n].flatten(), dim=0).item()
-                assert cos > 0.6, (n, cos)   # measured r01: 0.71-0.80 (mixed bf16 mode: 0.82-0.88, bf16 dense alone: 0.92-0.94)
     finally:
         H.set_sparse_compute_dtype("f32")
+
+
+def _round_conv_weights_to_bf16(module):
+    """the s16 kernels read bf16 weight images: start both sides from weights that are exactly representable"""
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.dim() == 5:
+                p.copy_(p.to(torch.bfloat16).to(p.dtype))
+    return module
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_s16_backbone_gradients_vs_bf16_storage_oracle(train):
+    """The BENCHMARKED mode (bf16 feature storage) against the float64 oracle restated with the same storage roundings
+    (oracle/spconv_ref.py `bf16_storage`: input, every conv output, every fused BN(+residual)(+ReLU) output and the
+    gradients flowing back through those points are rounded to bf16; accumulation and statistics exact).  What is left
+    is fp32-vs-exact accumulation, i.e. rare one-bf16-ulp flips.  Eval-mode BN (the teacher's mode) is well conditioned:
+    tight norm-wise bars.  Train-mode BN: the same bars, or at most 3x the error the fp32 CPU restatement itself shows
+    against float64 (the `_compare_grads(ref32=...)` calibration of the conditioning)."""
+    from sparse2dense_amd import hip_ops as H
+    feats, coors = _scene_voxels(8000, seed=7, batch=2)
+    grid = np.array([1504, 1504, 40])
+    mk = lambda m: (m.train() if train else m.eval())
+    net = mk(_round_conv_weights_to_bf16(fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5)))))
+    ref = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5))).double())
+    ref32 = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5)))) if train else None
+    g = torch.randn((2, 256, 188, 188), generator=torch.Generator().manual_seed(5))
+    with R.bf16_storage():
+        b, ms_ref = ref(torch.from_numpy(feats).double(), coors, 2, grid)
+        (b * g.double()).sum().backward()
+        if train:
+            b32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
+            (b32 * g).sum().backward()
+    net = net.to(DEV)
+    H.set_sparse_compute_dtype("s16")
+    try:
+        a, ms = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
+        (a * g.to(DEV)).sum().backward()
+    finally:
+        H.set_sparse_compute_dtype("f32")
+    assert ms["conv4"].features.dtype == torch.bfloat16
+    err = ((a.cpu().double() - b).norm() / b.norm()).item()
+    e32 = ((b32.double() - b).norm() / b.norm()).item() if train else 0.0
+    print(f"s16 vs bf16-storage oracle (train={train}): forward {err:.2e} (fp32 oracle {e32:.2e})")
+    assert err <= max(5e-3, 3 * e32), err
+    for k in ["conv1", "conv2", "conv3", "conv4"]:
+        fe = ((ms[k].features.double().cpu() - ms_ref[k].features).norm() / ms_ref[k].features.norm()).item()
+        assert fe <= max(5e-3, 3 * e32), (k, fe)
+    errs = _rel_errors(_grad_dict(net), _grad_dict(ref))
+    print("  gradient errors:", {k: f"{v:.1e}" for k, v in sorted(errs.items()) if k.endswith("weight") and "conv" in k})
+    _compare_grads(net, ref, tol=1e-2, ref32=ref32)
 
 
 def test_second_config1_forward_vs_cpu_reference_path():

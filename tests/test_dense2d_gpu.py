@@ -1,4 +1,5 @@
-"""Dense 3x3 NHWC bf16 MFMA convolution (csrc/conv2d_nhwc.hip) against torch fp32 on the same bf16-rounded operands.
+"""Dense 3x3 NHWC bf16 MFMA convolution (csrc/conv2d_nhwc.hip) against a CPU convolution (torch on the host, fp32
+accumulate - not MIOpen on the same GPU) on the same bf16-rounded operands.
 
 Tolerance: inputs/weights are rounded to bf16 once (both sides see the rounded values), products accumulate in
 fp32 on both sides, the kernel rounds its output to bf16 -> |err| <= 2^-8 relative to the output scale (+ accumulation
@@ -9,6 +10,20 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+def _cpu_conv(x, w, b, padding, stride=1):
+    """the reference convolution: on the HOST (never MIOpen), returned on the device for comparison"""
+    out = F.conv2d(x.detach().float().cpu().contiguous(), w.detach().float().cpu(), None if b is None else b.detach().float().cpu(),
+                   padding=padding, stride=stride)
+    return out.to(x.device)
+
+
+def _cpu_conv_grads(x, w, dy, padding, stride=1):
+    xr = x.detach().float().cpu().contiguous().requires_grad_(True)
+    wr = w.detach().float().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=padding, stride=stride).backward(dy.detach().float().cpu().contiguous())
+    return xr.grad.to(x.device), wr.grad.to(x.device)
+
 
 CASES = [(2, 64, 64, 20, 24, 1), (1, 128, 192, 17, 19, 0), (3, 64, 128, 33, 9, 1), (1, 256, 64, 130, 7, 0),
          (2, 128, 128, 47, 47, 1)]
@@ -30,16 +45,15 @@ def test_forward_and_dgrad(n, cin, cout, h, w, pad, w_nhwc):
     wsrc = wt.contiguous(memory_format=torch.channels_last) if w_nhwc else wt
     wr = wt.to(torch.bfloat16).float()
     y = D.conv3x3_nhwc(x, D.pack_weights(wsrc), b, cin, cout, pad)
-    ref = F.conv2d(x.float(), wr, b, padding=pad)
+    ref = _cpu_conv(x, wr, b, pad)
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     assert (y.float() - ref).abs().max() <= 6e-3 * ref.abs().max()
     dy = torch.randn_like(ref).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    xr = x.float().requires_grad_(True)
-    F.conv2d(xr, wr, None, padding=pad).backward(dy.float())
+    dx_ref, _ = _cpu_conv_grads(x, wr, dy, pad)
     src = dy if pad == 1 else F.pad(dy, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
     dx = D.conv3x3_nhwc(src, D.pack_weights(wsrc, True), None, cout, cin, 1)
     assert dx.shape == x.shape
-    assert (dx.float() - xr.grad).abs().max() <= 6e-3 * xr.grad.abs().max()
+    assert (dx.float() - dx_ref).abs().max() <= 6e-3 * dx_ref.abs().max()
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,pad,rows", [(4, 128, 128, 188, 188, 1, 128), (4, 256, 256, 94, 94, 1, 96),
@@ -51,7 +65,7 @@ def test_bev_sized_launches_cover_every_tile_height(n, cin, cout, h, w, pad, row
     from sparse2dense_amd import _lib, dense2d as D
     x, wt, b = _mk(n, cin, cout, h, w, seed=11)
     y, part = D.conv3x3_nhwc(x, D.pack_weights(wt), b, cin, cout, pad, bn_stats=True)
-    ref = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), b, padding=pad)
+    ref = _cpu_conv(x, wt.to(torch.bfloat16).float(), b, pad)
     assert (y.float() - ref).abs().max() <= 6e-3 * ref.abs().max()
     m = n * ref.shape[2] * ref.shape[3]
     tiles = _lib.load().s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, 1)
@@ -78,8 +92,8 @@ def test_module_autograd_matches_stock_conv(pad, bias, wgrad_hip, monkeypatch):
     monkeypatch.setattr(D, "WGRAD_HIP", wgrad_hip)   # MIOpen's and the hand-written weight-gradient kernel
     torch.manual_seed(1)
     m = D.Conv3x3(64, 128, 3, padding=pad, bias=bias).cuda()
-    ref = torch.nn.Conv2d(64, 128, 3, padding=pad, bias=bias).cuda()
-    ref.load_state_dict(m.state_dict())
+    ref = torch.nn.Conv2d(64, 128, 3, padding=pad, bias=bias)   # stays on the HOST: the reference is a CPU convolution
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     x = torch.randn(2, 64, 40, 36, device="cuda")
     dy = torch.randn(2, 128, 40 + 2 * pad - 2, 36 + 2 * pad - 2, device="cuda")
     xa = x.clone().requires_grad_(True)
@@ -87,15 +101,16 @@ def test_module_autograd_matches_stock_conv(pad, bias, wgrad_hip, monkeypatch):
         ya = m(xa)
     assert ya.dtype == torch.bfloat16
     ya.backward(dy.to(torch.bfloat16))
-    # reference in fp32 on bf16-rounded operands
-    xb = x.to(torch.bfloat16).float().requires_grad_(True)
+    # reference in fp32 on bf16-rounded operands, on the CPU
+    xb = x.to(torch.bfloat16).float().cpu().requires_grad_(True)
     with torch.no_grad():
         ref.weight.copy_(ref.weight.to(torch.bfloat16).float())
     yr = ref(xb)
-    yr.backward(dy.to(torch.bfloat16).float())
+    yr.backward(dy.to(torch.bfloat16).float().cpu())
 
     def close(a, r, tol):
-        assert (a.float() - r).abs().max() <= tol * r.abs().max(), (a.float() - r).abs().max() / r.abs().max()
+        a, r = a.float().cpu(), r.float().cpu()
+        assert (a - r).abs().max() <= tol * r.abs().max(), (a - r).abs().max() / r.abs().max()
     close(ya, yr, 6e-3)
     close(xa.grad, xb.grad, 6e-3)
     close(m.weight.grad, ref.weight.grad, 1e-2)      # MIOpen bf16 wgrad (bf16 output rounding)
@@ -237,10 +252,10 @@ def test_conv3x3_wgrad_matches_float64(n, cin, cout, h, w, pad):
     ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
     dy = torch.randn(n, cout, ho, wo, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dw = D.conv3x3_wgrad(x, dy, pad)
-    wr = wt.double().requires_grad_(True)
-    F.conv2d(x.double(), wr, None, padding=pad).backward(dy.double())
+    wr = wt.double().cpu().requires_grad_(True)   # float64 on the host
+    F.conv2d(x.double().cpu().contiguous(), wr, None, padding=pad).backward(dy.double().cpu().contiguous())
     assert dw.shape == wr.grad.shape and dw.dtype == torch.float32
-    err = (dw.double() - wr.grad).abs().max() / wr.grad.abs().max()
+    err = (dw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max()
     assert err <= 1e-3, float(err)
 
 
@@ -250,7 +265,7 @@ def test_stride2_forward_and_module_backward(pad):
     from sparse2dense_amd import dense2d as D
     x, wt, b = _mk(2, 128, 256, 41, 38, seed=5)
     y = D.conv3x3_nhwc(x, D.pack_weights(wt), b, 128, 256, pad, stride=2)
-    ref = F.conv2d(x.float(), wt.to(torch.bfloat16).float(), b, padding=pad, stride=2)
+    ref = _cpu_conv(x, wt.to(torch.bfloat16).float(), b, pad, stride=2)
     assert y.shape == ref.shape
     assert (y.float() - ref).abs().max() <= 6e-3 * ref.abs().max()
     m = D.Conv3x3(128, 256, 3, stride=2, padding=pad, bias=False).cuda()
@@ -258,11 +273,11 @@ def test_stride2_forward_and_module_backward(pad):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ya = m(xa)
     ya.float().sum().backward()
-    xr = x.float().requires_grad_(True)
-    yr = F.conv2d(xr, m.weight.detach().to(torch.bfloat16).float(), None, padding=pad, stride=2)
+    xr = x.float().cpu().contiguous().requires_grad_(True)
+    yr = F.conv2d(xr, m.weight.detach().to(torch.bfloat16).float().cpu(), None, padding=pad, stride=2)
     yr.sum().backward()
-    assert (ya.float() - yr).abs().max() <= 6e-3 * yr.abs().max()
-    assert (xa.grad - xr.grad).abs().max() <= 1e-2 * xr.grad.abs().max()
+    assert (ya.float().cpu() - yr).abs().max() <= 6e-3 * yr.abs().max()
+    assert (xa.grad.cpu() - xr.grad).abs().max() <= 1e-2 * xr.grad.abs().max()
 
 
 @pytest.mark.parametrize("cin,cout,pad,stride", [(64, 128, 1, 1), (128, 64, 0, 1), (128, 256, 0, 2), (512, 64, 1, 1)])
@@ -306,3 +321,38 @@ def test_wide_layernorm_matches_stock():
     assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
     assert torch.allclose(m.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5) and torch.allclose(m.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Depth-wise 7x7 (csrc/dwconv.hip) vs torch's grouped conv in float64 on the HOST, same bf16-rounded operands.
+# Tolerance: bf16 outputs (y, dx) one output rounding = 6e-3 of max; fp32 outputs (dW, db) 2e-3 of max.
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,h,w", [(4, 256, 47, 47), (1, 64, 9, 5), (2, 8, 20, 33), (1, 512, 59, 59)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_depthwise7_forward_backward_vs_cpu_float64(n, c, h, w, bias):
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(4)
+    m = D.DepthwiseConv7(c, c, 7, padding=3, groups=c, bias=bias).cuda()
+    x = torch.randn(n, c, h, w, device="cuda").to(torch.bfloat16).float()
+    dy = torch.randn(n, c, h, w, device="cuda").to(torch.bfloat16).float()
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert m._hip_ok(xa)
+        ya = m(xa)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy.to(torch.bfloat16))
+    ref = torch.nn.Conv2d(c, c, 7, padding=3, groups=c, bias=bias).double()
+    ref.load_state_dict({k: v.cpu().double() for k, v in m.state_dict().items()})
+    xr = x.cpu().double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.cpu().double())
+
+    def close(a, r, tol):
+        a, r = a.double().cpu(), r.double()
+        assert (a - r).abs().max() <= tol * r.abs().max(), float((a - r).abs().max() / r.abs().max())
+    close(ya, yr, 6e-3)
+    close(xa.grad, xr.grad, 6e-3)
+    close(m.weight.grad, ref.weight.grad, 2e-3)
+    if bias:
+        close(m.bias.grad, ref.bias.grad, 2e-3)
+    assert m(x).dtype == torch.float32   # no autocast: the stock layer

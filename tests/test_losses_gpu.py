@@ -1,0 +1,51 @@
+"""PCR losses from the sparse recon voxels (csrc/losses.hip) against the reference's dense formulation
+(/root/reference/det3d/models/detectors/voxelnet.py:171-185,203-249 = heads.mask_offset_loss on the densified target and
+heads.metric_grid, both pinned to the reference by tests/golden/losses.npz) evaluated in float64 on the host.
+Tolerance: fp32 sums of ~1e5..1e7 softplus terms: 1e-5 relative on the values, 1e-5 of max on the gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sparse2dense_amd import heads
+
+
+def _case(b, d, h, w, m, seed, special=True):
+    g = torch.Generator().manual_seed(seed)
+    cells = torch.randperm(b * d * h * w, generator=g)[:m]
+    coors = torch.stack([cells // (d * h * w), (cells // (h * w)) % d, (cells // w) % h, cells % w], 1).int()
+    grid = heads.metric_grid(b, d, h, w, torch.zeros(1))
+    centre = grid[coors[:, 0].long(), :, coors[:, 1].long(), coors[:, 2].long(), coors[:, 3].long()]   # [m,3]
+    feats = torch.cat([centre + torch.randn(m, 3, generator=g) * 0.05, torch.rand(m, 2, generator=g)], 1).float()
+    if special and m >= 4:
+        feats[0] = torch.tensor([1.0, -1.0, 0.25, -0.25, 0.0])       # feature sum exactly 0: not an occupied cell, but tgt = f != 0
+        feats[1, 0] = centre[1, 0]                                     # one target component exactly 0: not selected
+        feats[2] = 0.0                                                 # all-zero voxel: contributes nothing
+    gen_off = torch.randn(b, 3, d, h, w, generator=g)
+    gen_mask = torch.randn(b, 1, d, h, w, generator=g) * 3
+    return coors, feats, gen_off, gen_mask
+
+
+@pytest.mark.parametrize("b,d,h,w,m", [(2, 6, 20, 24, 300), (1, 5, 17, 9, 40), (4, 10, 94, 94, 20000)])
+def test_pcr_sparse_losses_match_dense_formulation(b, d, h, w, m):
+    coors, feats, gen_off, gen_mask = _case(b, d, h, w, m, seed=b * 7 + m)
+    # reference: dense target + metric grid, float64, host
+    gt = torch.zeros(b, d, h, w, 5, dtype=torch.float64)
+    c = coors.long()
+    gt[c[:, 0], c[:, 1], c[:, 2], c[:, 3]] = feats.double()
+    gt = gt.permute(0, 4, 1, 2, 3).contiguous()
+    grid = heads.metric_grid(b, d, h, w, torch.zeros(1)).double()
+    # the grid must be the fp32 one the reference computes (tgt != 0 is an exact test)
+    ro, rm = gen_off.double().requires_grad_(True), gen_mask.double().requires_grad_(True)
+    ml_ref, ol_ref = heads.mask_offset_loss(ro, rm, gt, grid)
+    (1.7 * ml_ref + 0.6 * ol_ref).backward()
+    go = gen_off.cuda().requires_grad_(True)
+    gm = gen_mask.cuda().requires_grad_(True)
+    ml, ol = heads.mask_offset_loss_sparse(go, gm, coors.cuda(), feats.cuda())
+    (1.7 * ml + 0.6 * ol).backward()
+    np.testing.assert_allclose(ml.item(), ml_ref.item(), rtol=1e-5)
+    np.testing.assert_allclose(ol.item(), ol_ref.item(), rtol=1e-5)
+    for a, r in ((go.grad, ro.grad), (gm.grad, rm.grad)):
+        assert (a.double().cpu() - r).abs().max() <= 1e-5 * r.abs().max(), float((a.double().cpu() - r).abs().max() / r.abs().max())
+    assert int((go.grad != 0).sum()) == int((ro.grad != 0).sum())

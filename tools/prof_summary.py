@@ -32,7 +32,7 @@ def main():
     ours = sum(v[0] for k, v in agg.items() if "s2d::" in k)
     print(f"# hand-written s2d:: kernels {ours / 1e6:.3f} ms ({100 * ours / tot:.1f} %)")
     print("# share   total_ms  calls  avg_us   kernel")
-    for n, (dur, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+    for n, (dur, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:220]:
         print(f"{100 * dur / tot:6.2f}% {dur / 1e6:9.3f} {c:6d} {dur / c / 1e3:8.1f}   {n[:140]}")
 
 
