@@ -337,6 +337,28 @@ int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_wei
                        int cout, const void *zero_page, void *out_feat, s2d_stream_t stream);
 
 /*
+ * Submanifold 3x3x3 sparse convolution, bf16 storage, "neighbourhood-resident" implicit GEMM (csrc/spconv_nb.hip): same
+ * contract as s2d_spconv_s16_fwd for cin == cout == channels in {16,32,64,128} and kvol == 27, driven by a TILE PLAN built
+ * once per rulebook from its gather map nbr[27][n]: rows are grouped into tiles of s2d_spconv_nb_tile_rows(channels) rows in
+ * the order `perm` (a spatially blocked permutation of the rows, or NULL for the identity), each tile lists the distinct
+ * input rows its offsets touch and a local gather map.  The kernel keeps a tile's input rows resident in LDS.  The data
+ * gradient is the same entry with the weight image packed with transpose=1, flip=1 (SubM map is symmetric).
+ * stats (optional): fp32 [tiles][2][channels] per-tile sum / sum of squares of the stored outputs (batch-norm statistics).
+ */
+int s2d_spconv_nb_supported(int channels, int kvol);
+int s2d_spconv_nb_tile_rows(int channels);
+int s2d_spconv_nb_plan_sizes(int channels, int64_t n, int64_t sizes[6]);
+int s2d_spconv_nb_plan_build(const int32_t *nbr, const int32_t *perm, int64_t n, int channels, int32_t *rows,
+                             int32_t *u, int32_t *in_rows, uint16_t *lnbr, uint32_t *act, s2d_stream_t stream);
+size_t s2d_spconv_nb_packed_elems(int channels);
+int s2d_spconv_nb_pack_weights(const float *weight, int channels, int transpose, int flip, void *packed,
+                               s2d_stream_t stream);
+int s2d_spconv_nb_fwd(const void *in_feat, const void *packed_weight, const float *bias,
+                      const int32_t *plan_rows, const int32_t *plan_u, const int32_t *plan_in,
+                      const uint16_t *plan_lnbr, const uint32_t *plan_act, int64_t n_tiles, int channels,
+                      const void *zero_page, void *out_feat, float *stats, s2d_stream_t stream);
+
+/*
  * Weight gradient of the dense 3x3 stride-1 convolution above (replaces the cuDNN backward-filter call):
  * x [n][h][w][cin] bf16 (the forward input), dy [n][ho][wo][cout] bf16, dweight fp32 in the torch layout
  * [cout][cin][3][3].  cin, cout multiples of 64.  Pixels are contracted on v_mfma_f32_16x16x32_bf16 through LDS
@@ -362,6 +384,31 @@ size_t s2d_dwconv7_wgrad_workspace_bytes(int n_img, int h, int w, int c);
 int s2d_dwconv7_wgrad_nhwc_bf16(const void *x, const void *dy, int n_img, int h, int w, int c,
                                 float *dweight, float *dbias, void *ws, size_t ws_bytes,
                                 s2d_stream_t stream);
+
+/*
+ * ConvTranspose3d(kernel 4, stride 2, padding 1) of the PCR head on the bf16 matrix cores (bf16 compute mode;
+ * det3d/models/necks/rpn.py:263-296: 32->32 and 16->3).  Tensors are NCDHW fp32 exactly as in s2d_convt3d_k4s2p1_*_f32;
+ * activations and weights are rounded to bf16 while staged, accumulation is fp32.  cin in {16, 32}, cout <= 32.
+ * `packed` = s2d_convt3d_mfma_packed_elems bf16 elements holding the forward and data-gradient weight images (rebuild it
+ * whenever the weight changes).
+ */
+int s2d_convt3d_mfma_supported(int cin, int cout);
+size_t s2d_convt3d_mfma_packed_elems(int cin, int cout);
+int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream);
+int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout,
+                         int d, int h, int w, float *out, s2d_stream_t stream);
+int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int cin, int cout, int d, int h,
+                           int w, float *din, s2d_stream_t stream);
+size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w);
+int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int cin, int cout, int d, int h,
+                           int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/* weight (+ bias) gradient of the 1x1x1 Conv3d layers of the PCR head: dweight[cout][cin] = sum_{n,p} dout[n][co][p] in[n][ci][p],
+ * dbias[cout] = sum dout (NCDHW fp32 tensors, positions % 4 == 0); deterministic two-stage reduction */
+size_t s2d_pointwise_conv_wgrad_workspace_bytes(int cin, int cout);
+int s2d_pointwise_conv_wgrad_f32(const float *in, const float *dout, int batch, int cin, int cout,
+                                 int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                 s2d_stream_t stream);
 
 /*
  * PCR (point-cloud reconstruction) losses of the S2D student, det3d/models/detectors/voxelnet.py:171-185,203-249

@@ -1,0 +1,592 @@
+// ConvTranspose3d(kernel 4, stride 2, padding 1) of the PCR head (/root/reference/det3d/models/necks/rpn.py:263-296:
+// 32->32 on [B,32,5,188,188] and 16->3 on [B,16,10,376,376]) on the bf16 matrix cores, for the bf16 compute mode.
+// Tensors stay NCDHW fp32 in HBM (what the neighbouring layers and the loss read); operands are rounded to bf16 while
+// they are staged, accumulation is fp32.  r02 baseline (fp32 VALU / fp32 MFMA kernels of dense3d.hip, B=4):
+// forward 3.7 + 1.05 ms, data gradient 2 x 2.06 ms, weight gradient 10.9 + 4.9 ms per step.
+//
+// Geometry: out o = 2h - 1 + k per axis (k = 0..3).  Output parity p = o & 1 selects two taps per axis:
+//   p = 0 (o = 2h'):   (k = 1, h = h'), (k = 3, h = h' - 1)        p = 1 (o = 2h' + 1): (k = 0, h = h' + 1), (k = 2, h = h')
+// so each of the 8 output parity classes is a dense 2x2x2 convolution over the input (forward), every input cell
+// gathers 4x4x4 output positions (data gradient), and dW[ci][co][k] correlates x with the stride-2 sampled dout.
+//
+//   ct_fwd_mfma<CIN, NT>     block = one input row (n,hz,hy) x 64 cells; the 3x3 neighbouring rows are staged in LDS as
+//                            [row][x][ci] bf16 (ci innermost: an A fragment = one ds_read_b128); wave w owns the output rows
+//                            (pz,py) = (w>>1, w&1), both px; B = pre-packed weight fragments straight from L2.
+//   ct_dgrad_mfma<COP, NT, G> block = one input row x 64 cells; G of the 16 (kz,ky) output rows are staged per round as
+//                            de-interleaved arrays T[kx][c][co] = dout[co][2c-1+kx] (co innermost); wave w owns 16 cells.
+//   ct_wgrad_mfma<CIT, COT, KG> no LDS staging: M = ci, N = co, K = cells of a row; lanes load their A / B fragments
+//                            straight from the planar tensors (one 18-float window of dout feeds the 4 kx fragments).
+#include "s2d_common.h"
+#include <algorithm>
+
+namespace s2d {
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
+
+struct CtDims {
+    int n, d, h, w;   // batch and INPUT extents; output is 2d x 2h x 2w
+    int cin, cout;
+};
+
+// tap tables: for parity p and tap a in {0,1}: kernel index and input offset
+__device__ __forceinline__ int ct_k(int p, int a) { return p ? (a ? 2 : 0) : (a ? 3 : 1); }
+__device__ __forceinline__ int ct_d(int p, int a) { return p ? (a ? 0 : 1) : (a ? -1 : 0); }
+
+// ---- weight packing ------------------------------------------------------------------------------
+// forward image: [class 8 = pz*4+py*2+px][kstep][nt][lane 64][8]; K index kk = 8q+e within a k-step:
+//   CIN = 32: kstep = tap (a*4+b*2+c), ci = kk ;  CIN = 16: kstep = tap >> 1, tap = 2*kstep + (kk >> 4), ci = kk & 15
+// column n = lane & 15 -> co = nt*16 + n.
+__global__ __launch_bounds__(256) void ct_pack_fwd_kernel(const float *__restrict__ w, int cin, int cout, int nt_count, __bf16 *__restrict__ out) {
+    const int ksteps = cin == 32 ? 8 : 4;
+    const int total = 8 * ksteps * nt_count * 64 * 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int r = i;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % nt_count; r /= nt_count;
+    const int ks = r % ksteps; r /= ksteps;
+    const int cls = r;
+    const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    const int kk = 8 * (lane >> 4) + e;
+    const int tap = cin == 32 ? ks : 2 * ks + (kk >> 4);
+    const int ci = cin == 32 ? kk : (kk & 15);
+    const int a = tap >> 2, b = (tap >> 1) & 1, c = tap & 1;
+    const int co = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (co < cout) v = w[((((int64_t)ci * cout + co) * 4 + ct_k(pz, a)) * 4 + ct_k(py, b)) * 4 + ct_k(px, c)];
+    out[i] = (__bf16)v;
+}
+
+// data-gradient image: [kzky 16][kstep][nt (ci tiles)][lane][8]; COP = 32: kstep = kx, co = kk ; COP = 8: one k-step,
+// kx = kk >> 3, co = kk & 7.  column n -> ci = nt*16 + n.
+__global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restrict__ w, int cin, int cout, int cop, int nt_count,
+                                                            __bf16 *__restrict__ out) {
+    const int ksteps = cop == 32 ? 4 : 1;
+    const int total = 16 * ksteps * nt_count * 64 * 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int r = i;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int nt = r % nt_count; r /= nt_count;
+    const int ks = r % ksteps; r /= ksteps;
+    const int kzky = r;
+    const int kk = 8 * (lane >> 4) + e;
+    const int kx = cop == 32 ? ks : (kk >> 3);
+    const int co = cop == 32 ? kk : (kk & 7);
+    const int ci = nt * 16 + (lane & 15);
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[((((int64_t)ci * cout + co) * 4 + (kzky >> 2)) * 4 + (kzky & 3)) * 4 + kx];
+    out[i] = (__bf16)v;
+}
+
+// ---- forward -------------------------------------------------------------------------------------
+constexpr int CT_TX = 64;   // cells per block along x
+
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void ct_fwd_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                          CtDims s, int xtiles, float *__restrict__ out) {
+    constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
+    constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
+    constexpr int KSTEPS = CIN == 32 ? 8 : 4;
+    __shared__ __attribute__((aligned(16))) __bf16 xs[9 * XS * CIN];   // [row9][xx][ci]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int xt = blockIdx.x % xtiles;
+    const int64_t row = blockIdx.x / xtiles;
+    const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+    const int x0 = xt * CT_TX;
+    const int64_t cells = (int64_t)s.d * s.h * s.w;
+    const float *xb = x + (int64_t)n * CIN * cells;
+    // stage: piece = (row9, group, xx); a thread gathers 8 channels of one position
+    for (int p = t; p < 9 * GROUPS * XS; p += 256) {
+        const int xx = p % XS, g = (p / XS) % GROUPS, r9 = p / (XS * GROUPS);
+        const int z = hz + r9 / 3 - 1, y = hy + r9 % 3 - 1, xp = x0 - 1 + xx;
+        bf16x8m v;
+        if ((unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w) {
+            const float *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[(int64_t)e * cells];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8m *>(&xs[((r9 * XS + xx) * GROUPS + g) * 8]) = v;
+    }
+    __syncthreads();
+    const int pz = wid >> 1, py = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4m acc[2][4][NT];
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+        const int cls = pz * 4 + py * 2 + px;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8m b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)cls * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+            const int tap = CIN == 32 ? ks : 2 * ks + (q >> 1);
+            const int g = CIN == 32 ? q : (q & 1);
+            const int ta = tap >> 2, tb = (tap >> 1) & 1, tc = tap & 1;
+            const int r9 = (ct_d(pz, ta) + 1) * 3 + (ct_d(py, tb) + 1);
+            const int dx = ct_d(px, tc);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int xx = mt * 16 + r + 1 + dx;
+                const bf16x8m a = *reinterpret_cast<const bf16x8m *>(&xs[((r9 * XS + xx) * GROUPS + g) * 8]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[px][mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane holds column co = nt*16 + r and the 4 cells 4q..4q+3 of every m-tile, both px -> 8 consecutive floats
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int oz = 2 * hz + pz, oy = 2 * hy + py;
+    float *ob = out + (int64_t)n * s.cout * od * oh * ow;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 16 + r;
+        if (co >= s.cout) continue;
+        const float bv = bias ? bias[co] : 0.f;
+        float *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int c0 = x0 + mt * 16 + 4 * q;
+            if (c0 + 3 < s.w && (ow & 3) == 0) {
+                float4 lo{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv};
+                float4 hi{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv};
+                *reinterpret_cast<float4 *>(orow + 2 * c0) = lo;
+                *reinterpret_cast<float4 *>(orow + 2 * c0 + 4) = hi;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < s.w) {
+                        orow[2 * (c0 + j)] = acc[0][mt][nt][j] + bv;
+                        orow[2 * (c0 + j) + 1] = acc[1][mt][nt][j] + bv;
+                    }
+            }
+        }
+    }
+}
+
+// ---- data gradient -------------------------------------------------------------------------------
+template <int COP, int NT, int G>
+__global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int xtiles,
+                                                            float *__restrict__ din) {
+    constexpr int GROUPS = COP / 8;
+    constexpr int KSTEPS = COP == 32 ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 ts[G * 4 * CT_TX * COP];   // [g][kx][c][co]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int xt = blockIdx.x % xtiles;
+    const int64_t row = blockIdx.x / xtiles;
+    const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+    const int x0 = xt * CT_TX;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t oplane = (int64_t)od * oh * ow;
+    const float *db = dout + (int64_t)n * s.cout * oplane;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4m acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    for (int round = 0; round < 16 / G; ++round) {
+        if (round) __syncthreads();
+        // staging: a wave = the 64 cells of the tile for one (output row gi, channel group g).  Each lane loads the aligned
+        // pair dout[co][2c], dout[co][2c+1] of 8 planes (coalesced float2 rows) and takes positions 2c-1 / 2c+2 from its
+        // neighbour lanes: the four kx samples of cell c are exactly dout[2c-1 .. 2c+2].
+        for (int p = t; p < G * GROUPS * CT_TX; p += 256) {
+            const int c = p % CT_TX, g = (p / CT_TX) % GROUPS, gi = p / (CT_TX * GROUPS);
+            const int kzky = round * G + gi;
+            const int z = 2 * hz - 1 + (kzky >> 2), y = 2 * hy - 1 + (kzky & 3);
+            const bool rowok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform
+            const int xe = 2 * (x0 + c);
+            const bool cellok = rowok && x0 + c < s.w;
+            const float *src = db + ((int64_t)(rowok ? z : 0) * oh + (rowok ? y : 0)) * ow + (int64_t)(g * 8) * oplane;
+            bf16x8m v0, v1, v2, v3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool chok = cellok && g * 8 + e < s.cout;
+                float2 m = float2{0.f, 0.f};
+                if (chok) m = *reinterpret_cast<const float2 *>(src + (int64_t)e * oplane + xe);
+                float lo = __shfl_up(m.y, 1, 64), hi = __shfl_down(m.x, 1, 64);
+                if (c == 0) lo = (chok && xe > 0) ? src[(int64_t)e * oplane + xe - 1] : 0.f;
+                if (c == CT_TX - 1) hi = (chok && xe + 2 < ow) ? src[(int64_t)e * oplane + xe + 2] : 0.f;
+                if (!chok) { lo = 0.f; hi = 0.f; }
+                v0[e] = (__bf16)lo; v1[e] = (__bf16)m.x; v2[e] = (__bf16)m.y; v3[e] = (__bf16)hi;
+            }
+            __bf16 *dst = &ts[(((gi * 4 + 0) * CT_TX + c) * GROUPS + g) * 8];
+            *reinterpret_cast<bf16x8m *>(dst) = v0;
+            *reinterpret_cast<bf16x8m *>(dst + 1 * CT_TX * GROUPS * 8) = v1;
+            *reinterpret_cast<bf16x8m *>(dst + 2 * CT_TX * GROUPS * 8) = v2;
+            *reinterpret_cast<bf16x8m *>(dst + 3 * CT_TX * GROUPS * 8) = v3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int kzky = round * G + gi;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int kx = COP == 32 ? ks : q;
+                const int g = COP == 32 ? q : 0;
+                const bf16x8m a = *reinterpret_cast<const bf16x8m *>(&ts[(((gi * 4 + kx) * CT_TX + wid * 16 + r) * GROUPS + g) * 8]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8m b = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int64_t cells = (int64_t)s.d * s.h * s.w;
+    float *ib = din + (int64_t)n * s.cin * cells + ((int64_t)hz * s.h + hy) * s.w;
+    const int c0 = x0 + wid * 16 + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ci = nt * 16 + r;
+        if (ci >= s.cin) continue;
+        float *dst = ib + (int64_t)ci * cells + c0;
+        if (c0 + 3 < s.w && (s.w & 3) == 0) {
+            *reinterpret_cast<float4 *>(dst) = float4{acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < s.w) dst[j] = acc[nt][j];
+        }
+    }
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------
+// grid (row chunks, 16 / KG groups of (kz,ky)); a wave walks the rows of its chunk (wave w takes rows w, w+4, ...), keeps
+// acc[KG][4 kx][CIT][COT] in registers, and the block folds its 4 waves through LDS into partial[chunk][ci][co][64].
+template <int CIT, int COT, int KG>
+__global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
+                                                            float *__restrict__ partial) {
+    constexpr int FR = KG * 4 * CIT * COT;
+    __shared__ float red[FR * 4][64];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
+    const int64_t total_rows = (int64_t)s.n * s.d * s.h;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < total_rows ? r0 + rows_per_block : total_rows;
+    const int grp = blockIdx.y;
+    f32x4m acc[KG][4][CIT][COT];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                for (int b = 0; b < COT; ++b) acc[g][k][a][b] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const int steps = (s.w + 31) / 32;
+    for (int64_t row = r0 + wid; row < r1; row += 4) {
+        const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+        const float *xrow = x + (int64_t)n * s.cin * cells + ((int64_t)hz * s.h + hy) * s.w;
+        const float *dbase = dout + (int64_t)n * s.cout * oplane;
+        for (int st = 0; st < steps; ++st) {
+            const int c0 = st * 32 + 8 * q;   // this lane's 8 cells
+            bf16x8m a[CIT];
+#pragma unroll
+            for (int ai = 0; ai < CIT; ++ai) {
+                const int ci = ai * 16 + r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[ai][e] = (__bf16)0.f;
+                if (ci < s.cin) {
+                    const float *src = xrow + (int64_t)ci * cells + c0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + e < s.w) a[ai][e] = (__bf16)src[e];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const int kzky = grp * KG + g;
+                const int z = 2 * hz - 1 + (kzky >> 2), y = 2 * hy - 1 + (kzky & 3);
+                if ((unsigned)z >= (unsigned)od || (unsigned)y >= (unsigned)oh) continue;   // wave-uniform
+#pragma unroll
+                for (int bi = 0; bi < COT; ++bi) {
+                    const int co = bi * 16 + r;
+                    float win[20];   // win[j] = dout[co][z][y][2*c0 - 2 + j], j = 0..19 (aligned float2 loads); tap kx of cell e = win[1 + kx + 2e]
+#pragma unroll
+                    for (int j = 0; j < 20; ++j) win[j] = 0.f;
+                    if (co < s.cout) {
+                        const float *src = dbase + (int64_t)co * oplane + ((int64_t)z * oh + y) * ow + 2 * c0 - 2;
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            const int pos = 2 * c0 - 2 + 2 * j;
+                            if (pos >= 0 && pos + 1 < ow) {
+                                const float2 m = *reinterpret_cast<const float2 *>(src + 2 * j);
+                                win[2 * j] = m.x; win[2 * j + 1] = m.y;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        bf16x8m b;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b[e] = (__bf16)((c0 + e < s.w) ? win[1 + kx + 2 * e] : 0.f);
+#pragma unroll
+                        for (int ai = 0; ai < CIT; ++ai)
+                            acc[g][kx][ai][bi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], b, acc[g][kx][ai][bi], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // fold the 4 waves in a fixed order (wave 0 stores, waves 1..3 add in turn) and write this block's slab
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                        for (int b = 0; b < COT; ++b)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                float *slot = &red[(((g * 4 + k) * CIT + a) * COT + b) * 4 + reg][lane];
+                                *slot = wv ? *slot + acc[g][k][a][b][reg] : acc[g][k][a][b][reg];
+                            }
+        }
+        __syncthreads();
+    }
+    float *dst = partial + (int64_t)blockIdx.x * s.cin * s.cout * 64;
+    for (int e = t; e < FR * 4 * 64; e += 256) {
+        const int ln = e % 64, f4 = e / 64, reg = f4 % 4, f = f4 / 4;
+        const int b = f % COT, a = (f / COT) % CIT, k = (f / (COT * CIT)) % 4, g = f / (COT * CIT * 4);
+        const float v = red[f4][ln];
+        const int ci = a * 16 + 4 * (ln >> 4) + reg, co = b * 16 + (ln & 15);   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+        const int kzky = grp * KG + g;
+        if (ci < s.cin && co < s.cout) dst[(((int64_t)ci * s.cout + co) * 16 + kzky) * 4 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void ct_slab_reduce_kernel(const float *__restrict__ partial, int n_slabs, int64_t size, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    float sum = 0.f;
+    for (int sidx = 0; sidx < n_slabs; ++sidx) sum += partial[(int64_t)sidx * size + i];
+    out[i] = sum;
+}
+
+static bool ct_mfma_ok(int cin, int cout) { return (cin == 32 || cin == 16) && cout >= 1 && cout <= 32; }
+static int ct_wgrad_blocks(int64_t rows) { return (int)(rows < 512 ? rows : 512); }
+
+}  // namespace s2d
+
+using namespace s2d;
+
+extern "C" int s2d_convt3d_mfma_supported(int cin, int cout) { return ct_mfma_ok(cin, cout); }
+
+/* packed weight images: forward [8][ksteps][nt][64][8] then data gradient [16][ksteps'][nt'][64][8] (bf16 elements) */
+extern "C" size_t s2d_convt3d_mfma_packed_elems(int cin, int cout) {
+    if (!ct_mfma_ok(cin, cout)) return 0;
+    const int nt_f = (cout + 15) / 16, nt_d = cin / 16, cop = cout <= 8 ? 8 : 32;
+    return (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512 + (size_t)16 * (cop == 32 ? 4 : 1) * nt_d * 512;
+}
+
+extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed, "convt3d_mfma_pack: null argument");
+    if (!ct_mfma_ok(cin, cout)) {
+        set_error("convt3d_mfma: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int nt_f = (cout + 15) / 16, nt_d = cin / 16, cop = cout <= 8 ? 8 : 32;
+    const int n_f = 8 * (cin == 32 ? 8 : 4) * nt_f * 512, n_d = 16 * (cop == 32 ? 4 : 1) * nt_d * 512;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ct_pack_fwd_kernel, dim3((n_f + 255) / 256), dim3(256), 0, st, weight, cin, cout, nt_f, (__bf16 *)packed);
+    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, (__bf16 *)packed + n_f);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
+                                    int w, float *out, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && packed && out && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_fwd: bad argument");
+    if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
+    CtDims s{batch, d, h, w, cin, cout};
+    const int xtiles = (w + CT_TX - 1) / CT_TX;
+    const int64_t blocks = (int64_t)batch * d * h * xtiles;
+    S2D_CHECK_ARG(blocks < 0x7fffffff, "convt3d_mfma_fwd: grid too large");
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *wp = (const __bf16 *)packed;
+    const int nt = (cout + 15) / 16;
+    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
+    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
+    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
+    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w,
+                                      float *din, s2d_stream_t stream) {
+    S2D_CHECK_ARG(dout && packed && din && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_dgrad: bad argument");
+    if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
+    CtDims s{batch, d, h, w, cin, cout};
+    const int xtiles = (w + CT_TX - 1) / CT_TX;
+    const int64_t blocks = (int64_t)batch * d * h * xtiles;
+    S2D_CHECK_ARG(blocks < 0x7fffffff, "convt3d_mfma_dgrad: grid too large");
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int nt_f = (cout + 15) / 16;
+    const __bf16 *wp = (const __bf16 *)packed + (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512;
+    const bool narrow = cout <= 8;
+    if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 2, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
+    else if (narrow) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 1, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
+    else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<32, 2, 2>), grid, blk, 0, st, dout, wp, s, xtiles, din);
+    else hipLaunchKernelGGL((ct_dgrad_mfma_kernel<32, 1, 2>), grid, blk, 0, st, dout, wp, s, xtiles, din);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w) {
+    if (batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !ct_mfma_ok(cin, cout)) return 0;
+    return align_up((size_t)ct_wgrad_blocks((int64_t)batch * d * h) * cin * cout * 64 * sizeof(float), 256);
+}
+
+extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int cin, int cout, int d, int h, int w,
+                                      float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && dout && dweight && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_wgrad: bad argument");
+    if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
+    const size_t need = s2d_convt3d_mfma_wgrad_workspace_bytes(batch, cin, cout, d, h, w);
+    if (!ws || ws_bytes < need) {
+        set_error("convt3d_mfma_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    CtDims s{batch, d, h, w, cin, cout};
+    const int64_t rows = (int64_t)batch * d * h;
+    const int bx = ct_wgrad_blocks(rows);
+    const int rpb = (int)ceil_div(rows, bx);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)ws;
+    const int cit = cin / 16, cot = (cout + 15) / 16;
+    if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 1, 8>), dim3(bx, 2), dim3(256), 0, st, in, dout, s, rpb, partial);
+    const int64_t size = (int64_t)cin * cout * 64;
+    hipLaunchKernelGGL(ct_slab_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, bx, size, dweight);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// ---- 1x1x1 Conv3d weight gradient (planar fp32 tensors) ------------------------------------------------------------
+// dW[co][ci] = sum_{n,p} dy[n][co][p] * x[n][ci][p], db[co] = sum dy: skinny GEMMs with a reduction axis of 1e6..5e7 positions
+// (hipBLASLt ran them at 1.0-1.8 ms each, r02 baseline).  Streaming reduction: grid (position chunks, co tiles of PW_CT, ci tiles
+// of PW_CIT); a thread accumulates PW_CT x PW_CIT products over float4 position quads, the block folds its lanes by shuffles +
+// LDS in a fixed order and writes partial[chunk][co][ci]; pw_wgrad_reduce folds the chunks.
+namespace s2d {
+constexpr int PW_CT = 4, PW_CIT = 32;
+
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int64_t p4, int batch, int cin,
+                                                       int cout, int64_t quads_per_block, float *__restrict__ partial) {
+    __shared__ float red[4][PW_CT * (PW_CIT + 1)];
+    const int co0 = blockIdx.y * PW_CT, ci0 = blockIdx.z * PW_CIT;
+    float acc[PW_CT][PW_CIT + 1];   // column PW_CIT: sum of dy (bias gradient), written by the ci0 == 0 blocks
+#pragma unroll
+    for (int c = 0; c < PW_CT; ++c)
+#pragma unroll
+        for (int i = 0; i <= PW_CIT; ++i) acc[c][i] = 0.f;
+    const int64_t q0 = (int64_t)blockIdx.x * quads_per_block;
+    const int64_t q1 = q0 + quads_per_block < p4 ? q0 + quads_per_block : p4;
+    for (int n = 0; n < batch; ++n) {
+        const float4 *xb = reinterpret_cast<const float4 *>(x) + (int64_t)n * cin * p4;
+        const float4 *db = reinterpret_cast<const float4 *>(dy) + (int64_t)n * cout * p4;
+        for (int64_t qd = q0 + threadIdx.x; qd < q1; qd += 256) {
+            float4 g[PW_CT];
+#pragma unroll
+            for (int c = 0; c < PW_CT; ++c) {
+                g[c] = co0 + c < cout ? db[(int64_t)(co0 + c) * p4 + qd] : float4{0.f, 0.f, 0.f, 0.f};
+                acc[c][PW_CIT] += (g[c].x + g[c].y) + (g[c].z + g[c].w);
+            }
+#pragma unroll
+            for (int i = 0; i < PW_CIT; ++i) {
+                if (ci0 + i < cin) {
+                    const float4 v = xb[(int64_t)(ci0 + i) * p4 + qd];
+#pragma unroll
+                    for (int c = 0; c < PW_CT; ++c)
+                        acc[c][i] += (g[c].x * v.x + g[c].y * v.y) + (g[c].z * v.z + g[c].w * v.w);
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < PW_CT; ++c)
+#pragma unroll
+        for (int i = 0; i <= PW_CIT; ++i) {
+            float s = acc[c][i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) red[wid][c * (PW_CIT + 1) + i] = s;
+        }
+    __syncthreads();
+    float *dst = partial + (int64_t)blockIdx.x * cout * (cin + 1);
+    for (int e = threadIdx.x; e < PW_CT * (PW_CIT + 1); e += 256) {
+        const int c = e / (PW_CIT + 1), i = e % (PW_CIT + 1);
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (co0 + c >= cout) continue;
+        if (i == PW_CIT) {
+            if (ci0 == 0) dst[(int64_t)(co0 + c) * (cin + 1) + cin] = v;
+        } else if (ci0 + i < cin) {
+            dst[(int64_t)(co0 + c) * (cin + 1) + ci0 + i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ partial, int chunks, int cin, int cout, float *__restrict__ dw,
+                                                              float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int total = cout * (cin + 1);
+    if (i >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * total + i];
+    const int co = i / (cin + 1), ci = i % (cin + 1);
+    if (ci < cin) dw[(int64_t)co * cin + ci] = s;
+    else if (db) db[co] = s;
+}
+constexpr int PW_CHUNKS = 512;
+}  // namespace s2d
+
+extern "C" size_t s2d_pointwise_conv_wgrad_workspace_bytes(int cin, int cout) {
+    if (cin <= 0 || cout <= 0) return 0;
+    return s2d::align_up((size_t)s2d::PW_CHUNKS * cout * (cin + 1) * sizeof(float), 256);
+}
+
+extern "C" int s2d_pointwise_conv_wgrad_f32(const float *in, const float *dout, int batch, int cin, int cout, int64_t positions,
+                                            float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && dout && dweight && batch > 0 && cin > 0 && cout > 0 && positions > 0, "pointwise_conv_wgrad: bad argument");
+    if (positions % 4) {
+        s2d::set_error("pointwise_conv_wgrad: the position count must be a multiple of 4 (%lld)", (long long)positions);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const size_t need = s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout);
+    if (!ws || ws_bytes < need) {
+        s2d::set_error("pointwise_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    const int64_t p4 = positions / 4;
+    const int chunks = (int)std::min<int64_t>(s2d::PW_CHUNKS, s2d::ceil_div(p4, 256));
+    const int64_t qpb = s2d::ceil_div(p4, chunks);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)ws;
+    hipLaunchKernelGGL(s2d::pw_wgrad_kernel, dim3(chunks, (unsigned)s2d::ceil_div(cout, s2d::PW_CT), (unsigned)s2d::ceil_div(cin, s2d::PW_CIT)),
+                       dim3(256), 0, st, in, dout, p4, batch, cin, cout, qpb, partial);
+    hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 256)), dim3(256), 0, st, partial, chunks,
+                       cin, cout, dweight, dbias);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

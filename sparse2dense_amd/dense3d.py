@@ -56,26 +56,54 @@ class _PwConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = pointwise_conv(dout, w2d.t().contiguous(), None)
-        if ctx.needs_input_grad[1]:
-            n, cout = dout.shape[0], dout.shape[1]
-            dw = torch.matmul(dout.reshape(n, cout, -1), x.reshape(n, x.shape[1], -1).transpose(1, 2)).sum(0)
-            dw = dw.reshape(ctx.wshape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.sum(dim=[0] + list(range(2, dout.dim())))
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            lib = _lib.load()
+            n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
+            pos = x[0, 0].numel()
+            if pos % 4 == 0:   # streaming reduction over the positions (csrc/convt3d_mfma.hip pw_wgrad_kernel)
+                dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+                db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
+                ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
+                check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws),
+                                                       ws.numel(), _stream()), "s2d_pointwise_conv_wgrad_f32")
+                dw = dw.reshape(ctx.wshape)
+            else:
+                dw = torch.matmul(dout.reshape(n, cout, -1), x.reshape(n, cin, -1).transpose(1, 2)).sum(0).reshape(ctx.wshape)
+                db = dout.sum(dim=[0] + list(range(2, dout.dim()))) if want_db else None
         return dx, dw, db
+
+
+def _convt_packed(weight):
+    """bf16 weight images (forward + data gradient) of the MFMA ConvTranspose3d kernels, cached per parameter version"""
+    from .dense2d import cached_pack
+
+    def build():
+        lib = _lib.load()
+        cin, cout = weight.shape[0], weight.shape[1]
+        packed = torch.empty(lib.s2d_convt3d_mfma_packed_elems(cin, cout), dtype=torch.bfloat16, device=weight.device)
+        check(lib.s2d_convt3d_mfma_pack_weights(_ptr(weight.detach().float().contiguous()), cin, cout, _ptr(packed), _stream()),
+              "s2d_convt3d_mfma_pack_weights")
+        return packed
+    return cached_pack(weight, ("convt3d_mfma",), build)
 
 
 class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bf16=False):
         lib = _lib.load()
         x = x.contiguous()
         weight = weight.contiguous()
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
         out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
-        check(lib.s2d_convt3d_k4s2p1_fwd_f32(_ptr(x), _ptr(weight), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _stream()),
-              "s2d_convt3d_k4s2p1_fwd_f32")
+        ctx.mfma = bool(bf16 and lib.s2d_convt3d_mfma_supported(cin, cout))
+        if ctx.mfma:   # bf16 compute mode: operands rounded to bf16 in the kernel, fp32 accumulate (csrc/convt3d_mfma.hip)
+            check(lib.s2d_convt3d_mfma_fwd(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out),
+                                           _stream()), "s2d_convt3d_mfma_fwd")
+        else:
+            check(lib.s2d_convt3d_k4s2p1_fwd_f32(_ptr(x), _ptr(weight), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _stream()),
+                  "s2d_convt3d_k4s2p1_fwd_f32")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return out
@@ -90,11 +118,19 @@ class _ConvT3dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.s2d_convt3d_k4s2p1_dgrad_f32(_ptr(dout), _ptr(weight), n, cin, cout, d, h, w, _ptr(dx), _stream()),
-                  "s2d_convt3d_k4s2p1_dgrad_f32")
+            if ctx.mfma:
+                check(lib.s2d_convt3d_mfma_dgrad(_ptr(dout), _ptr(_convt_packed(weight)), n, cin, cout, d, h, w, _ptr(dx), _stream()),
+                      "s2d_convt3d_mfma_dgrad")
+            else:
+                check(lib.s2d_convt3d_k4s2p1_dgrad_f32(_ptr(dout), _ptr(weight), n, cin, cout, d, h, w, _ptr(dx), _stream()),
+                      "s2d_convt3d_k4s2p1_dgrad_f32")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            if cin <= 32 and cout <= 32:
+            if ctx.mfma:
+                ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
+                check(lib.s2d_convt3d_mfma_wgrad(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(), _stream()),
+                      "s2d_convt3d_mfma_wgrad")
+            elif cin <= 32 and cout <= 32:
                 ws = torch.empty(max(lib.s2d_convt3d_k4s2p1_wgrad_workspace_bytes(n, cin, cout, d, h, w), 256),
                                  dtype=torch.uint8, device=x.device)
                 check(lib.s2d_convt3d_k4s2p1_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws),
@@ -109,7 +145,7 @@ class _ConvT3dFn(torch.autograd.Function):
                             dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(dim=(0, 2, 3, 4))
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def _hip_ok(x):
@@ -127,12 +163,15 @@ class PointwiseConv3d(nn.Conv3d):
 
 
 class ConvTranspose3dK4S2(nn.ConvTranspose3d):
-    """nn.ConvTranspose3d(cin, cout, 4, 2, 1)."""
+    """nn.ConvTranspose3d(cin, cout, 4, 2, 1).  `bf16_compute` (set by the detector in its bf16 mode) selects the matrix-core
+    kernels: operands rounded to bf16, fp32 accumulate, fp32 NCDHW tensors."""
+
+    bf16_compute = False
 
     def forward(self, x, output_size=None):
         if _hip_ok(x) and self.kernel_size == (4, 4, 4) and self.stride == (2, 2, 2) and self.padding == (1, 1, 1) \
                 and self.output_padding == (0, 0, 0) and self.groups == 1 and self.dilation == (1, 1, 1):
-            return _ConvT3dFn.apply(x, self.weight, self.bias)
+            return _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute)
         return super().forward(x, output_size)
 
 

@@ -95,3 +95,52 @@ def test_channel_major_batchnorm3d(c, shape, relu, train):
     if train:
         torch.testing.assert_close(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(bn.running_var.cpu().double(), ref.running_var, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 matrix-core ConvTranspose3d (csrc/convt3d_mfma.hip): float64 torch reference on the HOST evaluated on the SAME
+# bf16-rounded operands (x, weight, and - for the gradients - dout), so what is left is fp32 accumulation order:
+# 1e-4 of max on outputs and gradients (K <= 256 products per output, <= ~1e6 per weight-gradient entry).
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (1, 4, 7, 66)), (32, 3, (1, 2, 5, 9)), (16, 32, (2, 2, 3, 130)),
+                                            (32, 32, (1, 5, 20, 188)), (16, 3, (1, 3, 9, 376))])
+def test_convtranspose3d_bf16_mfma(cin, cout, shape):
+    torch.manual_seed(cin * 5 + cout)
+    n, d, h, w = shape
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(n, cin, d, h, w))
+    hip = ConvTranspose3dK4S2(cin, cout, 4, 2, 1)
+    with torch.no_grad():
+        hip.weight.copy_(rb(hip.weight))
+    hip.bf16_compute = True
+    ref = nn.ConvTranspose3d(cin, cout, 4, 2, 1)
+    ref.load_state_dict(hip.state_dict())
+    ref = ref.double()
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    g = rb(torch.randn(yr.shape, generator=torch.Generator().manual_seed(3)))
+    gr = torch.autograd.grad(yr, [xr] + list(ref.parameters()), g.double())
+    hip = hip.to(DEV)
+    xh = x.to(DEV).requires_grad_(True)
+    yh = hip(xh)
+    gh = torch.autograd.grad(yh, [xh] + list(hip.parameters()), g.to(DEV))
+    for name, a, b in [("y", yh, yr)] + [(f"grad{i}", a, b) for i, (a, b) in enumerate(zip(gh, gr))]:
+        err = (a.detach().cpu().double() - b.detach()).abs().max().item() / (b.abs().max().item() + 1e-12)
+        assert err <= 1e-4, (name, err)
+
+
+@pytest.mark.parametrize("cin,cout,pos_shape", [(128, 32, (2, 5, 12, 16)), (32, 3, (1, 4, 10, 12)), (32, 1, (2, 3, 8, 8)), (32, 16, (4, 10, 94, 94)),
+                                                (3, 3, (2, 20, 94, 94)), (3, 1, (2, 2, 6, 4))])
+def test_pointwise_conv3d_weight_gradient_kernel(cin, cout, pos_shape):
+    """dW / db of the 1x1x1 convs through the streaming reduction (s2d_pointwise_conv_wgrad_f32) vs float64 on the host"""
+    torch.manual_seed(cin + 3 * cout)
+    n, d, h, w = pos_shape
+    x = torch.randn(n, cin, d, h, w)
+    dy = torch.randn(n, cout, d, h, w)
+    layer = PointwiseConv3d(cin, cout, 1, 1, 0).to(DEV)
+    xh = x.to(DEV).requires_grad_(True)
+    layer(xh).backward(dy.to(DEV))
+    dw = torch.einsum("ncp,nkp->ck", dy.double().reshape(n, cout, -1), x.double().reshape(n, cin, -1))
+    db = dy.double().sum(dim=(0, 2, 3, 4))
+    assert (layer.weight.grad.cpu().double().reshape(cout, cin) - dw).abs().max() <= 2e-5 * dw.abs().max() + 1e-4
+    assert (layer.bias.grad.cpu().double() - db).abs().max() <= 2e-5 * db.abs().max() + 1e-4
