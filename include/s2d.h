@@ -429,6 +429,45 @@ int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const i
                          float *g_gen_mask, float *g_gen_offset_zeroed, s2d_stream_t stream);
 
 /*
+ * Rotated bird's-eye-view IoU and greedy NMS of CenterHead.predict (det3d/core/bbox/box_torch_ops.py:449-464 rotate_nms_pcdet,
+ * det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-326, src/iou3d_nms.cpp:92-130).  Boxes: 7 floats (x,y,z,dx,dy,dz,heading).
+ * s2d_nms_rotated_bev takes the boxes SORTED by descending score and writes the kept indices (into that order) and their count
+ * to device memory - the suppression matrix is walked on the device, no host round trip.
+ */
+int s2d_bev_iou_f32(const float *boxes_a, int na, const float *boxes_b, int nb, float *iou, s2d_stream_t stream);
+size_t s2d_nms_workspace_bytes(int n);
+int s2d_nms_rotated_bev(const float *boxes_sorted, int n, float iou_threshold, int max_keep, int64_t *keep,
+                        int32_t *n_keep, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/*
+ * CenterPoint training targets on the device = AssignLabel.__call__ (det3d/datasets/pipelines/preprocess.py:489-653, one-task
+ * Waymo head) with gaussian_radius / draw_umich_gaussian (det3d/core/utils/center_utils.py:18-64).  gt_boxes fp32
+ * [frames][max_boxes][9] (x,y,z,w,l,h,vx,vy,yaw), gt_classes int32 [frames][max_boxes] (1-based, <= 0 = padding).  Outputs per
+ * frame: hm fp32 [num_classes][fmap_h][fmap_w] (ZEROED by the caller), anno_box fp32 [max_objs][10], ind int64 [max_objs],
+ * mask uint8 [max_objs], cat int64 [max_objs], gt_boxes_and_cls fp32 [max_objs][10] (optional, two-stage code).
+ */
+int s2d_assign_label(const float *gt_boxes, const int32_t *gt_classes, int frames, int max_boxes,
+                     const float pc_range_xy[2], const float voxel_size_xy[2], int out_size_factor, int fmap_w,
+                     int fmap_h, int num_classes, int max_objs, double gaussian_overlap, int min_radius,
+                     float *hm_zeroed, float *anno_box, int64_t *ind, uint8_t *mask, int64_t *cat,
+                     float *gt_boxes_and_cls, s2d_stream_t stream);
+
+/*
+ * Optimizer step of the reference's training loop (det3d/torchie/apis/train.py:168-186, det3d/solver/fastai_optim.py:158-171,
+ * hooks/optimizer.py:15-21): gradient L2 norm -> clip coefficient (device scalar, clip_grad_norm_ semantics) -> fused
+ * multi-tensor Adam with decoupled weight decay: p *= 1 - lr*wd; Adam(betas, eps) on grad*clip_coef with bias correction of
+ * step `step` (1-based).  Up to s2d_adam_max_tensors() tensors per call (host pointer tables of DEVICE pointers).
+ */
+int s2d_adam_max_tensors(void);
+int s2d_adam_step_f32(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                      float *const *exp_avg_sq, const int64_t *numel, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, const float *clip_coef, s2d_stream_t stream);
+size_t s2d_grad_norm_workspace_floats(int count, const int64_t *numel);
+int s2d_grad_sumsq_f32(int count, const float *const *grads, const int64_t *numel, float *partial,
+                       int *written, s2d_stream_t stream);
+int s2d_grad_norm_finalize_f32(const float *partial, int n, float max_norm, float *out2, s2d_stream_t stream);
+
+/*
  * SyncBN statistics all-reduce on the compute stream (det3d/torchie/apis/train.py:281-300: apex SyncBatchNorm + DDP when
  * training distributed).  The RCCL already loaded in the process is resolved at run time; s2d_comm_available() == 0 means
  * the host keeps using its own collective.  Bootstrap: rank 0 calls s2d_comm_unique_id (128 bytes), the host broadcasts

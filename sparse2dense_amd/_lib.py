@@ -98,6 +98,17 @@ SIGNATURES = {
                              [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_loss_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 4 +
                              [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_bev_iou_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "s2d_nms_rotated_bev": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_assign_label": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_float * 2, ctypes.c_float * 2] + [ctypes.c_int] * 5 +
+                         [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 7),
+    "s2d_adam_max_tensors": (ctypes.c_int, []),
+    "s2d_adam_step_f32": (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_float] * 5 + [ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_grad_norm_workspace_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_void_p]),
+    "s2d_grad_sumsq_f32": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_grad_norm_finalize_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, c_f32p, ctypes.c_void_p]),
     "s2d_dwconv7_supported": (ctypes.c_int, [ctypes.c_int]),
     "s2d_dwconv7_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_dwconv7_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),

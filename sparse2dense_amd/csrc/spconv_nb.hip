@@ -12,8 +12,12 @@
 //   * the kernel loads the tile's U input rows into LDS ONCE (LDS-DMA, XOR-swizzled 16-byte pieces); A fragments are then
 //     read straight out of the resident rows with per-lane addresses (slot of the lane's row at offset k) - no A tile is
 //     materialised, no barrier inside the K loop.  Missing neighbours point at a zero row.
-//   * B fragments (weights) are loaded from L2 straight into registers in fragment order (1 KiB contiguous per wave
-//     instruction), double buffered one kernel offset ahead.
+//   * the weight image of a K-step (C x C bf16, fragment order) is copied ONCE per workgroup into a double-buffered LDS slab
+//     and shared by the four waves (each wave covers 64 rows x all C columns); measured r02: what bounds these kernels is the
+//     bytes a CU pulls from L2 (~16 B/clk/CU whether by LDS-DMA or by plain loads - a first version that loaded B fragments
+//     per wave straight into registers moved 2-4x the weight bytes and was slower than the gather kernel), so the design
+//     minimises fetched bytes per CU: 256-row tiles, resident rows, shared weights, and K-steps no row of the tile uses
+//     are skipped entirely (no copy, no MFMA).
 //   * 16-row MFMA tiles with no neighbour at an offset are skipped (bit table per tile and offset); spatial tiles make
 //     neighbouring rows share their occupied offsets, so the skip removes most of the zero work.
 //   * tiles whose neighbourhood exceeds the LDS budget are processed in several phases (slots [p*UMAX, (p+1)*UMAX)).
@@ -33,20 +37,20 @@ constexpr int NB_KS = 28;         // offset slots (even: the 16-channel kernel p
 
 template <int C>
 struct NbCfg {   // CIN == COUT == C (SubM layers of the backbone)
-    static constexpr int WN = C == 128 ? 2 : 1;
-    static constexpr int WM = 4 / WN;
+    static constexpr int WM = 4;                           // the 4 waves split the rows; every wave covers all C columns
     static constexpr int MI = 4;
-    static constexpr int T = WM * MI * 16;                 // rows per tile: 128 (C = 128) or 256
-    static constexpr int NJ = C / WN / 16;                 // 16-column MFMA tiles per wave
+    static constexpr int T = WM * MI * 16;                 // 256 rows per tile
+    static constexpr int NJ = C / 16;                      // 16-column MFMA tiles
     static constexpr int PARTS = C / 8;                    // 16-byte pieces per row
     static constexpr int ROWB = C * 2;
     static constexpr int CH = C >= 32 ? C / 32 : 1;        // 32-deep K chunks per offset (C = 16: two offsets share one)
     static constexpr int KSTEPS = C == 16 ? NB_KS / 2 : NB_K;   // weight images per launch (offset pairs for C = 16)
-    // resident slots per phase, sized so that 2 (C >= 64), 3 (C = 32) or 4 (C = 16) workgroups share a CU's 160 KiB of LDS
-    static constexpr int UMAX = C == 128 ? 256 : (C == 64 ? 448 : (C == 32 ? 576 : 704));
+    static constexpr int BBYTES = CH * NJ * 1024;          // one weight image (K-step) in LDS
+    // resident slots per phase, sized so that 1 (C = 128), 2 (C = 64), 3 (C = 32) or 4 (C = 16) workgroups fit a CU's 160 KiB
+    static constexpr int UMAX = C == 128 ? 416 : (C == 64 ? 432 : (C == 32 ? 544 : 720));
     static constexpr int RPB = 256 / ROWB;                 // rows per 256-byte LDS bank row
     static constexpr int UCAP = NB_K * T;                  // slots reserved per tile in the plan (worst case)
-    static constexpr size_t LDS = (size_t)(UMAX + 1) * ROWB + (size_t)NB_KS * T * 2 + (size_t)T * 4 + NB_KS * 4 + 64;
+    static constexpr size_t LDS = (size_t)(UMAX + 1) * ROWB + (size_t)BBYTES + (size_t)NB_KS * T * 2 + (size_t)T * 4 + NB_KS * 4 + 16;
     __host__ __device__ static int key(int slot) { return (slot / RPB) & (PARTS - 1); }
 };
 
@@ -57,7 +61,7 @@ template <int T>
 __global__ __launch_bounds__(256) void nb_plan_kernel(const int32_t *__restrict__ nbr, const int32_t *__restrict__ perm, int n, int32_t *__restrict__ rows_out,
                                                       int32_t *__restrict__ u_out, int32_t *__restrict__ in_rows, uint16_t *__restrict__ lnbr,
                                                       uint32_t *__restrict__ act) {
-    constexpr int HC = T == 128 ? 8192 : 16384;   // hash capacity >= 2 x the worst case 27 T distinct rows... (27*128 = 3456, 27*256 = 6912)
+    constexpr int HC = 8192;   // hash capacity: worst case 27 * 256 = 6912 distinct rows (84 % load); typical neighbourhoods fill < 10 %
     extern __shared__ int32_t sm[];
     int32_t *hkey = sm;                 // [HC] row id or -1
     int32_t *hslot = sm + HC;           // [HC] slot of the key
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void nb_plan_kernel(const int32_t *__restrict_
         const int j = nbr[(int64_t)k * n + row];
         if (j < 0) continue;
         atomicOr(&actl[k], 1u << (r >> 4));
-        uint32_t h = ((uint32_t)j * 2654435761u) >> (T == 128 ? 19 : 18);   // top log2(HC) bits
+        uint32_t h = ((uint32_t)j * 2654435761u) >> 19;   // top log2(HC) bits
         while (true) {
             const int prev = atomicCAS(&hkey[h], -1, j);
             if (prev == -1 || prev == j) break;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void nb_plan_kernel(const int32_t *__restrict_
         if (k < NB_K && row >= 0) {
             const int j = nbr[(int64_t)k * n + row];
             if (j >= 0) {
-                uint32_t h = ((uint32_t)j * 2654435761u) >> (T == 128 ? 19 : 18);
+                uint32_t h = ((uint32_t)j * 2654435761u) >> 19;
                 while (hkey[h] != j) h = (h + 1) & (HC - 1);
                 s = (uint16_t)hslot[h];
             }
@@ -176,12 +180,13 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
     typedef NbCfg<C> F;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *rowsb = smem;                                                         // [(UMAX+1)][ROWB] resident input rows (+ zero row)
-    uint16_t *lnbr = reinterpret_cast<uint16_t *>(smem + (size_t)(F::UMAX + 1) * F::ROWB);   // [NB_KS][T]
+    char *bbuf = smem + (size_t)(F::UMAX + 1) * F::ROWB;                        // [BBYTES] weight image of the current K-step
+    uint16_t *lnbr = reinterpret_cast<uint16_t *>(bbuf + F::BBYTES);            // [NB_KS][T]
     int32_t *orow = reinterpret_cast<int32_t *>(lnbr + NB_KS * F::T);           // [T]
     uint32_t *act = reinterpret_cast<uint32_t *>(orow + F::T);                  // [NB_KS]
     const int t = threadIdx.x, lane = t & 63;
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wid / F::WN, wn = wid % F::WN;
+    const int wm = wid;
     const int r = lane & 15, q = lane >> 4;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     if (tile >= n_tiles) return;
@@ -204,11 +209,35 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
 #pragma unroll
         for (int jn = 0; jn < F::NJ; ++jn) acc[i][jn] = f32x4n{0.f, 0.f, 0.f, 0.f};
 
+    // weight image of K-step ks -> the LDS slab (linear copy, 1 KiB per wave instruction, spread over the waves)
+    auto stage_b = [&](int ks) {
+        const char *wsrc = reinterpret_cast<const char *>(wpack) + (int64_t)ks * F::BBYTES;
+        constexpr int UNITS = F::BBYTES / 1024;
+#pragma unroll
+        for (int u0 = 0; u0 < (UNITS + 3) / 4; ++u0) {
+            const int unit = u0 * 4 + wid;
+            if (unit < UNITS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + unit * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(bbuf + unit * 1024), 16, 0, 0);
+        }
+    };
+
+    __syncthreads();   // descriptors visible
+    // K-steps with at least one pair in this tile (flat neighbourhoods use few of the 27): the others cost neither a weight
+    // copy nor MFMAs.  One bit per K-step, wave-uniform.
+    uint32_t live_all = 0u;
+#pragma unroll 1
+    for (int ks = 0; ks < F::KSTEPS; ++ks) {
+        const uint32_t m = C == 16 ? (act[2 * ks] | act[2 * ks + 1]) : act[ks];
+        live_all |= (m != 0u ? 1u : 0u) << ks;
+    }
+    live_all = __builtin_amdgcn_readfirstlane(live_all);
+
     const int phases = (u_total + F::UMAX - 1) / F::UMAX;
     for (int ph = 0; ph < max(phases, 1); ++ph) {
         const int sbase = ph * F::UMAX;
         const int cnt = min(F::UMAX, u_total - sbase);
-        __syncthreads();   // descriptors written / previous phase's reads done
+        if (ph) __syncthreads();   // previous phase's reads of the resident rows are done
         // gather the phase's rows: piece p = slot*PARTS + part', source part = part' ^ key(slot)
         for (int p0 = wid * 64; p0 < cnt * F::PARTS; p0 += 256) {
             const int p = p0 + lane;
@@ -218,27 +247,29 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(rowsb + (size_t)p0 * 16), 16, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-
-        auto load_b = [&](int ks, bf16x8n (&b)[F::CH][F::NJ]) {
-            const __bf16 *wsrc = wpack + ((((int64_t)ks * F::WN + wn) * F::CH) * F::NJ) * 512 + lane * 8;
+        uint32_t live = live_all;
+        if (live) stage_b(__builtin_ctz(live));
+#pragma unroll 1
+        while (live) {
+            const int ks = __builtin_ctz(live);
+            live &= live - 1u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                 // the weight image of ks (and, first time round, the resident rows) has landed
+            bf16x8n b[F::CH][F::NJ];         // this wave's copy of the image: every wave covers all C columns
 #pragma unroll
             for (int c = 0; c < F::CH; ++c)
 #pragma unroll
-                for (int jn = 0; jn < F::NJ; ++jn) b[c][jn] = *reinterpret_cast<const bf16x8n *>(wsrc + (c * F::NJ + jn) * 512);
-        };
-        auto compute = [&](int ks, const bf16x8n (&b)[F::CH][F::NJ]) {
-            uint32_t on;
-            if (C == 16) on = act[2 * ks] | act[2 * ks + 1];
-            else on = act[ks];
-            on = __builtin_amdgcn_readfirstlane(on);
+                for (int jn = 0; jn < F::NJ; ++jn) b[c][jn] = *reinterpret_cast<const bf16x8n *>(bbuf + (c * F::NJ + jn) * 1024 + lane * 16);
+            uint32_t on = C == 16 ? (act[2 * ks] | act[2 * ks + 1]) : act[ks];
+            on = (__builtin_amdgcn_readfirstlane(on) >> (wm * F::MI)) & ((1u << F::MI) - 1u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                 // every wave holds the image in registers: the slab can be refilled ...
+            if (live) stage_b(__builtin_ctz(live));   // ... with the next live K-step while this one's MFMAs run
             const int koff = C == 16 ? 2 * ks + (q >> 1) : ks;
 #pragma unroll
             for (int i = 0; i < F::MI; ++i) {
-                const int rt = wm * F::MI + i;
-                if (!((on >> rt) & 1u)) continue;
-                int sl = (int)lnbr[koff * F::T + rt * 16 + r] - sbase;
+                if (!((on >> i) & 1u)) continue;   // 16-row tile without a neighbour at this offset (wave-uniform)
+                int sl = (int)lnbr[koff * F::T + (wm * F::MI + i) * 16 + r] - sbase;
                 sl = (unsigned)sl < (unsigned)cnt ? sl : F::UMAX;
                 const char *rowp = rowsb + (size_t)sl * F::ROWB;
                 const int key = F::key(sl);
@@ -253,25 +284,12 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
 #pragma unroll
                     for (int jn = 0; jn < F::NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b[c][jn], acc[i][jn], 0, 0, 0);
             }
-        };
-        // offsets without a single pair in this tile (flat neighbourhoods: most of the 27) cost neither a weight load nor MFMAs
-        auto live = [&](int ks) -> bool {
-            if (ks >= F::KSTEPS) return false;
-            const uint32_t m = C == 16 ? (act[2 * ks] | act[2 * ks + 1]) : act[ks];
-            return __builtin_amdgcn_readfirstlane(m) != 0u;
-        };
-        bf16x8n b0[F::CH][F::NJ], b1[F::CH][F::NJ];
-        if (live(0)) load_b(0, b0);
-        for (int ks = 0; ks < F::KSTEPS; ks += 2) {
-            if (live(ks + 1)) load_b(ks + 1, b1);
-            if (live(ks)) compute(ks, b0);
-            if (live(ks + 2)) load_b(ks + 2, b0);
-            if (live(ks + 1)) compute(ks + 1, b1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     // epilogue: C/D layout row = 4*(lane>>4)+reg, col = lane&15 -> columns co_base + r*NJ + jn (NJ consecutive)
-    const int co_base = wn * (C / F::WN);
+    const int co_base = 0;
     float bv[F::NJ];
 #pragma unroll
     for (int jn = 0; jn < F::NJ; ++jn) bv[jn] = bias ? bias[co_base + r * F::NJ + jn] : 0.f;
@@ -295,7 +313,12 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
                 }
             }
             __bf16 *dst = out + (int64_t)row * C + co_base + r * F::NJ;
-            if (F::NJ == 4) {
+            if (F::NJ == 8) {
+                bf16x8n o;
+#pragma unroll
+                for (int jn = 0; jn < 8; ++jn) o[jn] = v[jn % F::NJ];
+                *reinterpret_cast<bf16x8n *>(dst) = o;
+            } else if (F::NJ == 4) {
                 bf16x4n o; o[0] = v[0]; o[1] = v[1 % F::NJ]; o[2] = v[2 % F::NJ]; o[3] = v[3 % F::NJ];
                 *reinterpret_cast<bf16x4n *>(dst) = o;
             } else if (F::NJ == 2) {
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(256) void spconv_nb_kernel(const __bf16 *__restrict
 }
 
 static bool nb_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
-static int nb_tile_rows(int c) { return c == 128 ? 128 : 256; }
+static int nb_tile_rows(int) { return 256; }
 
 template <int C>
 static int nb_launch(const __bf16 *in, const __bf16 *wp, const float *bias, const int32_t *p_rows, const int32_t *p_u, const int32_t *p_in,
@@ -374,13 +397,8 @@ extern "C" int s2d_spconv_nb_plan_build(const int32_t *nbr, const int32_t *perm,
     const int t = nb_tile_rows(channels);
     const int tiles = (int)ceil_div(n, t);
     hipStream_t st = (hipStream_t)stream;
-    if (t == 128) {
-        const size_t lds = (size_t)(2 * 8192 + 128 + 8 + NB_KS) * 4;
-        static bool done = false;
-        if (!done) { S2D_HIP(hipFuncSetAttribute((const void *)nb_plan_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-        hipLaunchKernelGGL(nb_plan_kernel<128>, dim3(tiles), dim3(256), lds, st, nbr, perm, (int)n, rows, u, in_rows, lnbr, act);
-    } else {
-        const size_t lds = (size_t)(2 * 16384 + 256 + 8 + NB_KS) * 4;
+    {
+        const size_t lds = (size_t)(2 * 8192 + 256 + 8 + NB_KS) * 4;
         static bool done = false;
         if (!done) { S2D_HIP(hipFuncSetAttribute((const void *)nb_plan_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
         hipLaunchKernelGGL(nb_plan_kernel<256>, dim3(tiles), dim3(256), lds, st, nbr, perm, (int)n, rows, u, in_rows, lnbr, act);
@@ -391,15 +409,15 @@ extern "C" int s2d_spconv_nb_plan_build(const int32_t *nbr, const int32_t *perm,
 
 extern "C" size_t s2d_spconv_nb_packed_elems(int channels) {
     if (!nb_ok(channels)) return 0;
-    const int wn = channels == 128 ? 2 : 1, ch = channels >= 32 ? channels / 32 : 1, nj = channels / wn / 16;
-    return (size_t)(channels == 16 ? NB_KS / 2 : NB_K) * wn * ch * nj * 512;
+    const int ch = channels >= 32 ? channels / 32 : 1, nj = channels / 16;
+    return (size_t)(channels == 16 ? NB_KS / 2 : NB_K) * ch * nj * 512;
 }
 
 extern "C" int s2d_spconv_nb_pack_weights(const float *weight, int channels, int transpose, int flip, void *packed, s2d_stream_t stream) {
     S2D_CHECK_ARG(weight && packed && nb_ok(channels), "spconv_nb_pack: bad argument");
     const int64_t total = (int64_t)s2d_spconv_nb_packed_elems(channels);
-    hipLaunchKernelGGL(nb_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, channels,
-                       channels == 128 ? 2 : 1, transpose, flip, (__bf16 *)packed);
+    hipLaunchKernelGGL(nb_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, channels, 1, transpose,
+                       flip, (__bf16 *)packed);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

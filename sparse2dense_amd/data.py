@@ -34,6 +34,7 @@ class SyntheticFrames:
         self.distill = distill
         self.gens = waymo_generators(distill)
         self.points, self.dense_points, self.recon_points = [], [], []
+        gt_b, gt_c = [], []
         tg = {k: [] for k in ["hm", "anno_box", "ind", "mask", "cat"]}
         for b in range(batch_size):
             s = scene.make_scene(n_points, seed=seed + b, beam_jitter=beam_jitter)
@@ -42,11 +43,26 @@ class SyntheticFrames:
                 d, r = scene.make_distill_points(s, seed=seed + 100 + b)
                 self.dense_points.append(torch.from_numpy(d).to(self.device))
                 self.recon_points.append(torch.from_numpy(r).to(self.device))
-            t = scene.assign_targets(s["gt_boxes"], s["gt_classes"])
-            for k in tg:
-                tg[k].append(torch.from_numpy(t[k]))
-        self.targets = {k: [torch.stack(v).to(self.device)] for k, v in tg.items()}
+            # AssignLabel regroups a task's objects class by class (preprocess.py:506-530)
+            order = np.concatenate([np.where(s["gt_classes"] == c)[0] for c in (1, 2, 3)])
+            gt_b.append(s["gt_boxes"][order]); gt_c.append(s["gt_classes"][order])
+            if self.device.type != "cuda":   # host restatement (tests without a GPU)
+                t = scene.assign_targets(gt_b[-1], gt_c[-1])
+                for k in tg:
+                    tg[k].append(torch.from_numpy(t[k]))
+        if self.device.type == "cuda":   # ground-truth boxes stay on the device; targets are assigned there every iteration
+            from . import targets as _targets
+            self.gt_boxes, self.gt_classes = _targets.pad_boxes(gt_b, gt_c, self.device)
+            self.targets = None
+        else:
+            self.targets = {k: [torch.stack(v).to(self.device)] for k, v in tg.items()}
         self.grid_size = self.gens[""].grid_size
+
+    def _targets(self):
+        if self.targets is not None:
+            return self.targets
+        from . import targets as _targets
+        return _targets.assign_label(self.gt_boxes, self.gt_classes)
 
     def example(self):
         ex = voxelize_batch(self.gens[""], self.points)
@@ -58,7 +74,7 @@ class SyntheticFrames:
                 for k, v in r.items():
                     ex[k + suf] = v
         ex["shape"] = np.stack([self.grid_size] * len(self.points))
-        ex.update(self.targets)
+        ex.update(self._targets())
         return ex
 
 

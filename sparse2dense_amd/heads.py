@@ -243,9 +243,67 @@ class CenterHead(nn.Module):
                 merged[k].append(v)
         return merged
 
+    @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
-        raise NotImplementedError("CenterHead.predict (decode + rotated NMS) is inference post-processing; "
-                                  "out of scope of the training hot path (DESIGN.md, SURVEY.md §8(f))")
+        """Decode + score / range filter + rotated NMS (center_head.py:293-448,452-495).
+        Returns one dict per sample: box3d_lidar [n, 7 or 9], scores [n], label_preds [n], metadata.  Not supported (not used by
+        the Waymo configs): double-flip test-time augmentation, circular NMS, per-class NMS."""
+        get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
+        if get("double_flip", False) or get("circular_nms", False) or get("per_class_nms", False):
+            raise NotImplementedError("CenterHead.predict: double_flip / circular_nms / per_class_nms are not on this path")
+        nms_cfg = get("nms")
+        nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
+        hm0 = preds_dicts[0]["hm"]
+        pcr = get("post_center_limit_range")
+        pcr = torch.tensor(pcr, dtype=torch.float32, device=hm0.device) if len(pcr) > 0 else None
+        factor, vs, pc0 = get("out_size_factor"), get("voxel_size"), get("pc_range")
+        rets = []
+        for preds in preds_dicts:
+            p = {k: v.float().permute(0, 2, 3, 1).contiguous() for k, v in preds.items()}   # N C H W -> N H W C
+            batch, h, w, num_cls = p["hm"].shape
+            hm = torch.sigmoid(p["hm"]).reshape(batch, h * w, num_cls)
+            dim = torch.exp(p["dim"]).reshape(batch, h * w, 3)
+            rot = torch.atan2(p["rot"][..., 0:1], p["rot"][..., 1:2]).reshape(batch, h * w, 1)
+            reg = p["reg"].reshape(batch, h * w, 2)
+            hei = p["height"].reshape(batch, h * w, 1)
+            ys, xs = torch.meshgrid(torch.arange(0, h, device=hm.device), torch.arange(0, w, device=hm.device), indexing="ij")
+            xs = xs.reshape(1, -1, 1).to(hm) + reg[:, :, 0:1]
+            ys = ys.reshape(1, -1, 1).to(hm) + reg[:, :, 1:2]
+            xs = xs * factor * vs[0] + pc0[0]
+            ys = ys * factor * vs[1] + pc0[1]
+            parts = [xs, ys, hei, dim] + ([p["vel"].reshape(batch, h * w, 2)] if "vel" in p else []) + [rot]
+            boxes = torch.cat(parts, dim=2)
+            rets.append(self.post_processing(boxes, hm, get("score_threshold"), pcr, nget("nms_iou_threshold"),
+                                             nget("nms_pre_max_size"), nget("nms_post_max_size")))
+        meta = example.get("metadata") if isinstance(example, dict) else None
+        out = []
+        for i in range(len(rets[0])):
+            ret, flag = {}, 0
+            ret["box3d_lidar"] = torch.cat([r[i]["box3d_lidar"] for r in rets])
+            ret["scores"] = torch.cat([r[i]["scores"] for r in rets])
+            labels = []
+            for j, num_class in enumerate(self.num_classes):   # label offsets of the later tasks (center_head.py:431-437)
+                labels.append(rets[j][i]["label_preds"] + flag)
+                flag += num_class
+            ret["label_preds"] = torch.cat(labels)
+            ret["metadata"] = meta[i] if meta else None
+            out.append(ret)
+        return out
+
+    @torch.no_grad()
+    def post_processing(self, batch_box_preds, batch_hm, score_threshold, post_center_range, iou_threshold, pre_max, post_max):
+        """center_head.py:452-495 per sample: max over classes, score + centre-range mask, rotate_nms_pcdet"""
+        from .nms import rotate_nms
+        res = []
+        for box_preds, hm_preds in zip(batch_box_preds, batch_hm):
+            scores, labels = torch.max(hm_preds, dim=-1)
+            mask = scores > score_threshold
+            if post_center_range is not None:
+                mask &= (box_preds[..., :3] >= post_center_range[:3]).all(1) & (box_preds[..., :3] <= post_center_range[3:]).all(1)
+            box_preds, scores, labels = box_preds[mask], scores[mask], labels[mask]
+            sel = rotate_nms(box_preds[:, [0, 1, 2, 3, 4, 5, -1]].float(), scores.float(), iou_threshold, pre_max, post_max)
+            res.append(dict(box3d_lidar=box_preds[sel], scores=scores[sel], label_preds=labels[sel]))
+        return res
 
 
 # ----------------------------------------------------------------------------------------------

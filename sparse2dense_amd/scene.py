@@ -205,14 +205,22 @@ def assign_targets(gt_boxes, gt_classes, pc_range=WAYMO_RANGE, voxel_size=WAYMO_
     mask = np.zeros((max_objs,), np.uint8)
     cat = np.zeros((max_objs,), np.int64)
     n = min(gt_boxes.shape[0], max_objs)
+    gt_boxes = np.array(gt_boxes, np.float32, copy=True)
+    if n:   # rotation limited to [-pi, pi) first (preprocess.py:540-543, box_np_ops.limit_period), on the fp32 box array
+        gt_boxes[:, -1] = gt_boxes[:, -1] - np.floor(gt_boxes[:, -1] / (np.pi * 2) + 0.5) * (np.pi * 2)
+    voxel_size = np.asarray(voxel_size, np.float32)
+    pc_range = np.asarray(pc_range, np.float32)
     for k in range(n):
         box = gt_boxes[k]
         cls_id = int(gt_classes[k]) - 1
+        if cls_id < 0:
+            continue
         w = box[3] / voxel_size[0] / out_size_factor
         l = box[4] / voxel_size[1] / out_size_factor
         if not (w > 0 and l > 0):
             continue
-        radius = max(min_radius, int(gaussian_radius((l, w), min_overlap=gaussian_overlap)))
+        # the three roots in float64 from the fp32 sizes (the reference's numpy promoted fp32-scalar x python-float to float64)
+        radius = max(min_radius, int(gaussian_radius((float(l), float(w)), min_overlap=gaussian_overlap)))
         cx = (box[0] - pc_range[0]) / voxel_size[0] / out_size_factor
         cy = (box[1] - pc_range[1]) / voxel_size[1] / out_size_factor
         ct = np.array([cx, cy], np.float32)
