@@ -112,6 +112,19 @@ class VoxelNet(SingleStageDetector):
         return boxes if not return_feature else (boxes, F_D_a, F_D_b)
 
 
+    def forward_two_stage(self, example, return_loss=True, **kwargs):
+        """first-stage pass of TwoStageDetector (voxelnet.py:107-141): decoded + NMS'd boxes, the neck map, voxel features"""
+        prefix = "dense_" if "dense_voxels" in example else ""
+        data = dict(features=self._read(example, prefix), coors=example[prefix + "coordinates"], batch_size=len(example[prefix + "num_voxels"]),
+                    input_shape=example["shape"][0], bev_private=False)
+        x, voxel_feature, F_D_a = self.extract_feat(data)
+        preds = self._dense(self.bbox_head, x)
+        boxes = self.bbox_head.predict(example, [{k: v.detach() for k, v in p.items()} for p in preds], self.test_cfg)
+        if return_loss:
+            return boxes, x, voxel_feature, self.bbox_head.loss(example, preds)
+        return boxes, x, voxel_feature, None, F_D_a, F_D_a
+
+
 @DETECTORS.register_module
 class KD_VoxelNet(VoxelNet):
     def extract_feat(self, data, train_pcm=True):
@@ -166,3 +179,19 @@ class KD_VoxelNet(VoxelNet):
             return losses, F_S_a, F_S_b, preds, mask_loss, comp_loss
         boxes = self.bbox_head.predict(example, preds, self.test_cfg)
         return boxes if not return_feature else (boxes, F_S_a, F_S_b)
+
+    def forward_two_stage(self, example, return_loss=True, **kwargs):
+        """voxelnet.py:266-301 (the PCR head is not evaluated: train_pcm=False)"""
+        data = dict(features=self._read(example), coors=example["coordinates"], batch_size=len(example["num_voxels"]),
+                    input_shape=example["shape"][0])
+        was_training = self.neck.training
+        self.neck.eval() if not return_loss else None   # S2D_RPN builds its PCR outputs only in training mode
+        try:
+            x, _, _, _, _, F_S_a, F_S_b, voxel_feature = self.extract_feat(data, train_pcm=False)
+        finally:
+            self.neck.train(was_training)
+        preds = self._dense(self.bbox_head, x)
+        boxes = self.bbox_head.predict(example, [{k: v.detach() for k, v in p.items()} for p in preds], self.test_cfg)
+        if return_loss:
+            return boxes, x, voxel_feature, self.bbox_head.loss(example, preds)
+        return boxes, x, voxel_feature, None, F_S_a, F_S_b

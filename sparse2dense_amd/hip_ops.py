@@ -530,7 +530,13 @@ def spconv_s16_wgrad(feat, dout, nbr, kvol, pair_count=None):
 # ------------------------------------------------------------------------------------------------
 # neighbourhood-resident SubM kernel (csrc/spconv_nb.hip): tile plans + launcher
 # ------------------------------------------------------------------------------------------------
-NB_ENABLED = True        # tests / A-B runs can switch the new kernel off (falls back to the gather kernel of spconv_s16.hip)
+# The neighbourhood-resident kernel is correct (tests/test_s16_gpu.py) but, as measured in r02, slower than
+# the gather kernel at every channel count on the bench scene: with 256-row tiles a workgroup needs ~100 KB of resident rows, so
+# one workgroup (one wave per SIMD) per CU, and the per-offset chain "weight image lands -> fragments to registers -> barrier ->
+# A reads -> MFMAs" is exposed latency (119 vs 57 us at 128 channels, 67 vs 48 us at 64).  It stays behind this switch
+# (S2D_NB=1) as the starting point for a software-pipelined version.
+import os as _os
+NB_ENABLED = _os.environ.get("S2D_NB", "0") == "1"
 NB_MIN_ROWS = 2048       # below this the plan build costs more than it saves
 
 

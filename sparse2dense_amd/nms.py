@@ -26,7 +26,7 @@ def rotate_nms(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
     if not boxes.is_cuda:
         raise _lib.S2DError("rotate_nms: CUDA tensors expected (no CPU fallback)")
     lib = _lib.load()
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = torch.sort(scores, dim=0, descending=True, stable=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     n = int(order.shape[0])

@@ -64,7 +64,7 @@ ROI_HEAD = Registry("roi_head")
 
 def _ensure_registered():
     """The model modules register themselves on import; make `build_*` usable on its own."""
-    from . import backbones, detectors, heads, necks, pillars  # noqa: F401
+    from . import backbones, detectors, heads, necks, pillars, second_stage  # noqa: F401
 
 
 def build(cfg, registry, default_args=None):

@@ -172,7 +172,7 @@ def _nb_scene(n_points, batch, seed):
 
 @pytest.mark.parametrize("c", [16, 32, 64, 128])
 @pytest.mark.parametrize("shape,div", [((41, 1504, 1504), 1), ((11, 376, 376), 4)])
-def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div):
+def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div, monkeypatch):
     import numpy as np
     from oracle import spconv_ref as R
     coors = _nb_scene(30000, 2, 5)
@@ -181,6 +181,7 @@ def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div):
     n = coors.shape[0]
     cd = torch.from_numpy(coors).to(DEV)
     rb = H.build_subm_rulebook(cd, 2, shape, (3, 3, 3))
+    monkeypatch.setattr(H, "NB_ENABLED", True)   # off by default (slower than the gather kernel)
     assert H.nb_supported(rb, c)
     plan = H.nb_plan(rb, c)
     # plan invariants: every row in exactly one tile; slots are the distinct neighbours; local map consistent with the global one
@@ -219,9 +220,5 @@ def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div):
     dx = H.spconv_nb_run(dy.to(DEV), H.spconv_nb_pack(w.to(DEV), transpose=True, flip=True), None, plan, n)
     assert (dx.float().cpu() - dref).abs().max() <= 8e-3 * dref.abs().max()
     # and it is what the autograd function of the module layer now runs (same result as the gather kernel)
-    H.NB_ENABLED = False
-    try:
-        old = H.spconv_s16(f.to(DEV), w.to(DEV), b.to(DEV), rb.nbr_out, n)
-    finally:
-        H.NB_ENABLED = True
+    old = H.spconv_s16(f.to(DEV), w.to(DEV), b.to(DEV), rb.nbr_out, n)   # the gather kernel on the same operands
     assert (old.float() - out.float()).abs().max() <= 8e-3 * ref.abs().max()
