@@ -52,6 +52,18 @@ int s2d_version(void);
 int s2d_last_error(char *buf, size_t buf_len);
 
 /* ---- voxelization (hard voxelizer + fused reader mean) ------------------------------------ */
+/*
+ * Batched form: `frames` point clouds concatenated frame after frame (point_offsets[frames + 1], HOST array, offsets[0] = 0),
+ * voxelized in ONE launch chain into the COLLATED example (preprocess.py:316-345 per frame + collate.py:105-144): voxels / num_points /
+ * mean rows frame by frame in first-seen order, coors4[row] = (b, z, y, x) with the batch index prepended, out_m[frames] = voxels
+ * per frame (device), out_base[frames + 1] = their exclusive prefix (out_base[frames] = total rows).  Outputs must hold
+ * sum_b min(n_b, max_voxels) rows.  Same per-frame results as s2d_voxelize_run (bit exact).  frames <= 64.
+ */
+size_t s2d_voxelize_batch_workspace_bytes(int frames, const int64_t *point_offsets, int max_points, int max_voxels);
+int s2d_voxelize_batch_run(const float *points, int frames, const int64_t *point_offsets, int ndim,
+                           const float coors_range[6], const float voxel_size[3], int max_points, int max_voxels,
+                           float *voxels, int32_t *coors4, int32_t *num_points, float *mean, int32_t *out_m,
+                           int32_t *out_base, void *ws, size_t ws_bytes, s2d_stream_t stream);
 /* workspace bytes for one call (hash table, per-point slots, scan scratch, k-smallest lists) */
 size_t s2d_voxelize_workspace_bytes(int64_t n_points, int max_points, int max_voxels);
 /*
@@ -427,6 +439,26 @@ int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const i
                          const float *feats, int64_t m, int batch, int d, int h, int w,
                          const float *fwd_out8, const float *go_mask, const float *go_offset,
                          float *g_gen_mask, float *g_gen_offset_zeroed, s2d_stream_t stream);
+
+/*
+ * Fused PCR level heads + losses: gen_mask_k / gen_out_k (1x1x1 Conv3d C->1 / C->3, det3d/models/necks/rpn.py:273-275,292-294)
+ * and mask_offset_loss (voxelnet.py:171-185) evaluated straight from the level's feature volume g[B][C][D*H*W] - the occupancy
+ * logits, the offset volume and its zero-filled gradient are never written; the offset conv runs at the m recon voxels only.
+ * head_params (device, 4C+4 floats) = w_mask[C] | w_off[3][C] | b_mask | b_off[3].  out8 as s2d_pcr_loss_fwd_f32.
+ * bwd writes dg[B][C][cells] = w_mask*dL/dlogit (+ w2^T.dz when co > 0: the data gradient of the level's next 1x1x1 conv
+ * g -> z[B][co][cells], w2[co][C]) plus the sparse corrections, and dw_mask[C], db_mask[1], dw_off[3][C], db_off[3].
+ * Supported: (C, co) in {(32,0), (32,16), (3,0)}, cells % 4 == 0.
+ */
+int s2d_pcr_heads_supported(int c, int co, int64_t cells);
+size_t s2d_pcr_heads_workspace_bytes(int c);
+int s2d_pcr_heads_fwd_f32(const float *g, const float *head_params, const int32_t *coors, const float *feats,
+                          int64_t m, int batch, int c, int d, int h, int w, float *out8, void *ws,
+                          size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_heads_bwd_f32(const float *g, const float *head_params, const int32_t *coors, const float *feats,
+                          int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                          const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co,
+                          float *dg, float *dw_mask, float *db_mask, float *dw_off, float *db_off, void *ws,
+                          size_t ws_bytes, s2d_stream_t stream);
 
 /*
  * Rotated bird's-eye-view IoU and greedy NMS of CenterHead.predict (det3d/core/bbox/box_torch_ops.py:449-464 rotate_nms_pcdet,

@@ -23,6 +23,9 @@ SIGNATURES = {
     "s2d_voxelize_run": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, _F6, _F3, ctypes.c_int, ctypes.c_int,
                                         c_f32p, c_i32p, c_i32p, c_f32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t,
                                         ctypes.c_void_p]),
+    "s2d_voxelize_batch_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "s2d_voxelize_batch_run": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, _F6, _F3, ctypes.c_int, ctypes.c_int,
+                                              c_f32p, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_rulebook_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _I3, ctypes.c_int64]),
     "s2d_rulebook_subm_build": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, c_i32p, c_i32p,
                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -98,6 +101,13 @@ SIGNATURES = {
                              [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_loss_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 4 +
                              [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_pcr_heads_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "s2d_pcr_heads_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "s2d_pcr_heads_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                              [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_heads_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                              [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int] + [c_f32p] * 5 +
+                              [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bev_iou_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_nms_rotated_bev": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -372,6 +372,98 @@ __global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restr
     }
 }
 
+// narrow-output variant (cout <= 4, the 16 -> 3 layer): the 16 MFMA columns carry (co, kx) pairs instead of 16 output channels
+// (which would leave 13 of 16 columns and lanes idle): column n = co*4 + kx reads dout[co][2c-1+kx] at stride 2 from one aligned
+// float2 window, one MFMA per (kz,ky) row and 32-cell step instead of four, and one wave keeps all 16 (kz,ky) accumulators.
+template <int CIT>
+__global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
+                                                              float *__restrict__ partial) {
+    constexpr int FR = 16 * CIT;
+    __shared__ float red[FR * 4][64];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int co = r >> 2, kx = r & 3;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
+    const int64_t total_rows = (int64_t)s.n * s.d * s.h;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < total_rows ? r0 + rows_per_block : total_rows;
+    f32x4m acc[16][CIT];
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int a = 0; a < CIT; ++a) acc[g][a] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const int steps = (s.w + 31) / 32;
+    for (int64_t row = r0 + wid; row < r1; row += 4) {
+        const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+        const float *xrow = x + (int64_t)n * s.cin * cells + ((int64_t)hz * s.h + hy) * s.w;
+        const float *dbase = dout + (int64_t)n * s.cout * oplane + (int64_t)co * oplane;
+        for (int st = 0; st < steps; ++st) {
+            const int c0 = st * 32 + 8 * q;
+            bf16x8m a[CIT];
+#pragma unroll
+            for (int ai = 0; ai < CIT; ++ai) {
+                const int ci = ai * 16 + r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[ai][e] = (__bf16)0.f;
+                if (ci < s.cin) {
+                    const float *src = xrow + (int64_t)ci * cells + c0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + e < s.w) a[ai][e] = (__bf16)src[e];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int z = 2 * hz - 1 + (g >> 2), y = 2 * hy - 1 + (g & 3);
+                if ((unsigned)z >= (unsigned)od || (unsigned)y >= (unsigned)oh) continue;   // wave-uniform
+                // this lane's 8 samples dout[co][z][y][2*(c0+e) - 1 + kx]: positions p0 + 2e with p0 = 2*c0 - 1 + kx.  Aligned
+                // float2 window starting at the even position 2*c0 - 2 + 2*((kx + 1) >> 1); the sample is its .x (kx odd) or .y
+                bf16x8m b;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[e] = (__bf16)0.f;
+                if (co < s.cout) {
+                    const float *src = dbase + ((int64_t)z * oh + y) * ow;
+                    const int base = 2 * c0 - 2 + 2 * ((kx + 1) >> 1);
+                    const bool odd = kx & 1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int pos = base + 2 * e;   // even position of the pair holding the sample
+                        if (c0 + e < s.w && pos >= 0 && pos + 1 < ow) {
+                            const float2 m = *reinterpret_cast<const float2 *>(src + pos);
+                            b[e] = (__bf16)(odd ? m.x : m.y);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int ai = 0; ai < CIT; ++ai) acc[g][ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], b, acc[g][ai], 0, 0, 0);
+            }
+        }
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+#pragma unroll
+                for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        float *slot = &red[(g * CIT + a) * 4 + reg][lane];
+                        *slot = wv ? *slot + acc[g][a][reg] : acc[g][a][reg];
+                    }
+        }
+        __syncthreads();
+    }
+    float *dst = partial + (int64_t)blockIdx.x * s.cin * s.cout * 64;
+    for (int e = t; e < FR * 4 * 64; e += 256) {
+        const int ln = e % 64, f4 = e / 64, reg = f4 % 4, f = f4 / 4;
+        const int a = f % CIT, g = f / CIT;
+        const int ci = a * 16 + 4 * (ln >> 4) + reg, n_col = ln & 15;
+        const int oc = n_col >> 2, okx = n_col & 3;
+        if (ci < s.cin && oc < s.cout) dst[(((int64_t)ci * s.cout + oc) * 16 + g) * 4 + okx] = red[f4][ln];
+    }
+}
+
 __global__ __launch_bounds__(256) void ct_slab_reduce_kernel(const float *__restrict__ partial, int n_slabs, int64_t size, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= size) return;
@@ -473,7 +565,9 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)ws;
     const int cit = cin / 16, cot = (cout + 15) / 16;
-    if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
+    if (cout <= 4 && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else if (cout <= 4) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
     else hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 1, 8>), dim3(bx, 2), dim3(256), 0, st, in, dout, s, rpb, partial);

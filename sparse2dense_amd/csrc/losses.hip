@@ -214,3 +214,374 @@ extern "C" int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_ma
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
+
+// =====================================================================================================================
+// Fused PCR level heads: gen_mask_k / gen_out_k (1x1x1 Conv3d C->1 and C->3, rpn.py:273-275,292-294) + their two losses
+// evaluated straight from the level's feature volume g[B][C][S] (S = D*H*W cells):
+//   * the occupancy logits are never written: one dense pass computes x = w_mask.g + b and accumulates softplus(x);
+//   * the offsets are only ever looked at in the occupied target cells (sel = tgt != 0 is empty elsewhere), so the C->3 conv
+//     runs at the M recon voxels only;
+//   * backward: ONE dense pass writes dg = w_mask * dL/dx (+ w2^T . dz, the data gradient of the level's next 1x1x1 conv when the
+//     caller hands its output gradient in) and the dense part of dw_mask/db_mask; a sparse pass adds the occupied-cell
+//     corrections and the offset-head terms in place (recon voxels are unique cells: no atomics).
+// Compared with conv -> loss kernels this removes the logits / offsets / zero-filled offset gradient volumes and every separate
+// data-gradient accumulation over g (at the 2x level: 7 passes over 181-543 MB tensors -> 3).
+// =====================================================================================================================
+namespace s2d {
+
+template <int C>
+struct PcrHeadW {
+    float wm[C];
+    float wo[3][C];
+    float bm;
+    float bo[3];
+};
+
+template <int V> struct VecOf;
+template <> struct VecOf<2> { using T = float2; };
+template <> struct VecOf<4> { using T = float4; };
+
+template <int V> __device__ __forceinline__ void vec_load(const float *p, float (&v)[V]) {
+    const typename VecOf<V>::T t = *reinterpret_cast<const typename VecOf<V>::T *>(p);
+    const float *f = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = f[k];
+}
+template <int V> __device__ __forceinline__ void vec_store(float *p, const float (&v)[V]) {
+    typename VecOf<V>::T t;
+    float *f = reinterpret_cast<float *>(&t);
+#pragma unroll
+    for (int k = 0; k < V; ++k) f[k] = v[k];
+    *reinterpret_cast<typename VecOf<V>::T *>(p) = t;
+}
+
+// head parameters (device): w_mask[C] | w_off[3][C] | b_mask | b_off[3] = the memory image of PcrHeadW<C>; every block keeps a copy in LDS
+template <int C>
+__device__ __forceinline__ void pcr_load_head(const float *__restrict__ hp, PcrHeadW<C> &hw) {
+    float *dst = reinterpret_cast<float *>(&hw);
+    for (int i = threadIdx.x; i < 4 * C + 4; i += 256) dst[i] = hp[i];
+    __syncthreads();
+}
+
+template <int K>
+__device__ __forceinline__ void block_sums_n(float (&v)[K], float *out) {
+    __shared__ float red[4][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) out[(int64_t)blockIdx.x * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+
+template <int C, int V>
+__global__ __launch_bounds__(256) void pcr_heads_fwd_dense_kernel(const float *__restrict__ g, const float *__restrict__ hp, int64_t cells, int batch,
+                                                                  float *__restrict__ partial) {
+    __shared__ PcrHeadW<C> hw;
+    pcr_load_head<C>(hp, hw);
+    float acc[1] = {0.f};
+    const int64_t sv = cells / V, total = sv * batch, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / sv, j = i - b * sv;
+        const float *base = g + b * C * cells + j * V;
+        float x[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) x[k] = hw.bm;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float v[V];
+            vec_load<V>(base + (int64_t)c * cells, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = fmaf(hw.wm[c], v[k], x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[0] += softplusf(x[k]);
+    }
+    block_sums<1>(acc, partial);
+}
+
+// the site's logit and offsets from its C feature values
+template <int C>
+__device__ __forceinline__ void pcr_site_eval(const float *__restrict__ g, const PcrHeadW<C> &hw, int64_t cells, int b, int64_t cell, float (&gv)[C],
+                                              float &x, float (&off)[3]) {
+    x = hw.bm;
+    off[0] = hw.bo[0]; off[1] = hw.bo[1]; off[2] = hw.bo[2];
+    const float *base = g + (int64_t)b * C * cells + cell;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gv[c] = base[(int64_t)c * cells];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        x = fmaf(hw.wm[c], gv[c], x);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) off[k] = fmaf(hw.wo[k][c], gv[c], off[k]);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void pcr_heads_fwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
+                                                                   PcrGeo geo, const float *__restrict__ g, const float *__restrict__ hp,
+                                                                   float *__restrict__ partial) {
+    __shared__ PcrHeadW<C> hw;
+    pcr_load_head<C>(hp, hw);
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        const int4 c = reinterpret_cast<const int4 *>(coors)[i];   // b,z,y,x
+        if ((unsigned)c.x >= (unsigned)geo.batch || (unsigned)c.y >= (unsigned)geo.d || (unsigned)c.z >= (unsigned)geo.h ||
+            (unsigned)c.w >= (unsigned)geo.w)
+            continue;
+        const float *f = feats + i * 5;
+        const float s = (((f[0] + f[1]) + f[2]) + f[3]) + f[4];
+        const bool pos = s != 0.f;
+        const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
+        float gv[C], x, off[3];
+        pcr_site_eval<C>(g, hw, cells, c.x, cell, gv, x, off);
+        if (pos) {
+            acc[0] += 1.f;
+            acc[1] += softplusf(-x);
+            acc[2] += softplusf(x);
+        }
+        float gc[3];
+        pcr_grid(geo, c.y, c.z, c.w, gc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = pos ? f[k] - gc[k] : f[k];
+            if (t != 0.f) {
+                acc[3] += fabsf(off[k] - t);
+                acc[4] += 1.f;
+            }
+        }
+    }
+    block_sums<5>(acc, partial);
+}
+
+template <int C, int CO, int V>
+__global__ __launch_bounds__(256) void pcr_heads_bwd_dense_kernel(const float *__restrict__ g, const float *__restrict__ dz,
+                                                                  const float *__restrict__ w2, const float *__restrict__ hp, const float *__restrict__ go_mask,
+                                                                  const float *__restrict__ fin, int64_t cells, int batch, float *__restrict__ dg,
+                                                                  float *__restrict__ partial) {
+    __shared__ float w2s[CO > 0 ? CO * C : 1];
+    __shared__ PcrHeadW<C> hw;
+    pcr_load_head<C>(hp, hw);
+    if (CO > 0) {
+        for (int i = threadIdx.x; i < CO * C; i += 256) w2s[i] = w2[i];
+        __syncthreads();
+    }
+    const float scale = go_mask[0] / fin[4];
+    float pw[C + 1];
+#pragma unroll
+    for (int c = 0; c <= C; ++c) pw[c] = 0.f;
+    const int64_t sv = cells / V, total = sv * batch, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / sv, j = i - b * sv;
+        const float *base = g + b * C * cells + j * V;
+        float x[V], dm[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) x[k] = hw.bm;
+        float gv[C][V];
+#pragma unroll
+        for (int c = 0; c < C; ++c) vec_load<V>(base + (int64_t)c * cells, gv[c]);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = fmaf(hw.wm[c], gv[c][k], x[k]);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            dm[k] = scale * sigmoidf(x[k]);
+            pw[C] += dm[k];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < V; ++k) pw[c] = fmaf(dm[k], gv[c][k], pw[c]);
+        float o[C][V];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[c][k] = hw.wm[c] * dm[k];
+        if (CO > 0) {
+            const float *zb = dz + b * CO * cells + j * V;
+#pragma unroll
+            for (int q = 0; q < CO; ++q) {
+                float zv[V];
+                vec_load<V>(zb + (int64_t)q * cells, zv);
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) o[c][k] = fmaf(w2s[q * C + c], zv[k], o[c][k]);
+            }
+        }
+        float *ob = dg + b * C * cells + j * V;
+#pragma unroll
+        for (int c = 0; c < C; ++c) vec_store<V>(ob + (int64_t)c * cells, o[c]);
+    }
+    block_sums_n<C + 1>(pw, partial);
+}
+
+// per recon voxel: corrections of dg in place + partial sums [dw_mask(C) | dw_off(3C) | db_mask | db_off(3)]
+template <int C>
+__global__ __launch_bounds__(256) void pcr_heads_bwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
+                                                                   PcrGeo geo, const float *__restrict__ g, const float *__restrict__ hp,
+                                                                   const float *__restrict__ go_mask, const float *__restrict__ go_off,
+                                                                   const float *__restrict__ fin, float *__restrict__ dg,
+                                                                   float *__restrict__ partial) {
+    __shared__ PcrHeadW<C> hw;
+    pcr_load_head<C>(hp, hw);
+    float acc[4 * C + 4];
+#pragma unroll
+    for (int k = 0; k < 4 * C + 4; ++k) acc[k] = 0.f;
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float sm = go_mask[0] / fin[4], beta = fin[2], so = go_off[0] / fin[3];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        const int4 c = reinterpret_cast<const int4 *>(coors)[i];
+        if ((unsigned)c.x >= (unsigned)geo.batch || (unsigned)c.y >= (unsigned)geo.d || (unsigned)c.z >= (unsigned)geo.h ||
+            (unsigned)c.w >= (unsigned)geo.w)
+            continue;
+        const float *f = feats + i * 5;
+        const float s = (((f[0] + f[1]) + f[2]) + f[3]) + f[4];
+        const bool pos = s != 0.f;
+        const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
+        float gv[C], x, off[3];
+        pcr_site_eval<C>(g, hw, cells, c.x, cell, gv, x, off);
+        // occupied cell: d/dx beta*softplus(-x) = -beta*(1 - sigmoid(x)) replaces the dense pass's sigmoid(x)
+        float dmk = 0.f;
+        if (pos) {
+            const float sg = sigmoidf(x);
+            dmk = -sm * (beta * (1.f - sg) + sg);
+        }
+        float gc[3], dk[3];
+        pcr_grid(geo, c.y, c.z, c.w, gc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = pos ? f[k] - gc[k] : f[k];
+            const float dlt = off[k] - t;
+            dk[k] = (t != 0.f) ? (dlt > 0.f ? so : (dlt < 0.f ? -so : 0.f)) : 0.f;
+        }
+        float *ob = dg + (int64_t)c.x * C * cells + cell;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const float add = (hw.wm[q] * dmk + hw.wo[0][q] * dk[0]) + (hw.wo[1][q] * dk[1] + hw.wo[2][q] * dk[2]);
+            ob[(int64_t)q * cells] += add;
+            acc[q] = fmaf(dmk, gv[q], acc[q]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[C + k * C + q] = fmaf(dk[k], gv[q], acc[C + k * C + q]);
+        }
+        acc[4 * C] += dmk;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[4 * C + 1 + k] += dk[k];
+    }
+    block_sums_n<4 * C + 4>(acc, partial);
+}
+
+template <int C>
+__global__ void pcr_heads_param_grads_kernel(const float *__restrict__ dense_partial, int nd, const float *__restrict__ sparse_partial, int ns,
+                                             float *__restrict__ dw_mask, float *__restrict__ db_mask, float *__restrict__ dw_off,
+                                             float *__restrict__ db_off) {
+    const int t = threadIdx.x;
+    if (t >= 4 * C + 4) return;
+    double s = 0;
+    for (int i = 0; i < ns; ++i) s += sparse_partial[(int64_t)i * (4 * C + 4) + t];
+    if (t < C || t == 4 * C) {
+        const int col = t < C ? t : C;
+        for (int i = 0; i < nd; ++i) s += dense_partial[(int64_t)i * (C + 1) + col];
+    }
+    if (t < C) dw_mask[t] = (float)s;
+    else if (t < 4 * C) dw_off[t - C] = (float)s;
+    else if (t == 4 * C) db_mask[0] = (float)s;
+    else db_off[t - 4 * C - 1] = (float)s;
+}
+
+constexpr int PCRH_DENSE_BLOCKS = 2048, PCRH_SPARSE_BLOCKS = 256;
+
+template <int C, int V>
+static int pcr_heads_fwd_t(const float *g, const float *hw, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo, float *out8,
+                           float *ws, hipStream_t st) {
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
+    float *dense_partial = ws, *sparse_partial = ws + PCRH_DENSE_BLOCKS;
+    const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(n / V, 256)));
+    const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
+    hipLaunchKernelGGL((pcr_heads_fwd_dense_kernel<C, V>), dim3(nd), dim3(256), 0, st, g, hw, cells, geo.batch, dense_partial);
+    hipLaunchKernelGGL((pcr_heads_fwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, g, hw, sparse_partial);
+    hipLaunchKernelGGL(pcr_finalize_kernel, dim3(1), dim3(64), 0, st, dense_partial, nd, sparse_partial, ns, (double)n, out8);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+template <int C, int CO, int V>
+static int pcr_heads_bwd_t(const float *g, const float *hw, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo, const float *fin,
+                           const float *go_mask, const float *go_off, const float *dz, const float *w2, float *dg, float *dw_mask, float *db_mask,
+                           float *dw_off, float *db_off, float *ws, hipStream_t st) {
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
+    float *dense_partial = ws, *sparse_partial = ws + (size_t)PCRH_DENSE_BLOCKS * (C + 1);
+    const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(n / V, 256)));
+    const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
+    hipLaunchKernelGGL((pcr_heads_bwd_dense_kernel<C, CO, V>), dim3(nd), dim3(256), 0, st, g, dz, w2, hw, go_mask, fin, cells, geo.batch, dg,
+                       dense_partial);
+    hipLaunchKernelGGL((pcr_heads_bwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, g, hw, go_mask, go_off, fin, dg,
+                       sparse_partial);
+    hipLaunchKernelGGL((pcr_heads_param_grads_kernel<C>), dim3(1), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, dw_mask, db_mask, dw_off,
+                       db_off);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+}  // namespace s2d
+
+extern "C" int s2d_pcr_heads_supported(int c, int co, int64_t cells) {
+    return ((c == 32 && (co == 0 || co == 16)) || (c == 3 && co == 0)) && cells > 0 && cells % 4 == 0;
+}
+
+extern "C" size_t s2d_pcr_heads_workspace_bytes(int c) {
+    return ((size_t)PCRH_DENSE_BLOCKS * (c + 1) + (size_t)PCRH_SPARSE_BLOCKS * (4 * c + 4)) * sizeof(float) + 512;
+}
+
+// head_params (device, 4C+4 floats): w_mask[C] | w_off[3][C] | b_mask | b_off[3]  (the two Conv3d's weights and biases)
+extern "C" int s2d_pcr_heads_fwd_f32(const float *g, const float *head_params, const int32_t *coors, const float *feats, int64_t m, int batch,
+                                     int c, int d, int h, int w, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(g && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)),
+                  "pcr_heads_fwd: bad argument");
+    if (!s2d_pcr_heads_supported(c, 0, (int64_t)d * h * w)) {
+        set_error("pcr_heads_fwd: unsupported channels %d / cells %lld", c, (long long)d * h * w);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < s2d_pcr_heads_workspace_bytes(c)) {
+        set_error("pcr_heads_fwd: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    PcrGeo geo{batch, d, h, w};
+    if (c == 32) return pcr_heads_fwd_t<32, 2>(g, head_params, coors, feats, m, geo, out8, (float *)ws, (hipStream_t)stream);
+    return pcr_heads_fwd_t<3, 4>(g, head_params, coors, feats, m, geo, out8, (float *)ws, (hipStream_t)stream);
+}
+
+extern "C" int s2d_pcr_heads_bwd_f32(const float *g, const float *head_params, const int32_t *coors, const float *feats, int64_t m, int batch,
+                                     int c, int d, int h, int w, const float *fwd_out8, const float *go_mask, const float *go_offset,
+                                     const float *dz, const float *w2, int co, float *dg, float *dw_mask, float *db_mask, float *dw_off,
+                                     float *db_off, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(g && head_params && fwd_out8 && go_mask && go_offset && dg && dw_mask && db_mask && dw_off && db_off && batch > 0 && d > 0 &&
+                      h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
+                  "pcr_heads_bwd: bad argument");
+    if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
+        set_error("pcr_heads_bwd: unsupported channels %d -> %d / cells %lld", c, co, (long long)d * h * w);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < s2d_pcr_heads_workspace_bytes(c)) {
+        set_error("pcr_heads_bwd: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    PcrGeo geo{batch, d, h, w};
+    hipStream_t st = (hipStream_t)stream;
+    float *wsf = (float *)ws;
+    if (c == 32 && co == 16)
+        return pcr_heads_bwd_t<32, 16, 2>(g, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, dg, dw_mask, db_mask, dw_off,
+                                          db_off, wsf, st);
+    if (c == 32)
+        return pcr_heads_bwd_t<32, 0, 2>(g, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, dg, dw_mask, db_mask, dw_off,
+                                         db_off, wsf, st);
+    return pcr_heads_bwd_t<3, 0, 4>(g, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, dg, dw_mask, db_mask, dw_off, db_off,
+                                    wsf, st);
+}

@@ -276,3 +276,287 @@ extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim,
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
+
+// =====================================================================================================================
+// Batched voxelizer: B frames in ONE launch chain, writing the collated example directly (what Voxelization.__call__ per frame +
+// collate_kitti produce: /root/reference/det3d/datasets/pipelines/preprocess.py:316-345, det3d/torchie/parallel/collate.py:105-144):
+// points of all frames concatenated frame after frame, voxels numbered frame by frame in first-seen order, coordinates with the
+// batch index prepended (b, z, y, x).  Per-frame hash tables (key = cell inside the frame) share one allocation; `first` holds
+// GLOBAL point indices, so one scan over all points yields global first-seen ranks; per-frame starts S_b turn them into local
+// ranks for the max_voxels cut (new cells past the cap are dropped, existing ones keep filling: point_cloud_ops.py:44-54).
+// =====================================================================================================================
+namespace s2d {
+
+constexpr int VOXB_MAX_FRAMES = 64;
+
+struct VoxBatch {
+    int frames;
+    int offs[VOXB_MAX_FRAMES + 1];        // point offsets of the frames
+    int table_base[VOXB_MAX_FRAMES];      // first hash slot of the frame
+    uint32_t table_mask[VOXB_MAX_FRAMES];
+    int table_shift[VOXB_MAX_FRAMES];
+};
+
+__device__ __forceinline__ int voxb_frame_of(const VoxBatch &vb, int i) {
+    int b = 0;
+    while (b + 1 < vb.frames && i >= vb.offs[b + 1]) ++b;   // <= 64 frames: a short scalar-friendly scan
+    return b;
+}
+
+__global__ __launch_bounds__(256) void voxb_insert_kernel(const float *__restrict__ points, int n, VoxParams p, VoxBatch vb,
+                                                          uint32_t *__restrict__ keys, int *__restrict__ first, int *__restrict__ pt_slot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = voxb_frame_of(vb, i);
+    const float *pt = points + (int64_t)i * p.ndim;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float q = __fdiv_rn(__fsub_rn(pt[j], p.lo[j]), p.vs[j]);
+        float f = floorf(q);
+        ok = ok && (f >= 0.0f) && (f < (float)p.grid[j]);
+        c[j] = (int)f;
+    }
+    int slot = -1;
+    if (ok) {
+        const uint32_t key = ((uint32_t)c[2] * (uint32_t)p.grid[1] + (uint32_t)c[1]) * (uint32_t)p.grid[0] + (uint32_t)c[0];
+        uint32_t h = vox_hash(key, vb.table_shift[b]);
+        uint32_t *kb = keys + vb.table_base[b];
+        while (true) {
+            uint32_t old = atomicCAS(&kb[h], VOX_EMPTY, key);
+            if (old == VOX_EMPTY || old == key) break;
+            h = (h + 1) & vb.table_mask[b];
+        }
+        atomicMin(&first[vb.table_base[b] + h], i);
+        slot = vb.table_base[b] + (int)h;
+    }
+    pt_slot[i] = slot;
+}
+
+// scan output: global first-seen rank per table slot, and the rank at every frame start (S_b)
+struct VoxbRankOut {
+    const int *pt_slot;
+    int *rank_of_slot;
+    int *frame_start_rank;   // [frames + 1]
+    VoxBatch vb;
+    int n;
+    __device__ void operator()(int64_t i, int flag, int rank) const {
+        for (int b = 0; b < vb.frames; ++b)
+            if ((int)i == vb.offs[b]) frame_start_rank[b] = rank;
+        if ((int)i == n - 1) frame_start_rank[vb.frames] = rank + flag;
+        if (flag) rank_of_slot[pt_slot[i]] = rank;
+    }
+};
+
+// one block: per-frame voxel counts (capped), their exclusive prefix (output row base), totals
+__global__ void voxb_frame_counts_kernel(const int *__restrict__ frame_start_rank, VoxBatch vb, int max_voxels, int32_t *__restrict__ out_m /*[frames]*/,
+                                         int *__restrict__ out_base /*[frames + 1]*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int base = 0;
+    for (int b = 0; b < vb.frames; ++b) {
+        // a frame start at or past the last point was never visited by the scan: its rank is the total
+        const int n = vb.offs[vb.frames];
+        const int s0 = vb.offs[b] >= n ? frame_start_rank[vb.frames] : frame_start_rank[b];
+        const int s1 = vb.offs[b + 1] >= n ? frame_start_rank[vb.frames] : frame_start_rank[b + 1];
+        int m = s1 - s0;
+        m = m < max_voxels ? m : max_voxels;
+        out_m[b] = m;
+        out_base[b] = base;
+        base += m;
+    }
+    out_base[vb.frames] = base;
+}
+
+// first points only: voxel row (or -1 past the cap) per table slot + the collated coordinate row
+__global__ __launch_bounds__(256) void voxb_assign_kernel(const int *__restrict__ pt_slot, const int *__restrict__ first, const uint32_t *__restrict__ keys,
+                                                          const int *__restrict__ rank_of_slot, const int *__restrict__ frame_start_rank,
+                                                          const int *__restrict__ out_base, int n, VoxParams p, VoxBatch vb, int *__restrict__ vid,
+                                                          int32_t *__restrict__ coors4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = pt_slot[i];
+    if (s < 0 || first[s] != i) return;
+    const int b = voxb_frame_of(vb, i);
+    int start = frame_start_rank[b];
+    const int local = rank_of_slot[s] - start;
+    if (local < p.max_voxels) {
+        const int row = out_base[b] + local;
+        vid[s] = row;
+        uint32_t key = keys[s];
+        const int x = key % (uint32_t)p.grid[0];
+        key /= (uint32_t)p.grid[0];
+        const int y = key % (uint32_t)p.grid[1];
+        const int z = key / (uint32_t)p.grid[1];
+        reinterpret_cast<int4 *>(coors4)[row] = int4{b, z, y, x};
+    } else {
+        vid[s] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void voxb_fill_kernel(const float *__restrict__ points, const int *__restrict__ ksmall, const int *__restrict__ out_base,
+                                                        int frames, int ndim, int max_points, float *__restrict__ voxels,
+                                                        int32_t *__restrict__ num_points) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (voxel, slot)
+    const int m = out_base[frames];
+    const int64_t v = t / max_points;
+    const int r = (int)(t - v * max_points);
+    if (v >= m) return;
+    const int pid = ksmall[t];
+    float *dst = voxels + t * ndim;
+    if (pid != IDX_EMPTY) {
+        const float *src = points + (int64_t)pid * ndim;
+        for (int c = 0; c < ndim; ++c) dst[c] = src[c];
+    } else {
+        for (int c = 0; c < ndim; ++c) dst[c] = 0.0f;
+    }
+    if (r == 0) {
+        int cnt = 0;
+        for (int q = 0; q < max_points; ++q) cnt += (ksmall[v * max_points + q] != IDX_EMPTY) ? 1 : 0;
+        num_points[v] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(256) void voxb_mean_kernel(const float *__restrict__ points, const int *__restrict__ ksmall, const int *__restrict__ out_base,
+                                                        int frames, int ndim, int max_points, float *__restrict__ mean) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (voxel, channel)
+    const int m = out_base[frames];
+    const int64_t v = t / ndim;
+    const int c = (int)(t - v * ndim);
+    if (v >= m) return;
+    float s = 0.0f;
+    int cnt = 0;
+    for (int q = 0; q < max_points; ++q) {
+        int pid = ksmall[v * max_points + q];
+        if (pid != IDX_EMPTY) {
+            s = __fadd_rn(s, points[(int64_t)pid * ndim + c]);
+            ++cnt;
+        }
+    }
+    mean[t] = __fdiv_rn(s, (float)cnt);
+}
+
+struct VoxbWs {
+    uint32_t *keys;
+    int *first, *vid, *rank_of_slot, *pt_slot, *block_sums, *total, *ksmall, *frame_start_rank, *out_base;
+    size_t table_total;
+    size_t bytes;
+};
+
+static size_t voxb_table(int64_t n) {
+    size_t t = 1024;
+    while (t < (size_t)(2 * (n > 0 ? n : 1))) t <<= 1;
+    return t;
+}
+
+static VoxbWs voxb_carve(void *ws, int frames, const int64_t *offsets, int max_points, int max_voxels) {
+    VoxbWs w;
+    size_t tt = 0;
+    int64_t rows = 0;
+    for (int b = 0; b < frames; ++b) {
+        const int64_t nb = offsets[b + 1] - offsets[b];
+        tt += voxb_table(nb);
+        rows += nb < max_voxels ? nb : max_voxels;
+    }
+    const int64_t n = offsets[frames];
+    w.table_total = tt;
+    Carver c(ws);
+    w.keys = c.take<uint32_t>(tt);
+    w.first = c.take<int>(tt);
+    w.vid = c.take<int>(tt);
+    w.rank_of_slot = c.take<int>(tt);
+    w.pt_slot = c.take<int>(n > 0 ? n : 1);
+    w.block_sums = c.take<int>(scan_num_blocks(n));
+    w.total = c.take<int>(1);
+    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.frame_start_rank = c.take<int>(frames + 1);
+    w.out_base = c.take<int>(frames + 1);
+    w.bytes = c.total();
+    return w;
+}
+
+}  // namespace s2d
+
+extern "C" size_t s2d_voxelize_batch_workspace_bytes(int frames, const int64_t *point_offsets, int max_points, int max_voxels) {
+    if (frames <= 0 || frames > VOXB_MAX_FRAMES || !point_offsets || max_points <= 0 || max_voxels <= 0) return 0;
+    return voxb_carve(nullptr, frames, point_offsets, max_points, max_voxels).bytes;
+}
+
+extern "C" int s2d_voxelize_batch_run(const float *points, int frames, const int64_t *point_offsets, int ndim, const float coors_range[6],
+                                      const float voxel_size[3], int max_points, int max_voxels, float *voxels, int32_t *coors4,
+                                      int32_t *num_points, float *mean, int32_t *out_m, int32_t *out_base, void *ws, size_t ws_bytes,
+                                      s2d_stream_t stream) {
+    S2D_CHECK_ARG(frames > 0 && frames <= VOXB_MAX_FRAMES && point_offsets, "voxelize_batch: 1..%d frames", VOXB_MAX_FRAMES);
+    S2D_CHECK_ARG(ndim >= 3 && max_points > 0 && max_voxels > 0, "voxelize_batch: bad ndim/max_points/max_voxels");
+    S2D_CHECK_ARG(coors_range && voxel_size && out_m && out_base && coors4 && voxels && num_points, "voxelize_batch: null argument");
+    const int64_t n_points = point_offsets[frames];
+    S2D_CHECK_ARG(point_offsets[0] == 0 && n_points >= 0 && n_points < (int64_t)INT_MAX / 2, "voxelize_batch: bad offsets");
+    S2D_CHECK_ARG(n_points == 0 || points, "voxelize_batch: null points");
+    hipStream_t st = (hipStream_t)stream;
+    VoxParams p;
+    double cells = 1.0;
+    for (int j = 0; j < 3; ++j) {
+        p.lo[j] = coors_range[j];
+        p.vs[j] = voxel_size[j];
+        float g = (coors_range[3 + j] - coors_range[j]) / voxel_size[j];
+        p.grid[j] = (int)nearbyintf(g);
+        S2D_CHECK_ARG(p.grid[j] > 0, "voxelize_batch: empty grid on axis %d", j);
+        cells *= p.grid[j];
+    }
+    if (cells >= 4294967295.0) {
+        set_error("voxelize_batch: grid of %.0f cells exceeds the 32-bit key space", cells);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    p.ndim = ndim; p.max_points = max_points; p.max_voxels = max_voxels; p.table_mask = 0; p.table_shift = 0;
+    VoxbWs w = voxb_carve(ws, frames, point_offsets, max_points, max_voxels);
+    if (ws_bytes < w.bytes || !ws) {
+        set_error("voxelize_batch: workspace too small (%zu < %zu)", ws_bytes, w.bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    VoxBatch vb;
+    vb.frames = frames;
+    int64_t rows = 0;
+    size_t tb = 0;
+    for (int b = 0; b < frames; ++b) {
+        S2D_CHECK_ARG(point_offsets[b + 1] >= point_offsets[b], "voxelize_batch: offsets must not decrease");
+        const int64_t nb = point_offsets[b + 1] - point_offsets[b];
+        const size_t t = voxb_table(nb);
+        int lg = 0;
+        while (((size_t)1 << lg) < t) ++lg;
+        vb.offs[b] = (int)point_offsets[b];
+        vb.table_base[b] = (int)tb;
+        vb.table_mask[b] = (uint32_t)(t - 1);
+        vb.table_shift[b] = 32 - lg;
+        tb += t;
+        rows += nb < max_voxels ? nb : max_voxels;
+    }
+    vb.offs[frames] = (int)n_points;
+    if (n_points == 0) {
+        S2D_HIP(hipMemsetAsync(out_m, 0, sizeof(int32_t) * frames, st));
+        S2D_HIP(hipMemsetAsync(out_base, 0, sizeof(int32_t) * (frames + 1), st));
+        return S2D_OK;
+    }
+    const int n = (int)n_points;
+    S2D_HIP(hipMemsetAsync(w.keys, 0xFF, w.table_total * sizeof(uint32_t), st));
+    S2D_HIP(hipMemsetAsync(w.first, 0x7F, w.table_total * sizeof(int), st));
+    S2D_HIP(hipMemsetAsync(w.ksmall, 0x7F, (size_t)rows * max_points * sizeof(int), st));
+    const dim3 blk(256);
+    hipLaunchKernelGGL(voxb_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, vb, w.keys, w.first, w.pt_slot);
+    S2D_LAUNCH_CHECK();
+    FirstFlagIn fin{w.pt_slot, w.first};
+    VoxbRankOut fout{w.pt_slot, w.rank_of_slot, w.frame_start_rank, vb, n};
+    int rc = device_exclusive_scan(fin, fout, n_points, w.block_sums, w.total, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base);
+    S2D_HIP(hipMemcpyAsync(out_base, w.out_base, sizeof(int32_t) * (frames + 1), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(voxb_assign_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.keys, w.rank_of_slot, w.frame_start_rank,
+                       w.out_base, n, p, vb, w.vid, coors4);
+    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.vid, n, max_points, w.ksmall);
+    hipLaunchKernelGGL(voxb_fill_kernel, dim3((unsigned)ceil_div(rows * max_points, 256)), blk, 0, st, points, w.ksmall, w.out_base, frames, ndim,
+                       max_points, voxels, num_points);
+    if (mean)
+        hipLaunchKernelGGL(voxb_mean_kernel, dim3((unsigned)ceil_div(rows * ndim, 256)), blk, 0, st, points, w.ksmall, w.out_base, frames, ndim,
+                           max_points, mean);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

@@ -151,10 +151,16 @@ class KD_VoxelNet(VoxelNet):
         batch_size = len(example["num_voxels"])
         data = dict(features=self._read(example), coors=example["coordinates"], batch_size=batch_size,
                     input_shape=example["shape"][0])
+        want_pcr = self.training and return_loss
+        if want_pcr and data["features"].is_cuda and hasattr(self.neck, "pcr_targets"):
+            # hand the recon voxels to the neck: its PCR levels return their losses directly (heads.pcr_level)
+            self.neck.pcr_targets = {s: (example[f"reconstruction_coordinates_{s}"], self._read_scaled(example, s)) for s in (4, 2)}
         x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, _ = self.extract_feat(data)
         mask_loss = comp_loss = 0
-        if self.training and return_loss:
-            if gen_offset_2.is_cuda and gen_offset_2.dtype == torch.float32:
+        if want_pcr:
+            if gen_offset_2.dim() == 0:   # fused levels: the slots already hold the losses
+                m4, o4, m2, o2 = gen_mask_4, gen_offset_4, gen_mask_2, gen_offset_2
+            elif gen_offset_2.is_cuda and gen_offset_2.dtype == torch.float32:
                 # the reconstruction targets stay sparse: both PCR losses are evaluated at the recon voxels plus one dense
                 # reduction over the occupancy logits (csrc/losses.hip) - no [B,5,20,752,752] / [B,5,10,376,376] volumes
                 m4, o4 = mask_offset_loss_sparse(gen_offset_4, gen_mask_4, example["reconstruction_coordinates_4"],

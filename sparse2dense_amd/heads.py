@@ -140,6 +140,87 @@ def mask_offset_loss_sparse(gen_offset, gen_mask, coors, feats):
     return _PcrLossFn.apply(gen_offset, gen_mask, coors if coors.dtype == torch.int32 else coors.int(), feats.float())
 
 
+class _PcrLevelFn(torch.autograd.Function):
+    """One PCR level: the mask / offset 1x1x1 heads and their two losses straight from the level's feature volume, plus
+    (optionally) the level's next 1x1x1 conv g -> z whose data gradient joins the same backward pass (csrc/losses.hip,
+    "Fused PCR level heads").  Returns (mask_loss, offset_loss, z | None)."""
+
+    @staticmethod
+    def forward(ctx, g, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        from .dense3d import pointwise_conv
+        lib = _lib.load()
+        g = g.contiguous()
+        b, c, d, h, w = g.shape
+        hp = torch.cat([w_mask.reshape(-1), w_off.reshape(-1), b_mask.reshape(-1), b_off.reshape(-1)]).float().contiguous()
+        coors, feats = coors.contiguous(), feats.contiguous()
+        out = torch.empty(8, dtype=torch.float32, device=g.device)
+        ws = _ws(lib.s2d_pcr_heads_workspace_bytes(c), g.device)
+        _lib.check(lib.s2d_pcr_heads_fwd_f32(_ptr(g), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(ws),
+                                             ws.numel(), _stream()), "s2d_pcr_heads_fwd_f32")
+        z = w2d = None
+        if w2 is not None:
+            w2d = w2.reshape(w2.shape[0], w2.shape[1]).contiguous()
+            z = pointwise_conv(g, w2d, b2)
+        ctx.save_for_backward(g, hp, coors, feats, out, w2d)
+        ctx.shapes = (w_mask.shape, w_off.shape, None if w2 is None else w2.shape, b2 is not None)
+        return out[0], out[1], z
+
+    @staticmethod
+    def backward(ctx, go_mask, go_off, dz):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        lib = _lib.load()
+        g, hp, coors, feats, out, w2d = ctx.saved_tensors
+        b, c, d, h, w = g.shape
+        dev = g.device
+        zero = lambda: torch.zeros(1, dtype=torch.float32, device=dev)
+        go_mask = zero() if go_mask is None else go_mask.float().reshape(1).contiguous()
+        go_off = zero() if go_off is None else go_off.float().reshape(1).contiguous()
+        co = 0
+        if w2d is not None:
+            co = w2d.shape[0]
+            dz = torch.zeros((b, co, d, h, w), dtype=torch.float32, device=dev) if dz is None else dz.contiguous()
+        dg = torch.empty_like(g)
+        grads = torch.empty(4 * c + 4, dtype=torch.float32, device=dev)   # dw_mask | dw_off | db_mask | db_off
+        ws = _ws(lib.s2d_pcr_heads_workspace_bytes(c), dev)
+        base = grads.data_ptr()
+        _lib.check(lib.s2d_pcr_heads_bwd_f32(_ptr(g), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(go_mask),
+                                             _ptr(go_off), _ptr(dz) if co else None, _ptr(w2d) if co else None, co, _ptr(dg), base,
+                                             base + 4 * 4 * c, base + 4 * c, base + 4 * (4 * c + 1), _ptr(ws), ws.numel(), _stream()),
+                   "s2d_pcr_heads_bwd_f32")
+        wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
+        dw2 = db2 = None
+        if co:
+            dw2 = torch.empty((co, c), dtype=torch.float32, device=dev)
+            db2 = torch.empty((co,), dtype=torch.float32, device=dev) if has_b2 else None
+            ws2 = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(c, co), dev)
+            _lib.check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(g), _ptr(dz), b, c, co, d * h * w, _ptr(dw2), _ptr(db2), _ptr(ws2), ws2.numel(),
+                                                        _stream()), "s2d_pointwise_conv_wgrad_f32")
+            dw2 = dw2.reshape(w2_shape)
+        return (dg, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:], None, None,
+                dw2, db2)
+
+
+def pcr_level_supported(g, next_conv=None):
+    """the fused level (heads + losses [+ next 1x1x1 conv]) runs on CUDA fp32 volumes of 32 or 3 channels"""
+    if not (torch.is_tensor(g) and g.is_cuda and g.dtype == torch.float32 and g.dim() == 5):
+        return False
+    from . import _lib
+    co = 0 if next_conv is None else next_conv.weight.shape[0]
+    return bool(_lib.load().s2d_pcr_heads_supported(g.shape[1], co, g.shape[2] * g.shape[3] * g.shape[4]))
+
+
+def pcr_level(g, mask_conv, offset_conv, coors, feats, next_conv=None):
+    """(mask_loss, offset_loss, next_conv(g) | None) of one PCR level: `mask_offset_loss(offset_conv(g), mask_conv(g), gt, grid)` with
+    the sparse recon voxels (coors i32[M,4], feats f32[M,5]) standing in for the dense gt (voxelnet.py:171-185,203-249)."""
+    assert mask_conv.bias is not None and offset_conv.bias is not None
+    coors = coors if coors.dtype == torch.int32 else coors.int()
+    return _PcrLevelFn.apply(g, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors, feats.float(),
+                             None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias)
+
+
 def metric_grid(n, d, h, w, like):
     """Cell-centre metric coordinates (x,y,z) of a [D,H,W] grid over the Waymo range
     (voxelnet.py:232-236; the x step reuses 150.4/H exactly as the reference does)."""

@@ -79,6 +79,35 @@ def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max
     return voxels[:m], coors[:m], num[:m], (mean[:m] if with_mean else None)
 
 
+def voxelize_batch(points_cat: torch.Tensor, offsets, voxel_size, coors_range, max_points: int, max_voxels: int):
+    """B frames (points concatenated frame after frame, `offsets` = B+1 host ints) voxelized in ONE launch chain straight into
+    the collated layout.  Returns (voxels f32[M,P,C], coors i32[M,4] (b,z,y,x), num_points i32[M], mean f32[M,C],
+    num_voxels i64[B]) with ONE host read (the B+1 row offsets)."""
+    lib = _lib.load()
+    _need_gpu(points_cat)
+    points_cat = points_cat.contiguous().float()
+    n, ndim = points_cat.shape
+    frames = len(offsets) - 1
+    assert offsets[0] == 0 and offsets[-1] == n
+    offs = (ctypes.c_int64 * (frames + 1))(*[int(o) for o in offsets])
+    dev = points_cat.device
+    rows = max(sum(min(int(offsets[b + 1] - offsets[b]), max_voxels) for b in range(frames)), 1)
+    voxels = torch.empty((rows, max_points, ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+    num = torch.empty((rows,), dtype=torch.int32, device=dev)
+    mean = torch.empty((rows, ndim), dtype=torch.float32, device=dev)
+    out_m = torch.empty((frames,), dtype=torch.int32, device=dev)
+    out_base = torch.empty((frames + 1,), dtype=torch.int32, device=dev)
+    ws = _ws(lib.s2d_voxelize_batch_workspace_bytes(frames, offs, max_points, max_voxels), dev)
+    check(lib.s2d_voxelize_batch_run(_ptr(points_cat), frames, offs, ndim, f6(coors_range), f3(voxel_size), max_points, max_voxels,
+                                     _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(out_m), _ptr(out_base), _ptr(ws), ws.numel(),
+                                     _stream()), "s2d_voxelize_batch_run")
+    base = out_base.cpu().tolist()   # the one host read of the batch
+    m = base[-1]
+    counts = torch.tensor([base[b + 1] - base[b] for b in range(frames)], dtype=torch.int64, device=dev)
+    return voxels[:m], coors[:m], num[:m], mean[:m], counts
+
+
 # ------------------------------------------------------------------------------------------------
 # rulebooks
 # ------------------------------------------------------------------------------------------------

@@ -17,6 +17,7 @@ from torch import nn
 from .backbones import build_norm_layer
 from .dense2d import Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
+from .heads import pcr_level, pcr_level_supported
 from .registry import NECKS
 
 
@@ -107,6 +108,22 @@ class RPN(nn.Module):
         return self._trunk(x, relu_between=True)  # rpn.py:156
 
 
+class _ToPlanarF32(torch.autograd.Function):
+    """NHWC bf16 map -> contiguous (NCHW) fp32 in ONE cast+layout pass, and the gradient back to NHWC bf16 in one pass: the
+    layers on either side then see the layout they are written for (a plain `.float().contiguous()` left the gradient in NCHW
+    strides, which sent the GELU / batch-norm backward of the producing layer down strided, non-vectorised kernels)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.src_dtype = x.dtype
+        ctx.channels_last = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        return x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(dtype=ctx.src_dtype, memory_format=torch.channels_last if ctx.channels_last else torch.contiguous_format)
+
+
 def _cbg(*convs_and_channels):
     """conv -> BatchNorm2d -> GELU groups of the S2D module (rpn.py:186-253); the drop-in layer classes take the HIP
     kernels on NHWC bf16 inputs and are the stock layers otherwise"""
@@ -153,6 +170,9 @@ class S2D_RPN(RPN):
                                          ConvTranspose3dK4S2(16, 3, 4, 2, 1), bnr(3), nn.Identity())
         self.gen_out_2 = nn.Sequential(PointwiseConv3d(3, 3, 1, 1, 0))
         self.gen_mask_2 = nn.Sequential(PointwiseConv3d(3, 1, 1, 1, 0))
+        # {4: (coors, feats), 2: (coors, feats)} of the recon voxels, set by KD_VoxelNet for ONE forward: the PCR levels then return
+        # their losses (0-dim tensors in the gen_mask_* / gen_offset_* slots) instead of the dense logits / offsets
+        self.pcr_targets = None
 
     def forward(self, x):
         if self.trunk_channels_last and x.is_cuda:   # NHWC end to end: conv, batch norm and GELU all keep the layout
@@ -172,14 +192,26 @@ class S2D_RPN(RPN):
             # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
             with torch.autocast("cuda", enabled=False):
                 if gen.dtype in (torch.bfloat16, torch.float16):
-                    gen = gen.float()
+                    gen = _ToPlanarF32.apply(gen)
                 gen = gen.contiguous().view(n, 128, 5, h, w)
                 gen = self.generator_1(gen)
-                gen_offset_4 = self.gen_out_4(gen)
-                gen_mask_4 = self.gen_mask_4(gen)
-                gen = self.generator_2(gen)
-                gen_mask_2 = self.gen_mask_2(gen)
-                gen_offset_2 = self.gen_out_2(gen)
+                tg, self.pcr_targets = self.pcr_targets, None
+                if tg is not None and pcr_level_supported(gen, self.generator_2[0]):
+                    # the detector handed the recon voxels in: each level's mask / offset heads and losses are evaluated without
+                    # writing the logits / offset volumes (heads.pcr_level); the gen_* slots carry the 0-dim losses instead
+                    gen_mask_4, gen_offset_4, z = pcr_level(gen, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
+                    gen = self.generator_2[1:](z)
+                    if pcr_level_supported(gen):
+                        gen_mask_2, gen_offset_2, _ = pcr_level(gen, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
+                    else:
+                        from .heads import mask_offset_loss_sparse
+                        gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
+                else:
+                    gen_offset_4 = self.gen_out_4(gen)
+                    gen_mask_4 = self.gen_mask_4(gen)
+                    gen = self.generator_2(gen)
+                    gen_mask_2 = self.gen_mask_2(gen)
+                    gen_offset_2 = self.gen_out_2(gen)
         else:
             gen_offset_2 = gen_mask_2 = gen_offset_4 = gen_mask_4 = None
         # the trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)

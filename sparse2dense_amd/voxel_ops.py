@@ -71,11 +71,22 @@ class VoxelGenerator:
         return self._grid_size
 
 
-def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefix=""):
+def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefix="", batched=True):
     """List of per-sample cuda point tensors -> the collated example fields
     `{prefix}voxels f32[sum M,P,C]`, `{prefix}coordinates i32[sum M,4] (b,z,y,x)`,
     `{prefix}num_points i32[sum M]`, `{prefix}num_voxels i64[B]`, plus `{prefix}voxel_mean`
     (the fused reader output).  Key names: collate.py:105-144 / trainer.py:78-124."""
+    mv = generator._max_voxels if max_voxels == -1 else max_voxels
+    if batched and point_clouds[0].is_cuda and len(point_clouds) <= 64:
+        # device-side batched voxelizer: one launch chain and one host read for the whole batch (csrc/voxelize.hip)
+        offs = [0]
+        for pts in point_clouds:
+            offs.append(offs[-1] + int(pts.shape[0]))
+        cat = point_clouds[0] if len(point_clouds) == 1 else torch.cat([p.float() for p in point_clouds], 0)
+        v, c, n, m, counts = H.voxelize_batch(cat, offs, generator.voxel_size, generator.point_cloud_range,
+                                              generator.max_num_points_per_voxel, mv)
+        return {prefix + "voxels": v, prefix + "coordinates": c, prefix + "num_points": n, prefix + "num_voxels": counts,
+                prefix + "voxel_mean": m}
     # launch every frame's voxelizer first, then read the B voxel counts with ONE host sync
     pend = [H.voxelize_async(pts, generator.voxel_size, generator.point_cloud_range, generator.max_num_points_per_voxel,
                              generator._max_voxels if max_voxels == -1 else max_voxels, with_mean=True)

@@ -83,6 +83,31 @@ def test_voxelize_is_deterministic_and_idempotent():
     assert torch.equal(c2, a[1])
 
 
+@pytest.mark.parametrize("max_voxels,max_points,voxel,rng", [(150000, 5, "WAYMO", None), (6000, 5, "WAYMO", None),
+                                                              (32000, 20, "PILLAR", None)])
+def test_batched_voxelizer_matches_per_frame_oracle(max_voxels, max_points, voxel, rng):
+    """one launch chain for B frames == per-frame oracle + collate (batch index prepended), incl. an empty frame, a frame whose
+    points all fall outside the range, and the max_voxels cut applied per frame"""
+    vs, pr = (scene.WAYMO_VOXEL, scene.WAYMO_RANGE) if voxel == "WAYMO" else (scene.PILLAR_VOXEL, scene.PILLAR_RANGE)
+    frames = [scene.make_scene(20000, seed=1)["points"], np.zeros((0, 5), np.float32), scene.make_scene(35000, seed=2)["points"],
+              np.full((100, 5), 1e4, np.float32), scene.make_scene(9000, seed=3)["points"]]
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in frames])])
+    out = H.voxelize_batch(_dev(np.concatenate(frames, 0)), offs.tolist(), vs, pr, max_points, max_voxels)
+    ev, ec, en, em, cnt = [], [], [], [], []
+    for b, f in enumerate(frames):
+        v, c, n = OV.points_to_voxel(f, vs, pr, max_points, max_voxels)
+        ev.append(v); en.append(n); cnt.append(len(n))
+        ec.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+        em.append(OV.voxel_mean(v, n).reshape(len(n), 5))
+    assert out[4].cpu().tolist() == cnt
+    _check_vox(out[:4], np.concatenate(ev), np.concatenate(ec), np.concatenate(en), np.concatenate(em), max_points)
+
+
+def test_batched_voxelizer_all_frames_empty():
+    out = H.voxelize_batch(torch.zeros((0, 5), device=DEV), [0, 0, 0], scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 1000)
+    assert out[0].shape[0] == 0 and out[1].shape == (0, 4) and out[4].cpu().tolist() == [0, 0]
+
+
 # ------------------------------------------------------------------------------------------------
 # rulebooks
 # ------------------------------------------------------------------------------------------------

@@ -3,8 +3,7 @@
    python tools/prof_summary.py <dir-with-*_kernel_trace.csv> [voxelizer_launches_per_step]
 Prints (a) whole-run per-kernel stats and (b) the kernel breakdown of the LAST steady-state step
 (steps are delimited by the voxelizer's first kernel; launches per step = frames for the single-stage workloads,
-5 x frames for the S2D workloads, whose frames are voxelized as points / dense / reconstruction at three scales - or 1
-with the batched voxelizer)."""
+5 for the S2D workloads with the batched voxelizer: points / dense / reconstruction at three scales)."""
 import collections
 import csv
 import glob
@@ -18,7 +17,7 @@ def main():
     trace = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "vox_insert" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "vox_insert" in r["Kernel_Name"] or "voxb_insert" in r["Kernel_Name"]]
     starts = idx[::frames]
     a, b = starts[-2], starts[-1]
     seg = rows[a:b]
