@@ -299,7 +299,8 @@ int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c,
  * ([n sites][c], scn.py:73-83) with `residual` added before the ReLU.  Backward: with y == NULL the
  * ReLU mask is recomputed from x, scale and shift (y > 0 <=> x*scale+shift > 0; only valid without a
  * residual), otherwise taken from y; dres (optional) receives the masked dy, i.e. the gradient of
- * the residual branch.
+ * the residual branch.  `relu` is an activation code: 0 none, 1 ReLU, 2 exact (erf) GELU - the conv-BN-GELU groups of the
+ * S2D module (det3d/models/necks/rpn.py:186-253); the GELU derivative is always recomputed from x, scale and shift.
  */
 size_t s2d_bnrow_workspace_bytes(int64_t n, int c);
 /* stats: [2c] sums, plus the row count at stats[2c] when write_count (the [2c+1] vector SyncBN all-reduces) */
@@ -419,6 +420,12 @@ int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int ci
  * dbias[cout] = sum dout (NCDHW fp32 tensors, positions % 4 == 0); deterministic two-stage reduction */
 size_t s2d_pointwise_conv_wgrad_workspace_bytes(int cin, int cout);
 int s2d_pointwise_conv_wgrad_f32(const float *in, const float *dout, int batch, int cin, int cout,
+                                 int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                 s2d_stream_t stream);
+/* same contract (and workspace) with both operands rounded to bf16 and contracted on the matrix cores in ONE pass over the two
+ * tensors; supported: (cin 128, cout <= 32), (cin 32, cout <= 16), positions % 4 == 0, one sample's planes < 2 GB */
+int s2d_pointwise_conv_wgrad_bf16_supported(int cin, int cout, int64_t positions);
+int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout, int batch, int cin, int cout,
                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
                                  s2d_stream_t stream);
 

@@ -96,6 +96,9 @@ SIGNATURES = {
     "s2d_pointwise_conv_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "s2d_pointwise_conv_wgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, c_f32p,
                                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pointwise_conv_wgrad_bf16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "s2d_pointwise_conv_wgrad_bf16": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, c_f32p,
+                                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_loss_workspace_bytes": (ctypes.c_size_t, []),
     "s2d_pcr_loss_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 4 +
                              [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

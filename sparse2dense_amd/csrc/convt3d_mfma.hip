@@ -24,6 +24,11 @@ namespace s2d {
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
 
+// planar tensors through buffer instructions (s2d_common.h)
+constexpr unsigned CT_OOB = BUF_OOB;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ct_rsrc(const void *base, unsigned bytes) { return buf_rsrc(base, bytes); }
+__device__ __forceinline__ f32x4m ct_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return buf_load4(r, voff, soff); }
+
 struct CtDims {
     int n, d, h, w;   // batch and INPUT extents; output is 2d x 2h x 2w
     int cin, cout;
@@ -262,6 +267,91 @@ __global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restr
     }
 }
 
+// ---- data gradient without LDS staging -------------------------------------------------------------
+// M = 16 input cells per MFMA row tile, N = ci, and per (kz,ky) output row K = (kx, co): COP = 8: one MFMA, lane (r = cell,
+// q = kx) holds co 0..7 at position 2c-1+q;  COP = 32: four MFMAs (kx = k-step), lane (r, q) holds co 8q..8q+7 at position 2c-1+kx.
+// The A fragments come straight from the planar dout through dword buffer loads (lanes r walk the row at stride 2: one
+// instruction covers ~140 contiguous bytes per plane), rows / columns / channels outside the tensor get an out-of-range per-lane
+// offset.  A wave owns MT row tiles of one input row, so every weight fragment it reads (L1) feeds MT MFMAs.  The staged kernel
+// above holds 64 KB of LDS per block (two blocks per CU) and waits for memory once per staging round: 1.9 ms for the 16 -> 3
+// layer at [4,16,10,376,376] against a 0.2 ms stream.
+template <int COP, int NT, int MT>
+__global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
+                                                              float *__restrict__ din) {
+    constexpr int KSTEPS = COP == 32 ? 4 : 1;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
+    const unsigned oplane_b = (unsigned)(oplane * 4), dbytes = (unsigned)(s.cout * oplane * 4), ibytes = (unsigned)(s.cin * cells * 4);
+    const int64_t items = (int64_t)s.n * s.d * s.h * tiles_per_row;
+    // plane part of the per-lane offset: COP = 32 lanes own channels 8q..8q+7 (the e-th load adds e planes through the scalar offset)
+    const unsigned lane_plane = COP == 32 ? (unsigned)(8 * q) * oplane_b : 0u;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wid; item < items; item += (int64_t)gridDim.x * 4) {
+        const int xt = (int)(item % tiles_per_row);
+        const int64_t row = item / tiles_per_row;
+        const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+        const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
+        const int x0 = xt * 16 * MT;
+        f32x4m acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int kzky = 0; kzky < 16; ++kzky) {
+            const int z = 2 * hz - 1 + (kzky >> 2), y = 2 * hy - 1 + (kzky & 3);
+            const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform
+            const unsigned soff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8m bfr[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bfr[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                const int kx = COP == 32 ? ks : q;
+                float v[MT][8];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int c = x0 + mt * 16 + r, p = 2 * c - 1 + kx;
+                    const bool ok = rok && c < s.w && (unsigned)p < (unsigned)ow;
+                    const unsigned voff = ok ? lane_plane + (unsigned)p * 4u : CT_OOB;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (COP == 32 || e < s.cout) {   // COP = 8: wave-uniform; COP = 32 layers have all 32 channels
+                            const bool chok = COP != 32 || 8 * q + e < s.cout;
+                            v[mt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, chok ? voff : CT_OOB, soff + (unsigned)e * oplane_b, 0));
+                        } else {
+                            v[mt][e] = 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    bf16x8m a;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[mt][e];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // C/D layout: row (cell) = 4q + reg, column (ci) = r: a lane stores 4 consecutive cells of its plane (w % 4 == 0)
+        const __amdgpu_buffer_rsrc_t ir = ct_rsrc(din + (int64_t)n * s.cin * cells, ibytes);
+        const unsigned rowoff = (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c0 = x0 + mt * 16 + 4 * q;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ci = nt * 16 + r;
+                const unsigned voff = (c0 < s.w && ci < s.cin) ? (unsigned)(ci * cells * 4) + (unsigned)c0 * 4u : CT_OOB;
+                buf_store4(ir, voff, rowoff, acc[mt][nt]);
+            }
+        }
+    }
+}
+
 // ---- weight gradient -----------------------------------------------------------------------------
 // grid (row chunks, 16 / KG groups of (kz,ky)); a wave walks the rows of its chunk (wave w takes rows w, w+4, ...), keeps
 // acc[KG][4 kx][CIT][COT] in registers, and the block folds its 4 waves through LDS into partial[chunk][ci][co][64].
@@ -372,9 +462,12 @@ __global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restr
     }
 }
 
-// narrow-output variant (cout <= 4, the 16 -> 3 layer): the 16 MFMA columns carry (co, kx) pairs instead of 16 output channels
-// (which would leave 13 of 16 columns and lanes idle): column n = co*4 + kx reads dout[co][2c-1+kx] at stride 2 from one aligned
-// float2 window, one MFMA per (kz,ky) row and 32-cell step instead of four, and one wave keeps all 16 (kz,ky) accumulators.
+// narrow-output variant (cout <= 4, the 16 -> 3 layer; w % 8 == 0): the 16 MFMA columns carry (co, kx) pairs instead of 16 output
+// channels (which would leave 13 of 16 columns and lanes idle): column n = co*4 + kx needs dout[co][2c-1+kx] for the lane's 8 cells
+// = every second float of one 16-float window (four 16-byte loads), one MFMA per (kz,ky) row and 32-cell step, and one wave keeps
+// all 16 (kz,ky) accumulators.  The 16 window loads of four (kz,ky) rows are issued together, branch-free (rows / columns / lanes
+// outside the tensor get an out-of-range buffer offset): the first version waited for memory once per (kz,ky) row with two
+// waves per SIMD (3.5 ms at [4,16,10,376,376]).
 template <int CIT>
 __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
                                                               float *__restrict__ partial) {
@@ -394,49 +487,61 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
 #pragma unroll
         for (int a = 0; a < CIT; ++a) acc[g][a] = f32x4m{0.f, 0.f, 0.f, 0.f};
     const int steps = (s.w + 31) / 32;
+    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * 4);
+    // window of the lane: floats [base, base + 16) of the dout row with base = 2*c0 - 2 + 2*((kx + 1) >> 1); sample e = element
+    // 2e + (kx odd ? 0 : 1), i.e. position 2*(c0 + e) - 1 + kx
+    const int wshift = 2 * ((kx + 1) >> 1) - 2;
+    const bool odd = kx & 1;
+    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * 4) : CT_OOB;
     for (int64_t row = r0 + wid; row < r1; row += 4) {
         const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
-        const float *xrow = x + (int64_t)n * s.cin * cells + ((int64_t)hz * s.h + hy) * s.w;
-        const float *dbase = dout + (int64_t)n * s.cout * oplane + (int64_t)co * oplane;
+        const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)n * s.cin * cells, xbytes);
+        const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
+        const unsigned xrow = (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4);
         for (int st = 0; st < steps; ++st) {
             const int c0 = st * 32 + 8 * q;
+            const bool cok = c0 < s.w;   // w % 8 == 0: the lane's 8 cells are all inside or all outside
             bf16x8m a[CIT];
 #pragma unroll
             for (int ai = 0; ai < CIT; ++ai) {
                 const int ci = ai * 16 + r;
+                const unsigned voff = (cok && ci < s.cin) ? (unsigned)(ci * cells * 4) + xrow + (unsigned)c0 * 4u : CT_OOB;
+                const f32x4m lo = ct_load4(xr, voff, 0), hi = ct_load4(xr, voff, 16);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[ai][e] = (__bf16)0.f;
-                if (ci < s.cin) {
-                    const float *src = xrow + (int64_t)ci * cells + c0;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (c0 + e < s.w) a[ai][e] = (__bf16)src[e];
-                }
+                for (int e = 0; e < 4; ++e) { a[ai][e] = (__bf16)lo[e]; a[ai][4 + e] = (__bf16)hi[e]; }
             }
+            // the window of the row's first cells with kx = 0 would start at position -2: an offset below the plane start is out
+            // of range as a whole for plane 0, so those lanes start at 0 and take their samples two elements earlier
+            const bool shifted = 2 * c0 + wshift < 0;
+            const unsigned wlane = cok ? dlane + (unsigned)((2 * c0 + wshift + (shifted ? 2 : 0)) * 4) : CT_OOB;
+            const bool first_bad = 2 * c0 - 1 + kx < 0, last_bad = 2 * (c0 + 7) - 1 + kx >= ow;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int z = 2 * hz - 1 + (g >> 2), y = 2 * hy - 1 + (g & 3);
-                if ((unsigned)z >= (unsigned)od || (unsigned)y >= (unsigned)oh) continue;   // wave-uniform
-                // this lane's 8 samples dout[co][z][y][2*(c0+e) - 1 + kx]: positions p0 + 2e with p0 = 2*c0 - 1 + kx.  Aligned
-                // float2 window starting at the even position 2*c0 - 2 + 2*((kx + 1) >> 1); the sample is its .x (kx odd) or .y
-                bf16x8m b;
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4m wv[4][4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) b[e] = (__bf16)0.f;
-                if (co < s.cout) {
-                    const float *src = dbase + ((int64_t)z * oh + y) * ow;
-                    const int base = 2 * c0 - 2 + 2 * ((kx + 1) >> 1);
-                    const bool odd = kx & 1;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int z = 2 * hz - 1 + gq, y = 2 * hy - 1 + g4;
+                    const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform
+                    const unsigned soff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+                    const unsigned wl = rok ? wlane : CT_OOB;   // the range check sees the per-lane offset only
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wv[g4][j] = ct_load4(dr, wl, soff + 16u * j);
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x8m b;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int pos = base + 2 * e;   // even position of the pair holding the sample
-                        if (c0 + e < s.w && pos >= 0 && pos + 1 < ow) {
-                            const float2 m = *reinterpret_cast<const float2 *>(src + pos);
-                            b[e] = (__bf16)(odd ? m.x : m.y);
-                        }
+                        float v = odd ? wv[g4][e >> 1][(2 * e) & 3] : wv[g4][e >> 1][(2 * e + 1) & 3];
+                        if (e > 0) v = shifted ? wv[g4][(2 * e - 1) >> 2][(2 * e - 1) & 3] : v;   // (kx = 0 is even: element 2e + 1 - 2)
+                        if (e == 0) v = first_bad ? 0.f : v;   // position -1 of the row (c0 = 0, kx = 0) belongs to the previous row
+                        if (e == 7) v = last_bad ? 0.f : v;    // position ow (last cells, kx = 3) to the next one
+                        b[e] = (__bf16)v;
                     }
-                }
 #pragma unroll
-                for (int ai = 0; ai < CIT; ++ai) acc[g][ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], b, acc[g][ai], 0, 0, 0);
+                    for (int ai = 0; ai < CIT; ++ai)
+                        acc[gq * 4 + g4][ai] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai], b, acc[gq * 4 + g4][ai], 0, 0, 0);
+                }
             }
         }
     }
@@ -464,16 +569,30 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
     }
 }
 
+// fold the per-block slabs: 16 outputs x 16 slab lanes per block, fixed-order fold of the lanes through LDS
 __global__ __launch_bounds__(256) void ct_slab_reduce_kernel(const float *__restrict__ partial, int n_slabs, int64_t size, float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + o;
     float sum = 0.f;
-    for (int sidx = 0; sidx < n_slabs; ++sidx) sum += partial[(int64_t)sidx * size + i];
-    out[i] = sum;
+    if (i < size)
+        for (int sidx = sl; sidx < n_slabs; sidx += 16) sum += partial[(int64_t)sidx * size + i];
+    red[sl][o] = sum;
+    __syncthreads();
+    if (sl == 0 && i < size) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][o];
+        out[i] = tot;
+    }
 }
 
 static bool ct_mfma_ok(int cin, int cout) { return (cin == 32 || cin == 16) && cout >= 1 && cout <= 32; }
 static int ct_wgrad_blocks(int64_t rows) { return (int)(rows < 512 ? rows : 512); }
+static bool ct_wgrad_is_narrow(int cout, int w) { return cout <= 4 && w % 8 == 0; }
+static int ct_wgrad_blocks_for(int64_t rows, int cout, int w) {
+    return ct_wgrad_is_narrow(cout, w) ? (int)(rows < 1024 ? rows : 1024) : ct_wgrad_blocks(rows);
+}
 
 }  // namespace s2d
 
@@ -536,6 +655,18 @@ extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int
     const int nt_f = (cout + 15) / 16;
     const __bf16 *wp = (const __bf16 *)packed + (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512;
     const bool narrow = cout <= 8;
+    if (w % 4 == 0 && (int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31)) {   // direct fragments, no LDS staging
+        constexpr int MT = 4;
+        const int tpr = (w + 16 * MT - 1) / (16 * MT);
+        const int64_t items = (int64_t)batch * d * h * tpr;
+        const dim3 g2((unsigned)std::min<int64_t>(ceil_div(items, 4), 256 * 16));
+        if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
+        else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
+        else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
+        else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 2, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
     else if (narrow) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 1, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
     else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<32, 2, 2>), grid, blk, 0, st, dout, wp, s, xtiles, din);
@@ -546,7 +677,7 @@ extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int
 
 extern "C" size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w) {
     if (batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !ct_mfma_ok(cin, cout)) return 0;
-    return align_up((size_t)ct_wgrad_blocks((int64_t)batch * d * h) * cin * cout * 64 * sizeof(float), 256);
+    return align_up((size_t)ct_wgrad_blocks_for((int64_t)batch * d * h, cout, w) * cin * cout * 64 * sizeof(float), 256);
 }
 
 extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int cin, int cout, int d, int h, int w,
@@ -560,19 +691,20 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
     }
     CtDims s{batch, d, h, w, cin, cout};
     const int64_t rows = (int64_t)batch * d * h;
-    const int bx = ct_wgrad_blocks(rows);
+    const int bx = ct_wgrad_blocks_for(rows, cout, w);
     const int rpb = (int)ceil_div(rows, bx);
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)ws;
     const int cit = cin / 16, cot = (cout + 15) / 16;
-    if (cout <= 4 && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
-    else if (cout <= 4) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
+    const bool narrow = ct_wgrad_is_narrow(cout, w);
+    if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
+    else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
     else hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 1, 8>), dim3(bx, 2), dim3(256), 0, st, in, dout, s, rpb, partial);
     const int64_t size = (int64_t)cin * cout * 64;
-    hipLaunchKernelGGL(ct_slab_reduce_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, st, partial, bx, size, dweight);
+    hipLaunchKernelGGL(ct_slab_reduce_kernel, dim3((unsigned)ceil_div(size, 16)), dim3(256), 0, st, partial, bx, size, dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -641,17 +773,121 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(const float *__restrict__
     }
 }
 
+// 16 outputs x 16 chunk lanes per block, fixed-order fold of the lanes through LDS
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ partial, int chunks, int cin, int cout, float *__restrict__ dw,
                                                               float *__restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
     const int total = cout * (cin + 1);
-    if (i >= total) return;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * total + i];
+    if (i < total)
+        for (int k = sl; k < chunks; k += 16) s += partial[(int64_t)k * total + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl != 0 || i >= total) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += red[k][o];
     const int co = i / (cin + 1), ci = i % (cin + 1);
-    if (ci < cin) dw[(int64_t)co * cin + ci] = s;
-    else if (db) db[co] = s;
+    if (ci < cin) dw[(int64_t)co * cin + ci] = tot;
+    else if (db) db[co] = tot;
 }
+
+// bf16-operand variant on the matrix cores (the bf16 compute mode): M = output channels (MT tiles of 16), N = input channels (NT
+// tiles), K = positions, 32 per MFMA.  Both operands are read ONCE (the VALU kernel above re-reads x per tile of 4 output
+// channels: 2.9 GB for the 32 -> 16 layer at [4,32,10,376,376], 0.76 ms).  A lane's 8 K-elements are the two 4-float chunks at
+// p0 + 4q and p0 + 16 + 4q of its plane (the same position permutation on both operands, so the products pair up correctly):
+// every load instruction reads 64 contiguous bytes per plane.  db = the VALU sum of the lane's own dy values.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, int64_t positions, int batch,
+                                                            int cin, int cout, int steps_per_block, float *__restrict__ partial) {
+    __shared__ float red[MT * NT * 4 + MT][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4m acc[MT][NT];
+    float bsum[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        bsum[m] = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t steps = (positions + 31) / 32;
+    const int64_t s0 = (int64_t)blockIdx.x * steps_per_block;
+    const int64_t s1 = s0 + steps_per_block < steps ? s0 + steps_per_block : steps;
+    const unsigned plane = (unsigned)(positions * 4);
+    for (int b = 0; b < batch; ++b) {
+        const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)b * cin * positions, (unsigned)cin * plane);
+        const __amdgpu_buffer_rsrc_t yr = ct_rsrc(dy + (int64_t)b * cout * positions, (unsigned)cout * plane);
+        for (int64_t st = s0 + wid; st < s1; st += 4) {
+            const int64_t p0 = st * 32 + 4 * q;
+            const bool ok0 = p0 < positions, ok1 = p0 + 16 < positions;   // positions % 4 == 0: chunks are all-in or all-out
+            bf16x8m av[MT], bv[NT];
+            f32x4m lo[MT + NT], hi[MT + NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int o = m * 16 + r;
+                const unsigned base = o < cout ? (unsigned)o * plane + (unsigned)p0 * 4u : CT_OOB;
+                lo[m] = ct_load4(yr, ok0 ? base : CT_OOB, 0);
+                hi[m] = ct_load4(yr, ok1 ? base : CT_OOB, 64);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned base = (unsigned)(n * 16 + r) * plane + (unsigned)p0 * 4u;
+                lo[MT + n] = ct_load4(xr, ok0 ? base : CT_OOB, 0);
+                hi[MT + n] = ct_load4(xr, ok1 ? base : CT_OOB, 64);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { av[m][e] = (__bf16)lo[m][e]; av[m][4 + e] = (__bf16)hi[m][e]; }
+                bsum[m] += ((lo[m][0] + lo[m][1]) + (lo[m][2] + lo[m][3])) + ((hi[m][0] + hi[m][1]) + (hi[m][2] + hi[m][3]));
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bv[n][e] = (__bf16)lo[MT + n][e]; bv[n][4 + e] = (__bf16)hi[MT + n][e]; }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // fold the 4 waves in a fixed order, then write this block's slab partial[block][co][cin + 1]
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        float *slot = &red[(m * NT + n) * 4 + reg][lane];
+                        *slot = wv ? *slot + acc[m][n][reg] : acc[m][n][reg];
+                    }
+                float *bs = &red[MT * NT * 4 + m][lane];
+                *bs = wv ? *bs + bsum[m] : bsum[m];
+            }
+        }
+        __syncthreads();
+    }
+    float *dst = partial + (int64_t)blockIdx.x * cout * (cin + 1);
+    for (int e = threadIdx.x; e < MT * NT * 4 * 64; e += 256) {
+        const int ln = e & 63, f4 = e >> 6, reg = f4 & 3, tile = f4 >> 2;
+        const int n = tile % NT, m = tile / NT;
+        const int o = m * 16 + 4 * (ln >> 4) + reg, c = n * 16 + (ln & 15);   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+        if (o < cout && c < cin) dst[(int64_t)o * (cin + 1) + c] = red[f4][ln];
+    }
+    for (int e = threadIdx.x; e < MT * 16; e += 256) {   // bias gradient: the 4 q-lanes of row r hold disjoint positions
+        const int m = e >> 4, rr = e & 15, o = m * 16 + rr;
+        if (o < cout) {
+            const float *bs = red[MT * NT * 4 + m];
+            dst[(int64_t)o * (cin + 1) + cin] = (bs[rr] + bs[16 + rr]) + (bs[32 + rr] + bs[48 + rr]);
+        }
+    }
+}
+
 constexpr int PW_CHUNKS = 512;
 }  // namespace s2d
 
@@ -679,7 +915,40 @@ extern "C" int s2d_pointwise_conv_wgrad_f32(const float *in, const float *dout, 
     float *partial = (float *)ws;
     hipLaunchKernelGGL(s2d::pw_wgrad_kernel, dim3(chunks, (unsigned)s2d::ceil_div(cout, s2d::PW_CT), (unsigned)s2d::ceil_div(cin, s2d::PW_CIT)),
                        dim3(256), 0, st, in, dout, p4, batch, cin, cout, qpb, partial);
-    hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 256)), dim3(256), 0, st, partial, chunks,
+    hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 16)), dim3(256), 0, st, partial, chunks,
+                       cin, cout, dweight, dbias);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_pointwise_conv_wgrad_bf16_supported(int cin, int cout, int64_t positions) {
+    return ((cin == 128 && cout <= 32) || (cin == 32 && cout <= 16)) && cout > 0 && positions > 0 && positions % 4 == 0 &&
+           (int64_t)cin * positions * 4 < ((int64_t)1 << 31) && (int64_t)cout * positions * 4 < ((int64_t)1 << 31);
+}
+
+/* same contract as s2d_pointwise_conv_wgrad_f32 (workspace included) with the operands rounded to bf16 on the matrix cores */
+extern "C" int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout, int batch, int cin, int cout, int64_t positions,
+                                             float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && dout && dweight && batch > 0, "pointwise_conv_wgrad_bf16: bad argument");
+    if (!s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, positions)) {
+        s2d::set_error("pointwise_conv_wgrad_bf16: unsupported %d -> %d over %lld positions", cin, cout, (long long)positions);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const size_t need = s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout);
+    if (!ws || ws_bytes < need) {
+        s2d::set_error("pointwise_conv_wgrad_bf16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    const int64_t steps = (positions + 31) / 32;
+    const int chunks = (int)std::min<int64_t>(s2d::PW_CHUNKS, s2d::ceil_div(steps, 16));
+    const int spb = (int)s2d::ceil_div(steps, chunks);
+    hipStream_t st = (hipStream_t)stream;
+    float *partial = (float *)ws;
+    if (cin == 128)
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8>), dim3(chunks), dim3(256), 0, st, in, dout, positions, batch, cin, cout, spb, partial);
+    else
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2>), dim3(chunks), dim3(256), 0, st, in, dout, positions, batch, cin, cout, spb, partial);
+    hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 16)), dim3(256), 0, st, partial, chunks,
                        cin, cout, dweight, dbias);
     S2D_LAUNCH_CHECK();
     return S2D_OK;

@@ -431,14 +431,20 @@ static int check_c(int c, const char *who) {
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 constexpr int ROW_UNROLL = 4;   // rows per thread and trip in the row-major bf16 kernels
 
-// RELU / HAS_Y are compile-time: with run-time flags hipcc keeps a uniform branch per element in the unrolled bodies
-template <bool BWD, bool RELU, bool HAS_Y>
+// activation fused behind the normalisation: 0 none, 1 ReLU, 2 exact (erf) GELU = nn.GELU() of the S2D module's conv-BN-GELU groups
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
+
+// ACT / HAS_Y are compile-time: with run-time flags hipcc keeps a uniform branch per element in the unrolled bodies
+template <bool BWD, int ACT, bool HAS_Y>
 __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                                       const __bf16 *__restrict__ y,
                                                                       const float *__restrict__ scale,
                                                                       const float *__restrict__ shift, int64_t n, int c,
                                                                       int rows_per_block, float *__restrict__ partial) {
-    constexpr bool relu = RELU;
+    constexpr bool relu = ACT == 1, gelu = ACT == 2, act = ACT != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [row_lanes][2][C]
     const int c8 = c >> 3;
     const int lanes = RED_THREADS / c8;
@@ -449,8 +455,8 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
-        sc[e] = (BWD && relu && !HAS_Y) ? scale[grp * 8 + e] : 0.f;
-        sh[e] = (BWD && relu && !HAS_Y) ? shift[grp * 8 + e] : 0.f;
+        sc[e] = (BWD && act && !HAS_Y) ? scale[grp * 8 + e] : 0.f;
+        sh[e] = (BWD && act && !HAS_Y) ? shift[grp * 8 + e] : 0.f;
     }
     if (rl < lanes) {
         constexpr int RU = BWD ? ROW_UNROLL : 2 * ROW_UNROLL;   // the statistics pass carries one tensor: twice the rows in flight
@@ -475,6 +481,7 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
                         float g = (float)gv[u][e];
                         if constexpr (relu && HAS_Y) g = (float)yv[u][e] > 0.f ? g : 0.f;
                         else if constexpr (relu) g = fmaf(xf, sc[e], sh[e]) > 0.f ? g : 0.f;
+                        else if constexpr (gelu) g *= gelu_grad_f(fmaf(xf, sc[e], sh[e]));
                         s0[e] += g;
                         s1[e] += g * xf;
                     }
@@ -504,11 +511,11 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 
 // apply kernels: blockDim.x = lanes*c8 (a multiple of c8), thread -> (row lane, 8-channel group); the per-channel constants
 // live in registers, rows are strided over the grid.
-template <bool RES, bool RELU>
+template <bool RES, int ACT>
 __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
                                                              const float *__restrict__ shift, const __bf16 *__restrict__ res_p,
                                                              int64_t n, int c8, __bf16 *__restrict__ y) {
-    constexpr bool relu = RELU;
+    constexpr bool relu = ACT == 1, gelu = ACT == 2;
     const __bf16 *__restrict__ res = RES ? res_p : nullptr;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8];
@@ -538,6 +545,7 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
                 float v = fmaf((float)xv[u][e], sc[e], sh[e]);
                 if (RES) v += (float)rv[u][e];
                 if (relu) v = fmaxf(v, 0.f);
+                if (gelu) v = gelu_f(v);
                 o[e] = (__bf16)v;
             }
             reinterpret_cast<bf16x8r *>(y)[r * c8 + g] = o;
@@ -545,21 +553,21 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
     }
 }
 
-template <bool RELU, bool HAS_Y, bool HAS_DRES>
+template <int ACT, bool HAS_Y, bool HAS_DRES>
 __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ x,
                                                                  const __bf16 *__restrict__ y,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  const float *__restrict__ a, const float *__restrict__ b,
                                                                  const float *__restrict__ d, int64_t n, int c8,
                                                                  __bf16 *__restrict__ dx, __bf16 *__restrict__ dres) {
-    constexpr bool relu = RELU;
+    constexpr bool relu = ACT == 1, gelu = ACT == 2, act = ACT != 0;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8], av[8], bv[8], dv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = g * 8 + e;
-        sc[e] = (relu && !HAS_Y) ? scale[ch] : 0.f;
-        sh[e] = (relu && !HAS_Y) ? shift[ch] : 0.f;
+        sc[e] = (act && !HAS_Y) ? scale[ch] : 0.f;
+        sh[e] = (act && !HAS_Y) ? shift[ch] : 0.f;
         av[e] = a[ch];
         bv[e] = b[ch];
         dv[e] = d[ch];
@@ -584,6 +592,7 @@ __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *_
                 const float xf = (float)xv[u][e];
                 float gg = (float)gv[u][e];
                 if (relu) gg = (HAS_Y ? (float)yv[u][e] : fmaf(xf, sc[e], sh[e])) > 0.f ? gg : 0.f;
+                if (gelu) gg *= gelu_grad_f(fmaf(xf, sc[e], sh[e]));
                 if (HAS_DRES) gm[e] = (__bf16)gg;
                 o[e] = (__bf16)fmaf(av[e], gg, fmaf(bv[e], xf, dv[e]));
             }
@@ -921,7 +930,8 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, 
                         int64_t n, int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who) {
     int rc = check_c8(c, who);
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || y || (scale && shift)), "bnrow reduce: bad argument");
+    S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || (y && relu == 1) || (scale && shift)) && relu >= 0 && relu <= 2,
+                  "bnrow reduce: bad argument");
     RedPlan p = row_plan_bf16(n, c);
     if (!ws || ws_bytes < p.ws_bytes) {
         set_error("%s: workspace too small (%zu < %zu)", who, ws_bytes, p.ws_bytes);
@@ -930,10 +940,11 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, 
 #define S2D_ROW_REDUCE(B, R, Y)                                                                                              \
     hipLaunchKernelGGL((row_reduce_bf16_kernel<B, R, Y>), dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x, \
                        (const __bf16 *)dy, (const __bf16 *)y, scale, shift, n, c, p.rows_per_block, (float *)ws)
-    if (!bwd) S2D_ROW_REDUCE(false, false, false);
-    else if (!relu) S2D_ROW_REDUCE(true, false, false);
-    else if (y) S2D_ROW_REDUCE(true, true, true);
-    else S2D_ROW_REDUCE(true, true, false);
+    if (!bwd) S2D_ROW_REDUCE(false, 0, false);
+    else if (!relu) S2D_ROW_REDUCE(true, 0, false);
+    else if (relu == 2) S2D_ROW_REDUCE(true, 2, false);
+    else if (y) S2D_ROW_REDUCE(true, 1, true);
+    else S2D_ROW_REDUCE(true, 1, false);
 #undef S2D_ROW_REDUCE
     *plan_out = p;
     return S2D_OK;
@@ -977,10 +988,11 @@ extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const flo
 #define S2D_ROW_APPLY(RS, RL)                                                                                                   \
     hipLaunchKernelGGL((row_apply_bf16_kernel<RS, RL>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, \
                        scale, shift, (const __bf16 *)residual, n, c / 8, (__bf16 *)y)
+    S2D_CHECK_ARG(relu >= 0 && relu <= 2, "bnrow_apply: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
     if (residual) {
-        if (relu) S2D_ROW_APPLY(true, true); else S2D_ROW_APPLY(true, false);
+        if (relu == 2) S2D_ROW_APPLY(true, 2); else if (relu) S2D_ROW_APPLY(true, 1); else S2D_ROW_APPLY(true, 0);
     } else {
-        if (relu) S2D_ROW_APPLY(false, true); else S2D_ROW_APPLY(false, false);
+        if (relu == 2) S2D_ROW_APPLY(false, 2); else if (relu) S2D_ROW_APPLY(false, 1); else S2D_ROW_APPLY(false, 0);
     }
 #undef S2D_ROW_APPLY
     S2D_LAUNCH_CHECK();
@@ -1021,19 +1033,22 @@ extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const voi
                                         void *dres, s2d_stream_t stream) {
     int rc = check_c8(c, "bnrow_bwd_apply");
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || y || (scale && shift)), "bnrow_bwd_apply: bad argument");
+    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || (y && relu == 1) || (scale && shift)) && relu >= 0 && relu <= 2,
+                  "bnrow_bwd_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
 #define S2D_ROW_BWD(RL, Y, DR)                                                                                                     \
     hipLaunchKernelGGL((row_bwd_apply_bf16_kernel<RL, Y, DR>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream,         \
                        (const __bf16 *)dy, (const __bf16 *)x, (const __bf16 *)y, scale, shift, a, b, d, n, c / 8, (__bf16 *)dx,    \
                        (__bf16 *)dres)
-    const bool use_y = relu && y;
+    const bool use_y = relu == 1 && y;
     if (!relu) {
-        if (dres) S2D_ROW_BWD(false, false, true); else S2D_ROW_BWD(false, false, false);
+        if (dres) S2D_ROW_BWD(0, false, true); else S2D_ROW_BWD(0, false, false);
+    } else if (relu == 2) {
+        if (dres) S2D_ROW_BWD(2, false, true); else S2D_ROW_BWD(2, false, false);
     } else if (use_y) {
-        if (dres) S2D_ROW_BWD(true, true, true); else S2D_ROW_BWD(true, true, false);
+        if (dres) S2D_ROW_BWD(1, true, true); else S2D_ROW_BWD(1, true, false);
     } else {
-        if (dres) S2D_ROW_BWD(true, false, true); else S2D_ROW_BWD(true, false, false);
+        if (dres) S2D_ROW_BWD(1, false, true); else S2D_ROW_BWD(1, false, false);
     }
 #undef S2D_ROW_BWD
     S2D_LAUNCH_CHECK();

@@ -99,14 +99,20 @@ __global__ __launch_bounds__(256) void pcr_sparse_terms_kernel(const int32_t *__
 }
 
 // out[0] = mask_loss, out[1] = offset_loss, out[2] = beta, out[3] = n_sel, out[4] = N, out[5] = n_pos
-__global__ void pcr_finalize_kernel(const float *__restrict__ dense_partial, int nd, const float *__restrict__ sparse_partial, int ns,
-                                    double n_cells, float *__restrict__ out) {
+__global__ __launch_bounds__(64) void pcr_finalize_kernel(const float *__restrict__ dense_partial, int nd, const float *__restrict__ sparse_partial, int ns,
+                                                          double n_cells, float *__restrict__ out) {
+    // one wave: lanes stride over the partial rows in double, fixed-order shuffle fold
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nd; i += 64) v[5] += dense_partial[i];
+    for (int i = threadIdx.x; i < ns; i += 64)
+        for (int k = 0; k < 5; ++k) v[k] += sparse_partial[i * 5 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s_all = 0;
-    for (int i = 0; i < nd; ++i) s_all += dense_partial[i];
-    double t[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < ns; ++i)
-        for (int k = 0; k < 5; ++k) t[k] += sparse_partial[i * 5 + k];
+    const double s_all = v[5];
+    const double *t = v;
     const double npos = t[0], nneg = n_cells - npos;
     const float beta = (float)(nneg / npos);          // count_neg / count_pos (inf / nan for an empty target, as in torch)
     out[0] = (float)((s_all - t[2] + (double)beta * t[1]) / n_cells);
@@ -263,6 +269,26 @@ __device__ __forceinline__ void pcr_load_head(const float *__restrict__ hp, PcrH
     __syncthreads();
 }
 
+// planar tensors through buffer instructions (s2d_common.h): V consecutive floats of one plane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t planes_rsrc(const void *base, unsigned bytes) { return buf_rsrc(base, bytes); }
+template <int V> __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float (&v)[V]) {
+    if constexpr (V == 2) {
+        const buf_f32x2 t = buf_load2(r, voff, soff);
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        const buf_f32x4 t = buf_load4(r, voff, soff);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t[k];
+    }
+}
+template <int V> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float (&v)[V]) {
+    if constexpr (V == 2) {
+        buf_store2(r, voff, soff, buf_f32x2{v[0], v[1]});
+    } else {
+        buf_store4(r, voff, soff, buf_f32x4{v[0], v[1], v[2], v[3]});
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void block_sums_n(float (&v)[K], float *out) {
     __shared__ float red[4][K];
@@ -283,22 +309,24 @@ __global__ __launch_bounds__(256) void pcr_heads_fwd_dense_kernel(const float *_
     __shared__ PcrHeadW<C> hw;
     pcr_load_head<C>(hp, hw);
     float acc[1] = {0.f};
-    const int64_t sv = cells / V, total = sv * batch, stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const int64_t b = i / sv, j = i - b * sv;
-        const float *base = g + b * C * cells + j * V;
+    const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
+    const unsigned plane = (unsigned)cells * 4u;   // bytes per channel plane (C * plane < 4 GB: checked on the host)
+    for (int b = 0; b < batch; ++b) {
+    const __amdgpu_buffer_rsrc_t gr = planes_rsrc(g + (int64_t)b * C * cells, C * plane);
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
         float x[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) x[k] = hw.bm;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float v[V];
-            vec_load<V>(base + (int64_t)c * cells, v);
+            buf_load<V>(gr, j * (V * 4u), c * plane, v);
 #pragma unroll
             for (int k = 0; k < V; ++k) x[k] = fmaf(hw.wm[c], v[k], x[k]);
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[0] += softplusf(x[k]);
+    }
     }
     block_sums<1>(acc, partial);
 }
@@ -368,56 +396,71 @@ __global__ __launch_bounds__(256) void pcr_heads_bwd_dense_kernel(const float *_
     __shared__ PcrHeadW<C> hw;
     pcr_load_head<C>(hp, hw);
     if (CO > 0) {
-        for (int i = threadIdx.x; i < CO * C; i += 256) w2s[i] = w2[i];
+        for (int i = threadIdx.x; i < CO * C; i += 256) w2s[(i % C) * CO + i / C] = w2[i];   // [C][CO]
         __syncthreads();
     }
     const float scale = go_mask[0] / fin[4];
+    // an opaque per-lane zero keeps the weight reads ordinary vector LDS loads with immediate offsets: known-uniform addresses are
+    // scalarised (v_readfirstlane into ~550 SGPRs, which then spill into VGPR lanes: 256 VGPRs, one wave per SIMD, 1.4 ms)
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;   // w_mask[C] leads the struct image
+    const float *w2v = w2s + lane_zero;
     float pw[C + 1];
 #pragma unroll
     for (int c = 0; c <= C; ++c) pw[c] = 0.f;
-    const int64_t sv = cells / V, total = sv * batch, stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-        const int64_t b = i / sv, j = i - b * sv;
-        const float *base = g + b * C * cells + j * V;
+    // batch index in the outer (uniform) loop: plane bases stay scalar, lanes carry one 32-bit offset (per-lane 64-bit plane
+    // addresses cost 2 VGPRs per plane: 160 for the 32 + 16 + 32 planes of this kernel)
+    const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
+    const unsigned plane = (unsigned)cells * 4u;
+    for (int b = 0; b < batch; ++b) {
+    const __amdgpu_buffer_rsrc_t gr = planes_rsrc(g + (int64_t)b * C * cells, C * plane), dgr = planes_rsrc(dg + (int64_t)b * C * cells, C * plane),
+                                 zr = planes_rsrc(CO > 0 ? dz + (int64_t)b * CO * cells : g, (CO > 0 ? CO : C) * plane);
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
+        asm volatile("" ::: "memory");   // and keep them inside the loop (hoisted, 512 + C weights would live in registers)
+        const unsigned voff = j * (V * 4u);
         float x[V], dm[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) x[k] = hw.bm;
         float gv[C][V];
 #pragma unroll
-        for (int c = 0; c < C; ++c) vec_load<V>(base + (int64_t)c * cells, gv[c]);
+        for (int c = 0; c < C; ++c) buf_load<V>(gr, voff, c * plane, gv[c]);
+        float zv[CO > 0 ? CO : 1][V];
+        if (CO > 0) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+            for (int q = 0; q < CO; ++q) buf_load<V>(zr, voff, q * plane, zv[q]);
+        }
 #pragma unroll
-            for (int k = 0; k < V; ++k) x[k] = fmaf(hw.wm[c], gv[c][k], x[k]);
+        for (int c = 0; c < C; ++c) {
+            const float wc = wmv[c];
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = fmaf(wc, gv[c][k], x[k]);
+        }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             dm[k] = scale * sigmoidf(x[k]);
             pw[C] += dm[k];
         }
 #pragma unroll
-        for (int c = 0; c < C; ++c)
+        for (int c = 0; c < C; ++c) {
+            float o[V];
+            const float wc = wmv[c];
 #pragma unroll
-            for (int k = 0; k < V; ++k) pw[c] = fmaf(dm[k], gv[c][k], pw[c]);
-        float o[C][V];
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int k = 0; k < V; ++k) o[c][k] = hw.wm[c] * dm[k];
-        if (CO > 0) {
-            const float *zb = dz + b * CO * cells + j * V;
-#pragma unroll
-            for (int q = 0; q < CO; ++q) {
-                float zv[V];
-                vec_load<V>(zb + (int64_t)q * cells, zv);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-#pragma unroll
-                    for (int k = 0; k < V; ++k) o[c][k] = fmaf(w2s[q * C + c], zv[k], o[c][k]);
+            for (int k = 0; k < V; ++k) {
+                pw[c] = fmaf(dm[k], gv[c][k], pw[c]);
+                o[k] = wc * dm[k];
             }
-        }
-        float *ob = dg + b * C * cells + j * V;
+            if (CO > 0) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) vec_store<V>(ob + (int64_t)c * cells, o[c]);
+                for (int q = 0; q < CO; ++q) {
+                    const float wq = w2v[c * CO + q];   // transposed image: the CO weights of channel c are contiguous
+#pragma unroll
+                    for (int k = 0; k < V; ++k) o[k] = fmaf(wq, zv[q][k], o[k]);
+                }
+            }
+            buf_store<V>(dgr, voff, c * plane, o);
+        }
+    }
     }
     block_sums_n<C + 1>(pw, partial);
 }
@@ -478,22 +521,38 @@ __global__ __launch_bounds__(256) void pcr_heads_bwd_sparse_kernel(const int32_t
     block_sums_n<4 * C + 4>(acc, partial);
 }
 
+// one block per parameter-gradient element t (4C+4 of them): 256 threads stride over the partial rows, fixed-order fold
 template <int C>
-__global__ void pcr_heads_param_grads_kernel(const float *__restrict__ dense_partial, int nd, const float *__restrict__ sparse_partial, int ns,
-                                             float *__restrict__ dw_mask, float *__restrict__ db_mask, float *__restrict__ dw_off,
-                                             float *__restrict__ db_off) {
-    const int t = threadIdx.x;
-    if (t >= 4 * C + 4) return;
-    double s = 0;
-    for (int i = 0; i < ns; ++i) s += sparse_partial[(int64_t)i * (4 * C + 4) + t];
+__global__ __launch_bounds__(256) void pcr_heads_param_grads_kernel(const float *__restrict__ dense_partial, int nd,
+                                                                    const float *__restrict__ sparse_partial, int ns, float *__restrict__ dw_mask,
+                                                                    float *__restrict__ db_mask, float *__restrict__ dw_off,
+                                                                    float *__restrict__ db_off) {
+    const int t = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < ns; i += 256) s += sparse_partial[(int64_t)i * (4 * C + 4) + t];
     if (t < C || t == 4 * C) {
         const int col = t < C ? t : C;
-        for (int i = 0; i < nd; ++i) s += dense_partial[(int64_t)i * (C + 1) + col];
+        for (int i = threadIdx.x; i < nd; i += 256) s += dense_partial[(int64_t)i * (C + 1) + col];
     }
-    if (t < C) dw_mask[t] = (float)s;
-    else if (t < 4 * C) dw_off[t - C] = (float)s;
-    else if (t == 4 * C) db_mask[0] = (float)s;
-    else db_off[t - 4 * C - 1] = (float)s;
+    float v[1] = {s};
+    __shared__ float tot[1];
+    // block_sums writes out[blockIdx.x * K + k]: fold into a one-element LDS slot instead
+    {
+        __shared__ float red[4];
+        float x = v[0];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) tot[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const float r = tot[0];
+    if (t < C) dw_mask[t] = r;
+    else if (t < 4 * C) dw_off[t - C] = r;
+    else if (t == 4 * C) db_mask[0] = r;
+    else db_off[t - 4 * C - 1] = r;
 }
 
 constexpr int PCRH_DENSE_BLOCKS = 2048, PCRH_SPARSE_BLOCKS = 256;
@@ -524,7 +583,7 @@ static int pcr_heads_bwd_t(const float *g, const float *hw, const int32_t *coors
                        dense_partial);
     hipLaunchKernelGGL((pcr_heads_bwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, g, hw, go_mask, go_off, fin, dg,
                        sparse_partial);
-    hipLaunchKernelGGL((pcr_heads_param_grads_kernel<C>), dim3(1), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, dw_mask, db_mask, dw_off,
+    hipLaunchKernelGGL((pcr_heads_param_grads_kernel<C>), dim3(4 * C + 4), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, dw_mask, db_mask, dw_off,
                        db_off);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -533,7 +592,8 @@ static int pcr_heads_bwd_t(const float *g, const float *hw, const int32_t *coors
 }  // namespace s2d
 
 extern "C" int s2d_pcr_heads_supported(int c, int co, int64_t cells) {
-    return ((c == 32 && (co == 0 || co == 16)) || (c == 3 && co == 0)) && cells > 0 && cells % 4 == 0;
+    // one batch item's planes are addressed through a 32-bit buffer offset
+    return ((c == 32 && (co == 0 || co == 16)) || (c == 3 && co == 0)) && cells > 0 && cells % 4 == 0 && (int64_t)c * cells * 4 < ((int64_t)1 << 31);
 }
 
 extern "C" size_t s2d_pcr_heads_workspace_bytes(int c) {

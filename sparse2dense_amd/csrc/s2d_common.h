@@ -44,6 +44,34 @@ static inline unsigned xcd_grid(int64_t tiles) { return (unsigned)(ceil_div(tile
 __device__ __forceinline__ int xcd_tile(int block_id, int grid) { return (block_id % S2D_XCDS) * (grid / S2D_XCDS) + block_id / S2D_XCDS; }
 #endif
 
+#if defined(__HIPCC__)
+// Planar (channel-major) tensors through buffer instructions: ONE per-lane 32-bit byte offset plus a scalar offset per access,
+// where flat global pointers cost a 64-bit per-lane address per plane (two VGPRs each: 160 for a 32 + 16 + 32-plane kernel), and
+// a per-lane offset >= num_records reads as zero / drops the store (masked lanes need no branch).  The range check looks at
+// the PER-LANE offset only: the scalar offset must always be valid.  The b64/b128 builtins return clang-internal vector types
+// that do not convert to ext_vector types element-wise (an implicit conversion splats the first element): always bit_cast.
+typedef float buf_f32x2 __attribute__((ext_vector_type(2)));
+typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BUF_OOB = 0x80000000u;   // per-lane offset that is out of range for every resource made below (< 2 GB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);   // raw buffer
+}
+__device__ __forceinline__ buf_f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(buf_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ buf_f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(buf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, buf_f32x2 v) {
+    using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0u, 0u, 0));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, buf_f32x4 v) {
+    using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0u, 0u, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
+}
+#endif
+
 // carve aligned sub-buffers out of a caller workspace
 struct Carver {
     char *base;

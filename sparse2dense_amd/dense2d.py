@@ -372,6 +372,7 @@ class _BNRowFn(torch.autograd.Function):
         check(lib.s2d_bnrow_apply_bf16(x.data_ptr(), fp + 2 * rb, fp + 3 * rb, _ptr(residual), int(relu), rows, c, y.data_ptr(),
                                        stream), "s2d_bnrow_apply_bf16")
         has_res = residual is not None
+        assert not (has_res and int(relu) == 2), "fused GELU behind a residual add is not supported (its derivative needs bn(x)+res)"
         # with a residual the ReLU mask cannot be recomputed from x alone: keep y
         ctx.save_for_backward(x, gamma, fin, count, y if (has_res and relu) else None)
         ctx.relu, ctx.sync, ctx.training, ctx.has_res = relu, sync, training, has_res
@@ -460,6 +461,8 @@ class FastBatchNorm2d(nn.BatchNorm2d):
                               dist.group.WORLD, dist.get_world_size())
         else:
             y = super().forward(x)
+        if int(relu) == 2:
+            return torch.nn.functional.gelu(y)
         return torch.relu(y) if relu else y
 
 
@@ -470,6 +473,9 @@ def fuse_bn_relu(layers):
     for i in range(len(layers) - 1):
         if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.ReLU):
             layers[i].fused_relu = True
+            layers[i + 1] = nn.Identity()
+        if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.GELU) and layers[i + 1].approximate == "none":
+            layers[i].fused_relu = 2   # activation code 2: exact GELU behind the normalisation (csrc/features.hip)
             layers[i + 1] = nn.Identity()
         if isinstance(layers[i], Conv3x3) and isinstance(layers[i + 1], FastBatchNorm2d):
             layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials

@@ -39,9 +39,28 @@ def pointwise_conv(x, w2d, bias):
     return out
 
 
+def pointwise_conv_wgrad(x, dout, want_db, bf16=False):
+    """(dW [Cout,Cin], db [Cout] | None) of a 1x1x1 conv over planar fp32 tensors (position count % 4 == 0).  bf16: operands
+    rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported."""
+    lib = _lib.load()
+    n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
+    pos = x[0, 0].numel()
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
+    ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
+    if bf16 and lib.s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, pos):
+        check(lib.s2d_pointwise_conv_wgrad_bf16(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+              "s2d_pointwise_conv_wgrad_bf16")
+    else:
+        check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+              "s2d_pointwise_conv_wgrad_f32")
+    return dw, db
+
+
 class _PwConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bf16=False):
+        ctx.bf16 = bool(bf16)
         x = x.contiguous()
         w2d = weight.reshape(weight.shape[0], weight.shape[1]).contiguous()
         ctx.save_for_backward(x, w2d)
@@ -58,20 +77,15 @@ class _PwConvFn(torch.autograd.Function):
             dx = pointwise_conv(dout, w2d.t().contiguous(), None)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_db:
-            lib = _lib.load()
             n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
             pos = x[0, 0].numel()
-            if pos % 4 == 0:   # streaming reduction over the positions (csrc/convt3d_mfma.hip pw_wgrad_kernel)
-                dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
-                db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
-                ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
-                check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws),
-                                                       ws.numel(), _stream()), "s2d_pointwise_conv_wgrad_f32")
+            if pos % 4 == 0:   # streaming reduction over the positions (csrc/convt3d_mfma.hip pw_wgrad_*)
+                dw, db = pointwise_conv_wgrad(x, dout, want_db, ctx.bf16)
                 dw = dw.reshape(ctx.wshape)
             else:
                 dw = torch.matmul(dout.reshape(n, cout, -1), x.reshape(n, cin, -1).transpose(1, 2)).sum(0).reshape(ctx.wshape)
                 db = dout.sum(dim=[0] + list(range(2, dout.dim()))) if want_db else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def _convt_packed(weight):
@@ -153,12 +167,15 @@ def _hip_ok(x):
 
 
 class PointwiseConv3d(nn.Conv3d):
-    """nn.Conv3d with kernel_size 1 (stride 1, no padding)."""
+    """nn.Conv3d with kernel_size 1 (stride 1, no padding).  `bf16_compute` (set by the detector in its bf16 mode): the weight
+    gradient contracts bf16-rounded operands on the matrix cores; forward and data gradient stay fp32 streams."""
+
+    bf16_compute = False
 
     def forward(self, x):
         if _hip_ok(x) and self.kernel_size == (1, 1, 1) and self.stride == (1, 1, 1) and self.padding == (0, 0, 0) \
                 and self.groups == 1:
-            return _PwConvFn.apply(x, self.weight, self.bias)
+            return _PwConvFn.apply(x, self.weight, self.bias, self.bf16_compute)
         return super().forward(x)
 
 

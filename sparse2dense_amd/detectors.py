@@ -46,11 +46,11 @@ class SingleStageDetector(nn.Module):
         if self.neck is not None:
             mods += list(self.neck.modules())
             self.neck.trunk_channels_last = True
-        from .dense3d import ConvTranspose3dK4S2
+        from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
         for mod in mods:
             if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
                 mod.to(memory_format=torch.channels_last)
-            if isinstance(mod, ConvTranspose3dK4S2):   # PCR up-samplers: bf16 MFMA inputs in the bf16 mode
+            if isinstance(mod, (ConvTranspose3dK4S2, PointwiseConv3d)):   # PCR head: bf16 MFMA inputs in the bf16 mode
                 mod.bf16_compute = True
         self.dense_channels_last = True
         return self

@@ -146,7 +146,7 @@ class _PcrLevelFn(torch.autograd.Function):
     "Fused PCR level heads").  Returns (mask_loss, offset_loss, z | None)."""
 
     @staticmethod
-    def forward(ctx, g, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2):
+    def forward(ctx, g, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bf16=False):
         from . import _lib
         from .dense2d import _ptr, _stream, _ws
         from .dense3d import pointwise_conv
@@ -165,6 +165,7 @@ class _PcrLevelFn(torch.autograd.Function):
             z = pointwise_conv(g, w2d, b2)
         ctx.save_for_backward(g, hp, coors, feats, out, w2d)
         ctx.shapes = (w_mask.shape, w_off.shape, None if w2 is None else w2.shape, b2 is not None)
+        ctx.bf16 = bool(bf16)
         return out[0], out[1], z
 
     @staticmethod
@@ -193,14 +194,11 @@ class _PcrLevelFn(torch.autograd.Function):
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None
         if co:
-            dw2 = torch.empty((co, c), dtype=torch.float32, device=dev)
-            db2 = torch.empty((co,), dtype=torch.float32, device=dev) if has_b2 else None
-            ws2 = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(c, co), dev)
-            _lib.check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(g), _ptr(dz), b, c, co, d * h * w, _ptr(dw2), _ptr(db2), _ptr(ws2), ws2.numel(),
-                                                        _stream()), "s2d_pointwise_conv_wgrad_f32")
+            from .dense3d import pointwise_conv_wgrad
+            dw2, db2 = pointwise_conv_wgrad(g, dz, has_b2, ctx.bf16)
             dw2 = dw2.reshape(w2_shape)
         return (dg, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:], None, None,
-                dw2, db2)
+                dw2, db2, None)
 
 
 def pcr_level_supported(g, next_conv=None):
@@ -218,7 +216,8 @@ def pcr_level(g, mask_conv, offset_conv, coors, feats, next_conv=None):
     assert mask_conv.bias is not None and offset_conv.bias is not None
     coors = coors if coors.dtype == torch.int32 else coors.int()
     return _PcrLevelFn.apply(g, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors, feats.float(),
-                             None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias)
+                             None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
+                             bool(getattr(next_conv, "bf16_compute", False)))
 
 
 def metric_grid(n, d, h, w, like):

@@ -127,7 +127,7 @@ def test_module_autograd_matches_stock_conv(pad, bias, wgrad_hip, monkeypatch):
 # quantities (running stats, dgamma, dbeta) 2e-3 relative to their max (bf16 dy/x products, fp32 sums).
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,c,h,w", [(2, 64, 20, 24), (4, 128, 47, 47), (1, 256, 33, 9), (2, 8, 5, 7), (1, 512, 16, 16)])
-@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("relu", [False, True, 2])   # 2 = fused exact GELU (the S2D module's conv-BN-GELU groups)
 def test_fast_batchnorm2d_training(n, c, h, w, relu):
     from sparse2dense_amd import dense2d as D
     torch.manual_seed(2)
@@ -145,7 +145,7 @@ def test_fast_batchnorm2d_training(n, c, h, w, relu):
     xr = x.double().cpu().contiguous().requires_grad_(True)
     yr = ref(xr)
     if relu:
-        yr = torch.relu(yr)
+        yr = torch.relu(yr) if relu is True else F.gelu(yr)
     yr.backward(dy.double().cpu().contiguous())
 
     def close(what, a, r, tol):

@@ -103,7 +103,8 @@ def test_channel_major_batchnorm3d(c, shape, relu, train):
 # 1e-4 of max on outputs and gradients (K <= 256 products per output, <= ~1e6 per weight-gradient entry).
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (1, 4, 7, 66)), (32, 3, (1, 2, 5, 9)), (16, 32, (2, 2, 3, 130)),
-                                            (32, 32, (1, 5, 20, 188)), (16, 3, (1, 3, 9, 376))])
+                                            (32, 32, (1, 5, 20, 188)), (16, 3, (1, 3, 9, 376)), (32, 3, (2, 2, 3, 40)), (16, 3, (2, 2, 3, 24)),
+                                            (16, 2, (1, 1, 1, 8))])
 def test_convtranspose3d_bf16_mfma(cin, cout, shape):
     torch.manual_seed(cin * 5 + cout)
     n, d, h, w = shape
@@ -143,4 +144,26 @@ def test_pointwise_conv3d_weight_gradient_kernel(cin, cout, pos_shape):
     dw = torch.einsum("ncp,nkp->ck", dy.double().reshape(n, cout, -1), x.double().reshape(n, cin, -1))
     db = dy.double().sum(dim=(0, 2, 3, 4))
     assert (layer.weight.grad.cpu().double().reshape(cout, cin) - dw).abs().max() <= 2e-5 * dw.abs().max() + 1e-4
+    assert (layer.bias.grad.cpu().double() - db).abs().max() <= 2e-5 * db.abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,pos_shape", [(128, 32, (2, 5, 12, 16)), (32, 16, (4, 10, 94, 94)), (32, 16, (1, 3, 5, 4)), (128, 32, (3, 5, 47, 48)),
+                                                (32, 7, (2, 2, 9, 12)), (128, 20, (1, 1, 3, 4))])
+def test_pointwise_conv3d_weight_gradient_bf16_mfma(cin, cout, pos_shape):
+    """s2d_pointwise_conv_wgrad_bf16 (bf16 operands on the matrix cores, one pass) vs float64 on the host over the SAME
+    bf16-rounded x and dy; db sums the unrounded dy.  What is left is fp32 accumulation order: 1e-4 of max."""
+    from sparse2dense_amd import _lib
+    torch.manual_seed(cin + 5 * cout)
+    n, d, h, w = pos_shape
+    assert _lib.load().s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, d * h * w)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = torch.randn(n, cin, d, h, w)
+    dy = torch.randn(n, cout, d, h, w)
+    layer = PointwiseConv3d(cin, cout, 1, 1, 0).to(DEV)
+    layer.bf16_compute = True
+    xh = x.to(DEV).requires_grad_(True)
+    layer(xh).backward(dy.to(DEV))
+    dw = torch.einsum("ncp,nkp->ck", rb(dy).double().reshape(n, cout, -1), rb(x).double().reshape(n, cin, -1))
+    db = dy.double().sum(dim=(0, 2, 3, 4))
+    assert (layer.weight.grad.cpu().double().reshape(cout, cin) - dw).abs().max() <= 1e-4 * dw.abs().max()
     assert (layer.bias.grad.cpu().double() - db).abs().max() <= 2e-5 * db.abs().max() + 1e-4

@@ -49,3 +49,53 @@ def test_pcr_sparse_losses_match_dense_formulation(b, d, h, w, m):
     for a, r in ((go.grad, ro.grad), (gm.grad, rm.grad)):
         assert (a.double().cpu() - r).abs().max() <= 1e-5 * r.abs().max(), float((a.double().cpu() - r).abs().max() / r.abs().max())
     assert int((go.grad != 0).sum()) == int((ro.grad != 0).sum())
+
+
+@pytest.mark.parametrize("b,c,co,d,h,w,m", [(2, 32, 16, 6, 20, 24, 300), (2, 3, 0, 6, 20, 24, 300), (1, 32, 0, 4, 10, 12, 50),
+                                              (3, 32, 16, 10, 94, 94, 20000), (2, 3, 0, 20, 188, 188, 30000)])
+def test_pcr_level_heads_match_conv_plus_dense_loss(b, c, co, d, h, w, m):
+    """fused level (csrc/losses.hip "Fused PCR level heads") == 1x1x1 convs -> mask_offset_loss on the dense target, float64 host:
+    loss values, d/dg, every head parameter gradient, and the next conv's output and gradients"""
+    from torch import nn
+    coors, feats, _, _ = _case(b, d, h, w, m, seed=b * 11 + m + c)
+    gen = torch.Generator().manual_seed(5 + c + m)
+    g0 = torch.randn(b, c, d, h, w, generator=gen).relu()   # a post-ReLU feature volume
+    mask_conv, off_conv = nn.Conv3d(c, 1, 1), nn.Conv3d(c, 3, 1)
+    nxt = nn.Conv3d(c, co, 1) if co else None
+    with torch.no_grad():
+        for mod in (mask_conv, off_conv, nxt):
+            if mod is not None:
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=gen) * 0.3)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.3)
+    r = torch.randn(b, co, d, h, w, generator=gen) / (b * d * h * w) if co else None
+
+    def run(dev, dtype, fused):
+        mods = [None if mm is None else __import__("copy").deepcopy(mm).to(dev, dtype) for mm in (mask_conv, off_conv, nxt)]
+        g = g0.to(dev, dtype).requires_grad_(True)
+        if fused:
+            ml, ol, z = heads.pcr_level(g, mods[0], mods[1], coors.to(dev), feats.to(dev), next_conv=mods[2])
+        else:
+            gt = torch.zeros(b, d, h, w, 5, dtype=dtype)
+            cc = coors.long()
+            gt[cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3]] = feats.to(dtype)
+            gt = gt.permute(0, 4, 1, 2, 3).contiguous()
+            grid = heads.metric_grid(b, d, h, w, torch.zeros(1)).to(dtype)
+            ml, ol = heads.mask_offset_loss(mods[1](g), mods[0](g), gt, grid)
+            z = mods[2](g) if co else None
+        total = 1.7 * ml + 0.6 * ol
+        if co:
+            total = total + (z * r.to(dev, dtype)).sum()
+        total.backward()
+        grads = [g.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+        return ml, ol, z, grads
+
+    ml_r, ol_r, z_r, gr_r = run("cpu", torch.float64, False)
+    assert heads.pcr_level_supported(g0.cuda(), nxt)
+    ml, ol, z, gr = run("cuda", torch.float32, True)
+    np.testing.assert_allclose(ml.item(), ml_r.item(), rtol=2e-5)
+    np.testing.assert_allclose(ol.item(), ol_r.item(), rtol=2e-5)
+    if co:
+        assert (z.double().cpu() - z_r).abs().max() <= 1e-5 * z_r.abs().max()
+    for a, ref in zip(gr, gr_r):
+        err = float((a.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= 3e-5, err
