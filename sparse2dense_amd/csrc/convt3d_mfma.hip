@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void ct_pack_fwd_kernel(const float *__restric
 
 // data-gradient image: [kzky 16][kstep][nt (ci tiles)][lane][8]; COP = 32: kstep = kx, co = kk ; COP = 8: one k-step,
 // kx = kk >> 3, co = kk & 7.  column n -> ci = nt*16 + n.
-__global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restrict__ w, int cin, int cout, int cop, int nt_count,
+// direct = 1 (the no-LDS kernel): K index kk <-> co = 8*kstep + 2*(kk >> 3) + ((kk & 7) >> 2), kx = kk & 3: a lane's 8 elements are the four
+// kx samples of two channels = two 16-byte loads at position 2c-1.
+__global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restrict__ w, int cin, int cout, int cop, int nt_count, int direct,
                                                             __bf16 *__restrict__ out) {
     const int ksteps = cop == 32 ? 4 : 1;
     const int total = 16 * ksteps * nt_count * 64 * 8;
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restr
     const int ks = r % ksteps; r /= ksteps;
     const int kzky = r;
     const int kk = 8 * (lane >> 4) + e;
-    const int kx = cop == 32 ? ks : (kk >> 3);
-    const int co = cop == 32 ? kk : (kk & 7);
+    const int kx = direct ? (kk & 3) : (cop == 32 ? ks : (kk >> 3));
+    const int co = direct ? 8 * ks + 2 * (kk >> 3) + ((kk & 7) >> 2) : (cop == 32 ? kk : (kk & 7));
     const int ci = nt * 16 + (lane & 15);
     float v = 0.f;
     if (co < cout && ci < cin) v = w[((((int64_t)ci * cout + co) * 4 + (kzky >> 2)) * 4 + (kzky & 3)) * 4 + kx];
@@ -268,13 +270,14 @@ __global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restr
 }
 
 // ---- data gradient without LDS staging -------------------------------------------------------------
-// M = 16 input cells per MFMA row tile, N = ci, and per (kz,ky) output row K = (kx, co): COP = 8: one MFMA, lane (r = cell,
-// q = kx) holds co 0..7 at position 2c-1+q;  COP = 32: four MFMAs (kx = k-step), lane (r, q) holds co 8q..8q+7 at position 2c-1+kx.
-// The A fragments come straight from the planar dout through dword buffer loads (lanes r walk the row at stride 2: one
-// instruction covers ~140 contiguous bytes per plane), rows / columns / channels outside the tensor get an out-of-range per-lane
-// offset.  A wave owns MT row tiles of one input row, so every weight fragment it reads (L1) feeds MT MFMAs.  The staged kernel
-// above holds 64 KB of LDS per block (two blocks per CU) and waits for memory once per staging round: 1.9 ms for the 16 -> 3
-// layer at [4,16,10,376,376] against a 0.2 ms stream.
+// M = 16 input cells per MFMA row tile, N = ci, K = (co, kx) per (kz,ky) output row: the four kx samples of cell c are the four
+// consecutive floats dout[co][z][y][2c-1 .. 2c+2], ONE 16-byte load.  Lane (r = cell, q) holds K elements e = (co 2q + (e >> 2),
+// kx e & 3) of k-step ks (channels 8ks .. 8ks+7): two 16-byte buffer loads per fragment, straight from the planar tensor (lanes
+// r walk the row in 8-byte steps: one instruction covers ~140 contiguous bytes per plane); rows / columns / channels outside
+// the tensor get an out-of-range per-lane offset.  A wave owns MT row tiles of one input row, so every weight fragment it reads
+// (L1) feeds MT MFMAs.  The staged kernel above holds 32-64 KB of LDS per block and waits for memory once per staging round
+// (1.9 ms for the 16 -> 3 layer at [4,16,10,376,376] against a 0.2 ms stream); a first direct version with dword loads (one
+// per channel and kx) ran at ~70 clocks per load instruction: 1.9 / 1.5 ms.
 template <int COP, int NT, int MT>
 __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
                                                               float *__restrict__ din) {
@@ -285,8 +288,6 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
     const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
     const unsigned oplane_b = (unsigned)(oplane * 4), dbytes = (unsigned)(s.cout * oplane * 4), ibytes = (unsigned)(s.cin * cells * 4);
     const int64_t items = (int64_t)s.n * s.d * s.h * tiles_per_row;
-    // plane part of the per-lane offset: COP = 32 lanes own channels 8q..8q+7 (the e-th load adds e planes through the scalar offset)
-    const unsigned lane_plane = COP == 32 ? (unsigned)(8 * q) * oplane_b : 0u;
     for (int64_t item = (int64_t)blockIdx.x * 4 + wid; item < items; item += (int64_t)gridDim.x * 4) {
         const int xt = (int)(item % tiles_per_row);
         const int64_t row = item / tiles_per_row;
@@ -294,10 +295,17 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
         const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
         const int x0 = xt * 16 * MT;
         f32x4m acc[MT][NT];
+        unsigned pos[MT];     // byte offset of the lane's window in a row (the first cell's starts at 0 instead of -4: `shifted`)
+        bool shifted[MT], last[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+            const int c = x0 + mt * 16 + r;
+            shifted[mt] = c == 0;
+            last[mt] = c == s.w - 1;
+            pos[mt] = c < s.w ? (unsigned)((2 * c - (c == 0 ? 0 : 1)) * 4) : CT_OOB;
+        }
 #pragma unroll 2
         for (int kzky = 0; kzky < 16; ++kzky) {
             const int z = 2 * hz - 1 + (kzky >> 2), y = 2 * hy - 1 + (kzky & 3);
@@ -309,34 +317,37 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bfr[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
-                const int kx = COP == 32 ? ks : q;
-                float v[MT][8];
+                const int co0 = 8 * ks + 2 * q;
+                const unsigned pl0 = (rok && co0 < s.cout) ? (unsigned)co0 * oplane_b : CT_OOB;
+                const unsigned pl1 = (rok && co0 + 1 < s.cout) ? (unsigned)(co0 + 1) * oplane_b : CT_OOB;
+                f32x4m v0[MT], v1[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const int c = x0 + mt * 16 + r, p = 2 * c - 1 + kx;
-                    const bool ok = rok && c < s.w && (unsigned)p < (unsigned)ow;
-                    const unsigned voff = ok ? lane_plane + (unsigned)p * 4u : CT_OOB;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (COP == 32 || e < s.cout) {   // COP = 8: wave-uniform; COP = 32 layers have all 32 channels
-                            const bool chok = COP != 32 || 8 * q + e < s.cout;
-                            v[mt][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, chok ? voff : CT_OOB, soff + (unsigned)e * oplane_b, 0));
-                        } else {
-                            v[mt][e] = 0.f;
-                        }
-                    }
+                    // an out-of-range marker in either addend keeps the sum >= 2^31 > num_records (both are < 2^31 otherwise)
+                    v0[mt] = ct_load4(dr, (pos[mt] | pl0) >= CT_OOB ? CT_OOB : pos[mt] + pl0, soff);
+                    v1[mt] = ct_load4(dr, (pos[mt] | pl1) >= CT_OOB ? CT_OOB : pos[mt] + pl1, soff);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     bf16x8m a;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[mt][e];
+                    for (int e = 0; e < 4; ++e) {
+                        // shifted lanes loaded positions 0..3: sample kx = element kx - 1 (kx = 0 is position -1: zero)
+                        float s0 = shifted[mt] ? (e ? v0[mt][e - (e ? 1 : 0)] : 0.f) : v0[mt][e];
+                        float s1 = shifted[mt] ? (e ? v1[mt][e - (e ? 1 : 0)] : 0.f) : v1[mt][e];
+                        if (e == 3) {   // position 2w of the last cell belongs to the next row
+                            s0 = last[mt] ? 0.f : s0;
+                            s1 = last[mt] ? 0.f : s1;
+                        }
+                        a[e] = (__bf16)s0;
+                        a[4 + e] = (__bf16)s1;
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
-        // C/D layout: row (cell) = 4q + reg, column (ci) = r: a lane stores 4 consecutive cells of its plane (w % 4 == 0)
+        // C/D layout: row (cell) = 4q + reg, column (ci) = r: a lane stores 4 consecutive cells of its plane
         const __amdgpu_buffer_rsrc_t ir = ct_rsrc(din + (int64_t)n * s.cin * cells, ibytes);
         const unsigned rowoff = (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4);
 #pragma unroll
@@ -345,8 +356,14 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int ci = nt * 16 + r;
-                const unsigned voff = (c0 < s.w && ci < s.cin) ? (unsigned)(ci * cells * 4) + (unsigned)c0 * 4u : CT_OOB;
-                buf_store4(ir, voff, rowoff, acc[mt][nt]);
+                const unsigned plane = ci < s.cin ? (unsigned)(ci * cells * 4) : CT_OOB;
+                if ((s.w & 3) == 0) {
+                    buf_store4(ir, (c0 < s.w && ci < s.cin) ? plane + (unsigned)c0 * 4u : CT_OOB, rowoff, acc[mt][nt]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        buf_store1(ir, (c0 + j < s.w && ci < s.cin) ? plane + (unsigned)(c0 + j) * 4u : CT_OOB, rowoff, acc[mt][nt][j]);
+                }
             }
         }
     }
@@ -459,6 +476,137 @@ __global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restr
         const int ci = a * 16 + 4 * (ln >> 4) + reg, co = b * 16 + (ln & 15);   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
         const int kzky = grp * KG + g;
         if (ci < s.cin && co < s.cout) dst[(((int64_t)ci * s.cout + co) * 16 + kzky) * 4 + k] = v;
+    }
+}
+
+// output-row-major variant (w % 4 == 0): a block owns one output parity class (pz,py) and one tile of 16 output channels and walks
+// the dout rows z = 2zz+pz, y = 2yy+py of its class.  A dout row of parity (pz,py) meets exactly the 2 x 2 taps (kz,ky) =
+// (ct_k(pz,a), ct_k(py,b)) with the input rows (zz + ct_d(pz,a), yy + ct_d(py,b)), so every dout element is read ONCE (the
+// input-row-major kernel above reads each 4 times, from 8 blocks with one resident wave per SIMD: 1.9 ms for 32 -> 32 at
+// [4,32,5,188,188]); the small x tensor is re-read instead.  Per 32-cell step a wave issues all its loads first (five 16-byte
+// pieces of the 20-float dout window = the 4 kx fragments, and the 8 cells of the four input rows), then 16*CIT MFMAs into
+// acc[a][b][kx][ci tile].
+template <int CIT>
+__global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
+                                                            int co_tiles, float *__restrict__ partial) {
+    constexpr int FR = 16 * CIT;
+    __shared__ float red[FR * 4][64];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    // blockIdx.y = (input-channel group, output-channel tile, parity class); a group = CIT tiles of 16 input channels
+    const int cls = blockIdx.y & 3, bt = (blockIdx.y >> 2) % co_tiles, ci_base = (blockIdx.y >> 2) / co_tiles * 16 * CIT;
+    const int pz = cls >> 1, py = cls & 1;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
+    const int64_t total_rows = (int64_t)s.n * s.d * s.h;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < total_rows ? r0 + rows_per_block : total_rows;
+    f32x4m acc[2][2][4][CIT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) acc[a][b][k][i] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    const int steps = (s.w + 31) / 32;
+    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * 4);
+    const int co = bt * 16 + r;
+    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * 4) : CT_OOB;
+    for (int64_t row = r0 + wid; row < r1; row += 4) {
+        const int yy = (int)(row % s.h), zz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
+        const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)n * s.cin * cells, xbytes);
+        const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
+        const unsigned drow = (unsigned)(((int64_t)(2 * zz + pz) * oh + (2 * yy + py)) * ow * 4);
+        unsigned xrow[2][2];
+        bool xok[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int hz = zz + ct_d(pz, a), hy = yy + ct_d(py, b);
+                xok[a][b] = (unsigned)hz < (unsigned)s.d && (unsigned)hy < (unsigned)s.h;   // wave-uniform
+                xrow[a][b] = xok[a][b] ? (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4) : 0u;
+            }
+        for (int st = 0; st < steps; ++st) {
+            const int c0 = st * 32 + 8 * q;
+            const bool lo_ok = c0 < s.w, hi_ok = c0 + 4 < s.w;   // w % 4 == 0
+            // dout window: floats [2*c0 - 2, 2*c0 + 18) of the row; tap kx of cell c0 + e = element 1 + kx + 2e.  The first cells'
+            // window would start at -2 (out of range as a whole for plane 0): those lanes start at 0 and index two elements earlier.
+            const bool shifted = c0 == 0;
+            const unsigned wl = lo_ok ? dlane + (unsigned)((2 * c0 - (shifted ? 0 : 2)) * 4) : CT_OOB;
+            f32x4m wv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wv[j] = ct_load4(dr, wl, drow + 16u * j);
+            f32x4m xl[2][2][CIT], xh[2][2][CIT];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i) {
+                        const int ci = ci_base + i * 16 + r;
+                        const unsigned base = (xok[a][b] && ci < s.cin) ? (unsigned)(ci * cells * 4) + (unsigned)c0 * 4u : CT_OOB;
+                        xl[a][b][i] = ct_load4(xr, lo_ok ? base : CT_OOB, xrow[a][b]);
+                        xh[a][b][i] = ct_load4(xr, hi_ok ? base : CT_OOB, xrow[a][b] + 16u);
+                    }
+            float win[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const float plain = wv[j >> 2][j & 3];
+                const float early = j >= 2 ? wv[(j - 2) >> 2][(j - 2) & 3] : 0.f;   // shifted lanes: element j of the window = loaded j - 2
+                win[j] = shifted ? early : plain;
+            }
+            bf16x8m bk[4];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = win[1 + kx + 2 * e];
+                    if (kx == 3) v = (c0 + e == s.w - 1) ? 0.f : v;   // position 2w belongs to the next row
+                    bk[kx][e] = (__bf16)v;
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < CIT; ++i) {
+                        bf16x8m av;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { av[e] = (__bf16)xl[a][b][i][e]; av[4 + e] = (__bf16)xh[a][b][i][e]; }
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx)
+                            acc[a][b][kx][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bk[kx], acc[a][b][kx][i], 0, 0, 0);
+                    }
+        }
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                float *slot = &red[((((a * 2 + b) * 4 + k) * CIT + i) * 4) + reg][lane];
+                                *slot = wv ? *slot + acc[a][b][k][i][reg] : acc[a][b][k][i][reg];
+                            }
+        }
+        __syncthreads();
+    }
+    float *dst = partial + (int64_t)blockIdx.x * s.cin * s.cout * 64;
+    for (int e = t; e < FR * 4 * 64; e += 256) {
+        const int ln = e % 64, f4 = e / 64, reg = f4 % 4, f = f4 / 4;
+        const int i = f % CIT, k = (f / CIT) % 4, b = (f / (CIT * 4)) % 2, a = f / (CIT * 8);
+        const int ci = ci_base + i * 16 + 4 * (ln >> 4) + reg, oc = bt * 16 + (ln & 15);   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+        const int kz = ct_k(pz, a), ky = ct_k(py, b);
+        if (ci < s.cin && oc < s.cout) dst[(((int64_t)ci * s.cout + oc) * 16 + kz * 4 + ky) * 4 + k] = red[f4][ln];
     }
 }
 
@@ -591,7 +739,9 @@ static bool ct_mfma_ok(int cin, int cout) { return (cin == 32 || cin == 16) && c
 static int ct_wgrad_blocks(int64_t rows) { return (int)(rows < 512 ? rows : 512); }
 static bool ct_wgrad_is_narrow(int cout, int w) { return cout <= 4 && w % 8 == 0; }
 static int ct_wgrad_blocks_for(int64_t rows, int cout, int w) {
-    return ct_wgrad_is_narrow(cout, w) ? (int)(rows < 1024 ? rows : 1024) : ct_wgrad_blocks(rows);
+    if (ct_wgrad_is_narrow(cout, w)) return (int)(rows < 1024 ? rows : 1024);
+    if (w % 4 == 0) return (int)(rows < 128 ? rows : 128);   // output-row-major kernel: grid (chunks, 4 classes x co tiles)
+    return ct_wgrad_blocks(rows);
 }
 
 }  // namespace s2d
@@ -600,11 +750,12 @@ using namespace s2d;
 
 extern "C" int s2d_convt3d_mfma_supported(int cin, int cout) { return ct_mfma_ok(cin, cout); }
 
-/* packed weight images: forward [8][ksteps][nt][64][8] then data gradient [16][ksteps'][nt'][64][8] (bf16 elements) */
+/* packed weight images: forward [8][ksteps][nt][64][8], data gradient [16][ksteps'][nt'][64][8] (staged kernel), then the same
+ * shape in the direct kernel's K order (bf16 elements) */
 extern "C" size_t s2d_convt3d_mfma_packed_elems(int cin, int cout) {
     if (!ct_mfma_ok(cin, cout)) return 0;
     const int nt_f = (cout + 15) / 16, nt_d = cin / 16, cop = cout <= 8 ? 8 : 32;
-    return (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512 + (size_t)16 * (cop == 32 ? 4 : 1) * nt_d * 512;
+    return (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512 + (size_t)2 * 16 * (cop == 32 ? 4 : 1) * nt_d * 512;
 }
 
 extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream) {
@@ -617,7 +768,9 @@ extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int c
     const int n_f = 8 * (cin == 32 ? 8 : 4) * nt_f * 512, n_d = 16 * (cop == 32 ? 4 : 1) * nt_d * 512;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ct_pack_fwd_kernel, dim3((n_f + 255) / 256), dim3(256), 0, st, weight, cin, cout, nt_f, (__bf16 *)packed);
-    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, (__bf16 *)packed + n_f);
+    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, 0, (__bf16 *)packed + n_f);
+    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, 1,
+                       (__bf16 *)packed + n_f + n_d);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -655,15 +808,16 @@ extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int
     const int nt_f = (cout + 15) / 16;
     const __bf16 *wp = (const __bf16 *)packed + (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512;
     const bool narrow = cout <= 8;
-    if (w % 4 == 0 && (int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31)) {   // direct fragments, no LDS staging
+    if ((int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31)) {   // direct fragments, no LDS staging (one sample's dout < 2 GB)
         constexpr int MT = 4;
         const int tpr = (w + 16 * MT - 1) / (16 * MT);
         const int64_t items = (int64_t)batch * d * h * tpr;
         const dim3 g2((unsigned)std::min<int64_t>(ceil_div(items, 4), 256 * 16));
-        if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
-        else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
-        else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
-        else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT>), g2, blk, 0, st, dout, wp, s, tpr, din);
+        const __bf16 *wd = wp + (size_t)16 * (narrow ? 1 : 4) * (cin / 16) * 512;   // the direct kernel's image follows the staged one
+        if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, din);
+        else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, din);
+        else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, din);
+        else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, din);
         S2D_LAUNCH_CHECK();
         return S2D_OK;
     }
@@ -699,6 +853,8 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
     const bool narrow = ct_wgrad_is_narrow(cout, w);
     if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
+    // one tile of 16 input channels per block (two resident waves per SIMD; with both tiles the 128 accumulators leave room for one)
+    else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1>), dim3(bx, 4 * cot * cit), dim3(256), 0, st, in, dout, s, rpb, cot, partial);
     else if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);

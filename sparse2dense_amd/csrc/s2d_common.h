@@ -62,6 +62,13 @@ __device__ __forceinline__ buf_f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigne
 __device__ __forceinline__ buf_f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(buf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b32(r, 0u, 0u, 0));
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, buf_f32x2 v) {
     using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0u, 0u, 0));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
