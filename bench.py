@@ -6,7 +6,7 @@
 One step = one pass of the hot path over one batch of synthetic frames that are already resident
 in HBM as raw points: device voxelization (+fused reader) -> 8 rulebooks -> SpMiddleResNetFHD
 (MFMA sparse convs, fused BN) -> densify -> neck -> CenterHead -> losses -> backward ->
-grad-clip(35) -> AdamW step; bucketed gradient all-reduce overlapped with the backward when N>1.
+grad-clip(35) -> Adam (true weight decay, OneCycle schedule: the reference's fastai optimizer) step; bucketed gradient all-reduce overlapped with the backward when N>1.
 
 Default workload = north_star's target: CenterPoint-voxelnet + S2D (`KD_VoxelNet` student: S2D
 densify module + PCR head + RPN trunk + CenterHead), forward + backward, B=4 frames per GPU of the
@@ -104,9 +104,10 @@ def build_models(args, workload, dev):
     return model.to(dev).train(), teacher
 
 
-def make_step(workload, model, teacher, frames, optimizer):
-    from sparse2dense_amd.train_step import backward_and_clip, distill_loss, single_stage_loss
+def make_step(workload, model, teacher, frames, optimizer, scheduler=None):
+    from sparse2dense_amd.train_step import backward_and_clip, backward_and_step, distill_loss, single_stage_loss
     params = [p for p in model.parameters() if p.requires_grad]
+    it = [0]
 
     def step():
         ex = frames.example()                       # device voxelization of the resident points
@@ -122,9 +123,11 @@ def make_step(workload, model, teacher, frames, optimizer):
             loss = sum(losses["loss"]) + (mask_loss + offset_loss)
         else:
             loss, _ = single_stage_loss(model, ex)
-        backward_and_clip(loss, params, 35.0)
-        if optimizer is not None:
-            optimizer.step()
+        if optimizer is None:
+            backward_and_clip(loss, params, 35.0)
+        else:   # the reference's optimizer step: OneCycle schedule, clip(35) folded into the fused Adam + true weight decay update
+            backward_and_step(loss, params, optimizer, scheduler, it[0], 35.0)
+            it[0] += 1
         return loss
 
     return step
@@ -143,11 +146,14 @@ def setup_workload(args, workload, dev, rank):
     else:
         frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
                                  distill=(workload != "centerpoint"), device=dev, beam_jitter=jitter)
-    optimizer = None
+    optimizer = scheduler = None
     if not args.no_optim:
-        optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99),
-                                      weight_decay=0.01, fused=True)
-    return model, teacher, frames, make_step(workload, model, teacher, frames, optimizer)
+        # apis/train.py:168-186 + configs `lr_config`: fastai Adam (betas (mom, 0.99), true weight decay 0.01) under OneCycle
+        from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+        optimizer = build_one_cycle_optimizer(model, dict(wd=0.01))
+        scheduler = build_one_cycle_scheduler(optimizer, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0,
+                                                               pct_start=0.4), total_steps=36 * 1000)
+    return model, teacher, frames, make_step(workload, model, teacher, frames, optimizer, scheduler)
 
 
 def timed(step, steps, warmup, world, dev):
@@ -517,7 +523,7 @@ def main():
                        "points_per_frame": args.points, "frames_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}",
                        "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"),
-                       "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + AdamW"),
+                       "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + Adam/OneCycle (true weight decay)"),
                        "loss": loss_value, "scene": stats},
             "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "cpu_baseline": base,
         }

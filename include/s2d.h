@@ -448,6 +448,26 @@ int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const i
                          float *g_gen_mask, float *g_gen_offset_zeroed, s2d_stream_t stream);
 
 /*
+ * Layout + precision hand-over between the bf16 NHWC neck and the fp32 planar PCR head (rpn.py:283-285): tiled transposes,
+ * x bf16 [batch][hw][c] <-> y fp32 [batch][c][hw].  c % 8 == 0, hw % 4 == 0.
+ */
+int s2d_nhwc_bf16_to_nchw_f32(const void *x, int batch, int c, int64_t hw, float *y, s2d_stream_t stream);
+int s2d_nchw_f32_to_nhwc_bf16(const float *x, int batch, int c, int64_t hw, void *y, s2d_stream_t stream);
+
+/*
+ * LayerNorm over a whole [C,H,W] map per sample (nn.LayerNorm([256,47,47]) of the S2D ConvNeXt blocks, det3d/models/necks/rpn.py:
+ * 210-247): each row is split over many workgroups (two-level fixed-order reduction).  x / y / dy / dx: bf16 [batch][row] in
+ * MEMORY order; weight / bias and their gradients: fp32 [row] in that same order (the caller permutes); row % 8 == 0;
+ * stats [batch][2] = (mean, rstd).  bwd: dx, dweight, dbias are each optional.
+ */
+size_t s2d_lnwide_workspace_bytes(int batch);
+int s2d_lnwide_fwd_bf16(const void *x, const float *weight, const float *bias, int batch, int64_t row, float eps,
+                        void *y, float *stats, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_lnwide_bwd_bf16(const void *dy, const void *x, const float *weight, const float *stats, int batch,
+                        int64_t row, void *dx, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                        s2d_stream_t stream);
+
+/*
  * Fused PCR level heads + losses: gen_mask_k / gen_out_k (1x1x1 Conv3d C->1 / C->3, det3d/models/necks/rpn.py:273-275,292-294)
  * and mask_offset_loss (voxelnet.py:171-185) evaluated straight from the level's feature volume g[B][C][D*H*W] - the occupancy
  * logits, the offset volume and its zero-filled gradient are never written; the offset conv runs at the m recon voxels only.

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import scene
-from .voxel_ops import VoxelGenerator, voxelize_batch
+from .voxel_ops import VoxelGenerator, voxelize_batch, voxelize_batches
 
 WAYMO_TRAIN_MAX_VOXELS = 150000
 
@@ -65,14 +65,29 @@ class SyntheticFrames:
         return _targets.assign_label(self.gt_boxes, self.gt_classes)
 
     def example(self):
-        ex = voxelize_batch(self.gens[""], self.points)
-        if self.distill:
-            ex.update(voxelize_batch(self.gens[""], self.dense_points, prefix="dense_"))
-            ex.update(voxelize_batch(self.gens[""], self.recon_points, prefix="reconstruction_"))
-            for suf in ("_2", "_4"):
-                r = voxelize_batch(self.gens[suf], self.recon_points, prefix="reconstruction_")
-                for k, v in r.items():
-                    ex[k + suf] = v
+        if self.device.type == "cuda" and len(self.points) <= 64:
+            # every cloud of the example is voxelized before the host reads the (five) row-offset vectors in one go
+            req = [(self.gens[""], self.points, "")]
+            if self.distill:
+                req += [(self.gens[""], self.dense_points, "dense_"), (self.gens[""], self.recon_points, "reconstruction_"),
+                        (self.gens["_2"], self.recon_points, "reconstruction@_2"), (self.gens["_4"], self.recon_points, "reconstruction@_4")]
+            ex = {}
+            for k, v in voxelize_batches(req).items():
+                if "@" in k:   # scaled reconstruction clouds: the scale suffix goes to the END of the key (trainer.py:100-124)
+                    head, rest = k.split("@")
+                    suf, field = rest[:2], rest[2:]
+                    ex[head + "_" + field + suf] = v
+                else:
+                    ex[k] = v
+        else:
+            ex = voxelize_batch(self.gens[""], self.points)
+            if self.distill:
+                ex.update(voxelize_batch(self.gens[""], self.dense_points, prefix="dense_"))
+                ex.update(voxelize_batch(self.gens[""], self.recon_points, prefix="reconstruction_"))
+                for suf in ("_2", "_4"):
+                    r = voxelize_batch(self.gens[suf], self.recon_points, prefix="reconstruction_")
+                    for k, v in r.items():
+                        ex[k + suf] = v
         ex["shape"] = np.stack([self.grid_size] * len(self.points))
         ex.update(self._targets())
         return ex

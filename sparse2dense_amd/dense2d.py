@@ -15,6 +15,7 @@ import torch
 
 from . import collective as _collective
 from torch import nn
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check
@@ -466,6 +467,22 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         return torch.relu(y) if relu else y
 
 
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d with a 1x1 kernel (stride 1, no padding; same parameters / state_dict keys).  On NHWC activations a 1x1 conv IS a
+    plain GEMM [N*H*W, Cin] x [Cin, Cout]: forward, data and weight gradient go to the library GEMM (hipBLASLt through F.linear)
+    instead of MIOpen's implicit-GEMM convolution kernels (0.23 ms per call for 256 -> 640 at 188 x 188; the GEMM runs at the
+    same rate as the dense 3x3 kernels).  Other inputs take the stock layer."""
+
+    def forward(self, x):
+        if (ENABLED and x.is_cuda and x.dim() == 4 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.groups == 1 and self.dilation == (1, 1) and x.is_contiguous(memory_format=torch.channels_last)
+                and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
+            n, c, h, w = x.shape
+            y = F.linear(x.permute(0, 2, 3, 1).reshape(n * h * w, c), self.weight.reshape(self.out_channels, c), self.bias)
+            return y.view(n, h, w, self.out_channels).permute(0, 3, 1, 2)
+        return super().forward(x)
+
+
 def fuse_bn_relu(layers):
     """[.., FastBatchNorm2d, nn.ReLU, ..] -> [.., FastBatchNorm2d(fused_relu), nn.Identity, ..]: same indices (state_dict
     keys of the reference checkpoints), one kernel instead of two."""
@@ -489,18 +506,70 @@ def fuse_bn_relu(layers):
 # --------------------------------------------------------------------------------------------------
 # LayerNorm over a whole [C,H,W] map (ConvNeXt blocks of the S2D module, rpn.py:186-259)
 # --------------------------------------------------------------------------------------------------
+class _WideLNFn(torch.autograd.Function):
+    """LayerNorm over whole [C,H,W] maps of a bf16 batch (csrc/layernorm.hip): everything runs in the memory order of x; weight
+    and bias are handed over permuted to that order (cached per parameter version) and their gradients permuted back."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        b = x.shape[0]
+        row = x.numel() // b
+        nhwc = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        to_mem = (lambda t: t.detach().float().permute(1, 2, 0).contiguous()) if nhwc else (lambda t: t.detach().float().contiguous())
+        w_t = cached_pack(weight, ("lnwide", nhwc), lambda: to_mem(weight))
+        b_t = cached_pack(bias, ("lnwide", nhwc), lambda: to_mem(bias))
+        y = torch.empty_like(x)   # same strides
+        stats = torch.empty((b, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.s2d_lnwide_workspace_bytes(b), x.device)
+        check(lib.s2d_lnwide_fwd_bf16(x.data_ptr(), _ptr(w_t), _ptr(b_t), b, row, float(eps), y.data_ptr(), _ptr(stats), _ptr(ws), ws.numel(),
+                                      _stream()), "s2d_lnwide_fwd_bf16")
+        ctx.save_for_backward(x, w_t, stats)
+        ctx.nhwc, ctx.pshape = nhwc, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w_t, stats = ctx.saved_tensors
+        b = x.shape[0]
+        row = x.numel() // b
+        if dy.stride() != x.stride():
+            dy = torch.empty_like(x).copy_(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(row, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        db = torch.empty(row, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[2] else None
+        ws = _ws(lib.s2d_lnwide_workspace_bytes(b), x.device)
+        check(lib.s2d_lnwide_bwd_bf16(dy.data_ptr(), x.data_ptr(), _ptr(w_t), _ptr(stats), b, row, _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                      ws.numel(), _stream()), "s2d_lnwide_bwd_bf16")
+
+        def back(t):
+            if t is None:
+                return None
+            if ctx.nhwc:
+                c, h, w = ctx.pshape
+                return t.view(h, w, c).permute(2, 0, 1).contiguous()
+            return t.view(ctx.pshape)
+        return dx, back(dw), back(db), None
+
+
 class WideLayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters / state_dict keys).  The S2D blocks normalise over the whole [C, 47, 47] map, i.e.
     a few rows of ~5e5 elements: torch's row-per-workgroup kernels then run on B (= 2-4) workgroups of a 256-CU GPU
-    (measured 0.44 ms forward + 1.13 ms backward per layer).  For that shape the statistics are taken with torch's
-    multi-workgroup reductions and the rest is elementwise (autograd differentiates it); anything else is the stock path."""
+    (measured 0.44 ms forward + 1.13 ms backward per layer).  bf16 CUDA maps take the multi-workgroup kernels of
+    csrc/layernorm.hip; other large-row inputs compose the statistics from torch's multi-workgroup reductions; anything else is
+    the stock path."""
 
     def forward(self, x):
         nd = len(self.normalized_shape)
         row = 1
         for d in self.normalized_shape:
             row *= int(d)
-        if x.is_cuda and row >= (1 << 16) and x.numel() // row <= 64 and self.elementwise_affine:
+        big = x.is_cuda and row >= (1 << 16) and x.numel() // row <= 64 and self.elementwise_affine
+        if big and ENABLED and x.dtype == torch.bfloat16 and nd == 3 and x.dim() == 4 and row % 8 == 0 and self.bias is not None and (
+                x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+            return _WideLNFn.apply(x, self.weight, self.bias, self.eps)
+        if big:
             dims = tuple(range(x.dim() - nd, x.dim()))
             xf = x.float()
             var, mean = torch.var_mean(xf, dim=dims, unbiased=False, keepdim=True)

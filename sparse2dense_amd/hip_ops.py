@@ -79,10 +79,10 @@ def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max
     return voxels[:m], coors[:m], num[:m], (mean[:m] if with_mean else None)
 
 
-def voxelize_batch(points_cat: torch.Tensor, offsets, voxel_size, coors_range, max_points: int, max_voxels: int):
-    """B frames (points concatenated frame after frame, `offsets` = B+1 host ints) voxelized in ONE launch chain straight into
-    the collated layout.  Returns (voxels f32[M,P,C], coors i32[M,4] (b,z,y,x), num_points i32[M], mean f32[M,C],
-    num_voxels i64[B]) with ONE host read (the B+1 row offsets)."""
+def voxelize_batch_launch(points_cat: torch.Tensor, offsets, voxel_size, coors_range, max_points: int, max_voxels: int):
+    """Launch the batched voxelizer (B frames, points concatenated frame after frame, `offsets` = B+1 host ints) without reading
+    anything back.  Returns the capacity-sized outputs + the device row offsets `out_base` i32[B+1]; voxelize_batch_collect trims
+    them once the host knows out_base (several launches can share ONE host read)."""
     lib = _lib.load()
     _need_gpu(points_cat)
     points_cat = points_cat.contiguous().float()
@@ -102,10 +102,22 @@ def voxelize_batch(points_cat: torch.Tensor, offsets, voxel_size, coors_range, m
     check(lib.s2d_voxelize_batch_run(_ptr(points_cat), frames, offs, ndim, f6(coors_range), f3(voxel_size), max_points, max_voxels,
                                      _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(out_m), _ptr(out_base), _ptr(ws), ws.numel(),
                                      _stream()), "s2d_voxelize_batch_run")
-    base = out_base.cpu().tolist()   # the one host read of the batch
-    m = base[-1]
-    counts = torch.tensor([base[b + 1] - base[b] for b in range(frames)], dtype=torch.int64, device=dev)
+    return (voxels, coors, num, mean, out_base)
+
+
+def voxelize_batch_collect(pending, base):
+    """trim a voxelize_batch_launch result with its row offsets `base` (B+1 host ints)"""
+    voxels, coors, num, mean, out_base = pending
+    m = int(base[-1])
+    counts = torch.tensor([int(base[b + 1]) - int(base[b]) for b in range(len(base) - 1)], dtype=torch.int64, device=voxels.device)
     return voxels[:m], coors[:m], num[:m], mean[:m], counts
+
+
+def voxelize_batch(points_cat: torch.Tensor, offsets, voxel_size, coors_range, max_points: int, max_voxels: int):
+    """B frames voxelized in ONE launch chain straight into the collated layout.  Returns (voxels f32[M,P,C], coors i32[M,4]
+    (b,z,y,x), num_points i32[M], mean f32[M,C], num_voxels i64[B]) with ONE host read (the B+1 row offsets)."""
+    pending = voxelize_batch_launch(points_cat, offsets, voxel_size, coors_range, max_points, max_voxels)
+    return voxelize_batch_collect(pending, pending[4].cpu().tolist())   # the one host read of the batch
 
 
 # ------------------------------------------------------------------------------------------------

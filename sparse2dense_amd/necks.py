@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .heads import pcr_level, pcr_level_supported
 from .registry import NECKS
@@ -117,10 +117,26 @@ class _ToPlanarF32(torch.autograd.Function):
     def forward(ctx, x):
         ctx.src_dtype = x.dtype
         ctx.channels_last = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+        n, c, h, w = x.shape
+        ctx.hip = bool(ctx.channels_last and x.is_cuda and x.dtype == torch.bfloat16 and c % 8 == 0 and (h * w) % 4 == 0)
+        if ctx.hip:   # tiled transpose (csrc/layout.hip)
+            from . import _lib
+            from .dense2d import _stream
+            y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.load().s2d_nhwc_bf16_to_nchw_f32(x.data_ptr(), n, c, h * w, y.data_ptr(), _stream()), "s2d_nhwc_bf16_to_nchw_f32")
+            return y
         return x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.hip and g.dtype == torch.float32:
+            from . import _lib
+            from .dense2d import _stream
+            g = g.contiguous()
+            n, c, h, w = g.shape
+            dx = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            _lib.check(_lib.load().s2d_nchw_f32_to_nhwc_bf16(g.data_ptr(), n, c, h * w, dx.data_ptr(), _stream()), "s2d_nchw_f32_to_nhwc_bf16")
+            return dx
         return g.to(dtype=ctx.src_dtype, memory_format=torch.channels_last if ctx.channels_last else torch.contiguous_format)
 
 
@@ -135,7 +151,7 @@ def _cbg(*convs_and_channels):
 
 def _convnext(c, hw):
     return nn.Sequential(DepthwiseConv7(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
-                         nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
+                         Conv1x1(c, 4 * c, 1), nn.GELU(), Conv1x1(4 * c, c, 1))
 
 
 @NECKS.register_module
@@ -153,9 +169,9 @@ class S2D_RPN(RPN):
         self.convnext_block_3 = _convnext(256, 47)
         self.decoder_1 = _cbg((nn.ConvTranspose2d(256, 256, 4, 2, 1), 256))
         self.decoder_2 = _cbg((Conv3x3(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
-        self.fusion_sparse = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
-        self.fusion_dense = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
-        self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
+        self.fusion_sparse = _cbg((Conv1x1(c, c, 1, 1, 0), c))
+        self.fusion_dense = _cbg((Conv1x1(c, c, 1, 1, 0), c))
+        self.out_conv = _cbg((Conv1x1(c, 640, 1, 1, 0), 640))
         # ---- PCR point-cloud-reconstruction head (rpn.py:263-296) ----
         # (nn.Conv3d / nn.ConvTranspose3d subclasses: same parameters, HIP streaming kernels on CUDA fp32)
         # BN+ReLU pairs are fused in FastBatchNorm3d; an nn.Identity keeps the reference's Sequential indices

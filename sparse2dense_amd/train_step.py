@@ -54,7 +54,8 @@ def distill_loss(T_model, S_model, example):
 def backward_and_clip(loss, params, max_norm=35.0):
     """zero_grad -> backward -> clip_grad_norm_(35) (hooks/optimizer.py:15-21, config :216).  Under data parallelism
     (dp.wrap_ddp, routes "overlap"/"flat") the gradients are averaged over the ranks by the model's GradBuckets: its
-    all-reduces are launched from gradient hooks during the backward and awaited here, before the clip."""
+    all-reduces are launched from gradient hooks during the backward and awaited here, before the clip.
+    max_norm=None: no clip here (solver.OneCycleAdam.clip_and_step folds it into the update)."""
     from . import dp
     params = list(params)
     syncs = dp.bucketers_of(params)
@@ -65,4 +66,16 @@ def backward_and_clip(loss, params, max_norm=35.0):
     loss.backward()
     for g in syncs:
         g.finish()
+    if max_norm is None:
+        return None
     return torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm)
+
+
+def backward_and_step(loss, params, optimizer, scheduler=None, iteration=None, max_norm=35.0):
+    """One OptimizerHook.after_train_iter of the reference (hooks/optimizer.py:15-21) with its optimizer (apis/train.py:168-186,
+    fastai OptimWrapper Adam + true weight decay under the OneCycle schedule): schedule step -> zero_grad -> backward (+ overlapped
+    gradient all-reduce) -> clip(35) and update in the fused multi-tensor kernels (solver.OneCycleAdam.clip_and_step)."""
+    if scheduler is not None:
+        scheduler.step(iteration)
+    backward_and_clip(loss, params, None)
+    return optimizer.clip_and_step(max_norm)

@@ -71,6 +71,29 @@ class VoxelGenerator:
         return self._grid_size
 
 
+def voxelize_batches(requests):
+    """Several collated voxelizations (a training example voxelizes the same frames as input / dense / reconstruction clouds at up to
+    three scales) with ONE host read between them: requests = [(generator, point_clouds, prefix), ...] -> merged dict of the
+    `voxelize_batch` fields.  CUDA point clouds, <= 64 frames each."""
+    pend = []
+    for generator, point_clouds, prefix in requests:
+        offs = [0]
+        for pts in point_clouds:
+            offs.append(offs[-1] + int(pts.shape[0]))
+        cat = point_clouds[0] if len(point_clouds) == 1 else torch.cat([p.float() for p in point_clouds], 0)
+        pend.append((prefix, H.voxelize_batch_launch(cat, offs, generator.voxel_size, generator.point_cloud_range,
+                                                     generator.max_num_points_per_voxel, generator._max_voxels)))
+    bases = torch.cat([p[1][4] for p in pend]).cpu().tolist()   # the one host read
+    out, at = {}, 0
+    for prefix, p in pend:
+        k = p[4].numel()
+        v, c, n, m, counts = H.voxelize_batch_collect(p, bases[at:at + k])
+        at += k
+        out.update({prefix + "voxels": v, prefix + "coordinates": c, prefix + "num_points": n, prefix + "num_voxels": counts,
+                    prefix + "voxel_mean": m})
+    return out
+
+
 def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefix="", batched=True):
     """List of per-sample cuda point tensors -> the collated example fields
     `{prefix}voxels f32[sum M,P,C]`, `{prefix}coordinates i32[sum M,4] (b,z,y,x)`,

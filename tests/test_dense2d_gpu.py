@@ -323,6 +323,38 @@ def test_wide_layernorm_matches_stock():
     assert torch.allclose(m.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-5) and torch.allclose(m.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c,h,w,nhwc", [(4, 256, 47, 47, True), (2, 64, 47, 47, False), (3, 8, 96, 100, True), (1, 256, 47, 47, True)])
+def test_wide_layernorm_bf16_kernels_vs_float64(n, c, h, w, nhwc):
+    """csrc/layernorm.hip on bf16 maps (NHWC and NCHW memory order) vs nn.LayerNorm in float64 on the HOST over the same bf16
+    input / gradient.  bf16 outputs (y, dx): one rounding = 6e-3 of max; fp32 dW / db: 1e-4 of max."""
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(7)
+    m = D.WideLayerNorm([c, h, w], eps=1e-6).cuda()
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-1, 1)
+    ref = torch.nn.LayerNorm([c, h, w], eps=1e-6).double()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    x = (torch.randn(n, c, h, w, device="cuda") * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=fmt)
+    dy = torch.randn(n, c, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=fmt)
+    xa = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    ya = m(xa)
+    assert ya.dtype == torch.bfloat16 and ya.stride() == x.stride()
+    ya.backward(dy)
+    xr = x.double().cpu().contiguous().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double().cpu().contiguous())
+    for name, a, r, tol in (("y", ya, yr, 6e-3), ("dx", xa.grad, xr.grad, 6e-3), ("dw", m.weight.grad, ref.weight.grad, 1e-4),
+                            ("db", m.bias.grad, ref.bias.grad, 1e-4)):
+        err = float((a.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        assert err <= tol, (name, err)
+    # a second call after an in-place parameter update sees the new weights (packed copies are keyed on the version counter)
+    with torch.no_grad():
+        m.weight.mul_(2.0)
+    y2 = m(x)
+    assert float((y2.float() - (ya.float() - m.bias.view(1, c, h, w)) * 2 - m.bias.view(1, c, h, w)).abs().max()) <= 0.1
+
+
 # ---------------------------------------------------------------------------------------------------
 # Depth-wise 7x7 (csrc/dwconv.hip) vs torch's grouped conv in float64 on the HOST, same bf16-rounded operands.
 # Tolerance: bf16 outputs (y, dx) one output rounding = 6e-3 of max; fp32 outputs (dW, db) 2e-3 of max.
@@ -356,3 +388,17 @@ def test_depthwise7_forward_backward_vs_cpu_float64(n, c, h, w, bias):
     if bias:
         close(m.bias.grad, ref.bias.grad, 2e-3)
     assert m(x).dtype == torch.float32   # no autocast: the stock layer
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 640, 47, 48), (4, 64, 10, 6), (1, 8, 3, 4), (2, 72, 33, 20), (3, 136, 5, 52)])
+def test_planar_handover_transposes_bit_exact(n, c, h, w):
+    """NHWC bf16 -> NCHW fp32 and its gradient path (csrc/layout.hip) are pure data movement: bit-exact vs torch's copies"""
+    from sparse2dense_amd.necks import _ToPlanarF32
+    torch.manual_seed(1)
+    x = torch.randn(n, c, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = _ToPlanarF32.apply(x)
+    assert y.dtype == torch.float32 and y.is_contiguous() and torch.equal(y, x.detach().float().contiguous())
+    g = torch.randn(n, c, h, w, device="cuda")
+    y.backward(g)
+    assert x.grad.dtype == torch.bfloat16 and x.grad.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(x.grad.float(), g.to(torch.bfloat16).float())
