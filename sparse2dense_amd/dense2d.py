@@ -467,22 +467,6 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         return torch.relu(y) if relu else y
 
 
-class Conv1x1(nn.Conv2d):
-    """nn.Conv2d with a 1x1 kernel (stride 1, no padding; same parameters / state_dict keys).  On NHWC activations a 1x1 conv IS a
-    plain GEMM [N*H*W, Cin] x [Cin, Cout]: forward, data and weight gradient go to the library GEMM (hipBLASLt through F.linear)
-    instead of MIOpen's implicit-GEMM convolution kernels (0.23 ms per call for 256 -> 640 at 188 x 188; the GEMM runs at the
-    same rate as the dense 3x3 kernels).  Other inputs take the stock layer."""
-
-    def forward(self, x):
-        if (ENABLED and x.is_cuda and x.dim() == 4 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
-                and self.groups == 1 and self.dilation == (1, 1) and x.is_contiguous(memory_format=torch.channels_last)
-                and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
-            n, c, h, w = x.shape
-            y = F.linear(x.permute(0, 2, 3, 1).reshape(n * h * w, c), self.weight.reshape(self.out_channels, c), self.bias)
-            return y.view(n, h, w, self.out_channels).permute(0, 3, 1, 2)
-        return super().forward(x)
-
-
 def fuse_bn_relu(layers):
     """[.., FastBatchNorm2d, nn.ReLU, ..] -> [.., FastBatchNorm2d(fused_relu), nn.Identity, ..]: same indices (state_dict
     keys of the reference checkpoints), one kernel instead of two."""
