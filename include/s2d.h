@@ -428,6 +428,11 @@ int s2d_pointwise_conv_wgrad_bf16_supported(int cin, int cout, int64_t positions
 int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout, int batch, int cin, int cout,
                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
                                  s2d_stream_t stream);
+/* ... with x = relu(in*scale + shift) applied on the fly (the conv's input was a batch norm + ReLU of `in`):
+ * in_scale_shift (device, 2*cin) = scale[cin] | shift[cin], NULL = plain */
+int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *in_scale_shift, const float *dout, int batch,
+                                       int cin, int cout, int64_t positions, float *dweight, float *dbias,
+                                       void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /*
  * PCR (point-cloud reconstruction) losses of the S2D student, det3d/models/detectors/voxelnet.py:171-185,203-249
@@ -486,6 +491,29 @@ int s2d_pcr_heads_bwd_f32(const float *g, const float *head_params, const int32_
                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co,
                           float *dg, float *dw_mask, float *db_mask, float *dw_off, float *db_off, void *ws,
                           size_t ws_bytes, s2d_stream_t stream);
+
+/*
+ * The same level with the preceding BatchNorm3d + ReLU folded in (rpn.py:265-272,287-291): y is the RAW ConvTranspose3d output,
+ * g = relu(y*scale + shift) is applied on the fly (bn_scale_shift, device, 2C = scale[C] | shift[C]); neither g, its gradient nor
+ * the masked batch-norm gradient is written.  fwd also writes z[B][co][cells] = w2.g + b2 when co > 0.  The backward is two
+ * passes around the batch norm's own finalisation: bwd_sums -> grads[4C+4] = dw_mask | dw_off | db_mask | db_off and bn_sums[2C] =
+ * (sum dG*m, sum dG*m*y) (what s2d_bncm_bwd_reduce_f32 produces); bwd_apply -> dy = a*dG*m + b*y + d with abd (device, 3C).
+ */
+size_t s2d_pcr_level_workspace_bytes(int c);
+int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2,
+                          const float *b2, const int32_t *coors, const float *feats, int64_t m, int batch, int c,
+                          int co, int d, int h, int w, float *z, float *out8, void *ws, size_t ws_bytes,
+                          s2d_stream_t stream);
+int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_shift, const float *head_params,
+                               const int32_t *coors, const float *feats, int64_t m, int batch, int c, int d, int h,
+                               int w, const float *fwd_out8, const float *go_mask, const float *go_offset,
+                               const float *dz, const float *w2, int co, float *grads, float *bn_sums, void *ws,
+                               size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale_shift, const float *head_params,
+                                const int32_t *coors, const float *feats, int64_t m, int batch, int c, int d, int h,
+                                int w, const float *fwd_out8, const float *go_mask, const float *go_offset,
+                                const float *dz, const float *w2, int co, const float *abd, float *dy,
+                                s2d_stream_t stream);
 
 /*
  * Rotated bird's-eye-view IoU and greedy NMS of CenterHead.predict (det3d/core/bbox/box_torch_ops.py:449-464 rotate_nms_pcdet,

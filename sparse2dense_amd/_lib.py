@@ -97,6 +97,8 @@ SIGNATURES = {
     "s2d_pointwise_conv_wgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, c_f32p,
                                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pointwise_conv_wgrad_bf16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "s2d_pointwise_conv_wgrad_norm_bf16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p,
+                                                          c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pointwise_conv_wgrad_bf16": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, c_f32p,
                                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_loss_workspace_bytes": (ctypes.c_size_t, []),
@@ -118,6 +120,14 @@ SIGNATURES = {
     "s2d_pcr_heads_bwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
                               [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int] + [c_f32p] * 5 +
                               [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_level_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "s2d_pcr_level_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 6 +
+                              [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_level_bwd_sums_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                                   [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                    ctypes.c_void_p]),
+    "s2d_pcr_level_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                                    [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_bev_iou_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_nms_rotated_bev": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -956,11 +956,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
 // p0 + 4q and p0 + 16 + 4q of its plane (the same position permutation on both operands, so the products pair up correctly):
 // every load instruction reads 64 contiguous bytes per plane.  db = the VALU sum of the lane's own dy values.
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, int64_t positions, int batch,
-                                                            int cin, int cout, int steps_per_block, float *__restrict__ partial) {
+__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ bnp,
+                                                            int64_t positions, int batch, int cin, int cout, int steps_per_block,
+                                                            float *__restrict__ partial) {
     __shared__ float red[MT * NT * 4 + MT][64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
+    // optional prologue on x: relu(x*scale + shift) per input channel (x = the raw input of a batch norm + ReLU whose output the conv read)
+    float psc[NT], psh[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        psc[n] = bnp ? bnp[n * 16 + r] : 1.f;
+        psh[n] = bnp ? bnp[cin + n * 16 + r] : 0.f;
+    }
     f32x4m acc[MT][NT];
     float bsum[MT];
 #pragma unroll
@@ -1003,7 +1011,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restr
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[n][e] = (__bf16)lo[MT + n][e]; bv[n][4 + e] = (__bf16)hi[MT + n][e]; }
+                for (int e = 0; e < 4; ++e) {
+                    float a0 = lo[MT + n][e], a1 = hi[MT + n][e];
+                    if (bnp) {   // out-of-range positions read 0 and must stay 0: their dy is 0 too, so the product vanishes either way
+                        a0 = fmaxf(fmaf(a0, psc[n], psh[n]), 0.f);
+                        a1 = fmaxf(fmaf(a1, psc[n], psh[n]), 0.f);
+                    }
+                    bv[n][e] = (__bf16)a0;
+                    bv[n][4 + e] = (__bf16)a1;
+                }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1077,6 +1093,10 @@ extern "C" int s2d_pointwise_conv_wgrad_f32(const float *in, const float *dout, 
     return S2D_OK;
 }
 
+extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
+                                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                                  s2d_stream_t stream);
+
 extern "C" int s2d_pointwise_conv_wgrad_bf16_supported(int cin, int cout, int64_t positions) {
     return ((cin == 128 && cout <= 32) || (cin == 32 && cout <= 16)) && cout > 0 && positions > 0 && positions % 4 == 0 &&
            (int64_t)cin * positions * 4 < ((int64_t)1 << 31) && (int64_t)cout * positions * 4 < ((int64_t)1 << 31);
@@ -1085,6 +1105,13 @@ extern "C" int s2d_pointwise_conv_wgrad_bf16_supported(int cin, int cout, int64_
 /* same contract as s2d_pointwise_conv_wgrad_f32 (workspace included) with the operands rounded to bf16 on the matrix cores */
 extern "C" int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout, int batch, int cin, int cout, int64_t positions,
                                              float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return s2d_pointwise_conv_wgrad_norm_bf16(in, nullptr, dout, batch, cin, cout, positions, dweight, dbias, ws, ws_bytes, stream);
+}
+
+/* ... with x = relu(in*scale + shift) applied on the fly: in_scale_shift (device, 2*cin) = scale[cin] | shift[cin], or NULL */
+extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
+                                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                                  s2d_stream_t stream) {
     S2D_CHECK_ARG(in && dout && dweight && batch > 0, "pointwise_conv_wgrad_bf16: bad argument");
     if (!s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, positions)) {
         s2d::set_error("pointwise_conv_wgrad_bf16: unsupported %d -> %d over %lld positions", cin, cout, (long long)positions);
@@ -1101,9 +1128,11 @@ extern "C" int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout,
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)ws;
     if (cin == 128)
-        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8>), dim3(chunks), dim3(256), 0, st, in, dout, positions, batch, cin, cout, spb, partial);
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
+                           partial);
     else
-        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2>), dim3(chunks), dim3(256), 0, st, in, dout, positions, batch, cin, cout, spb, partial);
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
+                           partial);
     hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 16)), dim3(256), 0, st, partial, chunks,
                        cin, cout, dweight, dbias);
     S2D_LAUNCH_CHECK();

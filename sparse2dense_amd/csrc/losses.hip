@@ -645,3 +645,506 @@ extern "C" int s2d_pcr_heads_bwd_f32(const float *g, const float *head_params, c
     return pcr_heads_bwd_t<3, 0, 4>(g, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, dg, dw_mask, db_mask, dw_off, db_off,
                                     wsf, st);
 }
+
+// =====================================================================================================================
+// PCR level with the preceding BatchNorm3d + ReLU folded in (rpn.py:265-272,287-291: ConvTranspose3d -> BatchNorm3d -> ReLU ->
+// {gen_mask_k, gen_out_k, next 1x1x1 conv}).  The kernels read the RAW ConvTranspose3d output y and apply g = relu(y*scale+shift)
+// on the fly; the post-norm volume g, its gradient and the masked gradient of the batch norm are never written:
+//   fwd   one dense pass: logits -> softplus sums, z = w2.g + b2 written (the level's next conv);  sparse terms at the recon voxels
+//   bwd A one dense pass, no writes: dG = w_mask*dL/dlogit + w2^T.dz; per-channel batch-norm sums (sum dG*m, sum dG*m*y) and the
+//         dense part of dw_mask / db_mask;  sparse pass: corrections of both + the offset-head gradients
+//   (batch-norm finalisation on the host side: (a, b, d) per channel)
+//   bwd B one dense pass: dy = a*dG*m + b*y + d;  sparse pass: dy[cell] += a * correction * m
+// against conv -> BN apply -> heads -> BN reduce -> BN apply this removes 5 of 9 passes over the level's 0.5-0.7 GB volumes.
+// =====================================================================================================================
+namespace s2d {
+
+template <int C>
+struct PcrNorm {
+    float sc[C];
+    float sh[C];
+};
+template <int C>
+__device__ __forceinline__ void pcr_load_norm(const float *__restrict__ bnp, PcrNorm<C> &nm) {
+    float *dst = reinterpret_cast<float *>(&nm);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = bnp[i];
+    __syncthreads();
+}
+
+template <int C, int CO, int V>
+__global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *__restrict__ y, const float *__restrict__ bnp, const float *__restrict__ hp,
+                                                                  const float *__restrict__ w2, const float *__restrict__ b2, int64_t cells, int batch,
+                                                                  float *__restrict__ z, float *__restrict__ partial) {
+    __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
+    __shared__ float b2s[CO > 0 ? CO : 1];
+    __shared__ PcrHeadW<C> hw;
+    __shared__ PcrNorm<C> nm;
+    pcr_load_head<C>(hp, hw);
+    pcr_load_norm<C>(bnp, nm);
+    if (CO > 0) {
+        for (int i = threadIdx.x; i < CO * C; i += 256) w2s[(i % C) * CO + i / C] = w2[i];
+        for (int i = threadIdx.x; i < CO; i += 256) b2s[i] = b2 ? b2[i] : 0.f;
+        __syncthreads();
+    }
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;
+    const float *scv = nm.sc + lane_zero, *shv = nm.sh + lane_zero, *w2v = w2s + lane_zero;
+    float acc[1] = {0.f};
+    const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
+    const unsigned plane = (unsigned)cells * 4u;
+    for (int b = 0; b < batch; ++b) {
+        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * plane);
+        const __amdgpu_buffer_rsrc_t zr = planes_rsrc(CO > 0 ? z + (int64_t)b * CO * cells : y, (CO > 0 ? CO : C) * plane);
+        for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
+            asm volatile("" ::: "memory");
+            const unsigned voff = j * (V * 4u);
+            float yv[C][V];
+#pragma unroll
+            for (int c = 0; c < C; ++c) buf_load<V>(yr, voff, c * plane, yv[c]);
+            float x[V], za[CO > 0 ? CO : 1][V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = hw.bm;
+            if (CO > 0) {
+#pragma unroll
+                for (int q = 0; q < CO; ++q)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) za[q][k] = b2s[q];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+                float g[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    g[k] = fmaxf(fmaf(yv[c][k], sc, sh), 0.f);
+                    x[k] = fmaf(wc, g[k], x[k]);
+                }
+                if (CO > 0) {
+#pragma unroll
+                    for (int q = 0; q < CO; ++q) {
+                        const float wq = w2v[c * CO + q];
+#pragma unroll
+                        for (int k = 0; k < V; ++k) za[q][k] = fmaf(wq, g[k], za[q][k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[0] += softplusf(x[k]);
+            if (CO > 0) {
+#pragma unroll
+                for (int q = 0; q < CO; ++q) buf_store<V>(zr, voff, q * plane, za[q]);
+            }
+        }
+    }
+    block_sums<1>(acc, partial);
+}
+
+// the site's raw values, post-norm values, logit and offsets
+template <int C>
+__device__ __forceinline__ void pcr_site_eval_norm(const float *__restrict__ y, const PcrHeadW<C> &hw, const PcrNorm<C> &nm, int64_t cells, int b,
+                                                   int64_t cell, float (&yv)[C], float (&gv)[C], float &x, float (&off)[3]) {
+    x = hw.bm;
+    off[0] = hw.bo[0]; off[1] = hw.bo[1]; off[2] = hw.bo[2];
+    const float *base = y + (int64_t)b * C * cells + cell;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yv[c] = base[(int64_t)c * cells];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        gv[c] = fmaxf(fmaf(yv[c], nm.sc[c], nm.sh[c]), 0.f);
+        x = fmaf(hw.wm[c], gv[c], x);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) off[k] = fmaf(hw.wo[k][c], gv[c], off[k]);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
+                                                                   PcrGeo geo, const float *__restrict__ y, const float *__restrict__ bnp,
+                                                                   const float *__restrict__ hp, float *__restrict__ partial) {
+    __shared__ PcrHeadW<C> hw;
+    __shared__ PcrNorm<C> nm;
+    pcr_load_head<C>(hp, hw);
+    pcr_load_norm<C>(bnp, nm);
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        const int4 c = reinterpret_cast<const int4 *>(coors)[i];   // b,z,y,x
+        if ((unsigned)c.x >= (unsigned)geo.batch || (unsigned)c.y >= (unsigned)geo.d || (unsigned)c.z >= (unsigned)geo.h ||
+            (unsigned)c.w >= (unsigned)geo.w)
+            continue;
+        const float *f = feats + i * 5;
+        const float s = (((f[0] + f[1]) + f[2]) + f[3]) + f[4];
+        const bool pos = s != 0.f;
+        const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
+        float yv[C], gv[C], x, off[3];
+        pcr_site_eval_norm<C>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        if (pos) {
+            acc[0] += 1.f;
+            acc[1] += softplusf(-x);
+            acc[2] += softplusf(x);
+        }
+        float gc[3];
+        pcr_grid(geo, c.y, c.z, c.w, gc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = pos ? f[k] - gc[k] : f[k];
+            if (t != 0.f) {
+                acc[3] += fabsf(off[k] - t);
+                acc[4] += 1.f;
+            }
+        }
+    }
+    block_sums<5>(acc, partial);
+}
+
+// pass A (APPLY = false): partial[block][3C+1] = dw_mask(C) | db_mask | sum dG*m (C) | sum dG*m*y (C), nothing written;
+// pass B (APPLY = true):  dy = a*dG*m + b*y + d
+template <int C, int CO, int V, bool APPLY>
+__global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *__restrict__ y, const float *__restrict__ dz, const float *__restrict__ bnp,
+                                                                  const float *__restrict__ w2, const float *__restrict__ hp,
+                                                                  const float *__restrict__ go_mask, const float *__restrict__ fin,
+                                                                  const float *__restrict__ abd, int64_t cells, int batch, float *__restrict__ dy,
+                                                                  float *__restrict__ partial) {
+    __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
+    __shared__ float abds[APPLY ? 3 * C : 1];
+    __shared__ PcrHeadW<C> hw;
+    __shared__ PcrNorm<C> nm;
+    pcr_load_head<C>(hp, hw);
+    pcr_load_norm<C>(bnp, nm);
+    if (CO > 0)
+        for (int i = threadIdx.x; i < CO * C; i += 256) w2s[(i % C) * CO + i / C] = w2[i];
+    if (APPLY)
+        for (int i = threadIdx.x; i < 3 * C; i += 256) abds[i] = abd[i];
+    __syncthreads();
+    const float scale = go_mask[0] / fin[4];
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;
+    const float *scv = nm.sc + lane_zero, *shv = nm.sh + lane_zero, *w2v = w2s + lane_zero, *abv = abds + lane_zero;
+    float pw[APPLY ? 1 : 3 * C + 1];
+#pragma unroll
+    for (int c = 0; c < (APPLY ? 1 : 3 * C + 1); ++c) pw[c] = 0.f;
+    const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
+    const unsigned plane = (unsigned)cells * 4u;
+    for (int b = 0; b < batch; ++b) {
+        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * plane);
+        const __amdgpu_buffer_rsrc_t dyr = planes_rsrc(APPLY ? dy + (int64_t)b * C * cells : y, C * plane);
+        const __amdgpu_buffer_rsrc_t zr = planes_rsrc(CO > 0 ? dz + (int64_t)b * CO * cells : y, (CO > 0 ? CO : C) * plane);
+        for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
+            asm volatile("" ::: "memory");
+            const unsigned voff = j * (V * 4u);
+            float yv[C][V];
+#pragma unroll
+            for (int c = 0; c < C; ++c) buf_load<V>(yr, voff, c * plane, yv[c]);
+            float zv[CO > 0 ? CO : 1][V];
+            if (CO > 0) {
+#pragma unroll
+                for (int q = 0; q < CO; ++q) buf_load<V>(zr, voff, q * plane, zv[q]);
+            }
+            float x[V], dm[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[k] = hw.bm;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+#pragma unroll
+                for (int k = 0; k < V; ++k) x[k] = fmaf(wc, fmaxf(fmaf(yv[c][k], sc, sh), 0.f), x[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                dm[k] = scale * sigmoidf(x[k]);
+                if (!APPLY) pw[C] += dm[k];
+            }
+            asm volatile("" ::: "memory");   // re-read the per-channel constants below instead of keeping 3C of them live across both loops
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+                float o[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) o[k] = wc * dm[k];
+                if (CO > 0) {
+#pragma unroll
+                    for (int q = 0; q < CO; ++q) {
+                        const float wq = w2v[c * CO + q];
+#pragma unroll
+                        for (int k = 0; k < V; ++k) o[k] = fmaf(wq, zv[q][k], o[k]);
+                    }
+                }
+                if (APPLY) {
+                    const float a = abv[c], bb = abv[C + c], dd = abv[2 * C + c];
+                    float r[V];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float g = fmaf(yv[c][k], sc, sh);
+                        r[k] = fmaf(a, g > 0.f ? o[k] : 0.f, fmaf(bb, yv[c][k], dd));
+                    }
+                    buf_store<V>(dyr, voff, c * plane, r);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float g = fmaxf(fmaf(yv[c][k], sc, sh), 0.f);
+                        const float om = g > 0.f ? o[k] : 0.f;
+                        pw[c] = fmaf(dm[k], g, pw[c]);
+                        pw[C + 1 + c] += om;
+                        pw[2 * C + 1 + c] = fmaf(om, yv[c][k], pw[2 * C + 1 + c]);
+                    }
+                }
+            }
+        }
+    }
+    if (!APPLY) block_sums_n<APPLY ? 1 : 3 * C + 1>(pw, partial);
+}
+
+// sparse pass A (APPLY = false): partial[block][6C+4] = dw_mask(C) | dw_off(3C) | db_mask | db_off(3) | sum corr*m (C) | sum corr*m*y (C);
+//   blockIdx.y selects a group of CG channels whose accumulators the thread keeps (6*CG+4 registers instead of 6*C+4)
+// sparse pass B (APPLY = true):  dy[c][cell] += a[c] * corr[c] * m
+template <int C, int CG, bool APPLY>
+__global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
+                                                                   PcrGeo geo, const float *__restrict__ y, const float *__restrict__ bnp,
+                                                                   const float *__restrict__ hp, const float *__restrict__ go_mask,
+                                                                   const float *__restrict__ go_off, const float *__restrict__ fin,
+                                                                   const float *__restrict__ abd, float *__restrict__ dy, float *__restrict__ partial) {
+    __shared__ PcrHeadW<C> hw;
+    __shared__ PcrNorm<C> nm;
+    pcr_load_head<C>(hp, hw);
+    pcr_load_norm<C>(bnp, nm);
+    constexpr int NACC = APPLY ? 1 : 6 * CG + 4;
+    const int q0 = APPLY ? 0 : blockIdx.y * CG;   // first channel of this block's group
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.f;
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float sm = go_mask[0] / fin[4], beta = fin[2], so = go_off[0] / fin[3];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        const int4 c = reinterpret_cast<const int4 *>(coors)[i];
+        if ((unsigned)c.x >= (unsigned)geo.batch || (unsigned)c.y >= (unsigned)geo.d || (unsigned)c.z >= (unsigned)geo.h ||
+            (unsigned)c.w >= (unsigned)geo.w)
+            continue;
+        const float *f = feats + i * 5;
+        const float s = (((f[0] + f[1]) + f[2]) + f[3]) + f[4];
+        const bool pos = s != 0.f;
+        const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
+        float yv[C], gv[C], x, off[3];
+        pcr_site_eval_norm<C>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        float dmk = 0.f;
+        if (pos) {
+            const float sg = sigmoidf(x);
+            dmk = -sm * (beta * (1.f - sg) + sg);
+        }
+        float gc[3], dk[3];
+        pcr_grid(geo, c.y, c.z, c.w, gc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = pos ? f[k] - gc[k] : f[k];
+            const float dlt = off[k] - t;
+            dk[k] = (t != 0.f) ? (dlt > 0.f ? so : (dlt < 0.f ? -so : 0.f)) : 0.f;
+        }
+        if (APPLY) {
+            float *ob = dy + (int64_t)c.x * C * cells + cell;
+#pragma unroll
+            for (int q = 0; q < C; ++q) {
+                const float corr = (hw.wm[q] * dmk + hw.wo[0][q] * dk[0]) + (hw.wo[1][q] * dk[1] + hw.wo[2][q] * dk[2]);
+                if (gv[q] > 0.f) ob[(int64_t)q * cells] += abd[q] * corr;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < CG; ++e) {
+                // channel q0 + e: q0 is block-uniform; the unrolled selects below pick the group's values out of the C registers
+                float g = 0.f, yy = 0.f, wmq = 0.f, wo0 = 0.f, wo1 = 0.f, wo2 = 0.f;
+#pragma unroll
+                for (int grp = 0; grp < C / CG; ++grp)
+                    if (q0 == grp * CG) {
+                        g = gv[grp * CG + e]; yy = yv[grp * CG + e];
+                        wmq = hw.wm[grp * CG + e]; wo0 = hw.wo[0][grp * CG + e]; wo1 = hw.wo[1][grp * CG + e]; wo2 = hw.wo[2][grp * CG + e];
+                    }
+                const float corr = (wmq * dmk + wo0 * dk[0]) + (wo1 * dk[1] + wo2 * dk[2]);
+                const float cm = g > 0.f ? corr : 0.f;
+                acc[e] = fmaf(dmk, g, acc[e]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[CG + k * CG + e] = fmaf(dk[k], g, acc[CG + k * CG + e]);
+                acc[4 * CG + 4 + e] += cm;
+                acc[5 * CG + 4 + e] = fmaf(cm, yy, acc[5 * CG + 4 + e]);
+            }
+            acc[4 * CG] += dmk;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[4 * CG + 1 + k] += dk[k];
+        }
+    }
+    if (!APPLY) {
+        // scatter the group's sums into the [6C+4] row of this block: fold per value, then lane 0 of the block writes
+        __shared__ float red[4][NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            float v = acc[k];
+#pragma unroll
+            for (int off2 = 32; off2 > 0; off2 >>= 1) v += __shfl_down(v, off2, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+        }
+        __syncthreads();
+        float *row = partial + (int64_t)blockIdx.x * (6 * C + 4);
+        for (int k = threadIdx.x; k < NACC; k += 256) {
+            const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+            int col;   // group layout [dwm CG | dwo 3CG | dbm | dbo 3 | S1 CG | S2 CG] -> row layout [dwm C | dwo 3C | dbm | dbo 3 | S1 C | S2 C]
+            if (k < CG) col = q0 + k;
+            else if (k < 4 * CG) col = C + ((k - CG) / CG) * C + q0 + (k - CG) % CG;
+            else if (k < 4 * CG + 4) col = (blockIdx.y == 0) ? 4 * C + (k - 4 * CG) : -1;   // the scalars once
+            else if (k < 5 * CG + 4) col = 4 * C + 4 + q0 + (k - 4 * CG - 4);
+            else col = 5 * C + 4 + q0 + (k - 5 * CG - 4);
+            if (col >= 0) row[col] = v;
+        }
+    }
+}
+
+// one block per output t: grads[4C+4] = dw_mask | dw_off | db_mask | db_off, then bn_sums[2C]
+template <int C>
+__global__ __launch_bounds__(256) void pcr_level_fold_kernel(const float *__restrict__ dense_partial, int nd, const float *__restrict__ sparse_partial,
+                                                             int ns, float *__restrict__ grads, float *__restrict__ bn_sums) {
+    const int t = blockIdx.x;   // 0 .. 6C+3 in the sparse layout
+    float s = 0.f;
+    for (int i = threadIdx.x; i < ns; i += 256) s += sparse_partial[(int64_t)i * (6 * C + 4) + t];
+    int col = -1;   // matching column of the dense layout dw_mask(C) | db_mask | S1(C) | S2(C)
+    if (t < C) col = t;
+    else if (t == 4 * C) col = C;
+    else if (t >= 4 * C + 4) col = C + 1 + (t - 4 * C - 4);
+    if (col >= 0)
+        for (int i = threadIdx.x; i < nd; i += 256) s += dense_partial[(int64_t)i * (3 * C + 1) + col];
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t < 4 * C + 4) grads[t] = r;
+    else bn_sums[t - 4 * C - 4] = r;
+}
+
+template <int C, int CO, int V>
+static int pcr_level_fwd_t(const float *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
+                           int64_t m, PcrGeo geo, float *z, float *out8, float *ws, hipStream_t st) {
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
+    float *dense_partial = ws, *sparse_partial = ws + PCRH_DENSE_BLOCKS;
+    const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
+    const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
+    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial);
+    hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
+    hipLaunchKernelGGL(pcr_finalize_kernel, dim3(1), dim3(64), 0, st, dense_partial, nd, sparse_partial, ns, (double)n, out8);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+template <int C, int CO, int V>
+static int pcr_level_bwd_sums_t(const float *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
+                                const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, float *grads,
+                                float *bn_sums, float *ws, hipStream_t st) {
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    float *dense_partial = ws, *sparse_partial = ws + (size_t)PCRH_DENSE_BLOCKS * (3 * C + 1);
+    const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
+    const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
+                       geo.batch, nullptr, dense_partial);
+    constexpr int CG = C == 32 ? 8 : C;   // channel groups of the sparse pass (accumulator registers)
+    hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask, go_off,
+                       fin, nullptr, nullptr, sparse_partial);
+    hipLaunchKernelGGL((pcr_level_fold_kernel<C>), dim3(6 * C + 4), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, grads, bn_sums);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+template <int C, int CO, int V>
+static int pcr_level_bwd_apply_t(const float *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
+                                 const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, const float *abd,
+                                 float *dy, hipStream_t st) {
+    const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
+    const int nd = (int)std::min<int64_t>(2 * PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
+                       dy, nullptr);
+    if (m > 0)
+        hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
+                           coors, feats, m, geo, y, bnp, hp, go_mask, go_off, fin, abd, dy, nullptr);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+}  // namespace s2d
+
+extern "C" size_t s2d_pcr_level_workspace_bytes(int c) {
+    return ((size_t)PCRH_DENSE_BLOCKS * (3 * c + 1) + (size_t)PCRH_SPARSE_BLOCKS * (6 * c + 4)) * sizeof(float) + 512;
+}
+
+// y: RAW ConvTranspose3d output [B][C][cells]; bn_scale_shift (device, 2C) = scale[C] | shift[C] of the batch norm that follows it
+// (g = relu(y*scale + shift)); head_params as s2d_pcr_heads_fwd_f32; z[B][co][cells] = w2.g + b2 (co > 0); out8 as s2d_pcr_loss_fwd_f32.
+extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                                     const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
+                                     float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(y && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
+                      (co == 0 || (w2 && z)),
+                  "pcr_level_fwd: bad argument");
+    if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
+        set_error("pcr_level_fwd: unsupported channels %d -> %d / cells %lld", c, co, (long long)d * h * w);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < s2d_pcr_level_workspace_bytes(c)) {
+        set_error("pcr_level_fwd: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    PcrGeo geo{batch, d, h, w};
+    hipStream_t st = (hipStream_t)stream;
+    float *wsf = (float *)ws;
+    if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+    if (c == 32) return pcr_level_fwd_t<32, 0, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+    return pcr_level_fwd_t<3, 0, 4>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+}
+
+// pass A of the backward: grads[4C+4] = dw_mask[C] | dw_off[3][C] | db_mask | db_off[3] and bn_sums[2C] = (sum dG*m, sum dG*m*y) per
+// channel, the batch norm's backward reduction (s2d_bncm_bwd_reduce_f32's output)
+extern "C" int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                          const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                          const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
+                                          float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(y && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && grads && bn_sums && batch > 0 && d > 0 && h > 0 && w > 0 &&
+                      m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
+                  "pcr_level_bwd_sums: bad argument");
+    if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
+        set_error("pcr_level_bwd_sums: unsupported channels %d -> %d / cells %lld", c, co, (long long)d * h * w);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < s2d_pcr_level_workspace_bytes(c)) {
+        set_error("pcr_level_bwd_sums: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    PcrGeo geo{batch, d, h, w};
+    hipStream_t st = (hipStream_t)stream;
+    float *wsf = (float *)ws;
+    if (c == 32 && co == 16)
+        return pcr_level_bwd_sums_t<32, 16, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums,
+                                               wsf, st);
+    if (c == 32)
+        return pcr_level_bwd_sums_t<32, 0, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums, wsf,
+                                              st);
+    return pcr_level_bwd_sums_t<3, 0, 4>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums, wsf, st);
+}
+
+// pass B: dy[B][C][cells] = a*dG*m + b*y + d with abd (device, 3C) = a[C] | b[C] | d[C] from the batch-norm backward finalisation
+extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
+                                           float *dy, s2d_stream_t stream) {
+    S2D_CHECK_ARG(y && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dy && batch > 0 && d > 0 && h > 0 && w > 0 &&
+                      m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
+                  "pcr_level_bwd_apply: bad argument");
+    if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
+        set_error("pcr_level_bwd_apply: unsupported channels %d -> %d / cells %lld", c, co, (long long)d * h * w);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    PcrGeo geo{batch, d, h, w};
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 32 && co == 16)
+        return pcr_level_bwd_apply_t<32, 16, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
+    if (c == 32)
+        return pcr_level_bwd_apply_t<32, 0, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
+    return pcr_level_bwd_apply_t<3, 0, 4>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
+}

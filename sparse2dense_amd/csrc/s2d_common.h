@@ -73,9 +73,14 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
     using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0u, 0u, 0));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
 }
+// 16-byte stores fold the scalar offset into the per-lane one: with a REGISTER scalar offset hipcc assumes that a >64-bit buffer
+// store may be followed at once by a write of its data registers (no wait state inserted) - measured on gfx950: the next channel's
+// v_pk_fma overwrote the data of `buffer_store_dwordx4 ..., s22 offen` before the store had read it.  With an immediate scalar
+// offset the hazard recogniser inserts the wait state.  (An out-of-range per-lane offset stays out of range: soff < 2^31.)
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, buf_f32x4 v) {
     using raw_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0u, 0u, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw_t, v), r, voff, soff, 0);
+    const unsigned off = voff >= BUF_OOB ? voff : voff + soff;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw_t, v), r, off, 0, 0);
 }
 #endif
 

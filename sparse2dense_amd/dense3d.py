@@ -39,9 +39,10 @@ def pointwise_conv(x, w2d, bias):
     return out
 
 
-def pointwise_conv_wgrad(x, dout, want_db, bf16=False):
+def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
     """(dW [Cout,Cin], db [Cout] | None) of a 1x1x1 conv over planar fp32 tensors (position count % 4 == 0).  bf16: operands
-    rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported."""
+    rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported.  norm (f32[2*Cin] = scale |
+    shift): the conv's input was relu(x*scale + shift), applied on the fly (bf16 route) or materialised (fp32 route)."""
     lib = _lib.load()
     n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
     pos = x[0, 0].numel()
@@ -49,9 +50,12 @@ def pointwise_conv_wgrad(x, dout, want_db, bf16=False):
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
     ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
     if bf16 and lib.s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, pos):
-        check(lib.s2d_pointwise_conv_wgrad_bf16(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
-              "s2d_pointwise_conv_wgrad_bf16")
+        check(lib.s2d_pointwise_conv_wgrad_norm_bf16(_ptr(x), _ptr(norm), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                                     _stream()), "s2d_pointwise_conv_wgrad_norm_bf16")
     else:
+        if norm is not None:
+            shape = (1, cin) + (1,) * (x.dim() - 2)
+            x = torch.relu(x * norm[:cin].view(shape) + norm[cin:].view(shape))
         check(lib.s2d_pointwise_conv_wgrad_f32(_ptr(x), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
               "s2d_pointwise_conv_wgrad_f32")
     return dw, db

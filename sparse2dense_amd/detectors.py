@@ -55,9 +55,11 @@ class SingleStageDetector(nn.Module):
         self.dense_channels_last = True
         return self
 
-    def _dense(self, module, x, keep_first=False):
+    def _dense(self, module, x, keep_first=False, keep=()):
         """neck / head call; optionally under bf16 autocast (fp32 master weights, fp32 outputs).  keep_first: the first
-        (or only) output stays in the compute dtype — the neck map that only feeds the head."""
+        (or only) output stays in the compute dtype — the neck map that only feeds the head.  keep: further tuple positions left
+        in the compute dtype (feature maps whose consumers upcast per element: a `.float()` of a [4,256,188,188] map is a 36 ->
+        72 MB pass that the student-only step never uses)."""
         if self.dense_channels_last and x.is_cuda and x.dim() == 4 and module is self.bbox_head:
             x = x.contiguous(memory_format=torch.channels_last)   # NHWC: what the bf16 MFMA conv kernels consume
         if self.dense_dtype == torch.float32 or not x.is_cuda:
@@ -69,6 +71,8 @@ class SingleStageDetector(nn.Module):
             conv = [({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for o in out]
             if keep_first and torch.is_tensor(out[0]):
                 conv[0] = out[0]
+            for i in keep:
+                conv[i] = out[i]
             return type(out)(conv)
         return out if keep_first and torch.is_tensor(out) else f32(out)
 
@@ -128,8 +132,11 @@ class VoxelNet(SingleStageDetector):
 @DETECTORS.register_module
 class KD_VoxelNet(VoxelNet):
     def extract_feat(self, data, train_pcm=True):
-        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"])
-        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True)
+        # the BEV map goes straight to NHWC bf16 when only the bf16 neck reads it (as in VoxelNet.extract_feat)
+        bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and data["features"].is_cuda)
+        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"], bev_nhwc_bf16=bev)
+        # F_S_a / F_S_b stay in the neck's compute dtype (sparse2dense_loss upcasts per element)
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True, keep=(5, 6))
         return x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, voxel_feature
 
     mask_offset_loss = staticmethod(mask_offset_loss)

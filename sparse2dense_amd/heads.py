@@ -71,6 +71,7 @@ def distill_reg_loss(output, target, mask, ind):
 def masked_mse_pair(student, teacher, w_pos, w_neg):
     """w_pos*MSE over teacher>0 + w_neg*MSE over the rest (trainer.py:783-789), without
     materialising boolean-indexed copies: two masked sums and two counts."""
+    student, teacher = student.float(), teacher.float()   # bf16 feature maps: differences and sums in fp32
     pos = teacher > 0
     d2 = (student - teacher) ** 2
     n_pos = pos.sum()
@@ -199,6 +200,99 @@ class _PcrLevelFn(torch.autograd.Function):
             dw2 = dw2.reshape(w2_shape)
         return (dg, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:], None, None,
                 dw2, db2, None)
+
+
+class _PcrLevelNormFn(torch.autograd.Function):
+    """A PCR level together with the BatchNorm3d + ReLU in front of it (csrc/losses.hip "PCR level with the preceding BatchNorm3d"):
+    input = the RAW ConvTranspose3d output; the normalised volume, its gradient and the batch norm's masked gradient are never
+    written.  The batch-norm statistics / finalisation (running stats, SyncBN all-reduces) are the FastBatchNorm3d ones."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16):
+        from . import _lib, collective as _collective, hip_ops as H
+        from .dense2d import _ptr, _stream, _ws
+        from .dense3d import _bncm_reduce
+        lib = _lib.load()
+        y = y.contiguous()
+        b, c, d, h, w = y.shape
+        pos, dev = d * h * w, y.device
+        sync = _collective.sync_on()
+        stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(y),), b, c, pos, dev)
+        count = torch.full((1,), float(b * pos), device=dev)
+        if sync:
+            packed = torch.cat([stats, count])
+            _collective.allreduce_sum_(packed)
+            stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+        track = bn.track_running_stats
+        fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None,
+                                  bn.running_var if track else None, bn.num_batches_tracked if track else None)
+        mean, invstd = fin[0], fin[1]
+        norm = torch.cat([fin[2].reshape(-1), fin[3].reshape(-1)]).contiguous()   # scale | shift
+        hp = torch.cat([w_mask.reshape(-1), w_off.reshape(-1), b_mask.reshape(-1), b_off.reshape(-1)]).float().contiguous()
+        coors, feats = coors.contiguous(), feats.contiguous()
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        co, z, w2d = 0, None, None
+        if w2 is not None:
+            co = w2.shape[0]
+            w2d = w2.reshape(co, c).contiguous()
+            z = torch.empty((b, co, d, h, w), dtype=torch.float32, device=dev)
+        ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
+        _lib.check(lib.s2d_pcr_level_fwd_f32(_ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h,
+                                             w, _ptr(z), _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd_f32")
+        ctx.save_for_backward(y, norm, hp, coors, feats, out, w2d, gamma, mean, invstd, count)
+        ctx.shapes = (w_mask.shape, w_off.shape, None if w2 is None else w2.shape, b2 is not None)
+        ctx.bf16, ctx.sync = bool(bf16), sync
+        return out[0], out[1], z
+
+    @staticmethod
+    def backward(ctx, go_mask, go_off, dz):
+        from . import _lib, collective as _collective, hip_ops as H
+        from .dense2d import _ptr, _stream, _ws
+        from .dense3d import pointwise_conv_wgrad
+        lib = _lib.load()
+        y, norm, hp, coors, feats, out, w2d, gamma, mean, invstd, count = ctx.saved_tensors
+        b, c, d, h, w = y.shape
+        dev = y.device
+        zero = lambda: torch.zeros(1, dtype=torch.float32, device=dev)
+        go_mask = zero() if go_mask is None else go_mask.float().reshape(1).contiguous()
+        go_off = zero() if go_off is None else go_off.float().reshape(1).contiguous()
+        co = 0
+        if w2d is not None:
+            co = w2d.shape[0]
+            dz = torch.zeros((b, co, d, h, w), dtype=torch.float32, device=dev) if dz is None else dz.contiguous()
+        grads = torch.empty(4 * c + 4, dtype=torch.float32, device=dev)   # dw_mask | dw_off | db_mask | db_off
+        sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
+        ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
+        args = (_ptr(y), _ptr(norm), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(go_mask), _ptr(go_off),
+                _ptr(dz) if co else None, _ptr(w2d) if co else None, co)
+        _lib.check(lib.s2d_pcr_level_bwd_sums_f32(*args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums_f32")
+        sums_all = sums
+        if ctx.sync:
+            sums_all = sums.clone()
+            _collective.allreduce_sum_(sums_all)
+        fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+        dgamma, dbeta = fin[0], fin[1]
+        abd = torch.cat([fin[2].reshape(-1), fin[3].reshape(-1), fin[4].reshape(-1)]).contiguous()
+        dy = torch.empty_like(y)
+        _lib.check(lib.s2d_pcr_level_bwd_apply_f32(*args, _ptr(abd), _ptr(dy), _stream()), "s2d_pcr_level_bwd_apply_f32")
+        wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
+        dw2 = db2 = None
+        if co:
+            dw2, db2 = pointwise_conv_wgrad(y, dz, has_b2, ctx.bf16, norm=norm)
+            dw2 = dw2.reshape(w2_shape)
+        return (dy, dgamma, dbeta, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:],
+                None, None, dw2, db2, None, None)
+
+
+def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
+    """`pcr_level(relu(bn(y)), ...)` with the training-mode BatchNorm3d + ReLU folded into the level's kernels: y is the raw output of
+    the level's ConvTranspose3d.  Same returns as pcr_level."""
+    assert bn.training and bn.affine and getattr(bn, "fused_relu", False) and bn.momentum is not None
+    assert mask_conv.bias is not None and offset_conv.bias is not None
+    coors = coors if coors.dtype == torch.int32 else coors.int()
+    return _PcrLevelNormFn.apply(y, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors,
+                                 feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
+                                 bn, bool(getattr(next_conv, "bf16_compute", False)))
 
 
 def pcr_level_supported(g, next_conv=None):

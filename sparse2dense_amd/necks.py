@@ -17,7 +17,7 @@ from torch import nn
 from .backbones import build_norm_layer
 from .dense2d import Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
-from .heads import pcr_level, pcr_level_supported
+from .heads import pcr_level, pcr_level_norm, pcr_level_supported
 from .registry import NECKS
 
 
@@ -210,9 +210,29 @@ class S2D_RPN(RPN):
                 if gen.dtype in (torch.bfloat16, torch.float16):
                     gen = _ToPlanarF32.apply(gen)
                 gen = gen.contiguous().view(n, 128, 5, h, w)
-                gen = self.generator_1(gen)
                 tg, self.pcr_targets = self.pcr_targets, None
-                if tg is not None and pcr_level_supported(gen, self.generator_2[0]):
+                bn1, bn2 = self.generator_1[4], self.generator_2[4]
+                fold = (tg is not None and gen.is_cuda and isinstance(bn1, FastBatchNorm3d) and isinstance(bn2, FastBatchNorm3d)
+                        and bn1.training and bn2.training and bn1.fused_relu and bn2.fused_relu)
+                if fold:
+                    raw = self.generator_1[:4](gen)   # ... up to the RAW output of the first up-sampler
+                    fold = pcr_level_supported(raw, self.generator_2[0])
+                    gen = raw if fold else self.generator_1[4:](raw)
+                else:
+                    gen = self.generator_1(gen)
+                if fold:
+                    # the detector handed the recon voxels in and the levels' batch norms are ours: BatchNorm3d + ReLU + mask / offset heads +
+                    # losses (+ the next 1x1x1 conv) run from the raw up-sampler outputs (heads.pcr_level_norm); the gen_* slots carry
+                    # the 0-dim losses
+                    gen_mask_4, gen_offset_4, z = pcr_level_norm(gen, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
+                    raw2 = self.generator_2[1:4](z)
+                    if pcr_level_supported(raw2):
+                        gen_mask_2, gen_offset_2, _ = pcr_level_norm(raw2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
+                    else:
+                        gen = self.generator_2[4:](raw2)
+                        from .heads import mask_offset_loss_sparse
+                        gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
+                elif tg is not None and pcr_level_supported(gen, self.generator_2[0]):
                     # the detector handed the recon voxels in: each level's mask / offset heads and losses are evaluated without
                     # writing the logits / offset volumes (heads.pcr_level); the gen_* slots carry the 0-dim losses instead
                     gen_mask_4, gen_offset_4, z = pcr_level(gen, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])

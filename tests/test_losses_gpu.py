@@ -99,3 +99,63 @@ def test_pcr_level_heads_match_conv_plus_dense_loss(b, c, co, d, h, w, m):
     for a, ref in zip(gr, gr_r):
         err = float((a.double().cpu() - ref).abs().max() / ref.abs().max())
         assert err <= 3e-5, err
+
+
+@pytest.mark.parametrize("b,c,co,d,h,w,m", [(2, 32, 16, 6, 20, 24, 300), (2, 3, 0, 6, 20, 24, 300), (1, 32, 0, 4, 10, 12, 50),
+                                              (3, 32, 16, 10, 94, 94, 20000), (2, 3, 0, 20, 188, 188, 30000)])
+def test_pcr_level_with_folded_batchnorm_matches_unfused(b, c, co, d, h, w, m):
+    """heads.pcr_level_norm (BatchNorm3d + ReLU + heads + losses + next conv from the RAW up-sampler output) == BatchNorm3d (train) ->
+    ReLU -> 1x1x1 convs -> mask_offset_loss on the dense target in float64 on the host: losses, z, d/dy, every parameter gradient
+    (batch norm included) and the running statistics"""
+    import copy
+    from torch import nn
+    from sparse2dense_amd.dense3d import FastBatchNorm3d
+    coors, feats, _, _ = _case(b, d, h, w, m, seed=b * 13 + m + c)
+    gen = torch.Generator().manual_seed(9 + c + m)
+    y0 = torch.randn(b, c, d, h, w, generator=gen) * 1.5 + 0.2
+    bn = FastBatchNorm3d(c, fused_relu=True)
+    mask_conv, off_conv = nn.Conv3d(c, 1, 1), nn.Conv3d(c, 3, 1)
+    nxt = nn.Conv3d(c, co, 1) if co else None
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=gen) + 0.5); bn.bias.copy_(torch.randn(c, generator=gen) * 0.3)
+        for mod in (mask_conv, off_conv, nxt):
+            if mod is not None:
+                mod.weight.copy_(torch.randn(mod.weight.shape, generator=gen) * 0.3)
+                mod.bias.copy_(torch.randn(mod.bias.shape, generator=gen) * 0.3)
+    r = torch.randn(b, co, d, h, w, generator=gen) / (b * d * h * w) if co else None
+
+    def run(dev, dtype, fused):
+        mods = [None if mm is None else copy.deepcopy(mm).to(dev, dtype) for mm in (bn, mask_conv, off_conv, nxt)]
+        mods[0].train()
+        y = y0.to(dev, dtype).requires_grad_(True)
+        if fused:
+            ml, ol, z = heads.pcr_level_norm(y, mods[0], mods[1], mods[2], coors.to(dev), feats.to(dev), next_conv=mods[3])
+        else:
+            g = torch.relu(nn.functional.batch_norm(y, mods[0].running_mean, mods[0].running_var, mods[0].weight, mods[0].bias, True,
+                                                    mods[0].momentum, mods[0].eps))
+            gt = torch.zeros(b, d, h, w, 5, dtype=dtype)
+            cc = coors.long()
+            gt[cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3]] = feats.to(dtype)
+            gt = gt.permute(0, 4, 1, 2, 3).contiguous()
+            grid = heads.metric_grid(b, d, h, w, torch.zeros(1)).to(dtype)
+            ml, ol = heads.mask_offset_loss(mods[2](g), mods[1](g), gt, grid)
+            z = mods[3](g) if co else None
+        total = 1.7 * ml + 0.6 * ol
+        if co:
+            total = total + (z * r.to(dev, dtype)).sum()
+        total.backward()
+        grads = [y.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+        return ml, ol, z, grads, mods[0]
+
+    ml_r, ol_r, z_r, gr_r, bn_r = run("cpu", torch.float64, False)
+    ml, ol, z, gr, bn_h = run("cuda", torch.float32, True)
+    np.testing.assert_allclose(ml.item(), ml_r.item(), rtol=3e-5)
+    np.testing.assert_allclose(ol.item(), ol_r.item(), rtol=3e-5)
+    if co:
+        assert (z.double().cpu() - z_r).abs().max() <= 2e-5 * z_r.abs().max()
+    names = ["dy", "dgamma", "dbeta", "dw_mask", "db_mask", "dw_off", "db_off", "dw2", "db2"]
+    for name, a, ref in zip(names, gr, gr_r):
+        err = float((a.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-4, (name, err)
+    assert (bn_h.running_mean.double().cpu() - bn_r.running_mean).abs().max() <= 1e-5
+    assert (bn_h.running_var.double().cpu() - bn_r.running_var).abs().max() <= 1e-4 * bn_r.running_var.abs().max()
