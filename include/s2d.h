@@ -384,6 +384,21 @@ int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zer
                                   size_t ws_bytes, s2d_stream_t stream);
 
 /*
+ * 1x1 convolutions (stride 1) of the S2D module (det3d/models/necks/rpn.py:186-253: fusion_sparse / fusion_dense, out_conv, the ConvNeXt
+ * point-wise pairs) on NHWC bf16: GEMMs over the pixel rows on the same tile pipeline, weight image and epilogue (bias, per-tile
+ * batch-norm statistics [tiles][2][cout], tiles = s2d_conv2d1x1_stats_tiles) as the 3x3 kernels.  pack: weight = torch
+ * [Cout][Cin][1][1] of the forward conv, (cin, cout) = dimensions of the packed operand, transpose = 1 for the data gradient (run the
+ * forward entry on dY).  Channels: multiples of 64.
+ */
+int s2d_conv2d1x1_pack_weights_bf16(const float *weight, int cin, int cout, int transpose, void *packed, s2d_stream_t stream);
+int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w);
+int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img,
+                            int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);
+size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout);
+int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin,
+                                  int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/*
  * Depth-wise 7x7 convolution, padding 3, stride 1 (nn.Conv2d(C, C, 7, padding=3, groups=C): first layer of the three
  * ConvNeXt blocks of the S2D module, det3d/models/necks/rpn.py:204-225) on NHWC bf16 maps.  x, y [n][h][w][c] bf16;
  * weight fp32 [c][49] (the torch layout [c][1][7][7]); bias fp32 [c] or NULL; fp32 accumulation.  flip=1 mirrors the taps:

@@ -108,6 +108,13 @@ SIGNATURES = {
                              [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_nhwc_bf16_to_nchw_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_nchw_f32_to_nhwc_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_conv2d1x1_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_conv2d1x1_stats_tiles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "s2d_conv2d1x1_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 5 +
+                                [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
+    "s2d_conv2d1x1_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "s2d_conv2d1x1_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 +
+                                      [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_lnwide_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_lnwide_fwd_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, c_f32p,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

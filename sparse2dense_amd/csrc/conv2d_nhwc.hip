@@ -26,9 +26,9 @@ typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 // source w[Cout][Cin][3][3] (torch layout).  transpose_flip=1 builds the data-gradient operand:
 //   packed "cin" runs over the source's Cout, packed "cout" over its Cin, taps mirrored.
 __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int bn,
-                                                          int transpose_flip, int w_nhwc, __bf16 *__restrict__ out) {
+                                                          int transpose_flip, int w_nhwc, int taps, __bf16 *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)9 * cin * cout;
+    const int64_t total = (int64_t)taps * cin * cout;
     if (i >= total) return;
     const int ntile = bn / 16, per_wave = bn / 32;
     int64_t r = i;
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
     const int ci = chunk * 64 + h * 32 + 8 * q + e;
     const int co = blk * bn + (nt / per_wave) * (bn / 2) + c * per_wave + (nt % per_wave);
     // source element (o, c, t) of the forward weight; w_nhwc: memory order [o][t][c] (torch channels_last) instead of [o][c][t]
-    const int so = transpose_flip ? ci : co, sc = transpose_flip ? co : ci, st = transpose_flip ? 8 - tap : tap;
+    const int so = transpose_flip ? ci : co, sc = transpose_flip ? co : ci, st = transpose_flip ? taps - 1 - tap : tap;
     const int src_c = transpose_flip ? cout : cin;
-    const float v = w_nhwc ? w[((int64_t)so * 9 + st) * src_c + sc] : w[((int64_t)so * src_c + sc) * 9 + st];
+    const float v = w_nhwc ? w[((int64_t)so * taps + st) * src_c + sc] : w[((int64_t)so * src_c + sc) * taps + st];
     out[i] = (__bf16)v;
 }
 
@@ -126,7 +126,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // K-steps of LDS-DMA stay in flight across the barrier.  Measured (r01, MI355X, 128->128 @ 4x188x188): NS=2 563 TFLOP/s,
 // NS=3 360, NS=4 365 — the deeper rings cost the second resident workgroup per CU (96 / 128 KiB of LDS), and the four
 // extra waves hide more latency than the extra K-steps in flight; the host launches NS=2 unless S2D_CONV_NS says otherwise.
-template <int BN, int NS>
+// KS = kernel size (3, or 1: the 1x1 convs of the S2D module run the same tile pipeline with cin/64 K-steps per tile)
+template <int BN, int NS, int KS = 3>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                 const float *__restrict__ bias,
                                                                 const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
     auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_BYTES) + A_BYTES; };
     constexpr int LPS = 4 + (B_BYTES / 1024) / 4;   // global_load_lds instructions per wave and K-step (A: 4, B: 4 or 2)
 
-    const int Ho = (H + 2 * pad - 3) / stride + 1, Wo = (W + 2 * pad - 3) / stride + 1;
+    const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
     const int64_t m_total = (int64_t)n_img * Ho * Wo;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
     if (m0 >= m_total) return;
     const int blk_n = blockIdx.y;
     const int chunks = cin / 64;
-    const int ksteps = 9 * chunks;
+    const int ksteps = KS * KS * chunks;
 
     // A staging: thread t moves 16-byte chunks t, t+256, t+512, t+768 of the [128][64ch] tile: pixel = id/8, part = id%8
     int a_img[4], a_y[4], a_x[4];
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 
     auto stage = [&](int s, int buf) {
         const int tap = s / chunks, chunk = s - tap * chunks;
-        const int dy = tap / 3 - pad, dx = tap % 3 - pad;
+        const int dy = tap / KS - pad, dx = tap % KS - pad;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int id = threadIdx.x + 256 * u;
@@ -586,7 +587,7 @@ extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int
     }
     const int64_t total = (int64_t)9 * cin * cout;
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin,
-                       cout, conv_bn(cout), transpose_flip, weight_nhwc, (__bf16 *)packed);
+                       cout, conv_bn(cout), transpose_flip, weight_nhwc, 9, (__bf16 *)packed);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -728,6 +729,57 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
         if (ns == 4) S2D_CONV_LAUNCH(64, 4); else if (ns == 3) S2D_CONV_LAUNCH(64, 3); else S2D_CONV_LAUNCH(64, 2);
     }
 #undef S2D_CONV_LAUNCH
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+
+// ---- 1x1 convolution (stride 1) on the same tile pipeline ------------------------------------------------------------
+// The S2D module's 1x1 convs (/root/reference/det3d/models/necks/rpn.py:186-253: fusion_sparse / fusion_dense 256->256, out_conv
+// 256->640 at 188 x 188, the ConvNeXt point-wise pairs 256<->1024 at 47 x 47) are GEMMs [N*H*W, Cin] x [Cin, Cout] on NHWC rows: the
+// 64-deep double-buffered kernel with KS = 1 (cin/64 K-steps per 128-pixel tile), same packed-weight image, same epilogue incl.
+// the per-tile batch-norm statistics.  The data gradient is the same entry on dY with the transposed image.
+extern "C" int s2d_conv2d1x1_pack_weights_bf16(const float *weight, int cin, int cout, int transpose, void *packed, s2d_stream_t stream) {
+    // (cin, cout) = dimensions of the PACKED operand; weight is torch [Cout][Cin][1][1] of the forward conv (any memory format)
+    S2D_CHECK_ARG(weight && packed, "conv2d1x1_pack: null argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d1x1_pack: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
+                       conv_bn(cout), transpose, 0, 1, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w) { return ceil_div((int64_t)n_img * h * w, 128); }
+
+extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
+                                       int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0, "conv2d1x1: bad argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d1x1: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t m = (int64_t)n_img * h * w;
+    const int bn = conv_bn(cout);
+    const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
+    const size_t lds = (size_t)2 * (128 * 64 * 2 + 64 * bn * 2);
+    hipStream_t st = (hipStream_t)stream;
+#define S2D_CONV1_LAUNCH(BN_)                                                                                             \
+    do {                                                                                                                  \
+        auto kern = conv3x3_nhwc_bf16_kernel<BN_, 2, 1>;                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,              \
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, 0, 1, (__bf16 *)y, stats_partial);          \
+    } while (0)
+    if (bn == 128) S2D_CONV1_LAUNCH(128); else S2D_CONV1_LAUNCH(64);
+#undef S2D_CONV1_LAUNCH
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

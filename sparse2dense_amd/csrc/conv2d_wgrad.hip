@@ -75,7 +75,8 @@ __device__ __forceinline__ bf16x8w tr_pack(const i32x2w &lo, const i32x2w &hi) {
     return __builtin_bit_cast(bf16x8w, v);
 }
 
-template <int TCO, int TCI>
+// KS = kernel size: 3, or 1 (the 1x1 convs: one "kernel row", one kx tap, the same transposed-operand pipeline)
+template <int TCO, int TCI, int KS = 3>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                             const __bf16 *__restrict__ zero_page, int n_img, int H, int W, int cin,
                                                             int cout, int pad, int steps_per_block, float *__restrict__ partial) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wco = wid / C::WCI, wci = wid % C::WCI;
     const int g = lane >> 4, c16 = lane & 15;
-    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    const int Ho = H + 2 * pad - (KS - 1), Wo = W + 2 * pad - (KS - 1);
     const int XC = (Wo + 31) / 32;
     const int total = n_img * Ho * XC;
     const int ky = blockIdx.y;
@@ -97,13 +98,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     const int s0 = blockIdx.x * steps_per_block;
     const int s1 = min(total, s0 + steps_per_block);
 
-    f32x4w acc[C::MI][C::NJ][3];
+    f32x4w acc[C::MI][C::NJ][KS];
 #pragma unroll
     for (int i = 0; i < C::MI; ++i)
 #pragma unroll
         for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc[i][j][k] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < KS; ++k) acc[i][j][k] = f32x4w{0.f, 0.f, 0.f, 0.f};
 
     // (n, y, xc) of step s, advanced incrementally
     int sn = s0 / (Ho * XC), sy = (s0 / XC) % Ho, sxc = s0 % XC;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         } else {
             const int q = c - C::A_CHUNKS;
             const int row = q / C::CPR_B, col = q % C::CPR_B;
-            row_u[u] = (col < TCI / 8 && row < 34) ? row : 0x40000000;
+            row_u[u] = (col < TCI / 8 && row < 32 + KS - 1) ? row : 0x40000000;
             ptr_u[u] = x + (int64_t)row * cin + cit * TCI + col * 8;
         }
     }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     //   issue the reads of step i+1;  MFMAs of step i.
     // A kernel row outside the image stages zero tiles (lim_b = 0), so no step is skipped.
     struct Frags {
-        i32x2w alo[C::MI], ahi[C::MI], blo[3][C::NJ], bhi[3][C::NJ];
+        i32x2w alo[C::MI], ahi[C::MI], blo[KS][C::NJ], bhi[KS][C::NJ];
     };
     const unsigned a_off = tr_row * C::RS_A + wco * C::MI * 32 + tr_col;
     const unsigned b_off = C::A_BYTES + tr_row * C::RS_B + wci * C::NJ * 32 + tr_col;
@@ -184,13 +185,13 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) tr_issue<16 * C::RS_A>(f.alo[i], f.ahi[i], base + a_off + i * 32);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
             for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(f.blo[kx][j], f.bhi[kx][j], base + b_off + j * 32 + kx * C::RS_B);
     };
     auto mfmas = [&](const Frags &f) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
             for (int j = 0; j < C::NJ; ++j) {
                 const bf16x8w xf = tr_pack(f.blo[kx][j], f.bhi[kx][j]);
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     static_assert(8 * EP_BYTES <= (int)C::LDS, "epilogue tiles exceed the ring");
     __syncthreads();   // every wave is out of the K loop
     char *ep = smem + wid * EP_BYTES;
-    float *dst = partial + ((int64_t)blockIdx.x * 9 + ky * 3) * (int64_t)cout * cin;
+    float *dst = partial + ((int64_t)blockIdx.x * (KS * KS) + ky * KS) * (int64_t)cout * cin;
     const int co0 = cot * TCO + wco * C::MI * 16, ci0 = cit * TCI + wci * C::NJ * 16;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -272,11 +273,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
 // A workgroup owns 64 float4 columns of the [tap][co][ci] plane; 4 thread rows stride over the splits (more loads in
 // flight than one thread per element walking all splits), fixed-order fold through LDS.  cin % 4 == 0.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float4 *__restrict__ partial, int splits, int cin, int cout,
-                                                                   float *__restrict__ dw) {
+                                                                   int taps, float *__restrict__ dw) {
     __shared__ float4 red[4][64];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int64_t plane = (int64_t)cout * cin;          // floats per tap
-    const int64_t size4 = 9 * plane / 4;
+    const int64_t size4 = taps * plane / 4;
     const int64_t i4 = (int64_t)blockIdx.x * 64 + col;  // float4 index over [tap][co][ci]
     float4 s = float4{0.f, 0.f, 0.f, 0.f};
     if (i4 < size4) {
@@ -297,10 +298,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float4 
         const int64_t i = i4 * 4;
         const int tap = (int)(i / plane);
         const int64_t r = i - tap * plane;               // co * cin + ci, 4 consecutive ci
-        dw[r * 9 + tap] = t.x;
-        dw[(r + 1) * 9 + tap] = t.y;
-        dw[(r + 2) * 9 + tap] = t.z;
-        dw[(r + 3) * 9 + tap] = t.w;
+        dw[r * taps + tap] = t.x;
+        dw[(r + 1) * taps + tap] = t.y;
+        dw[(r + 2) * taps + tap] = t.z;
+        dw[(r + 3) * taps + tap] = t.w;
     }
 }
 
@@ -309,11 +310,11 @@ struct WgPlan {
     size_t ws_bytes;
 };
 static bool wg_supported(int cin, int cout) { return cin % 64 == 0 && cout % 64 == 0 && cin >= 64 && cout >= 64; }
-static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad) {
+static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int ks = 3) {
     WgPlan p;
     p.tco = cout % 128 == 0 ? 128 : 64;
     p.tci = cin % 128 == 0 ? 128 : 64;
-    const int ho = h + 2 * pad - 2, wo = w + 2 * pad - 2;
+    const int ho = h + 2 * pad - (ks - 1), wo = w + 2 * pad - (ks - 1);
     const int64_t total = (int64_t)n_img * ho * ((wo + 31) / 32);
     const int tiles = (cout / p.tco) * (cin / p.tci);
     // one 8-wave workgroup per CU (203 VGPRs: a second one does not fit), and never more workgroups than CUs: 258
@@ -325,26 +326,26 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad) {
             n = 256;
         cus = n;
     }
-    int64_t splits = cus / (3 * tiles);
+    int64_t splits = cus / (ks * tiles);
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.steps_per_block = (int)ceil_div(total, splits);
     p.splits = (int)ceil_div(total, p.steps_per_block);
-    p.ws_bytes = (size_t)p.splits * 9 * cout * cin * sizeof(float);
+    p.ws_bytes = (size_t)p.splits * ks * ks * cout * cin * sizeof(float);
     return p;
 }
 
-template <int TCO, int TCI>
+template <int TCO, int TCI, int KS = 3>
 static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
                      int cout, int pad, float *partial, hipStream_t st) {
     typedef WgCfg<TCO, TCI> C;
-    auto kern = conv3x3_wgrad_kernel<TCO, TCI>;
+    auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS>;
     static bool attr_set = false;   // once per instantiation (idempotent if raced)
     if (C::LDS > 48 * 1024 && !attr_set) {
         S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr_set = true;
     }
-    const dim3 grid(p.splits, 3, (cout / TCO) * (cin / TCI));
+    const dim3 grid(p.splits, KS, (cout / TCO) * (cin / TCI));
     hipLaunchKernelGGL(kern, grid, dim3(512), C::LDS, st, x, dy, zero_page, n_img, h, w, cin, cout, pad, p.steps_per_block, partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -385,7 +386,41 @@ extern "C" int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, cons
     if (rc) return rc;
     const int64_t total = (int64_t)9 * cin * cout;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
-                       p.splits, cin, cout, dweight);
+                       p.splits, cin, cout, 9, dweight);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* 1x1 convolution (stride 1): dW[co][ci] = sum over pixels of dY[m][co] * X[m][ci], same kernel with one tap */
+extern "C" size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout) {
+    if (!wg_supported(cin, cout) || n_img <= 0 || h <= 0 || w <= 0) return 0;
+    return wg_plan(n_img, h, w, cin, cout, 0, 1).ws_bytes;
+}
+
+extern "C" int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin, int cout,
+                                             float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && dy && zero_page && dweight && n_img > 0 && h > 0 && w > 0, "conv2d1x1_wgrad: bad argument");
+    if (!wg_supported(cin, cout)) {
+        set_error("conv2d1x1_wgrad: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const WgPlan p = wg_plan(n_img, h, w, cin, cout, 0, 1);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("conv2d1x1_wgrad: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *xp = (const __bf16 *)x, *dp = (const __bf16 *)dy, *zp = (const __bf16 *)zero_page;
+    float *partial = (float *)ws;
+    int rc;
+    if (p.tco == 128 && p.tci == 128) rc = wg_launch<128, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
+    else if (p.tco == 64 && p.tci == 128) rc = wg_launch<64, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
+    else if (p.tco == 128 && p.tci == 64) rc = wg_launch<128, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
+    else rc = wg_launch<64, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
+    if (rc) return rc;
+    const int64_t total = (int64_t)cin * cout;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
+                       p.splits, cin, cout, 1, dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -232,6 +232,96 @@ class Conv3x3(nn.Conv2d):
 
 
 # --------------------------------------------------------------------------------------------------
+# 1x1 convolutions of the S2D module (csrc/conv2d_nhwc.hip / conv2d_wgrad.hip with one tap)
+# --------------------------------------------------------------------------------------------------
+def _pack_weights_1x1(weight, transpose):
+    def build():
+        lib = _lib.load()
+        cout, cin = weight.shape[0], weight.shape[1]
+        w = weight.detach().float().reshape(cout, cin).contiguous()
+        packed = torch.empty(cin * cout, dtype=torch.bfloat16, device=weight.device)
+        pc_in, pc_out = (cout, cin) if transpose else (cin, cout)
+        check(lib.s2d_conv2d1x1_pack_weights_bf16(_ptr(w), pc_in, pc_out, int(transpose), _ptr(packed), _stream()),
+              "s2d_conv2d1x1_pack_weights_bf16")
+        return packed
+    return cached_pack(weight, ("conv1x1", bool(transpose)), build)
+
+
+def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
+    """x: bf16 [N,cin,H,W] channels_last -> bf16 [N,cout,H,W] channels_last (+ the per-tile batch-norm statistics slabs)"""
+    lib = _lib.load()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
+    n, _, h, w = x.shape
+    y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    partial = torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w), 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
+    check(lib.s2d_conv2d1x1_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y),
+                                      _ptr(partial), _stream()), "s2d_conv2d1x1_nhwc_bf16")
+    return (y, partial) if bn_stats else y
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_stats):
+        xb = _nhwc_bf16(x)
+        cout, cin = weight.shape[0], weight.shape[1]
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        b = None if bias is None else bias.detach().float().contiguous()
+        if bn_stats:
+            y, partial = conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout, bn_stats=True)
+            ctx.mark_non_differentiable(partial)
+            return y, partial
+        return conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout)
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        lib = _lib.load()
+        xb, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        dyb = _nhwc_bf16(dy)
+        n, _, h, w = xb.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin)
+        if ctx.needs_input_grad[1]:
+            dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
+            ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
+            check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(ws),
+                                                    ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
+            dw = dwf.reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:   # per-channel sum of dY: the row-reduce kernel's first output half
+            rows = n * h * w
+            stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
+            ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)
+            check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
+            db = stats[:cout]
+        return dx, dw, db, None
+
+
+class Conv1x1(nn.Conv2d):
+    """nn.Conv2d with a 1x1 kernel, stride 1, no padding (same parameters / state_dict keys).  CUDA inputs under bf16 autocast with
+    channel counts that are multiples of 64 run the NHWC tile kernels (forward, data and weight gradient); anything else is the
+    stock layer."""
+
+    emit_bn_stats = False   # set by fuse_bn_relu() when a FastBatchNorm2d follows
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0)
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            if self.emit_bn_stats and self.training and torch.is_grad_enabled():
+                y, partial = _Conv1x1Fn.apply(x, self.weight, self.bias, True)
+                y._s2d_bn_partial = partial   # read (forward pass only) by the FastBatchNorm2d that follows
+                return y
+            return _Conv1x1Fn.apply(x, self.weight, self.bias, False)
+        return super().forward(x)
+
+
+# --------------------------------------------------------------------------------------------------
 # depth-wise 7x7 convolution of the S2D ConvNeXt blocks (csrc/dwconv.hip)
 # --------------------------------------------------------------------------------------------------
 class _DwConv7Fn(torch.autograd.Function):
@@ -478,7 +568,7 @@ def fuse_bn_relu(layers):
         if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.GELU) and layers[i + 1].approximate == "none":
             layers[i].fused_relu = 2   # activation code 2: exact GELU behind the normalisation (csrc/features.hip)
             layers[i + 1] = nn.Identity()
-        if isinstance(layers[i], Conv3x3) and isinstance(layers[i + 1], FastBatchNorm2d):
+        if isinstance(layers[i], (Conv3x3, Conv1x1)) and isinstance(layers[i + 1], FastBatchNorm2d):
             layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials
         if type(layers[i]) is nn.ZeroPad2d and tuple(layers[i].padding) == (1, 1, 1, 1) and isinstance(layers[i + 1], Conv3x3) \
                 and layers[i + 1].padding == (0, 0) and layers[i + 1].kernel_size == (3, 3):

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .heads import pcr_level, pcr_level_norm, pcr_level_supported
 from .registry import NECKS
@@ -151,7 +151,7 @@ def _cbg(*convs_and_channels):
 
 def _convnext(c, hw):
     return nn.Sequential(DepthwiseConv7(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
-                         nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
+                         Conv1x1(c, 4 * c, 1), nn.GELU(), Conv1x1(4 * c, c, 1))
 
 
 @NECKS.register_module
@@ -169,9 +169,9 @@ class S2D_RPN(RPN):
         self.convnext_block_3 = _convnext(256, 47)
         self.decoder_1 = _cbg((nn.ConvTranspose2d(256, 256, 4, 2, 1), 256))
         self.decoder_2 = _cbg((Conv3x3(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
-        self.fusion_sparse = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
-        self.fusion_dense = _cbg((nn.Conv2d(c, c, 1, 1, 0), c))
-        self.out_conv = _cbg((nn.Conv2d(c, 640, 1, 1, 0), 640))
+        self.fusion_sparse = _cbg((Conv1x1(c, c, 1, 1, 0), c))
+        self.fusion_dense = _cbg((Conv1x1(c, c, 1, 1, 0), c))
+        self.out_conv = _cbg((Conv1x1(c, 640, 1, 1, 0), 640))
         # ---- PCR point-cloud-reconstruction head (rpn.py:263-296) ----
         # (nn.Conv3d / nn.ConvTranspose3d subclasses: same parameters, HIP streaming kernels on CUDA fp32)
         # BN+ReLU pairs are fused in FastBatchNorm3d; an nn.Identity keeps the reference's Sequential indices

@@ -402,3 +402,46 @@ def test_planar_handover_transposes_bit_exact(n, c, h, w):
     y.backward(g)
     assert x.grad.dtype == torch.bfloat16 and x.grad.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(x.grad.float(), g.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 256, 1024, 47, 47), (2, 1024, 256, 20, 12), (2, 256, 640, 33, 20), (1, 64, 64, 5, 7),
+                                            (4, 256, 256, 94, 94), (1, 128, 192, 9, 130)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv1x1_forward_backward_vs_cpu_float64(n, cin, cout, h, w, bias):
+    """Conv1x1 (the 3x3 tile kernels with one tap) vs torch conv2d in float64 on the HOST over the same bf16-rounded operands.
+    bf16 outputs (y, dx): one rounding = 6e-3 of max; fp32 outputs (dW, db): 2e-3 of max; epilogue statistics == sums of the
+    stored outputs."""
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(n + cin + cout)
+    m = D.Conv1x1(cin, cout, 1, 1, 0, bias=bias).cuda()
+    rb = lambda t: t.to(torch.bfloat16).float()
+    with torch.no_grad():
+        m.weight.copy_(rb(m.weight))
+    x = rb(torch.randn(n, cin, h, w, device="cuda"))
+    dy = rb(torch.randn(n, cout, h, w, device="cuda"))
+    xa = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = m(xa)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy.to(torch.bfloat16))
+    ref = torch.nn.Conv2d(cin, cout, 1, bias=bias).double()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    xr = x.double().cpu().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double().cpu())
+    checks = [("y", ya, yr, 6e-3), ("dx", xa.grad, xr.grad, 6e-3), ("dw", m.weight.grad, ref.weight.grad, 2e-3)]
+    if bias:
+        checks.append(("db", m.bias.grad, ref.bias.grad, 2e-3))
+    for name, a, r, tol in checks:
+        err = float((a.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        assert err <= tol, (name, err)
+    # batch-norm statistics from the epilogue
+    m.emit_bn_stats = True
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y2 = m(x.contiguous(memory_format=torch.channels_last).requires_grad_(True))
+    part = y2._s2d_bn_partial
+    yf = y2.detach().float()
+    s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
+    assert (part[:, 0].sum(0) - s1).abs().max() <= 1e-3 * s1.abs().max() + 1e-2
+    assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
