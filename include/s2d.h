@@ -488,6 +488,17 @@ int s2d_lnwide_bwd_bf16(const void *dy, const void *x, const float *weight, cons
                         s2d_stream_t stream);
 
 /*
+ * Feature-distillation loss of the S2D step (det3d/torchie/trainer/trainer.py:783-789): w_pos * MSE over teacher > 0 + w_neg * MSE
+ * over the rest, between two dense tensors of n elements (n % 8 == 0) in the SAME memory order, bf16 (flag 1) or fp32 (0) each.
+ * out4 (device) = loss, 2*w_pos/n_pos, 2*w_neg/n_neg, n_pos.  bwd: dstudent (student's element type) = go * dloss/dstudent.
+ */
+size_t s2d_masked_mse_workspace_bytes(void);
+int s2d_masked_mse_fwd(const void *student, int student_bf16, const void *teacher, int teacher_bf16, int64_t n, float w_pos,
+                       float w_neg, float *out4, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_masked_mse_bwd(const void *student, int student_bf16, const void *teacher, int teacher_bf16, int64_t n,
+                       const float *fwd_out4, const float *go, void *dstudent, s2d_stream_t stream);
+
+/*
  * Fused PCR level heads + losses: gen_mask_k / gen_out_k (1x1x1 Conv3d C->1 / C->3, det3d/models/necks/rpn.py:273-275,292-294)
  * and mask_offset_loss (voxelnet.py:171-185) evaluated straight from the level's feature volume g[B][C][D*H*W] - the occupancy
  * logits, the offset volume and its zero-filled gradient are never written; the offset conv runs at the m recon voxels only.

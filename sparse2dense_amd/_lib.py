@@ -120,6 +120,11 @@ SIGNATURES = {
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_lnwide_bwd_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, c_f32p,
                                            c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_masked_mse_workspace_bytes": (ctypes.c_size_t, []),
+    "s2d_masked_mse_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                          c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_masked_mse_bwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, c_f32p, c_f32p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_pcr_heads_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "s2d_pcr_heads_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_pcr_heads_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +

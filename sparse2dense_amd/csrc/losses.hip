@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 dm[k] = scale * sigmoidf(x[k]);
-                if (!APPLY) pw[C] += dm[k];
+                if constexpr (!APPLY) pw[C] += dm[k];
             }
             asm volatile("" ::: "memory");   // re-read the per-channel constants below instead of keeping 3C of them live across both loops
 #pragma unroll
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
                         for (int k = 0; k < V; ++k) o[k] = fmaf(wq, zv[q][k], o[k]);
                     }
                 }
-                if (APPLY) {
+                if constexpr (APPLY) {
                     const float a = abv[c], bb = abv[C + c], dd = abv[2 * C + c];
                     float r[V];
 #pragma unroll
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t
             const float dlt = off[k] - t;
             dk[k] = (t != 0.f) ? (dlt > 0.f ? so : (dlt < 0.f ? -so : 0.f)) : 0.f;
         }
-        if (APPLY) {
+        if constexpr (APPLY) {
             float *ob = dy + (int64_t)c.x * C * cells + cell;
 #pragma unroll
             for (int q = 0; q < C; ++q) {
@@ -1147,4 +1147,145 @@ extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale
     if (c == 32)
         return pcr_level_bwd_apply_t<32, 0, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
     return pcr_level_bwd_apply_t<3, 0, 4>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
+}
+
+// =====================================================================================================================
+// Feature-distillation loss of the S2D step (/root/reference/det3d/torchie/trainer/trainer.py:783-789):
+//   w_pos * MSE(student[teacher > 0], teacher[teacher > 0]) + w_neg * MSE(student[teacher <= 0], teacher[teacher <= 0])
+// over [B,256,188,188] feature maps (36 MB in bf16): ONE pass for the three sums (pos squared error, all squared error, pos count),
+// one for the gradient.  The torch formulation (mask, difference, square, two masked sums, their backward) made ~10 passes.
+// Elementwise over the flat memory of two dense tensors with IDENTICAL strides (the caller checks); bf16 or fp32 elements.
+// =====================================================================================================================
+namespace s2d {
+
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[8]) {
+        const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[8]) {
+        reinterpret_cast<float4 *>(p)[0] = float4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<float4 *>(p)[1] = float4{v[4], v[5], v[6], v[7]};
+    }
+};
+typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
+template <> struct Vec8<__bf16> {
+    static __device__ __forceinline__ void load(const __bf16 *p, float (&v)[8]) {
+        const bf16x8m a = *reinterpret_cast<const bf16x8m *>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+    static __device__ __forceinline__ void store(__bf16 *p, const float (&v)[8]) {
+        bf16x8m a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x8m *>(p) = a;
+    }
+};
+
+constexpr int MSE_BLOCKS = 1024;
+
+// partial[block][3] = (sum_{t>0} (s-t)^2, sum (s-t)^2, count t>0)
+template <typename TS, typename TT>
+__global__ __launch_bounds__(256) void masked_mse_fwd_kernel(const TS *__restrict__ s, const TT *__restrict__ t, int64_t n8, float *__restrict__ partial) {
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float sv[8], tv[8];
+        Vec8<TS>::load(s + i * 8, sv);
+        Vec8<TT>::load(t + i * 8, tv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = sv[e] - tv[e], d2 = d * d;
+            const bool pos = tv[e] > 0.f;
+            acc[0] += pos ? d2 : 0.f;
+            acc[1] += d2;
+            acc[2] += pos ? 1.f : 0.f;
+        }
+    }
+    block_sums<3>(acc, partial);
+}
+
+// out[0] = loss, out[1] = 2*w_pos/n_pos, out[2] = 2*w_neg/n_neg (the gradient scales), out[3] = n_pos
+__global__ __launch_bounds__(64) void masked_mse_finalize_kernel(const float *__restrict__ partial, int nb, double n, float w_pos, float w_neg,
+                                                                 float *__restrict__ out) {
+    double v[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < nb; i += 64)
+        for (int k = 0; k < 3; ++k) v[k] += partial[i * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    if (threadIdx.x != 0) return;
+    const double n_pos = v[2], n_neg = n - n_pos;
+    out[0] = (float)((double)w_pos * v[0] / n_pos + (double)w_neg * (v[1] - v[0]) / n_neg);   // an empty class gives nan, as torch's mean of nothing
+    out[1] = (float)(2.0 * w_pos / n_pos);
+    out[2] = (float)(2.0 * w_neg / n_neg);
+    out[3] = (float)n_pos;
+}
+
+template <typename TS, typename TT>
+__global__ __launch_bounds__(256) void masked_mse_bwd_kernel(const TS *__restrict__ s, const TT *__restrict__ t, const float *__restrict__ fin,
+                                                             const float *__restrict__ go, int64_t n8, TS *__restrict__ ds) {
+    const float gp = go[0] * fin[1], gn = go[0] * fin[2];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float sv[8], tv[8], o[8];
+        Vec8<TS>::load(s + i * 8, sv);
+        Vec8<TT>::load(t + i * 8, tv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (sv[e] - tv[e]) * (tv[e] > 0.f ? gp : gn);
+        Vec8<TS>::store(ds + i * 8, o);
+    }
+}
+
+}  // namespace s2d
+
+extern "C" size_t s2d_masked_mse_workspace_bytes(void) { return (size_t)MSE_BLOCKS * 3 * sizeof(float) + 256; }
+
+// student / teacher: dense tensors of n elements (n % 8 == 0) in the SAME memory order; *_bf16 = 1: bf16 elements, 0: fp32.
+// out4 (device): loss, gradient scales, positive count.
+extern "C" int s2d_masked_mse_fwd(const void *student, int student_bf16, const void *teacher, int teacher_bf16, int64_t n, float w_pos,
+                                  float w_neg, float *out4, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(student && teacher && out4 && n > 0, "masked_mse_fwd: bad argument");
+    if (n % 8) {
+        set_error("masked_mse_fwd: the element count must be a multiple of 8 (%lld)", (long long)n);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < s2d_masked_mse_workspace_bytes()) {
+        set_error("masked_mse_fwd: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n8 = n / 8;
+    const int nb = (int)std::min<int64_t>(MSE_BLOCKS, ceil_div(n8, 256));
+    float *partial = (float *)ws;
+#define S2D_MSE_FWD(TS, TT) \
+    hipLaunchKernelGGL((masked_mse_fwd_kernel<TS, TT>), dim3(nb), dim3(256), 0, st, (const TS *)student, (const TT *)teacher, n8, partial)
+    if (student_bf16 && teacher_bf16) S2D_MSE_FWD(__bf16, __bf16);
+    else if (student_bf16) S2D_MSE_FWD(__bf16, float);
+    else if (teacher_bf16) S2D_MSE_FWD(float, __bf16);
+    else S2D_MSE_FWD(float, float);
+#undef S2D_MSE_FWD
+    hipLaunchKernelGGL(masked_mse_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nb, (double)n, w_pos, w_neg, out4);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// dstudent (same element type and order as student) = go * d loss / d student
+extern "C" int s2d_masked_mse_bwd(const void *student, int student_bf16, const void *teacher, int teacher_bf16, int64_t n, const float *fwd_out4,
+                                  const float *go, void *dstudent, s2d_stream_t stream) {
+    S2D_CHECK_ARG(student && teacher && fwd_out4 && go && dstudent && n > 0 && n % 8 == 0, "masked_mse_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n8 = n / 8;
+    const int nb = (int)std::min<int64_t>(4096, ceil_div(n8, 256));
+#define S2D_MSE_BWD(TS, TT) \
+    hipLaunchKernelGGL((masked_mse_bwd_kernel<TS, TT>), dim3(nb), dim3(256), 0, st, (const TS *)student, (const TT *)teacher, fwd_out4, go, n8, \
+                       (TS *)dstudent)
+    if (student_bf16 && teacher_bf16) S2D_MSE_BWD(__bf16, __bf16);
+    else if (student_bf16) S2D_MSE_BWD(__bf16, float);
+    else if (teacher_bf16) S2D_MSE_BWD(float, __bf16);
+    else S2D_MSE_BWD(float, float);
+#undef S2D_MSE_BWD
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
 }

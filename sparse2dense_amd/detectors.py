@@ -86,9 +86,9 @@ class SingleStageDetector(nn.Module):
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
     def extract_feat(self, data):
-        # the BEV map goes straight to NHWC bf16 when nobody but the bf16 neck reads it
-        bev = bool(data.get("bev_private", False) and self.dense_channels_last and self.dense_dtype == torch.bfloat16
-                   and self.with_neck and data["features"].is_cuda)
+        # the BEV map goes straight to NHWC bf16 in the bf16 mode: the neck reads exactly that, and a caller that asked for the
+        # feature (the distillation teacher's F_D_a) gets it in the compute dtype / layout (sparse2dense_loss upcasts per element)
+        bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and self.with_neck and data["features"].is_cuda)
         x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"],
                                          bev_nhwc_bf16=bev)
         neck = self._dense(self.neck, x, keep_first=True) if self.with_neck else x
@@ -102,8 +102,9 @@ class VoxelNet(SingleStageDetector):
         x, _, F_D_a = self.extract_feat(data)
         F_D_b = None
         if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)
+            bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and data["features"].is_cuda)
             F_D_b, _ = self.backbone(self._read(example, "reconstruction_"), example["reconstruction_coordinates"],
-                                     batch_size, example["shape"][0])
+                                     batch_size, example["shape"][0], bev_nhwc_bf16=bev)
         preds = self._dense(self.bbox_head, x)
         if return_loss:
             losses = self.bbox_head.loss(example, preds)

@@ -68,9 +68,48 @@ def distill_reg_loss(output, target, mask, ind):
     return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
 
 
+class _MaskedMseFn(torch.autograd.Function):
+    """w_pos*MSE over teacher>0 + w_neg*MSE over the rest in one pass per direction (csrc/losses.hip)"""
+
+    @staticmethod
+    def forward(ctx, student, teacher, w_pos, w_neg):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        lib = _lib.load()
+        out = torch.empty(4, dtype=torch.float32, device=student.device)
+        ws = _ws(lib.s2d_masked_mse_workspace_bytes(), student.device)
+        _lib.check(lib.s2d_masked_mse_fwd(student.data_ptr(), int(student.dtype == torch.bfloat16), teacher.data_ptr(),
+                                          int(teacher.dtype == torch.bfloat16), student.numel(), float(w_pos), float(w_neg), _ptr(out), _ptr(ws),
+                                          ws.numel(), _stream()), "s2d_masked_mse_fwd")
+        ctx.save_for_backward(student, teacher, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        student, teacher, out = ctx.saved_tensors
+        ds = torch.empty_like(student)   # same strides
+        _lib.check(_lib.load().s2d_masked_mse_bwd(student.data_ptr(), int(student.dtype == torch.bfloat16), teacher.data_ptr(),
+                                                  int(teacher.dtype == torch.bfloat16), student.numel(), _ptr(out),
+                                                  _ptr(go.float().reshape(1).contiguous()), ds.data_ptr(), _stream()), "s2d_masked_mse_bwd")
+        return ds, None, None, None
+
+
+def _dense_same_layout(a, b):
+    ok = lambda t: t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    return a.shape == b.shape and a.stride() == b.stride() and ok(a) and ok(b)
+
+
 def masked_mse_pair(student, teacher, w_pos, w_neg):
-    """w_pos*MSE over teacher>0 + w_neg*MSE over the rest (trainer.py:783-789), without
-    materialising boolean-indexed copies: two masked sums and two counts."""
+    """w_pos*MSE over teacher>0 + w_neg*MSE over the rest (trainer.py:783-789).  CUDA bf16 / fp32 maps of identical layout take the
+    fused kernels; otherwise two masked sums and two counts (no boolean-indexed copies)."""
+    if (student.is_cuda and student.dtype in (torch.bfloat16, torch.float32) and teacher.dtype in (torch.bfloat16, torch.float32)
+            and student.numel() % 8 == 0 and student.shape == teacher.shape):
+        if not _dense_same_layout(student, teacher):   # bring the (gradient-free) teacher map into the student's memory order once
+            teacher = torch.empty_like(student, dtype=teacher.dtype).copy_(teacher.detach())
+        if _dense_same_layout(student, teacher):
+            return _MaskedMseFn.apply(student, teacher.detach(), w_pos, w_neg)
     student, teacher = student.float(), teacher.float()   # bf16 feature maps: differences and sums in fp32
     pos = teacher > 0
     d2 = (student - teacher) ** 2

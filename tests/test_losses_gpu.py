@@ -159,3 +159,27 @@ def test_pcr_level_with_folded_batchnorm_matches_unfused(b, c, co, d, h, w, m):
         assert err <= 2e-4, (name, err)
     assert (bn_h.running_mean.double().cpu() - bn_r.running_mean).abs().max() <= 1e-5
     assert (bn_h.running_var.double().cpu() - bn_r.running_var).abs().max() <= 1e-4 * bn_r.running_var.abs().max()
+
+
+@pytest.mark.parametrize("sdt,tdt,s_cl,t_cl", [(torch.bfloat16, torch.bfloat16, True, True), (torch.bfloat16, torch.float32, True, False),
+                                              (torch.float32, torch.float32, False, False), (torch.float32, torch.bfloat16, False, True)])
+@pytest.mark.parametrize("shape", [(4, 256, 47, 48), (2, 8, 5, 12)])
+def test_masked_mse_pair_fused_matches_float64(sdt, tdt, s_cl, t_cl, shape):
+    """heads.masked_mse_pair (trainer.py:783-789) through the fused kernels vs float64 on the host over the same stored values:
+    value 1e-5 relative; gradient one output rounding (6e-3 of max for a bf16 student, 1e-5 for fp32)."""
+    g = torch.Generator().manual_seed(3)
+    fmt = lambda cl: torch.channels_last if cl else torch.contiguous_format
+    s0 = torch.randn(shape, generator=g).to(sdt).contiguous(memory_format=fmt(s_cl))
+    t0 = torch.randn(shape, generator=g).relu().to(tdt).contiguous(memory_format=fmt(t_cl))   # ~half the teacher entries are 0
+    sr = s0.double().requires_grad_(True)
+    tr = t0.double()
+    pos = tr > 0
+    ref = 10.0 * ((sr - tr)[pos] ** 2).mean() + 20.0 * ((sr - tr)[~pos] ** 2).mean()
+    ref.backward()
+    sh = s0.cuda().requires_grad_(True)
+    out = heads.masked_mse_pair(sh, t0.cuda(), 10.0, 20.0)
+    (out * 1.0).backward()
+    np.testing.assert_allclose(out.item(), ref.item(), rtol=1e-5)
+    assert sh.grad.dtype == sdt and sh.grad.stride() == sh.stride()
+    err = float((sh.grad.double().cpu() - sr.grad).abs().max() / sr.grad.abs().max())
+    assert err <= (6e-3 if sdt == torch.bfloat16 else 1e-5), err
