@@ -853,7 +853,9 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
     const bool narrow = ct_wgrad_is_narrow(cout, w);
     if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(bx), dim3(256), 0, st, in, dout, s, rpb, partial);
-    // one tile of 16 input channels per block (two resident waves per SIMD; with both tiles the 128 accumulators leave room for one)
+    // both input-channel tiles in one block: dout is read once (measured 0.62 ms against 0.85 ms with one tile per block and two
+    // resident waves per SIMD, 32 -> 32 at [4,32,5,188,188])
+    else if (w % 4 == 0 && cit == 2) hipLaunchKernelGGL((ct_wgrad_rows_kernel<2>), dim3(bx, 4 * cot), dim3(256), 0, st, in, dout, s, rpb, cot, partial);
     else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1>), dim3(bx, 4 * cot * cit), dim3(256), 0, st, in, dout, s, rpb, cot, partial);
     else if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
     else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
