@@ -399,6 +399,15 @@ int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zer
                                   int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /*
+ * 2x2 stride-2 convolution forward (encoder_1[0] of the S2D module, rpn.py:188) on the same tile pipeline; weight = torch
+ * [Cout][Cin][2][2] (weight_nhwc = 1: channels_last memory), output [n][h/2][w/2][cout], optional BN-statistics slabs.
+ */
+int s2d_conv2d2x2s2_pack_weights_bf16(const float *weight, int cin, int cout, int weight_nhwc, void *packed, s2d_stream_t stream);
+int64_t s2d_conv2d2x2s2_stats_tiles(int n_img, int h, int w);
+int s2d_conv2d2x2s2_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img,
+                              int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);
+
+/*
  * Depth-wise 7x7 convolution, padding 3, stride 1 (nn.Conv2d(C, C, 7, padding=3, groups=C): first layer of the three
  * ConvNeXt blocks of the S2D module, det3d/models/necks/rpn.py:204-225) on NHWC bf16 maps.  x, y [n][h][w][c] bf16;
  * weight fp32 [c][49] (the torch layout [c][1][7][7]); bias fp32 [c] or NULL; fp32 accumulation.  flip=1 mirrors the taps:

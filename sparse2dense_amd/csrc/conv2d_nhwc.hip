@@ -783,3 +783,51 @@ extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight,
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
+
+
+// ---- 2x2 stride-2 convolution (forward) ----------------------------------------------------------------------------------
+// encoder_1[0] of the S2D module (rpn.py:188: nn.Conv2d(c, 256, 2, 2)): KS = 2, stride 2, no padding on the same kernel (4 taps x
+// cin/64 K-steps per tile), with the batch-norm statistics epilogue.  Its backward stays with the library.
+extern "C" int s2d_conv2d2x2s2_pack_weights_bf16(const float *weight, int cin, int cout, int weight_nhwc, void *packed, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed, "conv2d2x2s2_pack: null argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d2x2s2_pack: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)4 * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
+                       conv_bn(cout), 0, weight_nhwc, 4, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int64_t s2d_conv2d2x2s2_stats_tiles(int n_img, int h, int w) { return ceil_div((int64_t)n_img * (h / 2) * (w / 2), 128); }
+
+extern "C" int s2d_conv2d2x2s2_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
+                                         int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h >= 2 && w >= 2, "conv2d2x2s2: bad argument");
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
+        set_error("conv2d2x2s2: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t m = (int64_t)n_img * (h / 2) * (w / 2);
+    const int bn = conv_bn(cout);
+    const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
+    const size_t lds = (size_t)2 * (128 * 64 * 2 + 64 * bn * 2);
+    hipStream_t st = (hipStream_t)stream;
+#define S2D_CONV2_LAUNCH(BN_)                                                                                             \
+    do {                                                                                                                  \
+        auto kern = conv3x3_nhwc_bf16_kernel<BN_, 2, 2>;                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,              \
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, 0, 2, (__bf16 *)y, stats_partial);          \
+    } while (0)
+    if (bn == 128) S2D_CONV2_LAUNCH(128); else S2D_CONV2_LAUNCH(64);
+#undef S2D_CONV2_LAUNCH
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}

@@ -321,6 +321,69 @@ class Conv1x1(nn.Conv2d):
         return super().forward(x)
 
 
+class _Conv2x2S2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_stats):
+        lib = _lib.load()
+        xb = _nhwc_bf16(x)
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, h, w = xb.shape
+
+        def build():
+            wf = weight.detach().float()
+            nhwc = (not wf.is_contiguous()) and wf.is_contiguous(memory_format=torch.channels_last)
+            if not nhwc:
+                wf = wf.contiguous()
+            packed = torch.empty(4 * cin * cout, dtype=torch.bfloat16, device=weight.device)
+            check(lib.s2d_conv2d2x2s2_pack_weights_bf16(_ptr(wf), cin, cout, int(nhwc), _ptr(packed), _stream()), "s2d_conv2d2x2s2_pack_weights_bf16")
+            return packed
+        packed = cached_pack(weight, ("conv2x2s2",), build)
+        y = torch.empty((n, cout, h // 2, w // 2), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
+        partial = torch.empty((lib.s2d_conv2d2x2s2_stats_tiles(n, h, w), 2, cout), dtype=torch.float32, device=xb.device) if bn_stats else None
+        b = None if bias is None else bias.detach().float().contiguous()
+        check(lib.s2d_conv2d2x2s2_nhwc_bf16(_ptr(xb), _ptr(packed), _ptr(b), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(y), _ptr(partial),
+                                            _stream()), "s2d_conv2d2x2s2_nhwc_bf16")
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        if bn_stats:
+            ctx.mark_non_differentiable(partial)
+            return y, partial
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        xb, weight = ctx.saved_tensors
+        dyb = _nhwc_bf16(dy)
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx, dwb, dbb = torch.ops.aten.convolution_backward(dyb, xb, wb, [weight.shape[0]] if ctx.has_bias else None, [2, 2], [0, 0], [1, 1], False,
+                                                           [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                                       bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        return dx, None if dwb is None else dwb.to(weight.dtype), None if dbb is None else dbb.float(), None
+
+
+class Conv2x2S2(nn.Conv2d):
+    """nn.Conv2d(cin, cout, 2, stride 2) (same parameters / state_dict keys): the forward (with the batch-norm statistics of a following
+    FastBatchNorm2d) runs the NHWC tile kernel with 4 taps; the backward stays with the library."""
+
+    emit_bn_stats = False
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and self.dilation == (1, 1)
+                and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            if self.emit_bn_stats and self.training and torch.is_grad_enabled():
+                y, partial = _Conv2x2S2Fn.apply(x, self.weight, self.bias, True)
+                y._s2d_bn_partial = partial
+                return y
+            return _Conv2x2S2Fn.apply(x, self.weight, self.bias, False)
+        return super().forward(x)
+
+
 # --------------------------------------------------------------------------------------------------
 # depth-wise 7x7 convolution of the S2D ConvNeXt blocks (csrc/dwconv.hip)
 # --------------------------------------------------------------------------------------------------
@@ -568,7 +631,7 @@ def fuse_bn_relu(layers):
         if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.GELU) and layers[i + 1].approximate == "none":
             layers[i].fused_relu = 2   # activation code 2: exact GELU behind the normalisation (csrc/features.hip)
             layers[i + 1] = nn.Identity()
-        if isinstance(layers[i], (Conv3x3, Conv1x1)) and isinstance(layers[i + 1], FastBatchNorm2d):
+        if isinstance(layers[i], (Conv3x3, Conv1x1, Conv2x2S2)) and isinstance(layers[i + 1], FastBatchNorm2d):
             layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials
         if type(layers[i]) is nn.ZeroPad2d and tuple(layers[i].padding) == (1, 1, 1, 1) and isinstance(layers[i + 1], Conv3x3) \
                 and layers[i + 1].padding == (0, 0) and layers[i + 1].kernel_size == (3, 3):

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv1x1, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .heads import pcr_level, pcr_level_norm, pcr_level_supported
 from .registry import NECKS
@@ -162,7 +162,7 @@ class S2D_RPN(RPN):
                          num_input_features, norm_cfg, name, logger)
         c = num_input_features
         # ---- S2D module (rpn.py:186-253): 188 -> 94 -> 47 -> 3x ConvNeXt -> 94 -> 188 ----
-        self.encoder_1 = _cbg((nn.Conv2d(c, 256, 2, 2), 256), (Conv3x3(256, 256, 3, 1, 1), 256))
+        self.encoder_1 = _cbg((Conv2x2S2(c, 256, 2, 2), 256), (Conv3x3(256, 256, 3, 1, 1), 256))
         self.encoder_2 = _cbg((Conv3x3(256, 256, 3, 2, 1), 256), (Conv3x3(256, 256, 3, 1, 1), 256))
         self.convnext_block_1 = _convnext(256, 47)
         self.convnext_block_2 = _convnext(256, 47)

@@ -445,3 +445,37 @@ def test_conv1x1_forward_backward_vs_cpu_float64(n, cin, cout, h, w, bias):
     s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
     assert (part[:, 0].sum(0) - s1).abs().max() <= 1e-3 * s1.abs().max() + 1e-2
     assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(4, 256, 256, 188, 188), (2, 64, 128, 10, 6), (1, 128, 64, 34, 18)])
+def test_conv2x2_stride2_forward_vs_cpu_float64(n, cin, cout, h, w):
+    """Conv2x2S2 (encoder_1[0] of the S2D module) forward on the tile kernel with 4 taps vs float64 on the host over bf16-rounded
+    operands (one output rounding: 6e-3 of max) + its epilogue statistics; the backward (library) against the same reference, 1e-2."""
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(cin + cout + h)
+    m = D.Conv2x2S2(cin, cout, 2, 2).cuda()
+    rb = lambda t: t.to(torch.bfloat16).float()
+    with torch.no_grad():
+        m.weight.copy_(rb(m.weight))
+    x = rb(torch.randn(n, cin, h, w, device="cuda"))
+    dy = rb(torch.randn(n, cout, h // 2, w // 2, device="cuda"))
+    xa = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    m.emit_bn_stats = True
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = m(xa)
+    part = ya._s2d_bn_partial
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    ya.backward(dy.to(torch.bfloat16))
+    ref = torch.nn.Conv2d(cin, cout, 2, 2).double()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    xr = x.double().cpu().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double().cpu())
+    for name, a, r, tol in (("y", ya, yr, 6e-3), ("dx", xa.grad, xr.grad, 1e-2), ("dw", m.weight.grad, ref.weight.grad, 1e-2),
+                            ("db", m.bias.grad, ref.bias.grad, 1e-2)):
+        err = float((a.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        assert err <= tol, (name, err)
+    yf = ya.detach().float()
+    s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
+    assert (part[:, 0].sum(0) - s1).abs().max() <= 1e-3 * s1.abs().max() + 1e-2
+    assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
