@@ -19,7 +19,7 @@ from torch import nn
 
 from . import registry
 from .backbones import build_norm_layer
-from .dense2d import WideLayerNorm
+from .dense2d import Conv1x1, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import FastBatchNorm3d, PointwiseConv3d
 from .detectors import SingleStageDetector
 from .heads import mask_offset_loss, metric_grid
@@ -117,12 +117,15 @@ class PointPillarsScatter(nn.Module):
 
 
 def _cbg(conv, c):
-    return [conv, nn.BatchNorm2d(c), nn.GELU()]
+    """conv -> BatchNorm2d -> GELU (point_pillars.py S2D module): the drop-in layer classes take the HIP kernels on NHWC bf16 inputs
+    under autocast (3x3 / 1x1 tile kernels, row batch norm with the GELU fused behind it) and are the stock layers otherwise; same
+    Sequential indices and state_dict keys"""
+    return fuse_bn_relu([conv, FastBatchNorm2d(c), nn.GELU()])
 
 
 def _convnext(c, hw):
-    return nn.Sequential(nn.Conv2d(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
-                         nn.Conv2d(c, 4 * c, 1), nn.GELU(), nn.Conv2d(4 * c, c, 1))
+    return nn.Sequential(DepthwiseConv7(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
+                         Conv1x1(c, 4 * c, 1), nn.GELU(), Conv1x1(4 * c, c, 1))
 
 
 @BACKBONES.register_module
@@ -136,16 +139,16 @@ class PointPillarsScatter_S2D(nn.Module):
         self.nchannels = num_input_features
         self.encoder_1 = nn.Sequential(nn.MaxPool2d(2, 2), *_cbg(nn.Conv2d(64, 32, 1, 1, 0), 32),
                                        *_cbg(nn.Conv2d(32, 32, 2, 2), 32), *_cbg(nn.Conv2d(32, 128, 1, 1, 0), 128))
-        self.encoder_2 = nn.Sequential(*_cbg(nn.Conv2d(128, 128, 3, 2, 1), 128), *_cbg(nn.Conv2d(128, 256, 3, 1, 1), 256))
+        self.encoder_2 = nn.Sequential(*_cbg(Conv3x3(128, 128, 3, 2, 1), 128), *_cbg(Conv3x3(128, 256, 3, 1, 1), 256))
         self.convnext_block_1 = _convnext(256, 59)
         self.convnext_block_2 = _convnext(256, 59)
         self.convnext_block_3 = _convnext(256, 59)
-        self.decoder_1 = nn.Sequential(*_cbg(nn.Conv2d(256, 128, 3, 1, 1), 128), nn.Upsample((117, 117)))
-        self.decoder_2 = nn.Sequential(*_cbg(nn.Conv2d(128 + 128, 64, 3, 1, 1), 64),
+        self.decoder_1 = nn.Sequential(*_cbg(Conv3x3(256, 128, 3, 1, 1), 128), nn.Upsample((117, 117)))
+        self.decoder_2 = nn.Sequential(*_cbg(Conv3x3(128 + 128, 64, 3, 1, 1), 64),
                                        *_cbg(nn.ConvTranspose2d(64, 64, 4, 2, 1), 64),
-                                       *_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
-        self.fusion_sparse = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), num_input_features))
-        self.fusion_dense = nn.Sequential(*_cbg(nn.Conv2d(64, 64, 1, 1, 0), 64))
+                                       *_cbg(Conv1x1(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
+        self.fusion_sparse = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), num_input_features))
+        self.fusion_dense = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), 64))
         self.generator = nn.Sequential(PointwiseConv3d(64, 32, 1, 1, 0), FastBatchNorm3d(32), nn.GELU(),
                                        PointwiseConv3d(32, 16, 1, 1, 0), FastBatchNorm3d(16), nn.GELU())
         self.gen_out = nn.Sequential(PointwiseConv3d(16, 3, 1, 1, 0))

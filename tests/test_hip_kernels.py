@@ -384,3 +384,25 @@ def test_spconv_wgrad_bf16_vs_oracle(cin, cout):
     torch.testing.assert_close(gw.double(), exact_rounded, rtol=1e-4, atol=2e-4)
     full = ref_wgrad(feats, g)
     assert (gw.double() - full).abs().max().item() <= 2e-2 * full.abs().max().item()
+
+
+def test_distillation_example_fields_match_the_oracle_at_every_scale():
+    """Voxelization.__call__ of the S2D example (preprocess.py:316-397): the input, `dense_*` and `reconstruction_*` clouds and the
+    reconstruction clouds on the 2x / 4x voxel grids (`*_2`, `*_4`), each bit-exact vs the oracle per frame + collate (one host read
+    serves all five voxelizations)"""
+    from sparse2dense_amd.data import SyntheticFrames
+    fr = SyntheticFrames(2, n_points=12000, seed=5, distill=True, device=DEV)
+    ex = fr.example()
+    clouds = {"": fr.points, "dense_": fr.dense_points, "reconstruction_": fr.recon_points}
+    for prefix, suf in (("", ""), ("dense_", ""), ("reconstruction_", ""), ("reconstruction_", "_2"), ("reconstruction_", "_4")):
+        gen = fr.gens[suf]
+        ev, ec, en = [], [], []
+        for b, pts in enumerate(clouds[prefix]):
+            v, c, n = OV.points_to_voxel(pts.cpu().numpy(), gen.voxel_size, gen.point_cloud_range, gen.max_num_points_per_voxel, gen._max_voxels)
+            ev.append(v); en.append(n)
+            ec.append(np.concatenate([np.full((len(c), 1), b, np.int32), c], 1))
+        key = lambda f: prefix + f + suf
+        assert np.array_equal(ex[key("coordinates")].cpu().numpy(), np.concatenate(ec)), (prefix, suf)
+        assert np.array_equal(ex[key("num_points")].cpu().numpy(), np.concatenate(en))
+        assert np.array_equal(ex[key("voxels")].cpu().numpy().view(np.uint32), np.concatenate(ev).view(np.uint32))
+        assert ex[key("num_voxels")].cpu().tolist() == [len(n) for n in en]
