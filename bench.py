@@ -450,6 +450,11 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print there (RCCL writes a version banner to stdout when
+    # its first communicator is created) is redirected to stderr; the result goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.set_num_threads(min(effective_cpu_count(), 16))
     from sparse2dense_amd import dp
     rank, local, world = dp.init_distributed()
@@ -532,7 +537,8 @@ def main():
         if rows:
             out["config"]["event_timed_kernels"] = [
                 {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
