@@ -94,7 +94,7 @@ constexpr int CT_TX = 64;   // cells per block along x
 
 template <int CIN, int NT>
 __global__ __launch_bounds__(256) void ct_fwd_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
-                                                          CtDims s, int xtiles, float *__restrict__ out) {
+                                                          CtDims s, int xtiles, float *__restrict__ out, float *__restrict__ stats_partial) {
     constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
     constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
     constexpr int KSTEPS = CIN == 32 ? 8 : 4;
@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256) void ct_fwd_mfma_kernel(const float *__restric
     const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
     const int oz = 2 * hz + pz, oy = 2 * hy + py;
     float *ob = out + (int64_t)n * s.cout * od * oh * ow;
+    float st1[NT], st2[NT];   // per-channel (sum, sum of squares) of this lane's outputs: the batch norm that follows skips its statistics pass
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+        st1[nt] = 0.f;
+        st2[nt] = 0.f;
         const int co = nt * 16 + r;
         if (co >= s.cout) continue;
         const float bv = bias ? bias[co] : 0.f;
@@ -172,14 +175,39 @@ __global__ __launch_bounds__(256) void ct_fwd_mfma_kernel(const float *__restric
                 float4 hi{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv};
                 *reinterpret_cast<float4 *>(orow + 2 * c0) = lo;
                 *reinterpret_cast<float4 *>(orow + 2 * c0 + 4) = hi;
+                st1[nt] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                st2[nt] += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (c0 + j < s.w) {
-                        orow[2 * (c0 + j)] = acc[0][mt][nt][j] + bv;
-                        orow[2 * (c0 + j) + 1] = acc[1][mt][nt][j] + bv;
+                        const float v0 = acc[0][mt][nt][j] + bv, v1 = acc[1][mt][nt][j] + bv;
+                        orow[2 * (c0 + j)] = v0;
+                        orow[2 * (c0 + j) + 1] = v1;
+                        st1[nt] += v0 + v1;
+                        st2[nt] += v0 * v0 + v1 * v1;
                     }
             }
+        }
+    }
+    if (stats_partial) {   // block partial [2][cout]: lanes of a channel (4 q groups), then the 4 waves (= the 4 (pz,py) classes), fixed order
+        __shared__ float sred[4][2][NT * 16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float a = st1[nt], b = st2[nt];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (q == 0) {
+                sred[wid][0][nt * 16 + r] = a;
+                sred[wid][1][nt * 16 + r] = b;
+            }
+        }
+        __syncthreads();
+        if (t < 2 * NT * 16) {
+            const int which = t / (NT * 16), co = t % (NT * 16);
+            if (co < s.cout)
+                stats_partial[((int64_t)blockIdx.x * 2 + which) * s.cout + co] =
+                    (sred[0][which][co] + sred[1][which][co]) + (sred[2][which][co] + sred[3][which][co]);
         }
     }
 }
@@ -775,8 +803,14 @@ extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int c
     return S2D_OK;
 }
 
-extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
-                                    int w, float *out, s2d_stream_t stream) {
+extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int d, int h, int w) {
+    return (int64_t)batch * d * h * ((w + CT_TX - 1) / CT_TX);
+}
+
+/* stats_partial (optional, [s2d_convt3d_mfma_stats_tiles][2][cout]): per-block (sum, sum of squares) per output channel of the written
+ * output - the statistics pass of the BatchNorm3d that follows (s2d_bn_partials_sum_f32 folds them) */
+extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
+                                          int w, float *out, float *stats_partial, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && packed && out && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_fwd: bad argument");
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
     CtDims s{batch, d, h, w, cin, cout};
@@ -787,12 +821,17 @@ extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const f
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *wp = (const __bf16 *)packed;
     const int nt = (cout + 15) / 16;
-    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
-    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
-    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
-    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out);
+    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out, stats_partial);
+    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out, stats_partial);
+    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, out, stats_partial);
+    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, out, stats_partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
+                                    int w, float *out, s2d_stream_t stream) {
+    return s2d_convt3d_mfma_fwd_stats(in, packed, bias, batch, cin, cout, d, h, w, out, nullptr, stream);
 }
 
 extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w,

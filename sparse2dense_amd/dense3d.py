@@ -108,7 +108,7 @@ def _convt_packed(weight):
 
 class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bf16=False):
+    def forward(ctx, x, weight, bias, bf16=False, bn_stats=False):
         lib = _lib.load()
         x = x.contiguous()
         weight = weight.contiguous()
@@ -116,18 +116,32 @@ class _ConvT3dFn(torch.autograd.Function):
         cout = weight.shape[1]
         out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
         ctx.mfma = bool(bf16 and lib.s2d_convt3d_mfma_supported(cin, cout))
+        stats = None
         if ctx.mfma:   # bf16 compute mode: operands rounded to bf16 in the kernel, fp32 accumulate (csrc/convt3d_mfma.hip)
-            check(lib.s2d_convt3d_mfma_fwd(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out),
-                                           _stream()), "s2d_convt3d_mfma_fwd")
+            partial = None
+            if bn_stats:   # the epilogue also produces the statistics of the batch norm that follows
+                tiles = lib.s2d_convt3d_mfma_stats_tiles(n, d, h, w)
+                partial = torch.empty((tiles, 2, cout), dtype=torch.float32, device=x.device)
+            check(lib.s2d_convt3d_mfma_fwd_stats(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial),
+                                                 _stream()), "s2d_convt3d_mfma_fwd_stats")
+            if bn_stats:
+                stats = torch.empty((2 * cout,), dtype=torch.float32, device=x.device)
+                check(lib.s2d_bn_partials_sum_f32(_ptr(partial), partial.shape[0], out.numel() // cout, cout, _ptr(stats), 0, _stream()),
+                      "s2d_bn_partials_sum_f32")
         else:
             check(lib.s2d_convt3d_k4s2p1_fwd_f32(_ptr(x), _ptr(weight), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _stream()),
                   "s2d_convt3d_k4s2p1_fwd_f32")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if bn_stats:
+            if stats is None:   # fp32 kernels: the separate statistics pass
+                stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(out),), n, cout, out[0, 0].numel(), x.device)
+            ctx.mark_non_differentiable(stats)
+            return out, stats
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         lib = _lib.load()
         x, weight = ctx.saved_tensors
         dout = dout.contiguous()
@@ -163,7 +177,7 @@ class _ConvT3dFn(torch.autograd.Function):
                             dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(dim=(0, 2, 3, 4))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _hip_ok(x):
@@ -188,10 +202,15 @@ class ConvTranspose3dK4S2(nn.ConvTranspose3d):
     kernels: operands rounded to bf16, fp32 accumulate, fp32 NCDHW tensors."""
 
     bf16_compute = False
+    emit_bn_stats = False   # set by the owner when a batch norm consumes the output: y._s2d_bn_stats = [sum | sum of squares] per channel
 
     def forward(self, x, output_size=None):
         if _hip_ok(x) and self.kernel_size == (4, 4, 4) and self.stride == (2, 2, 2) and self.padding == (1, 1, 1) \
                 and self.output_padding == (0, 0, 0) and self.groups == 1 and self.dilation == (1, 1, 1):
+            if self.emit_bn_stats and self.training and torch.is_grad_enabled():
+                y, stats = _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute, True)
+                y._s2d_bn_stats = stats
+                return y
             return _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute)
         return super().forward(x, output_size)
 
@@ -213,7 +232,7 @@ def _bncm_reduce(fn_name, args_front, n, c, pos, device):
 
 class _BNChannelMajorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, relu, eps, sync, module, training):
+    def forward(ctx, x, gamma, beta, relu, eps, sync, module, training, stats=None):
         import torch.distributed as dist
         from . import hip_ops as H
         lib = _lib.load()
@@ -222,7 +241,8 @@ class _BNChannelMajorFn(torch.autograd.Function):
         pos = x[0, 0].numel()
         dev = x.device
         if training:
-            stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(x),), n, c, pos, dev)
+            if stats is None:   # (else: the producing kernel's epilogue already reduced them)
+                stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(x),), n, c, pos, dev)
             count = torch.full((1,), float(n * pos), device=dev)
             if sync:
                 packed = torch.cat([stats, count])
@@ -272,7 +292,7 @@ class _BNChannelMajorFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(a), _ptr(b), _ptr(d), int(ctx.relu), n, c, pos,
                                              _ptr(dx), _stream()), "s2d_bncm_bwd_apply_f32")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 class FastBatchNorm3d(nn.BatchNorm3d):
@@ -289,7 +309,10 @@ class FastBatchNorm3d(nn.BatchNorm3d):
         sync = training and _collective.sync_on()
         if _hip_ok(x) and x.dim() >= 3 and x[0, 0].numel() % 4 == 0 and self.affine and x.shape[0] * x.shape[1] <= 65535 \
                 and self.momentum is not None:
-            return _BNChannelMajorFn.apply(x, self.weight, self.bias, self.fused_relu, self.eps, sync, self, training)
+            stats = getattr(x, "_s2d_bn_stats", None) if training else None
+            if stats is not None and stats.numel() != 2 * self.num_features:
+                stats = None
+            return _BNChannelMajorFn.apply(x, self.weight, self.bias, self.fused_relu, self.eps, sync, self, training, stats)
         if sync and x.is_cuda:   # inputs the channel-major kernels do not cover still synchronise (as FastBatchNorm2d does)
             import torch.distributed as dist
             from torch.nn.modules._functions import SyncBatchNorm as _SyncFn

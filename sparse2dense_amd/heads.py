@@ -247,7 +247,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
     written.  The batch-norm statistics / finalisation (running stats, SyncBN all-reduces) are the FastBatchNorm3d ones."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16):
+    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16, stats=None):
         from . import _lib, collective as _collective, hip_ops as H
         from .dense2d import _ptr, _stream, _ws
         from .dense3d import _bncm_reduce
@@ -256,7 +256,8 @@ class _PcrLevelNormFn(torch.autograd.Function):
         b, c, d, h, w = y.shape
         pos, dev = d * h * w, y.device
         sync = _collective.sync_on()
-        stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(y),), b, c, pos, dev)
+        if stats is None or stats.numel() != 2 * c:   # (else: reduced in the epilogue of the kernel that produced y)
+            stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(y),), b, c, pos, dev)
         count = torch.full((1,), float(b * pos), device=dev)
         if sync:
             packed = torch.cat([stats, count])
@@ -320,7 +321,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
             dw2, db2 = pointwise_conv_wgrad(y, dz, has_b2, ctx.bf16, norm=norm)
             dw2 = dw2.reshape(w2_shape)
         return (dy, dgamma, dbeta, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:],
-                None, None, dw2, db2, None, None)
+                None, None, dw2, db2, None, None, None)
 
 
 def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
@@ -331,7 +332,7 @@ def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
     coors = coors if coors.dtype == torch.int32 else coors.int()
     return _PcrLevelNormFn.apply(y, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors,
                                  feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
-                                 bn, bool(getattr(next_conv, "bf16_compute", False)))
+                                 bn, bool(getattr(next_conv, "bf16_compute", False)), getattr(y, "_s2d_bn_stats", None))
 
 
 def pcr_level_supported(g, next_conv=None):

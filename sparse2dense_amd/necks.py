@@ -187,6 +187,7 @@ class S2D_RPN(RPN):
                                          ConvTranspose3dK4S2(16, 3, 4, 2, 1), bnr(3), nn.Identity())
         self.gen_out_2 = nn.Sequential(PointwiseConv3d(3, 3, 1, 1, 0))
         self.gen_mask_2 = nn.Sequential(PointwiseConv3d(3, 1, 1, 1, 0))
+        self.generator_1[3].emit_bn_stats = self.generator_2[3].emit_bn_stats = True   # up-samplers: BN statistics from the epilogue
         # {4: (coors, feats), 2: (coors, feats)} of the recon voxels, set by KD_VoxelNet for ONE forward: the PCR levels then return
         # their losses (0-dim tensors in the gen_mask_* / gen_offset_* slots) instead of the dense logits / offsets
         self.pcr_targets = None

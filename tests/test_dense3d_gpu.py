@@ -167,3 +167,27 @@ def test_pointwise_conv3d_weight_gradient_bf16_mfma(cin, cout, pos_shape):
     db = dy.double().sum(dim=(0, 2, 3, 4))
     assert (layer.weight.grad.cpu().double().reshape(cout, cin) - dw).abs().max() <= 1e-4 * dw.abs().max()
     assert (layer.bias.grad.cpu().double() - db).abs().max() <= 2e-5 * db.abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (2, 4, 7, 376)), (16, 3, (1, 2, 3, 24))])
+def test_convtranspose3d_epilogue_batchnorm_statistics(cin, cout, shape):
+    """the (sum, sum of squares) per output channel that the MFMA forward kernel's epilogue emits == the sums over the written output,
+    and FastBatchNorm3d fed with them == FastBatchNorm3d doing its own statistics pass"""
+    from sparse2dense_amd.dense3d import FastBatchNorm3d
+    torch.manual_seed(cin + cout)
+    n, d, h, w = shape
+    m = ConvTranspose3dK4S2(cin, cout, 4, 2, 1).to(DEV).train()
+    m.bf16_compute, m.emit_bn_stats = True, True
+    x = torch.randn(n, cin, d, h, w, device=DEV).requires_grad_(True)
+    y = m(x)
+    st = y._s2d_bn_stats
+    s1, s2 = y.detach().double().sum(dim=(0, 2, 3, 4)), (y.detach().double() ** 2).sum(dim=(0, 2, 3, 4))
+    assert (st[:cout].double() - s1).abs().max() <= 1e-5 * s2.sqrt().max() * (y[0, 0].numel() * n) ** 0.5
+    assert (st[cout:].double() - s2).abs().max() <= 1e-5 * s2.abs().max()
+    bn_a, bn_b = FastBatchNorm3d(cout, fused_relu=True).to(DEV).train(), FastBatchNorm3d(cout, fused_relu=True).to(DEV).train()
+    za = bn_a(y)                       # consumes y._s2d_bn_stats
+    zb = bn_b(y.detach().clone())      # own statistics pass
+    assert (za - zb).abs().max() <= 1e-5 * zb.abs().max() + 1e-6
+    assert (bn_a.running_var - bn_b.running_var).abs().max() <= 1e-6 * bn_b.running_var.abs().max() + 1e-7
+    za.sum().backward()                # the two-output autograd node still back-propagates
+    assert x.grad is not None and torch.isfinite(x.grad).all()
