@@ -480,7 +480,7 @@ def main():
             step()
             step()
             torch.cuda.synchronize()
-        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70,
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("S2D_PROFILE_ROWS", "70")),
                                                                  max_name_column_width=48, max_shapes_column_width=70),
               file=sys.stderr)
 

@@ -398,6 +398,20 @@ size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int
 int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin,
                                   int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
+/* 3x3 / padding 1 / stride 1 convolutions with 1..4 output channels: the last conv of every CenterHead branch
+ * (/root/reference/det3d/models/bbox_heads/center_head.py:33-61 SepHead, Conv2d(64, classes, 3, padding=1); replaces the
+ * torch.nn.Conv2d -> MIOpen call there).  x, dx: bf16 NHWC [n][h][w][cin] (cin % 8 == 0, cin <= 128); weight / dweight: fp32
+ * [cout][cin][3][3] (torch layout); y, dy: fp32 planar [n][cout][h][w] - the predictions the losses and the decoder read.
+ * wgrad also returns dbias (optional); its per-block partial sums are folded in a fixed order (deterministic). */
+int s2d_smallconv3x3_supported(int cin, int cout);
+int s2d_smallconv3x3_fwd(const void *x, const float *weight, const float *bias, int n_img, int h, int w, int cin, int cout, float *y,
+                         s2d_stream_t stream);
+int s2d_smallconv3x3_dgrad(const float *dy, const float *weight, int n_img, int h, int w, int cin, int cout, void *dx,
+                           s2d_stream_t stream);
+size_t s2d_smallconv3x3_wgrad_workspace_bytes(int cin, int cout);
+int s2d_smallconv3x3_wgrad(const void *x, const float *dy, int n_img, int h, int w, int cin, int cout, float *dweight, float *dbias,
+                           void *ws, size_t ws_bytes, s2d_stream_t stream);
+
 /*
  * 2x2 stride-2 convolution forward (encoder_1[0] of the S2D module, rpn.py:188) on the same tile pipeline; weight = torch
  * [Cout][Cin][2][2] (weight_nhwc = 1: channels_last memory), output [n][h/2][w/2][cout], optional BN-statistics slabs.

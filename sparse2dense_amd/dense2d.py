@@ -321,6 +321,63 @@ class Conv1x1(nn.Conv2d):
         return super().forward(x)
 
 
+class _SmallConv3x3Fn(torch.autograd.Function):
+    """3x3 / padding 1 conv with <= 4 output channels from an NHWC bf16 map to fp32 planar predictions (csrc/smallconv.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        xb = _nhwc_bf16(x)
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, h, w = xb.shape
+        wf = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((n, cout, h, w), dtype=torch.float32, device=xb.device)
+        check(lib.s2d_smallconv3x3_fwd(_ptr(xb), _ptr(wf), _ptr(b), n, h, w, cin, cout, _ptr(y), _stream()), "s2d_smallconv3x3_fwd")
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xb, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, h, w = xb.shape
+        dyf = dy.float().contiguous()
+        wf = weight.detach().float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=xb.device).contiguous(memory_format=torch.channels_last)
+            check(lib.s2d_smallconv3x3_dgrad(_ptr(dyf), _ptr(wf), n, h, w, cin, cout, _ptr(dx), _stream()), "s2d_smallconv3x3_dgrad")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dwf = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xb.device)
+            dbf = torch.empty((cout,), dtype=torch.float32, device=xb.device)
+            ws = _ws(lib.s2d_smallconv3x3_wgrad_workspace_bytes(cin, cout), xb.device)
+            check(lib.s2d_smallconv3x3_wgrad(_ptr(xb), _ptr(dyf), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(), _stream()),
+                  "s2d_smallconv3x3_wgrad")
+            dw = dwf.to(weight.dtype)
+            db = dbf if ctx.has_bias else None
+        return dx, dw, db
+
+
+class SmallConv3x3(nn.Conv2d):
+    """nn.Conv2d(cin, 1..4, 3, padding=1): the last conv of every CenterHead branch (same parameters / state_dict keys).  CUDA
+    inputs under bf16 autocast run the streaming kernels and return fp32 NCHW predictions (what the losses and the decoder read);
+    anything else is the stock layer."""
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1)
+                and self.groups == 1 and self.in_channels % 8 == 0 and self.in_channels <= 128 and self.out_channels <= 4)
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            return _SmallConv3x3Fn.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 class _Conv2x2S2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_stats):

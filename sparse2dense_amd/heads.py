@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .dense2d import Conv3x3, FastBatchNorm2d, fuse_bn_relu
+from .dense2d import Conv3x3, FastBatchNorm2d, SmallConv3x3, fuse_bn_relu
 from .registry import HEADS, LOSSES
 
 
@@ -382,7 +382,8 @@ class SepHead(nn.Module):
                 if bn:
                     layers.append(FastBatchNorm2d(head_conv))
                 layers.append(nn.ReLU())
-            layers.append(nn.Conv2d(head_conv, classes, final_kernel, 1, final_kernel // 2, bias=True))
+            last = SmallConv3x3 if final_kernel == 3 and classes <= 4 else nn.Conv2d
+            layers.append(last(head_conv, classes, final_kernel, 1, final_kernel // 2, bias=True))
             fc = nn.Sequential(*fuse_bn_relu(layers))
             if "hm" in head:
                 fc[-1].bias.data.fill_(init_bias)

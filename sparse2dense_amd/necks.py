@@ -62,7 +62,7 @@ class RPN(nn.Module):
                 conv = nn.ConvTranspose2d(ds_num_filters[i], us_num_filters[j], up, stride=up, bias=False)
             else:
                 down = int(np.round(1 / up))
-                conv = nn.Conv2d(ds_num_filters[i], us_num_filters[j], down, stride=down, bias=False)
+                conv = (Conv1x1 if down == 1 else nn.Conv2d)(ds_num_filters[i], us_num_filters[j], down, stride=down, bias=False)
             deblocks.append(nn.Sequential(*fuse_bn_relu([conv, build_norm_layer(self._norm_cfg, us_num_filters[j])[1], nn.ReLU()])))
         self.blocks = nn.ModuleList(blocks)
         self.deblocks = nn.ModuleList(deblocks)

@@ -479,3 +479,49 @@ def test_conv2x2_stride2_forward_vs_cpu_float64(n, cin, cout, h, w):
     s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
     assert (part[:, 0].sum(0) - s1).abs().max() <= 1e-3 * s1.abs().max() + 1e-2
     assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(4, 64, 3, 188, 188), (2, 64, 1, 33, 20), (1, 64, 2, 7, 5), (2, 128, 4, 19, 30), (3, 8, 3, 1, 9)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_small_cout_conv3x3_forward_backward_vs_cpu_float64(n, cin, cout, h, w, bias):
+    """SmallConv3x3 (the last conv of every CenterHead branch; streaming kernels of csrc/smallconv.hip) vs torch conv2d in float64 on
+    the HOST over the same bf16-rounded input.  Weights, products and sums are fp32, the predictions fp32: y, dW, db within 1e-5 of
+    max; dx is stored as bf16 (one rounding: 4e-3 of max).  Two runs are bit-identical (fixed-order folds)."""
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(n + cin + cout + h)
+    m = D.SmallConv3x3(cin, cout, 3, 1, 1, bias=bias).cuda()
+    x = torch.randn(n, cin, h, w, device="cuda").to(torch.bfloat16).float()
+    dy = torch.randn(n, cout, h, w, device="cuda")
+    outs = []
+    for _ in range(2):
+        m.zero_grad()
+        xa = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ya = m(xa)
+        assert ya.dtype == torch.float32 and ya.is_contiguous()
+        ya.backward(dy)
+        outs.append((ya.detach().clone(), xa.grad.clone(), m.weight.grad.clone(), None if not bias else m.bias.grad.clone()))
+    for a, b in zip(*outs):
+        assert a is None or torch.equal(a, b)
+    ref = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=bias).double()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    xr = x.double().cpu().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(dy.double().cpu())
+    checks = [("y", ya, yr, 1e-5), ("dx", xa.grad, xr.grad, 4e-3), ("dw", m.weight.grad, ref.weight.grad, 1e-5)]
+    if bias:
+        checks.append(("db", m.bias.grad, ref.bias.grad, 1e-5))
+    for name, a, r, tol in checks:
+        err = float((a.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        assert err <= tol, (name, err)
+    assert xa.grad.dtype == torch.bfloat16
+
+
+def test_center_head_branches_end_in_the_streaming_conv():
+    from sparse2dense_amd import dense2d as D
+    from sparse2dense_amd.heads import SepHead
+    head = SepHead(64, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), hm=(3, 2)), bn=True, final_kernel=3)
+    for name in head.heads:
+        assert isinstance(getattr(head, name)[-1], D.SmallConv3x3), name
+    # same parameter names as the reference's nn.Sequential(Conv2d, BN, ReLU, Conv2d)
+    assert {k for k in head.state_dict() if k.startswith("hm.")} >= {"hm.0.weight", "hm.0.bias", "hm.1.weight", "hm.3.weight", "hm.3.bias"}
