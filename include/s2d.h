@@ -400,7 +400,7 @@ int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zer
 
 /* 3x3 / padding 1 / stride 1 convolutions with 1..4 output channels: the last conv of every CenterHead branch
  * (/root/reference/det3d/models/bbox_heads/center_head.py:33-61 SepHead, Conv2d(64, classes, 3, padding=1); replaces the
- * torch.nn.Conv2d -> MIOpen call there).  x, dx: bf16 NHWC [n][h][w][cin] (cin % 8 == 0, cin <= 128); weight / dweight: fp32
+ * torch.nn.Conv2d -> MIOpen call there).  x, dx: bf16 NHWC [n][h][w][cin] (cin in {8,16,32,64,128}); weight / dweight: fp32
  * [cout][cin][3][3] (torch layout); y, dy: fp32 planar [n][cout][h][w] - the predictions the losses and the decoder read.
  * wgrad also returns dbias (optional); its per-block partial sums are folded in a fixed order (deterministic). */
 int s2d_smallconv3x3_supported(int cin, int cout);

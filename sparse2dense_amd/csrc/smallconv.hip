@@ -3,177 +3,270 @@
 // reg / height / dim / rot / hm, on the 188 x 188 map).  With 1-3 output channels these are streaming reductions over a 64-channel
 // NHWC bf16 map (18 MB), not GEMMs: MIOpen's implicit-GEMM kernels ran them at 65 us forward and 80-116 us backward each (0.77 ms
 // per step for the five branches).  Here:
-//   fwd   thread = output pixel: 9 taps x cin/8 16-byte loads, KO accumulators, weights broadcast from LDS; output written as fp32
-//         planar [n][KO][h][w] - what the losses read (no bf16 round trip of the predictions)
-//   dgrad thread = (pixel, 8-channel group): 9 taps x KO fp32 gradient values (coalesced planar reads) -> one 16-byte bf16 store
-//   wgrad thread = (8-channel group, tap) worker x pixel lane: acc[8][KO] over a strip of pixels, fixed-order block fold, per-block
-//         partials [blocks][KO][cin][9] (+ bias gradient) reduced by a second kernel
-// x, dx: bf16 NHWC; weight fp32 [KO][cin][3][3] (torch layout); padding 1, stride 1; cin % 8 == 0, cin <= 128; KO <= 4.
+//   fwd   thread = (4 pixels of a row, 8-channel group): 3 x 6 16-byte loads issued together (the cin/8 lanes of a pixel read one
+//         contiguous row), each tap's weights read from LDS once for the four pixels, cross-lane fold; output written as fp32 planar [n][KO][h][w] - what the losses read (no bf16
+//         round trip of the predictions)
+//   dgrad thread = (4 pixels of a row, 8-channel group): 3 x 6 x KO fp32 gradient values, weights from LDS once per four pixels ->
+//         four 16-byte bf16 stores
+//   wgrad thread = (kernel row, 8-channel group) worker x 8 pixel lanes: acc[3 taps][8][KO] over a run of image rows (the input row is
+//         read 3x, not 9x), shuffle fold, per-block partials [blocks][KO*cin*9 + KO] (weights, bias) reduced by a second kernel
+// x, dx: bf16 NHWC; weight fp32 [KO][cin][3][3] (torch layout); padding 1, stride 1; cin in {8, 16, 32, 64, 128}; KO <= 4.
 #include "s2d_common.h"
 
 namespace s2d {
 
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
-constexpr int SC_MAX_CIN = 128, SC_WG_BLOCKS = 512;
+constexpr int SC_MAX_CIN = 128, SC_WG_BLOCKS = 384, SC_WG_LANES = 8;
 
+// thread = (four consecutive pixels of a row, 8-channel group g): the 3 x 6 input vectors the four pixels touch are loaded once
+// (the cin/8 lanes of a pixel read one contiguous 2*cin-byte row), every tap's 8 x KO weights are read from LDS once for the four
+// pixels, and the cin/8 partial sums are folded with cross-lane shuffles (cin/8 is a power of two).
 template <int KO>
 __global__ __launch_bounds__(256) void smallconv_fwd_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                            int n_img, int H, int W, int cin, float *__restrict__ y) {
+                                                            int n_img, int H, int W, int cin, int lg, float *__restrict__ y) {
     __shared__ float ws[9 * SC_MAX_CIN * KO];   // [tap][c][k]
     for (int i = threadIdx.x; i < 9 * cin * KO; i += 256) {
         const int k = i % KO, c = (i / KO) % cin, tap = i / (KO * cin);
-        ws[i] = w[((int64_t)k * cin + c) * 9 + tap];
+        ws[i] = w[(k * cin + c) * 9 + tap];
     }
     __syncthreads();
-    const int64_t hw = (int64_t)H * W, total = hw * n_img;
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= total) return;
-    const int px = (int)(m % W), py = (int)((m / W) % H);
-    const int64_t img = m / hw;
-    float acc[KO];
+    const unsigned qpr = (unsigned)(W + 3) >> 2, n_quads = qpr * H * n_img;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned g = t & ((1u << lg) - 1), q0 = t >> lg;
+    const bool live = q0 < n_quads;
+    const unsigned q = live ? q0 : 0;
+    const unsigned line = q / qpr;
+    const int px0 = (int)(q - line * qpr) * 4;
+    const unsigned img = line / (unsigned)H;
+    const int py = (int)(line - img * H);
+    bf16x8s v[3][6];
 #pragma unroll
-    for (int k = 0; k < KO; ++k) acc[k] = bias ? bias[k] : 0.f;
-    const int groups = cin >> 3;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int yy = py + r - 1, xx = px0 + c - 1;
+            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const int64_t pix = ok ? ((int64_t)img * H + yy) * W + xx : ((int64_t)img * H + py) * W + px0;
+            v[r][c] = reinterpret_cast<const bf16x8s *>(x + pix * cin)[g];
+            if (!ok) v[r][c] = bf16x8s{};
+        }
+    float acc[4][KO];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < KO; ++k) acc[u][k] = 0.f;
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-        const __bf16 *row = x + ((img * H + yy) * W + xx) * cin;
-        const float *wt = ws + tap * cin * KO;
-        for (int g = 0; g < groups; ++g) {
-            const bf16x8s v = reinterpret_cast<const bf16x8s *>(row)[g];
+        float wt[8][KO];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < KO; ++k) wt[e][k] = ws[(tap * cin + g * 8 + e) * KO + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xf = (float)v[e];
+                const float xf = (float)v[tap / 3][u + tap % 3][e];
 #pragma unroll
-                for (int k = 0; k < KO; ++k) acc[k] = fmaf(xf, wt[(g * 8 + e) * KO + k], acc[k]);
+                for (int k = 0; k < KO; ++k) acc[u][k] = fmaf(xf, wt[e][k], acc[u][k]);
+            }
+    }
+    for (int off = 1; off < (1 << lg); off <<= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < KO; ++k) acc[u][k] += __shfl_xor(acc[u][k], off);
+    }
+    if (live && g == 0) {
+        const int64_t hw = (int64_t)H * W;
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+            float *o = y + ((int64_t)img * KO + k) * hw + (int64_t)py * W + px0;
+            const float b = bias ? bias[k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (px0 + u < W) o[u] = acc[u][k] + b;
+        }
+    }
+}
+
+// dx[py][px][c] = sum_{ty,tx} sum_k dy[k][py-ty][px-tx] * w[k][c][tap(ty,tx)].  thread = (four consecutive pixels, 8-channel group)
+template <int KO>
+__global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ w, int n_img, int H, int W,
+                                                              int cin, int lg, __bf16 *__restrict__ dx) {
+    __shared__ float ws[9 * SC_MAX_CIN * KO];   // [tap][k][c]
+    for (int i = threadIdx.x; i < 9 * cin * KO; i += 256) {
+        const int c = i % cin, k = (i / cin) % KO, tap = i / (KO * cin);
+        ws[i] = w[(k * cin + c) * 9 + tap];
+    }
+    __syncthreads();
+    const unsigned qpr = (unsigned)(W + 3) >> 2, n_quads = qpr * H * n_img;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned g = t & ((1u << lg) - 1), q = t >> lg;
+    if (q >= n_quads) return;
+    const unsigned line = q / qpr;
+    const int px0 = (int)(q - line * qpr) * 4;
+    const unsigned img = line / (unsigned)H;
+    const int py = (int)(line - img * H);
+    const int64_t hw = (int64_t)H * W;
+    float d[3][6][KO];   // dy[k][py-1+r][px0-1+c]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int oy = py + r - 1, ox = px0 + c - 1;
+            const bool ok = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+            const int64_t o = ok ? (int64_t)oy * W + ox : (int64_t)py * W + px0;
+#pragma unroll
+            for (int k = 0; k < KO; ++k) {
+                const float val = dy[((int64_t)img * KO + k) * hw + o];
+                d[r][c][k] = ok ? val : 0.f;
+            }
+        }
+    float acc[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[u][e] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ty = tap / 3 - 1, tx = tap % 3 - 1;
+#pragma unroll
+        for (int k = 0; k < KO; ++k) {
+            float wt[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wt[e] = ws[(tap * KO + k) * cin + g * 8 + e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float dv = d[1 - ty][u + 1 - tx][k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[u][e] = fmaf(dv, wt[e], acc[u][e]);
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < KO; ++k) y[(img * KO + k) * hw + (int64_t)py * W + px] = acc[k];
+    for (int u = 0; u < 4; ++u) {
+        if (px0 + u >= W) break;
+        bf16x8s o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[u][e];
+        reinterpret_cast<bf16x8s *>(dx + (((int64_t)img * H + py) * W + px0 + u) * cin)[g] = o;
+    }
 }
 
-// dx[pix][c] = sum_tap sum_k dy[k][pix - (tap offset)] * w[k][c][tap]   (the output pixel pix - delta had pix as its tap `tap`)
+// block = a run of image rows; thread = worker (kernel row ty, 8-channel group g) x one of 8 pixel lanes (adjacent lanes of a wave).
+// A worker reads the input row py+ty once for its three taps: dW[k][c][ty][tx] += dy[k][py][xx-tx] * x[py+ty][xx][c].  Two pixels
+// per round; the 8 pixel lanes are folded with shuffles.  partial[block][KO*cin*9 + KO] (weights, then bias)
 template <int KO>
-__global__ __launch_bounds__(256) void smallconv_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ w, int n_img, int H, int W,
-                                                              int cin, __bf16 *__restrict__ dx) {
-    __shared__ float ws[9 * SC_MAX_CIN * KO];   // [tap][k][c]
-    for (int i = threadIdx.x; i < 9 * cin * KO; i += 256) {
-        const int c = i % cin, k = (i / cin) % KO, tap = i / (KO * cin);
-        ws[i] = w[((int64_t)k * cin + c) * 9 + tap];
-    }
-    __syncthreads();
+__global__ __launch_bounds__(384) void smallconv_wgrad_kernel(const __bf16 *__restrict__ x, const float *__restrict__ dy, int n_img, int H, int W,
+                                                              int cin, int lines_per_block, float *__restrict__ partial) {
+    constexpr int LN = SC_WG_LANES;
     const int groups = cin >> 3;
-    const int64_t hw = (int64_t)H * W, total = hw * n_img * groups;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int g = (int)(t % groups);
-    const int64_t m = t / groups;
-    const int px = (int)(m % W), py = (int)((m / W) % H);
-    const int64_t img = m / hw;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int oy = py - (tap / 3 - 1), ox = px - (tap % 3 - 1);   // output pixel whose tap `tap` reads this input pixel
-        if ((unsigned)oy >= (unsigned)H || (unsigned)ox >= (unsigned)W) continue;
-#pragma unroll
-        for (int k = 0; k < KO; ++k) {
-            const float d = dy[(img * KO + k) * hw + (int64_t)oy * W + ox];
-            const float *wt = ws + (tap * KO + k) * cin + g * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(d, wt[e], acc[e]);
-        }
-    }
-    bf16x8s o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
-    reinterpret_cast<bf16x8s *>(dx + m * cin)[g] = o;
-}
-
-// block = strip of pixels; thread = worker (g, tap) x pixel lane.  partial[block][KO][cin][9] and partial_b[block][KO]
-template <int KO>
-__global__ __launch_bounds__(256) void smallconv_wgrad_kernel(const __bf16 *__restrict__ x, const float *__restrict__ dy, int n_img, int H, int W,
-                                                              int cin, int64_t pix_per_block, float *__restrict__ partial,
-                                                              float *__restrict__ partial_b) {
-    extern __shared__ float red[];   // [lanes][workers][8][KO] fold buffer
-    const int groups = cin >> 3, workers = groups * 9, lanes = 256 / workers;
-    const int wk = threadIdx.x % workers, ln = threadIdx.x / workers;
-    const int g = wk / 9, tap = wk % 9;
-    const int64_t hw = (int64_t)H * W, total = hw * n_img;
-    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block, p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
-    float acc[8][KO], bsum[KO];
+    const int wk = threadIdx.x / LN, ln = threadIdx.x % LN;
+    const int ty = wk / groups - 1, g = wk % groups;
+    const int n_lines = n_img * H;
+    const int64_t hw = (int64_t)H * W;
+    const int l0 = blockIdx.x * lines_per_block, l1 = l0 + lines_per_block < n_lines ? l0 + lines_per_block : n_lines;
+    float acc[3][8][KO], bsum[KO];
 #pragma unroll
     for (int k = 0; k < KO; ++k) {
         bsum[k] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e][k] = 0.f;
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[a][e][k] = 0.f;
     }
-    if (ln < lanes) {
-        for (int64_t m = p0 + ln; m < p1; m += lanes) {
-            const int px = (int)(m % W), py = (int)((m / W) % H);
-            const int64_t img = m / hw;
-            float d[KO];
+    for (int line = l0; line < l1; ++line) {
+        const int img = line / H, py = line - img * H, yy = py + ty;
+        if ((unsigned)yy >= (unsigned)H) continue;   // uniform per worker; the bias sum lives in the ty == 0 worker (always valid)
+        const __bf16 *xrow = x + ((int64_t)img * H + yy) * W * cin + g * 8;
+        const float *drow = dy + (int64_t)img * KO * hw + (int64_t)py * W;
+        for (int p0 = ln; p0 < W; p0 += 2 * LN) {
+            bf16x8s v[2];
+            float d[2][3][KO];   // d[u][a][k] = dy[k][py][xx - (a-1)]
 #pragma unroll
-            for (int k = 0; k < KO; ++k) d[k] = dy[(img * KO + k) * hw + (int64_t)py * W + px];
-            if (wk == 0) {
+            for (int u = 0; u < 2; ++u) {
+                const int xx = p0 + u * LN;
+                const bool in = xx < W;
+                v[u] = *reinterpret_cast<const bf16x8s *>(xrow + (int64_t)(in ? xx : 0) * cin);
+                if (!in) v[u] = bf16x8s{};
 #pragma unroll
-                for (int k = 0; k < KO; ++k) bsum[k] += d[k];
+                for (int a = 0; a < 3; ++a) {
+                    const int ox = xx - (a - 1);
+                    const bool ok = in && (unsigned)ox < (unsigned)W;
+#pragma unroll
+                    for (int k = 0; k < KO; ++k) {
+                        const float val = drow[(int64_t)k * hw + (ok ? ox : 0)];
+                        d[u][a][k] = ok ? val : 0.f;
+                    }
+                }
             }
-            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-            if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
-            const bf16x8s v = reinterpret_cast<const bf16x8s *>(x + ((img * H + yy) * W + xx) * cin)[g];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xf = (float)v[e];
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int k = 0; k < KO; ++k) acc[e][k] = fmaf(d[k], xf, acc[e][k]);
+                for (int k = 0; k < KO; ++k) bsum[k] += d[u][1][k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xf = (float)v[u][e];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int k = 0; k < KO; ++k) acc[a][e][k] = fmaf(d[u][a][k], xf, acc[a][e][k]);
+                }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int k = 0; k < KO; ++k) red[((ln * workers + wk) * 8 + e) * KO + k] = acc[e][k];
     }
-    __syncthreads();
-    // fold the pixel lanes in order; element (k, c = g*8+e, tap)
-    for (int i = threadIdx.x; i < workers * 8 * KO; i += 256) {
-        const int k = i % KO, e = (i / KO) % 8, w2 = i / (KO * 8);
-        float s = 0.f;
-        for (int l = 0; l < lanes; ++l) s += red[((l * workers + w2) * 8 + e) * KO + k];
-        const int gg = w2 / 9, tt = w2 % 9;
-        partial[(((int64_t)blockIdx.x * KO + k) * cin + gg * 8 + e) * 9 + tt] = s;
-    }
-    // bias gradient: worker 0 of every lane holds a partial sum
-    __syncthreads();
-    if (wk == 0 && ln < lanes) {
+    for (int off = 1; off < LN; off <<= 1) {
 #pragma unroll
-        for (int k = 0; k < KO; ++k) red[ln * KO + k] = bsum[k];
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int k = 0; k < KO; ++k) acc[a][e][k] += __shfl_xor(acc[a][e][k], off);
+#pragma unroll
+        for (int k = 0; k < KO; ++k) bsum[k] += __shfl_xor(bsum[k], off);
     }
-    __syncthreads();
-    if (threadIdx.x < KO) {
-        float s = 0.f;
-        for (int l = 0; l < lanes; ++l) s += red[l * KO + threadIdx.x];
-        partial_b[(int64_t)blockIdx.x * KO + threadIdx.x] = s;
+    const int n_w = KO * cin * 9;
+    float *out = partial + (int64_t)blockIdx.x * (n_w + KO);
+    if (ln == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int k = 0; k < KO; ++k) out[(k * cin + g * 8 + e) * 9 + (ty + 1) * 3 + a] = acc[a][e][k];
+        if (ty == 0 && g == 0) {
+#pragma unroll
+            for (int k = 0; k < KO; ++k) out[n_w + k] = bsum[k];
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void smallconv_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ partial_b, int blocks,
-                                                                     int n_w, int ko, float *__restrict__ dw, float *__restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_w) {
-        float s = 0.f;
-        for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * n_w + i];
-        dw[i] = s;
-    } else if (i < n_w + ko && db) {
-        const int k = i - n_w;
-        float s = 0.f;
-        for (int b = 0; b < blocks; ++b) s += partial_b[(int64_t)b * ko + k];
-        db[k] = s;
+// 16 elements per block, 16 slices of the partial rows each, folded in a fixed order
+__global__ __launch_bounds__(256) void smallconv_wgrad_reduce_kernel(const float *__restrict__ partial, int blocks, int n_w, int ko,
+                                                                     float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float fold[16][16];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4, i = blockIdx.x * 16 + el, row = n_w + ko;
+    float s = 0.f;
+    if (i < row)
+        for (int b = sl; b < blocks; b += 16) s += partial[(int64_t)b * row + i];
+    fold[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && i < row) {
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) r += fold[q][el];
+        if (i < n_w) dw[i] = r;
+        else if (db) db[i - n_w] = r;
     }
 }
 
-static bool sc_ok(int cin, int ko) { return cin >= 8 && cin % 8 == 0 && cin <= SC_MAX_CIN && ko >= 1 && ko <= 4; }
+static bool sc_ok(int cin, int ko) { return cin >= 8 && cin <= SC_MAX_CIN && (cin & (cin - 1)) == 0 && ko >= 1 && ko <= 4; }
+static int sc_log2_groups(int cin) {
+    int lg = 0;
+    while ((8 << lg) < cin) ++lg;
+    return lg;
+}
 
 }  // namespace s2d
 
@@ -189,10 +282,12 @@ extern "C" int s2d_smallconv3x3_fwd(const void *x, const float *weight, const fl
         set_error("smallconv3x3: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
-    const int64_t total = (int64_t)n_img * h * w;
+    const int lg = sc_log2_groups(cin);
+    const int64_t total = ((int64_t)n_img * h * ((w + 3) / 4)) << lg;
+    S2D_CHECK_ARG(total < (int64_t)1 << 31, "smallconv3x3: map too large");
     const dim3 grid((unsigned)ceil_div(total, 256)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define S2D_SC_FWD(K) hipLaunchKernelGGL(smallconv_fwd_kernel<K>, grid, blk, 0, st, (const __bf16 *)x, weight, bias, n_img, h, w, cin, y)
+#define S2D_SC_FWD(K) hipLaunchKernelGGL(smallconv_fwd_kernel<K>, grid, blk, 0, st, (const __bf16 *)x, weight, bias, n_img, h, w, cin, lg, y)
     switch (cout) {
         case 1: S2D_SC_FWD(1); break;
         case 2: S2D_SC_FWD(2); break;
@@ -209,10 +304,12 @@ extern "C" int s2d_smallconv3x3_dgrad(const float *dy, const float *weight, int 
                                       s2d_stream_t stream) {
     S2D_CHECK_ARG(dy && weight && dx && n_img > 0 && h > 0 && w > 0, "smallconv3x3_dgrad: bad argument");
     if (!sc_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
-    const int64_t total = (int64_t)n_img * h * w * (cin / 8);
+    const int lg = sc_log2_groups(cin);
+    const int64_t total = ((int64_t)n_img * h * ((w + 3) / 4)) << lg;
+    S2D_CHECK_ARG(total < (int64_t)1 << 31, "smallconv3x3: map too large");
     const dim3 grid((unsigned)ceil_div(total, 256)), blk(256);
     hipStream_t st = (hipStream_t)stream;
-#define S2D_SC_DG(K) hipLaunchKernelGGL(smallconv_dgrad_kernel<K>, grid, blk, 0, st, dy, weight, n_img, h, w, cin, (__bf16 *)dx)
+#define S2D_SC_DG(K) hipLaunchKernelGGL(smallconv_dgrad_kernel<K>, grid, blk, 0, st, dy, weight, n_img, h, w, cin, lg, (__bf16 *)dx)
     switch (cout) {
         case 1: S2D_SC_DG(1); break;
         case 2: S2D_SC_DG(2); break;
@@ -238,17 +335,13 @@ extern "C" int s2d_smallconv3x3_wgrad(const void *x, const float *dy, int n_img,
         set_error("smallconv3x3_wgrad: workspace too small");
         return S2D_ERR_WORKSPACE;
     }
-    const int64_t total = (int64_t)n_img * h * w;
-    const int blocks = (int)std::min<int64_t>(SC_WG_BLOCKS, ceil_div(total, 64));
-    const int64_t ppb = ceil_div(total, blocks);
-    const int workers = (cin / 8) * 9, lanes = 256 / workers;
-    S2D_CHECK_ARG(lanes >= 1, "smallconv3x3_wgrad: too many input channels");
-    float *partial = (float *)ws, *partial_b = partial + (size_t)SC_WG_BLOCKS * cout * cin * 9;
-    const size_t lds = (size_t)std::max(lanes * workers * 8 * cout, lanes * cout) * sizeof(float);
+    const int n_lines = n_img * h;
+    const int lpb = (int)ceil_div(n_lines, SC_WG_BLOCKS), blocks = (int)ceil_div(n_lines, lpb);
+    const int threads = 3 * (cin / 8) * SC_WG_LANES;
+    float *partial = (float *)ws;
     hipStream_t st = (hipStream_t)stream;
-#define S2D_SC_WG(K)                                                                                                                         \
-    hipLaunchKernelGGL(smallconv_wgrad_kernel<K>, dim3(blocks), dim3(256), lds, st, (const __bf16 *)x, dy, n_img, h, w, cin, ppb, partial, \
-                       partial_b)
+#define S2D_SC_WG(K) \
+    hipLaunchKernelGGL(smallconv_wgrad_kernel<K>, dim3(blocks), dim3(threads), 0, st, (const __bf16 *)x, dy, n_img, h, w, cin, lpb, partial)
     switch (cout) {
         case 1: S2D_SC_WG(1); break;
         case 2: S2D_SC_WG(2); break;
@@ -257,8 +350,8 @@ extern "C" int s2d_smallconv3x3_wgrad(const void *x, const float *dy, int n_img,
     }
 #undef S2D_SC_WG
     const int n_w = cout * cin * 9;
-    hipLaunchKernelGGL(smallconv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(n_w + cout, 256)), dim3(256), 0, st, partial, partial_b, blocks, n_w, cout,
-                       dweight, dbias);
+    hipLaunchKernelGGL(smallconv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(n_w + cout, 16)), dim3(256), 0, st, partial, blocks, n_w, cout, dweight,
+                       dbias);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

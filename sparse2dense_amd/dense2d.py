@@ -370,7 +370,7 @@ class SmallConv3x3(nn.Conv2d):
         return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
                 and torch.get_autocast_gpu_dtype() == torch.bfloat16
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1)
-                and self.groups == 1 and self.in_channels % 8 == 0 and self.in_channels <= 128 and self.out_channels <= 4)
+                and self.groups == 1 and self.in_channels in (8, 16, 32, 64, 128) and self.out_channels <= 4)
 
     def forward(self, x):
         if self._hip_ok(x):
