@@ -476,11 +476,12 @@ def main():
 
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        stack_n = int(os.environ.get("S2D_PROFILE_STACK", "0"))   # > 0: also group by the innermost python frames (who issued the op)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=stack_n > 0) as prof:
             step()
             step()
             torch.cuda.synchronize()
-        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("S2D_PROFILE_ROWS", "70")),
+        print(prof.key_averages(group_by_input_shape=True, group_by_stack_n=stack_n).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("S2D_PROFILE_ROWS", "70")),
                                                                  max_name_column_width=48, max_shapes_column_width=70),
               file=sys.stderr)
 

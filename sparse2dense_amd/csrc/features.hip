@@ -73,6 +73,33 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restric
     }
 }
 
+// first stage for very long partial lists (a producer with one partial row per tile: 10^5..10^6 rows): block = a contiguous run of
+// rows, thread = (row lane, element) so that every load of the block is one contiguous run; fixed-order LDS fold.  out[slice][width]
+__global__ __launch_bounds__(256) void partial_sum_slices_kernel(const float *__restrict__ partial, int nblocks, int width, int rows_per_slice,
+                                                                 float *__restrict__ out) {
+    __shared__ float fold[256];
+    const int lanes = 256 / width, e = threadIdx.x % width, r = threadIdx.x / width;
+    const int64_t b0 = (int64_t)blockIdx.x * rows_per_slice, b1 = b0 + rows_per_slice < nblocks ? b0 + rows_per_slice : nblocks;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (r < lanes) {
+        int64_t b = b0 + r;
+        for (; b + 3 * lanes < b1; b += 4 * lanes) {
+            s0 += partial[b * width + e];
+            s1 += partial[(b + lanes) * width + e];
+            s2 += partial[(b + 2 * lanes) * width + e];
+            s3 += partial[(b + 3 * lanes) * width + e];
+        }
+        for (; b < b1; b += lanes) s0 += partial[b * width + e];
+    }
+    fold[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < width) {
+        float s = 0.f;
+        for (int l = 0; l < lanes; ++l) s += fold[l * width + threadIdx.x];
+        out[(int64_t)blockIdx.x * width + threadIdx.x] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                        const float *__restrict__ shift, const float *__restrict__ res,
                                                        int relu, int64_t n4, int c4, float *__restrict__ y) {
@@ -1069,11 +1096,33 @@ extern "C" int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, i
     return S2D_OK;
 }
 
-extern "C" int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c, float *stats, int write_count,
-                                       s2d_stream_t stream) {
+constexpr int PS_LONG = 8192, PS_SLICES = 1024;   // partial lists longer than PS_LONG rows are folded in two stages
+
+extern "C" size_t s2d_bn_partials_sum_workspace_bytes(int nblocks, int c) {
+    if (nblocks <= PS_LONG || c <= 0 || 2 * c > 256) return 0;
+    return align_up((size_t)PS_SLICES * 2 * c * sizeof(float), 256);
+}
+
+/* stats[2c] (+ count at [2c] when write_count) = column sums of partial[nblocks][2c].  ws (optional, s2d_bn_partials_sum_workspace_bytes):
+ * lets long lists (one row per producer tile) be folded in two stages */
+extern "C" int s2d_bn_partials_sum_ws_f32(const float *partial, int nblocks, int64_t n, int c, float *stats, int write_count, void *ws,
+                                          size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && stats, "bn_partials_sum: bad argument");
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, 2 * c, stats,
-                       (float *)nullptr, write_count ? (float)n : -1.f);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = s2d_bn_partials_sum_workspace_bytes(nblocks, c);
+    if (need && ws && ws_bytes >= need) {
+        const int rps = (int)ceil_div(nblocks, PS_SLICES), slices = (int)ceil_div(nblocks, rps);
+        hipLaunchKernelGGL(partial_sum_slices_kernel, dim3(slices), dim3(256), 0, st, partial, nblocks, 2 * c, rps, (float *)ws);
+        partial = (const float *)ws;
+        nblocks = slices;
+    }
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, nblocks, 2 * c, stats, (float *)nullptr,
+                       write_count ? (float)n : -1.f);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+extern "C" int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c, float *stats, int write_count,
+                                       s2d_stream_t stream) {
+    return s2d_bn_partials_sum_ws_f32(partial, nblocks, n, c, stats, write_count, nullptr, 0, stream);
 }

@@ -44,6 +44,28 @@ static inline unsigned xcd_grid(int64_t tiles) { return (unsigned)(ceil_div(tile
 __device__ __forceinline__ int xcd_tile(int block_id, int grid) { return (block_id % S2D_XCDS) * (grid / S2D_XCDS) + block_id / S2D_XCDS; }
 #endif
 
+// Division of 32-bit unsigned values by a divisor known at launch time (tile index -> coordinates): the multiplier is made on the host,
+// the device does a mul-hi, an add and two shifts instead of the ~30-instruction expansion of an integer division.
+struct FastDiv {
+    uint32_t d, m, s;
+};
+static inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f{d, 0u, 0u};
+    if (d <= 1) return f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;   // ceil(log2 d)
+    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    f.s = l;
+    return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t fastdiv(uint32_t x, const FastDiv &f) {
+    if (f.s == 0) return x;
+    const uint32_t t = __umulhi(x, f.m);
+    return (t + ((x - t) >> 1)) >> (f.s - 1);
+}
+#endif
+
 #if defined(__HIPCC__)
 // Planar (channel-major) tensors through buffer instructions: ONE per-lane 32-bit byte offset plus a scalar offset per access,
 // where flat global pointers cost a 64-bit per-lane address per plane (two VGPRs each: 160 for a 32 + 16 + 32-plane kernel), and

@@ -126,8 +126,9 @@ class _ConvT3dFn(torch.autograd.Function):
                                                  _stream()), "s2d_convt3d_mfma_fwd_stats")
             if bn_stats:
                 stats = torch.empty((2 * cout,), dtype=torch.float32, device=x.device)
-                check(lib.s2d_bn_partials_sum_f32(_ptr(partial), partial.shape[0], out.numel() // cout, cout, _ptr(stats), 0, _stream()),
-                      "s2d_bn_partials_sum_f32")
+                ws = _ws(lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], cout), x.device)   # one row per tile: two-stage fold
+                check(lib.s2d_bn_partials_sum_ws_f32(_ptr(partial), partial.shape[0], out.numel() // cout, cout, _ptr(stats), 0, _ptr(ws),
+                                                     ws.numel(), _stream()), "s2d_bn_partials_sum_ws_f32")
         else:
             check(lib.s2d_convt3d_k4s2p1_fwd_f32(_ptr(x), _ptr(weight), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _stream()),
                   "s2d_convt3d_k4s2p1_fwd_f32")
@@ -176,7 +177,10 @@ class _ConvT3dFn(torch.autograd.Function):
                             sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
                             dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dout.sum(dim=(0, 2, 3, 4))
+            if dout[0, 0].numel() % 4 == 0:   # per-channel sums of a planar tensor: the first half of the BN3d statistics pass
+                db = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, cout, dout[0, 0].numel(), x.device)[:cout]
+            else:
+                db = dout.sum(dim=(0, 2, 3, 4))
         return dx, dw, db, None, None
 
 

@@ -169,7 +169,8 @@ def test_pointwise_conv3d_weight_gradient_bf16_mfma(cin, cout, pos_shape):
     assert (layer.bias.grad.cpu().double() - db).abs().max() <= 2e-5 * db.abs().max() + 1e-4
 
 
-@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (2, 4, 7, 376)), (16, 3, (1, 2, 3, 24))])
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (2, 4, 7, 376)), (16, 3, (1, 2, 3, 24)),
+                                            (16, 3, (2, 8, 47, 188)), (32, 32, (1, 8, 94, 188))])   # last two: > 8192 tiles, two-stage fold
 def test_convtranspose3d_epilogue_batchnorm_statistics(cin, cout, shape):
     """the (sum, sum of squares) per output channel that the MFMA forward kernel's epilogue emits == the sums over the written output,
     and FastBatchNorm3d fed with them == FastBatchNorm3d doing its own statistics pass"""
@@ -191,3 +192,26 @@ def test_convtranspose3d_epilogue_batchnorm_statistics(cin, cout, shape):
     assert (bn_a.running_var - bn_b.running_var).abs().max() <= 1e-6 * bn_b.running_var.abs().max() + 1e-7
     za.sum().backward()                # the two-output autograd node still back-propagates
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("nblocks,c", [(20000, 3), (300001, 32), (9000, 128), (5000, 16), (70000, 200)])
+def test_partial_sums_fold_of_long_lists(nblocks, c):
+    """s2d_bn_partials_sum_ws_f32: column sums of [nblocks][2c] partial rows (two stages above 8192 rows when 2c <= 256) vs float64,
+    bit-identical between runs, count written on request"""
+    from sparse2dense_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(nblocks % 97 + c)
+    part = torch.randn(nblocks, 2 * c, device=DEV)
+    ws_bytes = lib.s2d_bn_partials_sum_workspace_bytes(nblocks, c)
+    assert (ws_bytes > 0) == (nblocks > 8192 and 2 * c <= 256)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        st = torch.full((2 * c + 1,), -7.0, device=DEV)
+        _lib.check(lib.s2d_bn_partials_sum_ws_f32(part.data_ptr(), nblocks, 12345, c, st.data_ptr(), 1, ws.data_ptr(), ws_bytes,
+                                                  torch.cuda.current_stream().cuda_stream), "s2d_bn_partials_sum_ws_f32")
+        outs.append(st)
+    assert torch.equal(outs[0], outs[1])
+    ref = part.double().sum(0)
+    assert (outs[0][:2 * c].double() - ref).abs().max() <= 2e-6 * part.abs().sum(0).max()
+    assert outs[0][2 * c].item() == 12345.0
