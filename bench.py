@@ -64,6 +64,8 @@ def parse():
     p.add_argument("--cpu-points", type=int, default=150000)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--beam-jitter", type=float, default=None, help="scene.make_scene(beam_jitter=...); default scene.WAYMO_BEAM_JITTER")
+    p.add_argument("--prefetch", action="store_true", help="build example k+1 (voxelization, targets, rulebooks) on a second stream from "
+                   "a loader thread while step k runs (data.PrefetchLoader); default: inside the step on the main stream")
     p.add_argument("--torch-profile", action="store_true", help="after the timed region: torch.profiler table of 2 steps "
                    "(ops with input shapes -> stderr); diagnostic only")
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
@@ -146,6 +148,12 @@ def setup_workload(args, workload, dev, rank):
     else:
         frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
                                  distill=(workload != "centerpoint"), device=dev, beam_jitter=jitter)
+    if args.prefetch and dev.type == "cuda" and not workload.startswith("pillar"):
+        # data pipeline overlapped with the step (the reference's DataLoader workers): example k+1 - voxelization, targets, rulebooks -
+        # is built on a second stream by a worker thread while step k runs.  Off by default: measured neutral at B=4 (the step is
+        # device-bound and the launch queue refills right after the row-count reads) and a loss at B=1 (the worker competes for the GIL).
+        from sparse2dense_amd.data import PrefetchLoader
+        frames = PrefetchLoader(frames, backbone=getattr(model, "module", model).backbone)
     optimizer = scheduler = None
     if not args.no_optim:
         # apis/train.py:168-186 + configs `lr_config`: fastai Adam (betas (mom, 0.99), true weight decay 0.01) under OneCycle

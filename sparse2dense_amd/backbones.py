@@ -99,7 +99,12 @@ def build_geometry(coors, batch_size, shape, strided_specs, subm_keys):
 
 def plan_geometry(x: SparseConvTensor, strided_specs, subm_keys):
     """Attach the geometry plan to the tensor's indice_dict — built before the first feature kernel, so that the
-    host reads of N_out happen while the device is otherwise idle."""
+    host reads of N_out happen while the device is otherwise idle.  A plan that the data pipeline already built for these
+    coordinates (data.attach_geometry: `indices._s2d_geometry`) is taken as is."""
+    pre = getattr(x.indices, "_s2d_geometry", None)
+    if pre is not None and pre[0] == tuple(int(s) for s in x.spatial_shape) and pre[1] == x.batch_size:
+        x.indice_dict.update(pre[2])
+        return
     x.indice_dict.update(build_geometry(x.indices, x.batch_size, x.spatial_shape, strided_specs, subm_keys))
 
 

@@ -120,3 +120,91 @@ class SyntheticPillarFrames:
         ex["shape"] = np.stack([self.grid_size] * len(self.points))
         ex.update(self.targets)
         return ex
+
+
+def attach_geometry(example, backbone, keys=("coordinates", "dense_coordinates", "reconstruction_coordinates")):
+    """Build every rulebook of a backbone pass from the coordinates alone (backbones.build_geometry) and hang the plan on the
+    coordinate tensor: the backbone's forward then finds it instead of building it (and reading four row counts) itself."""
+    from .backbones import build_geometry
+    strided, subm = backbone._specs()
+    shape = np.array(example["shape"][0][::-1]) + [1, 0, 0]   # (z + 1, y, x), scn.py:159
+    for key in keys:
+        coors = example.get(key)
+        if coors is None or not coors.is_cuda or coors.dtype != torch.int32:
+            continue
+        batch = len(example[key.replace("coordinates", "num_voxels")])
+        coors._s2d_geometry = (tuple(int(s) for s in shape), batch, build_geometry(coors, batch, shape, strided, subm))
+    return example
+
+
+class PrefetchLoader:
+    """The reference overlaps its data pipeline (voxelization, AssignLabel: DataLoader workers) with the training step; this is the
+    device-side equivalent.  A worker thread builds example k+1 on a second HIP stream - device voxelization, target assignment and
+    (with `backbone`) the rulebooks, including the host reads of the row counts those need - while the main thread enqueues step k.
+    The main stream then never waits on the host inside a step, so the launch queue stays ahead of the device.
+
+    Memory hand-over without record_stream(): tensors of example k are allocated on the side stream's pool; a block freed by the
+    main thread is only reused by side-stream work of a LATER prefetch, and every prefetch starts (side.wait_event) behind the
+    main-stream position recorded when it was requested, i.e. behind all work that could still read such a block."""
+
+    def __init__(self, frames, backbone=None, geometry_keys=None):
+        import queue
+        import threading
+        self.frames = frames
+        self.backbone = backbone
+        self.geometry_keys = geometry_keys
+        self.device = frames.device
+        self.side = torch.cuda.Stream(self.device)
+        self._go, self._out = queue.Queue(), queue.Queue()
+        self._closed = False
+        self._thread = threading.Thread(target=self._run, name="s2d-prefetch", daemon=True)
+        self._thread.start()
+        self._request()
+
+    def __getattr__(self, name):   # grid_size, gens, points, ... of the wrapped frames
+        return getattr(self.frames, name)
+
+    def _build(self):
+        ex = self.frames.example()
+        if self.backbone is not None:
+            kw = {} if self.geometry_keys is None else {"keys": self.geometry_keys}
+            attach_geometry(ex, self.backbone, **kw)
+        return ex
+
+    def _request(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._go.put(ev)
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            ev = self._go.get()
+            if ev is None:
+                return
+            try:
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    ex = self._build()
+                    done = torch.cuda.Event()
+                    done.record(self.side)
+                self._out.put((ex, done, None))
+            except BaseException as err:   # surfaced by the next example()
+                self._out.put((None, None, err))
+
+    def example(self):
+        if self._closed:
+            raise RuntimeError("PrefetchLoader is closed")
+        ex, done, err = self._out.get()
+        if err is not None:
+            self._closed = True
+            raise err
+        torch.cuda.current_stream(self.device).wait_event(done)
+        self._request()
+        return ex
+
+    def close(self):
+        if not self._closed:
+            self._closed = True
+            self._go.put(None)
+            self._thread.join(timeout=30)

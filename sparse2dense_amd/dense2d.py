@@ -165,6 +165,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         if bn_stats:
             y, partial = conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride, bn_stats=True)
             ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return y, partial
         return conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride)
 
@@ -270,6 +271,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if bn_stats:
             y, partial = conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout, bn_stats=True)
             ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return y, partial
         return conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout)
 
@@ -404,6 +406,7 @@ class _Conv2x2S2Fn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if bn_stats:
             ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return y, partial
         return y
 

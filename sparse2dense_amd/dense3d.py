@@ -138,6 +138,7 @@ class _ConvT3dFn(torch.autograd.Function):
             if stats is None:   # fp32 kernels: the separate statistics pass
                 stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(out),), n, cout, out[0, 0].numel(), x.device)
             ctx.mark_non_differentiable(stats)
+            ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return out, stats
         return out
 
