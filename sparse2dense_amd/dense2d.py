@@ -350,7 +350,7 @@ class _SmallConv3x3Fn(torch.autograd.Function):
         wf = weight.detach().float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=xb.device).contiguous(memory_format=torch.channels_last)
+            dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
             check(lib.s2d_smallconv3x3_dgrad(_ptr(dyf), _ptr(wf), n, h, w, cin, cout, _ptr(dx), _stream()), "s2d_smallconv3x3_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dwf = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xb.device)

@@ -68,11 +68,8 @@ class SingleStageDetector(nn.Module):
             out = module(x)
         f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
         if isinstance(out, (tuple, list)):
-            conv = [({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for o in out]
-            if keep_first and torch.is_tensor(out[0]):
-                conv[0] = out[0]
-            for i in keep:
-                conv[i] = out[i]
+            kept = set(keep) | ({0} if keep_first and torch.is_tensor(out[0]) else set())   # never upcast (and drop) a kept map
+            conv = [o if i in kept else ({k: f32(v) for k, v in o.items()} if isinstance(o, dict) else f32(o)) for i, o in enumerate(out)]
             return type(out)(conv)
         return out if keep_first and torch.is_tensor(out) else f32(out)
 
