@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void ct_pack_fwd_kernel(const float *__restric
 // kx = kk >> 3, co = kk & 7.  column n -> ci = nt*16 + n.
 // direct = 1 (the no-LDS kernel): K index kk <-> co = 8*kstep + 2*(kk >> 3) + ((kk & 7) >> 2), kx = kk & 3: a lane's 8 elements are the four
 // kx samples of two channels = two 16-byte loads at position 2c-1.
+// direct = 2 (cout <= 4): entry = (kz, ky pair); K index kk <-> ky = 2*pair + (kk >> 4), co = 2*((kk >> 3) & 1) + ((kk & 7) >> 2), kx = kk & 3:
+// all four lane groups carry data (with the direct = 1 mapping 5 of the 8 channel slots of a 3-channel layer are empty).
 __global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restrict__ w, int cin, int cout, int cop, int nt_count, int direct,
                                                             __bf16 *__restrict__ out) {
     const int ksteps = cop == 32 ? 4 : 1;
@@ -82,10 +84,16 @@ __global__ __launch_bounds__(256) void ct_pack_dgrad_kernel(const float *__restr
     const int kzky = r;
     const int kk = 8 * (lane >> 4) + e;
     const int kx = direct ? (kk & 3) : (cop == 32 ? ks : (kk >> 3));
-    const int co = direct ? 8 * ks + 2 * (kk >> 3) + ((kk & 7) >> 2) : (cop == 32 ? kk : (kk & 7));
+    int co = direct ? 8 * ks + 2 * (kk >> 3) + ((kk & 7) >> 2) : (cop == 32 ? kk : (kk & 7));
+    int kz = kzky >> 2, ky = kzky & 3;
+    if (direct == 2) {   // <= 4 output channels: K = (2 ky) x (2 channel pairs) x (4 kx); entry = kz * 2 + ky pair, 8 entries used
+        kz = kzky >> 1;
+        ky = 2 * (kzky & 1) + (kk >> 4);
+        co = kzky < 8 ? 2 * ((kk >> 3) & 1) + ((kk & 7) >> 2) : cout;
+    }
     const int ci = nt * 16 + (lane & 15);
     float v = 0.f;
-    if (co < cout && ci < cin) v = w[((((int64_t)ci * cout + co) * 4 + (kzky >> 2)) * 4 + (kzky & 3)) * 4 + kx];
+    if (co < cout && ci < cin) v = w[((((int64_t)ci * cout + co) * 4 + kz) * 4 + ky) * 4 + kx];
     out[i] = (__bf16)v;
 }
 
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restr
 // (L1) feeds MT MFMAs.  The staged kernel above holds 32-64 KB of LDS per block and waits for memory once per staging round
 // (1.9 ms for the 16 -> 3 layer at [4,16,10,376,376] against a 0.2 ms stream); a first direct version with dword loads (one
 // per channel and kx) ran at ~70 clocks per load instruction: 1.9 / 1.5 ms.
-template <int COP, int NT, int MT>
+template <int COP, int NT, int MT, bool N4 = false>
 __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
                                                               CtTileMap map, float *__restrict__ din) {
     constexpr int KSTEPS = COP == 32 ? 4 : 1;
@@ -473,19 +481,21 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
             pos[mt] = c < s.w ? (unsigned)((2 * c - (c == 0 ? 0 : 1)) * 4) : CT_OOB;
         }
 #pragma unroll 2
-        for (int kzky = 0; kzky < 16; ++kzky) {
-            const int z = 2 * hz - 1 + (kzky >> 2), y = 2 * hy - 1 + (kzky & 3);
-            const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform
-            const unsigned soff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+        for (int kzky = 0; kzky < (N4 ? 8 : 16); ++kzky) {
+            // N4 (cout <= 4): the lane groups q = (ky of a pair, channel pair) - the row is per lane and goes into the lane offset
+            const int z = 2 * hz - 1 + (N4 ? kzky >> 1 : kzky >> 2), y = 2 * hy - 1 + (N4 ? 2 * (kzky & 1) + (q >> 1) : kzky & 3);
+            const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform unless N4
+            const unsigned roff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+            const unsigned soff = N4 ? 0u : roff;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 bf16x8m bfr[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bfr[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
-                const int co0 = 8 * ks + 2 * q;
-                const unsigned pl0 = (rok && co0 < s.cout) ? (unsigned)co0 * oplane_b : CT_OOB;
-                const unsigned pl1 = (rok && co0 + 1 < s.cout) ? (unsigned)(co0 + 1) * oplane_b : CT_OOB;
+                const int co0 = N4 ? 2 * (q & 1) : 8 * ks + 2 * q;
+                const unsigned pl0 = (rok && co0 < s.cout) ? (unsigned)co0 * oplane_b + (N4 ? roff : 0u) : CT_OOB;
+                const unsigned pl1 = (rok && co0 + 1 < s.cout) ? (unsigned)(co0 + 1) * oplane_b + (N4 ? roff : 0u) : CT_OOB;
                 f32x4m v0[MT], v1[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -943,7 +953,7 @@ extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int c
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ct_pack_fwd_kernel, dim3((n_f + 255) / 256), dim3(256), 0, st, weight, cin, cout, nt_f, (__bf16 *)packed);
     hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, 0, (__bf16 *)packed + n_f);
-    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, 1,
+    hipLaunchKernelGGL(ct_pack_dgrad_kernel, dim3((n_d + 255) / 256), dim3(256), 0, st, weight, cin, cout, cop, nt_d, cout <= 4 ? 2 : 1,
                        (__bf16 *)packed + n_f + n_d);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1003,7 +1013,9 @@ extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int
         // live across a z step: 4 z planes x (2 yc + 2) rows of dout, cout planes each
         const CtTileMap map = ct_tile_map(d, h, tpr, ct_chunk_rows((int64_t)2 * w * cout * 4, 2, 2, 4));
         const __bf16 *wd = wp + (size_t)16 * (narrow ? 1 : 4) * (cin / 16) * 512;   // the direct kernel's image follows the staged one
-        if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+        if (narrow && cout <= 4 && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, true>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+        else if (narrow && cout <= 4) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, true>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+        else if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
         else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
         else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
         else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);

@@ -104,7 +104,7 @@ def test_channel_major_batchnorm3d(c, shape, relu, train):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (1, 4, 7, 66)), (32, 3, (1, 2, 5, 9)), (16, 32, (2, 2, 3, 130)),
                                             (32, 32, (1, 5, 20, 188)), (16, 3, (1, 3, 9, 376)), (32, 3, (2, 2, 3, 40)), (16, 3, (2, 2, 3, 24)),
-                                            (16, 2, (1, 1, 1, 8))])
+                                            (16, 2, (1, 1, 1, 8)), (16, 6, (1, 2, 3, 24)), (32, 4, (1, 3, 2, 70))])   # 5..8 channels: the channel-pair mapping
 def test_convtranspose3d_bf16_mfma(cin, cout, shape):
     torch.manual_seed(cin * 5 + cout)
     n, d, h, w = shape
