@@ -260,6 +260,56 @@ def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
     return (y, partial) if bn_stats else y
 
 
+def _pack_matrix_1x1(owner, tag, make, transpose=False):
+    """fp32 [out, in] matrix derived from parameter `owner` (a 2x2 kernel seen as a 1x1 conv over 4x the channels) -> the 1x1 kernels'
+    weight image, cached per version of the parameter"""
+    def build():
+        lib = _lib.load()
+        m = make().detach().float().contiguous()
+        out_c, in_c = m.shape
+        packed = torch.empty(out_c * in_c, dtype=torch.bfloat16, device=m.device)
+        pc_in, pc_out = (out_c, in_c) if transpose else (in_c, out_c)
+        check(lib.s2d_conv2d1x1_pack_weights_bf16(_ptr(m), pc_in, pc_out, int(transpose), _ptr(packed), _stream()),
+              "s2d_conv2d1x1_pack_weights_bf16")
+        return packed
+    return cached_pack(owner, tag, build)
+
+
+def _space_to_depth(t):
+    """NHWC [n, c, 2h, 2w] -> NHWC [n, 4c, h, w], channel = (py, px, c): the four pixels of a 2x2 block side by side"""
+    n, c, hh, ww = t.shape
+    v = t.permute(0, 2, 3, 1).reshape(n, hh // 2, 2, ww // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, hh // 2, ww // 2, 4 * c)
+    return v.permute(0, 3, 1, 2)
+
+
+def _depth_to_space(t, c):
+    """inverse of _space_to_depth: NHWC [n, 4c, h, w] -> NHWC [n, c, 2h, 2w]"""
+    n, _, h, w = t.shape
+    v = t.permute(0, 2, 3, 1).reshape(n, h, w, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, c)
+    return v.permute(0, 3, 1, 2)
+
+
+def _wgrad_1x1(xb, dyb, cin, cout):
+    """fp32 [cout, cin] = sum over pixels of dy (x) x, both bf16 NHWC"""
+    lib = _lib.load()
+    n, _, h, w = xb.shape
+    dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
+    ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
+    check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(ws),
+                                            ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
+    return dwf
+
+
+def _channel_sums(dyb):
+    """per-channel sum of a bf16 NHWC map (bias gradient): first half of the row-reduce kernel's output"""
+    lib = _lib.load()
+    n, c, h, w = dyb.shape
+    stats = torch.empty((2 * c,), dtype=torch.float32, device=dyb.device)
+    ws = _ws(lib.s2d_bnrow_workspace_bytes(n * h * w, c), dyb.device)
+    check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), n * h * w, c, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
+    return stats[:c]
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_stats):
@@ -412,18 +462,25 @@ class _Conv2x2S2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        # a 2x2 / stride-2 conv is a 1x1 conv over the space-to-depth image: both gradients run the 1x1 tile kernels
         xb, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
         dyb = _nhwc_bf16(dy)
-        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dx, dwb, dbb = torch.ops.aten.convolution_backward(dyb, xb, wb, [weight.shape[0]] if ctx.has_bias else None, [2, 2], [0, 0], [1, 1], False,
-                                                           [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                                                       bool(ctx.has_bias and ctx.needs_input_grad[2])])
-        return dx, None if dwb is None else dwb.to(weight.dtype), None if dbb is None else dbb.float(), None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:   # dy [.., cout] x Wd [(py, px, ci), cout] -> the four pixels of every 2x2 block, then depth-to-space
+            packed = _pack_matrix_1x1(weight, ("conv2x2s2", "dgrad"), lambda: weight.permute(2, 3, 1, 0).reshape(4 * cin, cout))
+            dx = _depth_to_space(conv1x1_nhwc(dyb, packed, None, cout, 4 * cin), cin)
+        if ctx.needs_input_grad[1]:
+            dwf = _wgrad_1x1(_space_to_depth(xb), dyb, 4 * cin, cout)   # [cout, (py, px, ci)]
+            dw = dwf.reshape(cout, 2, 2, cin).permute(0, 3, 1, 2).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sums(dyb)
+        return dx, dw, db, None
 
 
 class Conv2x2S2(nn.Conv2d):
     """nn.Conv2d(cin, cout, 2, stride 2) (same parameters / state_dict keys): the forward (with the batch-norm statistics of a following
-    FastBatchNorm2d) runs the NHWC tile kernel with 4 taps; the backward stays with the library."""
+    FastBatchNorm2d) runs the NHWC tile kernel with 4 taps; the backward = 1x1 kernels over the space-to-depth image."""
 
     emit_bn_stats = False
 
@@ -678,6 +735,55 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         if int(relu) == 2:
             return torch.nn.functional.gelu(y)
         return torch.relu(y) if relu else y
+
+
+class _ConvT2x2S2Fn(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2): a 1x1 conv to 4x the channels (py, px, co) followed by depth-to-space"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xb = _nhwc_bf16(x)
+        cin, cout = weight.shape[0], weight.shape[1]
+        packed = _pack_matrix_1x1(weight, ("convt2x2s2", "fwd"), lambda: weight.permute(2, 3, 1, 0).reshape(4 * cout, cin))
+        b4 = None if bias is None else bias.detach().float().repeat(4).contiguous()
+        y = _depth_to_space(conv1x1_nhwc(xb, packed, b4, cin, 4 * cout), cout)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, weight = ctx.saved_tensors
+        cin, cout = weight.shape[0], weight.shape[1]
+        dyb = _nhwc_bf16(dy)
+        dys = _space_to_depth(dyb)   # [n, (py, px, co), h, w]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            packed = _pack_matrix_1x1(weight, ("convt2x2s2", "dgrad"), lambda: weight.permute(2, 3, 1, 0).reshape(4 * cout, cin), transpose=True)
+            dx = conv1x1_nhwc(dys, packed, None, 4 * cout, cin)
+        if ctx.needs_input_grad[1]:
+            dwf = _wgrad_1x1(xb, dys, cin, 4 * cout)   # [(py, px, co), ci]
+            dw = dwf.reshape(2, 2, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sums(dyb)
+        return dx, dw, db
+
+
+class ConvT2x2S2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(cin, cout, 2, stride 2) (same parameters / state_dict keys): the RPN's up-sampling deblock
+    (/root/reference/det3d/models/necks/rpn.py:84-113).  CUDA inputs under bf16 autocast with channel counts that are multiples of 64
+    run as a 1x1 conv on the NHWC tile kernels plus a depth-to-space pass; anything else is the stock layer."""
+
+    def _hip_ok(self, x):
+        return (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and self.output_padding == (0, 0)
+                and self.dilation == (1, 1) and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0)
+
+    def forward(self, x, output_size=None):
+        if output_size is None and self._hip_ok(x):
+            return _ConvT2x2S2Fn.apply(x, self.weight, self.bias)
+        return super().forward(x, output_size)
 
 
 def fuse_bn_relu(layers):

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .heads import pcr_level, pcr_level_norm, pcr_level_supported
 from .registry import NECKS
@@ -59,7 +59,7 @@ class RPN(nn.Module):
                 continue
             up = us_layer_strides[j]
             if up > 1:
-                conv = nn.ConvTranspose2d(ds_num_filters[i], us_num_filters[j], up, stride=up, bias=False)
+                conv = (ConvT2x2S2 if up == 2 else nn.ConvTranspose2d)(ds_num_filters[i], us_num_filters[j], up, stride=up, bias=False)
             else:
                 down = int(np.round(1 / up))
                 conv = (Conv1x1 if down == 1 else nn.Conv2d)(ds_num_filters[i], us_num_filters[j], down, stride=down, bias=False)
