@@ -521,6 +521,22 @@ int s2d_lnwide_bwd_bf16(const void *dy, const void *x, const float *weight, cons
                         int64_t row, void *dx, float *dweight, float *dbias, void *ws, size_t ws_bytes,
                         s2d_stream_t stream);
 
+/* CenterHead losses on the device maps (csrc/center_loss.hip), one pass per direction; they replace the torch-op chains of
+ * FastFocalLoss / RegLoss (/root/reference/det3d/models/losses/centernet_loss.py:33-54 and :9-31; call site
+ * /root/reference/det3d/models/bbox_heads/center_head.py:236-283).  out / target / feat: fp32 [batch][c][hw] contiguous; ind, cat: int64
+ * [batch][max_objs]; mask: uint8 [batch][max_objs]; reg target: fp32 [batch][max_objs][channels].
+ * focal res (device, 4 floats): loss = -(pos + neg) / max(num_pos, 1), pos, neg, num_pos.  regloss res (device, channels + 1 floats):
+ * loss per channel, then sum(mask) + 1e-4.  The backward entries scale by the device scalar(s) `go`. */
+size_t s2d_focal_workspace_bytes(void);
+int s2d_focal_fwd(const float *out, const float *target, const int64_t *ind, const uint8_t *mask, const int64_t *cat, int batch, int classes,
+                  int64_t hw, int max_objs, float *res, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_focal_bwd(const float *out, const float *target, const int64_t *ind, const uint8_t *mask, const int64_t *cat, int batch, int classes,
+                  int64_t hw, int max_objs, const float *res, const float *go, float *dout, s2d_stream_t stream);
+int s2d_regloss_fwd(const float *feat, const int64_t *ind, const uint8_t *mask, const float *target, int batch, int channels, int64_t hw,
+                    int max_objs, float *res, s2d_stream_t stream);
+int s2d_regloss_bwd(const float *feat, const int64_t *ind, const uint8_t *mask, const float *target, int batch, int channels, int64_t hw,
+                    int max_objs, const float *res, const float *go, float *dfeat, s2d_stream_t stream);
+
 /*
  * Feature-distillation loss of the S2D step (det3d/torchie/trainer/trainer.py:783-789): w_pos * MSE over teacher > 0 + w_neg * MSE
  * over the rest, between two dense tensors of n elements (n % 8 == 0) in the SAME memory order, bf16 (flag 1) or fp32 (0) each.

@@ -132,6 +132,15 @@ SIGNATURES = {
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_lnwide_bwd_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, c_f32p,
                                            c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_focal_workspace_bytes": (ctypes.c_size_t, []),
+    "s2d_focal_fwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                     ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_focal_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                     ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_regloss_fwd": (ctypes.c_int, [c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                       c_f32p, ctypes.c_void_p]),
+    "s2d_regloss_bwd": (ctypes.c_int, [c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                       c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_masked_mse_workspace_bytes": (ctypes.c_size_t, []),
     "s2d_masked_mse_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                           c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -35,14 +35,85 @@ class RegLoss(nn.Module):
     """L1 of the gathered regression vector at <=max_objs centre indices, per output channel."""
 
     def forward(self, output, mask, ind, target):
+        if _loss_maps_ok(output, ind) and target.is_cuda and target.shape[-1] == output.shape[1]:
+            return _RegLossFn.apply(output, mask, ind, target)
         pred = _transpose_and_gather_feat(output, ind)
         m = mask.float().unsqueeze(2)
         loss = F.l1_loss(pred * m, target * m, reduction="none") / (m.sum() + 1e-4)
         return loss.transpose(2, 0).sum(dim=2).sum(dim=1)
 
 
+def _u8(mask):
+    return mask.view(torch.uint8) if mask.dtype == torch.bool else (mask if mask.dtype == torch.uint8 else (mask != 0).view(torch.uint8))
+
+
+def _loss_maps_ok(feat, ind, *others):
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 4 and feat.is_contiguous() and ind.dtype == torch.int64
+            and all(o.dtype == torch.int64 for o in others))
+
+
+class _FocalFn(torch.autograd.Function):
+    """fast_focal_loss in two launches per direction (csrc/center_loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, out, target, ind, mask, cat):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        lib = _lib.load()
+        b, c, h, w = out.shape
+        target = target.float().contiguous()
+        ind, cat, mask = ind.contiguous(), cat.contiguous(), _u8(mask).contiguous()
+        res = torch.empty(4, dtype=torch.float32, device=out.device)
+        ws = _ws(lib.s2d_focal_workspace_bytes(), out.device)
+        _lib.check(lib.s2d_focal_fwd(_ptr(out), _ptr(target), _ptr(ind), _ptr(mask), _ptr(cat), b, c, h * w, ind.shape[1], _ptr(res), _ptr(ws),
+                                     ws.numel(), _stream()), "s2d_focal_fwd")
+        ctx.save_for_backward(out, target, ind, mask, cat, res)
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        out, target, ind, mask, cat, res = ctx.saved_tensors
+        b, c, h, w = out.shape
+        dout = torch.empty_like(out)
+        _lib.check(_lib.load().s2d_focal_bwd(_ptr(out), _ptr(target), _ptr(ind), _ptr(mask), _ptr(cat), b, c, h * w, ind.shape[1], _ptr(res),
+                                             _ptr(go.float().reshape(1).contiguous()), _ptr(dout), _stream()), "s2d_focal_bwd")
+        return dout, None, None, None, None
+
+
+class _RegLossFn(torch.autograd.Function):
+    """RegLoss in one launch forward, memset + scatter backward (csrc/center_loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, output, mask, ind, target):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        b, c, h, w = output.shape
+        target = target.float().contiguous()
+        ind, mask = ind.contiguous(), _u8(mask).contiguous()
+        res = torch.empty(c + 1, dtype=torch.float32, device=output.device)
+        _lib.check(_lib.load().s2d_regloss_fwd(_ptr(output), _ptr(ind), _ptr(mask), _ptr(target), b, c, h * w, ind.shape[1], _ptr(res), _stream()),
+                   "s2d_regloss_fwd")
+        ctx.save_for_backward(output, mask, ind, target, res)
+        return res[:c]
+
+    @staticmethod
+    def backward(ctx, go):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        output, mask, ind, target, res = ctx.saved_tensors
+        b, c, h, w = output.shape
+        dfeat = torch.empty_like(output)
+        _lib.check(_lib.load().s2d_regloss_bwd(_ptr(output), _ptr(ind), _ptr(mask), _ptr(target), b, c, h * w, ind.shape[1], _ptr(res),
+                                               _ptr(go.float().contiguous()), _ptr(dfeat), _stream()), "s2d_regloss_bwd")
+        return dfeat, None, None, None
+
+
 def fast_focal_loss(out, target, ind, mask, cat):
     """CornerNet focal loss with gathered positives (centernet_loss.py:33-54)."""
+    if _loss_maps_ok(out, ind, cat) and target.shape == out.shape and target.is_cuda:
+        return _FocalFn.apply(out, target, ind, mask, cat)
     mask = mask.float()
     neg = (torch.log(1 - out) * out.pow(2) * (1 - target).pow(4)).sum()
     pos_pix = _transpose_and_gather_feat(out, ind)           # B x M x C
