@@ -143,8 +143,9 @@ class OneCycleAdam:
         assert all(p.dtype == torch.float32 and dense(p) for p in ps), "OneCycleAdam: dense fp32 parameters expected"
         # the kernel pairs elements by storage offset: gradients (and moments, created with preserve_format) must share the
         # parameter's strides - NHWC conv weights (detector.use_channels_last) get their gradient re-laid once here
-        grads = [p.grad if (p.grad.dtype == torch.float32 and p.grad.stride() == p.stride()) else torch.empty_like(p).copy_(p.grad)
-                 for p in ps]
+        # (strides of size-1 dimensions carry no layout: a 1x1 conv weight is the same memory in NCHW and NHWC)
+        same = lambda g, p: all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
+        grads = [p.grad if (p.grad.dtype == torch.float32 and same(p.grad, p)) else torch.empty_like(p).copy_(p.grad) for p in ps]
         states = [self._state(p) for p in ps]
         steps = {st["step"] for st in states}
         assert len(steps) == 1, "OneCycleAdam: parameters must share one step counter"
