@@ -353,6 +353,14 @@ int s2d_spconv_s16_wgrad(const void *in_feat, int64_t n_in, const void *dout, co
 int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_weight,
                        const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
                        int cout, const void *zero_page, void *out_feat, s2d_stream_t stream);
+/* the same with the batch-norm statistics of the layer that follows from the epilogue: stats_partial = fp32
+ * [s2d_spconv_s16_stats_tiles(n_out, kvol, cin, cout)][2][cout], per-workgroup (sum, sum of squares) of the stored bf16 rows, folded by
+ * s2d_bn_partials_finalize_f32 / s2d_bn_partials_sum_f32 (replaces the separate statistics pass of spconv's conv -> BatchNorm1d pairs,
+ * /root/reference/det3d/models/backbones/scn.py:60-90) */
+int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout);
+int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr,
+                             int64_t n_out, int kvol, int cin, int cout, const void *zero_page, void *out_feat, float *stats_partial,
+                             s2d_stream_t stream);
 
 /*
  * Submanifold 3x3x3 sparse convolution, bf16 storage, "neighbourhood-resident" implicit GEMM (csrc/spconv_nb.hip): same

@@ -206,6 +206,10 @@ SIGNATURES = {
     "s2d_spconv_s16_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, ctypes.c_int64,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p]),
+    "s2d_spconv_s16_stats_tiles": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "s2d_spconv_s16_fwd_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, ctypes.c_int64,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_f32p,
+                                                ctypes.c_void_p]),
     "s2d_conv2d3x3_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_conv2d3x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_conv2d3x3_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 +

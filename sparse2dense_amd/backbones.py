@@ -69,6 +69,7 @@ class SparseBasicBlock(SparseModule):
         self.bn2 = build_norm_layer(norm_cfg, planes)[1]
         self.downsample = downsample
         self.stride = stride
+        self.conv1.emit_bn_stats = self.conv2.emit_bn_stats = True   # bn1 / bn2 take their statistics from the conv epilogues
 
     def forward(self, x):
         out = self.conv1(x)

@@ -86,35 +86,74 @@ __global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__
 
 template <int CIN, int COUT, int BM, int MI_, int NJ_>
 __device__ __forceinline__ void s16_epilogue(f32x4s (&acc)[MI_][NJ_], const float *__restrict__ bias, __bf16 *__restrict__ out,
-                                             int row0, int row_end, int wm, int wn, int r, int q) {
+                                             int row0, int row_end, int wm, int wn, int r, int q, float *__restrict__ stats_partial,
+                                             int tile, char *smem) {
     typedef S16Cfg<CIN, COUT, BM> C;
     static_assert(MI_ == C::MI && NJ_ == C::NJ, "tile shape");
     // epilogue: C/D layout row = 4*(lane>>4)+reg, col = lane&15 -> columns co_base + r*NJ + jn (NJ consecutive)
+    // stats_partial (optional): per-workgroup (sum, sum of squares) of the STORED bf16 rows per output channel, [tile][2][COUT] - the
+    // partial-sum rows the batch-norm finalize kernel consumes, so the BatchNorm1d behind this conv skips its statistics pass
+    // (same scheme as the dense 3x3 kernel's epilogue; fixed summation order)
     const int co_base = wn * (COUT / C::WN);
-    float bv[C::NJ];
+    float bv[C::NJ], s1[C::NJ], s2[C::NJ];
 #pragma unroll
-    for (int jn = 0; jn < C::NJ; ++jn) bv[jn] = bias ? bias[co_base + r * C::NJ + jn] : 0.f;
+    for (int jn = 0; jn < C::NJ; ++jn) {
+        bv[jn] = bias ? bias[co_base + r * C::NJ + jn] : 0.f;
+        s1[jn] = 0.f;
+        s2[jn] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < C::MI; ++i)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = row0 + wm * 16 * C::MI + 16 * i + 4 * q + reg;
             if (row < row_end) {
+                __bf16 v[C::NJ];
+#pragma unroll
+                for (int jn = 0; jn < C::NJ; ++jn) {
+                    v[jn] = (__bf16)(acc[i][jn][reg] + bv[jn]);
+                    const float f = (float)v[jn];
+                    s1[jn] += f;
+                    s2[jn] += f * f;
+                }
                 __bf16 *dst = out + (int64_t)row * COUT + co_base + r * C::NJ;
                 if (C::NJ == 4) {
-                    bf16x4s v;
-                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % C::NJ][reg] + bv[1 % C::NJ]);
-                    v[2] = (__bf16)(acc[i][2 % C::NJ][reg] + bv[2 % C::NJ]); v[3] = (__bf16)(acc[i][3 % C::NJ][reg] + bv[3 % C::NJ]);
-                    *reinterpret_cast<bf16x4s *>(dst) = v;
+                    bf16x4s o;
+                    o[0] = v[0]; o[1] = v[1 % C::NJ]; o[2] = v[2 % C::NJ]; o[3] = v[3 % C::NJ];
+                    *reinterpret_cast<bf16x4s *>(dst) = o;
                 } else if (C::NJ == 2) {
-                    bf16x2s v;
-                    v[0] = (__bf16)(acc[i][0][reg] + bv[0]); v[1] = (__bf16)(acc[i][1 % C::NJ][reg] + bv[1 % C::NJ]);
-                    *reinterpret_cast<bf16x2s *>(dst) = v;
+                    bf16x2s o;
+                    o[0] = v[0]; o[1] = v[1 % C::NJ];
+                    *reinterpret_cast<bf16x2s *>(dst) = o;
                 } else {
-                    dst[0] = (__bf16)(acc[i][0][reg] + bv[0]);
+                    dst[0] = v[0];
                 }
             }
         }
+    if (stats_partial) {   // block-uniform
+#pragma unroll
+        for (int jn = 0; jn < C::NJ; ++jn) {   // lanes with the same r hold the same columns: fold the four q groups
+            s1[jn] += __shfl_xor(s1[jn], 16, 64); s1[jn] += __shfl_xor(s1[jn], 32, 64);
+            s2[jn] += __shfl_xor(s2[jn], 16, 64); s2[jn] += __shfl_xor(s2[jn], 32, 64);
+        }
+        float *red = reinterpret_cast<float *>(smem);   // [WM][2][COUT]; every wave is out of the K loop: its buffers are free
+        __syncthreads();
+        if (q == 0) {
+#pragma unroll
+            for (int jn = 0; jn < C::NJ; ++jn) {
+                red[(wm * 2 + 0) * COUT + co_base + r * C::NJ + jn] = s1[jn];
+                red[(wm * 2 + 1) * COUT + co_base + r * C::NJ + jn] = s2[jn];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * COUT; e += 256) {
+            const int which = e / COUT, col = e - which * COUT;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WM; ++w) s += red[(w * 2 + which) * COUT + col];
+            stats_partial[((int64_t)tile * 2 + which) * COUT + col] = s;
+        }
+    }
 }
 
 // Prologue shared by the forward kernels: the workgroup's slice of the gather map -> idx_lds [kslots][BM] (one coalesced
@@ -149,7 +188,7 @@ template <int CIN, int COUT, int BM>
 __global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__restrict__ in, const __bf16 *__restrict__ wpack,
                                                              const float *__restrict__ bias, const int32_t *__restrict__ nbr,
                                                              const __bf16 *__restrict__ zero_page, int n_out, int kvol,
-                                                             int rows_per_block, __bf16 *__restrict__ out) {
+                                                             int rows_per_block, __bf16 *__restrict__ out, float *__restrict__ stats_partial) {
     // rows_per_block <= BM (multiple of 16): the launcher shrinks it so that the grid fills whole rounds of resident
     // workgroups; the tiles past it stay unmarked and are skipped.
     typedef S16Cfg<CIN, COUT, BM> C;
@@ -164,7 +203,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__res
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wid / C::WN, wn = wid % C::WN;
     const int r = lane & 15, q = lane >> 4;
-    const int row0 = xcd_tile(blockIdx.x, gridDim.x) * rows_per_block;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int row0 = tile * rows_per_block;
     if (row0 >= n_out) return;
     const int row_end = min(n_out, row0 + rows_per_block);
     const int steps = s16_steps(CIN, kvol);
@@ -243,7 +283,7 @@ __global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__res
         __syncthreads();
     }
 
-    s16_epilogue<CIN, COUT, BM, C::MI, C::NJ>(acc, bias, out, row0, row_end, wm, wn, r, q);
+    s16_epilogue<CIN, COUT, BM, C::MI, C::NJ>(acc, bias, out, row0, row_end, wm, wn, r, q, stats_partial, tile, smem);
 }
 
 // Measured and dropped (r01): a variant with 32-channel K-steps on a 3-slot ring (manual vmcnt waits, three workgroups
@@ -284,7 +324,7 @@ static S16Plan s16_plan(int64_t n_out, int kvol, int cin, int cout) {
 
 template <int CIN, int COUT, int BM>
 static int s16_launch(const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias, const int32_t *nbr,
-                      const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
+                      const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, float *stats, hipStream_t st) {
     typedef S16Cfg<CIN, COUT, BM> C;
     auto kern = spconv_fwd_s16_kernel<CIN, COUT, BM>;
     static size_t attr_bytes = 48 * 1024;   // per instantiation; raising the limit is idempotent if raced
@@ -294,28 +334,28 @@ static int s16_launch(const S16Plan &p, const __bf16 *in, const __bf16 *wpack, c
         attr_bytes = lds;
     }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(p.grid)), dim3(256), lds, st, in, wpack, bias, nbr, zero_page, n_out, kvol,
-                       p.rows_per_block, out);
+                       p.rows_per_block, out, stats);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
 template <int CIN, int COUT>
 static int s16_dispatch_bm(const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias, const int32_t *nbr,
-                           const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
-    if (p.bm == 64) return s16_launch<CIN, COUT, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
-    if (p.bm == 128) return s16_launch<CIN, COUT, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
-    if constexpr (COUT != 128) return s16_launch<CIN, COUT, 256>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+                           const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, float *stats, hipStream_t st) {
+    if (p.bm == 64) return s16_launch<CIN, COUT, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
+    if (p.bm == 128) return s16_launch<CIN, COUT, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
+    if constexpr (COUT != 128) return s16_launch<CIN, COUT, 256>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
     return S2D_ERR_UNSUPPORTED;
 }
 
 template <int CIN>
 static int s16_dispatch_cout(int cout, const S16Plan &p, const __bf16 *in, const __bf16 *wpack, const float *bias,
-                             const int32_t *nbr, const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, hipStream_t st) {
+                             const int32_t *nbr, const __bf16 *zero_page, int n_out, int kvol, __bf16 *out, float *stats, hipStream_t st) {
     switch (cout) {
-        case 16: return s16_dispatch_bm<CIN, 16>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
-        case 32: return s16_dispatch_bm<CIN, 32>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
-        case 64: return s16_dispatch_bm<CIN, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
-        case 128: return s16_dispatch_bm<CIN, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, st);
+        case 16: return s16_dispatch_bm<CIN, 16>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
+        case 32: return s16_dispatch_bm<CIN, 32>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
+        case 64: return s16_dispatch_bm<CIN, 64>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
+        case 128: return s16_dispatch_bm<CIN, 128>(p, in, wpack, bias, nbr, zero_page, n_out, kvol, out, stats, st);
     }
     return S2D_ERR_UNSUPPORTED;
 }
@@ -347,9 +387,27 @@ extern "C" int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int ci
     return S2D_OK;
 }
 
+/* rows of the per-workgroup statistics s2d_spconv_s16_fwd_stats writes for a launch over n_out rows */
+extern "C" int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout) {
+    if (n_out <= 0 || kvol <= 0 || !s2d_spconv_s16_supported(cin, cout)) return 0;
+    return (int64_t)s16_plan(n_out, kvol, cin, cout).grid;
+}
+
+extern "C" int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr,
+                                        int64_t n_out, int kvol, int cin, int cout, const void *zero_page, void *out_feat,
+                                        float *stats_partial, s2d_stream_t stream);
+
 extern "C" int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias,
                                   const int32_t *nbr, int64_t n_out, int kvol, int cin, int cout, const void *zero_page,
                                   void *out_feat, s2d_stream_t stream) {
+    return s2d_spconv_s16_fwd_stats(in_feat, n_in, packed_weight, bias, nbr, n_out, kvol, cin, cout, zero_page, out_feat, nullptr, stream);
+}
+
+/* stats_partial (optional, fp32 [s2d_spconv_s16_stats_tiles][2][cout]): per-workgroup (sum, sum of squares) per output channel of the
+ * stored rows - the statistics pass of the BatchNorm1d that follows (s2d_bn_partials_finalize_f32 / _sum_f32 fold them) */
+extern "C" int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr,
+                                        int64_t n_out, int kvol, int cin, int cout, const void *zero_page, void *out_feat,
+                                        float *stats_partial, s2d_stream_t stream) {
     S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0, "spconv_s16_fwd: bad sizes");
     if (!s2d_spconv_s16_supported(cin, cout)) {
         set_error("spconv_s16_fwd: unsupported channels %d -> %d", cin, cout);
@@ -362,10 +420,10 @@ extern "C" int s2d_spconv_s16_fwd(const void *in_feat, int64_t n_in, const void 
     __bf16 *out = (__bf16 *)out_feat;
     const S16Plan plan = s16_plan(n_out, kvol, cin, cout);
     switch (cin) {
-        case 16: return s16_dispatch_cout<16>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
-        case 32: return s16_dispatch_cout<32>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
-        case 64: return s16_dispatch_cout<64>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
-        case 128: return s16_dispatch_cout<128>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, st);
+        case 16: return s16_dispatch_cout<16>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, stats_partial, st);
+        case 32: return s16_dispatch_cout<32>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, stats_partial, st);
+        case 64: return s16_dispatch_cout<64>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, stats_partial, st);
+        case 128: return s16_dispatch_cout<128>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, stats_partial, st);
     }
     return S2D_ERR_UNSUPPORTED;
 }

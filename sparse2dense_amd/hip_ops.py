@@ -511,21 +511,26 @@ def spconv_s16_pack(weight_kio, n_out, transpose=False, flip=False):
     return packed, kvol, cin, cout
 
 
-def spconv_s16_run(feat, packed, kvol, cin, cout, bias, nbr, n_out, pair_count=None, tag="fwd"):
+def spconv_s16_run(feat, packed, kvol, cin, cout, bias, nbr, n_out, pair_count=None, tag="fwd", bn_stats=False):
+    """bn_stats: also return the per-workgroup (sum, sum of squares) rows [tiles, 2, cout] of the stored output - the statistics pass of
+    the BatchNorm1d that follows, done in the epilogue"""
     lib = _lib.load()
     assert feat.dtype == torch.bfloat16 and feat.shape[1] == cin and feat.is_contiguous()
     out = torch.empty((n_out, cout), dtype=torch.bfloat16, device=feat.device)
+    partial = None
+    if bn_stats and n_out > 0:
+        partial = torch.empty((lib.s2d_spconv_s16_stats_tiles(int(n_out), kvol, cin, cout), 2, cout), dtype=torch.float32, device=feat.device)
     rec = None
     if PROFILE is not None:
         rec = dict(kernel="spconv_fwd_s16", tag=tag, cin=cin, cout=cout, n_out=int(n_out), kvol=kvol, pairs=pair_count,
                    elem_bytes=2, start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
-    check(lib.s2d_spconv_s16_fwd(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(bias), _ptr(nbr), int(n_out), kvol, cin, cout,
-                                 _ptr(zero_page(feat.device)), _ptr(out), _stream()), "s2d_spconv_s16_fwd")
+    check(lib.s2d_spconv_s16_fwd_stats(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(bias), _ptr(nbr), int(n_out), kvol, cin, cout,
+                                       _ptr(zero_page(feat.device)), _ptr(out), _ptr(partial), _stream()), "s2d_spconv_s16_fwd_stats")
     if rec is not None:
         rec["end"].record()
         PROFILE.append(rec)
-    return out
+    return (out, partial) if bn_stats else out
 
 
 def col_sums_bf16(x):

@@ -105,7 +105,7 @@ class _SparseConvFn(torch.autograd.Function):
         return w
 
     @staticmethod
-    def _s16(x, weight, bias, rb, nbr, n_out, transpose, flip, tag, cin_feat=None):
+    def _s16(x, weight, bias, rb, nbr, n_out, transpose, flip, tag, cin_feat=None, bn_stats=False):
         """bf16-storage conv / data gradient with the weight image cached per parameter version (dense2d.cached_pack)"""
         from .dense2d import cached_pack
         cin_feat = x.shape[1] if cin_feat is None else cin_feat
@@ -116,26 +116,34 @@ class _SparseConvFn(torch.autograd.Function):
             packed = cached_pack(weight, ("nb", bool(transpose), bool(flip), int(cin_feat)),
                                  lambda: H.spconv_nb_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), transpose, flip))
             b = None if bias is None else bias.detach().float().contiguous()
-            return H.spconv_nb_run(x.contiguous(), packed, b, H.nb_plan(rb, c), n_out, rb.pair_count, tag)
+            out = H.spconv_nb_run(x.contiguous(), packed, b, H.nb_plan(rb, c), n_out, rb.pair_count, tag)
+            return (out, None) if bn_stats else out
         packed, kvol, cin, cout = cached_pack(
             weight, ("s16", bool(transpose), bool(flip), int(cin_feat)),
             lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
         b = None if bias is None else bias.detach().float().contiguous()
-        return H.spconv_s16_run(x.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, rb.pair_count, tag)
+        return H.spconv_s16_run(x.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, rb.pair_count, tag, bn_stats=bn_stats)
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, rb):
+    def forward(ctx, feat, weight, bias, rb, bn_stats=False):
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         ctx.rb = rb
         ctx.has_bias = bias is not None
         ctx.save_for_backward(feat, weight)
         ctx.s16 = feat.dtype == torch.bfloat16
         if ctx.s16:   # bf16 feature storage: gather -> LDS -> MFMA, bf16 out
+            if bn_stats:   # second output: the statistics rows of the batch norm that follows (None on the neighbourhood-resident route)
+                out, partial = _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd", bn_stats=True)
+                if partial is not None:
+                    ctx.mark_non_differentiable(partial)
+                    ctx.set_materialize_grads(False)
+                    return out, partial
+                return out, torch.empty(0, device=out.device)
             return _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd")
         return H.spconv_gather_gemm(feat, w, bias, rb.nbr_out, rb.n_out, rb.pair_count, "fwd")
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_unused):
         feat, weight = ctx.saved_tensors
         rb = ctx.rb
         if ctx.s16:
@@ -149,7 +157,7 @@ class _SparseConvFn(torch.autograd.Function):
                 dw = dw[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = H.col_sums_bf16(dout)
-            return dfeat, dw, db, None
+            return dfeat, dw, db, None, None
         dout = dout.contiguous()
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         dfeat = dw = db = None
@@ -163,7 +171,7 @@ class _SparseConvFn(torch.autograd.Function):
             dw = H.spconv_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0)
-        return dfeat, dw, db, None
+        return dfeat, dw, db, None, None
 
 
 class SparseModule(nn.Module):
@@ -181,6 +189,7 @@ class SparseConvolution(SparseModule):
         self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
         self.padding, self.dilation = _triple(padding), _triple(dilation)
         self.subm = subm
+        self.emit_bn_stats = False   # set by the owner when a FeatureBatchNorm1d consumes the output (SparseSequential / residual blocks)
         self.indice_key = indice_key
         self.plan_key = None   # set by a backbone: name under which a pre-planned strided rulebook is stored
         self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
@@ -223,7 +232,12 @@ class SparseConvolution(SparseModule):
             if feats.shape[1] < 16:
                 feats = torch.nn.functional.pad(feats, (0, 16 - feats.shape[1]))
             feats = feats.to(torch.bfloat16)
-        feats = _SparseConvFn.apply(feats, self.weight, self.bias, rb)
+        if self.emit_bn_stats and self.training and torch.is_grad_enabled() and feats.dtype == torch.bfloat16 and rb.n_out > 0:
+            feats, partial = _SparseConvFn.apply(feats, self.weight, self.bias, rb, True)
+            if partial.numel():
+                feats._s2d_bn_partial = partial   # read (forward pass only) by the FeatureBatchNorm1d that follows
+        else:
+            feats = _SparseConvFn.apply(feats, self.weight, self.bias, rb)
         if self.subm:
             out = SparseConvTensor(feats, x.indices, x.spatial_shape, x.batch_size)
         else:
@@ -354,8 +368,11 @@ class FeatureBatchNorm1d(nn.BatchNorm1d):
             from .dense2d import _BNRowFn
             if self.num_features % 8:
                 raise RuntimeError("FeatureBatchNorm1d: bf16 features need a channel count that is a multiple of 8")
+            partial = getattr(x, "_s2d_bn_partial", None) if use_batch_stats else None
+            if partial is not None and (partial.shape[2] != self.num_features or not x.is_contiguous()):
+                partial = None
             return _BNRowFn.apply(x.contiguous(), self.weight, self.bias, None if residual is None else residual.contiguous(),
-                                  relu, self.eps, _dist_on() and use_batch_stats, self, use_batch_stats)
+                                  relu, self.eps, _dist_on() and use_batch_stats, self, use_batch_stats, partial)
         if use_batch_stats:
             return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, _dist_on() and self.training, self)
         return _BNEvalFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.eps)
@@ -378,6 +395,13 @@ class SparseSequential(SparseModule):
             if name in self._modules:
                 raise ValueError("name exists.")
             self.add_module(name, module)
+        self._mark_bn_producers()
+
+    def _mark_bn_producers(self):
+        mods = list(self._modules.values())
+        for a, b in zip(mods, mods[1:]):
+            if isinstance(a, SparseConvolution) and isinstance(b, FeatureBatchNorm1d):
+                a.emit_bn_stats = True
 
     def __getitem__(self, idx):
         if not (-len(self) <= idx < len(self)):
@@ -394,6 +418,7 @@ class SparseSequential(SparseModule):
         if name in self._modules:
             raise KeyError("name exists")
         self.add_module(name, module)
+        self._mark_bn_producers()
 
     def forward(self, x):
         mods = list(self._modules.values())

@@ -222,3 +222,54 @@ def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div, monkey
     # and it is what the autograd function of the module layer now runs (same result as the gather kernel)
     old = H.spconv_s16(f.to(DEV), w.to(DEV), b.to(DEV), rb.nbr_out, n)   # the gather kernel on the same operands
     assert (old.float() - out.float()).abs().max() <= 8e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 128), (64, 128), (16, 32)])
+@pytest.mark.parametrize("n_in,n_out", [(3000, 9100), (500, 333), (40, 1)])
+def test_s16_epilogue_statistics_equal_the_sums_of_the_stored_rows(cin, cout, n_in, n_out):
+    """the per-workgroup (sum, sum of squares) rows of s2d_spconv_s16_fwd_stats fold to the column sums of the bf16 output the same
+    launch stored (the statistics pass of the BatchNorm1d that follows), and the output is bit-identical to the plain launch"""
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(cin + cout + n_out)
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    w = torch.randn(27, cin, cout, device=DEV) * 0.1
+    b = torch.randn(cout, device=DEV)
+    nbr = _random_map(27, n_in, n_out)
+    packed, kvol, ci, co = H.spconv_s16_pack(w, n_out)
+    plain = H.spconv_s16_run(feat, packed, kvol, ci, co, b, nbr, n_out)
+    out, partial = H.spconv_s16_run(feat, packed, kvol, ci, co, b, nbr, n_out, bn_stats=True)
+    assert torch.equal(out, plain) and partial.shape[1:] == (2, cout)
+    s1, s2 = out.double().sum(0), (out.double() ** 2).sum(0)
+    assert (partial[:, 0].double().sum(0) - s1).abs().max() <= 1e-5 * out.double().abs().sum(0).max() + 1e-6
+    assert (partial[:, 1].double().sum(0) - s2).abs().max() <= 1e-5 * s2.max() + 1e-6
+
+
+def test_sparse_conv_bn_pair_with_epilogue_statistics_matches_the_separate_pass():
+    """SubMConv3d -> BatchNorm1d -> ReLU (spconv.SparseSequential) in the bf16-storage mode: statistics from the conv epilogue vs the
+    batch norm's own pass - outputs, running statistics and gradients agree to summation-order noise"""
+    from sparse2dense_amd import hip_ops as H, spconv as SP
+    old = H.SPARSE_COMPUTE_DTYPE
+    H.SPARSE_COMPUTE_DTYPE = "s16"
+    try:
+        torch.manual_seed(3)
+        g = torch.Generator().manual_seed(1)
+        cells = torch.randperm(2 * 9 * 40 * 40, generator=g)[:6000].sort().values
+        coors = torch.stack([cells // (9 * 40 * 40), (cells // (40 * 40)) % 9, (cells // 40) % 40, cells % 40], 1).int().to(DEV)
+        feats = torch.randn(6000, 16, device=DEV)
+        res = []
+        for emit in (True, False):
+            torch.manual_seed(7)
+            seq = SP.SparseSequential(SP.SubMConv3d(16, 32, 3, bias=False, indice_key="a"), SP.FeatureBatchNorm1d(32, eps=1e-3, momentum=0.01),
+                                      torch.nn.ReLU()).to(DEV).train()
+            assert seq[0].emit_bn_stats
+            seq[0].emit_bn_stats = emit
+            f = feats.clone().requires_grad_(True)
+            y = seq(SP.SparseConvTensor(f, coors, [9, 40, 40], 2)).features
+            y.float().square().sum().backward()
+            res.append((y.detach().float(), seq[1].running_mean.clone(), seq[1].running_var.clone(), f.grad.clone(), seq[0].weight.grad.clone()))
+        for a, b in zip(*res):
+            assert (a - b).abs().max() <= 2e-2 * b.abs().max() + 1e-6   # bf16 outputs: a last-bit flip of the statistics moves one rounding
+        assert (res[0][1] - res[1][1]).abs().max() <= 1e-6 * res[1][1].abs().max() + 1e-8
+        assert (res[0][2] - res[1][2]).abs().max() <= 1e-6 * res[1][2].abs().max() + 1e-8
+    finally:
+        H.SPARSE_COMPUTE_DTYPE = old
