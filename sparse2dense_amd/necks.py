@@ -6,9 +6,9 @@
 Module names / Sequential indices are the reference's, so state_dicts are interchangeable
 (`blocks.0.1.weight` — index 0 is the ZeroPad2d; `encoder_1.0.weight`; `generator_2.3.weight` ...).
 Under bf16 autocast on NHWC inputs the layers run on the hand-written kernels behind `dense2d` / `dense3d`
-(3x3, 1x1 and the 2x2-stride-2 convs, depth-wise 7x7, batch norms with the ReLU / GELU fused, the whole-map LayerNorm, the PCR
-head with its fused levels); layers without a kernel of ours (ConvTranspose2d, strided backward), fp32 runs and CPU inputs take
-the stock torch layer (DESIGN.md section 3 lists which).
+(3x3, 1x1 and the 2x2-stride-2 convs, the ConvTranspose2d(2,2) deblock, depth-wise 7x7, batch norms with the ReLU / GELU fused, the
+whole-map LayerNorm, the PCR head with its fused levels); layers without a kernel of ours (ConvTranspose2d(4,2,1), the backward of
+the stride-2 3x3 convs), fp32 runs and CPU inputs take the stock torch layer (DESIGN.md section 5 says what that costs).
 """
 import numpy as np
 import torch
