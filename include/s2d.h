@@ -462,9 +462,9 @@ int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int cout, void *
 int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout,
                          int d, int h, int w, float *out, s2d_stream_t stream);
 /* ... with the statistics pass of the BatchNorm3d that follows folded into the epilogue: stats_partial (optional)
- * [s2d_convt3d_mfma_stats_tiles(batch,d,h,w)][2][cout] = per-block (sum, sum of squares) per output channel of the written
+ * [s2d_convt3d_mfma_stats_tiles(batch,cin,d,h,w)][2][cout] = per-block (sum, sum of squares) per output channel of the written
  * output; s2d_bn_partials_sum_f32 folds them into the [2*cout] statistics vector */
-int64_t s2d_convt3d_mfma_stats_tiles(int batch, int d, int h, int w);
+int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h, int w);
 int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, const float *bias, int batch, int cin, int cout,
                                int d, int h, int w, float *out, float *stats_partial, s2d_stream_t stream);
 int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int cin, int cout, int d, int h,

@@ -89,7 +89,7 @@ SIGNATURES = {
     "s2d_convt3d_mfma_packed_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "s2d_convt3d_mfma_pack_weights": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_fwd": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
-    "s2d_convt3d_mfma_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "s2d_convt3d_mfma_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 5),
     "s2d_convt3d_mfma_fwd_stats": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_dgrad": (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),

@@ -117,14 +117,16 @@ static inline int ct_chunk_rows(int64_t row_bytes, int rows_per_y, int halo, int
 
 // waves_per_eu(3): the 32 -> 32 instantiation otherwise takes 176 registers (2 waves per SIMD); at 156 a third workgroup per CU overlaps
 // its staging round trip with the others' MFMA / store phases (372 -> 347 us)
-template <int CIN, int NT>
+template <int CIN, int NT, int YR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           CtDims s, int xtiles, CtTileMap map, float *__restrict__ out,
                                                           float *__restrict__ stats_partial) {
     constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
     constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
     constexpr int KSTEPS = CIN == 32 ? 8 : 4;
-    __shared__ __attribute__((aligned(16))) __bf16 xs[9 * XS * CIN];   // [row9][xx][ci]
+    // a block produces YR consecutive input rows y (the same z, x tile): 3 x (YR + 2) rows staged for them instead of 9 per row
+    constexpr int RY = YR + 2, ROWS = 3 * RY;
+    __shared__ __attribute__((aligned(16))) __bf16 xs[ROWS * XS * CIN];   // [zi * RY + yi][xx][ci]
     auto xa = [&](int cell, int g) -> int { return (cell * GROUPS + g) * 8; };
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // Tile order (XCD-aware): every tile re-reads the rows of its 8 (z, y) neighbours.  Workgroup ids are dealt round-robin over the
@@ -133,16 +135,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     // tiles, ordered (n, chunk of yc rows, z, y in chunk, x tile): the z and y re-reads then hit that XCD's L2
     // (3 planes x (yc + 2) rows x w x CIN floats, yc chosen to keep that under 2 MB).
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    if (tile >= s.n * s.d * s.h * xtiles) return;
+    const int hgroups = (s.h + YR - 1) / YR;   // the tile map counts groups of YR rows
+    if (tile >= s.n * s.d * hgroups * xtiles) return;
     const int n = (int)fastdiv((uint32_t)tile, map.per_n);
     int rem = tile - n * (int)map.per_n.d;
     const int chunk = (int)fastdiv((uint32_t)rem, map.per_chunk);
     rem -= chunk * (int)map.per_chunk.d;
-    const int yc = min(map.yc, s.h - chunk * map.yc);   // rows of this chunk
+    const int yc = min(map.yc, hgroups - chunk * map.yc);   // row groups of this chunk
     const int hz = yc == map.yc ? (int)fastdiv((uint32_t)rem, map.per_plane) : rem / (yc * xtiles);
     rem -= hz * (yc * xtiles);
     const int yr = (int)fastdiv((uint32_t)rem, map.per_row);
-    const int hy = chunk * map.yc + yr, xt = rem - yr * xtiles;
+    const int hy0 = (chunk * map.yc + yr) * YR, xt = rem - yr * xtiles;
     const int x0 = xt * CT_TX;
     const int64_t cells = (int64_t)s.d * s.h * s.w;
     const float *xb = x + (int64_t)n * CIN * cells;
@@ -152,14 +155,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const bool vec = (s.w & 3) == 0;
     if (vec) {
         // every thread issues the loads of its halo piece (threads < 18 * GROUPS) and of its first body piece before converting any
-        constexpr int HALO = 9 * GROUPS * 2, BODY = 9 * GROUPS * 16;
+        constexpr int HALO = ROWS * GROUPS * 2, BODY = ROWS * GROUPS * 16;
+        static_assert(HALO <= 256, "one halo piece per thread");
         float hv[8];
         const bool has_halo = t < HALO;
         int h_slot = 0;
         if (has_halo) {
             const int c = t & 1, g = (t >> 1) % GROUPS, r9 = (t >> 1) / GROUPS;
             const int xx = c * (XS - 1);
-            const int z = hz + r9 / 3 - 1, y = hy + r9 % 3 - 1, xp = x0 - 1 + xx;
+            const int z = hz + r9 / RY - 1, y = hy0 + r9 % RY - 1, xp = x0 - 1 + xx;
             h_slot = xa(r9 * XS + xx, g);
             const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w;
             const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         for (int p = t; p < BODY; p += 256) {
             const int xq = p & 15, g = (p >> 4) % GROUPS, r9 = (p >> 4) / GROUPS;
-            const int z = hz + r9 / 3 - 1, y = hy + r9 % 3 - 1, xp = x0 + 4 * xq;
+            const int z = hz + r9 / RY - 1, y = hy0 + r9 % RY - 1, xp = x0 + 4 * xq;
             const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && xp < s.w;
             const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
             float4 f[8];
@@ -193,9 +197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             *reinterpret_cast<bf16x8m *>(&xs[h_slot]) = v;
         }
     } else {
-        for (int p = t; p < 9 * GROUPS * XS; p += 256) {
+        for (int p = t; p < ROWS * GROUPS * XS; p += 256) {
             const int xx = p % XS, g = (p / XS) % GROUPS, r9 = p / (XS * GROUPS);
-            const int z = hz + r9 / 3 - 1, y = hy + r9 % 3 - 1, xp = x0 - 1 + xx;
+            const int z = hz + r9 / RY - 1, y = hy0 + r9 % RY - 1, xp = x0 - 1 + xx;
             bf16x8m v;
             if ((unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w) {
                 const float *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
@@ -211,127 +215,140 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     __syncthreads();
     const int pz = wid >> 1, py = wid & 1;
     const int r = lane & 15, q = lane >> 4;
-    f32x4m acc[2][4][NT];
-#pragma unroll
-    for (int px = 0; px < 2; ++px)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int px = 0; px < 2; ++px) {
-        const int cls = pz * 4 + py * 2 + px;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            bf16x8m b[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)cls * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
-            const int tap = CIN == 32 ? ks : 2 * ks + (q >> 1);
-            const int g = CIN == 32 ? q : (q & 1);
-            const int ta = tap >> 2, tb = (tap >> 1) & 1, tc = tap & 1;
-            const int r9 = (ct_d(pz, ta) + 1) * 3 + (ct_d(py, tb) + 1);
-            const int dx = ct_d(px, tc);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int xx = mt * 16 + r + 1 + dx;
-                const bf16x8m a = *reinterpret_cast<const bf16x8m *>(&xs[xa(r9 * XS + xx, g)]);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[px][mt][nt], 0, 0, 0);
-            }
-        }
-    }
-    // epilogue: lane holds column co = nt*16 + r and the 4 cells 4q..4q+3 of every m-tile, both px -> 8 consecutive floats
     const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
-    const int oz = 2 * hz + pz, oy = 2 * hy + py;
+    const int oz = 2 * hz + pz;
     float *ob = out + (int64_t)n * s.cout * od * oh * ow;
     float st1[NT], st2[NT];   // per-channel (sum, sum of squares) of this lane's outputs: the batch norm that follows skips its statistics pass
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        st1[nt] = 0.f;
+        st2[nt] = 0.f;
+    }
     // <= 4 output channels (the last up-sampler, 16 -> 3): only 4 of 16 column lanes hold outputs, so storing from the accumulator
-    // layout issues 32 store instructions per wave with 12 live lanes each - the store issue rate, not HBM, bounded the kernel.  The
-    // wave transposes its row through LDS instead and stores whole 512-byte channel rows with every lane.
+    // layout issues 32 store instructions per wave with 12 live lanes each.  The wave transposes its row through LDS instead and
+    // stores whole 512-byte channel rows with every lane (bias and statistics on the float4s).
     __shared__ __attribute__((aligned(16))) float tr[NT == 1 ? 4 * 4 * 2 * CT_TX : 4];   // [wave][co < 4][2 * CT_TX]
     const bool narrow = NT == 1 && s.cout <= 4 && (ow & 3) == 0;
     __shared__ float sred[4][2][NT * 16];
-    if (NT == 1 && narrow) {
-        // raw accumulators -> tr[wave][co][2 * cell + px]; bias, statistics and the stores are then done by all 64 lanes on float4s
-        float *dst = tr + wid * 4 * 2 * CT_TX;
-        if (r < s.cout) {
+    float na[2] = {0.f, 0.f}, nb[2] = {0.f, 0.f};   // narrow path: this lane's sums for channel (lane + 64 k) >> 5
+    for (int yy = 0; yy < YR; ++yy) {
+        const int hy = hy0 + yy;
+        if (hy >= s.h) break;   // block-uniform
+        const int oy = 2 * hy + py;
+        f32x4m acc[2][4][NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int c0 = mt * 16 + 4 * q;
-                *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0) = float4{acc[0][mt][0][0], acc[1][mt][0][0], acc[0][mt][0][1], acc[1][mt][0][1]};
-                *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0 + 4) = float4{acc[0][mt][0][2], acc[1][mt][0][2], acc[0][mt][0][3], acc[1][mt][0][3]};
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int cls = pz * 4 + py * 2 + px;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8m b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)cls * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                const int tap = CIN == 32 ? ks : 2 * ks + (q >> 1);
+                const int g = CIN == 32 ? q : (q & 1);
+                const int ta = tap >> 2, tb = (tap >> 1) & 1, tc = tap & 1;
+                const int r9 = (ct_d(pz, ta) + 1) * RY + (ct_d(py, tb) + 1 + yy);
+                const int dx = ct_d(px, tc);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int xx = mt * 16 + r + 1 + dx;
+                    const bf16x8m a = *reinterpret_cast<const bf16x8m *>(&xs[xa(r9 * XS + xx, g)]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[px][mt][nt], 0, 0, 0);
+                }
             }
         }
-        __syncthreads();
-        const int n4 = (min(CT_TX, s.w - x0) * 2) >> 2;   // float4 per channel row of this tile
+        // epilogue: lane holds column co = nt*16 + r and the 4 cells 4q..4q+3 of every m-tile, both px -> 8 consecutive floats
+        if (NT == 1 && narrow) {
+            // raw accumulators -> tr[wave][co][2 * cell + px] (the wave's own slab: LDS accesses of a wave stay in order)
+            float *dst = tr + wid * 4 * 2 * CT_TX;
+            if (r < s.cout) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {   // 4 channels x 32 float4: two per lane; a 32-lane half holds one channel
-            const int i = lane + 64 * k, co = i >> 5, x4 = i & 31;
-            float a = 0.f, b = 0.f;
-            if (co < s.cout && x4 < n4) {
-                float4 v = *reinterpret_cast<const float4 *>(dst + co * 2 * CT_TX + 4 * x4);
-                const float bv = bias ? bias[co] : 0.f;
-                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                *reinterpret_cast<float4 *>(ob + (((int64_t)co * od + oz) * oh + oy) * ow + 2 * x0 + 4 * x4) = v;
-                a = (v.x + v.y) + (v.z + v.w);
-                b = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int c0 = mt * 16 + 4 * q;
+                    *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0) = float4{acc[0][mt][0][0], acc[1][mt][0][0], acc[0][mt][0][1], acc[1][mt][0][1]};
+                    *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0 + 4) = float4{acc[0][mt][0][2], acc[1][mt][0][2], acc[0][mt][0][3], acc[1][mt][0][3]};
+                }
             }
-            if (stats_partial) {
+            __syncthreads();
+            const int n4 = (min(CT_TX, s.w - x0) * 2) >> 2;   // float4 per channel row of this tile
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {   // 4 channels x 32 float4: two per lane; a 32-lane half holds one channel
+                const int i = lane + 64 * k, co = i >> 5, x4 = i & 31;
+                if (co < s.cout && x4 < n4) {
+                    float4 v = *reinterpret_cast<const float4 *>(dst + co * 2 * CT_TX + 4 * x4);
+                    const float bv = bias ? bias[co] : 0.f;
+                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                    *reinterpret_cast<float4 *>(ob + (((int64_t)co * od + oz) * oh + oy) * ow + 2 * x0 + 4 * x4) = v;
+                    na[k] += (v.x + v.y) + (v.z + v.w);
+                    nb[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            }
+            __syncthreads();   // the slab is rewritten by the next row
+            continue;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 16 + r;
+            if (co >= s.cout) continue;
+            const float bv = bias ? bias[co] : 0.f;
+            float *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int c0 = x0 + mt * 16 + 4 * q;
+                if (c0 + 3 < s.w && (ow & 3) == 0) {
+                    float4 lo{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv};
+                    float4 hi{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv};
+                    *reinterpret_cast<float4 *>(orow + 2 * c0) = lo;
+                    *reinterpret_cast<float4 *>(orow + 2 * c0 + 4) = hi;
+                    st1[nt] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                    st2[nt] += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < s.w) {
+                            const float v0 = acc[0][mt][nt][j] + bv, v1 = acc[1][mt][nt][j] + bv;
+                            orow[2 * (c0 + j)] = v0;
+                            orow[2 * (c0 + j) + 1] = v1;
+                            st1[nt] += v0 + v1;
+                            st2[nt] += v0 * v0 + v1 * v1;
+                        }
+                }
+            }
+        }
+    }
+    if (stats_partial) {   // block partial [2][cout]: lanes of a channel, then the 4 waves (= the 4 (pz,py) classes), fixed order
+        if (NT == 1 && narrow) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float a = na[k], b = nb[k];
 #pragma unroll
                 for (int d = 1; d < 32; d <<= 1) {
                     a += __shfl_xor(a, d, 64);
                     b += __shfl_xor(b, d, 64);
                 }
                 if ((lane & 31) == 0) {
-                    sred[wid][0][co] = a;
-                    sred[wid][1][co] = b;
+                    sred[wid][0][(lane + 64 * k) >> 5] = a;
+                    sred[wid][1][(lane + 64 * k) >> 5] = b;
                 }
             }
-        }
-    }
+        } else {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (NT == 1 && narrow) break;
-        st1[nt] = 0.f;
-        st2[nt] = 0.f;
-        const int co = nt * 16 + r;
-        if (co >= s.cout) continue;
-        const float bv = bias ? bias[co] : 0.f;
-        float *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int c0 = x0 + mt * 16 + 4 * q;
-            if (c0 + 3 < s.w && (ow & 3) == 0) {
-                float4 lo{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv};
-                float4 hi{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv};
-                *reinterpret_cast<float4 *>(orow + 2 * c0) = lo;
-                *reinterpret_cast<float4 *>(orow + 2 * c0 + 4) = hi;
-                st1[nt] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
-                st2[nt] += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c0 + j < s.w) {
-                        const float v0 = acc[0][mt][nt][j] + bv, v1 = acc[1][mt][nt][j] + bv;
-                        orow[2 * (c0 + j)] = v0;
-                        orow[2 * (c0 + j) + 1] = v1;
-                        st1[nt] += v0 + v1;
-                        st2[nt] += v0 * v0 + v1 * v1;
-                    }
-            }
-        }
-    }
-    if (stats_partial) {   // block partial [2][cout]: lanes of a channel (4 q groups), then the 4 waves (= the 4 (pz,py) classes), fixed order
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (NT == 1 && narrow) break;   // already in sred
-            float a = st1[nt], b = st2[nt];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-            if (q == 0) {
-                sred[wid][0][nt * 16 + r] = a;
-                sred[wid][1][nt * 16 + r] = b;
+            for (int nt = 0; nt < NT; ++nt) {
+                float a = st1[nt], b = st2[nt];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (q == 0) {
+                    sred[wid][0][nt * 16 + r] = a;
+                    sred[wid][1][nt * 16 + r] = b;
+                }
             }
         }
         __syncthreads();
@@ -959,8 +976,13 @@ extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int c
     return S2D_OK;
 }
 
-extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int d, int h, int w) {
-    return (int64_t)batch * d * h * ((w + CT_TX - 1) / CT_TX);
+// input rows per forward block: 4 for 16 input channels (3 x 6 staged rows, 37 KB of LDS: 0.69 -> 0.56 ms for the 16 -> 3 layer); 32
+// input channels stay at one row - two rows (50 KB, fewer resident workgroups) measured 0.52 ms against 0.35
+static int ct_fwd_rows(int cin) { return cin == 32 ? 1 : 4; }
+
+extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h, int w) {
+    const int yr = ct_fwd_rows(cin);
+    return (int64_t)batch * d * ((h + yr - 1) / yr) * ((w + CT_TX - 1) / CT_TX);
 }
 
 /* stats_partial (optional, [s2d_convt3d_mfma_stats_tiles][2][cout]): per-block (sum, sum of squares) per output channel of the written
@@ -971,17 +993,19 @@ extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, c
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
     CtDims s{batch, d, h, w, cin, cout};
     const int xtiles = (w + CT_TX - 1) / CT_TX;
-    const int64_t blocks = (int64_t)batch * d * h * xtiles;
+    const int yr = ct_fwd_rows(cin), hg = (h + yr - 1) / yr;
+    const int64_t blocks = (int64_t)batch * d * hg * xtiles;
     S2D_CHECK_ARG(blocks < 0x7fffffff, "convt3d_mfma_fwd: grid too large");
     const dim3 grid(xcd_grid(blocks)), blk(256);
-    const CtTileMap map = ct_tile_map(d, h, xtiles, ct_chunk_rows((int64_t)w * cin * 4, 1, 2, 3));   // 3 z planes x (yc + 2) input rows live
+    // 3 z planes x (yc * yr + 2) input rows live per chunk of yc row groups
+    const CtTileMap map = ct_tile_map(d, hg, xtiles, ct_chunk_rows((int64_t)w * cin * 4, yr, 2, 3));
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *wp = (const __bf16 *)packed;
     const int nt = (cout + 15) / 16;
-    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -120,7 +120,7 @@ class _ConvT3dFn(torch.autograd.Function):
         if ctx.mfma:   # bf16 compute mode: operands rounded to bf16 in the kernel, fp32 accumulate (csrc/convt3d_mfma.hip)
             partial = None
             if bn_stats:   # the epilogue also produces the statistics of the batch norm that follows
-                tiles = lib.s2d_convt3d_mfma_stats_tiles(n, d, h, w)
+                tiles = lib.s2d_convt3d_mfma_stats_tiles(n, cin, d, h, w)
                 partial = torch.empty((tiles, 2, cout), dtype=torch.float32, device=x.device)
             check(lib.s2d_convt3d_mfma_fwd_stats(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial),
                                                  _stream()), "s2d_convt3d_mfma_fwd_stats")
