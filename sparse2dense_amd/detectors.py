@@ -46,9 +46,14 @@ class SingleStageDetector(nn.Module):
         if self.neck is not None:
             mods += list(self.neck.modules())
             self.neck.trunk_channels_last = True
+        from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, SmallConv3x3
         from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
+        own = (Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, SmallConv3x3)
         for mod in mods:
-            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            # NHWC weights only where the library convs read them: our kernels pack either order, and a contiguous parameter gets its
+            # (contiguous) gradient handed over as is - an NHWC one makes the autograd engine re-lay every weight gradient (a copy
+            # kernel per parameter and step)
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and not isinstance(mod, own):
                 mod.to(memory_format=torch.channels_last)
             if isinstance(mod, (ConvTranspose3dK4S2, PointwiseConv3d)):   # PCR head: bf16 MFMA inputs in the bf16 mode
                 mod.bf16_compute = True
