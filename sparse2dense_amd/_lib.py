@@ -187,6 +187,9 @@ SIGNATURES = {
     "s2d_bn_partials_finalize_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p,
                                                     ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                                     ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_bn_partials_finalize_ws_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p,
+                                                       ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bn_partials_sum_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_int,
                                                ctypes.c_void_p]),
     "s2d_bn_partials_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -1083,25 +1083,48 @@ extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const voi
 }
 
 // ---- batch-norm statistics whose reduction pass ran in a producer's epilogue -----------------------------------------
-extern "C" int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta,
-                                            float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
-                                            float *running_mean, float *running_var, int64_t *batches_tracked,
-                                            s2d_stream_t stream) {
-    S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && gamma && beta && mean && invstd && scale && shift,
-                  "bn_partials_finalize: bad argument");
-    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, nblocks, (float)n,
-                       gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
-                       (long long *)batches_tracked);
-    S2D_LAUNCH_CHECK();
-    return S2D_OK;
-}
-
-constexpr int PS_LONG = 8192, PS_SLICES = 1024;   // partial lists longer than PS_LONG rows are folded in two stages
+constexpr int PS_LONG = 2048, PS_SLICES = 1024;   // partial lists longer than PS_LONG rows are folded in two stages
 
 extern "C" size_t s2d_bn_partials_sum_workspace_bytes(int nblocks, int c) {
     if (nblocks <= PS_LONG || c <= 0 || 2 * c > 256) return 0;
     return align_up((size_t)PS_SLICES * 2 * c * sizeof(float), 256);
 }
+
+// first stage of a long list: [nblocks][2c] -> [slices][2c] in ws; returns the new row count (or nblocks when not applicable)
+static int partials_prefold(const float *&partial, int nblocks, int c, void *ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = s2d_bn_partials_sum_workspace_bytes(nblocks, c);
+    if (!need || !ws || ws_bytes < need) return nblocks;
+    const int rps = (int)ceil_div(nblocks, PS_SLICES), slices = (int)ceil_div(nblocks, rps);
+    hipLaunchKernelGGL(partial_sum_slices_kernel, dim3(slices), dim3(256), 0, st, partial, nblocks, 2 * c, rps, (float *)ws);
+    partial = (const float *)ws;
+    return slices;
+}
+
+/* ws (optional, s2d_bn_partials_sum_workspace_bytes): lists of more than 2048 rows (a sparse conv writes one row per 64-row tile: 4500 rows
+ * at the first stage) are folded in two stages - one wave per channel walking 70 x 64 scattered rows took 20-30 us */
+extern "C" int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta,
+                                               float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
+                                               float *running_mean, float *running_var, int64_t *batches_tracked, void *ws, size_t ws_bytes,
+                                               s2d_stream_t stream) {
+    S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && gamma && beta && mean && invstd && scale && shift,
+                  "bn_partials_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    nblocks = partials_prefold(partial, nblocks, c, ws, ws_bytes, st);
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nblocks, (float)n, gamma, beta, eps,
+                       momentum, c, mean, invstd, scale, shift, running_mean, running_var, (long long *)batches_tracked);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta,
+                                            float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
+                                            float *running_mean, float *running_var, int64_t *batches_tracked,
+                                            s2d_stream_t stream) {
+    return s2d_bn_partials_finalize_ws_f32(partial, nblocks, n, c, gamma, beta, eps, momentum, mean, invstd, scale, shift, running_mean,
+                                           running_var, batches_tracked, nullptr, 0, stream);
+}
+
+
 
 /* stats[2c] (+ count at [2c] when write_count) = column sums of partial[nblocks][2c].  ws (optional, s2d_bn_partials_sum_workspace_bytes):
  * lets long lists (one row per producer tile) be folded in two stages */
@@ -1109,13 +1132,7 @@ extern "C" int s2d_bn_partials_sum_ws_f32(const float *partial, int nblocks, int
                                           size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && stats, "bn_partials_sum: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = s2d_bn_partials_sum_workspace_bytes(nblocks, c);
-    if (need && ws && ws_bytes >= need) {
-        const int rps = (int)ceil_div(nblocks, PS_SLICES), slices = (int)ceil_div(nblocks, rps);
-        hipLaunchKernelGGL(partial_sum_slices_kernel, dim3(slices), dim3(256), 0, st, partial, nblocks, 2 * c, rps, (float *)ws);
-        partial = (const float *)ws;
-        nblocks = slices;
-    }
+    nblocks = partials_prefold(partial, nblocks, c, ws, ws_bytes, st);
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, partial, nblocks, 2 * c, stats, (float *)nullptr,
                        write_count ? (float)n : -1.f);
     S2D_LAUNCH_CHECK();

@@ -612,9 +612,13 @@ class _BNRowFn(torch.autograd.Function):
             fin = torch.empty((4, c), dtype=torch.float32, device=dev)   # rows: mean, invstd, scale, shift
             fp, rb = fin.data_ptr(), 4 * c
             if partial is not None and not sync:   # statistics pass already done in the producing conv's epilogue
-                check(lib.s2d_bn_partials_finalize_f32(partial.data_ptr(), partial.shape[0], rows, c, gamma.data_ptr(),
-                                                       beta.data_ptr(), float(eps), mom, fp, fp + rb, fp + 2 * rb, fp + 3 * rb,
-                                                       _ptr(rm), _ptr(rv), _ptr(nbt), stream), "s2d_bn_partials_finalize_f32")
+                pws = ws
+                if lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], c) > ws.numel():   # long list (sparse conv tiles): two stages
+                    pws = _ws(lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], c), dev)
+                check(lib.s2d_bn_partials_finalize_ws_f32(partial.data_ptr(), partial.shape[0], rows, c, gamma.data_ptr(),
+                                                          beta.data_ptr(), float(eps), mom, fp, fp + rb, fp + 2 * rb, fp + 3 * rb,
+                                                          _ptr(rm), _ptr(rv), _ptr(nbt), pws.data_ptr(), pws.numel(), stream),
+                      "s2d_bn_partials_finalize_ws_f32")
             elif not sync:
                 check(lib.s2d_bnrow_stats_finalize_bf16(x.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), float(eps), mom,
                                                         fp, fp + rb, fp + 2 * rb, fp + 3 * rb, _ptr(rm), _ptr(rv), _ptr(nbt),
@@ -623,8 +627,9 @@ class _BNRowFn(torch.autograd.Function):
                 import torch.distributed as dist
                 packed = torch.empty((2 * c + 1,), dtype=torch.float32, device=dev)   # [sum, sumsq, row count]
                 if partial is not None:
-                    check(lib.s2d_bn_partials_sum_f32(partial.data_ptr(), partial.shape[0], rows, c, packed.data_ptr(), 1, stream),
-                          "s2d_bn_partials_sum_f32")
+                    pws = _ws(max(lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], c), 256), dev)
+                    check(lib.s2d_bn_partials_sum_ws_f32(partial.data_ptr(), partial.shape[0], rows, c, packed.data_ptr(), 1, pws.data_ptr(),
+                                                         pws.numel(), stream), "s2d_bn_partials_sum_ws_f32")
                 else:
                     check(lib.s2d_bnrow_stats_bf16(x.data_ptr(), rows, c, packed.data_ptr(), 1, ws.data_ptr(), ws.numel(), stream),
                           "s2d_bnrow_stats_bf16")
