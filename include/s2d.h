@@ -288,12 +288,12 @@ int s2d_bn_partials_finalize_f32(const float *partial, int nblocks, int64_t n, i
                                  float *running_var, int64_t *batches_tracked, s2d_stream_t stream);
 int s2d_bn_partials_sum_f32(const float *partial, int nblocks, int64_t n, int c, float *stats,
                             int write_count, s2d_stream_t stream);
-/* the same with a workspace (s2d_bn_partials_sum_workspace_bytes, 0 = not needed): lists of more than 2048 rows (a producer that
+/* the same with a workspace (s2d_bn_partials_sum_workspace_bytes, 0 = not needed): lists of more than 1536 rows (a producer that
  * writes one row per tile, e.g. s2d_convt3d_mfma_fwd_stats) are folded in two stages, fixed order */
 size_t s2d_bn_partials_sum_workspace_bytes(int nblocks, int c);
 int s2d_bn_partials_sum_ws_f32(const float *partial, int nblocks, int64_t n, int c, float *stats, int write_count, void *ws,
                                size_t ws_bytes, s2d_stream_t stream);
-/* s2d_bn_partials_finalize_f32 with the same optional workspace (two-stage fold of lists longer than 2048 rows) */
+/* s2d_bn_partials_finalize_f32 with the same optional workspace (two-stage fold of lists longer than 1536 rows) */
 int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta, float eps,
                                     float momentum, float *mean, float *invstd, float *scale, float *shift, float *running_mean,
                                     float *running_var, int64_t *batches_tracked, void *ws, size_t ws_bytes, s2d_stream_t stream);

@@ -1083,7 +1083,7 @@ extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const voi
 }
 
 // ---- batch-norm statistics whose reduction pass ran in a producer's epilogue -----------------------------------------
-constexpr int PS_LONG = 2048, PS_SLICES = 1024;   // partial lists longer than PS_LONG rows are folded in two stages
+constexpr int PS_LONG = 1536, PS_SLICES = 512;   // partial lists longer than PS_LONG rows are folded in two stages
 
 extern "C" size_t s2d_bn_partials_sum_workspace_bytes(int nblocks, int c) {
     if (nblocks <= PS_LONG || c <= 0 || 2 * c > 256) return 0;
@@ -1100,7 +1100,7 @@ static int partials_prefold(const float *&partial, int nblocks, int c, void *ws,
     return slices;
 }
 
-/* ws (optional, s2d_bn_partials_sum_workspace_bytes): lists of more than 2048 rows (a sparse conv writes one row per 64-row tile: 4500 rows
+/* ws (optional, s2d_bn_partials_sum_workspace_bytes): lists of more than 1536 rows (a sparse conv writes one row per 64-row tile: 4500 rows
  * at the first stage) are folded in two stages - one wave per channel walking 70 x 64 scattered rows took 20-30 us */
 extern "C" int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *beta,
                                                float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,

@@ -196,14 +196,14 @@ def test_convtranspose3d_epilogue_batchnorm_statistics(cin, cout, shape):
 
 @pytest.mark.parametrize("nblocks,c", [(20000, 3), (300001, 32), (9000, 128), (5000, 16), (70000, 200)])
 def test_partial_sums_fold_of_long_lists(nblocks, c):
-    """s2d_bn_partials_sum_ws_f32: column sums of [nblocks][2c] partial rows (two stages above 2048 rows when 2c <= 256) vs float64,
+    """s2d_bn_partials_sum_ws_f32: column sums of [nblocks][2c] partial rows (two stages above 1536 rows when 2c <= 256) vs float64,
     bit-identical between runs, count written on request"""
     from sparse2dense_amd import _lib
     lib = _lib.load()
     torch.manual_seed(nblocks % 97 + c)
     part = torch.randn(nblocks, 2 * c, device=DEV)
     ws_bytes = lib.s2d_bn_partials_sum_workspace_bytes(nblocks, c)
-    assert (ws_bytes > 0) == (nblocks > 2048 and 2 * c <= 256)
+    assert (ws_bytes > 0) == (nblocks > 1536 and 2 * c <= 256)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
     outs = []
     for _ in range(2):
