@@ -349,6 +349,10 @@ int s2d_spconv_s16_supported(int cin, int cout);
 size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout);
 int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int cin, int cout, int transpose,
                                 int flip, int64_t n_out, void *packed, s2d_stream_t stream);
+/* both operands of a layer in one launch (the weight changes once per optimizer step): packed_fwd as above for a forward launch over
+ * n_out_fwd rows, packed_dgrad = the [cout -> cin] operand (transpose = 1, flip = flip_dgrad) for the data-gradient launch over n_out_dgrad rows */
+int s2d_spconv_s16_pack_weights_pair(const float *weight, int kvol, int cin, int cout, int flip_dgrad, int64_t n_out_fwd, int64_t n_out_dgrad,
+                                     void *packed_fwd, void *packed_dgrad, s2d_stream_t stream);
 /* weight gradient of the s16 path (in_feat, dout bf16; dweight fp32 [kvol][cin][cout]); workspace from
  * s2d_spconv_wgrad_workspace_bytes */
 int s2d_spconv_s16_wgrad(const void *in_feat, int64_t n_in, const void *dout, const int32_t *nbr,

@@ -52,11 +52,10 @@ struct S16Cfg {
 // packed image: [step][h (2)][nt = cout/16][q (4)][c (16)][e (8)]   (one K-step = 64*cout bf16, contiguous)
 //   K element kk = 32 h + 8 q + e ;  column co = wn*(cout/WN) + c*NJ + n  with nt = wn*NJ + n
 // source w: [K][cin][cout] fp32, or [K][cout][cin] when transpose (data gradient), offsets mirrored when flip.
-__global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int wn_count,
-                                                       int transpose, int flip, __bf16 *__restrict__ out) {
+__device__ __forceinline__ void s16_pack_element(const float *__restrict__ w, int kvol, int cin, int cout, int wn_count, int transpose, int flip,
+                                                 int64_t i, __bf16 *__restrict__ out) {
     const int steps = s16_steps(cin, kvol);
     const int64_t total = (int64_t)steps * 64 * cout;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int ntile = cout / 16, nj = ntile / wn_count;
     int64_t r = i;
@@ -82,6 +81,20 @@ __global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__
         v = transpose ? w[((int64_t)ks * cout + co) * cin + ch] : w[((int64_t)ks * cin + ch) * cout + co];
     }
     out[i] = (__bf16)v;
+}
+
+__global__ __launch_bounds__(256) void s16_pack_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int wn_count,
+                                                       int transpose, int flip, __bf16 *__restrict__ out) {
+    s16_pack_element(w, kvol, cin, cout, wn_count, transpose, flip, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, out);
+}
+
+// both operands of a layer in one launch: blockIdx.y = 0 the forward image [cin -> cout], 1 the data-gradient image [cout -> cin]
+// (transposed, offsets mirrored when flip_d) - the weight changes once per optimizer step and both are needed in every training step
+__global__ __launch_bounds__(256) void s16_pack_pair_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int wn_f, int wn_d, int flip_d,
+                                                            __bf16 *__restrict__ out_f, __bf16 *__restrict__ out_d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) s16_pack_element(w, kvol, cin, cout, wn_f, 0, 0, i, out_f);
+    else s16_pack_element(w, kvol, cout, cin, wn_d, 1, flip_d, i, out_d);
 }
 
 template <int CIN, int COUT, int BM, int MI_, int NJ_>
@@ -383,6 +396,23 @@ extern "C" int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int ci
     const int64_t total = (int64_t)s2d_spconv_s16_packed_elems(kvol, cin, cout);
     hipLaunchKernelGGL(s16_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, kvol, cin,
                        cout, s16_wn(cout, s16_plan(n_out, kvol, cin, cout).bm), transpose, flip, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* weight fp32 [kvol][cin][cout] -> packed_fwd (operand of a forward launch over n_out_fwd rows) and packed_dgrad (operand [cout -> cin] of the
+ * data-gradient launch over n_out_dgrad rows, offsets mirrored when flip_dgrad) in ONE launch */
+extern "C" int s2d_spconv_s16_pack_weights_pair(const float *weight, int kvol, int cin, int cout, int flip_dgrad, int64_t n_out_fwd,
+                                                int64_t n_out_dgrad, void *packed_fwd, void *packed_dgrad, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed_fwd && packed_dgrad && kvol > 0 && n_out_fwd >= 0 && n_out_dgrad >= 0, "spconv_s16_pack_pair: bad argument");
+    if (!s2d_spconv_s16_supported(cin, cout)) {
+        set_error("spconv_s16_pack_pair: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = std::max<int64_t>((int64_t)s2d_spconv_s16_packed_elems(kvol, cin, cout), (int64_t)s2d_spconv_s16_packed_elems(kvol, cout, cin));
+    hipLaunchKernelGGL(s16_pack_pair_kernel, dim3((unsigned)ceil_div(total, 256), 2), dim3(256), 0, (hipStream_t)stream, weight, kvol, cin, cout,
+                       s16_wn(cout, s16_plan(n_out_fwd, kvol, cin, cout).bm), s16_wn(cin, s16_plan(n_out_dgrad, kvol, cout, cin).bm), flip_dgrad,
+                       (__bf16 *)packed_fwd, (__bf16 *)packed_dgrad);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -69,6 +69,16 @@ def cached_pack(weight, variant, build):
     return hit
 
 
+def cached_pack_has(weight, variant):
+    ent = _pack_cache.get(id(weight))
+    return (ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version and variant in ent[3])
+
+
+def cached_pack_put(weight, variant, value):
+    """store an image that was built together with another variant (one launch for a layer's forward and data-gradient operands)"""
+    cached_pack(weight, variant, lambda: value)
+
+
 def clear_pack_cache():
     _pack_cache.clear()
 

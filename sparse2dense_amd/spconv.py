@@ -105,7 +105,7 @@ class _SparseConvFn(torch.autograd.Function):
         return w
 
     @staticmethod
-    def _s16(x, weight, bias, rb, nbr, n_out, transpose, flip, tag, cin_feat=None, bn_stats=False):
+    def _s16(x, weight, bias, rb, nbr, n_out, transpose, flip, tag, cin_feat=None, bn_stats=False, pair_dgrad=None):
         """bf16-storage conv / data gradient with the weight image cached per parameter version (dense2d.cached_pack)"""
         from .dense2d import cached_pack
         cin_feat = x.shape[1] if cin_feat is None else cin_feat
@@ -118,9 +118,17 @@ class _SparseConvFn(torch.autograd.Function):
             b = None if bias is None else bias.detach().float().contiguous()
             out = H.spconv_nb_run(x.contiguous(), packed, b, H.nb_plan(rb, c), n_out, rb.pair_count, tag)
             return (out, None) if bn_stats else out
+        key = ("s16", bool(transpose), bool(flip), int(cin_feat))
+        if pair_dgrad is not None and not transpose:
+            # training forward: the data-gradient operand of this step is packed in the same launch (pair_dgrad = its (flip, n_out))
+            from .dense2d import cached_pack_has, cached_pack_put
+            dkey = ("s16", True, bool(pair_dgrad[0]), int(cin_feat))
+            if not cached_pack_has(weight, key) and not cached_pack_has(weight, dkey):
+                pf, pd = H.spconv_s16_pack_pair(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, pair_dgrad[1], pair_dgrad[0])
+                cached_pack_put(weight, key, pf)
+                cached_pack_put(weight, dkey, pd)
         packed, kvol, cin, cout = cached_pack(
-            weight, ("s16", bool(transpose), bool(flip), int(cin_feat)),
-            lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
+            weight, key, lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
         b = None if bias is None else bias.detach().float().contiguous()
         return H.spconv_s16_run(x.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, rb.pair_count, tag, bn_stats=bn_stats)
 
@@ -132,14 +140,16 @@ class _SparseConvFn(torch.autograd.Function):
         ctx.save_for_backward(feat, weight)
         ctx.s16 = feat.dtype == torch.bfloat16
         if ctx.s16:   # bf16 feature storage: gather -> LDS -> MFMA, bf16 out
+            # the backward of this step will want the data-gradient operand (flip, rows) when the input needs a gradient
+            pair = (rb.subm, rb.n_in) if (ctx.needs_input_grad[0] and weight.shape[-2] == feat.shape[1]) else None
             if bn_stats:   # second output: the statistics rows of the batch norm that follows (None on the neighbourhood-resident route)
-                out, partial = _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd", bn_stats=True)
+                out, partial = _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd", bn_stats=True, pair_dgrad=pair)
                 if partial is not None:
                     ctx.mark_non_differentiable(partial)
                     ctx.set_materialize_grads(False)
                     return out, partial
                 return out, torch.empty(0, device=out.device)
-            return _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd")
+            return _SparseConvFn._s16(feat, weight, bias, rb, rb.nbr_out, rb.n_out, False, False, "fwd", pair_dgrad=pair)
         return H.spconv_gather_gemm(feat, w, bias, rb.nbr_out, rb.n_out, rb.pair_count, "fwd")
 
     @staticmethod
