@@ -412,6 +412,11 @@ int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zer
  * forward entry on dY).  Channels: multiples of 64.
  */
 int s2d_conv2d1x1_pack_weights_bf16(const float *weight, int cin, int cout, int transpose, void *packed, s2d_stream_t stream);
+/* both operands of a layer in one launch (the weight changes once per optimizer step, every training step needs both): weight = torch
+ * [cout][cin][k][k] of the forward conv; packed_fwd = its [cin -> cout] image, packed_dgrad = the [cout -> cin] image with mirrored taps */
+int s2d_conv2d3x3_pack_weights_pair_bf16(const float *weight, int cin, int cout, int weight_nhwc, void *packed_fwd, void *packed_dgrad,
+                                         s2d_stream_t stream);
+int s2d_conv2d1x1_pack_weights_pair_bf16(const float *weight, int cin, int cout, void *packed_fwd, void *packed_dgrad, s2d_stream_t stream);
 int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w);
 int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img,
                             int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);

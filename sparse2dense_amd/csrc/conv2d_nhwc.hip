@@ -25,9 +25,8 @@ typedef __bf16 bf16x4c __attribute__((ext_vector_type(4)));
 //   ci = chunk*64 + h*32 + 8q + e ;  co = blk*BN + wn*(BN/2) + c*(BN/32) + n  with nt = wn*(BN/32) + n
 // source w[Cout][Cin][3][3] (torch layout).  transpose_flip=1 builds the data-gradient operand:
 //   packed "cin" runs over the source's Cout, packed "cout" over its Cin, taps mirrored.
-__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int bn,
-                                                          int transpose_flip, int w_nhwc, int taps, __bf16 *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void conv2d_pack_element(const float *__restrict__ w, int cin, int cout, int bn, int transpose_flip, int w_nhwc, int taps,
+                                                    int64_t i, __bf16 *__restrict__ out) {
     const int64_t total = (int64_t)taps * cin * cout;
     if (i >= total) return;
     const int ntile = bn / 16, per_wave = bn / 32;
@@ -47,6 +46,19 @@ __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restric
     const int src_c = transpose_flip ? cout : cin;
     const float v = w_nhwc ? w[((int64_t)so * taps + st) * src_c + sc] : w[((int64_t)so * src_c + sc) * taps + st];
     out[i] = (__bf16)v;
+}
+
+__global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int bn,
+                                                          int transpose_flip, int w_nhwc, int taps, __bf16 *__restrict__ out) {
+    conv2d_pack_element(w, cin, cout, bn, transpose_flip, w_nhwc, taps, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, out);
+}
+
+// forward operand [cin -> cout] (blockIdx.y = 0) and data-gradient operand [cout -> cin], taps mirrored (1) of one layer in one launch
+__global__ __launch_bounds__(256) void conv2d_pack_pair_kernel(const float *__restrict__ w, int cin, int cout, int bn_f, int bn_d, int w_nhwc, int taps,
+                                                               __bf16 *__restrict__ out_f, __bf16 *__restrict__ out_d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) conv2d_pack_element(w, cin, cout, bn_f, 0, w_nhwc, taps, i, out_f);
+    else conv2d_pack_element(w, cout, cin, bn_d, 1, w_nhwc, taps, i, out_d);
 }
 
 // Shared epilogue.  C/D layout: row = 4*(lane>>4)+reg (pixel), col = lane&15 -> couts co_base + r*NT + j (NT consecutive).
@@ -590,6 +602,32 @@ extern "C" int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int
                        cout, conv_bn(cout), transpose_flip, weight_nhwc, 9, (__bf16 *)packed);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+/* both operands of a conv layer in one launch: weight = torch [cout][cin][k][k] of the forward conv (k = 3: taps 9, k = 1: taps 1);
+ * packed_fwd = the [cin -> cout] image, packed_dgrad = the [cout -> cin] image with the taps mirrored */
+static int conv2d_pack_pair(const float *weight, int cin, int cout, int weight_nhwc, int taps, void *packed_fwd, void *packed_dgrad,
+                            s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed_fwd && packed_dgrad, "conv2d_pack_pair: null argument");
+    if (!s2d_conv2d3x3_supported(cin, cout) || !s2d_conv2d3x3_supported(cout, cin)) {
+        set_error("conv2d_pack_pair: unsupported channels %d <-> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)taps * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_pair_kernel, dim3((unsigned)ceil_div(total, 256), 2), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
+                       conv_bn(cout), conv_bn(cin), weight_nhwc, taps, (__bf16 *)packed_fwd, (__bf16 *)packed_dgrad);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_conv2d3x3_pack_weights_pair_bf16(const float *weight, int cin, int cout, int weight_nhwc, void *packed_fwd, void *packed_dgrad,
+                                                    s2d_stream_t stream) {
+    return conv2d_pack_pair(weight, cin, cout, weight_nhwc, 9, packed_fwd, packed_dgrad, stream);
+}
+
+extern "C" int s2d_conv2d1x1_pack_weights_pair_bf16(const float *weight, int cin, int cout, void *packed_fwd, void *packed_dgrad,
+                                                    s2d_stream_t stream) {
+    return conv2d_pack_pair(weight, cin, cout, 0, 1, packed_fwd, packed_dgrad, stream);
 }
 
 // ---- launch plan --------------------------------------------------------------------------------------------------

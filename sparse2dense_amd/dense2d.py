@@ -83,8 +83,23 @@ def clear_pack_cache():
     _pack_cache.clear()
 
 
-def pack_weights(weight, transpose_flip=False):
-    """weight fp32 [Cout,Cin,3,3] -> bf16 LDS image of the forward (or data-gradient) operand (cached, see cached_pack)"""
+def pack_weights(weight, transpose_flip=False, with_dgrad=False):
+    """weight fp32 [Cout,Cin,3,3] -> bf16 LDS image of the forward (or data-gradient) operand (cached, see cached_pack).  with_dgrad (a
+    training forward whose input needs a gradient): the data-gradient image of the same step is packed in the same launch."""
+    if with_dgrad and not transpose_flip and not cached_pack_has(weight, ("conv3x3", False)) and not cached_pack_has(weight, ("conv3x3", True)):
+        lib = _lib.load()
+        cout, cin = weight.shape[0], weight.shape[1]
+        if lib.s2d_conv2d3x3_supported(cin, cout) and lib.s2d_conv2d3x3_supported(cout, cin):
+            w = weight.detach().float()
+            nhwc = (not w.is_contiguous()) and w.is_contiguous(memory_format=torch.channels_last)
+            if not nhwc:
+                w = w.contiguous()
+            pf = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=weight.device)
+            pd = torch.empty(9 * cin * cout, dtype=torch.bfloat16, device=weight.device)
+            check(lib.s2d_conv2d3x3_pack_weights_pair_bf16(_ptr(w), cin, cout, int(nhwc), _ptr(pf), _ptr(pd), _stream()),
+                  "s2d_conv2d3x3_pack_weights_pair_bf16")
+            cached_pack_put(weight, ("conv3x3", False), pf)
+            cached_pack_put(weight, ("conv3x3", True), pd)
     return cached_pack(weight, ("conv3x3", bool(transpose_flip)), lambda: _pack_weights(weight, transpose_flip))
 
 
@@ -172,12 +187,13 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.pad, ctx.stride = pad, stride
         ctx.has_bias = bias is not None
         b = None if bias is None else bias.detach().float().contiguous()
+        both = bool(ctx.needs_input_grad[0] and stride == 1)   # this step's backward will ask for the data-gradient operand
         if bn_stats:
-            y, partial = conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride, bn_stats=True)
+            y, partial = conv3x3_nhwc(xb, pack_weights(weight, with_dgrad=both), b, cin, cout, pad, stride, bn_stats=True)
             ctx.mark_non_differentiable(partial)
             ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return y, partial
-        return conv3x3_nhwc(xb, pack_weights(weight), b, cin, cout, pad, stride)
+        return conv3x3_nhwc(xb, pack_weights(weight, with_dgrad=both), b, cin, cout, pad, stride)
 
     @staticmethod
     def backward(ctx, dy, *_unused):
@@ -245,7 +261,19 @@ class Conv3x3(nn.Conv2d):
 # --------------------------------------------------------------------------------------------------
 # 1x1 convolutions of the S2D module (csrc/conv2d_nhwc.hip / conv2d_wgrad.hip with one tap)
 # --------------------------------------------------------------------------------------------------
-def _pack_weights_1x1(weight, transpose):
+def _pack_weights_1x1(weight, transpose, with_dgrad=False):
+    if with_dgrad and not transpose and not cached_pack_has(weight, ("conv1x1", False)) and not cached_pack_has(weight, ("conv1x1", True)):
+        lib = _lib.load()
+        cout, cin = weight.shape[0], weight.shape[1]
+        if lib.s2d_conv2d3x3_supported(cin, cout) and lib.s2d_conv2d3x3_supported(cout, cin):
+            w = weight.detach().float().reshape(cout, cin).contiguous()
+            pf = torch.empty(cin * cout, dtype=torch.bfloat16, device=weight.device)
+            pd = torch.empty(cin * cout, dtype=torch.bfloat16, device=weight.device)
+            check(lib.s2d_conv2d1x1_pack_weights_pair_bf16(_ptr(w), cin, cout, _ptr(pf), _ptr(pd), _stream()),
+                  "s2d_conv2d1x1_pack_weights_pair_bf16")
+            cached_pack_put(weight, ("conv1x1", False), pf)
+            cached_pack_put(weight, ("conv1x1", True), pd)
+
     def build():
         lib = _lib.load()
         cout, cin = weight.shape[0], weight.shape[1]
@@ -329,11 +357,11 @@ class _Conv1x1Fn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         b = None if bias is None else bias.detach().float().contiguous()
         if bn_stats:
-            y, partial = conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout, bn_stats=True)
+            y, partial = conv1x1_nhwc(xb, _pack_weights_1x1(weight, False, with_dgrad=ctx.needs_input_grad[0]), b, cin, cout, bn_stats=True)
             ctx.mark_non_differentiable(partial)
             ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
             return y, partial
-        return conv1x1_nhwc(xb, _pack_weights_1x1(weight, False), b, cin, cout)
+        return conv1x1_nhwc(xb, _pack_weights_1x1(weight, False, with_dgrad=ctx.needs_input_grad[0]), b, cin, cout)
 
     @staticmethod
     def backward(ctx, dy, *_unused):
