@@ -304,7 +304,24 @@ __global__ __launch_bounds__(256) void spconv_fwd_s16_kernel(const __bf16 *__res
 // instead of 128 B, and the gather rate, not the barrier round trip, is what bounds this kernel.  A 3-slot ring of the
 // 64-deep K-steps (two K-steps of gathers in flight, one 128-row workgroup per CU) was worse still: 128->128 62 -> 114 us.
 
-static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
+// register-gather kernel (spconv_rg.hip): the default; S2D_S16_KERNEL=lds selects the LDS-staged kernel of this file (A/B runs)
+struct RgPlan {
+    int mi, waves, tiles_per_block;
+    unsigned grid;
+};
+RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout);
+int rg_run(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
+           int cout, void *out_feat, float *stats_partial, hipStream_t st);
+static bool use_rg() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("S2D_S16_KERNEL");
+        v = !(e && strcmp(e, "lds") == 0);
+    }
+    return v != 0;
+}
+
+static int s16_wn(int cout, int bm) { return use_rg() ? 1 : (cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1)); }
 
 // Launch plan (tile template height and rows per workgroup).
 struct S16Plan {
@@ -420,6 +437,7 @@ extern "C" int s2d_spconv_s16_pack_weights_pair(const float *weight, int kvol, i
 /* rows of the per-workgroup statistics s2d_spconv_s16_fwd_stats writes for a launch over n_out rows */
 extern "C" int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout) {
     if (n_out <= 0 || kvol <= 0 || !s2d_spconv_s16_supported(cin, cout)) return 0;
+    if (use_rg()) return (int64_t)rg_plan(n_out, kvol, cin, cout).grid;
     return (int64_t)s16_plan(n_out, kvol, cin, cout).grid;
 }
 
@@ -446,6 +464,10 @@ extern "C" int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const
     if (n_out == 0) return S2D_OK;
     S2D_CHECK_ARG(in_feat && packed_weight && nbr && out_feat && zero_page && n_in > 0, "spconv_s16_fwd: null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (use_rg()) {
+        S2D_CHECK_ARG(n_in * cin * 2 < (int64_t)BUF_OOB, "spconv_s16_fwd: feature matrix of %lld rows exceeds the 2 GiB buffer window", (long long)n_in);
+        return rg_run(in_feat, n_in, packed_weight, bias, nbr, n_out, kvol, cin, cout, out_feat, stats_partial, st);
+    }
     const __bf16 *in = (const __bf16 *)in_feat, *wp = (const __bf16 *)packed_weight, *zp = (const __bf16 *)zero_page;
     __bf16 *out = (__bf16 *)out_feat;
     const S16Plan plan = s16_plan(n_out, kvol, cin, cout);

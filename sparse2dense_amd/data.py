@@ -137,6 +137,26 @@ def attach_geometry(example, backbone, keys=("coordinates", "dense_coordinates",
     return example
 
 
+def _tensors_of(obj, out=None, depth=0):
+    """every tensor reachable from an example (dict / list / tuple values, and the geometry plan attach_geometry hangs on the
+    coordinate tensors)"""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+        geo = getattr(obj, "_s2d_geometry", None)
+        if geo is not None and depth < 4:
+            _tensors_of(geo, out, depth + 1)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensors_of(v, out, depth)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _tensors_of(v, out, depth)
+    elif hasattr(obj, "__dict__") and depth < 4:      # Rulebook dataclasses of the plan
+        _tensors_of(vars(obj), out, depth + 1)
+    return out
+
+
 class PrefetchLoader:
     """The reference overlaps its data pipeline (voxelization, AssignLabel: DataLoader workers) with the training step; this is the
     device-side equivalent.  A worker thread builds example k+1 on a second HIP stream - device voxelization, target assignment and
@@ -145,7 +165,11 @@ class PrefetchLoader:
 
     Memory hand-over without record_stream(): tensors of example k are allocated on the side stream's pool; a block freed by the
     main thread is only reused by side-stream work of a LATER prefetch, and every prefetch starts (side.wait_event) behind the
-    main-stream position recorded when it was requested, i.e. behind all work that could still read such a block."""
+    main-stream position recorded when it was requested, i.e. behind all work that could still read such a block.  The one
+    prefetch that is NOT behind step k is k+1 (requested before step k was enqueued, running beside it): the loader therefore keeps
+    its own references to every tensor of example k (`_held`) until example k+1 has been handed out, so that a caller who drops
+    a tensor mid-step (`step(loader.example())`, `del ex`, popped keys) cannot return its block to the side pool while
+    prefetch k+1 still allocates."""
 
     def __init__(self, frames, backbone=None, geometry_keys=None):
         import queue
@@ -157,6 +181,7 @@ class PrefetchLoader:
         self.side = torch.cuda.Stream(self.device)
         self._go, self._out = queue.Queue(), queue.Queue()
         self._closed = False
+        self._held = None
         self._thread = threading.Thread(target=self._run, name="s2d-prefetch", daemon=True)
         self._thread.start()
         self._request()
@@ -200,6 +225,8 @@ class PrefetchLoader:
             self._closed = True
             raise err
         torch.cuda.current_stream(self.device).wait_event(done)
+        # prefetch k+1 is fully enqueued (it is `ex`): example k's tensors may go; example k+1's are pinned until the next call
+        self._held = _tensors_of(ex)
         self._request()
         return ex
 

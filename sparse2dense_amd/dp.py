@@ -92,6 +92,7 @@ class GradBuckets:
         if cur:
             self._close(cur)
         self._handles = []
+        self._next, self.launch_log = 0, []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 _BUCKETERS[id(p)] = self
@@ -103,7 +104,7 @@ class GradBuckets:
         views, off = [], 0
         for p in ps:
             views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
-        self.buckets.append(dict(params=ps, flat=flat, views=views, pending=len(ps), work=None, launched=False))
+        self.buckets.append(dict(index=len(self.buckets), params=ps, flat=flat, views=views, pending=len(ps), work=None, launched=False))
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -112,8 +113,19 @@ class GradBuckets:
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0 and self.overlap:
-                self._launch(b)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Launch, IN BUCKET-INDEX ORDER, every bucket whose predecessors have all been launched and whose own hooks have all
+        fired.  A bucket that is complete while an earlier one still waits for a gradient (a parameter unused on this rank this
+        step, a gated branch, an empty frame) is held back; `finish()` then launches the remainder in index order.  Every rank
+        therefore issues bucket 0, 1, 2, ... on the communicator whatever its local gradient arrival order was (ranks that
+        disagree on which parameters got a gradient would otherwise pair all-reduces of different buckets - torch DDP reduces
+        in index order for the same reason)."""
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, b):
         src, dst = [], []
@@ -126,20 +138,23 @@ class GradBuckets:
             torch._foreach_copy_(dst, src)
         b["work"] = dist.all_reduce(b["flat"], async_op=True)   # c10d: ordered after the copies, runs on its own stream
         b["launched"] = True
+        self.launch_log.append(b["index"])
 
     def prepare(self):
         for b in self.buckets:
             b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
             for p in b["params"]:
                 p.grad = None
+        self._next = 0
+        self.launch_log = []      # bucket indices in launch order (tests assert it is 0, 1, 2, ... on every rank)
         self._armed = True
 
     def finish(self):
         self._armed = False
         world = dist.get_world_size()
-        for b in self.buckets:   # buckets whose hooks did not all fire (unused parameters) or the "flat" route
-            if not b["launched"]:
-                self._launch(b)
+        for b in self.buckets[self._next:]:   # in index order: buckets held back behind one whose hooks did not all fire
+            self._launch(b)                  # (unused parameters), or every bucket on the "flat" route
+        self._next = len(self.buckets)
         for b in self.buckets:
             b["work"].wait()     # NCCL: the current stream waits for the collective, the host does not block
             if world > 1:

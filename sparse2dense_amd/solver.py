@@ -14,8 +14,12 @@ with lr and mom set by `OneCycle.step(global_step)` before the iteration (traine
 `OneCycleAdam` keeps that arithmetic and runs it as ONE fused multi-tensor kernel per <= 48 tensors (csrc/optim.hip) with the
 gradient-clip coefficient folded in as a device scalar: the norm is reduced on the device, never read by the host, and the
 clipped gradients are never written back.  CPU tensors (host-logic tests) take an equivalent torch implementation.
-State layout = torch.optim.Adam's (`state[p] = {step, exp_avg, exp_avg_sq}`), so `state_dict()` round-trips through the
-reference's checkpoint format.
+State layout = torch.optim.Adam's (`state[p] = {step, exp_avg, exp_avg_sq}`).  `load_state_dict` accepts (a) this class's own
+single-group state_dict and (b) the reference's: torch.optim.Adam over the TWO param groups `OptimWrapper.create` makes from
+`split_bn_bias(get_layer_groups(model))` (fastai_optim.py:17-28, apis/train.py:159-164) - every non-batch-norm leaf module's
+parameters first, then every batch-norm leaf's - which needs the model to rebuild the index map (`reference_param_order`).
+Every moment tensor is shape-checked against its parameter and re-laid to the parameter's strides before the raw-pointer
+kernel may see it; anything else is refused with a ValueError.
 """
 import ctypes
 import math
@@ -64,10 +68,36 @@ class OneCycle:
             self.optimizer.mom = mom
 
 
+def reference_param_order(model):
+    """The parameter order of the reference's optimizer (= the indices of its optimizer state_dict): leaf modules in
+    depth-first order (`flatten_model`, apis/train.py:159-160), non-batch-norm leaves first, then the batch-norm leaves
+    (`split_bn_bias`, fastai_optim.py:17-28), trainable parameters only, shared parameters once.  Parameters owned by a module
+    that also has children are not reached by the reference's grouping and are therefore not part of the order."""
+    from torch import nn
+
+    def leaves(m):
+        ch = list(m.children())
+        return sum((leaves(c) for c in ch), []) if ch else [m]
+
+    ls = leaves(model)
+    groups = ([m for m in ls if not isinstance(m, nn.modules.batchnorm._BatchNorm)], [m for m in ls if isinstance(m, nn.modules.batchnorm._BatchNorm)])
+    out, seen = [], set()
+    for g in groups:
+        part = []
+        for m in g:
+            for q in m.parameters(recurse=False):
+                if q.requires_grad and id(q) not in seen:
+                    seen.add(id(q))
+                    part.append(q)
+        out.append(part)
+    return out
+
+
 class OneCycleAdam:
     """Adam with true weight decay under an externally scheduled lr / momentum (see module docstring)."""
 
-    def __init__(self, params, lr=3e-3, mom=0.9, beta=0.99, eps=1e-8, wd=0.01, max_grad_norm=35.0):
+    def __init__(self, params, lr=3e-3, mom=0.9, beta=0.99, eps=1e-8, wd=0.01, max_grad_norm=35.0, model=None):
+        self.model = model      # only for load_state_dict of a reference-written optimizer state
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.mom, self.beta, self.eps, self.wd = lr, mom, beta, eps, wd
         self.max_grad_norm = max_grad_norm
@@ -95,12 +125,47 @@ class OneCycleAdam:
                                   "params": list(range(len(self.params)))}],
                 "wd": self.wd, "step_count": self.step_count}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, model=None):
+        groups = sd["param_groups"]
+        n_idx = sum(len(g["params"]) for g in groups)
+        if len(groups) == 1 and n_idx == len(self.params):
+            order = self.params                                    # this class's own layout
+        else:
+            model = self.model if model is None else model
+            if model is None:
+                raise ValueError(f"OneCycleAdam.load_state_dict: optimizer state with {len(groups)} param groups / {n_idx} parameters is not "
+                                 f"this optimizer's own layout ({len(self.params)} parameters, one group); pass the model to map the reference's "
+                                 "split_bn_bias ordering")
+            ref_groups = reference_param_order(model)
+            if [len(g["params"]) for g in groups] != [len(g) for g in ref_groups]:
+                raise ValueError("OneCycleAdam.load_state_dict: param group sizes "
+                                 f"{[len(g['params']) for g in groups]} do not match the reference ordering of this model {[len(g) for g in ref_groups]}")
+            order = [q for g in ref_groups for q in g]
+            ours = {id(q) for q in self.params}
+            if any(id(q) not in ours for q in order):
+                raise ValueError("OneCycleAdam.load_state_dict: the model has trainable parameters this optimizer does not own")
+        flat_ids = [i for g in groups for i in g["params"]]
+        pos = {int(i): k for k, i in enumerate(flat_ids)}
+        new_state = {}
         for i, st in sd["state"].items():
-            p = self.params[int(i)]
-            self.state[p] = {k: (v.to(p.device) if torch.is_tensor(v) else v) for k, v in st.items()}
-        g = sd["param_groups"][0]
-        self.lr, (self.mom, self.beta), self.eps = g["lr"], g["betas"], g["eps"]
+            if int(i) not in pos:
+                raise ValueError(f"OneCycleAdam.load_state_dict: state index {i} is in no param group")
+            p = order[pos[int(i)]]
+            ent = {}
+            for k, v in st.items():
+                if k == "step":
+                    ent[k] = int(v.item()) if torch.is_tensor(v) else int(v)       # newer torch.optim.Adam keeps a tensor
+                elif torch.is_tensor(v):
+                    if tuple(v.shape) != tuple(p.shape):
+                        raise ValueError(f"OneCycleAdam.load_state_dict: {k} of state {i} has shape {tuple(v.shape)}, its parameter {tuple(p.shape)}")
+                    # the kernel pairs elements by storage offset: same strides as the parameter (NCHW file -> channels_last model)
+                    ent[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(v)
+                else:
+                    ent[k] = v
+            new_state[p] = ent
+        self.state = new_state
+        g = groups[0]
+        self.lr, (self.mom, self.beta), self.eps = g["lr"], tuple(g["betas"]), g["eps"]
         self.wd = sd.get("wd", self.wd)
         self.step_count = sd.get("step_count", max([st["step"] for st in self.state.values()] or [0]))
 
@@ -147,11 +212,13 @@ class OneCycleAdam:
         same = lambda g, p: all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
         grads = [p.grad if (p.grad.dtype == torch.float32 and same(p.grad, p)) else torch.empty_like(p).copy_(p.grad) for p in ps]
         states = [self._state(p) for p in ps]
-        steps = {st["step"] for st in states}
-        assert len(steps) == 1, "OneCycleAdam: parameters must share one step counter"
-        step = states[0]["step"] + 1
+        # bias correction is a scalar per launch: parameters are grouped by their own step counter (torch.optim.Adam keeps one per
+        # parameter; a branch that starts receiving gradients later - a toggled PCR head, an unfrozen layer - has a younger one)
         for st in states:
-            st["step"] = step
+            st["step"] += 1
+        by_step = {}
+        for k, st in enumerate(states):
+            by_step.setdefault(st["step"], []).append(k)
         dev, stream = ps[0].device, _stream()
         cap = lib.s2d_adam_max_tensors()
         vp = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -170,14 +237,15 @@ class OneCycleAdam:
             _lib.check(lib.s2d_grad_norm_finalize_f32(ws.data_ptr(), written, float(max_norm), clip.data_ptr(), stream),
                        "s2d_grad_norm_finalize_f32")
         self._clip = clip
-        for i in range(0, len(ps), cap):
-            sl = slice(i, i + cap)
-            n = len(ps[sl])
-            _lib.check(lib.s2d_adam_step_f32(n, vp(ps[sl]), vp(grads[sl]), vp([st["exp_avg"] for st in states[sl]]),
-                                             vp([st["exp_avg_sq"] for st in states[sl]]),
-                                             (ctypes.c_int64 * n)(*[p.numel() for p in ps[sl]]), float(self.lr), float(self.mom),
-                                             float(self.beta), float(self.eps), float(self.wd), int(step),
-                                             None if clip is None else clip.data_ptr() + 4, stream), "s2d_adam_step_f32")
+        for step, members in by_step.items():
+            for i in range(0, len(members), cap):
+                ks = members[i:i + cap]
+                n = len(ks)
+                _lib.check(lib.s2d_adam_step_f32(n, vp([ps[k] for k in ks]), vp([grads[k] for k in ks]), vp([states[k]["exp_avg"] for k in ks]),
+                                                 vp([states[k]["exp_avg_sq"] for k in ks]),
+                                                 (ctypes.c_int64 * n)(*[ps[k].numel() for k in ks]), float(self.lr), float(self.mom),
+                                                 float(self.beta), float(self.eps), float(self.wd), int(step),
+                                                 None if clip is None else clip.data_ptr() + 4, stream), "s2d_adam_step_f32")
         # the kernel updated the parameters through raw pointers: their autograd version counters did not move, so drop the
         # packed weight images keyed on them (they are rebuilt at the next forward, as after any optimizer step)
         from .dense2d import clear_pack_cache
@@ -189,7 +257,7 @@ def build_one_cycle_optimizer(model, optimizer_config=None):
     """apis/train.py:168-186: Adam betas (0.9, 0.99), true weight decay `wd` (config `optimizer.wd`, 0.01), bn_wd=True."""
     wd = 0.01 if optimizer_config is None else getattr(optimizer_config, "wd", optimizer_config.get("wd", 0.01)
                                                        if isinstance(optimizer_config, dict) else 0.01)
-    return OneCycleAdam([p for p in model.parameters() if p.requires_grad], lr=3e-3, mom=0.9, beta=0.99, wd=wd)
+    return OneCycleAdam([p for p in model.parameters() if p.requires_grad], lr=3e-3, mom=0.9, beta=0.99, wd=wd, model=model)
 
 
 def build_one_cycle_scheduler(optimizer, lr_config, total_steps):
