@@ -1,23 +1,25 @@
 // Sparse-conv implicit GEMM, bf16 storage, REGISTER-GATHER form (r03; replaces the LDS-staged A tile of spconv_s16.hip).
 // (spconv.ops.indice_conv / indice_conv_backward; call sites det3d/models/backbones/scn.py:104-152)
 //
-// What bounded the LDS-staged kernel was not the L2 but the issue cost of the LDS-DMA pieces: a 128-row x 128-column
-// workgroup issued 32 one-KiB `global_load_lds` per 64-deep K-step (16 KiB gathered A + 16 KiB weight slab) next to 32 MFMAs
-// per wave, at 60-185 cycles of issue per piece (MI355X_MICROARCH.md, "LDS-DMA piece issue cost") - the step took ~1270
-// cycles against 544 of MFMA.  Here the A operand never touches LDS:
-//   * a wave owns MI 16-row MFMA tiles x ALL output columns.  Lane (r = lane & 15, q = lane >> 4) of v_mfma_f32_16x16x32_bf16
-//     holds A[row r][k = 8q..8q+7] = 16 contiguous bytes of the gathered input row, so the fragment IS one
-//     `buffer_load_dwordx4` from feature row nbr[offset][row r]; a missing neighbour is an out-of-range buffer offset
-//     (reads zero, moves no data, needs no zero page and no branch).  Four lanes cover 64 contiguous bytes of a row.
-//   * one step = one kernel offset (CIN >= 64) or 64 / CIN offsets (CIN < 64): the A registers of step s+1 are loaded while
-//     step s multiplies (register double buffer, loop unrolled by two), the gather indices one step further ahead.
-//   * only the weight slab of a step (K x COUT, 2..32 KiB, packed in fragment order) goes through LDS: global -> registers
-//     during step s-1 -> ds_write at the top of step s -> read by every wave in step s+1; two LDS stages, one barrier per step.
-//   * a workgroup is 8 waves (2 per SIMD) working on `tiles_per_block` <= 8 MI consecutive 16-row tiles dealt round-robin
-//     to the waves; the launcher sizes tiles_per_block so that the grid is a whole number of rounds of the 256 CUs.
-//   * 16-row tiles with no neighbour at a step skip their MFMAs (wave-uniform ballot of the indices).
-// The epilogue is the one of the LDS-staged kernel: bias, one bf16 rounding, 2*NJ-byte row stores, optional per-workgroup
-// (sum, sum of squares) rows for the BatchNorm1d that follows.
+// Measured on the LDS-staged kernel and on the first register-gather versions of this file (tools/spconv_kernel_bench.py with the
+// S2D_RG_DEBUG ablation switches, 128 -> 128 channels, 47 890 rows, 738 674 pairs): loads alone 43 us, MFMAs + weight-fragment LDS
+// reads alone 52 us, neither (index + weight-slab loads, barriers, epilogue) 28 us = ~1 us of exposed load latency per step;
+// two waves per SIMD with 32 rows each read every weight fragment from LDS once per 32 rows (256 KiB per step and CU).  Hence:
+//   * ONE wave per SIMD with the whole 512-register file: a wave owns MI (1..4) 16-row MFMA tiles x ALL output columns, so a
+//     weight fragment read from LDS feeds MI MFMAs, and there is room for a THREE-deep register ring of gathered A fragments:
+//     the rows of step s+2 are requested while step s multiplies (two steps = 3-4 k cycles of cover for ~2.4 k cycles of latency).
+//   * the A operand never touches LDS.  Lane (r = lane & 15, q = lane >> 4) of v_mfma_f32_16x16x32_bf16 holds
+//     A[row r][k = 8q..8q+7] = 16 contiguous bytes of the gathered input row, so the fragment IS one `buffer_load_dwordx4` from
+//     feature row nbr[offset][row r]; a missing neighbour is an out-of-range buffer offset (reads zero, moves no data, needs
+//     no zero page and no branch).
+//   * one step = 128 K-elements = 128 / CIN kernel offsets; gather indices are requested four steps ahead.
+//   * only the weight slab of a step (128 x COUT bf16, packed in fragment order) goes through LDS: global -> registers in
+//     step s -> ds_write in step s+1 -> read by every wave in step s+2; two LDS stages, one barrier per step.
+//   * no conditional memory operation and no peeled tail: the step count is padded to a multiple of three with phantom steps
+//     (indices -1, clamped slab), so hipcc's vmcnt bookkeeping sees one straight loop body and keeps every load class in flight.
+//   * a wave whose tiles have no neighbour at a step skips that step's MFMAs (wave-uniform ballot).
+// The epilogue: bias, one bf16 rounding, 2*NJ-byte row stores, optional per-workgroup (sum, sum of squares) rows for the
+// BatchNorm1d that follows.
 #include "s2d_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -28,33 +30,83 @@ namespace s2d {
 typedef float f32x4r __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 
-__host__ __device__ inline int rg_steps(int cin, int kvol) { return cin < 64 ? (kvol + 64 / cin - 1) / (64 / cin) : kvol; }
+constexpr int RG_KSTEP = 128;   // K elements per step
+__host__ __device__ inline int rg_steps(int cin, int kvol) { return (kvol * cin + RG_KSTEP - 1) / RG_KSTEP; }
 
 template <int CIN, int COUT, int MI_, int WAVES_>
 struct RgCfg {
     static constexpr int MI = MI_, WAVES = WAVES_;
-    static constexpr int OPS = CIN < 64 ? 64 / CIN : 1;      // kernel offsets per step
-    static constexpr int KC = CIN <= 64 ? 2 : CIN / 32;      // 32-deep MFMA K chunks per step
-    static constexpr int NIDX = CIN < 64 ? 2 : 1;            // gather indices per lane, tile and step (chunk c uses index c % NIDX)
-    static constexpr int NJ = COUT / 16;                     // 16-column MFMA tiles (a wave owns all of them)
+    static constexpr int OPS = RG_KSTEP / CIN;                // kernel offsets per step (1, 2, 4, 8)
+    static constexpr int KC = RG_KSTEP / 32;                  // 32-deep MFMA K chunks per step
+    static constexpr int NIDX = CIN == 128 ? 1 : (CIN == 64 ? 2 : 4);   // gather indices per lane, tile and step
+    static constexpr int NJ = COUT / 16;                      // 16-column MFMA tiles (a wave owns all of them)
     static constexpr int THREADS = WAVES * 64;
-    static constexpr int B_BYTES = KC * 32 * COUT * 2;       // weight slab of one step
+    static constexpr int B_BYTES = RG_KSTEP * COUT * 2;       // weight slab of one step
     static constexpr int B_PIECES = B_BYTES / 16;
-    static constexpr int B_LOADS = (B_PIECES + THREADS - 1) / THREADS;
-    static constexpr int CAP = WAVES * MI;                   // 16-row tiles per workgroup at most
+    static constexpr int B_LOADS = (B_PIECES + THREADS - 1) / THREADS;   // 16-byte pieces per thread
+    static constexpr bool B_FULL = B_PIECES % THREADS == 0;
+    static constexpr int CAP = WAVES * MI;                    // 16-row tiles per workgroup
     static constexpr size_t LDS = 2 * (size_t)B_BYTES > (size_t)WAVES * 2 * COUT * 4 ? 2 * (size_t)B_BYTES : (size_t)WAVES * 2 * COUT * 4;
 };
 
-// The packed weight image is the one of spconv_s16.hip's s16_pack_element with wn_count = 1:
-//   [64-deep K-step][h (2)][nt = COUT/16][lane = q*16 + r][e (8)],  K element 32 h + 8 q + e, column r * NJ + nt
-// (a lane's NJ accumulator columns are consecutive in the output row).  For CIN = 128 an offset is two consecutive K-steps.
+// packed weight image: [step][c (4)][nt = COUT/16][lane = q*16 + r][e (8)]   (one step = 128*COUT bf16, contiguous)
+//   K element kk = 32 c + 8 q + e  ->  kernel offset step*(128/CIN) + kk / CIN, input channel kk % CIN;  column r * NJ + nt
+// (a lane's NJ accumulator columns are consecutive in the output row).  Offsets past kvol are zero.
+// source w: [K][cin][cout] fp32, or [K][cout][cin] when transpose (data gradient), offsets mirrored when flip.
+__device__ __forceinline__ void rg_pack_element(const float *__restrict__ w, int kvol, int cin, int cout, int transpose, int flip, int64_t i,
+                                                __bf16 *__restrict__ out) {
+    const int64_t total = (int64_t)rg_steps(cin, kvol) * RG_KSTEP * cout;
+    if (i >= total) return;
+    const int nj = cout / 16;
+    int64_t x = i;
+    const int e = x % 8; x /= 8;
+    const int r = x % 16; x /= 16;
+    const int q = x % 4; x /= 4;
+    const int nt = x % nj; x /= nj;
+    const int c = x % 4; x /= 4;
+    const int step = (int)x;
+    const int kk = 32 * c + 8 * q + e;
+    const int k = step * (RG_KSTEP / cin) + kk / cin, ch = kk % cin;
+    const int co = r * nj + nt;
+    float v = 0.f;
+    if (k < kvol) {
+        const int ks = flip ? kvol - 1 - k : k;
+        v = transpose ? w[((int64_t)ks * cout + co) * cin + ch] : w[((int64_t)ks * cin + ch) * cout + co];
+    }
+    out[i] = (__bf16)v;
+}
 
-template <int CIN, int COUT, int MI, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__restrict__ in, unsigned in_bytes, const __bf16 *__restrict__ wpack,
-                                                               const float *__restrict__ bias, const int32_t *__restrict__ nbr, int n_out,
-                                                               int kvol, int tiles_per_block, __bf16 *__restrict__ out,
-                                                               float *__restrict__ stats_partial, int dbg) {
+__global__ __launch_bounds__(256) void rg_pack_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int transpose, int flip,
+                                                      __bf16 *__restrict__ out) {
+    rg_pack_element(w, kvol, cin, cout, transpose, flip, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, out);
+}
+
+// both operands of a layer in one launch: blockIdx.y = 0 the forward image [cin -> cout], 1 the data-gradient image [cout -> cin]
+__global__ __launch_bounds__(256) void rg_pack_pair_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int flip_d,
+                                                           __bf16 *__restrict__ out_f, __bf16 *__restrict__ out_d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) rg_pack_element(w, kvol, cin, cout, 0, 0, i, out_f);
+    else rg_pack_element(w, kvol, cout, cin, 1, flip_d, i, out_d);
+}
+
+// The work of one wave with MI valid tile slots (the workgroup's waves may run different instantiations: a workgroup of
+// tiles_per_block < WAVES * MI_max tiles deals its waves unequal tile counts; every instantiation executes the same barriers)
+template <int CIN, int COUT, int MI, int WAVES, int DBG>
+__device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned in_bytes, const __bf16 *__restrict__ wpack,
+                                                        const float *__restrict__ bias, const int32_t *__restrict__ nbr, int n_out, int kvol,
+                                                        int tiles_per_block, __bf16 *__restrict__ out, float *__restrict__ stats_partial,
+                                                        int dbg_arg, long long *__restrict__ trace) {
     typedef RgCfg<CIN, COUT, MI, WAVES> C;
+    const int dbg = DBG == 1 ? dbg_arg : 0;   // DBG: 0 production, 1 ablation switches + stamps, 2 stamps only (the production instruction stream)
+    // dbg & 32: wave 0 of every workgroup records s_memtime at kernel entry, after the prologue, after every step and at the end
+    auto stamp = [&](int k) {
+        if (DBG && (dbg_arg & 32) && trace && threadIdx.x == 0) {
+            trace[(int64_t)blockIdx.x * 64 + k] = (long long)__builtin_readcyclecounter();
+            if (k == 0) trace[(int64_t)blockIdx.x * 64 + 60] = (long long)__builtin_amdgcn_s_memrealtime();   // 100 MHz, chip-wide
+            if (k == 63) trace[(int64_t)blockIdx.x * 64 + 61] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);   // ablation switches (tools/spconv_kernel_bench.py): compiled in for two shapes only
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -67,32 +119,30 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
     const int tile_end = min(total_tiles, tile0 + tiles_per_block);
     const int steps = rg_steps(CIN, kvol);
 
-    // this lane's output row per tile slot (-1: no such tile / row past the end)
-    int row[MI];
+    // this lane's output row per tile slot (-1: no such tile / row past the end); tiles are dealt round-robin to the waves
+    int row[MI], rowc[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int tl = tile0 + wid + WAVES * i;
         const int rw = tl * 16 + r;
         row[i] = (tl < tile_end && rw < n_out) ? rw : -1;
+        rowc[i] = row[i] < 0 ? 0 : row[i];
     }
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(in, in_bytes);
-    // byte offset of this lane's 16 bytes inside a gathered row for chunk c, and which of the step's offsets it belongs to
-    auto chunk_byte = [&](int c) -> unsigned { return CIN >= 64 ? (unsigned)(64 * c + 16 * q) : (CIN == 32 ? (unsigned)(16 * q) : (unsigned)(16 * (q & 1))); };
-    auto chunk_off = [&](int s, int j) -> int { return CIN >= 64 ? s : (CIN == 32 ? 2 * s + j : 4 * s + 2 * j + (q >> 1)); };
+    // chunk c of a step: which of the step's NIDX index registers it gathers with, its kernel offset, and the byte offset of this
+    // lane's 16 bytes inside the gathered row
+    auto chunk_j = [&](int c) -> int { return CIN == 128 ? 0 : (CIN == 64 ? c >> 1 : c); };
+    auto idx_off = [&](int s, int j) -> int { return CIN == 16 ? 8 * s + 2 * j + (q >> 1) : s * C::OPS + j; };
+    auto chunk_byte = [&](int c) -> unsigned {
+        return CIN == 128 ? (unsigned)(64 * c + 16 * q) : (CIN == 64 ? (unsigned)(64 * (c & 1) + 16 * q) : (CIN == 32 ? (unsigned)(16 * q) : (unsigned)(16 * (q & 1))));
+    };
 
-    // A fragments travel as raw 4-dword vectors (a bf16x8 value carried around the loop is rebuilt half by half by hipcc, which
-    // puts a wait on the load right behind its issue); gather indices are loaded unconditionally from a clamped address and
-    // masked when they are consumed, so that no step of the loop has a conditional memory operation: hipcc's vmcnt bookkeeping
-    // then keeps every load class one full step in flight.
     typedef float f4 __attribute__((ext_vector_type(4)));
-    int rowc[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) rowc[i] = row[i] < 0 ? 0 : row[i];
-    auto load_idx = [&](int s, int (&idx)[MI][C::NIDX]) {
+    auto load_idx = [&](int s, int (&idx)[MI][C::NIDX]) {   // unconditional, clamped; masked by mask_idx when consumed
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < C::NIDX; ++j) idx[i][j] = nbr[(int64_t)min(chunk_off(s, j), kvol - 1) * n_out + rowc[i]];
+            for (int j = 0; j < C::NIDX; ++j) idx[i][j] = nbr[(int64_t)min(idx_off(s, j), kvol - 1) * n_out + rowc[i]];
     };
     auto mask_idx = [&](int s, int (&idx)[MI][C::NIDX]) {
 #pragma unroll
@@ -100,7 +150,7 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
 #pragma unroll
             for (int j = 0; j < C::NIDX; ++j) {
                 if (dbg & 1) idx[i][j] = rowc[i];   // ablation: sequential rows, every neighbour present
-                if (!(row[i] >= 0 && chunk_off(s, j) < kvol)) idx[i][j] = -1;
+                if (!(row[i] >= 0 && idx_off(s, j) < kvol)) idx[i][j] = -1;
             }
     };
     auto load_a = [&](const int (&idx)[MI][C::NIDX], f4 (&a)[MI][C::KC]) {
@@ -108,31 +158,21 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int c = 0; c < C::KC; ++c) {
-                const int j = idx[i][c % C::NIDX];
+                const int j = idx[i][chunk_j(c)];
                 const unsigned off = (j >= 0 && !(dbg & 4)) ? (unsigned)j * (unsigned)(CIN * 2) + chunk_byte(c) : BUF_OOB;
                 a[i][c] = buf_load4(rin, off, 0);
             }
     };
-    auto tile_flags = [&](const int (&idx)[MI][C::NIDX], bool (&on)[MI][C::NIDX]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < C::NIDX; ++j) on[i][j] = __ballot(idx[i][j] >= 0) != 0ull;
-    };
     auto load_b = [&](int s, f4 (&breg)[C::B_LOADS]) {
-        const char *src = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? 0 : s) * C::B_BYTES;
+        const char *src = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? 0 : min(s, steps - 1)) * C::B_BYTES;
 #pragma unroll
-        for (int u = 0; u < C::B_LOADS; ++u) {
-            const int piece = t + C::THREADS * u;
-            if (C::B_PIECES % C::THREADS == 0 || piece < C::B_PIECES) breg[u] = *reinterpret_cast<const f4 *>(src + (size_t)piece * 16);
-        }
+        for (int u = 0; u < C::B_LOADS; ++u)
+            if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) breg[u] = *reinterpret_cast<const f4 *>(src + (size_t)(t + C::THREADS * u) * 16);
     };
     auto store_b = [&](int stage, const f4 (&breg)[C::B_LOADS]) {
 #pragma unroll
-        for (int u = 0; u < C::B_LOADS; ++u) {
-            const int piece = t + C::THREADS * u;
-            if (C::B_PIECES % C::THREADS == 0 || piece < C::B_PIECES) *reinterpret_cast<f4 *>(smem + stage * C::B_BYTES + (size_t)piece * 16) = breg[u];
-        }
+        for (int u = 0; u < C::B_LOADS; ++u)
+            if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) *reinterpret_cast<f4 *>(smem + stage * C::B_BYTES + (size_t)(t + C::THREADS * u) * 16) = breg[u];
     };
 
     f32x4r acc[MI][C::NJ];
@@ -141,91 +181,97 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
 #pragma unroll
         for (int n = 0; n < C::NJ; ++n) acc[i][n] = f32x4r{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int stage, const f4 (&a)[MI][C::KC], const bool (&on)[MI][C::NIDX]) {
-        const char *bs = smem + stage * C::B_BYTES;
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < C::NIDX; ++j) any |= on[i][j];
-        if (any && !(dbg & 2)) {
-            // ONE straight-line block per step (a second, per-tile-branched path made hipcc copy the accumulators between the
-            // paths): tiles without a neighbour multiply the zeros their out-of-range loads returned.  The weight fragments
-            // travel in groups of FG column tiles, group g+1 is read from LDS while group g multiplies.
-            constexpr int FG = C::NJ < 4 ? C::NJ : 4, GPC = C::NJ / FG, NG = C::KC * GPC;
-            bf16x8r b[2][FG];
-            auto read_g = [&](int g, bf16x8r (&bb)[FG]) {
-#pragma unroll
-                for (int n = 0; n < FG; ++n)
-                    bb[n] = *reinterpret_cast<const bf16x8r *>(bs + (((g / GPC) * C::NJ + (g % GPC) * FG + n) * 64 + lane) * 16);
-            };
-            read_g(0, b[0]);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) read_g(g + 1, b[(g + 1) & 1]);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const bf16x8r av = __builtin_bit_cast(bf16x8r, a[i][g / GPC]);
-#pragma unroll
-                    for (int n = 0; n < FG; ++n)
-                        acc[i][(g % GPC) * FG + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[g & 1][n], acc[i][(g % GPC) * FG + n], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
+    // Two ring slots (step parity), refilled IN PLACE: slot p holds A(s) while step s (parity p) multiplies; as soon as the MFMAs
+    // of K chunk c have been issued, its registers are reloaded with A(s+2)[.][c], so every fragment is requested two steps
+    // before its use without a third register set (a three-slot ring made hipcc shuffle 116 registers between the VGPR and AGPR
+    // files per loop iteration).  idx_p holds the gather indices of step s+2 during step s and is reloaded with those of step
+    // s+4 after the last refill.  The loop is unrolled by two = the parity of the LDS weight stage.
     int idx0[MI][C::NIDX], idx1[MI][C::NIDX];
-    bool on0[MI][C::NIDX], on1[MI][C::NIDX];
     f4 a0[MI][C::KC], a1[MI][C::KC];
     f4 breg[C::B_LOADS];
+    const int steps2 = (steps + 1) / 2 * 2;
 
-    // prologue: B(0) -> stage 0, idx(0) -> A(0), idx(1), B(1) -> registers
+    // prologue: idx(0), idx(1); B(0) -> stage 0; A(0), A(1); B(1) -> registers; idx(2), idx(3)
     load_idx(0, idx0);
+    load_idx(1, idx1);
     load_b(0, breg);
-    if (steps > 1) load_idx(1, idx1);
     mask_idx(0, idx0);
     load_a(idx0, a0);
-    tile_flags(idx0, on0);
+    mask_idx(1, idx1);
+    load_a(idx1, a1);
     store_b(0, breg);
-    if (steps > 1) load_b(1, breg);
+    load_b(1, breg);
+    load_idx(2, idx0);
+    load_idx(3, idx1);
+    stamp(1);
 
-    // Step s (unrolled by two; slot = parity):  barrier | idx(s+2) -> the slot idx(s) came from | A(s+1) from idx(s+1) | multiply
-    // step s | ds_write B(s+1) | load B(s+2).  Every load is consumed one step after its issue: idx(s+2) at the top of step s+1,
-    // A(s+1) by the MFMAs of step s+1, B(s+2) by the ds_write at the end of step s+1.
-    auto step = [&](int s, auto has1, auto has2, const f4 (&acur)[MI][C::KC], f4 (&anxt)[MI][C::KC], const bool (&oncur)[MI][C::NIDX],
-                    bool (&onnxt)[MI][C::NIDX], int (&idxcur)[MI][C::NIDX], int (&idxnxt)[MI][C::NIDX]) {
-        const int stage = s & 1;
+    // Step s (slot = parity):  barrier | NG groups, group g = { ds_read the weight fragments of group g+1 | its share of the
+    // step's memory tasks: ds_write B(s+1) + reload B(s+2) pieces, refill of the A chunk whose MFMAs were issued in the groups
+    // before | MI*FG MFMAs on the fragments read during group g-1 } closed by a scheduling barrier | refill of the last chunk,
+    // idx(s+4).  With one wave per SIMD nothing else fills the matrix pipe while this wave issues memory instructions or waits
+    // for a fragment, and hipcc left to itself puts a step's loads in front of its MFMAs and every fragment read right in front
+    // of its first use; the scheduling barriers pin the interleave written here.
+    constexpr int FG = C::NJ < 4 ? C::NJ : 4, GPC = C::NJ / FG, NG = C::KC * GPC;
+    constexpr int BPER = (C::B_LOADS + NG - 1) / NG;   // B pieces per group
+    auto step = [&](int s, auto parity, f4 (&a)[MI][C::KC], int (&idx)[MI][C::NIDX]) {
+        constexpr int stage = decltype(parity)::value;
         __syncthreads();   // B(s) visible in `stage`; every wave is done reading the other stage (step s-1)
-        if constexpr (decltype(has2)::value) load_idx(s + 2, idxcur);
-        if constexpr (decltype(has1)::value) {
-            mask_idx(s + 1, idxnxt);
-            load_a(idxnxt, anxt);
-            tile_flags(idxnxt, onnxt);
+        mask_idx(s + 2, idx);
+        const char *bs = smem + stage * C::B_BYTES;
+        char *bw = smem + (stage ^ 1) * C::B_BYTES;
+        const char *bsrc = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? 0 : min(s + 2, steps - 1)) * C::B_BYTES;
+        auto b_task = [&](int u) {
+            if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) {
+                *reinterpret_cast<f4 *>(bw + (size_t)(t + C::THREADS * u) * 16) = breg[u];                 // B(s+1) -> LDS
+                if (!(dbg & 64)) breg[u] = *reinterpret_cast<const f4 *>(bsrc + (size_t)(t + C::THREADS * u) * 16);   // B(s+2) -> registers
+            }
+        };
+        auto refill = [&](int c) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int j = idx[i][chunk_j(c)];
+                const unsigned off = (j >= 0 && !(dbg & 4)) ? (unsigned)j * (unsigned)(CIN * 2) + chunk_byte(c) : BUF_OOB;
+                a[i][c] = buf_load4(rin, off, 0);
+            }
+        };
+        f4 b[2][FG];
+        auto read_g = [&](int g, f4 (&bb)[FG]) {
+#pragma unroll
+            for (int n = 0; n < FG; ++n)
+                bb[n] = *reinterpret_cast<const f4 *>(bs + (((g / GPC) * C::NJ + (g % GPC) * FG + n) * 64 + lane) * 16);
+        };
+        read_g(0, b[0]);
+        if (dbg & 16) read_g(0, b[1]);   // ablation: one fragment group per step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG && !(dbg & 16)) read_g(g + 1, b[(g + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < C::B_LOADS; ++u)
+                if (u / BPER == g) b_task(u);
+            if (g > 0 && g % GPC == 0) refill(g / GPC - 1);
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int n = 0; n < FG; ++n)
+                        // in-place accumulate in the AGPR file, written as asm: with the builtin hipcc gave the MFMAs a second
+                        // accumulator set (dst != src C) and copied ~120 registers back per loop iteration
+                        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][(g % GPC) * FG + n]) : "v"(a[i][g / GPC]), "v"(b[g & 1][n]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        compute(stage, acur, oncur);
-        if constexpr (decltype(has1)::value) store_b(stage ^ 1, breg);
-        if constexpr (decltype(has2)::value) load_b(s + 2, breg);
+        refill(C::KC - 1);
+        load_idx(s + 4, idx);
+        if (s + 2 < 60) stamp(s + 2);
     };
-    constexpr std::true_type T{};
-    constexpr std::false_type F{};
-    int s = 0;
-    for (; s + 3 < steps; s += 2) {
-        step(s, T, T, a0, a1, on0, on1, idx0, idx1);
-        step(s + 1, T, T, a1, a0, on1, on0, idx1, idx0);
-    }
-    const int rem = steps - s;   // 1..3 (steps >= 1)
-    if (rem == 3) {
-        step(s, T, T, a0, a1, on0, on1, idx0, idx1);
-        step(s + 1, T, F, a1, a0, on1, on0, idx1, idx0);
-        step(s + 2, F, F, a0, a1, on0, on1, idx0, idx1);
-    } else if (rem == 2) {
-        step(s, T, F, a0, a1, on0, on1, idx0, idx1);
-        step(s + 1, F, F, a1, a0, on1, on0, idx1, idx0);
-    } else {
-        step(s, F, F, a0, a1, on0, on1, idx0, idx1);
+    for (int s = 0; s < steps2; s += 2) {
+        step(s, std::integral_constant<int, 0>{}, a0, idx0);
+        step(s + 1, std::integral_constant<int, 1>{}, a1, idx1);
     }
 
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the accumulators were written by asm MFMAs: no hazard bookkeeping by the compiler
     // epilogue: C/D layout row = 4 q + reg, column (of tile n) = r  ->  output column r * NJ + n
     float bv[C::NJ], s1[C::NJ], s2[C::NJ];
 #pragma unroll
@@ -297,7 +343,34 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
             stats_partial[((int64_t)block * 2 + which) * COUT + col] = s;
         }
     }
+    stamp(63);
 }
+
+template <int CIN, int COUT, int MI, int WAVES, int DBG>
+__global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__restrict__ in, unsigned in_bytes, const __bf16 *__restrict__ wpack,
+                                                               const float *__restrict__ bias, const int32_t *__restrict__ nbr, int n_out,
+                                                               int kvol, int tiles_per_block, __bf16 *__restrict__ out,
+                                                               float *__restrict__ stats_partial, int dbg_arg, long long *__restrict__ trace) {
+    // valid tile slots of this wave (tiles are dealt round-robin: slot i = tile0 + wave + WAVES * i)
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_tiles = (n_out + 15) >> 4;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * tiles_per_block;
+    if (tile0 >= total_tiles) return;
+    const int tile_end = min(total_tiles, tile0 + tiles_per_block);
+    int nt = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) nt += (tile0 + wid + WAVES * i < tile_end) ? 1 : 0;
+    nt = __builtin_amdgcn_readfirstlane(nt);
+#define RG_ARGS in, in_bytes, wpack, bias, nbr, n_out, kvol, tiles_per_block, out, stats_partial, dbg_arg, trace
+    if constexpr (MI >= 4) { if (nt == 4) { rg_wave<CIN, COUT, 4, WAVES, DBG>(RG_ARGS); return; } }
+    if constexpr (MI >= 3) { if (nt == 3) { rg_wave<CIN, COUT, 3, WAVES, DBG>(RG_ARGS); return; } }
+    if constexpr (MI >= 2) { if (nt == 2) { rg_wave<CIN, COUT, 2, WAVES, DBG>(RG_ARGS); return; } }
+    rg_wave<CIN, COUT, 1, WAVES, DBG>(RG_ARGS);   // also a wave without a tile: one phantom slot, same barriers
+#undef RG_ARGS
+}
+
+static long long *g_rg_trace = nullptr;   // device buffer [grid][64] for the dbg & 32 timestamps (s2d_debug_rg_trace)
+void rg_set_trace(void *p) { g_rg_trace = (long long *)p; }
 
 // ---- launch plan -------------------------------------------------------------------------------------------------
 struct RgPlan {
@@ -315,24 +388,32 @@ static int rg_cus() {
     return cus;
 }
 
+// rows per workgroup: the fewest whole rounds of one workgroup per CU that cover the tiles, then the tile count per workgroup
+// that spreads them evenly (a 47 890-row stage = 2 994 tiles runs as 250 workgroups of 12 tiles, not 187 of 16)
 RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout) {
-    (void)kvol; (void)cin;
-    int mi = cout == 128 ? 2 : 4, waves = 8, tpb = 0;
+    (void)kvol; (void)cin; (void)cout;
+    const int64_t tiles = ceil_div(n_out, 16);
+    int mi = 0, waves = 4, tpb = 0;
     if (const char *ov = getenv("S2D_RG_PLAN")) {   // tuning hook: "mi,waves[,tiles_per_block]"
         int a = 0, b = 0, c = 0;
         const int got = sscanf(ov, "%d,%d,%d", &a, &b, &c);
-        if (got >= 2 && (a == 1 || a == 2 || a == 4) && (b == 4 || b == 8) && !(cout == 128 && a == 4)) {
+        if (got >= 2 && a >= 1 && a <= 4 && (b == 4 || b == 8) && !(b == 8 && a > 2 && cout > 64)) {
             mi = a; waves = b;
             if (got == 3 && c >= 1 && c <= a * b) tpb = c;
         }
     }
-    const int64_t tiles = ceil_div(n_out, 16);
-    const int cap = mi * waves;
+    if (!mi) {
+        const int mi_max = 4;
+        const int64_t per_round = (int64_t)rg_cus();
+        const int64_t rounds = std::max<int64_t>(1, ceil_div(tiles, per_round * waves * mi_max));
+        const int64_t want = std::max<int64_t>(1, ceil_div(tiles, per_round * rounds));   // tiles per workgroup
+        mi = (int)std::min<int64_t>(mi_max, ceil_div(want, waves));
+        tpb = (int)std::min<int64_t>(want, (int64_t)waves * mi);
+    }
     if (!tpb) {
-        // whole rounds of the chip: the smallest number of rounds that fits, then equal shares
-        const int64_t per_round = (int64_t)rg_cus() * (8 / waves);
-        const int64_t rounds = std::max<int64_t>(1, ceil_div(tiles, per_round * cap));
-        tpb = (int)std::min<int64_t>(cap, std::max<int64_t>(1, ceil_div(tiles, per_round * rounds)));
+        const int64_t per_round = (int64_t)rg_cus();
+        const int64_t rounds = std::max<int64_t>(1, ceil_div(tiles, per_round * waves * mi));
+        tpb = (int)std::min<int64_t>((int64_t)waves * mi, std::max<int64_t>(1, ceil_div(tiles, per_round * rounds)));
     }
     return RgPlan{mi, waves, tpb, (unsigned)std::max<int64_t>(1, ceil_div(tiles, tpb))};
 }
@@ -341,16 +422,20 @@ template <int CIN, int COUT, int MI, int WAVES>
 static int rg_launch(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf16 *wpack, const float *bias, const int32_t *nbr, int n_out, int kvol,
                      __bf16 *out, float *stats, hipStream_t st) {
     typedef RgCfg<CIN, COUT, MI, WAVES> C;
-    auto kern = spconv_rg_kernel<CIN, COUT, MI, WAVES>;
-    static bool attr_done = false;
-    if (!attr_done && C::LDS > 48 * 1024) {
-        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_done = true;
-    }
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("S2D_RG_DEBUG") ? atoi(getenv("S2D_RG_DEBUG")) : 0;   // ablation switches for tools/spconv_kernel_bench.py
+    auto kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 0>;
+    if constexpr (CIN == COUT && CIN >= 64 && (MI >= 3 || WAVES == 8)) {
+        if (dbg == 32) kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 2>;
+        else if (dbg) kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 1>;
+    }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[dbg != 0] && C::LDS > 48 * 1024) {
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr_done[dbg != 0] = true;
+    }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(p.grid)), dim3(C::THREADS), C::LDS, st, in, (unsigned)(n_in * CIN * 2), wpack, bias, nbr, n_out, kvol,
-                       p.tiles_per_block, out, stats, dbg);
+                       p.tiles_per_block, out, stats, dbg, g_rg_trace);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -358,16 +443,25 @@ static int rg_launch(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf
 template <int CIN, int COUT>
 static int rg_dispatch_plan(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf16 *wpack, const float *bias, const int32_t *nbr, int n_out,
                             int kvol, __bf16 *out, float *stats, hipStream_t st) {
-#define RG_CASE(MI_, W_) \
-    if (p.mi == MI_ && p.waves == W_) return rg_launch<CIN, COUT, MI_, W_>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st)
-    RG_CASE(2, 8);
-    RG_CASE(2, 4);
-    RG_CASE(1, 8);
-    if constexpr (COUT != 128) {
-        RG_CASE(4, 8);
-        RG_CASE(4, 4);
+    if (p.waves == 8) {
+        switch (p.mi) {
+            case 1: return rg_launch<CIN, COUT, 1, 8>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+            case 2: return rg_launch<CIN, COUT, 2, 8>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+        }
+        if constexpr (COUT <= 64) {
+            switch (p.mi) {
+                case 3: return rg_launch<CIN, COUT, 3, 8>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+                case 4: return rg_launch<CIN, COUT, 4, 8>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+            }
+        }
+        return S2D_ERR_UNSUPPORTED;
     }
-#undef RG_CASE
+    switch (p.mi) {
+        case 1: return rg_launch<CIN, COUT, 1, 4>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+        case 2: return rg_launch<CIN, COUT, 2, 4>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+        case 3: return rg_launch<CIN, COUT, 3, 4>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+        case 4: return rg_launch<CIN, COUT, 4, 4>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
+    }
     return S2D_ERR_UNSUPPORTED;
 }
 
@@ -375,8 +469,6 @@ template <int CIN>
 static int rg_dispatch_cout(int cout, const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf16 *wpack, const float *bias, const int32_t *nbr,
                             int n_out, int kvol, __bf16 *out, float *stats, hipStream_t st) {
     switch (cout) {
-        case 16: return rg_dispatch_plan<CIN, 16>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
-        case 32: return rg_dispatch_plan<CIN, 32>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
         case 64: return rg_dispatch_plan<CIN, 64>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
         case 128: return rg_dispatch_plan<CIN, 128>(p, in, n_in, wpack, bias, nbr, n_out, kvol, out, stats, st);
     }
@@ -388,13 +480,28 @@ int rg_run(const void *in_feat, int64_t n_in, const void *packed_weight, const f
     const RgPlan plan = rg_plan(n_out, kvol, cin, cout);
     const __bf16 *in = (const __bf16 *)in_feat, *wp = (const __bf16 *)packed_weight;
     __bf16 *out = (__bf16 *)out_feat;
-    switch (cin) {
-        case 16: return rg_dispatch_cout<16>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
-        case 32: return rg_dispatch_cout<32>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
+    switch (cin) {   // 16 / 32 channels: the LDS-staged kernel of spconv_s16.hip (64-byte rows: latency hiding by occupancy wins there)
         case 64: return rg_dispatch_cout<64>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
         case 128: return rg_dispatch_cout<128>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
     }
     return S2D_ERR_UNSUPPORTED;
+}
+
+size_t rg_packed_elems(int kvol, int cin, int cout) { return (size_t)rg_steps(cin, kvol) * RG_KSTEP * cout; }
+
+int rg_pack(const float *weight, int kvol, int cin, int cout, int transpose, int flip, void *packed, hipStream_t st) {
+    const int64_t total = (int64_t)rg_packed_elems(kvol, cin, cout);
+    hipLaunchKernelGGL(rg_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, weight, kvol, cin, cout, transpose, flip, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+int rg_pack_pair(const float *weight, int kvol, int cin, int cout, int flip_dgrad, void *packed_fwd, void *packed_dgrad, hipStream_t st) {
+    const int64_t total = (int64_t)std::max(rg_packed_elems(kvol, cin, cout), rg_packed_elems(kvol, cout, cin));
+    hipLaunchKernelGGL(rg_pack_pair_kernel, dim3((unsigned)ceil_div(total, 256), 2), dim3(256), 0, st, weight, kvol, cin, cout, flip_dgrad,
+                       (__bf16 *)packed_fwd, (__bf16 *)packed_dgrad);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
 }
 
 }  // namespace s2d

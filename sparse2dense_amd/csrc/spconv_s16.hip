@@ -312,16 +312,20 @@ struct RgPlan {
 RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout);
 int rg_run(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr, int64_t n_out, int kvol, int cin,
            int cout, void *out_feat, float *stats_partial, hipStream_t st);
-static bool use_rg() {
+size_t rg_packed_elems(int kvol, int cin, int cout);
+int rg_pack(const float *weight, int kvol, int cin, int cout, int transpose, int flip, void *packed, hipStream_t st);
+int rg_pack_pair(const float *weight, int kvol, int cin, int cout, int flip_dgrad, void *packed_fwd, void *packed_dgrad, hipStream_t st);
+void rg_set_trace(void *p);
+static bool use_rg(int cin, int cout) {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("S2D_S16_KERNEL");
         v = !(e && strcmp(e, "lds") == 0);
     }
-    return v != 0;
+    return v != 0 && cin >= 64 && cout >= 64;
 }
 
-static int s16_wn(int cout, int bm) { return use_rg() ? 1 : (cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1)); }
+static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
 
 // Launch plan (tile template height and rows per workgroup).
 struct S16Plan {
@@ -396,10 +400,15 @@ static bool s16_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 128; }
 
 using namespace s2d;
 
+/* tuning aid (tools/spconv_kernel_bench.py --trace): device buffer int64[grid][64] that the ablation build of the register-gather
+ * kernel fills with per-step s_memtime stamps when S2D_RG_DEBUG has bit 32 set; nullptr switches it off */
+extern "C" void s2d_debug_rg_trace(void *buf) { rg_set_trace(buf); }
+
 extern "C" int s2d_spconv_s16_supported(int cin, int cout) { return s16_ok(cin) && s16_ok(cout); }
 
 extern "C" size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout) {
     if (!s2d_spconv_s16_supported(cin, cout) || kvol <= 0) return 0;
+    if (use_rg(cin, cout)) return rg_packed_elems(kvol, cin, cout);
     return (size_t)s16_steps(cin, kvol) * 64 * cout;
 }
 
@@ -410,6 +419,7 @@ extern "C" int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int ci
         set_error("spconv_s16_pack: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
+    if (use_rg(cin, cout)) return rg_pack(weight, kvol, cin, cout, transpose, flip, packed, (hipStream_t)stream);
     const int64_t total = (int64_t)s2d_spconv_s16_packed_elems(kvol, cin, cout);
     hipLaunchKernelGGL(s16_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, kvol, cin,
                        cout, s16_wn(cout, s16_plan(n_out, kvol, cin, cout).bm), transpose, flip, (__bf16 *)packed);
@@ -426,6 +436,7 @@ extern "C" int s2d_spconv_s16_pack_weights_pair(const float *weight, int kvol, i
         set_error("spconv_s16_pack_pair: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
+    if (use_rg(cin, cout)) return rg_pack_pair(weight, kvol, cin, cout, flip_dgrad, packed_fwd, packed_dgrad, (hipStream_t)stream);
     const int64_t total = std::max<int64_t>((int64_t)s2d_spconv_s16_packed_elems(kvol, cin, cout), (int64_t)s2d_spconv_s16_packed_elems(kvol, cout, cin));
     hipLaunchKernelGGL(s16_pack_pair_kernel, dim3((unsigned)ceil_div(total, 256), 2), dim3(256), 0, (hipStream_t)stream, weight, kvol, cin, cout,
                        s16_wn(cout, s16_plan(n_out_fwd, kvol, cin, cout).bm), s16_wn(cin, s16_plan(n_out_dgrad, kvol, cout, cin).bm), flip_dgrad,
@@ -437,7 +448,7 @@ extern "C" int s2d_spconv_s16_pack_weights_pair(const float *weight, int kvol, i
 /* rows of the per-workgroup statistics s2d_spconv_s16_fwd_stats writes for a launch over n_out rows */
 extern "C" int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout) {
     if (n_out <= 0 || kvol <= 0 || !s2d_spconv_s16_supported(cin, cout)) return 0;
-    if (use_rg()) return (int64_t)rg_plan(n_out, kvol, cin, cout).grid;
+    if (use_rg(cin, cout)) return (int64_t)rg_plan(n_out, kvol, cin, cout).grid;
     return (int64_t)s16_plan(n_out, kvol, cin, cout).grid;
 }
 
@@ -464,7 +475,7 @@ extern "C" int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const
     if (n_out == 0) return S2D_OK;
     S2D_CHECK_ARG(in_feat && packed_weight && nbr && out_feat && zero_page && n_in > 0, "spconv_s16_fwd: null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (use_rg()) {
+    if (use_rg(cin, cout)) {
         S2D_CHECK_ARG(n_in * cin * 2 < (int64_t)BUF_OOB, "spconv_s16_fwd: feature matrix of %lld rows exceeds the 2 GiB buffer window", (long long)n_in);
         return rg_run(in_feat, n_in, packed_weight, bias, nbr, n_out, kvol, cin, cout, out_feat, stats_partial, st);
     }

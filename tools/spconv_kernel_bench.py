@@ -13,7 +13,8 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from sparse2dense_amd import hip_ops as H, waymo_configs
 from sparse2dense_amd.data import SyntheticFrames, attach_geometry
@@ -24,6 +25,7 @@ ap.add_argument("--check", action="store_true")
 ap.add_argument("--only", type=int, default=0, help="only shapes with this many input channels")
 ap.add_argument("--wgrad", action="store_true")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--trace", action="store_true", help="with S2D_RG_DEBUG bit 32: per-step s_memtime stamps of wave 0 of every workgroup")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 model = build_detector(waymo_configs.s2d_student()).to(dev)
@@ -90,6 +92,33 @@ for name, nbr, n_in, n_out, cin, cout, r in cases:
         usw = timeit(lambda: H.spconv_s16_wgrad(feat, dout, nbr, kvol), args.iters)
         rec["wgrad_us"] = round(usw, 1)
         rec["wgrad_tflops"] = round(2.0 * r * cin * cout / usw * 1e-6, 1)
+    if args.trace:
+        import ctypes
+        from sparse2dense_amd import _lib
+        lib = _lib.load()
+        tb = torch.zeros((4096, 64), dtype=torch.int64, device=dev)
+        lib.s2d_debug_rg_trace.argtypes = [ctypes.c_void_p]
+        lib.s2d_debug_rg_trace.restype = None
+        lib.s2d_debug_rg_trace(ctypes.c_void_p(tb.data_ptr()))
+        fn(); torch.cuda.synchronize()
+        lib.s2d_debug_rg_trace(None)
+        t = tb.cpu().numpy().astype("float64")
+        used = t[:, 0] > 0
+        t = t[used]
+        if len(t):
+            t0 = t[:, 0].min()
+            nst = int((t[0, 2:60] > 0).sum())
+            rt0, rt1 = t[:, 60], t[:, 61]
+            d = t[:, 1:2 + nst] - t[:, 0:1 + nst]          # [prologue, step 0, step 1, ...] durations per workgroup (100 MHz ticks?)
+            rec["trace"] = dict(blocks=int(len(t)), start_spread=float(t[:, 0].max() - t0), prologue_med=float(np.median(d[:, 0])),
+                                step_med=[float(x) for x in np.median(d[:, 1:], 0)], step_max=[float(x) for x in d[:, 1:].max(0)],
+                                epilogue_med=float(np.median(t[:, 63] - t[:, 1 + nst])), total_med=float(np.median(t[:, 63] - t[:, 0])),
+                                realtime_us=dict(wg_med=float(np.median(rt1 - rt0)) / 100, first_start_to_last_end=float(rt1.max() - rt0.min()) / 100,
+                                                 start_spread=float(rt0.max() - rt0.min()) / 100, end_spread=float(rt1.max() - rt1.min()) / 100),
+                                ghz=float(np.median((t[:, 63] - t[:, 0]) / np.maximum(rt1 - rt0, 1)) / 10),
+                                total_pct=[float(x) for x in np.percentile(t[:, 63] - t[:, 0], [0, 10, 50, 90, 100])],
+                                loop_pct=[float(x) for x in np.percentile(t[:, 1 + nst] - t[:, 1], [0, 10, 50, 90, 100])],
+                                end_spread=float(t[:, 63].max() - t[:, 63].min()), wall=float(t[:, 63].max() - t0))
     rows.append(rec)
     print(json.dumps(rec), flush=True)
 big = [x for x in rows if x["cin"] >= 64 and x["cout"] >= 64]
