@@ -341,11 +341,16 @@ int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const void *y, const
  * fp32 accumulation on v_mfma_f32_16x16x32_bf16.  Same gather-map contract as s2d_spconv_fwd_f32
  * (nbr[k][o] = input row feeding output row o through kernel offset k, or -1); the data gradient is
  * the same entry run on dout with nbr_in (or the SubM map with flip=1) and the weight image packed
- * with transpose=1.  cin, cout in {16, 32, 64, 128}.  The weight image depends on the launch tiling
- * chosen from n_out, so pack and fwd must be given the same n_out.  zero_page: >= 16 zero bytes of
- * device memory (what a missing neighbour reads).
+ * with transpose=1.  cin, cout in {16, 32, 64, 128}.  Two kernels sit behind these entries: shapes with 128 input or output
+ * channels (and >= 64 on the other side) run the register-gather kernel (csrc/spconv_rg.hip: A fragments gathered straight
+ * into MFMA operand registers, weight slab through LDS), the others the LDS-staged kernel (csrc/spconv_s16.hip).  The weight
+ * image depends on the kernel and its launch tiling chosen from n_out, so pack and fwd must be given the same n_out.
+ * zero_page: >= 16 zero bytes of device memory (what a missing neighbour reads in the LDS-staged kernel).
  */
 int s2d_spconv_s16_supported(int cin, int cout);
+/* tuning aid (tools/spconv_kernel_bench.py --trace): device buffer int64[grid][64] that the ablation build of the register-gather
+ * kernel (csrc/spconv_rg.hip) fills with per-step s_memtime stamps when S2D_RG_DEBUG has bit 32 set; NULL switches it off */
+void s2d_debug_rg_trace(void *buf);
 size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout);
 int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int cin, int cout, int transpose,
                                 int flip, int64_t n_out, void *packed, s2d_stream_t stream);
@@ -369,28 +374,6 @@ int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout);
 int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr,
                              int64_t n_out, int kvol, int cin, int cout, const void *zero_page, void *out_feat, float *stats_partial,
                              s2d_stream_t stream);
-
-/*
- * Submanifold 3x3x3 sparse convolution, bf16 storage, "neighbourhood-resident" implicit GEMM (csrc/spconv_nb.hip): same
- * contract as s2d_spconv_s16_fwd for cin == cout == channels in {16,32,64,128} and kvol == 27, driven by a TILE PLAN built
- * once per rulebook from its gather map nbr[27][n]: rows are grouped into tiles of s2d_spconv_nb_tile_rows(channels) rows in
- * the order `perm` (a spatially blocked permutation of the rows, or NULL for the identity), each tile lists the distinct
- * input rows its offsets touch and a local gather map.  The kernel keeps a tile's input rows resident in LDS.  The data
- * gradient is the same entry with the weight image packed with transpose=1, flip=1 (SubM map is symmetric).
- * stats (optional): fp32 [tiles][2][channels] per-tile sum / sum of squares of the stored outputs (batch-norm statistics).
- */
-int s2d_spconv_nb_supported(int channels, int kvol);
-int s2d_spconv_nb_tile_rows(int channels);
-int s2d_spconv_nb_plan_sizes(int channels, int64_t n, int64_t sizes[6]);
-int s2d_spconv_nb_plan_build(const int32_t *nbr, const int32_t *perm, int64_t n, int channels, int32_t *rows,
-                             int32_t *u, int32_t *in_rows, uint16_t *lnbr, uint32_t *act, s2d_stream_t stream);
-size_t s2d_spconv_nb_packed_elems(int channels);
-int s2d_spconv_nb_pack_weights(const float *weight, int channels, int transpose, int flip, void *packed,
-                               s2d_stream_t stream);
-int s2d_spconv_nb_fwd(const void *in_feat, const void *packed_weight, const float *bias,
-                      const int32_t *plan_rows, const int32_t *plan_u, const int32_t *plan_in,
-                      const uint16_t *plan_lnbr, const uint32_t *plan_act, int64_t n_tiles, int channels,
-                      const void *zero_page, void *out_feat, float *stats, s2d_stream_t stream);
 
 /*
  * Weight gradient of the dense 3x3 stride-1 convolution above (replaces the cuDNN backward-filter call):

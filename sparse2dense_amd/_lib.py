@@ -76,15 +76,6 @@ SIGNATURES = {
     "s2d_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "s2d_comm_ranks": (ctypes.c_int, []),
     "s2d_comm_shutdown": (ctypes.c_int, []),
-    "s2d_spconv_nb_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    "s2d_spconv_nb_tile_rows": (ctypes.c_int, [ctypes.c_int]),
-    "s2d_spconv_nb_plan_sizes": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64 * 6]),
-    "s2d_spconv_nb_plan_build": (ctypes.c_int, [c_i32p, c_i32p, ctypes.c_int64, ctypes.c_int, c_i32p, c_i32p, c_i32p, ctypes.c_void_p,
-                                                ctypes.c_void_p, ctypes.c_void_p]),
-    "s2d_spconv_nb_packed_elems": (ctypes.c_size_t, [ctypes.c_int]),
-    "s2d_spconv_nb_pack_weights": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
-    "s2d_spconv_nb_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_i32p, c_i32p, c_i32p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_convt3d_mfma_packed_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "s2d_convt3d_mfma_pack_weights": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
@@ -206,6 +197,7 @@ SIGNATURES = {
     "s2d_bnrow_bwd_reduce_finalize_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bnrow_bwd_apply_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_spconv_s16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "s2d_debug_rg_trace": (None, [ctypes.c_void_p]),
     "s2d_spconv_s16_packed_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "s2d_spconv_s16_pack_weights": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),

@@ -1,23 +1,30 @@
 // Sparse-conv implicit GEMM, bf16 storage, REGISTER-GATHER form (r03; replaces the LDS-staged A tile of spconv_s16.hip).
 // (spconv.ops.indice_conv / indice_conv_backward; call sites det3d/models/backbones/scn.py:104-152)
 //
-// Measured on the LDS-staged kernel and on the first register-gather versions of this file (tools/spconv_kernel_bench.py with the
-// S2D_RG_DEBUG ablation switches, 128 -> 128 channels, 47 890 rows, 738 674 pairs): loads alone 43 us, MFMAs + weight-fragment LDS
-// reads alone 52 us, neither (index + weight-slab loads, barriers, epilogue) 28 us = ~1 us of exposed load latency per step;
-// two waves per SIMD with 32 rows each read every weight fragment from LDS once per 32 rows (256 KiB per step and CU).  Hence:
-//   * ONE wave per SIMD with the whole 512-register file: a wave owns MI (1..4) 16-row MFMA tiles x ALL output columns, so a
-//     weight fragment read from LDS feeds MI MFMAs, and there is room for a THREE-deep register ring of gathered A fragments:
-//     the rows of step s+2 are requested while step s multiplies (two steps = 3-4 k cycles of cover for ~2.4 k cycles of latency).
+// What bounds these kernels (r03 measurements, tools/spconv_kernel_bench.py with the S2D_RG_DEBUG ablation switches and per-step
+// s_memtime stamps; 128 -> 128 channels, 47 890 rows, 738 674 pairs): seven structurally different versions - A through LDS-DMA,
+// A in registers with one or two waves per SIMD, one/two/three-slot rings, loads clustered or threaded through the MFMAs - all
+// took 51-57 us at an effective 1.9 GHz, while the MFMAs alone need 22 us.  The common term is the traffic every CU pulls
+// through its L1 from the XCD's L2: the gathered rows (189 MB) plus the weight image once per workgroup (250 x 884 KB = 221 MB):
+// 410 MB / 52 us = 7.9 TB/s; the 64 -> 128 strided layer (165 MB, 27 us) and the 64 -> 64 SubM layer (354 MB, 53 us) land at
+// 6-7 TB/s too (the same "~10 TB/s of L2 -> CU" r01 measured on the LDS-DMA path).  Within that bound this kernel is what wins
+// at 128 channels:
 //   * the A operand never touches LDS.  Lane (r = lane & 15, q = lane >> 4) of v_mfma_f32_16x16x32_bf16 holds
 //     A[row r][k = 8q..8q+7] = 16 contiguous bytes of the gathered input row, so the fragment IS one `buffer_load_dwordx4` from
 //     feature row nbr[offset][row r]; a missing neighbour is an out-of-range buffer offset (reads zero, moves no data, needs
 //     no zero page and no branch).
-//   * one step = 128 K-elements = 128 / CIN kernel offsets; gather indices are requested four steps ahead.
+//   * a wave owns MI 16-row MFMA tiles x ALL output columns; a workgroup is 8 waves (two per SIMD: one wave's memory-issue
+//     back-pressure and LDS waits are covered by its partner's MFMAs) working on tiles_per_block consecutive tiles dealt
+//     round-robin; waves with fewer tiles run a leaner instantiation (rg_wave<NT>).
+//   * one step = 128 K-elements = 128 / CIN kernel offsets.  Two register slots (step parity) refilled IN PLACE: as soon as
+//     the MFMAs of a K chunk of step s have been issued its registers are reloaded with the chunk of step s+2; gather
+//     indices are requested four steps ahead.
 //   * only the weight slab of a step (128 x COUT bf16, packed in fragment order) goes through LDS: global -> registers in
 //     step s -> ds_write in step s+1 -> read by every wave in step s+2; two LDS stages, one barrier per step.
-//   * no conditional memory operation and no peeled tail: the step count is padded to a multiple of three with phantom steps
-//     (indices -1, clamped slab), so hipcc's vmcnt bookkeeping sees one straight loop body and keeps every load class in flight.
-//   * a wave whose tiles have no neighbour at a step skips that step's MFMAs (wave-uniform ballot).
+//   * no conditional memory operation and no peeled tail: the step count is padded to even with phantom steps (indices -1,
+//     clamped slab), so hipcc's vmcnt bookkeeping sees one straight loop body and keeps every load class in flight.
+//   * the accumulators live in AGPRs and are updated by asm MFMAs ("+a"): with the builtin hipcc kept a second accumulator set
+//     and copied ~120 registers per loop iteration; scheduling barriers pin the ds_read / memory / MFMA interleave.
 // The epilogue: bias, one bf16 rounding, 2*NJ-byte row stores, optional per-workgroup (sum, sum of squares) rows for the
 // BatchNorm1d that follows.
 #include "s2d_common.h"
@@ -31,6 +38,9 @@ typedef float f32x4r __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 
 constexpr int RG_KSTEP = 128;   // K elements per step
+#ifndef RG_BBURST
+#define RG_BBURST 1   // 1: all weight-slab pieces of a step are stored / re-requested in its first group (all 32 KiB in flight at once)
+#endif
 __host__ __device__ inline int rg_steps(int cin, int kvol) { return (kvol * cin + RG_KSTEP - 1) / RG_KSTEP; }
 
 template <int CIN, int COUT, int MI_, int WAVES_>
@@ -248,7 +258,7 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
             if (g + 1 < NG && !(dbg & 16)) read_g(g + 1, b[(g + 1) & 1]);
 #pragma unroll
             for (int u = 0; u < C::B_LOADS; ++u)
-                if (u / BPER == g) b_task(u);
+                if ((RG_BBURST ? 0 : u / BPER) == g) b_task(u);
             if (g > 0 && g % GPC == 0) refill(g / GPC - 1);
             if (!(dbg & 2)) {
 #pragma unroll
@@ -391,9 +401,12 @@ static int rg_cus() {
 // rows per workgroup: the fewest whole rounds of one workgroup per CU that cover the tiles, then the tile count per workgroup
 // that spreads them evenly (a 47 890-row stage = 2 994 tiles runs as 250 workgroups of 12 tiles, not 187 of 16)
 RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout) {
-    (void)kvol; (void)cin; (void)cout;
+    (void)kvol; (void)cin;
     const int64_t tiles = ceil_div(n_out, 16);
-    int mi = 0, waves = 4, tpb = 0;
+    // measured on the bench scene (tools/spconv_kernel_bench.py, r03): two waves per SIMD with two tiles each win or tie at every
+    // shape with 128 input or output channels (128->128: 51 us vs 54 with one wave of three tiles per SIMD; 64->128: 26 vs 29;
+    // 128->64: 55-61 vs 63)
+    int mi = 2, waves = 8, tpb = 0;
     if (const char *ov = getenv("S2D_RG_PLAN")) {   // tuning hook: "mi,waves[,tiles_per_block]"
         int a = 0, b = 0, c = 0;
         const int got = sscanf(ov, "%d,%d,%d", &a, &b, &c);
@@ -402,15 +415,7 @@ RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout) {
             if (got == 3 && c >= 1 && c <= a * b) tpb = c;
         }
     }
-    if (!mi) {
-        const int mi_max = 4;
-        const int64_t per_round = (int64_t)rg_cus();
-        const int64_t rounds = std::max<int64_t>(1, ceil_div(tiles, per_round * waves * mi_max));
-        const int64_t want = std::max<int64_t>(1, ceil_div(tiles, per_round * rounds));   // tiles per workgroup
-        mi = (int)std::min<int64_t>(mi_max, ceil_div(want, waves));
-        tpb = (int)std::min<int64_t>(want, (int64_t)waves * mi);
-    }
-    if (!tpb) {
+    if (!tpb) {   // the fewest whole rounds of one workgroup per CU, then equal shares (unequal tile counts per wave: rg_wave<NT>)
         const int64_t per_round = (int64_t)rg_cus();
         const int64_t rounds = std::max<int64_t>(1, ceil_div(tiles, per_round * waves * mi));
         tpb = (int)std::min<int64_t>((int64_t)waves * mi, std::max<int64_t>(1, ceil_div(tiles, per_round * rounds)));
@@ -425,7 +430,7 @@ static int rg_launch(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf
     static int dbg = -1;
     if (dbg < 0) dbg = getenv("S2D_RG_DEBUG") ? atoi(getenv("S2D_RG_DEBUG")) : 0;   // ablation switches for tools/spconv_kernel_bench.py
     auto kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 0>;
-    if constexpr (CIN == COUT && CIN >= 64 && (MI >= 3 || WAVES == 8)) {
+    if constexpr (CIN == 128 && COUT == 128 && (MI == 3 || (WAVES == 8 && MI == 2))) {
         if (dbg == 32) kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 2>;
         else if (dbg) kern = spconv_rg_kernel<CIN, COUT, MI, WAVES, 1>;
     }

@@ -322,7 +322,7 @@ static bool use_rg(int cin, int cout) {
         const char *e = getenv("S2D_S16_KERNEL");
         v = !(e && strcmp(e, "lds") == 0);
     }
-    return v != 0 && cin >= 64 && cout >= 64;
+    return v != 0 && cin >= 64 && cout >= 64 && (cin == 128 || cout == 128);   // 64 -> 64 (48 vs 52 us) and narrower: the LDS-staged kernel
 }
 
 static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }

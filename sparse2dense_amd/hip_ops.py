@@ -135,8 +135,7 @@ class Rulebook:
     pair_count: torch.Tensor           # i32[K]
     out_coors: Optional[torch.Tensor]  # i32[n_out,4] (None for subm: same as input)
     out_shape: Tuple[int, int, int]
-    coors: Optional[torch.Tensor] = None   # subm: the i32[n,4] site coordinates (for the spatial tile plans)
-    nb_plans: Optional[dict] = None        # tile rows -> NbPlan (neighbourhood-resident kernel), built on first use
+    coors: Optional[torch.Tensor] = None   # subm: the i32[n,4] site coordinates
 
     def pairs(self):
         """spconv-style per-offset (in_idx, out_idx) lists, on the host (tests / export only)."""
@@ -584,97 +583,3 @@ def spconv_s16_wgrad(feat, dout, nbr, kvol, pair_count=None):
         rec["end"].record()
         PROFILE.append(rec)
     return dw
-
-
-# ------------------------------------------------------------------------------------------------
-# neighbourhood-resident SubM kernel (csrc/spconv_nb.hip): tile plans + launcher
-# ------------------------------------------------------------------------------------------------
-# The neighbourhood-resident kernel is correct (tests/test_s16_gpu.py) but, as measured in r02, slower than
-# the gather kernel at every channel count on the bench scene: with 256-row tiles a workgroup needs ~100 KB of resident rows, so
-# one workgroup (one wave per SIMD) per CU, and the per-offset chain "weight image lands -> fragments to registers -> barrier ->
-# A reads -> MFMAs" is exposed latency (119 vs 57 us at 128 channels, 67 vs 48 us at 64).  It stays behind this switch
-# (S2D_NB=1) as the starting point for a software-pipelined version.
-import os as _os
-NB_ENABLED = _os.environ.get("S2D_NB", "0") == "1"
-NB_MIN_ROWS = 2048       # below this the plan build costs more than it saves
-
-
-@dataclass
-class NbPlan:
-    channels_tile: int
-    n_tiles: int
-    rows: torch.Tensor
-    u: torch.Tensor
-    in_rows: torch.Tensor
-    lnbr: torch.Tensor
-    act: torch.Tensor
-
-
-def block_order(coors, shape, block=8):
-    """rows sorted by (batch, y-block, x-block, z, y, x): tiles of consecutive rows in this order are spatially compact
-    columns of `block` x `block` BEV cells (all z), so the 27 neighbours of a tile's rows are few distinct rows"""
-    c = coors.long()
-    d, h, w = (int(v) for v in shape)
-    nyb, nxb = -(-h // block), -(-w // block)
-    key = ((c[:, 0] * nyb + c[:, 2] // block) * nxb + c[:, 3] // block) * (d * block * block) \
-        + (c[:, 1] * block + c[:, 2] % block) * block + c[:, 3] % block
-    return torch.argsort(key).int()
-
-
-def nb_supported(rb: "Rulebook", channels: int) -> bool:
-    return bool(NB_ENABLED and rb.subm and rb.kvol == 27 and rb.coors is not None and rb.n_out >= NB_MIN_ROWS
-                and _lib.load().s2d_spconv_nb_supported(int(channels), 27))
-
-
-def nb_plan(rb: "Rulebook", channels: int) -> NbPlan:
-    lib = _lib.load()
-    t = lib.s2d_spconv_nb_tile_rows(int(channels))
-    if rb.nb_plans is None:
-        rb.nb_plans = {}
-    plan = rb.nb_plans.get(t)
-    if plan is None:
-        n, dev = rb.n_out, rb.nbr_out.device
-        sizes = (ctypes.c_int64 * 6)()
-        check(lib.s2d_spconv_nb_plan_sizes(int(channels), n, sizes), "s2d_spconv_nb_plan_sizes")
-        perm = block_order(rb.coors, rb.out_shape)
-        rows = torch.empty(sizes[1], dtype=torch.int32, device=dev)
-        u = torch.empty(sizes[2], dtype=torch.int32, device=dev)
-        in_rows = torch.empty(sizes[3], dtype=torch.int32, device=dev)
-        lnbr = torch.empty(sizes[4], dtype=torch.int16, device=dev)
-        act = torch.empty(sizes[5], dtype=torch.int32, device=dev)
-        check(lib.s2d_spconv_nb_plan_build(_ptr(rb.nbr_out), _ptr(perm), n, int(channels), _ptr(rows), _ptr(u), _ptr(in_rows), _ptr(lnbr),
-                                           _ptr(act), _stream()), "s2d_spconv_nb_plan_build")
-        plan = NbPlan(t, int(sizes[0]), rows, u, in_rows, lnbr, act)
-        rb.nb_plans[t] = plan
-    return plan
-
-
-def spconv_nb_pack(weight_kio, transpose=False, flip=False):
-    """fp32 [27, c, c] -> bf16 fragment image of the neighbourhood-resident kernel"""
-    lib = _lib.load()
-    c = weight_kio.shape[1]
-    assert weight_kio.shape == (27, c, c)
-    w = weight_kio.detach().float().contiguous()
-    packed = torch.empty(lib.s2d_spconv_nb_packed_elems(c), dtype=torch.bfloat16, device=w.device)
-    check(lib.s2d_spconv_nb_pack_weights(_ptr(w), c, int(transpose), int(flip), _ptr(packed), _stream()), "s2d_spconv_nb_pack_weights")
-    return packed
-
-
-def spconv_nb_run(feat, packed, bias, plan: NbPlan, n_out, pair_count=None, tag="fwd", want_stats=False):
-    lib = _lib.load()
-    c = feat.shape[1]
-    assert feat.dtype == torch.bfloat16 and feat.is_contiguous()
-    out = torch.empty((n_out, c), dtype=torch.bfloat16, device=feat.device)
-    stats = torch.empty((plan.n_tiles, 2, c), dtype=torch.float32, device=feat.device) if want_stats else None
-    rec = None
-    if PROFILE is not None:
-        rec = dict(kernel="spconv_fwd_nb", tag=tag, cin=c, cout=c, n_out=int(n_out), kvol=27, pairs=pair_count, elem_bytes=2,
-                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
-        rec["start"].record()
-    check(lib.s2d_spconv_nb_fwd(_ptr(feat), _ptr(packed), _ptr(bias), _ptr(plan.rows), _ptr(plan.u), _ptr(plan.in_rows), _ptr(plan.lnbr),
-                                _ptr(plan.act), plan.n_tiles, c, _ptr(zero_page(feat.device)), _ptr(out), _ptr(stats), _stream()),
-          "s2d_spconv_nb_fwd")
-    if rec is not None:
-        rec["end"].record()
-        PROFILE.append(rec)
-    return (out, stats) if want_stats else out

@@ -109,15 +109,6 @@ class _SparseConvFn(torch.autograd.Function):
         """bf16-storage conv / data gradient with the weight image cached per parameter version (dense2d.cached_pack)"""
         from .dense2d import cached_pack
         cin_feat = x.shape[1] if cin_feat is None else cin_feat
-        c = weight.shape[-1]
-        if cin_feat == c and x.shape[1] == c and nbr is rb.nbr_out and flip == (transpose and rb.subm) and H.nb_supported(rb, c):
-            # SubM layer, equal (stored) channel counts: the neighbourhood-resident kernel; its tile plan is cached on the
-            # rulebook and shared by every conv of the stage, forward and data gradient (the SubM map is symmetric)
-            packed = cached_pack(weight, ("nb", bool(transpose), bool(flip), int(cin_feat)),
-                                 lambda: H.spconv_nb_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), transpose, flip))
-            b = None if bias is None else bias.detach().float().contiguous()
-            out = H.spconv_nb_run(x.contiguous(), packed, b, H.nb_plan(rb, c), n_out, rb.pair_count, tag)
-            return (out, None) if bn_stats else out
         key = ("s16", bool(transpose), bool(flip), int(cin_feat))
         if pair_dgrad is not None and not transpose:
             # training forward: the data-gradient operand of this step is packed in the same launch (pair_dgrad = its (flip, n_out))

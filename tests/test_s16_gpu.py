@@ -150,78 +150,7 @@ def test_feature_bn_bf16_rows_with_residual(n, c, relu, with_res):
     assert int(m.num_batches_tracked) == 1
 
 
-# ---------------------------------------------------------------------------------------------------
-# neighbourhood-resident SubM kernel (csrc/spconv_nb.hip): tile plan invariants + the same numerical bar as the gather
-# kernel (fp32 restatement on the same bf16-rounded operands, one output rounding: 8e-3 of max), forward and data gradient,
-# and the fused batch-norm statistics.
-# ---------------------------------------------------------------------------------------------------
 from sparse2dense_amd import hip_ops as H
-
-
-def _nb_scene(n_points, batch, seed):
-    import numpy as np
-    from oracle import voxelize as OV
-    from sparse2dense_amd import scene
-    coors = []
-    for b in range(batch):
-        s = scene.make_scene(n_points, seed=seed + b)
-        _, c, _ = OV.points_to_voxel(s["points"], scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
-        coors.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
-    return np.concatenate(coors)
-
-
-@pytest.mark.parametrize("c", [16, 32, 64, 128])
-@pytest.mark.parametrize("shape,div", [((41, 1504, 1504), 1), ((11, 376, 376), 4)])
-def test_neighbourhood_resident_kernel_matches_restatement(c, shape, div, monkeypatch):
-    import numpy as np
-    from oracle import spconv_ref as R
-    coors = _nb_scene(30000, 2, 5)
-    if div > 1:   # a coarser, denser grid (many neighbours per site, like stages 2-3)
-        coors = np.unique(np.concatenate([coors[:, :1], coors[:, 1:2] // 4, coors[:, 2:] // div], 1), axis=0).astype(np.int32)
-    n = coors.shape[0]
-    cd = torch.from_numpy(coors).to(DEV)
-    rb = H.build_subm_rulebook(cd, 2, shape, (3, 3, 3))
-    monkeypatch.setattr(H, "NB_ENABLED", True)   # off by default (slower than the gather kernel)
-    assert H.nb_supported(rb, c)
-    plan = H.nb_plan(rb, c)
-    # plan invariants: every row in exactly one tile; slots are the distinct neighbours; local map consistent with the global one
-    t = plan.channels_tile
-    rows = plan.rows.cpu().numpy().reshape(plan.n_tiles, t)
-    assert sorted(rows[rows >= 0].tolist()) == list(range(n))
-    nbr = rb.nbr_out.cpu().numpy()
-    u = plan.u.cpu().numpy()
-    in_rows = plan.in_rows.cpu().numpy().reshape(plan.n_tiles, 27 * t)
-    lnbr = plan.lnbr.cpu().numpy().view(np.uint16).reshape(plan.n_tiles, 28, t)
-    for ti in (0, plan.n_tiles // 2, plan.n_tiles - 1):
-        rr = rows[ti]
-        want = nbr[:, rr[rr >= 0]]
-        assert set(in_rows[ti, :u[ti]].tolist()) == set(want[want >= 0].tolist()) and len(set(in_rows[ti, :u[ti]].tolist())) == u[ti]
-        loc = lnbr[ti, :27][:, rr >= 0]
-        assert np.array_equal(loc == 0xFFFF, want < 0)
-        assert np.array_equal(in_rows[ti][loc[loc != 0xFFFF]], want[want >= 0])
-    g = torch.Generator().manual_seed(c)
-    f = torch.randn(n, c, generator=g).to(torch.bfloat16)
-    w = (torch.randn(27, c, c, generator=g) * 0.05)
-    b = torch.randn(c, generator=g) * 0.1
-    pairs = rb.pairs()
-    wr = w.to(torch.bfloat16).float()
-    ref = R.sparse_conv(f.float(), wr.reshape(3, 3, 3, c, c), b, pairs, n)
-    out, stats = H.spconv_nb_run(f.to(DEV), H.spconv_nb_pack(w.to(DEV)), b.to(DEV), plan, n, want_stats=True)
-    assert (out.float().cpu() - ref).abs().max() <= 8e-3 * ref.abs().max()
-    s = stats.sum(0).cpu()
-    of = out.float().cpu()
-    assert (s[0] - of.sum(0)).abs().max() <= 1e-3 * of.abs().sum(0).max() and (s[1] - (of * of).sum(0)).abs().max() <= 1e-3 * (of * of).sum(0).max()
-    # data gradient: dX[j] = sum_k dY[o] W[k]^T over pairs (j -> o, k) == the same kernel on the mirrored / transposed image
-    dy = torch.randn(n, c, generator=g).to(torch.bfloat16)
-    dref = torch.zeros(n, c)
-    for k, (i_in, i_out) in enumerate(pairs):
-        if len(i_in):
-            dref.index_add_(0, torch.as_tensor(i_in), dy.float()[torch.as_tensor(i_out)] @ wr[k].t())
-    dx = H.spconv_nb_run(dy.to(DEV), H.spconv_nb_pack(w.to(DEV), transpose=True, flip=True), None, plan, n)
-    assert (dx.float().cpu() - dref).abs().max() <= 8e-3 * dref.abs().max()
-    # and it is what the autograd function of the module layer now runs (same result as the gather kernel)
-    old = H.spconv_s16(f.to(DEV), w.to(DEV), b.to(DEV), rb.nbr_out, n)   # the gather kernel on the same operands
-    assert (old.float() - out.float()).abs().max() <= 8e-3 * ref.abs().max()
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 128), (64, 128), (16, 32)])
