@@ -1,5 +1,14 @@
 // Rulebook construction for submanifold and strided sparse 3-D convolution on gfx950.
 //
+// r03: (1) SubM builds on grids of <= 8 M cells (stages 2 and 3) use a direct int32 cell -> row table: memset + scatter + probe, no
+// ranking.  (2) Measured and dropped for the large stages: a hash table of the N sites.  Open addressing with Fibonacci hashing,
+// load <= 0.5: insert 15 us + probe 77 us at stage 0 against 35 us for the rank/select probe (a miss walks to the next empty slot,
+// the three x-neighbours no longer share a word) = 98 us per build, no better than the ~100 us it replaced; a blocked variant (a
+// 2x4x4-cell block owning a 32-slot window so that a site's 27 neighbours share cache lines) took 450-900 us: occupied blocks are
+// dense, windows overflow into each other and linear probing degenerates into long chains.  (3) Also measured and dropped: fusing the scan launches (a reduce launch
+// whose last block - release fence + ticket - scans the block sums: 33 us against 8 + 5 for the two launches it replaced, the
+// per-block L2 write-back is the cost) and prefix + decode in one launch (82 us against 17 + 18).
+//
 // Replaces spconv's get_indice_pairs (dense int32 grid of B*D*H*W cells, 371 MB per Waymo sample,
 // or a sort+unique) with a rank/select OCCUPANCY INDEX: one bit per cell plus an exclusive
 // popcount prefix per 32-cell word, interleaved as uint2{bits,prefix}.  A coordinate lookup is a
@@ -12,6 +21,7 @@
 // coalesced (thread = row, loop = offset).
 #include "s2d_common.h"
 #include "scan.h"
+#include <cstdlib>
 
 namespace s2d {
 
@@ -209,6 +219,52 @@ __global__ __launch_bounds__(256) void conv_fill_kernel(const int32_t *__restric
         if (cnt[k]) atomicAdd(&pair_count[k], cnt[k]);
 }
 
+// ---- SubM on small grids: direct cell -> row table ---------------------------------------------------
+// grids of <= 8 M cells (stages 2 and 3 of the Waymo backbone: 6.2 M / 0.85 M cells at batch 4): an int32 per cell, no ranking
+__global__ __launch_bounds__(256) void subm_direct_scatter_kernel(const int32_t *__restrict__ coors, int64_t n, Geo g, int32_t *__restrict__ table,
+                                                                  int32_t *__restrict__ pair_count) {
+    if (blockIdx.x == 0 && threadIdx.x < g.kvol) pair_count[threadIdx.x] = 0;   // the probe launch accumulates into it
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coors)[i];  // b,z,y,x
+    if ((unsigned)c.x >= (unsigned)g.batch || (unsigned)c.y >= (unsigned)g.shape[0] || (unsigned)c.z >= (unsigned)g.shape[1] ||
+        (unsigned)c.w >= (unsigned)g.shape[2])
+        return;  // out-of-range rows are ignored (nothing can find them)
+    atomicMax(&table[lin_index(c.x, c.y, c.z, c.w, g.shape)], (int32_t)i);   // duplicate coordinate: the highest row wins
+}
+
+template <int KVOL_MAX>
+__global__ __launch_bounds__(256) void subm_direct_probe_kernel(const int32_t *__restrict__ coors, int64_t n, Geo g, const int32_t *__restrict__ table,
+                                                                int32_t *__restrict__ nbr_out, int32_t *__restrict__ pair_count) {
+    __shared__ int cnt[KVOL_MAX];
+    for (int k = threadIdx.x; k < g.kvol; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int4 c = reinterpret_cast<const int4 *>(coors)[i];
+        const bool valid = (unsigned)c.x < (unsigned)g.batch && (unsigned)c.y < (unsigned)g.shape[0] &&
+                           (unsigned)c.z < (unsigned)g.shape[1] && (unsigned)c.w < (unsigned)g.shape[2];
+        int k = 0;
+        for (int kz = 0; kz < g.ksize[0]; ++kz) {
+            const int z = c.y + (kz - g.ksize[0] / 2) * g.dil[0];
+            for (int ky = 0; ky < g.ksize[1]; ++ky) {
+                const int y = c.z + (ky - g.ksize[1] / 2) * g.dil[1];
+                for (int kx = 0; kx < g.ksize[2]; ++kx, ++k) {
+                    const int x = c.w + (kx - g.ksize[2] / 2) * g.dil[2];
+                    int j = -1;
+                    if (valid && (unsigned)z < (unsigned)g.shape[0] && (unsigned)y < (unsigned)g.shape[1] && (unsigned)x < (unsigned)g.shape[2])
+                        j = table[lin_index(c.x, z, y, x, g.shape)];
+                    nbr_out[(int64_t)k * n + i] = j;
+                    if (j >= 0) atomicAdd(&cnt[k], 1);   // one LDS atomic per wave and offset (the compiler folds the active-lane count)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < g.kvol; k += blockDim.x)
+        if (cnt[k]) atomicAdd(&pair_count[k], cnt[k]);
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 struct RbWs {
     uint2 *occ;
@@ -235,6 +291,10 @@ static RbWs rb_carve(void *ws, int64_t n_words, int64_t n_rows) {
     w.bytes = c.total();
     return w;
 }
+
+// SubM on a grid of at most DIRECT_CELLS cells: direct table (one int32 per cell)
+constexpr int64_t DIRECT_CELLS = 8 << 20;
+static bool direct_ok(int batch, const int *shape) { return (int64_t)batch * shape[0] * shape[1] * shape[2] <= DIRECT_CELLS; }
 
 static int fill_geo(Geo *g, int batch, const int32_t shape[3], const int32_t ksize[3], const int32_t stride[3],
                     const int32_t padding[3], const int32_t dilation[3], bool subm) {
@@ -288,6 +348,7 @@ using namespace s2d;
 extern "C" size_t s2d_rulebook_workspace_bytes(int batch, const int32_t shape[3], int64_t n_rows) {
     if (batch <= 0 || !shape || n_rows < 0) return 0;
     int s[3] = {shape[0], shape[1], shape[2]};
+    if (n_rows > 0 && direct_ok(batch, s)) return align_up((size_t)batch * s[0] * s[1] * s[2] * 4, 256);   // SubM: the direct table
     return rb_carve(nullptr, occ_words(batch, s), n_rows).bytes;
 }
 
@@ -300,6 +361,24 @@ extern "C" int s2d_rulebook_subm_build(const int32_t *coors, int64_t n, int batc
     S2D_CHECK_ARG(n >= 0 && n < 0x7fffffff, "rulebook_subm: bad n");
     S2D_CHECK_ARG(pair_count && (n == 0 || (coors && nbr_out)), "rulebook_subm: null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (direct_ok(batch, g.shape)) {
+        if (n == 0) {
+            S2D_HIP(hipMemsetAsync(pair_count, 0, sizeof(int32_t) * g.kvol, st));
+            return S2D_OK;
+        }
+        const size_t bytes = (size_t)batch * g.shape[0] * g.shape[1] * g.shape[2] * 4;
+        if (!ws || ws_bytes < bytes) {
+            set_error("rulebook_subm: workspace too small (%zu < %zu)", ws_bytes, bytes);
+            return S2D_ERR_WORKSPACE;
+        }
+        int32_t *table = (int32_t *)ws;
+        S2D_HIP(hipMemsetAsync(table, 0xFF, bytes, st));
+        const dim3 blk(256), grd((unsigned)ceil_div(n, 256));
+        hipLaunchKernelGGL(subm_direct_scatter_kernel, grd, blk, 0, st, coors, n, g, table, pair_count);
+        hipLaunchKernelGGL(subm_direct_probe_kernel<27>, grd, blk, 0, st, coors, n, g, table, nbr_out, pair_count);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     RbWs w = rb_carve(ws, occ_words(batch, g.shape), n);
     if (!ws || ws_bytes < w.bytes) {
         set_error("rulebook_subm: workspace too small (%zu < %zu)", ws_bytes, w.bytes);

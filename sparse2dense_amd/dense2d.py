@@ -293,8 +293,18 @@ def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
     n, _, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     partial = torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w), 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
+    from . import hip_ops as H
+    rec = None
+    if H.PROFILE is not None:   # bench.py roofline pass (the 1x1 instantiation of the tile kernel: conv3x3_nhwc_bf16_kernel<BN, 2, 1>)
+        rec = dict(kernel="conv1x1_nhwc_bf16", tag="dense1x1", cin=cin, cout=cout, n_out=n * h * w, kvol=1, pairs=None, dense=True,
+                   in_pixels=n * h * w, pad=0, stride=1, tile_rows=64, start=torch.cuda.Event(enable_timing=True),
+                   end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_conv2d1x1_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y),
                                       _ptr(partial), _stream()), "s2d_conv2d1x1_nhwc_bf16")
+    if rec is not None:
+        rec["end"].record()
+        H.PROFILE.append(rec)
     return (y, partial) if bn_stats else y
 
 

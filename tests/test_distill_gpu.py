@@ -118,3 +118,65 @@ def test_distill_step_benchmarked_bf16_mode_within_stated_tolerance(setup, oracl
         np.testing.assert_allclose(float(losses[k][0]), oracle_run["terms"][k], rtol=5e-2, atol=1e-4, err_msg=k)
     grads = {n: p.grad for n, p in s.named_parameters() if p.grad is not None}
     assert set(grads) == set(oracle_run["grads"]) and all(torch.isfinite(g).all() for g in grads.values())
+    # train-mode batch statistics under random weights amplify bf16 storage noise (see test_dense_modules.py); the numeric bar on the
+    # gradients of the benchmarked mode is held by the well-conditioned variant below
+
+
+def _bn_eval(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.eval()
+    return m
+
+
+@pytest.fixture(scope="module")
+def oracle_run_bn_eval(setup):
+    """the float64 oracle stack with every batch norm on its running statistics (fill_params: var in [0.5, 1.5])"""
+    import cpu_backend
+    ex, teacher, student = setup
+    mp = pytest.MonkeyPatch()
+    try:
+        cpu_backend.install(mp)
+        t64, s64 = copy.deepcopy(teacher).double(), _bn_eval(copy.deepcopy(student).double().train())
+        ex64 = _to(ex, "cpu", torch.float64)
+        feats = {}
+        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
+        total, losses = distill_loss(t64, s64, ex64)
+        total.backward()
+        hook.remove()
+        res = dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS}, F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
+                   grads={n: p.grad.clone() for n, p in s64.named_parameters() if p.grad is not None})
+    finally:
+        mp.undo()
+    return res
+
+
+def test_distill_step_bf16_mode_well_conditioned_gradients_within_stated_tolerance(setup, oracle_run_bn_eval):
+    """the BENCHMARKED mode (bf16 sparse storage + bf16 NHWC dense kernels) of the whole distillation step with
+    the student's batch norms on their running statistics, against the float64 oracle stack (NO rounding emulation: this is the
+    full price of bf16 storage): features 2e-2, every loss term 2e-2 (stated: 5e-2), every parameter gradient 5e-2 norm-wise."""
+    ex, teacher, student = setup
+    ref = oracle_run_bn_eval
+    t, s = copy.deepcopy(teacher).to(DEV), _bn_eval(copy.deepcopy(student).to(DEV).train())
+    for m in (t, s):
+        m.dense_dtype = torch.bfloat16
+        m.use_channels_last()
+    feats = {}
+    hook = s.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
+    H.set_sparse_compute_dtype("s16")
+    try:
+        total, losses = distill_loss(t, s, ex)
+        total.backward()
+    finally:
+        H.set_sparse_compute_dtype("f32")
+        hook.remove()
+    ferr = {k: _rel(feats[k].float(), ref[k]) for k in ("F_S_a", "F_S_b")}
+    lerr = {k: abs(float(losses[k][0]) - ref["terms"][k]) / (abs(ref["terms"][k]) + 1e-12) for k in TERMS}
+    errs = {n: _rel(p.grad, ref["grads"][n]) for n, p in s.named_parameters() if p.grad is not None and ref["grads"][n].norm() > 1e-8}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("bf16 distill step, BN on running statistics: features", {k: f"{v:.1e}" for k, v in ferr.items()}, "losses",
+          {k: f"{v:.1e}" for k, v in lerr.items()}, "worst gradients", [(n, f"{e:.1e}") for n, e in worst], f"({len(errs)} gradients)")
+    assert set(n for n, p in s.named_parameters() if p.grad is not None) == set(ref["grads"])
+    assert max(ferr.values()) <= 2e-2, ferr
+    assert max(lerr.values()) <= 2e-2, lerr
+    assert max(errs.values()) <= 5e-2, worst
