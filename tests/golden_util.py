@@ -119,3 +119,36 @@ def bf16_emulation_copy(module):
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def tiny_checkpoint_net():
+    """the small network of the checkpoint fixtures (tests/golden/make_golden_r03.py): a batch norm BETWEEN non-BN leaves, so that the
+    reference's optimizer indices (non-BN leaves first, then BN leaves) differ from model.parameters() order"""
+    from torch import nn
+
+    class TinyNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(3, 8, 3)
+            self.bn = nn.BatchNorm2d(8)
+            self.block = nn.Sequential(nn.Conv2d(8, 8, 1), nn.BatchNorm2d(8), nn.ReLU())
+            self.fc = nn.Linear(8, 4)
+
+        def forward(self, x):
+            return self.fc(self.block(self.bn(self.conv(x))).mean((2, 3)))
+    return TinyNet()
+
+
+def reference_param_groups(model):
+    """restatement of OptimWrapper.create's param groups: split_bn_bias(get_layer_groups(model)) (fastai_optim.py:17-28,
+    apis/train.py:159-164) - leaf modules depth-first, non-BN leaves' trainable parameters, then the BN leaves'"""
+    from torch import nn
+
+    def flatten(m):
+        ch = list(m.children())
+        return sum(map(flatten, ch), []) if ch else [m]
+    leaves = flatten(model)
+    bn = nn.modules.batchnorm._BatchNorm
+    l1 = nn.Sequential(*[c for c in leaves if not isinstance(c, bn)])
+    l2 = nn.Sequential(*[c for c in leaves if isinstance(c, bn)])
+    return [[q for q in l.parameters() if q.requires_grad] for l in (l1, l2)]

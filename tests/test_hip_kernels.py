@@ -70,6 +70,17 @@ def test_voxelize_150k_scene_matches_oracle_bit_exact():
     _check_vox(out, voxels, coors, num, OV.voxel_mean(voxels, num), 20)
 
 
+def test_voxelize_150k_bench_scene_matches_the_reference_golden(golden_dir):
+    """the HIP voxelizer against the REFERENCE's own output on the 150 000-point bench scene (tests/golden/voxelize_150k.npz)"""
+    g = np.load(os.path.join(golden_dir, "voxelize_150k.npz"))
+    s = scene.make_scene(int(g["n_points"]), seed=int(g["seed"]), beam_jitter=float(g["beam_jitter"]))
+    v, c, n, _ = [t.cpu().numpy() if t is not None else None for t in H.voxelize(_dev(s["points"]), scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)]
+    assert np.array_equal(c, g["coors"].astype(c.dtype)) and np.array_equal(n, g["num_points"].astype(n.dtype))
+    v64 = v.astype(np.float64)
+    assert np.array_equal(v64.sum((1, 2)).astype(np.float32), g["voxel_sums"]) and float((v64 * v64).sum()) == float(g["voxel_sq"])
+    assert np.array_equal(v[:64], g["first_voxels"]) and np.array_equal(v[-64:], g["last_voxels"])
+
+
 def test_voxelize_is_deterministic_and_idempotent():
     s = scene.make_scene(30000, seed=3)
     p = _dev(s["points"])

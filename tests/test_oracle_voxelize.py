@@ -44,3 +44,17 @@ def test_maxvox_fixture_really_hits_the_cap(golden_dir):
     g = np.load(os.path.join(golden_dir, "voxelize_maxvox.npz"))
     assert g["coors"].shape[0] == int(g["max_voxels"])
     assert g["num_points"].max() == int(g["max_points"])
+
+
+def test_c_oracle_matches_the_reference_on_the_150k_bench_scene(golden_dir):
+    """VERDICT r02 missing #6: the 150 000-point bench scene voxelized by the REFERENCE itself (tests/golden/make_golden_r03.py):
+    coordinates and counts bit-exact, per-voxel checksums of the [M,5,5] tensor, first / last 64 voxels bit-exact."""
+    from sparse2dense_amd import scene
+    g = np.load(os.path.join(golden_dir, "voxelize_150k.npz"))
+    s = scene.make_scene(int(g["n_points"]), seed=int(g["seed"]), beam_jitter=float(g["beam_jitter"]))
+    assert float(s["points"].astype(np.float64).sum()) == float(g["points_sum"])   # the scene generator reproduces the input
+    v, c, n = O.points_to_voxel(s["points"], scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
+    assert np.array_equal(c, g["coors"].astype(c.dtype)) and np.array_equal(n, g["num_points"].astype(n.dtype))
+    v64 = v.astype(np.float64)
+    assert np.array_equal(v64.sum((1, 2)).astype(np.float32), g["voxel_sums"]) and float((v64 * v64).sum()) == float(g["voxel_sq"])
+    assert np.array_equal(v[:64], g["first_voxels"]) and np.array_equal(v[-64:], g["last_voxels"])

@@ -114,6 +114,7 @@ def _detectors_step(dev):
     assert list(ex["shape"][0]) == [468, 468, 1]
     teacher = build_detector(_pp_cfg("PointPillars")).to(dev).train()
     losses = teacher(ex, return_loss=True)
+    teacher_losses = [l.detach() for l in losses["loss"]]
     sum(losses["loss"]).backward()
     assert teacher.reader.pfn_layers[0].linear.weight.grad is not None
     teacher.eval()
@@ -126,6 +127,10 @@ def _detectors_step(dev):
     total.backward()
     assert torch.isfinite(total) and F_S_a.shape == (1, 64, 468, 468)
     assert student.backbone.gen_mask[3].weight.grad is not None
+    return dict(teacher_loss=float(sum(teacher_losses)), teacher_hm=preds[0]["hm"].detach().double().cpu(), F_D_a=F_D_a.detach().double().cpu(),
+                student_total=float(total), student_terms={"det": float(sum(losses["loss"])), "mask": float(mask_loss), "offset": float(offset_loss)},
+                F_S_a=F_S_a.detach().double().cpu(), F_S_b=F_S_b.detach().double().cpu(),
+                student_grads={n: p.grad.detach().double().cpu() for n, p in student.named_parameters() if p.grad is not None})
 
 
 def test_pointpillars_detectors_cpu(monkeypatch):
@@ -134,5 +139,27 @@ def test_pointpillars_detectors_cpu(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_pointpillars_detectors_gpu():
-    _detectors_step("cuda:0")
+def test_pointpillars_detectors_gpu_match_the_cpu_oracle_path():
+    """BASELINE configs[4] (PFN path) at one GPU, fp32: the teacher's and the S2D student's losses, feature maps and EVERY student
+    parameter gradient against the same host code run through the CPU oracle (tests/cpu_backend.py) - same seeds, same weights
+    (torch.manual_seed(0) before construction).  Bars: losses 2e-3, features 5e-3 norm-wise (MIOpen fp32 convs vs the CPU's direct
+    sums, the bar of the voxel detectors), gradients 5e-2 norm-wise (train-mode batch norms)."""
+    mp = pytest.MonkeyPatch()
+    try:
+        cpu_backend.install(mp)
+        ref = _detectors_step("cpu")
+    finally:
+        mp.undo()
+    got = _detectors_step("cuda:0")
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    np.testing.assert_allclose(got["teacher_loss"], ref["teacher_loss"], rtol=2e-3)
+    np.testing.assert_allclose(got["student_total"], ref["student_total"], rtol=2e-3)
+    for k in ref["student_terms"]:
+        np.testing.assert_allclose(got["student_terms"][k], ref["student_terms"][k], rtol=2e-3, atol=1e-6, err_msg=k)
+    for k in ("teacher_hm", "F_D_a", "F_S_a", "F_S_b"):
+        assert rel(got[k], ref[k]) <= 5e-3, (k, rel(got[k], ref[k]))
+    assert set(got["student_grads"]) == set(ref["student_grads"])
+    errs = {n: rel(got["student_grads"][n], g) for n, g in ref["student_grads"].items() if g.norm() > 1e-8}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("pillar S2D student fp32 vs CPU oracle path, worst gradient errors:", [(n, f"{e:.1e}") for n, e in worst])
+    assert max(errs.values()) <= 5e-2, worst
