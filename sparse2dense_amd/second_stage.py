@@ -8,12 +8,20 @@
                                        roi_head_template.py:27-41,153-183 (make_fc_layers, generate_predicted_boxes)
   VoxelNet/KD_VoxelNet.forward_two_stage   /root/reference/det3d/models/detectors/voxelnet.py:107-141,266-301
 
+  ProposalTargetLayer                  /root/reference/det3d/models/roi_heads/target_assigner/proposal_target_layer.py:14-237
+  RoIHead.assign_targets / losses      /root/reference/det3d/models/roi_heads/roi_head_template.py:43-151
+  boxes_iou3d                          /root/reference/det3d/ops/iou3d_nms/iou3d_nms_utils.py:28-70
+
 Module / parameter names follow the reference (`single_det.*`, `roi_head.shared_fc_layer.0.weight` ...), so two-stage
 checkpoints load through checkpoint.load_state_dict.  Inference path (`return_loss=False`): first-stage decode + rotated NMS
 (heads.CenterHead.predict on the HIP kernels) -> 5 BEV feature samples per box -> RoI MLP -> refined boxes and scores.
-The RoI head's TRAINING targets (ProposalTargetLayer: IoU-sampled RoIs, roi_heads/target_assigner/) are not built here; its
-forward raises for training=True."""
+Training path (`return_loss=True`, two_stage.py:154-199): the same first stage with its loss, then the RoIs are matched to the
+ground truth by 3-D IoU (rotated BEV overlap from csrc/nms.hip x height overlap), sampled into ROI_PER_IMAGE foreground /
+hard- / easy-background boxes with the reference's numpy / torch random draws (same seeds -> same samples), residual targets are
+encoded in each RoI's frame, and the RoI MLP is trained with the IoU-scaled BCE + masked L1 losses."""
+import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import registry
@@ -57,8 +65,156 @@ class BEVFeatureExtractor(nn.Module):
         return ret
 
 
-def _cfg_get(cfg, key):
-    return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
+def _cfg_get(cfg, key, *default):
+    if isinstance(cfg, dict):
+        return cfg.get(key, *default) if default else cfg[key]
+    return getattr(cfg, key, *default)
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    return val - torch.floor(val / period + offset) * period
+
+
+def rotate_points_along_z(points, angle):
+    """points [B, N, 3+C] as ROW vectors times [[c, -s, 0], [s, c, 0], [0, 0, 1]] per batch entry (box_torch_ops.py:326-344)"""
+    cosa, sina = torch.cos(angle), torch.sin(angle)
+    x = points[:, :, 0] * cosa[:, None] + points[:, :, 1] * sina[:, None]
+    y = -points[:, :, 0] * sina[:, None] + points[:, :, 1] * cosa[:, None]
+    return torch.cat([x[..., None], y[..., None], points[:, :, 2:]], dim=-1)
+
+
+def _to_pcdet(boxes):
+    """(x, y, z, w, l, h, yaw) -> OpenPCDet's (x, y, z, dx, dy, dz, heading) (iou3d_nms_utils.py:22-26)"""
+    b = boxes[:, [0, 1, 2, 4, 3, 5, -1]].clone()
+    b[:, -1] = -b[:, -1] - np.pi / 2
+    return b
+
+
+def boxes_iou3d(boxes_a, boxes_b, bev_iou=None):
+    """3-D IoU matrix [N, M] of (x, y, z, w, l, h, yaw) boxes (iou3d_nms_utils.boxes_iou3d_gpu): rotated BEV overlap x height overlap
+    over the union of the volumes.  The BEV overlap comes from the device IoU kernel (IoU = o / (A + B - o) -> o = IoU (A + B) /
+    (1 + IoU)); `bev_iou` (tests: the CPU oracle) replaces it, otherwise CUDA tensors are required - no CPU fallback."""
+    a, b = _to_pcdet(boxes_a), _to_pcdet(boxes_b)
+    if bev_iou is None:
+        from . import nms
+        bev_iou = nms.boxes_iou_bev
+    iou = bev_iou(a.contiguous(), b.contiguous()).to(a.dtype)
+    area_a, area_b = (a[:, 3] * a[:, 4]).view(-1, 1), (b[:, 3] * b[:, 4]).view(1, -1)
+    overlaps_bev = iou * (area_a + area_b) / (1.0 + iou)
+    a_max, a_min = (a[:, 2] + a[:, 5] / 2).view(-1, 1), (a[:, 2] - a[:, 5] / 2).view(-1, 1)
+    b_max, b_min = (b[:, 2] + b[:, 5] / 2).view(1, -1), (b[:, 2] - b[:, 5] / 2).view(1, -1)
+    overlaps_h = torch.clamp(torch.min(a_max, b_max) - torch.max(a_min, b_min), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a, vol_b = (a[:, 3] * a[:, 4] * a[:, 5]).view(-1, 1), (b[:, 3] * b[:, 4] * b[:, 5]).view(1, -1)
+    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+
+
+class ProposalTargetLayer(nn.Module):
+    """IoU-based sampling of the first stage's RoIs and their classification / regression labels
+    (proposal_target_layer.py).  The random draws are the reference's (np.random.permutation / np.random.rand on the host,
+    torch.randint on the CPU generator), so a seeded run samples the same RoIs."""
+
+    def __init__(self, roi_sampler_cfg, iou_fn=None):
+        super().__init__()
+        self.cfg = roi_sampler_cfg
+        self.iou_fn = iou_fn or boxes_iou3d
+
+    def _c(self, key, default=None):
+        return _cfg_get(self.cfg, key, default)
+
+    def forward(self, batch_dict):
+        rois, gt_of_rois, ious, scores, labels, feats = self.sample_rois_for_rcnn(batch_dict)
+        reg_valid_mask = (ious > self._c("REG_FG_THRESH")).long()
+        kind = self._c("CLS_SCORE_TYPE")
+        if kind == "cls":
+            cls_labels = (ious > self._c("CLS_FG_THRESH")).long()
+            ignore = (ious > self._c("CLS_BG_THRESH")) & (ious < self._c("CLS_FG_THRESH"))
+            cls_labels[ignore > 0] = -1
+        elif kind == "roi_iou":
+            bg, fg = self._c("CLS_BG_THRESH"), self._c("CLS_FG_THRESH")
+            fg_mask, bg_mask = ious > fg, ious < bg
+            interval = (fg_mask == 0) & (bg_mask == 0)
+            cls_labels = (fg_mask > 0).float()
+            cls_labels[interval] = (ious[interval] - bg) / (fg - bg)
+        else:
+            raise NotImplementedError(kind)
+        return dict(rois=rois, gt_of_rois=gt_of_rois, gt_iou_of_rois=ious, roi_scores=scores, roi_labels=labels, roi_features=feats,
+                    reg_valid_mask=reg_valid_mask, rcnn_cls_labels=cls_labels)
+
+    def sample_rois_for_rcnn(self, batch_dict):
+        bs, per = batch_dict["batch_size"], self._c("ROI_PER_IMAGE")
+        rois, roi_scores, roi_labels = batch_dict["rois"], batch_dict["roi_scores"], batch_dict["roi_labels"]
+        gt_boxes, roi_features = batch_dict["gt_boxes_and_cls"], batch_dict["roi_features"]
+        code = rois.shape[-1]
+        out_rois, out_gt = rois.new_zeros(bs, per, code), rois.new_zeros(bs, per, code + 1)
+        out_iou, out_scores = rois.new_zeros(bs, per), rois.new_zeros(bs, per)
+        out_labels = rois.new_zeros((bs, per), dtype=torch.long)
+        out_feats = roi_features.new_zeros(bs, per, roi_features.shape[-1])
+        for i in range(bs):
+            cur_gt = gt_boxes[i]
+            k = len(cur_gt) - 1
+            rowsum = cur_gt.sum(-1).tolist()                    # the reference walks back over the zero padding rows (sum == 0)
+            while k > 0 and rowsum[k] == 0:
+                k -= 1
+            cur_gt = cur_gt[:k + 1]
+            cur_gt = cur_gt.new_zeros((1, cur_gt.shape[1])) if len(cur_gt) == 0 else cur_gt
+            if self._c("SAMPLE_ROI_BY_EACH_CLASS", False):
+                max_overlaps, assignment = self.get_max_iou_with_same_class(rois[i][:, :7], roi_labels[i], cur_gt[:, 0:7], cur_gt[:, -1].long())
+            else:
+                max_overlaps, assignment = torch.max(self.iou_fn(rois[i], cur_gt[:, 0:7]), dim=1)
+            idx = self.subsample_rois(max_overlaps)
+            out_rois[i], out_labels[i], out_iou[i], out_scores[i] = rois[i][idx], roi_labels[i][idx], max_overlaps[idx], roi_scores[i][idx]
+            out_gt[i], out_feats[i] = cur_gt[assignment[idx]], roi_features[i][idx]
+        return out_rois, out_gt, out_iou, out_scores, out_labels, out_feats
+
+    def subsample_rois(self, max_overlaps):
+        per = self._c("ROI_PER_IMAGE")
+        fg_per = int(np.round(self._c("FG_RATIO") * per))
+        fg_thresh = min(self._c("REG_FG_THRESH"), self._c("CLS_FG_THRESH"))
+        fg = (max_overlaps >= fg_thresh).nonzero().view(-1)
+        easy = (max_overlaps < self._c("CLS_BG_THRESH_LO")).nonzero().view(-1)
+        hard = ((max_overlaps < self._c("REG_FG_THRESH")) & (max_overlaps >= self._c("CLS_BG_THRESH_LO"))).nonzero().view(-1)
+        n_fg, n_bg = fg.numel(), hard.numel() + easy.numel()
+        if n_fg > 0 and n_bg > 0:
+            take = min(fg_per, n_fg)
+            perm = torch.from_numpy(np.random.permutation(n_fg)).to(max_overlaps.device).long()
+            fg = fg[perm[:take]]
+            bg = self.sample_bg_inds(hard, easy, per - take, self._c("HARD_BG_RATIO"))
+        elif n_fg > 0:
+            draw = torch.from_numpy(np.floor(np.random.rand(per) * n_fg)).to(max_overlaps.device).long()
+            fg = fg[draw]
+            bg = fg.new_zeros(0)
+        elif n_bg > 0:
+            bg = self.sample_bg_inds(hard, easy, per, self._c("HARD_BG_RATIO"))
+        else:
+            raise NotImplementedError(f"ProposalTargetLayer: no RoI to sample (max IoU in [{float(max_overlaps.min())}, {float(max_overlaps.max())}])")
+        return torch.cat((fg, bg), dim=0)
+
+    @staticmethod
+    def sample_bg_inds(hard, easy, count, hard_ratio):
+        draw = lambda n, k: torch.randint(low=0, high=n, size=(k,)).long()    # CPU generator, as in the reference
+        if hard.numel() > 0 and easy.numel() > 0:
+            n_hard = min(int(count * hard_ratio), len(hard))
+            h = hard[draw(hard.numel(), n_hard).to(hard.device)]
+            e = easy[draw(easy.numel(), count - n_hard).to(easy.device)]
+            return torch.cat([h, e], dim=0)
+        if hard.numel() > 0:
+            return hard[draw(hard.numel(), count).to(hard.device)]
+        if easy.numel() > 0:
+            return easy[draw(easy.numel(), count).to(easy.device)]
+        raise NotImplementedError
+
+    def get_max_iou_with_same_class(self, rois, roi_labels, gt_boxes, gt_labels):
+        max_overlaps = rois.new_zeros(rois.shape[0])
+        assignment = roi_labels.new_zeros(roi_labels.shape[0])
+        for k in range(int(gt_labels.min()), int(gt_labels.max()) + 1):
+            rm, gm = roi_labels == k, gt_labels == k
+            if rm.sum() > 0 and gm.sum() > 0:
+                orig = gm.nonzero().view(-1)
+                cur_max, cur_arg = torch.max(self.iou_fn(rois[rm], gt_boxes[gm]), dim=1)
+                max_overlaps[rm] = cur_max
+                assignment[rm] = orig[cur_arg]
+        return max_overlaps, assignment
 
 
 @ROI_HEAD.register_module
@@ -83,6 +239,71 @@ class RoIHead(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
         nn.init.normal_(self.reg_layers[-1].weight, mean=0, std=0.001)
+        target_cfg = _cfg_get(model_cfg, "TARGET_CONFIG", None)
+        self.proposal_target_layer = ProposalTargetLayer(target_cfg) if target_cfg else None   # no parameters: state_dict unchanged
+        self.forward_ret_dict = None
+
+    def assign_targets(self, batch_dict):
+        """sampled RoIs + their ground-truth boxes encoded in the RoI's frame (roi_head_template.py:43-92)"""
+        if self.proposal_target_layer is None:
+            raise ValueError("RoIHead: model_cfg.TARGET_CONFIG is required for training")
+        bs = batch_dict["batch_size"]
+        with torch.no_grad():
+            t = self.proposal_target_layer(batch_dict)
+        rois, gt = t["rois"], t["gt_of_rois"]
+        t["gt_of_rois_src"] = gt.clone().detach()
+        roi_ry = limit_period(rois[:, :, 6], offset=0.5, period=np.pi * 2)
+        gt[:, :, :6] = gt[:, :, :6] - rois[:, :, :6]
+        gt[:, :, 6] = gt[:, :, 6] - roi_ry
+        gt = rotate_points_along_z(gt.view(-1, 1, gt.shape[-1]), -roi_ry.view(-1)).view(bs, -1, gt.shape[-1])
+        if rois.shape[-1] == 9:
+            gt[:, :, 7:-1] = gt[:, :, 7:-1] - rois[:, :, 7:]
+        heading = gt[:, :, 6] % (2 * np.pi)                                  # flip when the RoI points the other way
+        opposite = (heading > np.pi * 0.5) & (heading < np.pi * 1.5)
+        heading[opposite] = (heading[opposite] + np.pi) % (2 * np.pi)
+        flag = heading > np.pi
+        heading[flag] = heading[flag] - np.pi * 2
+        gt[:, :, 6] = torch.clamp(heading, min=-np.pi / 2, max=np.pi / 2)
+        t["gt_of_rois"] = gt
+        return t
+
+    def get_box_reg_layer_loss(self, ret):
+        cfg = _cfg_get(self.model_cfg, "LOSS_CONFIG")
+        if _cfg_get(cfg, "REG_LOSS") != "L1":
+            raise NotImplementedError(_cfg_get(cfg, "REG_LOSS"))
+        weights = _cfg_get(cfg, "LOSS_WEIGHTS")
+        code = ret["rcnn_reg"].shape[-1]
+        fg = ret["reg_valid_mask"].view(-1) > 0
+        target = ret["gt_of_rois"][..., 0:code].reshape(-1, code)
+        loss = F.l1_loss(ret["rcnn_reg"].view(target.shape[0], -1), target, reduction="none")
+        loss = loss * loss.new_tensor(weights["code_weights"])
+        loss = (loss * fg.unsqueeze(-1).float()).sum() / max(int(fg.long().sum().item()), 1)
+        loss = loss * weights["rcnn_reg_weight"]
+        return loss, {"rcnn_loss_reg": loss.detach()}
+
+    def get_box_cls_layer_loss(self, ret):
+        cfg = _cfg_get(self.model_cfg, "LOSS_CONFIG")
+        labels = ret["rcnn_cls_labels"].view(-1)
+        kind = _cfg_get(cfg, "CLS_LOSS")
+        if kind == "BinaryCrossEntropy":
+            per = F.binary_cross_entropy(torch.sigmoid(ret["rcnn_cls"].view(-1)), labels.float(), reduction="none")
+        elif kind == "CrossEntropy":
+            per = F.cross_entropy(ret["rcnn_cls"], labels, reduction="none", ignore_index=-1)
+        else:
+            raise NotImplementedError(kind)
+        valid = (labels >= 0).float()
+        loss = (per * valid).sum() / torch.clamp(valid.sum(), min=1.0)
+        loss = loss * _cfg_get(cfg, "LOSS_WEIGHTS")["rcnn_cls_weight"]
+        return loss, {"rcnn_loss_cls": loss.detach()}
+
+    def get_loss(self, tb_dict=None):
+        tb = {} if tb_dict is None else tb_dict
+        cls, c = self.get_box_cls_layer_loss(self.forward_ret_dict)
+        reg, r = self.get_box_reg_layer_loss(self.forward_ret_dict)
+        tb.update(c); tb.update(r)
+        total = cls + reg
+        tb["rcnn_loss"] = total.item()
+        return total, tb
 
     @staticmethod
     def make_fc_layers(input_channels, output_channels, fc_list, dp_ratio):
@@ -116,13 +337,19 @@ class RoIHead(nn.Module):
         return batch_cls, box.view(batch_size, -1, code_size)
 
     def forward(self, batch_dict, training=True):
-        if training:
-            raise NotImplementedError("RoIHead training targets (ProposalTargetLayer) are outside the built path; inference only")
         batch_dict["batch_size"] = len(batch_dict["rois"])
+        targets = None
+        if training:   # roi_head.py:76-80
+            targets = self.assign_targets(batch_dict)
+            batch_dict["rois"], batch_dict["roi_labels"], batch_dict["roi_features"] = targets["rois"], targets["roi_labels"], targets["roi_features"]
         pooled = batch_dict["roi_features"].reshape(-1, 1, batch_dict["roi_features"].shape[-1]).permute(0, 2, 1).contiguous()
         shared = self.shared_fc_layer(pooled)
         rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
         rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        if training:
+            targets["rcnn_cls"], targets["rcnn_reg"] = rcnn_cls, rcnn_reg
+            self.forward_ret_dict = targets
+            return batch_dict
         cls, box = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"], rcnn_cls, rcnn_reg)
         batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"], batch_dict["cls_preds_normalized"] = cls, box, False
         return batch_dict
@@ -209,16 +436,34 @@ class TwoStageDetector(nn.Module):
             out.append(dict(box3d_lidar=box[m, :], scores=scores[m], label_preds=lab[m] - 1, metadata=meta[i] if meta else None))
         return out
 
+    @staticmethod
+    def combine_loss(one_stage_loss, roi_loss, tb_dict):
+        """two_stage.py:40-47: the RoI loss is added to the first task's loss; its two terms are logged per task"""
+        one_stage_loss["loss"][0] = one_stage_loss["loss"][0] + roi_loss
+        one_stage_loss.setdefault("roi_reg_loss", [])
+        one_stage_loss.setdefault("roi_cls_loss", [])
+        for _ in range(len(one_stage_loss["loss"])):
+            one_stage_loss["roi_reg_loss"].append(tb_dict["rcnn_loss_reg"])
+            one_stage_loss["roi_cls_loss"].append(tb_dict["rcnn_loss_cls"])
+        return one_stage_loss
+
     def forward(self, example, return_loss=True, return_feature=False, **kwargs):
-        if return_loss:
-            raise NotImplementedError("TwoStageDetector: RoI-head training (ProposalTargetLayer) is outside the built path")
         out = self.single_det.forward_two_stage(example, return_loss, **kwargs)
-        one_stage_pred, bev_feature, voxel_feature, _, f_a, f_b = out
+        f_a = f_b = None
+        if len(out) == 6:
+            one_stage_pred, bev_feature, voxel_feature, one_stage_loss, f_a, f_b = out
+        else:
+            one_stage_pred, bev_feature, voxel_feature, one_stage_loss = out
         example["voxel_feature"] = voxel_feature
         example["bev_feature"] = bev_feature.float().permute(0, 2, 3, 1).contiguous()   # N C H W -> N H W C
         centers = self.get_box_center(one_stage_pred)
+        if self.roi_head.code_size == 7 and return_loss:   # drop the velocity columns (two_stage.py:173-175)
+            example["gt_boxes_and_cls"] = example["gt_boxes_and_cls"][:, :, [0, 1, 2, 3, 4, 5, 6, -1]]
         features = [m(example, centers, self.num_point) for m in self.second_stage]
         example = self.reorder_first_stage_pred_and_feature(one_stage_pred, example, features)
-        batch_dict = self.roi_head(example, training=False)
+        batch_dict = self.roi_head(example, training=return_loss)
+        if return_loss:
+            roi_loss, tb = self.roi_head.get_loss()
+            return self.combine_loss(one_stage_loss, roi_loss, tb)
         res = self.post_process(batch_dict)
         return (res, f_a, f_b) if return_feature else res

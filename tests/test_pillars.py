@@ -159,7 +159,10 @@ def test_pointpillars_detectors_gpu_match_the_cpu_oracle_path():
     for k in ("teacher_hm", "F_D_a", "F_S_a", "F_S_b"):
         assert rel(got[k], ref[k]) <= 5e-3, (k, rel(got[k], ref[k]))
     assert set(got["student_grads"]) == set(ref["student_grads"])
-    errs = {n: rel(got["student_grads"][n], g) for n, g in ref["student_grads"].items() if g.norm() > 1e-8}
+    # a conv bias in front of a train-mode batch norm has an exactly-zero gradient (both sides hold rounding residue there): tensors
+    # below 1e-4 of the largest gradient norm are compared absolutely against that scale
+    top = max(float(g.norm()) for g in ref["student_grads"].values())
+    errs = {n: float((got["student_grads"][n] - g).norm() / max(float(g.norm()), 1e-4 * top)) for n, g in ref["student_grads"].items()}
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     print("pillar S2D student fp32 vs CPU oracle path, worst gradient errors:", [(n, f"{e:.1e}") for n, e in worst])
     assert max(errs.values()) <= 5e-2, worst
