@@ -1,9 +1,13 @@
 """Sum all-reduce of the small fp32 SyncBN vectors (82 per training step on this path).
 
-Default route: the RCCL communicator of csrc/comm.hip, called on the stream the batch-norm kernels run on (no c10d
-stream hand-off, ~3 us of host time per call instead of ~25).  It is bootstrapped collectively by `init_direct()`; if
-that does not succeed on EVERY rank within a time limit, all ranks fall back to `torch.distributed.all_reduce`
-together.  `S2D_RCCL_DIRECT=0` keeps torch.distributed."""
+Two routes.  (a) `torch.distributed.all_reduce` on the default process group: the DEFAULT whenever there is more than one rank -
+SyncBN vectors and gradient buckets then share ONE communicator and are issued in host program order, which is the same on
+every rank.  (b) The RCCL communicator of csrc/comm.hip, called on the stream the batch-norm kernels run on (no c10d stream
+hand-off, ~3 us of host time per call instead of ~25): opt-in with `S2D_RCCL_DIRECT=1` at world > 1, because a second
+communicator running beside c10d's has only ever been exercised with ONE rank here (no multi-GPU box inside a round; NCCL-family
+libraries can deadlock when two communicators' collectives interleave differently across ranks).  With one rank
+(`S2D_FORCE_DDP=1` measurement runs) it is on by default.  It is bootstrapped collectively by `init_direct()`; if that does not
+succeed on EVERY rank within a time limit, all ranks fall back to route (a) together."""
 import ctypes
 import os
 import threading
@@ -51,7 +55,9 @@ def init_direct(device_index, timeout_s=120.0):
         return True
     _DIRECT, _DIRECT_PG = False, None   # (a destroyed and re-created process group starts over)
     _CANCEL.clear()
-    if os.environ.get("S2D_RCCL_DIRECT", "1") == "0" or not dist.is_initialized() or dist.get_backend() != "nccl":
+    if not dist.is_initialized() or dist.get_backend() != "nccl":
+        return False
+    if os.environ.get("S2D_RCCL_DIRECT", "1" if dist.get_world_size() == 1 else "0") == "0":
         return False
     from . import _lib
     lib = _lib.load()
