@@ -431,6 +431,31 @@ int s2d_conv2d2x2s2_nhwc_bf16(const void *x, const void *packed_weight, const fl
                               int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);
 
 /*
+ * Stride-2 transposed convolutions and their gradients on the same tile pipeline (replace the MIOpen calls behind
+ * nn.ConvTranspose2d(256, 256, 4, 2, 1) in decoder_1 / decoder_2 of the S2D module, det3d/models/necks/rpn.py:217-231, and behind
+ * the backward of the RPN's stride-2 3x3 convs, rpn.py:126-133).
+ *   convup (ks = 4): ConvTranspose2d(4,2,1) forward, x [n][h][w][kc] -> y [n][2h][2w][nc], weight fp32 [kc][nc][4][4] (torch layout),
+ *          optional bias and BN-statistics slabs [s2d_convup_stats_tiles][2][nc];
+ *   convup (ks = 3): data gradient of Conv2d(nc -> kc, 3, stride 2, pad 1): dY [n][h][w][kc] -> dX [n][2h][2w][nc], weight [kc][nc][3][3];
+ *   conv2d4x4s2: Conv2d(cin -> cout, 4, stride 2, pad 1) = data gradient of ConvTranspose2d(cout -> cin, 4,2,1); weight fp32
+ *          [cout][cin][4][4] in the forward-conv sense = the transposed conv's weight as stored; x [n][h][w][cin] -> [n][h/2][w/2][cout];
+ *   conv2d_s2_wgrad: dW[ca][cb][ks][ks] = sum a[n][i][j][.] * b[n][2i-1+ky][2j-1+kx][.] with a [n][h/2][w/2][ca], b [n][h][w][cb]
+ *          (ConvTranspose2d: a = input, b = dY; stride-2 conv: a = dY, b = input); fixed-order split reduction in ws.
+ */
+int s2d_convup_supported(int kc, int nc, int ks);
+int s2d_convup_pack_weights_bf16(const float *weight, int kc, int nc, int ks, void *packed, s2d_stream_t stream);
+int64_t s2d_convup_stats_tiles(int n_img, int h, int w, int kc, int nc, int ks);
+int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h, int w,
+                         int kc, int nc, int ks, void *y, float *stats_partial, s2d_stream_t stream);
+int s2d_conv2d4x4s2_pack_weights_bf16(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream);
+int s2d_conv2d4x4s2_nhwc_bf16(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin,
+                              int cout, void *y, s2d_stream_t stream);
+int s2d_conv2d_s2_wgrad_supported(int ca, int cb, int ks);
+size_t s2d_conv2d_s2_wgrad_workspace_bytes(int n_img, int h, int w, int ca, int cb, int ks);
+int s2d_conv2d_s2_wgrad_nhwc_bf16(const void *a, const void *b, const void *zero_page, int n_img, int h, int w, int ca, int cb, int ks,
+                                  float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+
+/*
  * Depth-wise 7x7 convolution, padding 3, stride 1 (nn.Conv2d(C, C, 7, padding=3, groups=C): first layer of the three
  * ConvNeXt blocks of the S2D module, det3d/models/necks/rpn.py:204-225) on NHWC bf16 maps.  x, y [n][h][w][c] bf16;
  * weight fp32 [c][49] (the torch layout [c][1][7][7]); bias fp32 [c] or NULL; fp32 accumulation.  flip=1 mirrors the taps:

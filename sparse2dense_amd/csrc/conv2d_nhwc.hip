@@ -61,14 +61,50 @@ __global__ __launch_bounds__(256) void conv2d_pack_pair_kernel(const float *__re
     else conv2d_pack_element(w, cout, cin, bn_d, 1, w_nhwc, taps, i, out_d);
 }
 
+// Weight image of the stride-2 transposed kernels (conv3x3_k32_nhwc_bf16_kernel<.., UP = true>): source w[K ch][N ch][KS][KS] (the
+// layout of a ConvTranspose2d weight [Cin][Cout][kh][kw], and of a Conv2d weight [Cout][Cin][kh][kw] seen from its data gradient).
+// Packed tap t runs over the four parity classes (p, q) in order, each class's (KS + p) / 2 x (KS + q) / 2 window row-major from its
+// top-left source pixel: window position (ty, tx) is the tap ky = 2 (TY - 1 - ty) + 1 - p, kx = 2 (TX - 1 - tx) + 1 - q.
+__global__ __launch_bounds__(256) void conv2d_pack_up_kernel(const float *__restrict__ w, int kc, int nc, int bn, int ks,
+                                                             __bf16 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int taps = ks * ks;
+    if (i >= (int64_t)taps * kc * nc) return;
+    const int ntile = bn / 16, per_wave = bn / 32;
+    int64_t r = i;
+    const int e = r % 8; r /= 8;
+    const int c = r % 16; r /= 16;
+    const int q4 = r % 4; r /= 4;
+    const int nt = r % ntile; r /= ntile;
+    const int h = r % 2; r /= 2;
+    const int blk = r % (nc / bn); r /= (nc / bn);
+    const int chunk = r % (kc / 64); r /= (kc / 64);
+    int t = (int)r, p = 0, q = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        p = cls >> 1; q = cls & 1;
+        const int n = ((ks + p) / 2) * ((ks + q) / 2);
+        if (t < n) break;
+        t -= n;
+    }
+    const int TY = (ks + p) / 2, TX = (ks + q) / 2;
+    const int ty = t / TX, tx = t % TX;
+    const int ky = 2 * (TY - 1 - ty) + 1 - p, kx = 2 * (TX - 1 - tx) + 1 - q;
+    const int k = chunk * 64 + h * 32 + 8 * q4 + e;
+    const int n_ch = blk * bn + (nt / per_wave) * (bn / 2) + c * per_wave + (nt % per_wave);
+    out[i] = (__bf16)w[(((int64_t)k * nc + n_ch) * ks + ky) * ks + kx];
+}
+
 // Shared epilogue.  C/D layout: row = 4*(lane>>4)+reg (pixel), col = lane&15 -> couts co_base + r*NT + j (NT consecutive).
 // stats_partial (optional): per-tile (sum, sum of squares) of the STORED bf16 outputs per output channel, laid out
 // [tile][2][cout] — exactly the partial-sum slabs the batch-norm finalize kernel consumes, so the BatchNorm that
 // follows this conv skips its statistics pass over the tensor.  Fixed summation order (deterministic).
-template <int BN, int MI = 4>
+// UP (the stride-2 transposed kernels below): row m = (n, i, j) of the [up_h][up_w] source grid is stored at output pixel
+// (n, 2 i + up_p, 2 j + up_q) of the [2 up_h][2 up_w] image.
+template <int BN, int MI = 4, bool UP = false>
 __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[MI][BN / 32], const float *__restrict__ bias, __bf16 *__restrict__ y,
                                               int64_t m0, int64_t m_total, int cout, int blk_n, int wm, int wn, int r, int q,
-                                              char *smem, float *__restrict__ stats_partial, int tile) {
+                                              char *smem, float *__restrict__ stats_partial, int tile, int up_h = 0, int up_w = 0,
+                                              int up_p = 0, int up_q = 0) {
     constexpr int NT = BN / 32;
     const int co_base = blk_n * BN + wn * (BN / 2);
     float bv[NT], s1[NT], s2[NT];
@@ -92,7 +128,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[MI][BN / 32], const 
                     s1[j] += f;
                     s2[j] += f * f;
                 }
-                __bf16 *dst = y + m * cout + co_base + r * NT;
+                int64_t mo = m;
+                if (UP) {
+                    const int j = (int)(m % up_w);
+                    const int64_t t = m / up_w;
+                    const int i = (int)(t % up_h);
+                    mo = ((t / up_h * 2 * up_h) + 2 * i + up_p) * (2 * up_w) + 2 * j + up_q;
+                }
+                __bf16 *dst = y + mo * cout + co_base + r * NT;
                 if (NT == 4) {
                     bf16x4c o;
                     o[0] = v[0]; o[1] = v[1 % NT]; o[2] = v[2 % NT]; o[3] = v[3 % NT];
@@ -270,7 +313,13 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 // 48 KiB, so three workgroups (12 waves) stay resident per CU, each with two K-steps of LDS-DMA in flight across its
 // barrier.  A image: [128 px][4 parts of 16 B], part index XOR-swizzled by (row >> 1) & 3 (checked against the
 // ds_read_b128 lane groups: 16 distinct bank slots).  B = the h-th half of the 64-deep packed slab (same weight image).
-template <int BN, int MI>
+// KS = kernel size of the direct form (3; 4 with stride 2 = the data gradient of ConvTranspose2d(4,2,1)).  UP = the stride-2
+// TRANSPOSED form (pad 1) split into its four output parity classes (blockIdx.z = 2 p + q): output pixel (2 i + p, 2 j + q) reads
+// the source pixels (i + p - a, j + q - b) with the taps ky = 2 a + 1 - p < KS, kx = 2 b + 1 - q < KS - (KS + p) / 2 x (KS + q) / 2
+// dense taps per class, no zero taps.  KS = 4: the forward of ConvTranspose2d(4,2,1) (2 x 2 taps per class); KS = 3: the data
+// gradient of a stride-2 3x3 conv (1, 2, 2, 4 taps).  The weight image lists the classes one after another, each in the window's
+// row-major order (conv2d_pack_up_kernel); H, W are the SOURCE grid in that mode (pad / stride unused).
+template <int BN, int MI, int KS = 3, bool UP = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                     const float *__restrict__ bias,
                                                                     const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
@@ -286,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
     auto abuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF); };
     auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF) + A_BYTES; };
 
-    const int Ho = (H + 2 * pad - 3) / stride + 1, Wo = (W + 2 * pad - 3) / stride + 1;
+    const int Ho = UP ? H : (H + 2 * pad - KS) / stride + 1, Wo = UP ? W : (W + 2 * pad - KS) / stride + 1;
     const int64_t m_total = (int64_t)n_img * Ho * Wo;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -296,7 +345,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
     if (m0 >= m_total) return;
     const int blk_n = blockIdx.y;
     const int chunks = cin / 64;
-    const int T = 18 * chunks;   // sub-steps: (tap, 64-channel chunk, half)
+    // tap window of this launch (UP: of this parity class) and the K-steps of the classes before it in the weight image
+    const int up_p = UP ? (int)(blockIdx.z >> 1) : 0, up_q = UP ? (int)(blockIdx.z & 1) : 0;
+    const int TY = UP ? (KS + up_p) / 2 : KS, TX = UP ? (KS + up_q) / 2 : KS;
+    constexpr int N00 = (KS / 2) * (KS / 2), N01 = (KS / 2) * ((KS + 1) / 2);
+    const int tap_off = !UP ? 0 : blockIdx.z == 0 ? 0 : blockIdx.z == 1 ? N00 : blockIdx.z == 2 ? N00 + N01 : N00 + 2 * N01;
+    const int T = 2 * TY * TX * chunks;   // sub-steps: (tap, 64-channel chunk, half)
 
     // A staging: thread t moves the 16-byte chunks t and t+256 of the [128][32 ch] tile: row = id/4, slot = id%4.
     // Everything that depends on the thread is computed once: the address of the window's corner pixel (tap 0) and a
@@ -315,19 +369,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
         const int64_t m = m0 + row;
         const bool ok = m < m_total;
         const int64_t mm = ok ? m : 0;
-        const int ix0 = (int)(mm % Wo) * stride - pad;
-        const int iy0 = (int)((mm / Wo) % Ho) * stride - pad;
+        const int ix0 = UP ? (int)(mm % Wo) + up_q - (TX - 1) : (int)(mm % Wo) * stride - pad;
+        const int iy0 = UP ? (int)((mm / Wo) % Ho) + up_p - (TY - 1) : (int)((mm / Wo) % Ho) * stride - pad;
         const int img = (int)(mm / ((int64_t)Wo * Ho));
         a_base[u] = x + (((int64_t)img * H + iy0) * W + ix0) * cin + part * 8;
         unsigned mask = 0;
+        constexpr int TAPS_MAX = UP ? ((KS + 1) / 2) * ((KS + 1) / 2) : KS * KS;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-            if (ok && (unsigned)(iy0 + tap / 3) < (unsigned)H && (unsigned)(ix0 + tap % 3) < (unsigned)W) mask |= 1u << tap;
+        for (int tap = 0; tap < TAPS_MAX; ++tap)
+            if (ok && tap < TY * TX && (unsigned)(iy0 + tap / TX) < (unsigned)H && (unsigned)(ix0 + tap % TX) < (unsigned)W) mask |= 1u << tap;
         a_mask[u] = mask;
     }
     const int64_t wstep = (int64_t)(cout / BN) * (2 * B_HALF);
     // stage cursor (wave-uniform)
-    const char *st_w = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * (2 * B_HALF) + wid * 1024;
+    const char *st_w = reinterpret_cast<const char *>(wpack) + (int64_t)tap_off * chunks * wstep + (int64_t)blk_n * (2 * B_HALF) + wid * 1024;
     int st_tap = 0, st_kx = 0, st_coff = 0, st_off = 0, st_h = 0;
 
     auto stage_next = [&](int buf) {
@@ -355,9 +410,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
             ++st_tap;
             ++st_kx;
             st_off += cin;
-            if (st_kx == 3) {
+            if (st_kx == TX) {
                 st_kx = 0;
-                st_off += (W - 3) * cin;
+                st_off += (W - TX) * cin;
             }
         }
     };
@@ -412,7 +467,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
     __builtin_amdgcn_s_barrier();
     read_frags(0, fa[0], fb[0]);
     int t = 0;
-    for (; t + 4 < T; t += 2) {   // T = 18 * chunks is even; no conditional waits inside the loop
+    for (; t + 4 < T; t += 2) {   // T is even and >= 4 (host check); no conditional waits inside the loop
         sync_in_flight();
         read_frags(rd, fa[1], fb[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -448,7 +503,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
     mfmas(fa[0], fb[0]);
     mfmas(fa[1], fb[1]);
 
-    conv_epilogue<BN, MI>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / BM));
+    conv_epilogue<BN, MI, UP>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial,
+                              (int)(m0 / BM) + (UP ? (int)(blockIdx.z * ((m_total + BM - 1) / BM)) : 0), H, W, up_p, up_q);
 }
 
 // ---- pad = 1 variant with the A tile shared by the three kx taps ------------------------------------------------------
@@ -767,6 +823,98 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
         if (ns == 4) S2D_CONV_LAUNCH(64, 4); else if (ns == 3) S2D_CONV_LAUNCH(64, 3); else S2D_CONV_LAUNCH(64, 2);
     }
 #undef S2D_CONV_LAUNCH
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+
+// ---- stride-2 transposed forms and the 4x4 stride-2 conv on the 32-deep kernel -----------------------------------------------------
+// decoder_1 / decoder_2 of the S2D module (/root/reference/det3d/models/necks/rpn.py:217-231: nn.ConvTranspose2d(256, 256, 4, 2, 1)
+// at 47 -> 94 and 94 -> 188) and the backward of the RPN's stride-2 3x3 convs (rpn.py:126-133).  "up": source [n][h][w][kc] ->
+// [n][2h][2w][nc]; ks = 4: ConvTranspose2d(4,2,1) forward from its weight [kc][nc][4][4]; ks = 3: data gradient of
+// Conv2d(nc -> kc, 3, stride 2, pad 1) on a [2h][2w] input from its weight [kc][nc][3][3].
+static bool convup_supported(int kc, int nc, int ks) {
+    return (ks == 3 || ks == 4) && s2d_conv2d3x3_supported(kc, nc) && conv_bn(nc) == 128 && (ks == 4 || kc >= 128);   // >= 4 sub-steps per class
+}
+extern "C" int s2d_convup_supported(int kc, int nc, int ks) { return convup_supported(kc, nc, ks); }
+
+extern "C" int s2d_convup_pack_weights_bf16(const float *weight, int kc, int nc, int ks, void *packed, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed, "convup_pack: null argument");
+    if (!convup_supported(kc, nc, ks)) {
+        set_error("convup_pack: unsupported %d -> %d, kernel %d", kc, nc, ks);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)ks * ks * kc * nc;
+    hipLaunchKernelGGL(conv2d_pack_up_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, kc, nc,
+                       conv_bn(nc), ks, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+static int convup_rows(int64_t m, int col_blocks) { return conv_k32_rows(4 * m, col_blocks); }
+
+extern "C" int64_t s2d_convup_stats_tiles(int n_img, int h, int w, int kc, int nc, int ks) {
+    if (!convup_supported(kc, nc, ks) || n_img <= 0 || h <= 0 || w <= 0) return 0;
+    const int64_t m = (int64_t)n_img * h * w;
+    return 4 * ceil_div(m, convup_rows(m, nc / 128));
+}
+
+extern "C" int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
+                                    int w, int kc, int nc, int ks, void *y, float *stats_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0, "convup: bad argument");
+    if (!convup_supported(kc, nc, ks)) {
+        set_error("convup: unsupported %d -> %d, kernel %d", kc, nc, ks);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t m = (int64_t)n_img * h * w;
+    const int rows = convup_rows(m, nc / 128);
+    hipStream_t st = (hipStream_t)stream;
+#define S2D_CONVUP(MI_, KS_)                                                                                                       \
+    hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, KS_, true>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), nc / 128, 4),     \
+                       dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \
+                       bias, (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial)
+    if (ks == 4) {
+        if (rows == 128) S2D_CONVUP(4, 4); else if (rows == 96) S2D_CONVUP(3, 4); else S2D_CONVUP(2, 4);
+    } else {
+        if (rows == 128) S2D_CONVUP(4, 3); else if (rows == 96) S2D_CONVUP(3, 3); else S2D_CONVUP(2, 3);
+    }
+#undef S2D_CONVUP
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// Conv2d(cin -> cout, 4, stride 2, pad 1) = the data gradient of ConvTranspose2d(cout -> cin, 4, 2, 1): weight [cout][cin][4][4]
+// in the forward-conv sense, i.e. the ConvTranspose2d weight [its Cin = cout here][its Cout = cin here][4][4] as stored.
+extern "C" int s2d_conv2d4x4s2_pack_weights_bf16(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream) {
+    S2D_CHECK_ARG(weight && packed, "conv2d4x4s2_pack: null argument");
+    if (!s2d_conv2d3x3_supported(cin, cout) || conv_bn(cout) != 128) {
+        set_error("conv2d4x4s2_pack: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t total = (int64_t)16 * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
+                       128, 0, 0, 16, (__bf16 *)packed);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+extern "C" int s2d_conv2d4x4s2_nhwc_bf16(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin,
+                                         int cout, void *y, s2d_stream_t stream) {
+    S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
+                  "conv2d4x4s2: bad argument");
+    if (!s2d_conv2d3x3_supported(cin, cout) || conv_bn(cout) != 128) {
+        set_error("conv2d4x4s2: unsupported channels %d -> %d", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t m = (int64_t)n_img * (h / 2) * (w / 2);
+    const int rows = conv_k32_rows(m, cout / 128);
+    hipStream_t st = (hipStream_t)stream;
+#define S2D_CONV4(MI_)                                                                                                             \
+    hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, 4, false>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / 128),       \
+                       dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \
+                       (const float *)nullptr, (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr)
+    if (rows == 128) S2D_CONV4(4); else if (rows == 96) S2D_CONV4(3); else S2D_CONV4(2);
+#undef S2D_CONV4
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -36,16 +36,22 @@ typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 typedef short s16x8w __attribute__((ext_vector_type(8)));
 
-template <int TCO, int TCI>
+// STRIDE = 2 (pad 1): the contraction of a [Ho][Wo] tensor (A) with the [H][W] = [2 Ho][2 Wo] tensor (B) it is strided over,
+//   dW[a ch][b ch][ky][kx] = sum A[n][i][j][a ch] * B[n][2 i - 1 + ky][2 j - 1 + kx][b ch]
+// = the weight gradient of ConvTranspose2d(4,2,1) (A = its input, B = dY: [Cin][Cout][4][4]) and of a stride-2 3x3 conv (A = dY,
+// B = its input: [Cout][Cin][3][3]).  The B tile holds 31 * 2 + KS pixels and the transpose reads walk it with a two-pixel row stride;
+// its rows are padded by 16 B instead of 32 so that the doubled stride still spreads eight rows over all banks.
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1>
 struct WgCfg {
     static constexpr int WCI = TCI >= 128 ? (TCO >= 128 ? 4 : 8) : 4;   // waves across ci
     static constexpr int WCO = 8 / WCI;                                 // waves across co
     static constexpr int MI = TCO / WCO / 16;                           // 16-channel co tiles per wave
     static constexpr int NJ = TCI / WCI / 16;                           // 16-channel ci tiles per wave
-    static constexpr int CPR_A = TCO / 8 + 2, CPR_B = TCI / 8 + 2;      // 16-byte chunks per pixel row (data + 32 B pad)
+    static constexpr int CPR_A = TCO / 8 + 2, CPR_B = TCI / 8 + (STRIDE == 2 ? 1 : 2);   // 16-byte chunks per pixel row (data + pad)
     static constexpr int RS_A = CPR_A * 16, RS_B = CPR_B * 16;          // row strides in bytes
     static constexpr int A_CHUNKS = (32 * CPR_A + 63) / 64 * 64;        // 32 output pixels
-    static constexpr int B_CHUNKS = (34 * CPR_B + 63) / 64 * 64;        // 34 input pixels (three kx taps)
+    static constexpr int NB = 31 * STRIDE + (KS == 1 ? 3 : KS);         // input pixels of a K-step (34 for the 3x3 and 1x1 stride-1 cases)
+    static constexpr int B_CHUNKS = (NB * CPR_B + 63) / 64 * 64;
     static constexpr int A_BYTES = A_CHUNKS * 16, B_BYTES = B_CHUNKS * 16;
     static constexpr int CHUNKS = A_CHUNKS + B_CHUNKS;
     static constexpr int NS = 4;                                        // LDS ring depth: 3 K-steps of loads in flight
@@ -76,11 +82,12 @@ __device__ __forceinline__ bf16x8w tr_pack(const i32x2w &lo, const i32x2w &hi) {
 }
 
 // KS = kernel size: 3, or 1 (the 1x1 convs: one "kernel row", one kx tap, the same transposed-operand pipeline)
-template <int TCO, int TCI, int KS = 3>
+// KXN = kx taps per workgroup (blockIdx.y = ky * (KS / KXN) + kx group): 4x4 kernels run two per workgroup to stay in registers
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                             const __bf16 *__restrict__ zero_page, int n_img, int H, int W, int cin,
                                                             int cout, int pad, int steps_per_block, float *__restrict__ partial) {
-    typedef WgCfg<TCO, TCI> C;
+    typedef WgCfg<TCO, TCI, KS, STRIDE> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto abuf = [&](int b) -> char * { return smem + b * (C::A_BYTES + C::B_BYTES); };
     const unsigned smem_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
@@ -89,22 +96,23 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wco = wid / C::WCI, wci = wid % C::WCI;
     const int g = lane >> 4, c16 = lane & 15;
-    const int Ho = H + 2 * pad - (KS - 1), Wo = W + 2 * pad - (KS - 1);
+    const int Ho = (H + 2 * pad - KS) / STRIDE + 1, Wo = (W + 2 * pad - KS) / STRIDE + 1;
     const int XC = (Wo + 31) / 32;
     const int total = n_img * Ho * XC;
-    const int ky = blockIdx.y;
+    constexpr int KXG = KS / KXN;
+    const int ky = blockIdx.y / KXG, kx0 = (blockIdx.y % KXG) * KXN;
     const int cit_n = cin / TCI;
     const int cot = blockIdx.z / cit_n, cit = blockIdx.z % cit_n;
     const int s0 = blockIdx.x * steps_per_block;
     const int s1 = min(total, s0 + steps_per_block);
 
-    f32x4w acc[C::MI][C::NJ][KS];
+    f32x4w acc[C::MI][C::NJ][KXN];
 #pragma unroll
     for (int i = 0; i < C::MI; ++i)
 #pragma unroll
         for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
-            for (int k = 0; k < KS; ++k) acc[i][j][k] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < KXN; ++k) acc[i][j][k] = f32x4w{0.f, 0.f, 0.f, 0.f};
 
     // (n, y, xc) of step s, advanced incrementally
     int sn = s0 / (Ho * XC), sy = (s0 / XC) % Ho, sxc = s0 % XC;
@@ -136,15 +144,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         } else {
             const int q = c - C::A_CHUNKS;
             const int row = q / C::CPR_B, col = q % C::CPR_B;
-            row_u[u] = (col < TCI / 8 && row < 32 + KS - 1) ? row : 0x40000000;
+            row_u[u] = (col < TCI / 8 && row < 31 * STRIDE + KS) ? row : 0x40000000;
             ptr_u[u] = x + (int64_t)row * cin + cit * TCI + col * 8;
         }
     }
     auto stage = [&](int buf) {   // stages the tiles of step (sn, sy, sxc)
         const int x0 = sxc * 32;
-        const int yin = sy + ky - pad;
+        const int yin = sy * STRIDE + ky - pad;
         const int64_t ua = (((int64_t)sn * Ho + sy) * Wo + x0) * cout;          // element offset of dY[sn][sy][x0][0]
-        const int64_t ub = (((int64_t)sn * H + yin) * W + x0 - pad) * cin;      // of X[sn][yin][x0 - pad][0]
+        const int64_t ub = (((int64_t)sn * H + yin) * W + x0 * STRIDE - pad) * cin;   // of X[sn][yin][x0 * STRIDE - pad][0]
         const unsigned lim_b = (unsigned)yin < (unsigned)H ? (unsigned)W : 0u;  // a kernel row outside the image: all zero
         char *slot = abuf(buf);
 #pragma unroll
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
             if (has_u[u]) {   // wave-uniform
                 const int64_t uo = isa_u[u] ? ua : ub;
                 const unsigned lim = isa_u[u] ? (unsigned)Wo : lim_b;
-                const unsigned xv = (unsigned)(x0 - (isa_u[u] ? 0 : pad) + row_u[u]);
+                const unsigned xv = (unsigned)((isa_u[u] ? x0 : x0 * STRIDE - pad) + row_u[u]);
                 const __bf16 *src = xv < lim ? ptr_u[u] + uo : zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(slot + (size_t)(t + 512 * u - lane) * 16), 16, 0, 0);
@@ -176,22 +184,22 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     //   issue the reads of step i+1;  MFMAs of step i.
     // A kernel row outside the image stages zero tiles (lim_b = 0), so no step is skipped.
     struct Frags {
-        i32x2w alo[C::MI], ahi[C::MI], blo[KS][C::NJ], bhi[KS][C::NJ];
+        i32x2w alo[C::MI], ahi[C::MI], blo[KXN][C::NJ], bhi[KXN][C::NJ];
     };
     const unsigned a_off = tr_row * C::RS_A + wco * C::MI * 32 + tr_col;
-    const unsigned b_off = C::A_BYTES + tr_row * C::RS_B + wci * C::NJ * 32 + tr_col;
+    const unsigned b_off = C::A_BYTES + (tr_row * STRIDE + kx0) * C::RS_B + wci * C::NJ * 32 + tr_col;
     auto read_frags = [&](int slot, Frags &f) {
         const unsigned base = smem_addr + slot * (C::A_BYTES + C::B_BYTES);
 #pragma unroll
         for (int i = 0; i < C::MI; ++i) tr_issue<16 * C::RS_A>(f.alo[i], f.ahi[i], base + a_off + i * 32);
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx)
+        for (int kx = 0; kx < KXN; ++kx)
 #pragma unroll
-            for (int j = 0; j < C::NJ; ++j) tr_issue<16 * C::RS_B>(f.blo[kx][j], f.bhi[kx][j], base + b_off + j * 32 + kx * C::RS_B);
+            for (int j = 0; j < C::NJ; ++j) tr_issue<16 * STRIDE * C::RS_B>(f.blo[kx][j], f.bhi[kx][j], base + b_off + j * 32 + kx * C::RS_B);
     };
     auto mfmas = [&](const Frags &f) {
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx)
+        for (int kx = 0; kx < KXN; ++kx)
 #pragma unroll
             for (int j = 0; j < C::NJ; ++j) {
                 const bf16x8w xf = tr_pack(f.blo[kx][j], f.bhi[kx][j]);
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         }
         // step i+1 landed (in every wave after the barrier); the two younger steps stay in flight
         if (more) {
-            if (nl == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            if (nl == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (nl == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else if (nl == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         } else {
@@ -248,10 +257,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     static_assert(8 * EP_BYTES <= (int)C::LDS, "epilogue tiles exceed the ring");
     __syncthreads();   // every wave is out of the K loop
     char *ep = smem + wid * EP_BYTES;
-    float *dst = partial + ((int64_t)blockIdx.x * (KS * KS) + ky * KS) * (int64_t)cout * cin;
+    float *dst = partial + ((int64_t)blockIdx.x * (KS * KS) + ky * KS + kx0) * (int64_t)cout * cin;
     const int co0 = cot * TCO + wco * C::MI * 16, ci0 = cit * TCI + wci * C::NJ * 16;
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
+    for (int kx = 0; kx < KXN; ++kx) {
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
 #pragma unroll
@@ -310,11 +319,11 @@ struct WgPlan {
     size_t ws_bytes;
 };
 static bool wg_supported(int cin, int cout) { return cin % 64 == 0 && cout % 64 == 0 && cin >= 64 && cout >= 64; }
-static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int ks = 3) {
+static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int ks = 3, int stride = 1, int kxg = 1) {
     WgPlan p;
     p.tco = cout % 128 == 0 ? 128 : 64;
     p.tci = cin % 128 == 0 ? 128 : 64;
-    const int ho = h + 2 * pad - (ks - 1), wo = w + 2 * pad - (ks - 1);
+    const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
     const int64_t total = (int64_t)n_img * ho * ((wo + 31) / 32);
     const int tiles = (cout / p.tco) * (cin / p.tci);
     // one 8-wave workgroup per CU (203 VGPRs: a second one does not fit), and never more workgroups than CUs: 258
@@ -326,7 +335,7 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int k
             n = 256;
         cus = n;
     }
-    int64_t splits = cus / (ks * tiles);
+    int64_t splits = cus / (ks * kxg * tiles);
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.steps_per_block = (int)ceil_div(total, splits);
@@ -335,17 +344,17 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int k
     return p;
 }
 
-template <int TCO, int TCI, int KS = 3>
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
 static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
                      int cout, int pad, float *partial, hipStream_t st) {
-    typedef WgCfg<TCO, TCI> C;
-    auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS>;
+    typedef WgCfg<TCO, TCI, KS, STRIDE> C;
+    auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS, STRIDE, KXN>;
     static bool attr_set = false;   // once per instantiation (idempotent if raced)
     if (C::LDS > 48 * 1024 && !attr_set) {
         S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr_set = true;
     }
-    const dim3 grid(p.splits, KS, (cout / TCO) * (cin / TCI));
+    const dim3 grid(p.splits, KS * (KS / KXN), (cout / TCO) * (cin / TCI));
     hipLaunchKernelGGL(kern, grid, dim3(512), C::LDS, st, x, dy, zero_page, n_img, h, w, cin, cout, pad, p.steps_per_block, partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -421,6 +430,42 @@ extern "C" int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, cons
     const int64_t total = (int64_t)cin * cout;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
                        p.splits, cin, cout, 1, dweight);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* Stride-2 (pad 1) contraction, ks = 3 or 4 (see WgCfg):  dW[a ch][b ch][ky][kx] = sum a[n][i][j][a ch] * b[n][2 i - 1 + ky][2 j - 1 + kx][b ch]
+   with a = [n][h/2][w/2][ca] and b = [n][h][w][cb]: ConvTranspose2d(4,2,1) weight gradient (a = input, b = dY; rpn.py:217-231) and
+   the stride-2 3x3 conv's (a = dY, b = input; rpn.py:126-133). */
+extern "C" int s2d_conv2d_s2_wgrad_supported(int ca, int cb, int ks) { return wg_supported(cb, ca) && ca % 128 == 0 && cb % 128 == 0 && (ks == 3 || ks == 4); }
+
+extern "C" size_t s2d_conv2d_s2_wgrad_workspace_bytes(int n_img, int h, int w, int ca, int cb, int ks) {
+    if (!s2d_conv2d_s2_wgrad_supported(ca, cb, ks) || n_img <= 0 || h < 2 || w < 2 || h % 2 || w % 2) return 0;
+    return wg_plan(n_img, h, w, cb, ca, 1, ks, 2, ks == 4 ? 2 : 1).ws_bytes;
+}
+
+extern "C" int s2d_conv2d_s2_wgrad_nhwc_bf16(const void *a, const void *b, const void *zero_page, int n_img, int h, int w, int ca, int cb,
+                                             int ks, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(a && b && zero_page && dweight && n_img > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "conv2d_s2_wgrad: bad argument");
+    if (!s2d_conv2d_s2_wgrad_supported(ca, cb, ks)) {
+        set_error("conv2d_s2_wgrad: unsupported channels %d x %d, kernel %d", ca, cb, ks);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const WgPlan p = wg_plan(n_img, h, w, cb, ca, 1, ks, 2, ks == 4 ? 2 : 1);
+    if (!ws || ws_bytes < p.ws_bytes) {
+        set_error("conv2d_s2_wgrad: workspace too small (%zu < %zu)", ws_bytes, p.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *bp = (const __bf16 *)b, *ap = (const __bf16 *)a, *zp = (const __bf16 *)zero_page;
+    float *partial = (float *)ws;
+    // kernel roles: "x" = the strided-over tensor b (cin = cb), "dy" = a (cout = ca)
+    const int rc = ks == 4 ? wg_launch<128, 128, 4, 2, 2>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st)
+                           : wg_launch<128, 128, 3, 2, 3>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st);
+    if (rc) return rc;
+    const int64_t total = (int64_t)ks * ks * ca * cb;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
+                       p.splits, cb, ca, ks * ks, dweight);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

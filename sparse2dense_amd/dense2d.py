@@ -202,7 +202,14 @@ class _Conv3x3Fn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         dyb = _nhwc_bf16(dy)
         dx = dw = db = None
-        if stride != 1:   # the strided layer (one per RPN block): forward on the kernel above, both gradients through MIOpen
+        if stride == 2 and _s2_backward_ok(xb, dyb, cin, cout, pad):
+            # the strided layer (one per RPN block): data gradient = the transposed form split into its four output parity classes
+            # (1 + 2 + 2 + 4 dense taps), weight gradient = the stride-2 contraction (csrc/conv2d_nhwc.hip, conv2d_wgrad.hip)
+            if ctx.needs_input_grad[0]:
+                dx = conv_up(dyb, weight, None, 3)
+            if ctx.needs_input_grad[1]:
+                dw = conv_s2_wgrad(dyb, xb, 3).to(weight.dtype)
+        elif stride != 1:   # shapes the kernels above do not take: both gradients through MIOpen
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dx, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [stride, stride], [pad, pad], [1, 1], False,
                                                              [0, 0], 1, [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
@@ -839,6 +846,139 @@ class ConvT2x2S2(nn.ConvTranspose2d):
         return super().forward(x, output_size)
 
 
+# --------------------------------------------------------------------------------------------------
+# stride-2 transposed forms: ConvTranspose2d(4,2,1) (decoder_1 / decoder_2 of the S2D module, rpn.py:217-231) and the backward of the
+# stride-2 3x3 convs (rpn.py:126-133) on the tile kernels (csrc/conv2d_nhwc.hip "UP" mode, conv2d_wgrad.hip STRIDE = 2)
+# --------------------------------------------------------------------------------------------------
+def _s2_backward_ok(xb, dyb, cin, cout, pad):
+    lib = _lib.load()
+    return bool(pad == 1 and xb.shape[2] == 2 * dyb.shape[2] and xb.shape[3] == 2 * dyb.shape[3]
+                and lib.s2d_convup_supported(cout, cin, 3) and lib.s2d_conv2d_s2_wgrad_supported(cout, cin, 3))
+
+
+def conv_up(x, weight, bias, ks, bn_stats=False):
+    """x bf16 NHWC [n, kc, h, w], weight fp32 [kc, nc, ks, ks] -> bf16 NHWC [n, nc, 2h, 2w]: ks = 4 the forward of ConvTranspose2d(4,2,1),
+    ks = 3 the data gradient of a stride-2 / pad-1 3x3 conv (x = dY, weight = the conv's [cout, cin, 3, 3])."""
+    lib = _lib.load()
+    kc, nc = weight.shape[0], weight.shape[1]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == kc and weight.shape[2] == ks
+    n, _, h, w = x.shape
+
+    def build():
+        packed = torch.empty(ks * ks * kc * nc, dtype=torch.bfloat16, device=weight.device)
+        check(lib.s2d_convup_pack_weights_bf16(_ptr(weight.detach().float().contiguous()), kc, nc, ks, _ptr(packed), _stream()),
+              "s2d_convup_pack_weights_bf16")
+        return packed
+    packed = cached_pack(weight, ("convup", ks), build)
+    y = torch.empty((n, nc, 2 * h, 2 * w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    partial = (torch.empty((lib.s2d_convup_stats_tiles(n, h, w, kc, nc, ks), 2, nc), dtype=torch.float32, device=x.device)
+               if bn_stats else None)
+    from . import hip_ops as H
+    rec = None
+    if H.PROFILE is not None:
+        rec = dict(kernel="conv_up_nhwc_bf16", tag="dense", cin=kc, cout=nc, n_out=4 * n * h * w, kvol=ks * ks / 4.0, pairs=None, dense=True,
+                   in_pixels=n * h * w, pad=1, stride=2, tile_rows=0, start=torch.cuda.Event(enable_timing=True),
+                   end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
+    check(lib.s2d_convup_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, kc, nc, ks, _ptr(y), _ptr(partial),
+                                   _stream()), "s2d_convup_nhwc_bf16")
+    if rec is not None:
+        rec["end"].record()
+        H.PROFILE.append(rec)
+    return (y, partial) if bn_stats else y
+
+
+def conv4x4s2(x, weight):
+    """x bf16 NHWC [n, cin, h, w], weight fp32 [cout, cin, 4, 4] -> bf16 NHWC [n, cout, h/2, w/2] (stride 2, pad 1): the data gradient of
+    ConvTranspose2d(cout -> cin, 4, 2, 1), whose stored weight [its Cin, its Cout, 4, 4] is exactly that array."""
+    lib = _lib.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
+    n, _, h, w = x.shape
+
+    def build():
+        packed = torch.empty(16 * cin * cout, dtype=torch.bfloat16, device=weight.device)
+        check(lib.s2d_conv2d4x4s2_pack_weights_bf16(_ptr(weight.detach().float().contiguous()), cin, cout, _ptr(packed), _stream()),
+              "s2d_conv2d4x4s2_pack_weights_bf16")
+        return packed
+    packed = cached_pack(weight, ("conv4x4s2",), build)
+    y = torch.empty((n, cout, h // 2, w // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib.s2d_conv2d4x4s2_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y), _stream()),
+          "s2d_conv2d4x4s2_nhwc_bf16")
+    return y
+
+
+def conv_s2_wgrad(a, b, ks):
+    """a bf16 NHWC [n, ca, h/2, w/2], b bf16 NHWC [n, cb, h, w] -> fp32 [ca, cb, ks, ks] = sum a[i, j] * b[2i - 1 + ky, 2j - 1 + kx]"""
+    lib = _lib.load()
+    n, ca = a.shape[0], a.shape[1]
+    cb, h, w = b.shape[1], b.shape[2], b.shape[3]
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[2] * 2 == h and a.shape[3] * 2 == w
+    assert a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous(memory_format=torch.channels_last)
+    dw = torch.empty((ca, cb, ks, ks), dtype=torch.float32, device=a.device)
+    ws = _ws(lib.s2d_conv2d_s2_wgrad_workspace_bytes(n, h, w, ca, cb, ks), a.device)
+    check(lib.s2d_conv2d_s2_wgrad_nhwc_bf16(_ptr(a), _ptr(b), _ptr(_zero_page(a.device)), n, h, w, ca, cb, ks, _ptr(dw), _ptr(ws), ws.numel(),
+                                            _stream()), "s2d_conv2d_s2_wgrad_nhwc_bf16")
+    return dw
+
+
+class _ConvT4x4S2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_stats):
+        xb = _nhwc_bf16(x)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias = bias is not None
+        b = None if bias is None else bias.detach().float().contiguous()
+        if bn_stats:
+            y, partial = conv_up(xb, weight, b, 4, bn_stats=True)
+            ctx.mark_non_differentiable(partial)
+            ctx.set_materialize_grads(False)
+            return y, partial
+        return conv_up(xb, weight, b, 4)
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        xb, weight = ctx.saved_tensors
+        dyb = _nhwc_bf16(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv4x4s2(dyb, weight)
+        if ctx.needs_input_grad[1]:
+            dw = conv_s2_wgrad(xb, dyb, 4).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sums(dyb)
+        return dx, dw, db, None
+
+
+class ConvT4x4S2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(cin, cout, 4, 2, 1) (same parameters / state_dict keys): decoder_1 / decoder_2 of the S2D module
+    (/root/reference/det3d/models/necks/rpn.py:217-231).  CUDA inputs under bf16 autocast with channel counts that are multiples of 128:
+    forward = four parity-class 2x2 convs in one launch (with the batch-norm statistics of a following FastBatchNorm2d), data
+    gradient = a 4x4 stride-2 conv, weight gradient = the stride-2 contraction; anything else is the stock layer."""
+
+    emit_bn_stats = False
+
+    def _hip_ok(self, x):
+        if not (ENABLED and x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                and self.kernel_size == (4, 4) and self.stride == (2, 2) and self.padding == (1, 1) and self.output_padding == (0, 0)
+                and self.dilation == (1, 1) and self.groups == 1):
+            return False
+        lib = _lib.load()
+        cin, cout = self.in_channels, self.out_channels
+        return bool(lib.s2d_convup_supported(cin, cout, 4) and lib.s2d_conv2d_s2_wgrad_supported(cin, cout, 4)
+                    and lib.s2d_conv2d3x3_supported(cout, cin) and cin % 128 == 0)
+
+    def forward(self, x, output_size=None):
+        if output_size is None and self._hip_ok(x):
+            if self.emit_bn_stats and self.training and torch.is_grad_enabled():
+                y, partial = _ConvT4x4S2Fn.apply(x, self.weight, self.bias, True)
+                y._s2d_bn_partial = partial
+                return y
+            return _ConvT4x4S2Fn.apply(x, self.weight, self.bias, False)
+        return super().forward(x, output_size)
+
+
 def fuse_bn_relu(layers):
     """[.., FastBatchNorm2d, nn.ReLU, ..] -> [.., FastBatchNorm2d(fused_relu), nn.Identity, ..]: same indices (state_dict
     keys of the reference checkpoints), one kernel instead of two."""
@@ -850,7 +990,7 @@ def fuse_bn_relu(layers):
         if isinstance(layers[i], FastBatchNorm2d) and isinstance(layers[i + 1], nn.GELU) and layers[i + 1].approximate == "none":
             layers[i].fused_relu = 2   # activation code 2: exact GELU behind the normalisation (csrc/features.hip)
             layers[i + 1] = nn.Identity()
-        if isinstance(layers[i], (Conv3x3, Conv1x1, Conv2x2S2)) and isinstance(layers[i + 1], FastBatchNorm2d):
+        if isinstance(layers[i], (Conv3x3, Conv1x1, Conv2x2S2, ConvT4x4S2)) and isinstance(layers[i + 1], FastBatchNorm2d):
             layers[i].emit_bn_stats = True   # the conv epilogue produces the batch-norm statistics partials
         if type(layers[i]) is nn.ZeroPad2d and tuple(layers[i].padding) == (1, 1, 1, 1) and isinstance(layers[i + 1], Conv3x3) \
                 and layers[i + 1].padding == (0, 0) and layers[i + 1].kernel_size == (3, 3):

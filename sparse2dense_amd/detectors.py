@@ -46,9 +46,9 @@ class SingleStageDetector(nn.Module):
         if self.neck is not None:
             mods += list(self.neck.modules())
             self.neck.trunk_channels_last = True
-        from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, SmallConv3x3
+        from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, SmallConv3x3
         from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
-        own = (Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, SmallConv3x3)
+        own = (Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, SmallConv3x3)
         for mod in mods:
             # NHWC weights only where the library convs read them: our kernels pack either order, and a contiguous parameter gets its
             # (contiguous) gradient handed over as is - an NHWC one makes the autograd engine re-lay every weight gradient (a copy

@@ -7,8 +7,8 @@ Module names / Sequential indices are the reference's, so state_dicts are interc
 (`blocks.0.1.weight` — index 0 is the ZeroPad2d; `encoder_1.0.weight`; `generator_2.3.weight` ...).
 Under bf16 autocast on NHWC inputs the layers run on the hand-written kernels behind `dense2d` / `dense3d`
 (3x3, 1x1 and the 2x2-stride-2 convs, the ConvTranspose2d(2,2) deblock, depth-wise 7x7, batch norms with the ReLU / GELU fused, the
-whole-map LayerNorm, the PCR head with its fused levels); layers without a kernel of ours (ConvTranspose2d(4,2,1), the backward of
-the stride-2 3x3 convs), fp32 runs and CPU inputs take the stock torch layer (DESIGN.md section 5 says what that costs).
+whole-map LayerNorm, the PCR head with its fused levels, ConvTranspose2d(4,2,1) and the backward of the stride-2 3x3 convs as
+parity-class convs); fp32 runs and CPU inputs take the stock torch layer.
 """
 import numpy as np
 import torch
@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import build_norm_layer
-from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
 from .heads import pcr_level, pcr_level_norm, pcr_level_supported
 from .registry import NECKS
@@ -168,8 +168,8 @@ class S2D_RPN(RPN):
         self.convnext_block_1 = _convnext(256, 47)
         self.convnext_block_2 = _convnext(256, 47)
         self.convnext_block_3 = _convnext(256, 47)
-        self.decoder_1 = _cbg((nn.ConvTranspose2d(256, 256, 4, 2, 1), 256))
-        self.decoder_2 = _cbg((Conv3x3(512, 256, 3, 1, 1), 256), (nn.ConvTranspose2d(256, c, 4, 2, 1), c))
+        self.decoder_1 = _cbg((ConvT4x4S2(256, 256, 4, 2, 1), 256))
+        self.decoder_2 = _cbg((Conv3x3(512, 256, 3, 1, 1), 256), (ConvT4x4S2(256, c, 4, 2, 1), c))
         self.fusion_sparse = _cbg((Conv1x1(c, c, 1, 1, 0), c))
         self.fusion_dense = _cbg((Conv1x1(c, c, 1, 1, 0), c))
         self.out_conv = _cbg((Conv1x1(c, 640, 1, 1, 0), 640))

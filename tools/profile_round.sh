@@ -1,4 +1,5 @@
 R=$GRAFT_REPO_ROOT
+T=${TAG:-r03_final}
 cd $R
 O=gpurun_out/round
 mkdir -p $O
@@ -11,8 +12,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cp
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras --no-roofline > $R/$O/pmc_f.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras --no-roofline > $R/$O/pmc_w.log 2>&1 < /dev/null
 cd $R
-python tools/prof_summary.py /tmp/prof_s2d 5 > $O/r02_final_s2d_student_b4_step_summary.txt 2>&1
-python tools/prof_summary.py /tmp/prof_cp 1 > $O/r02_final_centerpoint_b4_step_summary.txt 2>&1
-cp $(find /tmp/prof_s2d -name "*kernel_stats.csv" | head -1) $O/r02_final_s2d_student_b4_kernel_stats.csv
-cp $(find /tmp/prof_cp -name "*kernel_stats.csv" | head -1) $O/r02_final_centerpoint_b4_kernel_stats.csv
-python tools/pmc_summary.py $O/r02_pmc_traffic.json /tmp/pmc_f /tmp/pmc_w > $O/r02_pmc_per_kernel.txt 2>&1
+python tools/prof_summary.py /tmp/prof_s2d 5 > $O/${T}_s2d_student_b4_step_summary.txt 2>&1
+python tools/prof_summary.py /tmp/prof_cp 1 > $O/${T}_centerpoint_b4_step_summary.txt 2>&1
+cp $(find /tmp/prof_s2d -name "*kernel_stats.csv" | head -1) $O/${T}_s2d_student_b4_kernel_stats.csv
+cp $(find /tmp/prof_cp -name "*kernel_stats.csv" | head -1) $O/${T}_centerpoint_b4_kernel_stats.csv
+python tools/pmc_summary.py $O/${T}_pmc_traffic.json /tmp/pmc_f /tmp/pmc_w > $O/${T}_pmc_per_kernel.txt 2>&1
