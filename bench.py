@@ -225,15 +225,15 @@ def roofline_pass(step, n_steps=3):
             continue
         ms = max(r["start"].elapsed_time(r["end"]) - over * 1e-3, 1e-4)
         kname = r["kernel"]
-        if r.get("dense") and r["kvol"] == 1:   # 1x1 conv = one-tap instantiation of the tile kernel
-            kname = f"conv3x3_nhwc_bf16_kernel<{128 if r['cout'] % 128 == 0 else 64}, 2, 1>"
+        if r.get("kname"):   # 1x1 convs and the stride-2 transposed forms: the host wrapper names the instantiation it launched
+            kname = r["kname"]
         elif r.get("dense"):   # mirror of the dispatch in csrc/conv2d_nhwc.hip (which device function serves this launch)
             if r["cout"] % 128 == 0:
-                kname = f"conv3x3_k32_nhwc_bf16_kernel<128, {r.get('tile_rows', 128) // 32}>"
+                kname = f"conv3x3_k32_nhwc_bf16_kernel<128, {r.get('tile_rows', 128) // 32}, 3, false>"
             elif r.get("pad") == 1 and r.get("stride") == 1 and r["cin"] >= 128:
                 kname = "conv3x3_p1_nhwc_bf16_kernel<64>"
             else:
-                kname = "conv3x3_k32_nhwc_bf16_kernel<64, 4>"
+                kname = "conv3x3_k32_nhwc_bf16_kernel<64, 4, 3, false>"
         key = (kname, r["cin"], r["cout"], r["n_out"], r.get("tag", ""))
         a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, tile_rows=r.get("tile_rows", 128)))
         a["ms"] += ms
@@ -366,7 +366,9 @@ def pmc_traffic(top):
     xcd = lambda tiles: -(-tiles // 8) * 8
     if top["kernel"].startswith("conv3x3_"):
         bn = 128 if top["cout"] % 128 == 0 else 64
-        want, grid = top["kernel"], xcd(-(-top["n_out"] // top.get("tile_rows", 128))) * (top["cout"] // bn) * 256
+        up = top["kernel"].endswith("true>")   # stride-2 transposed form: n_out = 4 parity classes (grid.z) of n_out / 4 rows
+        rows = top["n_out"] // 4 if up else top["n_out"]
+        want, grid = top["kernel"], xcd(-(-rows // top.get("tile_rows", 128))) * (top["cout"] // bn) * 256 * (4 if up else 1)
     elif top["kernel"] == "spconv_fwd_s16":
         bm = 128 if top["cout"] == 128 else 64
         want, grid = f"spconv_fwd_s16_kernel<{top['cin']}, {top['cout']}, {bm}>", xcd(-(-top["n_out"] // bm)) * 256

@@ -400,7 +400,7 @@ int s2d_conv2d1x1_pack_weights_bf16(const float *weight, int cin, int cout, int 
 int s2d_conv2d3x3_pack_weights_pair_bf16(const float *weight, int cin, int cout, int weight_nhwc, void *packed_fwd, void *packed_dgrad,
                                          s2d_stream_t stream);
 int s2d_conv2d1x1_pack_weights_pair_bf16(const float *weight, int cin, int cout, void *packed_fwd, void *packed_dgrad, s2d_stream_t stream);
-int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w);
+int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w, int cin, int cout);
 int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img,
                             int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);
 size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout);

@@ -105,7 +105,7 @@ SIGNATURES = {
     "s2d_conv2d3x3_pack_weights_pair_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                             ctypes.c_void_p]),
     "s2d_conv2d1x1_pack_weights_pair_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "s2d_conv2d1x1_stats_tiles": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "s2d_conv2d1x1_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 5),
     "s2d_conv2d1x1_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 5 +
                                 [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_conv2d1x1_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),

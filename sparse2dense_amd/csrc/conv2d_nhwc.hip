@@ -939,7 +939,21 @@ extern "C" int s2d_conv2d1x1_pack_weights_bf16(const float *weight, int cin, int
     return S2D_OK;
 }
 
-extern "C" int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w) { return ceil_div((int64_t)n_img * h * w, 128); }
+// 1x1 launches take the 32-deep three-slot-ring kernel with one tap (three workgroups per CU; measured r03 on the nine 1x1 shapes of
+// the S2D module: 393 us against 514 us for the 64-deep double buffer, e.g. 256 -> 256 @ 4 x 188^2 44.8 vs 61.3 us); S2D_CONV1X1=k64
+// forces the older route.  Rows per workgroup follow conv_k32_rows (128-wide column blocks only), as for the 3x3 launches.
+static bool conv1x1_use_k32(int cin) {
+    static const bool k64 = [] { const char *e = getenv("S2D_CONV1X1"); return e && e[0] == 'k' && e[1] == '6'; }();
+    return !k64 && cin >= 128;
+}
+static int conv1x1_rows(int64_t m, int cin, int cout) {
+    return conv1x1_use_k32(cin) && conv_bn(cout) == 128 ? conv_k32_rows(m, cout / 128) : 128;
+}
+
+extern "C" int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w, int cin, int cout) {
+    const int64_t m = (int64_t)n_img * h * w;
+    return ceil_div(m, conv1x1_rows(m, cin, cout));
+}
 
 extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
                                        int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream) {
@@ -953,6 +967,21 @@ extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight,
     const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
     const size_t lds = (size_t)2 * (128 * 64 * 2 + 64 * bn * 2);
     hipStream_t st = (hipStream_t)stream;
+    if (conv1x1_use_k32(cin)) {
+#define S2D_CONV1_K32(BN_, MI_)                                                                                                    \
+    hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<BN_, MI_, 1, false>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn), blk,   \
+                       3 * (size_t)(32 * MI_ * 64 + 64 * BN_), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,         \
+                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, 0, 1, (__bf16 *)y, stats_partial)
+        if (bn == 128) {
+            const int rows = conv1x1_rows(m, cin, cout);
+            if (rows == 128) S2D_CONV1_K32(128, 4); else if (rows == 96) S2D_CONV1_K32(128, 3); else S2D_CONV1_K32(128, 2);
+        } else {
+            S2D_CONV1_K32(64, 4);
+        }
+#undef S2D_CONV1_K32
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
 #define S2D_CONV1_LAUNCH(BN_)                                                                                             \
     do {                                                                                                                  \
         auto kern = conv3x3_nhwc_bf16_kernel<BN_, 2, 1>;                                                                  \

@@ -299,13 +299,18 @@ def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
     n, _, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    partial = torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w), 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
+    partial = torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w, cin, cout), 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
     from . import hip_ops as H
     rec = None
-    if H.PROFILE is not None:   # bench.py roofline pass (the 1x1 instantiation of the tile kernel: conv3x3_nhwc_bf16_kernel<BN, 2, 1>)
+    if H.PROFILE is not None:   # bench.py roofline pass (the one-tap instantiation of the 32-deep tile kernel, or the 64-deep one)
+        tiles = lib.s2d_conv2d1x1_stats_tiles(n, h, w, cin, cout)
+        rows = next(bm for bm in (128, 96, 64) if -(-n * h * w // bm) == tiles)
+        bn = 128 if cout % 128 == 0 else 64
+        k32 = cin >= 128 and _os.environ.get("S2D_CONV1X1", "")[:2] != "k6"
         rec = dict(kernel="conv1x1_nhwc_bf16", tag="dense1x1", cin=cin, cout=cout, n_out=n * h * w, kvol=1, pairs=None, dense=True,
-                   in_pixels=n * h * w, pad=0, stride=1, tile_rows=64, start=torch.cuda.Event(enable_timing=True),
-                   end=torch.cuda.Event(enable_timing=True))
+                   in_pixels=n * h * w, pad=0, stride=1, tile_rows=rows,
+                   kname=(f"conv3x3_k32_nhwc_bf16_kernel<{bn}, {rows // 32}, 1, false>" if k32 else f"conv3x3_nhwc_bf16_kernel<{bn}, 2, 1>"),
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     check(lib.s2d_conv2d1x1_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y),
                                       _ptr(partial), _stream()), "s2d_conv2d1x1_nhwc_bf16")
@@ -876,9 +881,11 @@ def conv_up(x, weight, bias, ks, bn_stats=False):
     from . import hip_ops as H
     rec = None
     if H.PROFILE is not None:
-        rec = dict(kernel="conv_up_nhwc_bf16", tag="dense", cin=kc, cout=nc, n_out=4 * n * h * w, kvol=ks * ks / 4.0, pairs=None, dense=True,
-                   in_pixels=n * h * w, pad=1, stride=2, tile_rows=0, start=torch.cuda.Event(enable_timing=True),
-                   end=torch.cuda.Event(enable_timing=True))
+        tiles = lib.s2d_convup_stats_tiles(n, h, w, kc, nc, ks) // 4
+        rows = next(bm for bm in (128, 96, 64) if -(-n * h * w // bm) == tiles)
+        rec = dict(kernel="conv_up_nhwc_bf16", tag="dense_up", cin=kc, cout=nc, n_out=4 * n * h * w, kvol=ks * ks / 4.0, pairs=None, dense=True,
+                   in_pixels=n * h * w, pad=1, stride=2, tile_rows=rows, kname=f"conv3x3_k32_nhwc_bf16_kernel<128, {rows // 32}, {ks}, true>",
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     check(lib.s2d_convup_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, kc, nc, ks, _ptr(y), _ptr(partial),
                                    _stream()), "s2d_convup_nhwc_bf16")
