@@ -164,6 +164,7 @@ class OneCycleAdam:
                     ent[k] = v
             new_state[p] = ent
         self.state = new_state
+        self._hip_cache = None   # moments were re-created: the cached pointer tables are stale
         g = groups[0]
         self.lr, (self.mom, self.beta), self.eps = g["lr"], tuple(g["betas"]), g["eps"]
         self.wd = sd.get("wd", self.wd)
@@ -204,48 +205,68 @@ class OneCycleAdam:
         from . import _lib
         from .dense2d import _stream
         lib = _lib.load()
-        dense = lambda t: t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
-        assert all(p.dtype == torch.float32 and dense(p) for p in ps), "OneCycleAdam: dense fp32 parameters expected"
+        # Everything that only depends on the parameter set (layout checks, element counts, the pointer tables of parameters and
+        # moments, the launch chunks) is built once and reused while the same parameters, in the same order, receive gradients: the
+        # per-step host work in front of the first launch was ~0.9 ms of an otherwise idle device (rocprofv3 gaps, r03).
+        ids = tuple(map(id, ps)) + (ps[0].data_ptr(), ps[-1].data_ptr())   # (+ a cheap guard against re-seated parameter storage)
+        c = self._hip_cache if getattr(self, "_hip_cache", None) is not None and self._hip_cache["ids"] == ids else None
+        cap = lib.s2d_adam_max_tensors()
+        vp = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
+        if c is None:
+            dense = lambda t: t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+            assert all(p.dtype == torch.float32 and dense(p) for p in ps), "OneCycleAdam: dense fp32 parameters expected"
+            states = [self._state(p) for p in ps]
+            numel = [p.numel() for p in ps]
+            c = dict(ids=ids, states=states, numel=numel, numel_all=(ctypes.c_int64 * len(ps))(*numel),
+                     moments=[(st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for st in states], groups=None, group_steps=None,
+                     norm_chunks=[(i, min(i + cap, len(ps)), (ctypes.c_int64 * (min(i + cap, len(ps)) - i))(*numel[i:i + cap]))
+                                  for i in range(0, len(ps), cap)])
+            c["ws_floats"] = lib.s2d_grad_norm_workspace_floats(len(ps), c["numel_all"])
+            self._hip_cache = c
+        states = c["states"]
         # the kernel pairs elements by storage offset: gradients (and moments, created with preserve_format) must share the
         # parameter's strides - NHWC conv weights (detector.use_channels_last) get their gradient re-laid once here
         # (strides of size-1 dimensions carry no layout: a 1x1 conv weight is the same memory in NCHW and NHWC)
-        same = lambda g, p: all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
+        same = lambda g, p: g.stride() == p.stride() or all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
         grads = [p.grad if (p.grad.dtype == torch.float32 and same(p.grad, p)) else torch.empty_like(p).copy_(p.grad) for p in ps]
-        states = [self._state(p) for p in ps]
+        gptr = [g.data_ptr() for g in grads]
         # bias correction is a scalar per launch: parameters are grouped by their own step counter (torch.optim.Adam keeps one per
         # parameter; a branch that starts receiving gradients later - a toggled PCR head, an unfrozen layer - has a younger one)
+        steps = []
         for st in states:
             st["step"] += 1
-        by_step = {}
-        for k, st in enumerate(states):
-            by_step.setdefault(st["step"], []).append(k)
+            steps.append(st["step"])
+        if c["group_steps"] is None or any(s != t + 1 for s, t in zip(steps, c["group_steps"])):   # first use, or counters set from outside
+            by_step = {}
+            for k, s_ in enumerate(steps):
+                by_step.setdefault(s_, []).append(k)
+            groups = []
+            for members in by_step.values():
+                for i in range(0, len(members), cap):
+                    ks = members[i:i + cap]
+                    groups.append(dict(ks=ks, n=len(ks), p=vp([ps[k].data_ptr() for k in ks]), m=vp([c["moments"][k][0] for k in ks]),
+                                       v=vp([c["moments"][k][1] for k in ks]), numel=(ctypes.c_int64 * len(ks))(*[c["numel"][k] for k in ks])))
+            c["groups"] = groups
+        c["group_steps"] = steps
         dev, stream = ps[0].device, _stream()
-        cap = lib.s2d_adam_max_tensors()
-        vp = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        numel_all = (ctypes.c_int64 * len(ps))(*[p.numel() for p in ps])
         clip = None
         if not math.isinf(max_norm):
-            ws = torch.empty(lib.s2d_grad_norm_workspace_floats(len(ps), numel_all), dtype=torch.float32, device=dev)
+            ws = torch.empty(c["ws_floats"], dtype=torch.float32, device=dev)
             written = 0
-            for i in range(0, len(ps), cap):
-                chunk = grads[i:i + cap]
+            for lo, hi, numel_chunk in c["norm_chunks"]:
                 w = ctypes.c_int(0)
-                _lib.check(lib.s2d_grad_sumsq_f32(len(chunk), vp(chunk), (ctypes.c_int64 * len(chunk))(*[g.numel() for g in chunk]),
-                                                  ws.data_ptr() + 4 * written, ctypes.byref(w), stream), "s2d_grad_sumsq_f32")
+                _lib.check(lib.s2d_grad_sumsq_f32(hi - lo, vp(gptr[lo:hi]), numel_chunk, ws.data_ptr() + 4 * written, ctypes.byref(w), stream),
+                           "s2d_grad_sumsq_f32")
                 written += w.value
             clip = torch.empty(2, dtype=torch.float32, device=dev)
             _lib.check(lib.s2d_grad_norm_finalize_f32(ws.data_ptr(), written, float(max_norm), clip.data_ptr(), stream),
                        "s2d_grad_norm_finalize_f32")
         self._clip = clip
-        for step, members in by_step.items():
-            for i in range(0, len(members), cap):
-                ks = members[i:i + cap]
-                n = len(ks)
-                _lib.check(lib.s2d_adam_step_f32(n, vp([ps[k] for k in ks]), vp([grads[k] for k in ks]), vp([states[k]["exp_avg"] for k in ks]),
-                                                 vp([states[k]["exp_avg_sq"] for k in ks]),
-                                                 (ctypes.c_int64 * n)(*[ps[k].numel() for k in ks]), float(self.lr), float(self.mom),
-                                                 float(self.beta), float(self.eps), float(self.wd), int(step),
-                                                 None if clip is None else clip.data_ptr() + 4, stream), "s2d_adam_step_f32")
+        for g in c["groups"]:
+            ks = g["ks"]
+            _lib.check(lib.s2d_adam_step_f32(g["n"], g["p"], vp([gptr[k] for k in ks]), g["m"], g["v"], g["numel"], float(self.lr), float(self.mom),
+                                             float(self.beta), float(self.eps), float(self.wd), int(steps[ks[0]]),
+                                             None if clip is None else clip.data_ptr() + 4, stream), "s2d_adam_step_f32")
         # the kernel updated the parameters through raw pointers: their autograd version counters did not move, so drop the
         # packed weight images keyed on them (they are rebuilt at the next forward, as after any optimizer step)
         from .dense2d import clear_pack_cache
