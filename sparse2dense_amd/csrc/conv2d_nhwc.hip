@@ -834,7 +834,7 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
 // [n][2h][2w][nc]; ks = 4: ConvTranspose2d(4,2,1) forward from its weight [kc][nc][4][4]; ks = 3: data gradient of
 // Conv2d(nc -> kc, 3, stride 2, pad 1) on a [2h][2w] input from its weight [kc][nc][3][3].
 static bool convup_supported(int kc, int nc, int ks) {
-    return (ks == 3 || ks == 4) && s2d_conv2d3x3_supported(kc, nc) && conv_bn(nc) == 128 && (ks == 4 || kc >= 128);   // >= 4 sub-steps per class
+    return (ks == 3 || ks == 4) && s2d_conv2d3x3_supported(kc, nc) && (ks == 4 || kc >= 128);   // >= 4 sub-steps per class
 }
 extern "C" int s2d_convup_supported(int kc, int nc, int ks) { return convup_supported(kc, nc, ks); }
 
@@ -851,12 +851,12 @@ extern "C" int s2d_convup_pack_weights_bf16(const float *weight, int kc, int nc,
     return S2D_OK;
 }
 
-static int convup_rows(int64_t m, int col_blocks) { return conv_k32_rows(4 * m, col_blocks); }
+static int convup_rows(int64_t m, int nc) { return conv_bn(nc) == 128 ? conv_k32_rows(4 * m, nc / 128) : 128; }
 
 extern "C" int64_t s2d_convup_stats_tiles(int n_img, int h, int w, int kc, int nc, int ks) {
     if (!convup_supported(kc, nc, ks) || n_img <= 0 || h <= 0 || w <= 0) return 0;
     const int64_t m = (int64_t)n_img * h * w;
-    return 4 * ceil_div(m, convup_rows(m, nc / 128));
+    return 4 * ceil_div(m, convup_rows(m, nc));
 }
 
 extern "C" int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
@@ -867,8 +867,20 @@ extern "C" int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, co
         return S2D_ERR_UNSUPPORTED;
     }
     const int64_t m = (int64_t)n_img * h * w;
-    const int rows = convup_rows(m, nc / 128);
+    const int rows = convup_rows(m, nc);
     hipStream_t st = (hipStream_t)stream;
+    if (conv_bn(nc) == 64) {   // 64-wide column blocks (the pillar S2D module's 64-channel decoder, pillar_encoder.py:337-394)
+        if (ks == 4)
+            hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 4, true>), dim3(xcd_grid(ceil_div(m, 128)), nc / 64, 4), dim3(256),
+                               3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial);
+        else
+            hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 3, true>), dim3(xcd_grid(ceil_div(m, 128)), nc / 64, 4), dim3(256),
+                               3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
+                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
 #define S2D_CONVUP(MI_, KS_)                                                                                                       \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, KS_, true>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), nc / 128, 4),     \
                        dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \
@@ -887,13 +899,13 @@ extern "C" int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, co
 // in the forward-conv sense, i.e. the ConvTranspose2d weight [its Cin = cout here][its Cout = cin here][4][4] as stored.
 extern "C" int s2d_conv2d4x4s2_pack_weights_bf16(const float *weight, int cin, int cout, void *packed, s2d_stream_t stream) {
     S2D_CHECK_ARG(weight && packed, "conv2d4x4s2_pack: null argument");
-    if (!s2d_conv2d3x3_supported(cin, cout) || conv_bn(cout) != 128) {
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
         set_error("conv2d4x4s2_pack: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
     const int64_t total = (int64_t)16 * cin * cout;
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
-                       128, 0, 0, 16, (__bf16 *)packed);
+                       conv_bn(cout), 0, 0, 16, (__bf16 *)packed);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -902,13 +914,20 @@ extern "C" int s2d_conv2d4x4s2_nhwc_bf16(const void *x, const void *packed_weigh
                                          int cout, void *y, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
                   "conv2d4x4s2: bad argument");
-    if (!s2d_conv2d3x3_supported(cin, cout) || conv_bn(cout) != 128) {
+    if (!s2d_conv2d3x3_supported(cin, cout)) {
         set_error("conv2d4x4s2: unsupported channels %d -> %d", cin, cout);
         return S2D_ERR_UNSUPPORTED;
     }
     const int64_t m = (int64_t)n_img * (h / 2) * (w / 2);
-    const int rows = conv_k32_rows(m, cout / 128);
     hipStream_t st = (hipStream_t)stream;
+    if (conv_bn(cout) == 64) {
+        hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 4, false>), dim3(xcd_grid(ceil_div(m, 128)), cout / 64), dim3(256),
+                           3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, (const float *)nullptr,
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
+    const int rows = conv_k32_rows(m, cout / 128);
 #define S2D_CONV4(MI_)                                                                                                             \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, 4, false>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / 128),       \
                        dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \

@@ -437,7 +437,7 @@ extern "C" int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, cons
 /* Stride-2 (pad 1) contraction, ks = 3 or 4 (see WgCfg):  dW[a ch][b ch][ky][kx] = sum a[n][i][j][a ch] * b[n][2 i - 1 + ky][2 j - 1 + kx][b ch]
    with a = [n][h/2][w/2][ca] and b = [n][h][w][cb]: ConvTranspose2d(4,2,1) weight gradient (a = input, b = dY; rpn.py:217-231) and
    the stride-2 3x3 conv's (a = dY, b = input; rpn.py:126-133). */
-extern "C" int s2d_conv2d_s2_wgrad_supported(int ca, int cb, int ks) { return wg_supported(cb, ca) && ca % 128 == 0 && cb % 128 == 0 && (ks == 3 || ks == 4); }
+extern "C" int s2d_conv2d_s2_wgrad_supported(int ca, int cb, int ks) { return wg_supported(cb, ca) && (ks == 3 || ks == 4); }
 
 extern "C" size_t s2d_conv2d_s2_wgrad_workspace_bytes(int n_img, int h, int w, int ca, int cb, int ks) {
     if (!s2d_conv2d_s2_wgrad_supported(ca, cb, ks) || n_img <= 0 || h < 2 || w < 2 || h % 2 || w % 2) return 0;
@@ -460,8 +460,15 @@ extern "C" int s2d_conv2d_s2_wgrad_nhwc_bf16(const void *a, const void *b, const
     const __bf16 *bp = (const __bf16 *)b, *ap = (const __bf16 *)a, *zp = (const __bf16 *)zero_page;
     float *partial = (float *)ws;
     // kernel roles: "x" = the strided-over tensor b (cin = cb), "dy" = a (cout = ca)
-    const int rc = ks == 4 ? wg_launch<128, 128, 4, 2, 2>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st)
-                           : wg_launch<128, 128, 3, 2, 3>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st);
+    int rc;
+#define S2D_WG2(TCO_, TCI_)                                                                                      \
+    (ks == 4 ? wg_launch<TCO_, TCI_, 4, 2, 2>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st)                \
+             : wg_launch<TCO_, TCI_, 3, 2, 3>(p, bp, ap, zp, n_img, h, w, cb, ca, 1, partial, st))
+    if (p.tco == 128 && p.tci == 128) rc = S2D_WG2(128, 128);
+    else if (p.tco == 64 && p.tci == 128) rc = S2D_WG2(64, 128);
+    else if (p.tco == 128 && p.tci == 64) rc = S2D_WG2(128, 64);
+    else rc = S2D_WG2(64, 64);
+#undef S2D_WG2
     if (rc) return rc;
     const int64_t total = (int64_t)ks * ks * ca * cb;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,

@@ -884,7 +884,8 @@ def conv_up(x, weight, bias, ks, bn_stats=False):
         tiles = lib.s2d_convup_stats_tiles(n, h, w, kc, nc, ks) // 4
         rows = next(bm for bm in (128, 96, 64) if -(-n * h * w // bm) == tiles)
         rec = dict(kernel="conv_up_nhwc_bf16", tag="dense_up", cin=kc, cout=nc, n_out=4 * n * h * w, kvol=ks * ks / 4.0, pairs=None, dense=True,
-                   in_pixels=n * h * w, pad=1, stride=2, tile_rows=rows, kname=f"conv3x3_k32_nhwc_bf16_kernel<128, {rows // 32}, {ks}, true>",
+                   in_pixels=n * h * w, pad=1, stride=2, tile_rows=rows,
+                   kname=f"conv3x3_k32_nhwc_bf16_kernel<{128 if nc % 128 == 0 else 64}, {rows // 32}, {ks}, true>",
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     check(lib.s2d_convup_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, kc, nc, ks, _ptr(y), _ptr(partial),
@@ -959,7 +960,8 @@ class _ConvT4x4S2Fn(torch.autograd.Function):
 
 class ConvT4x4S2(nn.ConvTranspose2d):
     """nn.ConvTranspose2d(cin, cout, 4, 2, 1) (same parameters / state_dict keys): decoder_1 / decoder_2 of the S2D module
-    (/root/reference/det3d/models/necks/rpn.py:217-231).  CUDA inputs under bf16 autocast with channel counts that are multiples of 128:
+    (/root/reference/det3d/models/necks/rpn.py:217-231; 64 channels in the pillar S2D module, readers/pillar_encoder.py:337-394).  CUDA inputs
+    under bf16 autocast with channel counts that are multiples of 64:
     forward = four parity-class 2x2 convs in one launch (with the batch-norm statistics of a following FastBatchNorm2d), data
     gradient = a 4x4 stride-2 conv, weight gradient = the stride-2 contraction; anything else is the stock layer."""
 
@@ -974,7 +976,7 @@ class ConvT4x4S2(nn.ConvTranspose2d):
         lib = _lib.load()
         cin, cout = self.in_channels, self.out_channels
         return bool(lib.s2d_convup_supported(cin, cout, 4) and lib.s2d_conv2d_s2_wgrad_supported(cin, cout, 4)
-                    and lib.s2d_conv2d3x3_supported(cout, cin) and cin % 128 == 0)
+                    and lib.s2d_conv2d3x3_supported(cout, cin))
 
     def forward(self, x, output_size=None):
         if output_size is None and self._hip_ok(x):

@@ -46,6 +46,8 @@ class SingleStageDetector(nn.Module):
         if self.neck is not None:
             mods += list(self.neck.modules())
             self.neck.trunk_channels_last = True
+        if hasattr(self.backbone, "_module_2d"):   # pillar S2D backbone: its 2-D module is dense, same treatment as the neck
+            mods += list(self.backbone.modules())
         from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, SmallConv3x3
         from .dense3d import ConvTranspose3dK4S2, PointwiseConv3d
         own = (Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, SmallConv3x3)

@@ -19,7 +19,7 @@ from torch import nn
 
 from . import registry
 from .backbones import build_norm_layer
-from .dense2d import Conv1x1, Conv3x3, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
+from .dense2d import Conv1x1, Conv3x3, ConvT4x4S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import FastBatchNorm3d, PointwiseConv3d
 from .detectors import SingleStageDetector
 from .heads import mask_offset_loss, metric_grid
@@ -145,7 +145,7 @@ class PointPillarsScatter_S2D(nn.Module):
         self.convnext_block_3 = _convnext(256, 59)
         self.decoder_1 = nn.Sequential(*_cbg(Conv3x3(256, 128, 3, 1, 1), 128), nn.Upsample((117, 117)))
         self.decoder_2 = nn.Sequential(*_cbg(Conv3x3(128 + 128, 64, 3, 1, 1), 64),
-                                       *_cbg(nn.ConvTranspose2d(64, 64, 4, 2, 1), 64),
+                                       *_cbg(ConvT4x4S2(64, 64, 4, 2, 1), 64),
                                        *_cbg(Conv1x1(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
         self.fusion_sparse = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), num_input_features))
         self.fusion_dense = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), 64))
@@ -155,8 +155,11 @@ class PointPillarsScatter_S2D(nn.Module):
         self.gen_mask = nn.Sequential(PointwiseConv3d(16, 8, 1, 1, 0), FastBatchNorm3d(8), nn.GELU(),
                                       PointwiseConv3d(8, 1, 1, 1, 0))
 
-    def forward(self, voxel_features, coords, batch_size, input_shape):
-        canvas = _scatter_canvas(voxel_features, coords, batch_size, input_shape)
+    # set by the detector in its bf16 mode (detectors.use_channels_last / dense_dtype): the 2-D S2D module then runs like the voxel neck -
+    # NHWC bf16 activations under autocast on the tile / row kernels of dense2d - and the 1x1x1 PCR heads on the fp32 planar copy of F_S_b
+    dense_dtype = torch.float32
+
+    def _module_2d(self, canvas):
         y_1 = self.encoder_1(canvas)
         y_2 = self.encoder_2(y_1)
         att = self.convnext_block_1(y_2) + y_2
@@ -165,12 +168,30 @@ class PointPillarsScatter_S2D(nn.Module):
         y_3 = torch.cat([self.decoder_1(att), y_1], 1)
         F_S_b = self.decoder_2(y_3)
         F_S_a = self.fusion_dense(F_S_b) + self.fusion_sparse(canvas)
+        return F_S_a, F_S_b
+
+    def forward(self, voxel_features, coords, batch_size, input_shape):
+        canvas = _scatter_canvas(voxel_features, coords, batch_size, input_shape)
+        bf16 = self.dense_dtype == torch.bfloat16 and canvas.is_cuda
+        if bf16:
+            from .necks import _ToPlanarF32
+            x = canvas.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                F_S_a, F_S_b = self._module_2d(x)
+        else:
+            F_S_a, F_S_b = self._module_2d(canvas)
         gen_offset = gen_mask = None
         if self.training:
             n, c, h, w = canvas.shape
-            gen = self.generator(F_S_b.view(n, c, 1, h, w))
-            gen_mask = self.gen_mask(gen)
-            gen_offset = self.gen_out(gen)
+            if bf16:
+                with torch.autocast("cuda", enabled=False):
+                    gen = self.generator(_ToPlanarF32.apply(F_S_b).view(n, c, 1, h, w))
+                    gen_mask = self.gen_mask(gen)
+                    gen_offset = self.gen_out(gen)
+            else:
+                gen = self.generator(F_S_b.view(n, c, 1, h, w))
+                gen_mask = self.gen_mask(gen)
+                gen_offset = self.gen_out(gen)
         return F_S_a, F_S_b, gen_offset, gen_mask
 
 
@@ -207,6 +228,7 @@ class KD_PointPillars(PointPillars):
 
     def extract_feat(self, data):
         feats = self.reader(data["features"], data["num_voxels"], data["coors"])
+        self.backbone.dense_dtype = self.dense_dtype if self.dense_channels_last else torch.float32   # bf16 mode: NHWC bf16 S2D module
         F_S_a, F_S_b, gen_offset, gen_mask = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
         x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
         return x, F_S_a, F_S_b, gen_offset, gen_mask

@@ -17,7 +17,7 @@ def _rel(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 47, 47, 256, 256), (1, 9, 13, 128, 256), (1, 94, 94, 256, 128), (3, 5, 3, 128, 128)])
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 47, 47, 256, 256), (1, 9, 13, 128, 256), (1, 94, 94, 256, 128), (3, 5, 3, 128, 128), (1, 58, 58, 64, 64), (2, 7, 9, 64, 128), (1, 6, 5, 192, 64)])
 def test_convtranspose2d_k4s2_forward_and_gradients(n, h, w, cin, cout):
     from sparse2dense_amd import dense2d as D
     dev = torch.device("cuda:0")
@@ -48,7 +48,7 @@ def test_convtranspose2d_k4s2_forward_and_gradients(n, h, w, cin, cout):
     assert _rel(D.conv_s2_wgrad(xd, dyd, 4), wr.grad) <= 2e-3
 
 
-@pytest.mark.parametrize("n,ho,wo,cin,cout", [(2, 47, 47, 128, 256), (1, 7, 10, 256, 256), (1, 94, 94, 128, 128)])
+@pytest.mark.parametrize("n,ho,wo,cin,cout", [(2, 47, 47, 128, 256), (1, 7, 10, 256, 256), (1, 94, 94, 128, 128), (1, 58, 58, 64, 128), (2, 9, 6, 64, 192)])
 def test_stride2_conv3x3_backward(n, ho, wo, cin, cout):
     from sparse2dense_amd import dense2d as D
     dev = torch.device("cuda:0")
