@@ -456,6 +456,17 @@ int s2d_conv2d_s2_wgrad_nhwc_bf16(const void *a, const void *b, const void *zero
                                   float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /*
+ * Weight gradient of a bias-free Linear over a long row-major fp32 matrix (PFNLayer.linear of the pillar reader,
+ * det3d/models/readers/pillar_encoder.py:41-56; replaces the GEMM behind torch.mm in nn.Linear's backward):
+ *   dweight[co][ci] = sum_r dy[r][co] * x[r][ci];  x [rows][ci], dy [rows][co]; ci, co <= 64; exact fp32 (v_mfma_f32_16x16x4_f32),
+ *   fixed-order split reduction in ws (s2d_rows_wgrad_workspace_bytes).
+ */
+int s2d_rows_wgrad_supported(int ci, int co);
+size_t s2d_rows_wgrad_workspace_bytes(int64_t rows, int ci, int co);
+int s2d_rows_wgrad_f32(const float *x, const float *dy, int64_t rows, int ci, int co, float *dweight, void *ws, size_t ws_bytes,
+                       s2d_stream_t stream);
+
+/*
  * Depth-wise 7x7 convolution, padding 3, stride 1 (nn.Conv2d(C, C, 7, padding=3, groups=C): first layer of the three
  * ConvNeXt blocks of the S2D module, det3d/models/necks/rpn.py:204-225) on NHWC bf16 maps.  x, y [n][h][w][c] bf16;
  * weight fp32 [c][49] (the torch layout [c][1][7][7]); bias fp32 [c] or NULL; fp32 accumulation.  flip=1 mirrors the taps:

@@ -133,6 +133,10 @@ SIGNATURES = {
     "s2d_conv2d_s2_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_conv2d_s2_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 +
                                       [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_rows_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "s2d_rows_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "s2d_rows_wgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]),
     "s2d_lnwide_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_lnwide_fwd_bf16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, c_f32p,
                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -36,6 +36,42 @@ def get_paddings_indicator(actual_num, max_num, axis=0):
     return actual_num.int() > idx
 
 
+class _RowLinearFn(torch.autograd.Function):
+    """y = x @ W^T for x [rows, Cin] fp32 on the device: the forward and the data gradient are plain (fat-by-skinny) products, the
+    weight gradient - a [Cout, rows] x [rows, Cin] product with rows ~ 7e5 that the library GEMM serves at 0.8 / 1.3 ms - runs on
+    csrc/rowgemm.hip (both operands read once, exact fp32 on the matrix cores, fixed-order split reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from .dense2d import _ptr, _stream, _ws
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            rows, ci, co = x.shape[0], x.shape[1], weight.shape[0]
+            dw = torch.empty((co, ci), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.s2d_rows_wgrad_workspace_bytes(rows, ci, co), x.device)
+            _lib.check(lib.s2d_rows_wgrad_f32(_ptr(x), _ptr(dy), rows, ci, co, _ptr(dw), _ptr(ws), ws.numel(), _stream()), "s2d_rows_wgrad_f32")
+        return dx, dw
+
+
+def _row_linear(x, linear):
+    """nn.Linear(bias=False) over [P, T, Cin]; fp32 CUDA inputs with <= 64 channels take _RowLinearFn"""
+    if (x.is_cuda and x.dtype == torch.float32 and linear.bias is None and linear.weight.dtype == torch.float32
+            and linear.in_features <= 64 and linear.out_features <= 64 and x.numel() > 0 and not torch.is_autocast_enabled()):
+        p, t, c = x.shape
+        return _RowLinearFn.apply(x.reshape(p * t, c).contiguous(), linear.weight).view(p, t, linear.out_features)
+    return linear(x)
+
+
 class PFNLayer(nn.Module):
     def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
         super().__init__()
@@ -50,7 +86,7 @@ class PFNLayer(nn.Module):
 
     def forward(self, inputs):
         p, t, _ = inputs.shape
-        x = self.linear(inputs)
+        x = _row_linear(inputs, self.linear)
         if isinstance(self.norm, FeatureBatchNorm1d):
             x = self.norm(x.reshape(p * t, self.units), relu=True).view(p, t, self.units)   # fused BN + ReLU
         else:
