@@ -38,7 +38,7 @@ import torch.distributed as dist
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = ["r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
+PMC_TRAFFIC_FILES = ["r03_final_pmc_traffic.json", "r03_mid_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
 
 WORKLOAD_NAMES = {
     "centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
@@ -334,8 +334,9 @@ def stats_top_kernels():
     (profiles/rNN_*s2d_student*_step_summary.txt, tools/prof_summary.py), in table order, as template names"""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_s2d_student*_step_summary.txt")), reverse=True)
-    files = [f for f in files if "start" not in os.path.basename(f)]
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_s2d_student*_step_summary.txt")) if "start" not in os.path.basename(f)]
+    # newest round first; within a round the end-state file (rNN_final_*) before the mid-round ones
+    files.sort(key=lambda f: (os.path.basename(f)[:3], "final" in os.path.basename(f), os.path.basename(f)), reverse=True)
     if not files:
         return [], None
     names = []
