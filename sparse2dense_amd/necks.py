@@ -109,6 +109,34 @@ class RPN(nn.Module):
         return self._trunk(x, relu_between=True)  # rpn.py:156
 
 
+class _ToNhwcBf16(torch.autograd.Function):
+    """contiguous (NCHW) fp32 map -> NHWC bf16 in ONE cast+layout pass (csrc/layout.hip), gradient back to contiguous fp32 in one pass:
+    the inverse hand-over of _ToPlanarF32 (the pillar canvas entering the bf16 S2D module, readers/pillar_encoder.py:337-394)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        ctx.hip = bool(x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and c % 8 == 0 and (h * w) % 4 == 0)
+        if ctx.hip:
+            from . import _lib
+            from .dense2d import _stream
+            y = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            _lib.check(_lib.load().s2d_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h * w, y.data_ptr(), _stream()), "s2d_nchw_f32_to_nhwc_bf16")
+            return y
+        return x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = g.shape
+        if ctx.hip and g.dtype == torch.bfloat16 and g.is_contiguous(memory_format=torch.channels_last):
+            from . import _lib
+            from .dense2d import _stream
+            dx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.load().s2d_nhwc_bf16_to_nchw_f32(g.data_ptr(), n, c, h * w, dx.data_ptr(), _stream()), "s2d_nhwc_bf16_to_nchw_f32")
+            return dx
+        return g.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+
+
 class _ToPlanarF32(torch.autograd.Function):
     """NHWC bf16 map -> contiguous (NCHW) fp32 in ONE cast+layout pass, and the gradient back to NHWC bf16 in one pass: the
     layers on either side then see the layout they are written for (a plain `.float().contiguous()` left the gradient in NCHW

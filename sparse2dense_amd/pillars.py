@@ -159,6 +159,17 @@ def _cbg(conv, c):
     return fuse_bn_relu([conv, FastBatchNorm2d(c), nn.GELU()])
 
 
+class _UpsampleKeepDtype(nn.Upsample):
+    """nn.Upsample (nearest) that keeps the dtype and memory format of its input under autocast: the autocast policy promotes
+    interpolation to fp32, which turned the NHWC bf16 map of the S2D module into an fp32 one right in front of three consumers"""
+
+    def forward(self, x):
+        if x.is_cuda and torch.is_autocast_enabled():
+            with torch.autocast("cuda", enabled=False):
+                return super().forward(x)
+        return super().forward(x)
+
+
 def _convnext(c, hw):
     return nn.Sequential(DepthwiseConv7(c, c, kernel_size=7, padding=3, groups=c), WideLayerNorm([c, hw, hw], eps=1e-6),
                          Conv1x1(c, 4 * c, 1), nn.GELU(), Conv1x1(4 * c, c, 1))
@@ -179,10 +190,10 @@ class PointPillarsScatter_S2D(nn.Module):
         self.convnext_block_1 = _convnext(256, 59)
         self.convnext_block_2 = _convnext(256, 59)
         self.convnext_block_3 = _convnext(256, 59)
-        self.decoder_1 = nn.Sequential(*_cbg(Conv3x3(256, 128, 3, 1, 1), 128), nn.Upsample((117, 117)))
+        self.decoder_1 = nn.Sequential(*_cbg(Conv3x3(256, 128, 3, 1, 1), 128), _UpsampleKeepDtype((117, 117)))
         self.decoder_2 = nn.Sequential(*_cbg(Conv3x3(128 + 128, 64, 3, 1, 1), 64),
                                        *_cbg(ConvT4x4S2(64, 64, 4, 2, 1), 64),
-                                       *_cbg(Conv1x1(64, 64, 1, 1, 0), 64), nn.Upsample(scale_factor=2))
+                                       *_cbg(Conv1x1(64, 64, 1, 1, 0), 64), _UpsampleKeepDtype(scale_factor=2))
         self.fusion_sparse = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), num_input_features))
         self.fusion_dense = nn.Sequential(*_cbg(Conv1x1(64, 64, 1, 1, 0), 64))
         self.generator = nn.Sequential(PointwiseConv3d(64, 32, 1, 1, 0), FastBatchNorm3d(32), nn.GELU(),
@@ -210,8 +221,8 @@ class PointPillarsScatter_S2D(nn.Module):
         canvas = _scatter_canvas(voxel_features, coords, batch_size, input_shape)
         bf16 = self.dense_dtype == torch.bfloat16 and canvas.is_cuda
         if bf16:
-            from .necks import _ToPlanarF32
-            x = canvas.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            from .necks import _ToNhwcBf16, _ToPlanarF32
+            x = _ToNhwcBf16.apply(canvas.contiguous())
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 F_S_a, F_S_b = self._module_2d(x)
         else:
