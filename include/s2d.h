@@ -384,7 +384,8 @@ int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *pack
 int s2d_conv2d3x3_wgrad_supported(int cin, int cout);
 size_t s2d_conv2d3x3_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout, int pad);
 int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img,
-                                  int h, int w, int cin, int cout, int pad, float *dweight, void *ws,
+                                  int h, int w, int cin, int cout, int pad, float *dweight, float *dbias /* [cout] or NULL: per-channel
+                                  sums of dy = nn.Conv2d's bias gradient, accumulated by the same launch */, void *ws,
                                   size_t ws_bytes, s2d_stream_t stream);
 
 /*
@@ -405,7 +406,7 @@ int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const floa
                             int h, int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream);
 size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, int cin, int cout);
 int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin,
-                                  int cout, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+                                  int cout, float *dweight, float *dbias /* [cout] or NULL */, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /* 3x3 / padding 1 / stride 1 convolutions with 1..4 output channels: the last conv of every CenterHead branch
  * (/root/reference/det3d/models/bbox_heads/center_head.py:33-61 SepHead, Conv2d(64, classes, 3, padding=1); replaces the

@@ -110,7 +110,7 @@ SIGNATURES = {
                                 [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_conv2d1x1_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "s2d_conv2d1x1_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5 +
-                                      [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+                                      [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_smallconv3x3_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_smallconv3x3_fwd": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p] + [ctypes.c_int] * 5 + [c_f32p, ctypes.c_void_p]),
     "s2d_smallconv3x3_dgrad": (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]),
@@ -229,7 +229,7 @@ SIGNATURES = {
     "s2d_conv2d3x3_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_conv2d3x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_conv2d3x3_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 +
-                                      [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+                                      [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_k4s2p1_dgrad_f32": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

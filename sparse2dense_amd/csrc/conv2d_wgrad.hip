@@ -86,7 +86,8 @@ __device__ __forceinline__ bf16x8w tr_pack(const i32x2w &lo, const i32x2w &hi) {
 template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                             const __bf16 *__restrict__ zero_page, int n_img, int H, int W, int cin,
-                                                            int cout, int pad, int steps_per_block, float *__restrict__ partial) {
+                                                            int cout, int pad, int steps_per_block, float *__restrict__ partial,
+                                                            float *__restrict__ dbias_partial) {
     typedef WgCfg<TCO, TCI, KS, STRIDE> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto abuf = [&](int b) -> char * { return smem + b * (C::A_BYTES + C::B_BYTES); };
@@ -113,6 +114,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
             for (int k = 0; k < KXN; ++k) acc[i][j][k] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+    // Bias gradient for free (dbias_partial != NULL): the dY fragments of the workgroups of kernel row 0 / input-channel tile 0 pass
+    // every output pixel exactly once, so their first ci wave column sums them per channel (8 pixels per lane and K-step) -
+    // the separate statistics pass over dY that produced nn.Conv2d's bias gradient is gone (39 launches of ~11 us per step).
+    const bool do_db = dbias_partial != nullptr && blockIdx.y == 0 && cit == 0 && wci == 0;   // wave-uniform
+    float dbs[C::MI];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) dbs[i] = 0.f;
 
     // (n, y, xc) of step s, advanced incrementally
     int sn = s0 / (Ho * XC), sy = (s0 / XC) % Ho, sxc = s0 % XC;
@@ -198,6 +207,14 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
             for (int j = 0; j < C::NJ; ++j) tr_issue<16 * STRIDE * C::RS_B>(f.blo[kx][j], f.bhi[kx][j], base + b_off + j * 32 + kx * C::RS_B);
     };
     auto mfmas = [&](const Frags &f) {
+        if (do_db) {
+#pragma unroll
+            for (int i = 0; i < C::MI; ++i) {
+                const bf16x8w a = tr_pack(f.alo[i], f.ahi[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dbs[i] += (float)a[e];
+            }
+        }
 #pragma unroll
         for (int kx = 0; kx < KXN; ++kx)
 #pragma unroll
@@ -255,6 +272,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
     constexpr int EP_ROWB = C::NJ * 64 + 16;              // padded LDS row (bytes)
     constexpr int EP_BYTES = C::MI * 16 * EP_ROWB;
     static_assert(8 * EP_BYTES <= (int)C::LDS, "epilogue tiles exceed the ring");
+    if (do_db) {   // lane (g, c16) holds channel c16 of co tile i over the pixels of its group: fold the four groups
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i) {
+            float v = dbs[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) dbias_partial[(int64_t)blockIdx.x * cout + cot * TCO + wco * C::MI * 16 + i * 16 + c16] = v;
+        }
+    }
     __syncthreads();   // every wave is out of the K loop
     char *ep = smem + wid * EP_BYTES;
     float *dst = partial + ((int64_t)blockIdx.x * (KS * KS) + ky * KS + kx0) * (int64_t)cout * cin;
@@ -282,9 +308,21 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
 // A workgroup owns 64 float4 columns of the [tap][co][ci] plane; 4 thread rows stride over the splits (more loads in
 // flight than one thread per element walking all splits), fixed-order fold through LDS.  cin % 4 == 0.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float4 *__restrict__ partial, int splits, int cin, int cout,
-                                                                   int taps, float *__restrict__ dw) {
+                                                                   int taps, float *__restrict__ dw, int main_blocks = 0x7fffffff,
+                                                                   const float *__restrict__ dbias_partial = nullptr,
+                                                                   float *__restrict__ dbias = nullptr) {
     __shared__ float4 red[4][64];
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= main_blocks) {   // trailing blocks: the bias gradient, dbias[co] = sum over splits of dbias_partial[split][co]
+        const int co = ((int)blockIdx.x - main_blocks) * 64 + col;
+        float s = 0.f;
+        if (co < cout)
+            for (int k = sl; k < splits; k += 4) s += dbias_partial[(int64_t)k * cout + co];
+        red[sl][col].x = s;
+        __syncthreads();
+        if (sl == 0 && co < cout) dbias[co] = (red[0][col].x + red[1][col].x) + (red[2][col].x + red[3][col].x);
+        return;
+    }
     const int64_t plane = (int64_t)cout * cin;          // floats per tap
     const int64_t size4 = taps * plane / 4;
     const int64_t i4 = (int64_t)blockIdx.x * 64 + col;  // float4 index over [tap][co][ci]
@@ -340,13 +378,13 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int k
     if (splits < 1) splits = 1;
     p.steps_per_block = (int)ceil_div(total, splits);
     p.splits = (int)ceil_div(total, p.steps_per_block);
-    p.ws_bytes = (size_t)p.splits * ks * ks * cout * cin * sizeof(float);
+    p.ws_bytes = (size_t)p.splits * ks * ks * cout * cin * sizeof(float) + (size_t)p.splits * cout * sizeof(float);   // + bias-gradient rows
     return p;
 }
 
 template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
 static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
-                     int cout, int pad, float *partial, hipStream_t st) {
+                     int cout, int pad, float *partial, hipStream_t st, float *dbias_partial = nullptr) {
     typedef WgCfg<TCO, TCI, KS, STRIDE> C;
     auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS, STRIDE, KXN>;
     static bool attr_set = false;   // once per instantiation (idempotent if raced)
@@ -355,7 +393,8 @@ static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const _
         attr_set = true;
     }
     const dim3 grid(p.splits, KS * (KS / KXN), (cout / TCO) * (cin / TCI));
-    hipLaunchKernelGGL(kern, grid, dim3(512), C::LDS, st, x, dy, zero_page, n_img, h, w, cin, cout, pad, p.steps_per_block, partial);
+    hipLaunchKernelGGL(kern, grid, dim3(512), C::LDS, st, x, dy, zero_page, n_img, h, w, cin, cout, pad, p.steps_per_block, partial,
+                       dbias_partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -372,7 +411,7 @@ extern "C" size_t s2d_conv2d3x3_wgrad_workspace_bytes(int n_img, int h, int w, i
 }
 
 extern "C" int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin,
-                                             int cout, int pad, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+                                             int cout, int pad, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && dy && zero_page && dweight && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1), "conv2d3x3_wgrad: bad argument");
     if (!wg_supported(cin, cout)) {
         set_error("conv2d3x3_wgrad: unsupported channels %d -> %d", cin, cout);
@@ -387,15 +426,17 @@ extern "C" int s2d_conv2d3x3_wgrad_nhwc_bf16(const void *x, const void *dy, cons
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *xp = (const __bf16 *)x, *dp = (const __bf16 *)dy, *zp = (const __bf16 *)zero_page;
     float *partial = (float *)ws;
+    float *dbp = dbias ? partial + (size_t)p.splits * 9 * cout * cin : nullptr;   // [splits][cout] behind the weight slabs
     int rc;
-    if (p.tco == 128 && p.tci == 128) rc = wg_launch<128, 128>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st);
-    else if (p.tco == 64 && p.tci == 128) rc = wg_launch<64, 128>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st);
-    else if (p.tco == 128 && p.tci == 64) rc = wg_launch<128, 64>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st);
-    else rc = wg_launch<64, 64>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st);
+    if (p.tco == 128 && p.tci == 128) rc = wg_launch<128, 128>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st, dbp);
+    else if (p.tco == 64 && p.tci == 128) rc = wg_launch<64, 128>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st, dbp);
+    else if (p.tco == 128 && p.tci == 64) rc = wg_launch<128, 64>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st, dbp);
+    else rc = wg_launch<64, 64>(p, xp, dp, zp, n_img, h, w, cin, cout, pad, partial, st, dbp);
     if (rc) return rc;
     const int64_t total = (int64_t)9 * cin * cout;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
-                       p.splits, cin, cout, 9, dweight);
+    const unsigned main_blocks = (unsigned)ceil_div(total / 4, 64);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(main_blocks + (dbias ? (unsigned)ceil_div(cout, 64) : 0u)), dim3(256), 0, st,
+                       (const float4 *)partial, p.splits, cin, cout, 9, dweight, (int)main_blocks, (const float *)dbp, dbias);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -407,7 +448,7 @@ extern "C" size_t s2d_conv2d1x1_wgrad_workspace_bytes(int n_img, int h, int w, i
 }
 
 extern "C" int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, const void *zero_page, int n_img, int h, int w, int cin, int cout,
-                                             float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+                                             float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && dy && zero_page && dweight && n_img > 0 && h > 0 && w > 0, "conv2d1x1_wgrad: bad argument");
     if (!wg_supported(cin, cout)) {
         set_error("conv2d1x1_wgrad: unsupported channels %d -> %d", cin, cout);
@@ -421,15 +462,17 @@ extern "C" int s2d_conv2d1x1_wgrad_nhwc_bf16(const void *x, const void *dy, cons
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *xp = (const __bf16 *)x, *dp = (const __bf16 *)dy, *zp = (const __bf16 *)zero_page;
     float *partial = (float *)ws;
+    float *dbp = dbias ? partial + (size_t)p.splits * cout * cin : nullptr;
     int rc;
-    if (p.tco == 128 && p.tci == 128) rc = wg_launch<128, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
-    else if (p.tco == 64 && p.tci == 128) rc = wg_launch<64, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
-    else if (p.tco == 128 && p.tci == 64) rc = wg_launch<128, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
-    else rc = wg_launch<64, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st);
+    if (p.tco == 128 && p.tci == 128) rc = wg_launch<128, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st, dbp);
+    else if (p.tco == 64 && p.tci == 128) rc = wg_launch<64, 128, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st, dbp);
+    else if (p.tco == 128 && p.tci == 64) rc = wg_launch<128, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st, dbp);
+    else rc = wg_launch<64, 64, 1>(p, xp, dp, zp, n_img, h, w, cin, cout, 0, partial, st, dbp);
     if (rc) return rc;
     const int64_t total = (int64_t)cin * cout;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total / 4, 64)), dim3(256), 0, st, (const float4 *)partial,
-                       p.splits, cin, cout, 1, dweight);
+    const unsigned main_blocks = (unsigned)ceil_div(total / 4, 64);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(main_blocks + (dbias ? (unsigned)ceil_div(cout, 64) : 0u)), dim3(256), 0, st,
+                       (const float4 *)partial, p.splits, cin, cout, 1, dweight, (int)main_blocks, (const float *)dbp, dbias);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

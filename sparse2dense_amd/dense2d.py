@@ -159,8 +159,9 @@ def _wgrad_hip(cin, cout):
     return bool(WGRAD_HIP)
 
 
-def conv3x3_wgrad(x, dy, pad):
-    """x bf16 NHWC [N,cin,H,W] (forward input), dy bf16 NHWC [N,cout,Ho,Wo] -> fp32 [cout,cin,3,3]"""
+def conv3x3_wgrad(x, dy, pad, want_db=False):
+    """x bf16 NHWC [N,cin,H,W] (forward input), dy bf16 NHWC [N,cout,Ho,Wo] -> fp32 [cout,cin,3,3]; want_db: also the per-channel sums
+    of dy (the bias gradient), accumulated by the same launch -> (dw, db)"""
     lib = _lib.load()
     n, cin, h, w = x.shape
     cout = dy.shape[1]
@@ -168,10 +169,11 @@ def conv3x3_wgrad(x, dy, pad):
     assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
     assert dy.shape[2] == h + 2 * pad - 2 and dy.shape[3] == w + 2 * pad - 2
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
     ws = _ws(lib.s2d_conv2d3x3_wgrad_workspace_bytes(n, h, w, cin, cout, pad), x.device)
-    check(lib.s2d_conv2d3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(_zero_page(x.device)), n, h, w, cin, cout, pad, _ptr(dw), _ptr(ws),
+    check(lib.s2d_conv2d3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(_zero_page(x.device)), n, h, w, cin, cout, pad, _ptr(dw), _ptr(db), _ptr(ws),
                                             ws.numel(), _stream()), "s2d_conv2d3x3_wgrad_nhwc_bf16")
-    return dw
+    return (dw, db) if want_db else dw
 
 
 def _nhwc_bf16(t):
@@ -224,13 +226,17 @@ class _Conv3x3Fn(torch.autograd.Function):
                     src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
                 dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
             if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):
-                dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
+                if ctx.has_bias and ctx.needs_input_grad[2]:   # the bias gradient rides on the weight-gradient launch
+                    dw, db = conv3x3_wgrad(xb, dyb, pad, want_db=True)
+                    dw = dw.to(weight.dtype)
+                else:
+                    dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
             elif ctx.needs_input_grad[1]:
                 wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
                                                                 [False, True, False])
                 dw = dwb.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:   # per-channel sum of dY: the row-reduce kernel's first output half
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:   # per-channel sum of dY: the row-reduce kernel's first output half
             lib = _lib.load()
             rows = dyb.shape[0] * dyb.shape[2] * dyb.shape[3]
             stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
@@ -355,7 +361,7 @@ def _wgrad_1x1(xb, dyb, cin, cout):
     n, _, h, w = xb.shape
     dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
     ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
-    check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(ws),
+    check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), None, _ptr(ws),
                                             ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
     return dwf
 
@@ -397,11 +403,13 @@ class _Conv1x1Fn(torch.autograd.Function):
             dx = conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin)
         if ctx.needs_input_grad[1]:
             dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
+            if ctx.has_bias and ctx.needs_input_grad[2]:   # the bias gradient rides on the weight-gradient launch
+                db = torch.empty((cout,), dtype=torch.float32, device=xb.device)
             ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
-            check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(ws),
-                                                    ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
+            check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(db),
+                                                    _ptr(ws), ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
             dw = dwf.reshape(weight.shape).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:   # per-channel sum of dY: the row-reduce kernel's first output half
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:   # per-channel sum of dY: the row-reduce kernel's first output half
             rows = n * h * w
             stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
             ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)

@@ -91,3 +91,26 @@ def test_modules_take_the_kernels_and_match_the_stock_layers():
         assert _rel(m.weight.grad, wr.grad) <= 2e-3
         if br is not None:
             assert _rel(m.bias.grad, br.grad) <= 2e-3
+
+
+@pytest.mark.parametrize("kind,cin,cout,shape", [("3x3", 128, 128, (2, 37, 41)), ("3x3", 64, 192, (1, 20, 33)), ("1x1", 256, 128, (2, 47, 47)),
+                                                  ("1x1", 1024, 256, (1, 13, 9))])
+def test_bias_gradient_rides_on_the_weight_gradient_launch(kind, cin, cout, shape):
+    """nn.Conv2d bias gradient = per-channel sums of dY, accumulated by the weight-gradient kernel's first kernel-row / input-channel
+    workgroups (csrc/conv2d_wgrad.hip do_db) instead of a separate pass over dY: against float64 sums of the same bf16-rounded dY"""
+    from sparse2dense_amd import dense2d as D
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cin + cout)
+    m = (D.Conv3x3(cin, cout, 3, 1, 1) if kind == "3x3" else D.Conv1x1(cin, cout, 1)).to(dev)
+    n, h, w = shape
+    x = torch.randn(n, cin, h, w, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    dy = torch.randn_like(y) + 0.25
+    y.backward(dy)
+    ref_db = dy.double().sum((0, 2, 3))
+    assert _rel(m.bias.grad, ref_db) <= 1e-5
+    wr = m.weight.detach().to(torch.bfloat16).double().cpu().requires_grad_(True)
+    xr = x.detach().double().cpu()
+    F.conv2d(xr, wr, None, padding=1 if kind == "3x3" else 0).backward(dy.double().cpu())
+    assert _rel(m.weight.grad, wr.grad) <= 2e-3
