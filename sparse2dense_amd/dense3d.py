@@ -100,8 +100,11 @@ def _convt_packed(weight):
         lib = _lib.load()
         cin, cout = weight.shape[0], weight.shape[1]
         packed = torch.empty(lib.s2d_convt3d_mfma_packed_elems(cin, cout), dtype=torch.bfloat16, device=weight.device)
-        check(lib.s2d_convt3d_mfma_pack_weights(_ptr(weight.detach().float().contiguous()), cin, cout, _ptr(packed), _stream()),
-              "s2d_convt3d_mfma_pack_weights")
+        wsrc = weight.detach().float().contiguous()
+        launch = lambda: check(lib.s2d_convt3d_mfma_pack_weights(_ptr(wsrc), cin, cout, _ptr(packed), _stream()), "s2d_convt3d_mfma_pack_weights")
+        launch()
+        from .dense2d import register_repack
+        register_repack(weight, [("convt3d_mfma",)], wsrc, launch)
         return packed
     return cached_pack(weight, ("convt3d_mfma",), build)
 

@@ -267,10 +267,10 @@ class OneCycleAdam:
             _lib.check(lib.s2d_adam_step_f32(g["n"], g["p"], vp([gptr[k] for k in ks]), g["m"], g["v"], g["numel"], float(self.lr), float(self.mom),
                                              float(self.beta), float(self.eps), float(self.wd), int(steps[ks[0]]),
                                              None if clip is None else clip.data_ptr() + 4, stream), "s2d_adam_step_f32")
-        # the kernel updated the parameters through raw pointers: their autograd version counters did not move, so drop the
-        # packed weight images keyed on them (they are rebuilt at the next forward, as after any optimizer step)
-        from .dense2d import clear_pack_cache
-        clear_pack_cache()
+        # the kernel updated the parameters through raw pointers: their autograd version counters did not move, so the packed weight
+        # images keyed on them are rebuilt here (one HIP graph of the registered pack launches) or dropped (dense2d.refresh_pack_cache)
+        from .dense2d import refresh_pack_cache
+        refresh_pack_cache()
         return None if clip is None else clip[0]
 
 
