@@ -72,3 +72,37 @@ def test_frozen_parameters_keep_their_images_and_stale_ones_are_dropped(monkeypa
     D.clear_pack_cache()
     assert torch.equal(D.pack_weights(b.weight).float(), pb.float() * 2)
     D.clear_pack_cache()
+
+
+def test_eval_batchnorm_affine_cache_of_frozen_layers_tracks_its_inputs():
+    """dense2d._BNRowFn caches [mean, invstd, scale, shift] of an eval-mode batch norm whose affine parameters are frozen (the
+    distillation teacher): the cache must follow load_state_dict / copy_ (version counters) and training-mode statistics updates made
+    through raw pointers (_s2d_stats_epoch), and must not be used for trainable layers"""
+    from sparse2dense_amd import dense2d as D
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    bn = D.FastBatchNorm2d(64).to(dev)
+    x = torch.randn(2, 64, 5, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def ref():
+        return torch.nn.functional.batch_norm(x.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+
+    def check():
+        y = bn(x)
+        assert float((y.float() - ref()).abs().max()) <= 2e-2 * float(ref().abs().max())
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-1, 1); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2.0)
+    bn.eval()
+    check()                                   # trainable: never cached
+    assert getattr(bn, "_s2d_eval_fin", None) is None
+    for p in bn.parameters():
+        p.requires_grad = False
+    check(); check()
+    assert bn._s2d_eval_fin is not None
+    with torch.no_grad():
+        bn.running_mean.add_(0.7)             # version bump
+    check()
+    bn.load_state_dict({k: v * 1.25 if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    check()
+    bn.train(); bn(x); bn.eval()              # running statistics moved by the finalize kernel (raw pointers)
+    check()
