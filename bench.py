@@ -64,8 +64,10 @@ def parse():
     p.add_argument("--cpu-points", type=int, default=150000)
     p.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--beam-jitter", type=float, default=None, help="scene.make_scene(beam_jitter=...); default scene.WAYMO_BEAM_JITTER")
-    p.add_argument("--prefetch", action="store_true", help="build example k+1 (voxelization, targets, rulebooks) on a second stream from "
-                   "a loader thread while step k runs (data.PrefetchLoader); default: inside the step on the main stream")
+    p.add_argument("--prefetch", action="store_true", help=argparse.SUPPRESS)   # (the default since r03; kept for old command lines)
+    p.add_argument("--no-prefetch", action="store_true", help="build every example inside its step on the main stream.  Default: the "
+                   "data pipeline is overlapped as in the reference (DataLoader workers): example k+1 - device voxelization, targets, "
+                   "rulebooks and their row-count reads - is built on a second stream by a loader thread while step k runs")
     p.add_argument("--torch-profile", action="store_true", help="after the timed region: torch.profiler table of 2 steps "
                    "(ops with input shapes -> stderr); diagnostic only")
     p.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
@@ -148,10 +150,13 @@ def setup_workload(args, workload, dev, rank):
     else:
         frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
                                  distill=(workload != "centerpoint"), device=dev, beam_jitter=jitter)
-    if args.prefetch and dev.type == "cuda" and not workload.startswith("pillar"):
+    raw_frames = frames
+    if not args.no_prefetch and (args.batch >= 2 or args.prefetch) and dev.type == "cuda" and not workload.startswith("pillar"):
         # data pipeline overlapped with the step (the reference's DataLoader workers): example k+1 - voxelization, targets, rulebooks -
-        # is built on a second stream by a worker thread while step k runs.  Off by default: measured neutral at B=4 (the step is
-        # device-bound and the launch queue refills right after the row-count reads) and a loss at B=1 (the worker competes for the GIL).
+        # is built on a second stream by a worker thread while step k runs; every timed step still builds exactly one example.
+        # r02 (27 ms steps): neutral at B=4.  r03, same box, B=4: S2D student 25.6 -> 24.5 ms, CenterPoint 12.9 -> 11.3, distillation
+        # 32.9 -> 29.1 - the main stream no longer drains at the five row-count reads of a step.  At one frame per GPU the step is
+        # host-bound and the loader thread competes for the GIL (73 -> 54 frames/s): the default there stays in-step (--prefetch forces it).
         from sparse2dense_amd.data import PrefetchLoader
         frames = PrefetchLoader(frames, backbone=getattr(model, "module", model).backbone)
     optimizer = scheduler = None
@@ -161,7 +166,10 @@ def setup_workload(args, workload, dev, rank):
         optimizer = build_one_cycle_optimizer(model, dict(wd=0.01))
         scheduler = build_one_cycle_scheduler(optimizer, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0,
                                                                pct_start=0.4), total_steps=36 * 1000)
-    return model, teacher, frames, make_step(workload, model, teacher, frames, optimizer, scheduler)
+    step = make_step(workload, model, teacher, frames, optimizer, scheduler)
+    # the same step with the example built inside it (roofline pass: per-launch events without a concurrent loader stream)
+    step.sync_step = make_step(workload, model, teacher, raw_frames, optimizer, scheduler) if frames is not raw_frames else step
+    return model, teacher, frames, step
 
 
 def timed(step, steps, warmup, world, dev):
@@ -554,10 +562,14 @@ def main():
               file=sys.stderr)
 
     single = rank == 0 and world == 1
+    prefetching = hasattr(frames, "close")
+    if prefetching:   # loader thread of the timed run: done (the passes below build their examples inside the step)
+        frames.close()
+        frames = frames.frames
     stats = scene_stats(model, frames) if rank == 0 else {}
     roof, rows, rulebook, sparse_gemm = (None, [], None, None)
     if single and not args.no_roofline:
-        roof, rows, rulebook, sparse_gemm = roofline_pass(step)
+        roof, rows, rulebook, sparse_gemm = roofline_pass(step.sync_step)
     loss_value = round(float(loss.item()), 4)
 
     others = {}
@@ -579,6 +591,8 @@ def main():
                 m2, t2, f2, st2 = setup_workload(a2, wl, dev, rank)
                 k = max(5, min(args.steps, 10))
                 el, _ = timed(st2, k, 3, 1, dev)
+                if hasattr(f2, "close"):
+                    f2.close()
                 others[name] = dict(workload=WORKLOAD_NAMES[wl], value=round(args.batch * k / el, 3), unit="frames/s",
                                     ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=3, frames_per_gpu=args.batch,
                                     dtype=f"dense {a2.dense_dtype}, sparse {a2.sparse_dtype}")
@@ -609,6 +623,9 @@ def main():
                        "parallelism": f"dp{world}",
                        "gradient_allreduce": (dp.dp_mode() if (world > 1 or os.environ.get("S2D_FORCE_DDP") == "1") else "none"),
                        "step": "device voxelize + fwd + loss + bwd + clip" + ("" if args.no_optim else " + Adam/OneCycle (true weight decay)"),
+                       "data_pipeline": ("overlapped as in the reference's DataLoader workers: example k+1 (device voxelization, targets, rulebooks) is "
+                                         "built on a second HIP stream by a loader thread while step k runs; one example per timed step"
+                                         if prefetching else "example built inside its step on the main stream"),
                        "loss": loss_value, "scene": stats},
             "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "cpu_baseline": base,
         }

@@ -217,7 +217,7 @@ class OneCycleAdam:
             assert all(p.dtype == torch.float32 and dense(p) for p in ps), "OneCycleAdam: dense fp32 parameters expected"
             states = [self._state(p) for p in ps]
             numel = [p.numel() for p in ps]
-            c = dict(ids=ids, states=states, numel=numel, numel_all=(ctypes.c_int64 * len(ps))(*numel),
+            c = dict(ids=ids, states=states, numel=numel, numel_all=(ctypes.c_int64 * len(ps))(*numel), strides=[p.stride() for p in ps],
                      moments=[(st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for st in states], groups=None, group_steps=None,
                      norm_chunks=[(i, min(i + cap, len(ps)), (ctypes.c_int64 * (min(i + cap, len(ps)) - i))(*numel[i:i + cap]))
                                   for i in range(0, len(ps), cap)])
@@ -227,9 +227,15 @@ class OneCycleAdam:
         # the kernel pairs elements by storage offset: gradients (and moments, created with preserve_format) must share the
         # parameter's strides - NHWC conv weights (detector.use_channels_last) get their gradient re-laid once here
         # (strides of size-1 dimensions carry no layout: a 1x1 conv weight is the same memory in NCHW and NHWC)
-        same = lambda g, p: g.stride() == p.stride() or all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
-        grads = [p.grad if (p.grad.dtype == torch.float32 and same(p.grad, p)) else torch.empty_like(p).copy_(p.grad) for p in ps]
-        gptr = [g.data_ptr() for g in grads]
+        same = lambda g, p: all(sg == sp for sg, sp, n in zip(g.stride(), p.stride(), p.shape) if n > 1)
+        f32, pstrides = torch.float32, c["strides"]
+        grads, gptr = [], []
+        for i, p in enumerate(ps):   # (one .grad access and one stride tuple per parameter: this loop is ~0.1 ms of idle device per step)
+            g = p.grad
+            if g.dtype is not f32 or (g.stride() != pstrides[i] and not same(g, p)):
+                g = torch.empty_like(p).copy_(g)
+            grads.append(g)
+            gptr.append(g.data_ptr())
         # bias correction is a scalar per launch: parameters are grouped by their own step counter (torch.optim.Adam keeps one per
         # parameter; a branch that starts receiving gradients later - a toggled PCR head, an unfrozen layer - has a younger one)
         steps = []
