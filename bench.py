@@ -151,14 +151,14 @@ def setup_workload(args, workload, dev, rank):
         frames = SyntheticFrames(args.batch, n_points=args.points, seed=20240928 + 1000 * rank,
                                  distill=(workload != "centerpoint"), device=dev, beam_jitter=jitter)
     raw_frames = frames
-    if not args.no_prefetch and (args.batch >= 2 or args.prefetch) and dev.type == "cuda" and not workload.startswith("pillar"):
+    if not args.no_prefetch and (args.batch >= 2 or args.prefetch) and dev.type == "cuda":
         # data pipeline overlapped with the step (the reference's DataLoader workers): example k+1 - voxelization, targets, rulebooks -
         # is built on a second stream by a worker thread while step k runs; every timed step still builds exactly one example.
         # r02 (27 ms steps): neutral at B=4.  r03, same box, B=4: S2D student 25.6 -> 24.5 ms, CenterPoint 12.9 -> 11.3, distillation
         # 32.9 -> 29.1 - the main stream no longer drains at the five row-count reads of a step.  At one frame per GPU the step is
         # host-bound and the loader thread competes for the GIL (73 -> 54 frames/s): the default there stays in-step (--prefetch forces it).
         from sparse2dense_amd.data import PrefetchLoader
-        frames = PrefetchLoader(frames, backbone=getattr(model, "module", model).backbone)
+        frames = PrefetchLoader(frames, backbone=None if workload.startswith("pillar") else getattr(model, "module", model).backbone)
     optimizer = scheduler = None
     if not args.no_optim:
         # apis/train.py:168-186 + configs `lr_config`: fastai Adam (betas (mom, 0.99), true weight decay 0.01) under OneCycle
