@@ -17,6 +17,7 @@
 //   convt3d_wgrad_kernel      LDS-staged rows contracted on the fp32 matrix cores (see below).
 // The 1x1x1 weight gradients are plain GEMMs over the position axis (hipBLASLt via torch.matmul).
 #include "s2d_common.h"
+#include <cstdlib>
 
 namespace s2d {
 
@@ -51,6 +52,38 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(const float *__restrict__ 
 #pragma unroll
     for (int c = 0; c < CO; ++c)
         if (co0 + c < cout) dst[(int64_t)(co0 + c) * p4] = acc[c];
+}
+
+// 32 output channels per thread on position PAIRS (float2): one pass over the input for the PCR head's 128 -> 32 conv, four instead of
+// eight for its 32 -> 128 data gradient, at 64 accumulator registers (the float4 variant with 32 channels drops to one wave per SIMD)
+__global__ __launch_bounds__(256) void pw_conv32_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, int64_t p2, int cin, int cout,
+                                                        float *__restrict__ out) {
+    constexpr int CO = 32;
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p2) return;
+    const int co0 = blockIdx.y * CO;
+    const int n = blockIdx.z;
+    const float2 *src = reinterpret_cast<const float2 *>(in) + (int64_t)n * cin * p2 + q;
+    float2 acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        const float b = bias ? bias[co0 + c] : 0.f;
+        acc[c] = float2{b, b};
+    }
+#pragma unroll 4
+    for (int ci = 0; ci < cin; ++ci) {
+        const float2 x = src[(int64_t)ci * p2];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float wv = w[(int64_t)(co0 + c) * cin + ci];  // wave-uniform -> s_load
+            acc[c].x = fmaf(wv, x.x, acc[c].x);
+            acc[c].y = fmaf(wv, x.y, acc[c].y);
+        }
+    }
+    float2 *dst = reinterpret_cast<float2 *>(out) + (int64_t)n * cout * p2 + q;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) dst[(int64_t)(co0 + c) * p2] = acc[c];
 }
 
 // scalar-position variant for P not divisible by 4
@@ -331,8 +364,14 @@ extern "C" int s2d_pointwise_conv_f32(const float *in, const float *weight, cons
         return S2D_OK;
     }
     const int64_t p4 = positions / 4;
-    // (32 output channels per thread - one pass over the input for the PCR head's 128 -> 32 conv instead of two - was measured r03:
-    // 256 VGPRs, one wave per SIMD, 466 us against 191 us with two passes of 16)
+    static const bool use32 = [] { const char *e = getenv("S2D_PW32"); return !(e && e[0] == '0'); }();
+    if (use32 && cout % 32 == 0 && cin >= 32) {   // (32 channels on float4 positions: 256 VGPRs, one wave per SIMD, 466 us vs 191 us)
+        const int64_t p2 = positions / 2;
+        hipLaunchKernelGGL(pw_conv32_kernel, dim3((unsigned)ceil_div(p2, 256), (unsigned)(cout / 32), batch), dim3(256), 0, st, in, weight, bias,
+                           p2, cin, cout, out);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     const int t = pick_tile(cout);
     const dim3 grid((unsigned)ceil_div(p4, 256), (unsigned)ceil_div(cout, t), batch), blk(256);
 #define S2D_PW(T) hipLaunchKernelGGL(pw_conv_kernel<T>, grid, blk, 0, st, in, weight, bias, p4, cin, cout, out)
