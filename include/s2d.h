@@ -619,8 +619,9 @@ int s2d_pcr_heads_bwd_f32(const float *g, const float *head_params, const int32_
 size_t s2d_pcr_level_workspace_bytes(int c);
 int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2,
                           const float *b2, const int32_t *coors, const float *feats, int64_t m, int batch, int c,
-                          int co, int d, int h, int w, float *z, float *out8, void *ws, size_t ws_bytes,
-                          s2d_stream_t stream);
+                          int co, int d, int h, int w, float *z, float *z_stats /* [2 co] sum | sumsq of z per channel (the
+                          statistics of the BatchNorm3d behind the 1x1x1 conv; c = 32, co = 16 only), or NULL */, float *out8,
+                          void *ws, size_t ws_bytes, s2d_stream_t stream);
 int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_shift, const float *head_params,
                                const int32_t *coors, const float *feats, int64_t m, int batch, int c, int d, int h,
                                int w, const float *fwd_out8, const float *go_mask, const float *go_offset,

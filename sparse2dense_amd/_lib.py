@@ -165,7 +165,7 @@ SIGNATURES = {
                               [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_level_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_pcr_level_fwd_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 6 +
-                              [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+                              [c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_level_bwd_sums_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
                                    [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
                                     ctypes.c_void_p]),

@@ -674,7 +674,8 @@ __device__ __forceinline__ void pcr_load_norm(const float *__restrict__ bnp, Pcr
 template <int C, int CO, int V>
 __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *__restrict__ y, const float *__restrict__ bnp, const float *__restrict__ hp,
                                                                   const float *__restrict__ w2, const float *__restrict__ b2, int64_t cells, int batch,
-                                                                  float *__restrict__ z, float *__restrict__ partial) {
+                                                                  float *__restrict__ z, float *__restrict__ partial,
+                                                                  float *__restrict__ zstat_partial) {
     __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
     __shared__ float b2s[CO > 0 ? CO : 1];
     __shared__ PcrHeadW<C> hw;
@@ -691,6 +692,11 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *_
     const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;
     const float *scv = nm.sc + lane_zero, *shv = nm.sh + lane_zero, *w2v = w2s + lane_zero;
     float acc[1] = {0.f};
+    // zstat_partial (block-uniform, CO > 0): per-channel (sum, sum of squares) of the z this kernel writes = the statistics pass of the
+    // BatchNorm3d that follows the 1x1x1 conv (generator_2[1], rpn.py:263-296) - one 362 MB read less per step
+    float zs[CO > 0 ? 2 * CO : 1];
+#pragma unroll
+    for (int q = 0; q < (CO > 0 ? 2 * CO : 1); ++q) zs[q] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
     const unsigned plane = (unsigned)cells * 4u;
     for (int b = 0; b < batch; ++b) {
@@ -734,10 +740,33 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *_
             if (CO > 0) {
 #pragma unroll
                 for (int q = 0; q < CO; ++q) buf_store<V>(zr, voff, q * plane, za[q]);
+                if (zstat_partial) {
+#pragma unroll
+                    for (int q = 0; q < CO; ++q)
+#pragma unroll
+                        for (int k = 0; k < V; ++k) {
+                            zs[q] += za[q][k];
+                            zs[CO + q] = fmaf(za[q][k], za[q][k], zs[CO + q]);
+                        }
+                }
             }
         }
     }
     block_sums<1>(acc, partial);
+    if (CO > 0 && zstat_partial) {
+        __syncthreads();   // block_sums' LDS rows are reused
+        block_sums<(CO > 0 ? 2 * CO : 1)>(zs, zstat_partial);
+    }
+}
+
+// zstats[k] = sum over the nd blocks of zstat_partial[block][k] (fixed order)
+__global__ __launch_bounds__(64) void pcr_zstats_fold_kernel(const float *__restrict__ partial, int nd, int k, float *__restrict__ out) {
+    const int col = blockIdx.x;
+    double v = 0;
+    for (int i = threadIdx.x; i < nd; i += 64) v += partial[(int64_t)i * k + col];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) out[col] = (float)v;
 }
 
 // the site's raw values, post-norm values, logit and offsets
@@ -1024,12 +1053,15 @@ __global__ __launch_bounds__(256) void pcr_level_fold_kernel(const float *__rest
 
 template <int C, int CO, int V>
 static int pcr_level_fwd_t(const float *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
-                           int64_t m, PcrGeo geo, float *z, float *out8, float *ws, hipStream_t st) {
+                           int64_t m, PcrGeo geo, float *z, float *out8, float *ws, hipStream_t st, float *z_stats = nullptr) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
     float *dense_partial = ws, *sparse_partial = ws + PCRH_DENSE_BLOCKS;
+    float *zstat_partial = (CO > 0 && z_stats) ? ws + PCRH_DENSE_BLOCKS + (size_t)PCRH_SPARSE_BLOCKS * 5 : nullptr;   // [nd][2 CO] behind the sparse rows
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial);
+    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
+                       zstat_partial);
+    if (zstat_partial) hipLaunchKernelGGL(pcr_zstats_fold_kernel, dim3(2 * CO), dim3(64), 0, st, (const float *)zstat_partial, nd, 2 * CO, z_stats);
     hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
     hipLaunchKernelGGL(pcr_finalize_kernel, dim3(1), dim3(64), 0, st, dense_partial, nd, sparse_partial, ns, (double)n, out8);
     S2D_LAUNCH_CHECK();
@@ -1072,14 +1104,18 @@ static int pcr_level_bwd_apply_t(const float *y, const float *bnp, const float *
 }  // namespace s2d
 
 extern "C" size_t s2d_pcr_level_workspace_bytes(int c) {
-    return ((size_t)PCRH_DENSE_BLOCKS * (3 * c + 1) + (size_t)PCRH_SPARSE_BLOCKS * (6 * c + 4)) * sizeof(float) + 512;
+    // (the forward pass uses [dense blocks][1] + [sparse blocks][5] + [dense blocks][2 co <= 32]: inside the backward passes' size for c >= 3... made explicit)
+    const size_t bwd = (size_t)PCRH_DENSE_BLOCKS * (3 * c + 1) + (size_t)PCRH_SPARSE_BLOCKS * (6 * c + 4);
+    const size_t fwd = (size_t)PCRH_DENSE_BLOCKS * (1 + 32) + (size_t)PCRH_SPARSE_BLOCKS * 5;
+    return std::max(bwd, fwd) * sizeof(float) + 512;
 }
 
 // y: RAW ConvTranspose3d output [B][C][cells]; bn_scale_shift (device, 2C) = scale[C] | shift[C] of the batch norm that follows it
 // (g = relu(y*scale + shift)); head_params as s2d_pcr_heads_fwd_f32; z[B][co][cells] = w2.g + b2 (co > 0); out8 as s2d_pcr_loss_fwd_f32.
 extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
                                      const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
-                                     float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+                                     float *z_stats /* [2 co] = sum | sum of squares of z per channel, or NULL */, float *out8, void *ws,
+                                     size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(y && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
                       (co == 0 || (w2 && z)),
                   "pcr_level_fwd: bad argument");
@@ -1094,7 +1130,7 @@ extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
     float *wsf = (float *)ws;
-    if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+    if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st, z_stats);
     if (c == 32) return pcr_level_fwd_t<32, 0, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
     return pcr_level_fwd_t<3, 0, 4>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
 }

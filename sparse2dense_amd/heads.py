@@ -318,7 +318,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
     written.  The batch-norm statistics / finalisation (running stats, SyncBN all-reduces) are the FastBatchNorm3d ones."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16, stats=None):
+    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16, stats=None, z_stats_out=None):
         from . import _lib, collective as _collective, hip_ops as H
         from .dense2d import _ptr, _stream, _ws
         from .dense3d import _bncm_reduce
@@ -348,8 +348,12 @@ class _PcrLevelNormFn(torch.autograd.Function):
             w2d = w2.reshape(co, c).contiguous()
             z = torch.empty((b, co, d, h, w), dtype=torch.float32, device=dev)
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
+        # the kernel that writes z also reduces its per-channel (sum, sum of squares): the statistics of the BatchNorm3d behind the conv
+        zst = torch.empty(2 * co, dtype=torch.float32, device=dev) if (z_stats_out is not None and c == 32 and co == 16) else None
         _lib.check(lib.s2d_pcr_level_fwd_f32(_ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h,
-                                             w, _ptr(z), _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd_f32")
+                                             w, _ptr(z), _ptr(zst), _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd_f32")
+        if zst is not None:
+            z_stats_out.append(zst)
         ctx.save_for_backward(y, norm, hp, coors, feats, out, w2d, gamma, mean, invstd, count)
         ctx.shapes = (w_mask.shape, w_off.shape, None if w2 is None else w2.shape, b2 is not None)
         ctx.bf16, ctx.sync = bool(bf16), sync
@@ -392,7 +396,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
             dw2, db2 = pointwise_conv_wgrad(y, dz, has_b2, ctx.bf16, norm=norm)
             dw2 = dw2.reshape(w2_shape)
         return (dy, dgamma, dbeta, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:],
-                None, None, dw2, db2, None, None, None)
+                None, None, dw2, db2, None, None, None, None)
 
 
 def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
@@ -401,9 +405,13 @@ def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
     assert bn.training and bn.affine and getattr(bn, "fused_relu", False) and bn.momentum is not None
     assert mask_conv.bias is not None and offset_conv.bias is not None
     coors = coors if coors.dtype == torch.int32 else coors.int()
-    return _PcrLevelNormFn.apply(y, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors,
-                                 feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
-                                 bn, bool(getattr(next_conv, "bf16_compute", False)), getattr(y, "_s2d_bn_stats", None))
+    holder = []
+    out = _PcrLevelNormFn.apply(y, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias, coors,
+                                feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
+                                bn, bool(getattr(next_conv, "bf16_compute", False)), getattr(y, "_s2d_bn_stats", None), holder)
+    if holder and out[2] is not None:
+        out[2]._s2d_bn_stats = holder[0]   # read by the FastBatchNorm3d that follows the 1x1x1 conv (dense3d.FastBatchNorm3d.forward)
+    return out
 
 
 def pcr_level_supported(g, next_conv=None):

@@ -153,6 +153,12 @@ def test_pcr_level_with_folded_batchnorm_matches_unfused(b, c, co, d, h, w, m):
     np.testing.assert_allclose(ol.item(), ol_r.item(), rtol=3e-5)
     if co:
         assert (z.double().cpu() - z_r).abs().max() <= 2e-5 * z_r.abs().max()
+        # the kernel that wrote z also hands the statistics of the BatchNorm3d behind it over (sum | sum of squares per channel)
+        st = getattr(z, "_s2d_bn_stats", None)
+        assert st is not None and st.numel() == 2 * co
+        zd = z.detach().double()
+        ref_st = torch.cat([zd.sum((0, 2, 3, 4)), (zd * zd).sum((0, 2, 3, 4))]).cpu()
+        assert (st.double().cpu() - ref_st).abs().max() <= 1e-5 * ref_st.abs().max() + 1e-3
     names = ["dy", "dgamma", "dbeta", "dw_mask", "db_mask", "dw_off", "db_off", "dw2", "db2"]
     for name, a, ref in zip(names, gr, gr_r):
         err = float((a.double().cpu() - ref).abs().max() / ref.abs().max())
