@@ -322,7 +322,10 @@ static bool use_rg(int cin, int cout) {
         const char *e = getenv("S2D_S16_KERNEL");
         v = !(e && strcmp(e, "lds") == 0);
     }
-    return v != 0 && cin >= 64 && cout >= 64 && (cin == 128 || cout == 128);   // 64 -> 64 (48 vs 52 us) and narrower: the LDS-staged kernel
+    // 64 -> 64 (48 vs 52 us) and narrower stay on the LDS-staged kernel.  r03 experiment: the register-gather template instantiated for
+    // 32 channels (four offsets per 128-deep K-step): 32 -> 32 61 vs 56 us, 64 -> 32 62 vs 68 us - no case for it; tile heights of the
+    // LDS kernel re-swept at the same time (S2D_S16_PLAN): 64 rows still beat 128 / 256 at every 16...64-channel shape
+    return v != 0 && cin >= 64 && cout >= 64 && (cin == 128 || cout == 128);
 }
 
 static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
