@@ -109,6 +109,32 @@ class RPN(nn.Module):
         return self._trunk(x, relu_between=True)  # rpn.py:156
 
 
+_PCR_STREAMS = {}
+
+
+def _pcr_side_stream(x):
+    """second stream for the PCR branch (S2D_PCR_STREAM=1), one per device; None = run it in line.  Measured r03 (B=4 S2D student step,
+    parity tests green in both modes): 23.7 / 23.7 ms in line, 23.8 / 23.3 ms with the branch on its own stream - its kernels fill
+    the chip on their own, so the overlap with the trunk / head buys nothing measurable; opt-in."""
+    import os
+    if os.environ.get("S2D_PCR_STREAM", "0") != "1" or not x.is_cuda or torch.cuda.is_current_stream_capturing():
+        return None
+    st = _PCR_STREAMS.get(x.device.index)
+    if st is None:
+        st = _PCR_STREAMS[x.device.index] = torch.cuda.Stream(x.device)
+    return st
+
+
+def _tensors_in(obj):
+    if torch.is_tensor(obj):
+        return [obj] if obj.is_cuda else []
+    if isinstance(obj, dict):
+        obj = list(obj.values())
+    if isinstance(obj, (list, tuple)):
+        return [t for o in obj for t in _tensors_in(o)]
+    return []
+
+
 class _ToNhwcBf16(torch.autograd.Function):
     """contiguous (NCHW) fp32 map -> NHWC bf16 in ONE cast+layout pass (csrc/layout.hip), gradient back to contiguous fp32 in one pass:
     the inverse hand-over of _ToPlanarF32 (the pillar canvas entering the bf16 S2D module, readers/pillar_encoder.py:337-394)"""
@@ -220,6 +246,58 @@ class S2D_RPN(RPN):
         # their losses (0-dim tensors in the gen_mask_* / gen_offset_* slots) instead of the dense logits / offsets
         self.pcr_targets = None
 
+    def _pcr_head(self, x, F_S_b):
+        """the PCR point-cloud-reconstruction branch behind F_S_b (rpn.py:263-296, 316-325): out_conv -> generator_1 -> level-4 heads ->
+        generator_2 -> level-2 heads; returns (gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4) - losses when the detector handed the
+        recon voxels in (pcr_targets), dense volumes otherwise"""
+        n, _, h, w = x.shape
+        gen = self.out_conv(F_S_b)
+        # PCR head in fp32 / standard layout: its 3-D convs are memory-bound, and MIOpen's
+        # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
+        with torch.autocast("cuda", enabled=False):
+            if gen.dtype in (torch.bfloat16, torch.float16):
+                gen = _ToPlanarF32.apply(gen)
+            gen = gen.contiguous().view(n, 128, 5, h, w)
+            tg, self.pcr_targets = self.pcr_targets, None
+            bn1, bn2 = self.generator_1[4], self.generator_2[4]
+            fold = (tg is not None and gen.is_cuda and isinstance(bn1, FastBatchNorm3d) and isinstance(bn2, FastBatchNorm3d)
+                    and bn1.training and bn2.training and bn1.fused_relu and bn2.fused_relu)
+            if fold:
+                raw = self.generator_1[:4](gen)   # ... up to the RAW output of the first up-sampler
+                fold = pcr_level_supported(raw, self.generator_2[0])
+                gen = raw if fold else self.generator_1[4:](raw)
+            else:
+                gen = self.generator_1(gen)
+            if fold:
+                # the detector handed the recon voxels in and the levels' batch norms are ours: BatchNorm3d + ReLU + mask / offset heads +
+                # losses (+ the next 1x1x1 conv) run from the raw up-sampler outputs (heads.pcr_level_norm); the gen_* slots carry
+                # the 0-dim losses
+                gen_mask_4, gen_offset_4, z = pcr_level_norm(gen, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
+                raw2 = self.generator_2[1:4](z)
+                if pcr_level_supported(raw2):
+                    gen_mask_2, gen_offset_2, _ = pcr_level_norm(raw2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
+                else:
+                    gen = self.generator_2[4:](raw2)
+                    from .heads import mask_offset_loss_sparse
+                    gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
+            elif tg is not None and pcr_level_supported(gen, self.generator_2[0]):
+                # the detector handed the recon voxels in: each level's mask / offset heads and losses are evaluated without
+                # writing the logits / offset volumes (heads.pcr_level); the gen_* slots carry the 0-dim losses instead
+                gen_mask_4, gen_offset_4, z = pcr_level(gen, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
+                gen = self.generator_2[1:](z)
+                if pcr_level_supported(gen):
+                    gen_mask_2, gen_offset_2, _ = pcr_level(gen, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
+                else:
+                    from .heads import mask_offset_loss_sparse
+                    gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
+            else:
+                gen_offset_4 = self.gen_out_4(gen)
+                gen_mask_4 = self.gen_mask_4(gen)
+                gen = self.generator_2(gen)
+                gen_mask_2 = self.gen_mask_2(gen)
+                gen_offset_2 = self.gen_out_2(gen)
+        return gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4
+
     def forward(self, x):
         if self.trunk_channels_last and x.is_cuda:   # NHWC end to end: conv, batch norm and GELU all keep the layout
             x = x.contiguous(memory_format=torch.channels_last)
@@ -231,55 +309,27 @@ class S2D_RPN(RPN):
         y_3 = torch.cat([self.decoder_1(att), y_1], 1)
         F_S_b = self.decoder_2(y_3)
         F_S_a = self.fusion_dense(F_S_b) + self.fusion_sparse(x)
+        side = None
         if self.training:
-            n, _, h, w = x.shape
-            gen = self.out_conv(F_S_b)
-            # PCR head in fp32 / standard layout: its 3-D convs are memory-bound, and MIOpen's
-            # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
-            with torch.autocast("cuda", enabled=False):
-                if gen.dtype in (torch.bfloat16, torch.float16):
-                    gen = _ToPlanarF32.apply(gen)
-                gen = gen.contiguous().view(n, 128, 5, h, w)
-                tg, self.pcr_targets = self.pcr_targets, None
-                bn1, bn2 = self.generator_1[4], self.generator_2[4]
-                fold = (tg is not None and gen.is_cuda and isinstance(bn1, FastBatchNorm3d) and isinstance(bn2, FastBatchNorm3d)
-                        and bn1.training and bn2.training and bn1.fused_relu and bn2.fused_relu)
-                if fold:
-                    raw = self.generator_1[:4](gen)   # ... up to the RAW output of the first up-sampler
-                    fold = pcr_level_supported(raw, self.generator_2[0])
-                    gen = raw if fold else self.generator_1[4:](raw)
-                else:
-                    gen = self.generator_1(gen)
-                if fold:
-                    # the detector handed the recon voxels in and the levels' batch norms are ours: BatchNorm3d + ReLU + mask / offset heads +
-                    # losses (+ the next 1x1x1 conv) run from the raw up-sampler outputs (heads.pcr_level_norm); the gen_* slots carry
-                    # the 0-dim losses
-                    gen_mask_4, gen_offset_4, z = pcr_level_norm(gen, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
-                    raw2 = self.generator_2[1:4](z)
-                    if pcr_level_supported(raw2):
-                        gen_mask_2, gen_offset_2, _ = pcr_level_norm(raw2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
-                    else:
-                        gen = self.generator_2[4:](raw2)
-                        from .heads import mask_offset_loss_sparse
-                        gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
-                elif tg is not None and pcr_level_supported(gen, self.generator_2[0]):
-                    # the detector handed the recon voxels in: each level's mask / offset heads and losses are evaluated without
-                    # writing the logits / offset volumes (heads.pcr_level); the gen_* slots carry the 0-dim losses instead
-                    gen_mask_4, gen_offset_4, z = pcr_level(gen, self.gen_mask_4[0], self.gen_out_4[0], *tg[4], next_conv=self.generator_2[0])
-                    gen = self.generator_2[1:](z)
-                    if pcr_level_supported(gen):
-                        gen_mask_2, gen_offset_2, _ = pcr_level(gen, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
-                    else:
-                        from .heads import mask_offset_loss_sparse
-                        gen_mask_2, gen_offset_2 = mask_offset_loss_sparse(self.gen_out_2(gen), self.gen_mask_2(gen), *tg[2])
-                else:
-                    gen_offset_4 = self.gen_out_4(gen)
-                    gen_mask_4 = self.gen_mask_4(gen)
-                    gen = self.generator_2(gen)
-                    gen_mask_2 = self.gen_mask_2(gen)
-                    gen_offset_2 = self.gen_out_2(gen)
+            side = _pcr_side_stream(x)
+            if side is None:
+                gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4 = self._pcr_head(x, F_S_b)
+            else:
+                # S2D_PCR_STREAM=1: the PCR branch (HBM-bound streaming kernels over 0.4-0.7 GB volumes) runs on a second stream beside the
+                # trunk / CenterHead (matrix-core convs) - forward here, and in the backward too: autograd replays every node on the stream
+                # of its forward.  The branch joins the main stream after the trunk; what it reads from the main stream is marked.
+                cur = torch.cuda.current_stream(x.device)
+                side.wait_stream(cur)
+                for t in _tensors_in((F_S_b, self.pcr_targets)):
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4 = self._pcr_head(x, F_S_b)
         else:
             gen_offset_2 = gen_mask_2 = gen_offset_4 = gen_mask_4 = None
         # the trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)
         out = self._trunk(F_S_a, relu_between=False)
+        if side is not None:
+            cur.wait_stream(side)
+            for t in _tensors_in((gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4)):
+                t.record_stream(cur)
         return out, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b
