@@ -17,7 +17,8 @@ densify module + PCR head + RPN trunk + CenterHead), forward + backward, B=4 fra
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   roofline     : the dominant hand-written kernel of the step by total time (per-launch HIP events)
   sparse_gemm  : MFMA fraction of the sparse implicit GEMM at C >= 64 (forward + data gradient)
-  rulebook     : HBM fraction of the rulebook stage (4 SubM + 4 strided builds per backbone pass)
+  rulebook     : HBM fraction of the rulebook stage (4 SubM + 4 strided builds per backbone pass, one launch chain since r04)
+  voxelize     : HBM fraction of the device voxelizer chains (20 B per point + 116 B per voxel)
   cpu_baseline : the CPU oracle stack on a bounded sample (150k-pt frame, and BASELINE configs[0]:
                  SECOND on the 8k-pt cloud, 3 warm-up + 10 timed iterations, median), host cores stated
 """
@@ -214,9 +215,31 @@ def roofline_pass(step, n_steps=3):
         step()
     torch.cuda.synchronize()
     recs, H.PROFILE = H.PROFILE, None
-    over = _event_overhead_us()
-    agg, rb = {}, dict(ms=0.0, n=0, bytes=0.0, subm=0, conv=0)
+    over = _event_overhead_us()   # reported, NOT subtracted: rocprofv3's per-kernel durations agree with the raw event times
+    agg, rb = {}, dict(ms=0.0, n=0, bytes=0.0, subm=0, conv=0, chains=0)
+    vox = dict(ms=0.0, n=0, bytes=0.0, points=0, voxels=0)
     for r in recs:
+        if r["kernel"] == "voxelize":
+            # 20 B per point read + 116 B per voxel written (voxels [M,5,5] f32 + coors + num_points); launch chain
+            m = int(r["out_base"][-1].item())
+            vox["ms"] += r["start"].elapsed_time(r["end"]); vox["n"] += 1
+            vox["bytes"] += 4.0 * r["ndim"] * r["n_points"] + m * (4.0 * r["max_points"] * r["ndim"] + 16.0)
+            vox["points"] += r["n_points"]; vox["voxels"] += m
+            continue
+        if r["kernel"] == "rulebook_chain":
+            # r04: every rulebook of the pass in one chain (plan phase + fill phase around ONE host read, which is not GPU time);
+            # algorithmic bytes = the sum of SURVEY 8(d)'s per-build figures over the builds the chain replaces
+            rows = r["rows"]
+            rb["ms"] += r["start"].elapsed_time(r["end"]) + r["start2"].elapsed_time(r["end2"])
+            for l, pc in enumerate(r["subm_pairs"]):
+                if pc is not None:
+                    rb["bytes"] += 16.0 * rows[l] + 8.0 * float(pc.sum().item()) + 4.0 * 27
+                    rb["subm"] += 1; rb["n"] += 1
+            for l, pc in enumerate(r["conv_pairs"]):
+                rb["bytes"] += 16.0 * rows[l] + 16.0 * rows[l + 1] + 8.0 * float(pc.sum().item()) + 4.0 * r["kvols"][l]
+                rb["conv"] += 1; rb["n"] += 1
+            rb["chains"] += 1
+            continue
         pairs = float(r["pairs"].sum().item()) if r.get("pairs") is not None else 0.0
         if r["kernel"] in ("rulebook_subm", "rulebook_conv"):
             # launch chains (several kernels inside one event pair): the event overhead is not subtracted
@@ -231,7 +254,7 @@ def roofline_pass(step, n_steps=3):
             rb["ms"] += ms
             rb["n"] += 1
             continue
-        ms = max(r["start"].elapsed_time(r["end"]) - over * 1e-3, 1e-4)
+        ms = max(r["start"].elapsed_time(r["end"]), 1e-4)
         kname = r["kernel"]
         if r.get("kname"):   # 1x1 convs and the stride-2 transposed forms: the host wrapper names the instantiation it launched
             kname = r["kname"]
@@ -260,7 +283,16 @@ def roofline_pass(step, n_steps=3):
                         builds_per_step=rb["n"] // n_steps, subm_builds=rb["subm"] // n_steps, strided_builds=rb["conv"] // n_steps,
                         avg_build_us=round(rb["ms"] / rb["n"] * 1e3, 1), total_ms_per_step=round(rb["ms"] / n_steps, 3),
                         algorithmic_mb_per_step=round(rb["bytes"] / n_steps / 1e6, 2),
+                        launch_chains_per_step=(rb["chains"] // n_steps) or None,
                         algorithmic_bytes="SubM 16 N + 8 R + 4 K; strided 16 N_in + 16 N_out + 8 R + 4 K (SURVEY 8(d))")
+    voxelize = None
+    if vox["n"]:
+        gbs = vox["bytes"] / (vox["ms"] * 1e-3) / 1e9
+        voxelize = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                        chains_per_step=vox["n"] // n_steps, avg_chain_us=round(vox["ms"] / vox["n"] * 1e3, 1),
+                        total_ms_per_step=round(vox["ms"] / n_steps, 3), points_per_step=vox["points"] // n_steps,
+                        voxels_per_step=vox["voxels"] // n_steps, algorithmic_mb_per_step=round(vox["bytes"] / n_steps / 1e6, 2),
+                        algorithmic_bytes="20 B per point + 116 B per voxel (SURVEY 8(d)); one chain = all frames of one cloud kind")
     rows = []
     for (kern, cin, cout, n_out, tag), a in agg.items():
         avg_ms = a["ms"] / a["n"]
@@ -283,7 +315,7 @@ def roofline_pass(step, n_steps=3):
                                         avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1),
                                         frac=round(r["tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4)) for r in sg_rows])
     if not rows:
-        return None, [], rulebook, sparse_gemm
+        return None, [], rulebook, sparse_gemm, voxelize
 
     # the dominant KERNEL is a device function (what rocprofv3 --stats lists); one template instantiation serves several
     # tensor shapes, so group the per-shape rows by instantiation before ranking
@@ -318,7 +350,7 @@ def roofline_pass(step, n_steps=3):
                    avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1)) for r in g["rows"]]
     common = dict(traffic=None, kernel=f"s2d::{name}", avg_launch_us=round(avg_us, 2), launches_per_step=g["n"] // n_steps,
                   algorithmic_tflops=round(tflops, 2), algorithmic_gbs=round(gbs, 1), flop_per_byte=round(intensity, 1),
-                  mfma_peak_tflops=peak_tf, shapes=shapes, event_pair_overhead_us_subtracted=round(over, 2),
+                  mfma_peak_tflops=peak_tf, shapes=shapes, event_pair_overhead_us_not_subtracted=round(over, 2),
                   chosen_by=chosen_by,
                   scope=("dominant hand-written kernel of the step: " +
                          ("dense NHWC bf16 implicit-GEMM tile kernel of the BEV neck/head (3x3 or its one-tap 1x1 instantiation), forward + "
@@ -334,7 +366,7 @@ def roofline_pass(step, n_steps=3):
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), **common)
     else:
         roof = dict(bound="mfma", achieved=round(tflops, 3), peak=peak_tf, unit="TFLOP/s", frac=round(tflops / peak_tf, 4), **common)
-    return roof, rows, rulebook, sparse_gemm
+    return roof, rows, rulebook, sparse_gemm, voxelize
 
 
 def stats_top_kernels():
@@ -521,11 +553,33 @@ def scene_stats(model, frames):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (the reference is started by torch.distributed.launch, tools/train.py:86-96):
+    re-run this command line under torch.distributed.run with one rank per GPU on 127.0.0.1; the rank-0 child prints the JSON
+    line to our stdout.  Fails loudly when the node has fewer than N GPUs - never measures fewer ranks than asked for."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly ONE line, the JSON result: whatever libraries print there (RCCL writes a version banner to stdout when
     # its first communicator is created) is redirected to stderr; the result goes to the saved descriptor.
     sys.stdout.flush()
@@ -534,10 +588,12 @@ def main():
     torch.set_num_threads(min(effective_cpu_count(), 16))
     from sparse2dense_amd import dp
     rank, local, world = dp.init_distributed()
-    if world != max(args.gpus, 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != max(args.gpus, 1):   # a launcher that started a different number of ranks than asked for: refuse, do not mislabel
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+                         "(or without a launcher: bench.py starts its own ranks)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} (local {local}) has no GPU: {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import __graft_entry__
@@ -567,9 +623,9 @@ def main():
         frames.close()
         frames = frames.frames
     stats = scene_stats(model, frames) if rank == 0 else {}
-    roof, rows, rulebook, sparse_gemm = (None, [], None, None)
+    roof, rows, rulebook, sparse_gemm, voxelize = (None, [], None, None, None)
     if single and not args.no_roofline:
-        roof, rows, rulebook, sparse_gemm = roofline_pass(step.sync_step)
+        roof, rows, rulebook, sparse_gemm, voxelize = roofline_pass(step.sync_step)
     loss_value = round(float(loss.item()), 4)
 
     others = {}
@@ -627,7 +683,7 @@ def main():
                                          "built on a second HIP stream by a loader thread while step k runs; one example per timed step"
                                          if prefetching else "example built inside its step on the main stream"),
                        "loss": loss_value, "scene": stats},
-            "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "cpu_baseline": base,
+            "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "voxelize": voxelize, "cpu_baseline": base,
         }
         if others:
             out["other_workloads"] = others

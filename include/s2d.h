@@ -112,6 +112,32 @@ int s2d_rulebook_conv_fill(const int32_t *coors, int64_t n, int batch, const int
                            int32_t *out_coors, int32_t *nbr_out, int32_t *nbr_in,
                            int32_t *pair_count, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
+/*
+ * r04 - every rulebook of one backbone pass in one chain (spconv get_indice_pairs x 8 as called by
+ * det3d/models/backbones/scn.py:104-152: conv_input/conv1 .. conv4 SubM keys res0..res3 + the four strided convs).
+ * Stage 0 = the input rows (any order); stage l+1 = outputs of strided conv l (ksize/stride/padding are [n_strided][3],
+ * dilation 1, the first conv must be k3 s2 p1: its outputs index the 2x2x2 blocks of stage 0).
+ *   _plan : marks + numbers the sites of stages 1..n (canonical sorted (b,z,y,x) order) and writes their row counts to the
+ *           device vector counts[n_strided + 1] (last element: non-zero = internal error).  ONE host read per pass.
+ *   _fill : with the counts known to the host (n_rows[n_strided]) writes out_coors[l] (stage l+1 rows), subm_nbr[l]
+ *           (i32[27][N_l], l = 0..n_strided, NULL = not wanted), conv_nbr_out[l] (i32[K_l][N_{l+1}]), conv_nbr_in[l]
+ *           (i32[K_l][N_l]) and pair_counts (i32[(2 n_strided + 1)][27]: SubM of stage l in row l, conv l in row
+ *           n_strided + 1 + l).  `child` = scratch i32[n_rows[0]][8].  Same workspace as _plan, unchanged in between.
+ * Maps are dense gather maps as above; every pointer array lives on the HOST and holds device pointers.
+ */
+int s2d_rulebook_chain_supported(int batch, const int32_t shape0[3], int n_strided, const int32_t *ksize,
+                                 const int32_t *stride, const int32_t *padding);
+size_t s2d_rulebook_chain_workspace_bytes(int batch, const int32_t shape0[3], int n_strided, const int32_t *ksize,
+                                          const int32_t *stride, const int32_t *padding);
+int s2d_rulebook_chain_plan(const int32_t *coors0, int64_t n0, int batch, const int32_t shape0[3], int n_strided,
+                            const int32_t *ksize, const int32_t *stride, const int32_t *padding, int32_t *counts,
+                            void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_rulebook_chain_fill(const int32_t *coors0, int64_t n0, int batch, const int32_t shape0[3], int n_strided,
+                            const int32_t *ksize, const int32_t *stride, const int32_t *padding, const int64_t *n_rows,
+                            int32_t *const *out_coors, int32_t *const *subm_nbr, int32_t *const *conv_nbr_out,
+                            int32_t *const *conv_nbr_in, int32_t *pair_counts, int32_t *child, void *ws, size_t ws_bytes,
+                            s2d_stream_t stream);
+
 /* ---- sparse convolution (implicit GEMM on MFMA) ------------------------------------------- */
 /*
  * out[o][:] = sum_k in[nbr[k][o]][:] * weight[k][:][:] (+ bias), fp32 in / fp32 accumulate on

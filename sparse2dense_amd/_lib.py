@@ -34,6 +34,14 @@ SIGNATURES = {
     "s2d_rulebook_conv_fill": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, _I3, _I3,
                                               ctypes.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_void_p,
                                               ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_rulebook_chain_supported": (ctypes.c_int, [ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_rulebook_chain_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                             ctypes.c_void_p]),
+    "s2d_rulebook_chain_plan": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, c_i32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_rulebook_chain_fill": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, c_i32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_spconv_fwd_f32": (ctypes.c_int, [c_f32p, ctypes.c_int64, c_f32p, c_f32p, c_i32p, ctypes.c_int64, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_spconv_bf16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

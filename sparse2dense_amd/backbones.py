@@ -85,6 +85,18 @@ def build_geometry(coors, batch_size, shape, strided_specs, subm_keys):
     (plan_key, ksize, stride, padding); `subm_keys[i]` = (indice_key, ksize) at the resolution
     before strided conv i.  Returns {indice_key: Rulebook, ("conv", plan_key): Rulebook}."""
     plan = {}
+    specs3 = [(tuple(int(v) for v in k), tuple(int(v) for v in s), tuple(int(v) for v in p)) for _, k, s, p in strided_specs]
+    if (coors.is_cuda and coors.shape[0] > 0 and all(sk is None or tuple(sk[1]) == (3, 3, 3) for sk in subm_keys)
+            and H.rulebook_chain_supported(batch_size, shape, specs3)):
+        # r04: one launch chain + one host read for the whole pass (csrc/rulebook_chain.hip)
+        want = [i < len(subm_keys) and subm_keys[i] is not None for i in range(len(strided_specs) + 1)]
+        subm, conv = H.build_rulebook_chain(coors, batch_size, shape, specs3, want)
+        for i, rb in enumerate(subm):
+            if rb is not None:
+                plan[subm_keys[i][0]] = rb
+        for (pk, _, _, _), rb in zip(strided_specs, conv):
+            plan[("conv", pk)] = rb
+        return plan
     for i in range(len(strided_specs) + 1):
         if i < len(subm_keys) and subm_keys[i] is not None:
             key, ksize = subm_keys[i]

@@ -10,6 +10,7 @@ Reference interfaces these stand in for (file:line under /root/reference):
   densify             spconv.SparseConvTensor.dense()       (scn.py:173)
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -99,9 +100,17 @@ def voxelize_batch_launch(points_cat: torch.Tensor, offsets, voxel_size, coors_r
     out_m = torch.empty((frames,), dtype=torch.int32, device=dev)
     out_base = torch.empty((frames + 1,), dtype=torch.int32, device=dev)
     ws = _ws(lib.s2d_voxelize_batch_workspace_bytes(frames, offs, max_points, max_voxels), dev)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="voxelize", tag="voxelize", cin=0, cout=0, n_points=int(n), frames=frames, out_base=out_base, max_points=max_points,
+                   ndim=int(ndim), start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_voxelize_batch_run(_ptr(points_cat), frames, offs, ndim, f6(coors_range), f3(voxel_size), max_points, max_voxels,
                                      _ptr(voxels), _ptr(coors), _ptr(num), _ptr(mean), _ptr(out_m), _ptr(out_base), _ptr(ws), ws.numel(),
                                      _stream()), "s2d_voxelize_batch_run")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
     return (voxels, coors, num, mean, out_base)
 
 
@@ -232,6 +241,94 @@ class ConvRulebookJob:
 
 def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)) -> Rulebook:
     return ConvRulebookJob(coors, batch, shape, ksize, stride, padding, dilation).count().finish()
+
+
+def _i32_flat(rows):
+    flat = [int(v) for r in rows for v in r]
+    return (ctypes.c_int32 * len(flat))(*flat)
+
+
+def rulebook_chain_supported(batch, shape, strided_specs):
+    """`strided_specs[l]` = (ksize, stride, padding) triples of the strided convs in order (s2d_rulebook_chain_supported)"""
+    if os.environ.get("S2D_RULEBOOK", "chain") != "chain" or not strided_specs:
+        return False
+    ks, st, pd = (_i32_flat([s[j] for s in strided_specs]) for j in range(3))
+    return bool(_lib.load().s2d_rulebook_chain_supported(int(batch), i3(shape), len(strided_specs), ks, st, pd))
+
+
+def build_rulebook_chain(coors: torch.Tensor, batch: int, shape, strided_specs, want_subm):
+    """Every rulebook of one backbone pass (s2d_rulebook_chain_plan -> ONE host read -> s2d_rulebook_chain_fill).
+    `strided_specs[l]` = (ksize, stride, padding) of strided conv l; `want_subm[l]` = whether the SubM 3x3x3 map at resolution l
+    (0 = input) is needed.  Returns (subm[l] or None for l in 0..n, conv[l] for l in 0..n-1) as Rulebook objects."""
+    lib = _lib.load()
+    _need_gpu(coors)
+    coors = coors.contiguous()
+    assert coors.dtype == torch.int32 and coors.dim() == 2 and coors.shape[1] == 4
+    dev = coors.device
+    n0, nst = int(coors.shape[0]), len(strided_specs) + 1
+    ks, st, pd = (_i32_flat([s[j] for s in strided_specs]) for j in range(3))
+    shapes = [tuple(int(v) for v in shape)]
+    for k, s, p in strided_specs:
+        shapes.append(conv_out_shape(shapes[-1], k, s, p))
+    kvols = [int(k[0] * k[1] * k[2]) for k, _, _ in strided_specs]
+    ws = _ws(lib.s2d_rulebook_chain_workspace_bytes(int(batch), i3(shape), nst - 1, ks, st, pd), dev)
+    counts = torch.empty((nst,), dtype=torch.int32, device=dev)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="rulebook_chain", tag="rulebook", cin=0, cout=0, n_in=n0, kvol=27,
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True),
+                   start2=torch.cuda.Event(enable_timing=True), end2=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
+    check(lib.s2d_rulebook_chain_plan(_ptr(coors), n0, int(batch), i3(shape), nst - 1, ks, st, pd, _ptr(counts), _ptr(ws), ws.numel(),
+                                      _stream()), "s2d_rulebook_chain_plan")
+    if rec is not None:
+        rec["end"].record()
+    got = counts.tolist()   # the one host read of the pass (spconv reads indice_pair_num once per layer)
+    if got[-1] != 0:
+        raise _lib.S2DError("s2d_rulebook_chain_plan: look-back scan timed out")
+    rows = [n0] + got[:-1]
+
+    # one allocation for every map of the pass; each piece 16-byte aligned
+    def up4(v):
+        return (v + 3) // 4 * 4
+    sizes = []
+    for l in range(nst):
+        sizes.append(("coors", l, 4 * rows[l] if l else 0))
+        sizes.append(("subm", l, 27 * rows[l] if want_subm[l] else 0))
+        if l + 1 < nst:
+            sizes.append(("out", l, kvols[l] * rows[l + 1]))
+            sizes.append(("in", l, kvols[l] * rows[l]))
+    sizes.append(("cnt", 0, 27 * (2 * nst - 1)))
+    sizes.append(("child", 0, 8 * rows[1]))
+    flat = torch.empty((sum(up4(sz) for _, _, sz in sizes),), dtype=torch.int32, device=dev)
+    view, off = {}, 0
+    for kind, l, sz in sizes:
+        view[(kind, l)] = flat[off:off + sz]
+        off += up4(sz)
+    cnt = view[("cnt", 0)].view(2 * nst - 1, 27)
+    vp = ctypes.c_void_p
+
+    def ptrs(kind, count):
+        return (vp * count)(*[(_ptr(view[(kind, l)]) if view[(kind, l)].numel() else None) for l in range(count)])
+    n_rows = (ctypes.c_int64 * (nst - 1))(*rows[1:])
+    coors_ptrs = (vp * (nst - 1))(*[(_ptr(view[("coors", l)]) if rows[l] else None) for l in range(1, nst)])
+    if rec is not None:
+        rec["start2"].record()
+    check(lib.s2d_rulebook_chain_fill(_ptr(coors), n0, int(batch), i3(shape), nst - 1, ks, st, pd, n_rows, coors_ptrs, ptrs("subm", nst),
+                                      ptrs("out", nst - 1), ptrs("in", nst - 1), _ptr(cnt), _ptr(view[("child", 0)]) if rows[1] else None,
+                                      _ptr(ws), ws.numel(), _stream()), "s2d_rulebook_chain_fill")
+    if rec is not None and PROFILE is not None:
+        rec["end2"].record()
+        rec.update(rows=rows, subm_pairs=[cnt[l] if want_subm[l] else None for l in range(nst)],
+                   conv_pairs=[cnt[nst + l][:kvols[l]] for l in range(nst - 1)], kvols=kvols)
+        PROFILE.append(rec)
+    stage_coors = [coors] + [view[("coors", l)].view(rows[l], 4) for l in range(1, nst)]
+    subm = [Rulebook(True, 27, rows[l], rows[l], view[("subm", l)].view(27, rows[l]), None, cnt[l], None, shapes[l], coors=stage_coors[l])
+            if want_subm[l] else None for l in range(nst)]
+    conv = [Rulebook(False, kvols[l], rows[l], rows[l + 1], view[("out", l)].view(kvols[l], rows[l + 1]),
+                     view[("in", l)].view(kvols[l], rows[l]), cnt[nst + l][:kvols[l]], stage_coors[l + 1], shapes[l + 1])
+            for l in range(nst - 1)]
+    return subm, conv
 
 
 # ------------------------------------------------------------------------------------------------
