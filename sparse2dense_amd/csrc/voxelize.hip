@@ -23,7 +23,8 @@
 
 namespace s2d {
 
-constexpr uint32_t VOX_EMPTY = 0xFFFFFFFFu;
+// r04: ONE hipMemsetAsync(0x7F) clears the hash keys, the first-point table, the k-smallest lists and the scan granules
+constexpr uint32_t VOX_EMPTY = 0x7F7F7F7Fu;   // > any cell key (grids are checked against it)
 constexpr int IDX_EMPTY = 0x7F7F7F7F;  // what hipMemsetAsync(.., 0x7F, ..) produces; > any point index
 
 struct VoxParams {
@@ -38,6 +39,24 @@ struct VoxParams {
 };
 
 __device__ __forceinline__ uint32_t vox_hash(uint32_t key, int shift) { return (key * 2654435761u) >> shift; }
+
+// Open-addressing insert of `key` + atomicMin of the point index.  The chip retires ~21 global atomics per ns (r04 measurement), and
+// two per point bounded this kernel: a relaxed load first - a slot that already holds the key needs no CAS, a first-point entry that is
+// already smaller needs no atomicMin.  Keys go EMPTY -> key once and first-point entries only decrease, so a stale read can only
+// make the thread take the atomic it would have taken anyway.
+__device__ __forceinline__ uint32_t vox_table_insert(uint32_t *__restrict__ keys, int *__restrict__ first, uint32_t key, uint32_t h, uint32_t mask, int i) {
+    while (true) {
+        const uint32_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) break;
+        if (cur == VOX_EMPTY) {
+            const uint32_t old = atomicCAS(&keys[h], VOX_EMPTY, key);
+            if (old == VOX_EMPTY || old == key) break;
+        }
+        h = (h + 1) & mask;
+    }
+    if (__hip_atomic_load(&first[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&first[h], i);
+    return h;
+}
 
 __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict__ points, int n, VoxParams p,
                                                          uint32_t *__restrict__ keys, int *__restrict__ first,
@@ -58,14 +77,7 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict
     int slot = -1;
     if (ok) {
         const uint32_t key = ((uint32_t)c[2] * (uint32_t)p.grid[1] + (uint32_t)c[1]) * (uint32_t)p.grid[0] + (uint32_t)c[0];
-        uint32_t h = vox_hash(key, p.table_shift);
-        while (true) {
-            uint32_t old = atomicCAS(&keys[h], VOX_EMPTY, key);
-            if (old == VOX_EMPTY || old == key) break;
-            h = (h + 1) & p.table_mask;
-        }
-        atomicMin(&first[h], i);
-        slot = (int)h;
+        slot = (int)vox_table_insert(keys, first, key, vox_hash(key, p.table_shift), p.table_mask, i);
     }
     pt_slot[i] = slot;
 }
@@ -109,7 +121,9 @@ __global__ void vox_finalize_count_kernel(const int *total, int max_voxels, int3
     *out_m = t < max_voxels ? t : max_voxels;
 }
 
-__global__ __launch_bounds__(256) void vox_ksmall_kernel(const int *__restrict__ pt_slot, const int *__restrict__ vid,
+// list[0] of a voxel is its first point, which vox_insert already knows (first[slot]): that thread stores it; the other points run
+// the atomicMin cascade over list[1..] only (r04: about half the atomics of a cascade from list[0], 70 -> see DESIGN us per chain)
+__global__ __launch_bounds__(256) void vox_ksmall_kernel(const int *__restrict__ pt_slot, const int *__restrict__ first, const int *__restrict__ vid,
                                                          int n, int max_points, int *__restrict__ ksmall) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -118,10 +132,15 @@ __global__ __launch_bounds__(256) void vox_ksmall_kernel(const int *__restrict__
     const int v = vid[s];
     if (v < 0) return;
     int *list = ksmall + (int64_t)v * max_points;
+    if (first[s] == i) {
+        list[0] = i;
+        return;
+    }
+    if (max_points < 2) return;
     int x = i;
     // cheap early-out: already larger than the current last entry (entries only decrease)
     if (__hip_atomic_load(&list[max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x) return;
-    for (int r = 0; r < max_points; ++r) {
+    for (int r = 1; r < max_points; ++r) {
         int old = atomicMin(&list[r], x);
         if (old == IDX_EMPTY) return;  // took an empty place, nothing displaced
         x = old > x ? old : x;       // carry the larger one down the list
@@ -176,10 +195,11 @@ struct VoxWs {
     int *first;
     int *vid;
     int *pt_slot;
-    int *block_sums;
+    unsigned long long *flags;   // scan granules
     int *total;
     int *ksmall;
     size_t table_size;
+    size_t clear_bytes;          // keys .. flags: one 0x7F memset
     size_t bytes;
 };
 
@@ -189,14 +209,15 @@ static VoxWs vox_carve(void *ws, int64_t n_points, int max_points, int max_voxel
     while (t < (size_t)(2 * (n_points > 0 ? n_points : 1))) t <<= 1;
     w.table_size = t;
     Carver c(ws);
+    int64_t rows = n_points < max_voxels ? n_points : max_voxels;
     w.keys = c.take<uint32_t>(t);
     w.first = c.take<int>(t);
+    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.flags = c.take<unsigned long long>(scan1_num_blocks(n_points));
+    w.clear_bytes = c.total();
     w.vid = c.take<int>(t);
     w.pt_slot = c.take<int>(n_points > 0 ? n_points : 1);
-    w.block_sums = c.take<int>(scan_num_blocks(n_points));
-    w.total = c.take<int>(1);
-    int64_t rows = n_points < max_voxels ? n_points : max_voxels;
-    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.total = c.take<int>(2);   // [1] = scan error flag
     w.bytes = c.total();
     return w;
 }
@@ -230,8 +251,8 @@ extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim,
         S2D_CHECK_ARG(p.grid[j] > 0, "voxelize: empty grid on axis %d", j);
         cells *= p.grid[j];
     }
-    if (cells >= 4294967295.0) {
-        set_error("voxelize: grid of %.0f cells exceeds the 32-bit key space", cells);
+    if (cells >= (double)VOX_EMPTY) {
+        set_error("voxelize: grid of %.0f cells exceeds the key space", cells);
         return S2D_ERR_UNSUPPORTED;
     }
     p.ndim = ndim;
@@ -253,18 +274,16 @@ extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim,
     }
     const int n = (int)n_points;
     const int64_t rows = n_points < max_voxels ? n_points : max_voxels;
-    S2D_HIP(hipMemsetAsync(w.keys, 0xFF, w.table_size * sizeof(uint32_t), st));
-    S2D_HIP(hipMemsetAsync(w.first, 0x7F, w.table_size * sizeof(int), st));
-    S2D_HIP(hipMemsetAsync(w.ksmall, 0x7F, (size_t)rows * max_points * sizeof(int), st));
+    S2D_HIP(hipMemsetAsync(w.keys, 0x7F, w.clear_bytes, st));
     const dim3 blk(256);
     hipLaunchKernelGGL(vox_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, w.keys, w.first, w.pt_slot);
     S2D_LAUNCH_CHECK();
     FirstFlagIn fin{w.pt_slot, w.first};
     AssignVoxelOut fout{w.pt_slot, w.keys, w.vid, coors, p};
-    int rc = device_exclusive_scan(fin, fout, n_points, w.block_sums, w.total, st);
+    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_finalize_count_kernel, dim3(1), dim3(1), 0, st, w.total, max_voxels, out_m);
-    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.vid, n, max_points, w.ksmall);
+    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.vid, n, max_points, w.ksmall);
     const int64_t fill_threads = rows * max_points;
     hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)ceil_div(fill_threads, 256)), blk, 0, st, points, w.ksmall, out_m,
                        ndim, max_points, voxels, num_points);
@@ -321,15 +340,8 @@ __global__ __launch_bounds__(256) void voxb_insert_kernel(const float *__restric
     int slot = -1;
     if (ok) {
         const uint32_t key = ((uint32_t)c[2] * (uint32_t)p.grid[1] + (uint32_t)c[1]) * (uint32_t)p.grid[0] + (uint32_t)c[0];
-        uint32_t h = vox_hash(key, vb.table_shift[b]);
-        uint32_t *kb = keys + vb.table_base[b];
-        while (true) {
-            uint32_t old = atomicCAS(&kb[h], VOX_EMPTY, key);
-            if (old == VOX_EMPTY || old == key) break;
-            h = (h + 1) & vb.table_mask[b];
-        }
-        atomicMin(&first[vb.table_base[b] + h], i);
-        slot = vb.table_base[b] + (int)h;
+        slot = vb.table_base[b] + (int)vox_table_insert(keys + vb.table_base[b], first + vb.table_base[b], key, vox_hash(key, vb.table_shift[b]),
+                                                        vb.table_mask[b], i);
     }
     pt_slot[i] = slot;
 }
@@ -351,7 +363,7 @@ struct VoxbRankOut {
 
 // one block: per-frame voxel counts (capped), their exclusive prefix (output row base), totals
 __global__ void voxb_frame_counts_kernel(const int *__restrict__ frame_start_rank, VoxBatch vb, int max_voxels, int32_t *__restrict__ out_m /*[frames]*/,
-                                         int *__restrict__ out_base /*[frames + 1]*/) {
+                                         int *__restrict__ out_base /*[frames + 1]*/, int32_t *__restrict__ out_base_user /*[frames + 1]*/) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int base = 0;
     for (int b = 0; b < vb.frames; ++b) {
@@ -362,10 +374,10 @@ __global__ void voxb_frame_counts_kernel(const int *__restrict__ frame_start_ran
         int m = s1 - s0;
         m = m < max_voxels ? m : max_voxels;
         out_m[b] = m;
-        out_base[b] = base;
+        out_base[b] = out_base_user[b] = base;
         base += m;
     }
-    out_base[vb.frames] = base;
+    out_base[vb.frames] = out_base_user[vb.frames] = base;
 }
 
 // first points only: voxel row (or -1 past the cap) per table slot + the collated coordinate row
@@ -438,8 +450,10 @@ __global__ __launch_bounds__(256) void voxb_mean_kernel(const float *__restrict_
 
 struct VoxbWs {
     uint32_t *keys;
-    int *first, *vid, *rank_of_slot, *pt_slot, *block_sums, *total, *ksmall, *frame_start_rank, *out_base;
+    int *first, *vid, *rank_of_slot, *pt_slot, *total, *ksmall, *frame_start_rank, *out_base;
+    unsigned long long *flags;   // scan granules
     size_t table_total;
+    size_t clear_bytes;          // keys .. flags: one 0x7F memset
     size_t bytes;
 };
 
@@ -463,12 +477,13 @@ static VoxbWs voxb_carve(void *ws, int frames, const int64_t *offsets, int max_p
     Carver c(ws);
     w.keys = c.take<uint32_t>(tt);
     w.first = c.take<int>(tt);
+    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.flags = c.take<unsigned long long>(scan1_num_blocks(n));
+    w.clear_bytes = c.total();
     w.vid = c.take<int>(tt);
     w.rank_of_slot = c.take<int>(tt);
     w.pt_slot = c.take<int>(n > 0 ? n : 1);
-    w.block_sums = c.take<int>(scan_num_blocks(n));
-    w.total = c.take<int>(1);
-    w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
+    w.total = c.take<int>(2);
     w.frame_start_rank = c.take<int>(frames + 1);
     w.out_base = c.take<int>(frames + 1);
     w.bytes = c.total();
@@ -503,8 +518,8 @@ extern "C" int s2d_voxelize_batch_run(const float *points, int frames, const int
         S2D_CHECK_ARG(p.grid[j] > 0, "voxelize_batch: empty grid on axis %d", j);
         cells *= p.grid[j];
     }
-    if (cells >= 4294967295.0) {
-        set_error("voxelize_batch: grid of %.0f cells exceeds the 32-bit key space", cells);
+    if (cells >= (double)VOX_EMPTY) {
+        set_error("voxelize_batch: grid of %.0f cells exceeds the key space", cells);
         return S2D_ERR_UNSUPPORTED;
     }
     p.ndim = ndim; p.max_points = max_points; p.max_voxels = max_voxels; p.table_mask = 0; p.table_shift = 0;
@@ -537,21 +552,18 @@ extern "C" int s2d_voxelize_batch_run(const float *points, int frames, const int
         return S2D_OK;
     }
     const int n = (int)n_points;
-    S2D_HIP(hipMemsetAsync(w.keys, 0xFF, w.table_total * sizeof(uint32_t), st));
-    S2D_HIP(hipMemsetAsync(w.first, 0x7F, w.table_total * sizeof(int), st));
-    S2D_HIP(hipMemsetAsync(w.ksmall, 0x7F, (size_t)rows * max_points * sizeof(int), st));
+    S2D_HIP(hipMemsetAsync(w.keys, 0x7F, w.clear_bytes, st));
     const dim3 blk(256);
     hipLaunchKernelGGL(voxb_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, vb, w.keys, w.first, w.pt_slot);
     S2D_LAUNCH_CHECK();
     FirstFlagIn fin{w.pt_slot, w.first};
     VoxbRankOut fout{w.pt_slot, w.rank_of_slot, w.frame_start_rank, vb, n};
-    int rc = device_exclusive_scan(fin, fout, n_points, w.block_sums, w.total, st);
+    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base);
-    S2D_HIP(hipMemcpyAsync(out_base, w.out_base, sizeof(int32_t) * (frames + 1), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base, out_base);
     hipLaunchKernelGGL(voxb_assign_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.keys, w.rank_of_slot, w.frame_start_rank,
                        w.out_base, n, p, vb, w.vid, coors4);
-    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.vid, n, max_points, w.ksmall);
+    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.vid, n, max_points, w.ksmall);
     hipLaunchKernelGGL(voxb_fill_kernel, dim3((unsigned)ceil_div(rows * max_points, 256)), blk, 0, st, points, w.ksmall, w.out_base, frames, ndim,
                        max_points, voxels, num_points);
     if (mean)
