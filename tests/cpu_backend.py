@@ -14,6 +14,17 @@ from oracle import voxelize as OV
 from sparse2dense_amd import hip_ops as H
 
 
+# bf16-STORAGE emulation of the sparse stack (the product's benchmarked "s16" mode): with STORAGE_BF16[0] set, every tensor the product
+# writes as bf16 rows - conv outputs (forward and data gradient), fused BN(+residual)(+ReLU) outputs and their gradients - and every
+# operand its kernels read as bf16 (features, packed weights) is rounded to bf16 here, while all arithmetic stays in the tensors'
+# dtype (float64 in the calibration runs): the price of the storage type alone, with exact accumulation.
+STORAGE_BF16 = [False]
+
+
+def _st(x):
+    return x.to(torch.bfloat16).to(x.dtype) if STORAGE_BF16[0] and x is not None else x
+
+
 def _pairs_to_maps(pairs, n_in, n_out, want_in):
     kvol = len(pairs)
     nbr_out = np.full((kvol, n_out), -1, np.int32)
@@ -59,15 +70,17 @@ def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag=
         weight_kio = weight_kio.flip(0)
     if transpose:
         weight_kio = weight_kio.transpose(1, 2)
+    feat, weight_kio = _st(feat), _st(weight_kio)
     out = feat.new_zeros((n_out, weight_kio.shape[2]))
     for k in range(weight_kio.shape[0]):
         o = (nbr[k] >= 0).nonzero().squeeze(1)
         if o.numel():
             out.index_add_(0, o, feat[nbr[k][o].long()] @ weight_kio[k])
-    return out + bias if bias is not None else out
+    return _st(out + bias if bias is not None else out)
 
 
 def spconv_wgrad(feat, dout, nbr, kvol, pair_count=None):
+    feat, dout = _st(feat), _st(dout)
     dw = feat.new_zeros((kvol, feat.shape[1], dout.shape[1]))
     for k in range(kvol):
         o = (nbr[k] >= 0).nonzero().squeeze(1)
@@ -124,7 +137,7 @@ def bn1d_apply(x, scale, shift, residual=None, relu=False):
     y = x * scale + shift
     if residual is not None:
         y = y + residual
-    return y.relu() if relu else y
+    return _st(y.relu() if relu else y)
 
 
 def bn1d_bwd_reduce(dy, y, x, relu, want_g=True):
@@ -133,7 +146,7 @@ def bn1d_bwd_reduce(dy, y, x, relu, want_g=True):
 
 
 def bn1d_bwd_apply(g, x, a, b, d):
-    return a * g + b * x + d
+    return _st(a * g + b * x + d)
 
 
 def densify(feat, coors, batch, shape):

@@ -105,15 +105,22 @@ def bf16_emulation_copy(module):
         for mod in m.modules():
             if isinstance(mod, (nn.Conv2d, nn.ConvTranspose2d)):
                 mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
+    add_bf16_storage_hooks(m)
+    return m
+
+
+def add_bf16_storage_hooks(m):
+    """in place: the 2-D leaf layers of `m` round their output (and the gradient flowing back through it) to bf16"""
+    from torch import nn
     leaf2d = (nn.Conv2d, nn.ConvTranspose2d, nn.BatchNorm2d, nn.GELU, nn.ReLU, nn.LayerNorm)
 
     def hook(_mod, _inp, out):
         return _RoundBf16STE.apply(out) if torch.is_tensor(out) and out.dim() == 4 else out
 
-    for mod in m.modules():
-        if isinstance(mod, leaf2d):
-            mod.register_forward_hook(hook)
-    return m
+    # the last conv of a head branch (1-3 output channels) writes fp32 planar predictions in the product: not rounded
+    handles = [mod.register_forward_hook(hook) for mod in m.modules()
+               if isinstance(mod, leaf2d) and not (isinstance(mod, nn.Conv2d) and mod.out_channels < 8)]
+    return handles
 
 
 def rel_err(a, b):

@@ -151,6 +151,105 @@ def oracle_run_bn_eval(setup):
     return res
 
 
+@pytest.fixture(scope="module")
+def oracle_run_bn_eval_bf16_storage(setup):
+    """the float64 oracle stack of `oracle_run_bn_eval` with the product's bf16 STORAGE points restated and nothing else changed:
+    sparse rows (cpu_backend.STORAGE_BF16: conv outputs forward and backward, fused BN outputs and their gradients, bf16 weight
+    images), 2-D neck / head layer outputs and their gradients + bf16 conv weights (golden_util.add_bf16_storage_hooks); accumulation,
+    statistics, losses and the 3-D PCR head exact.  Its distance to the exact run is what bf16 storage costs ANY arithmetic."""
+    import cpu_backend
+    from golden_util import add_bf16_storage_hooks
+    ex, teacher, student = setup
+    mp = pytest.MonkeyPatch()
+    try:
+        cpu_backend.install(mp)
+        mp.setattr(cpu_backend, "STORAGE_BF16", [True])
+        t64, s64 = copy.deepcopy(teacher).double(), _bn_eval(copy.deepcopy(student).double().train())
+        with torch.no_grad():
+            for m in (t64, s64):
+                for mod in list(m.neck.modules()) + list(m.bbox_head.modules()):
+                    if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                        mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
+        for m in (t64, s64):
+            add_bf16_storage_hooks(m.neck)
+            add_bf16_storage_hooks(m.bbox_head)
+        ex64 = _to(ex, "cpu", torch.float64)
+        feats = {}
+        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
+        total, losses = distill_loss(t64, s64, ex64)
+        total.backward()
+        hook.remove()
+        res = dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS}, F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
+                   grads={n: p.grad.clone() for n, p in s64.named_parameters() if p.grad is not None})
+    finally:
+        mp.undo()
+    return res
+
+
+def test_distill_step_bf16_mode_against_the_bf16_storage_oracle(setup, oracle_run_bn_eval, oracle_run_bn_eval_bf16_storage):
+    """what the benchmarked mode's early-backbone gradient gap (1e-1 .. 5e-1 against the exact float64 oracle) IS.
+    r04 decomposition on the GPU (scratch run, same fixture): fp32 sparse + bf16 dense neck -> conv1 4.4e-1; bf16 sparse + fp32
+    dense -> 1.2e-1; fp32 gradient ROWS change nothing (oracle experiment: backward-only rounding 7e-3, forward-only 5e-2).  The
+    deviation is produced by bf16 rounding of FORWARD activations: ~0.5 % of the ReLU / GELU' decisions flip, each flip switches a
+    gradient path on or off, and the white noise this adds to dBEV (8e-2 norm-wise) is damped less than the coherent signal on its
+    way back through 20 sparse layers.  It is a property of the storage type, not of a kernel - shown here by restating ONLY the
+    storage roundings in the float64 CPU stack:
+      (a) `spread` = bf16-storage oracle vs exact oracle, i.e. how far the REFERENCE arithmetic itself moves under bf16 storage.
+          Measured: conv_input 2.1e-1, conv1 4.8e-1, conv2 2.2e-1, conv3 9.0e-2, conv4 3.6e-2, LayerNorm scales 1.9e-1, everything
+          else <= 4.6e-2 - the same figures the GPU shows against the exact oracle (2.1e-1, 4.1e-1, 2.1e-1, 7.7e-2, 4.2e-2, 1.9e-1).
+          The amplification is in the (exact) backward pass: with an fp32 sparse stack and only the neck in bf16 the error still
+          doubles per sparse stage on the way back (2.7e-2 at extra_conv -> 4.4e-1 at conv1);
+      (b) where the problem is well conditioned (spread <= 3e-2: RPN trunk, up-samplers, fusion convs, PCR head, CenterHead - 150+
+          tensors) the GPU matches the bf16-storage oracle to <= 5e-2 (measured <= 1.7e-2): the kernels compute what the storage
+          type prescribes.  Where it is not, two bf16-storage runs that differ only in ACCUMULATION precision (fp32 on the GPU,
+          exact here) already differ by as much as either differs from the exact run (conv1 4.2e-1): the early-stage gradient of this
+          randomly initialised student is 2:1 signal to flip-noise under bf16 storage, whoever computes it;
+      (c) GPU vs the exact oracle stays inside 2 x spread + 5e-2 for every tensor.
+    The fp32 mode of the same step holds 5e-2 on every tensor (first test of this file) and is benchmarked beside the bf16 number
+    (`other_workloads.s2d_student_fp32`)."""
+    ex, teacher, student = setup
+    exact, emul = oracle_run_bn_eval, oracle_run_bn_eval_bf16_storage
+    t, s = copy.deepcopy(teacher).to(DEV), _bn_eval(copy.deepcopy(student).to(DEV).train())
+    for m in (t, s):
+        m.dense_dtype = torch.bfloat16
+        m.use_channels_last()
+    H.set_sparse_compute_dtype("s16")
+    try:
+        total, losses = distill_loss(t, s, ex)
+        total.backward()
+    finally:
+        H.set_sparse_compute_dtype("f32")
+    names = [n for n, p in s.named_parameters() if p.grad is not None and exact["grads"][n].norm() > 1e-8]
+    grads = dict(s.named_parameters())
+    spread = {n: _rel(emul["grads"][n], exact["grads"][n]) for n in names}
+    vs_emul = {n: _rel(grads[n].grad, emul["grads"][n]) for n in names}
+    vs_exact = {n: _rel(grads[n].grad, exact["grads"][n]) for n in names}
+
+    def group(d):
+        g = {}
+        for n, e in d.items():
+            k = ".".join(n.split(".")[:2])
+            g[k] = max(g.get(k, 0.0), e)
+        return {k: f"{v:.1e}" for k, v in g.items()}
+    print("spread of the float64 stack under bf16 storage:", group(spread))
+    print("GPU vs bf16-storage oracle:", group(vs_emul))
+    print("GPU vs exact oracle:", group(vs_exact))
+    lerr = {k: abs(float(losses[k][0]) - emul["terms"][k]) / (abs(emul["terms"][k]) + 1e-12) for k in TERMS}
+    assert max(lerr.values()) <= 2e-2, lerr
+
+    well = [n for n in names if spread[n] <= 3e-2]
+    assert len(well) >= 120, len(well)
+    over = {n: (vs_emul[n], spread[n]) for n in well if vs_emul[n] > 5e-2}
+    assert not over, over
+    loose = {n: (vs_exact[n], spread[n]) for n in names if vs_exact[n] > 2 * spread[n] + 5e-2}
+    assert not loose, loose
+    # the storage type, not the kernels, sets the early-stage figures: the reference arithmetic moves at least half as far
+    for stage in ("backbone.conv_input", "backbone.conv1", "backbone.conv2"):
+        sp = max(spread[n] for n in names if n.startswith(stage + "."))
+        ge = max(vs_exact[n] for n in names if n.startswith(stage + "."))
+        assert sp >= 0.5 * ge, (stage, sp, ge)
+
+
 def test_distill_step_bf16_mode_well_conditioned_gradients_within_stated_tolerance(setup, oracle_run_bn_eval):
     """the BENCHMARKED mode (bf16 sparse storage + bf16 NHWC dense kernels) of the whole distillation step with
     the student's batch norms on their running statistics, against the float64 oracle stack (NO rounding emulation: this is the
