@@ -303,6 +303,8 @@ int s2d_conv2d3x3_pack_weights_bf16(const float *weight, int cin, int cout, int 
  * outputs per channel — the statistics pass of a following batch norm, produced in the conv epilogue; finish it with
  * s2d_bn_partials_finalize_f32 (or s2d_bn_partials_sum_f32 -> all-reduce -> s2d_bn1d_finalize_fwd_f32). */
 int64_t s2d_conv2d3x3_stats_tiles(int n_img, int h, int w, int cin, int cout, int pad, int stride);
+/* output pixels per workgroup tile of the launch plan for this shape (= rows per BN-statistics slab) */
+int s2d_conv2d3x3_tile_rows(int n_img, int h, int w, int cin, int cout, int pad, int stride);
 int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias,
                             const void *zero_page, int n_img, int h, int w, int cin, int cout,
                             int pad, int stride, void *y, float *stats_partial, s2d_stream_t stream);

@@ -200,6 +200,7 @@ SIGNATURES = {
     "s2d_conv2d3x3_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 7),
     "s2d_conv2d3x3_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_conv2d3x3_tile_rows": (ctypes.c_int, [ctypes.c_int] * 7),
     "s2d_conv2d3x3_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p] +
                                 [ctypes.c_int] * 7 + [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_bn_partials_finalize_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p,

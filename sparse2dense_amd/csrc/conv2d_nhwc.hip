@@ -319,6 +319,15 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 // dense taps per class, no zero taps.  KS = 4: the forward of ConvTranspose2d(4,2,1) (2 x 2 taps per class); KS = 3: the data
 // gradient of a stride-2 3x3 conv (1, 2, 2, 4 taps).  The weight image lists the classes one after another, each in the window's
 // row-major order (conv2d_pack_up_kernel); H, W are the SOURCE grid in that mode (pad / stride unused).
+// r04 measurements on this kernel (128 -> 128 @ 4 x 188^2, 59.6 us = 700 TFLOP/s), ablations built as template flags and removed again:
+//   MFMAs only (no staging, no fragment reads) 32.3 us | + fragment reads 40.9 | + staging (no reads) 48.8 | staging only 42.4 | no MFMAs 42.8
+// i.e. the three streams add up instead of overlapping, and the MFMA-only floor is already 2 x the 17 us of the 2.5 PFLOP/s peak
+// (clock ~1.9 GHz under this load, 4.3 tiles per CU = 5 rounds, per-tile prologue / epilogue).  Tried and dropped (all bit-identical):
+//   * taller tiles on this kernel, MI = 6 / 8 (192 / 256 pixels, 2 workgroups per CU): 61 / 67 us;
+//   * a tall-tile kernel sharing the A tile between the three kx taps (288 pixels per workgroup, A staged 3 x instead of 9 x, weights
+//     once per 288 pixels: 250 MB of LDS-DMA per launch instead of 636 MB): 58-60 us; with all 13 fragment reads of a sub-step issued
+//     up front (hipcc had paired them with lgkmcnt(0) waits) 58 us; with the LDS-DMA pieces interleaved one per MFMA row group 61 us.
+//     Fewer staged bytes and fewer pieces per MFMA did not move the launch: the limit is not the L2 -> LDS byte rate.
 template <int BN, int MI, int KS = 3, bool UP = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                     const float *__restrict__ bias,
@@ -736,6 +745,12 @@ static int conv_tile_rows(int64_t m, int cin, int cout, int pad, int stride) {
     const int bn = conv_bn(cout);
     if (conv_use_shared_a(cin, bn, pad, stride) || !conv_use_k32(bn)) return 128;
     return bn == 128 ? conv_k32_rows(m, cout / bn) : 128;
+}
+
+extern "C" int s2d_conv2d3x3_tile_rows(int n_img, int h, int w, int cin, int cout, int pad, int stride) {
+    if (!s2d_conv2d3x3_supported(cin, cout) || n_img <= 0 || h + 2 * pad < 3 || w + 2 * pad < 3 || stride < 1) return 0;
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    return conv_tile_rows((int64_t)n_img * ho * wo, cin, cout, pad, stride);
 }
 
 extern "C" int64_t s2d_conv2d3x3_stats_tiles(int n_img, int h, int w, int cin, int cout, int pad, int stride) {

@@ -195,8 +195,7 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
     if H.PROFILE is not None:   # bench.py roofline pass: HIP events on the launch stream
         rec = dict(kernel="conv3x3_nhwc_bf16", tag="dense", cin=cin, cout=cout, n_out=n * ho * wo, kvol=9, pairs=None,
                    dense=True, in_pixels=n * h * w, pad=pad, stride=stride,
-                   tile_rows=next(bm for bm in (128, 96, 64)
-                                  if -(-n * ho * wo // bm) == lib.s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, stride)),
+                   tile_rows=lib.s2d_conv2d3x3_tile_rows(n, h, w, cin, cout, pad, stride),
                    start=torch.cuda.Event(enable_timing=True),
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
