@@ -91,6 +91,12 @@ class GradBuckets:
             cur.append(p); cur_bytes += nb; cur_key = key
         if cur:
             self._close(cur)
+        # r04: the buckets travel on THEIR OWN process group (communicator).  On the default group a bucket that `_launch_ready` holds
+        # back on one rank (a parameter without a gradient there) would be issued AFTER SyncBN-backward all-reduces which another rank
+        # issues BEFORE it - two ranks with different collective sequences on one communicator.  With a group of their own the bucket
+        # sequence is 0, 1, 2, ... on every rank and the SyncBN sequence is the autograd order on every rank, each on its own
+        # communicator (and, with NCCL/RCCL, its own stream).  Created collectively: every rank constructs its GradBuckets at the same point.
+        self.group = dist.new_group() if (dist.is_available() and dist.is_initialized()) else None
         self._handles = []
         self._next, self.launch_log = 0, []
         for bi, b in enumerate(self.buckets):
@@ -136,7 +142,7 @@ class GradBuckets:
                 src.append(p.grad); dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-        b["work"] = dist.all_reduce(b["flat"], async_op=True)   # c10d: ordered after the copies, runs on its own stream
+        b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)   # c10d: ordered after the copies, runs on its own stream
         b["launched"] = True
         self.launch_log.append(b["index"])
 

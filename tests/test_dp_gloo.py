@@ -221,6 +221,72 @@ def test_buckets_launch_in_index_order_when_an_early_bucket_has_no_gradient_on_o
         torch.testing.assert_close(r0[n], p.grad, rtol=1e-9, atol=1e-12, msg=n)
 
 
+def _worker_order_syncbn(rank, world, port, out_dir):
+    """self-synchronising batch norms on BOTH sides of a parameter that gets no gradient on rank 1.  Rank 0
+    launches bucket 0 from its hook, between the SyncBN-backward all-reduces of bn2 and bn1; rank 1 holds it (and every later bucket)
+    back until finish(), i.e. behind ALL SyncBN collectives.  On one communicator the two ranks' sequences differ; with the buckets
+    on their own process group (r04) both sequences are the same on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), S2D_DP_MODE="overlap", S2D_BUCKET_MB="0.00001")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    import cpu_backend
+    from sparse2dense_amd import collective, dp
+    from sparse2dense_amd.spconv import FeatureBatchNorm1d
+    from sparse2dense_amd.train_step import backward_and_clip
+    cpu_backend.install(None)
+    dp.init_distributed("gloo")
+    calls = []
+    orig = collective.allreduce_sum_
+    collective.allreduce_sum_ = lambda t: (calls.append(int(t.numel())), orig(t))[1]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 8)
+            self.bn1 = FeatureBatchNorm1d(8)
+            self.b = torch.nn.Linear(8, 16)
+            self.bn2 = FeatureBatchNorm1d(16)
+            self.c = torch.nn.Linear(16, 4)
+            self.gate = torch.nn.ParameterList([torch.nn.Parameter(torch.ones(16))])   # registered last -> bucket 0, consumed between bn2 and c
+
+        def forward(self, x, use_gate):
+            h = self.bn2(self.b(self.bn1(self.a(x), relu=True)), relu=True)
+            if use_gate:
+                h = h * self.gate[0]
+            return self.c(h).sum()
+
+    torch.manual_seed(13)
+    net = dp.wrap_ddp(Net().double())
+    gb = net._s2d_grad_buckets
+    assert gb.group is not None and gb.group is not dist.group.WORLD
+    assert gb.buckets[0]["params"][0] is net.gate[0]
+    for step in range(2):
+        x = torch.randn(6, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(40 + rank + 2 * step))
+        calls.clear()
+        loss = net(x, use_gate=(rank == 0))
+        backward_and_clip(loss, list(net.parameters()), max_norm=1e30)
+        assert gb.launch_log == list(range(len(gb.buckets))), gb.launch_log
+        assert len(calls) == 4, calls          # two SyncBN layers: one forward and one backward vector each, on the DEFAULT group
+    torch.save({n: p.grad.clone() for n, p in net.named_parameters()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_held_back_bucket_cannot_cross_pair_with_syncbn_collectives():
+    port = 36400 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_order_syncbn, args=(2, port, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    assert set(r0) == set(r1)
+    for n in r0:
+        torch.testing.assert_close(r0[n], r1[n], rtol=1e-12, atol=1e-14, msg=n)
+        assert torch.isfinite(r0[n]).all()
+    assert float(r0["gate.0"].abs().sum()) > 0      # rank 0's gradient of the gated parameter, averaged with rank 1's zeros
+
+
 def test_direct_rccl_route_falls_back_on_every_rank_when_unavailable():
     """collective.init_direct on a non-NCCL process group: returns False and leaves the torch.distributed route on
     (the agreement all-reduce itself needs a GPU; on gloo the early exit is what every rank takes)."""
