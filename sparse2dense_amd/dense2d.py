@@ -101,6 +101,8 @@ def register_repack(weight, variants, src, launch):
     if src.data_ptr() != weight.data_ptr() or src.dtype != weight.dtype:
         return
     for v in variants:
+        if _repack.get((id(weight), v)) is not launch:   # a re-packed weight: a captured graph would replay into the OLD image
+            _repack_state.update(sig=None, graph=None, last=None, stable=0)
         _repack[(id(weight), v)] = launch
 
 
@@ -109,7 +111,7 @@ def refresh_pack_cache():
     mode = os.environ.get("S2D_PACK_GRAPH", "0")
     if mode == "off":
         return clear_pack_cache()
-    launches = {}
+    launches, sig_items = {}, []
     for key, ent in list(_pack_cache.items()):
         w = ent[0]()
         if w is None or ent[1] != w.data_ptr() or ent[2] != w._version:
@@ -121,6 +123,7 @@ def refresh_pack_cache():
                 del ent[3][v]            # no single-launch rebuild registered (sparse images, derived matrices): rebuilt at the next use
             elif w.requires_grad:
                 launches[id(fn)] = fn    # one launch may fill two variants (forward + data-gradient operand)
+                sig_items.append((key, v, ent[1], id(fn)))   # (weight, variant, weight storage, closure): closure ids alone can be recycled
         if not ent[3]:
             _pack_cache.pop(key, None)
     for k in [k for k in _repack if k[0] not in _pack_cache]:
@@ -128,7 +131,7 @@ def refresh_pack_cache():
     if not launches:
         return
     st = _repack_state
-    sig = tuple(sorted(launches))
+    sig = tuple(sorted(sig_items, key=repr))
     if st["graph"] is not None and st["sig"] == sig:
         st["graph"].replay()
         return

@@ -208,8 +208,13 @@ class OneCycleAdam:
         # Everything that only depends on the parameter set (layout checks, element counts, the pointer tables of parameters and
         # moments, the launch chunks) is built once and reused while the same parameters, in the same order, receive gradients: the
         # per-step host work in front of the first launch was ~0.9 ms of an otherwise idle device (rocprofv3 gaps, r03).
-        ids = tuple(map(id, ps)) + (ps[0].data_ptr(), ps[-1].data_ptr())   # (+ a cheap guard against re-seated parameter storage)
+        # The cache holds RAW device pointers: it is keyed on every parameter's storage pointer, and the moments' pointers are
+        # re-read below - a parameter re-seated after the first step (use_channels_last(), load_state_dict(assign=True), p.data = ...)
+        # or a moment replaced from outside must never be reached through a stale pointer.
+        ids = tuple(map(id, ps)) + tuple(p.data_ptr() for p in ps)
         c = self._hip_cache if getattr(self, "_hip_cache", None) is not None and self._hip_cache["ids"] == ids else None
+        if c is not None and any((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) != mv for st, mv in zip(c["states"], c["moments"])):
+            c = None
         cap = lib.s2d_adam_max_tensors()
         vp = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
         if c is None:
