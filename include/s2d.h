@@ -715,6 +715,25 @@ int s2d_comm_ranks(void);
 int s2d_comm_shutdown(void);
 int s2d_comm_allreduce_sum_f32(float *buf, int64_t count, s2d_stream_t stream);
 
+/* ---- fused PointPillars feature net (r04) ----------------------------------------------------------------------------------
+ * One PFN layer of det3d/models/readers/pillar_encoder.py:41-56,114-154 (decorate -> Linear(10 -> 64) -> BatchNorm1d -> ReLU -> max over
+ * the slots) from the raw pillars voxels[P][slots][5], num_points[P], coors[P][4] (b,z,y,x), recomputing the per-row products in every
+ * pass instead of storing [P,slots,64] tensors.  _stats: per-workgroup partial slabs [s2d_pfn_blocks(P)][2][64] (fold with
+ * s2d_bn_partials_sum_f32, n = P * slots rows).  _apply_max: out[P][64] and the slot of the maximum (uint8, first maximum).  _bwd: per-
+ * workgroup rows of s2d_pfn_bwd_cols() floats: sum g[64] | sum g*h[64] | M1[10][64] | M2[10][64] | M3[10] (dout must already carry relu').
+ */
+int s2d_pfn_supported(int ndim, int slots, int feats, int cout);
+int s2d_pfn_blocks(int64_t pillars);
+int s2d_pfn_bwd_cols(void);
+int s2d_pfn_stats_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *weight, int64_t pillars,
+                      int slots, int ndim, float vx, float vy, float x_offset, float y_offset, float *partial, s2d_stream_t stream);
+int s2d_pfn_apply_max_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *weight, const float *scale,
+                          const float *shift, int64_t pillars, int slots, int ndim, float vx, float vy, float x_offset, float y_offset,
+                          float *out, uint8_t *argmax, s2d_stream_t stream);
+int s2d_pfn_bwd_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *weight, const float *dout,
+                    const uint8_t *argmax, int64_t pillars, int slots, int ndim, float vx, float vy, float x_offset, float y_offset,
+                    float *partial, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

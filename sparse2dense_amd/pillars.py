@@ -72,6 +72,85 @@ def _row_linear(x, linear):
     return linear(x)
 
 
+class _FusedPfnFn(torch.autograd.Function):
+    """decorate -> Linear(10 -> 64) -> BatchNorm1d -> ReLU -> max over the slots on csrc/pfn.hip (pillar_encoder.py:41-56,114-154): two
+    forward passes and one backward pass over the raw pillars, the per-row products recomputed in each - no [P,20,10] / [P,20,64]
+    tensor exists.  Train-mode statistics run over all P*slots rows (empty slots hold zeros), like the reference's BatchNorm1d on the
+    [P,64,20] tensor; with torch.distributed up they are all-reduced like every other batch norm of the path."""
+
+    @staticmethod
+    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, bn, geo):
+        from . import _lib, collective
+        from . import hip_ops as H
+        from .dense2d import _ptr, _stream
+        lib = _lib.load()
+        voxels, weight = voxels.contiguous(), weight.contiguous()
+        num_points = num_points.int().contiguous()
+        coors = coors.int().contiguous()
+        p, t, nd = voxels.shape
+        dev = voxels.device
+        vx, vy, xo, yo = geo
+        args = (p, t, nd, float(vx), float(vy), float(xo), float(yo))
+        training = bn.training or not bn.track_running_stats
+        count = torch.full((1,), float(p * t), device=dev)
+        if training:
+            partial = torch.empty((lib.s2d_pfn_blocks(p), 2, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.s2d_pfn_stats_f32(_ptr(voxels), _ptr(num_points), _ptr(coors), _ptr(weight), *args, _ptr(partial), _stream()), "s2d_pfn_stats_f32")
+            stats = partial.sum(0).reshape(128)
+            sync = collective.sync_on()
+            if sync:
+                packed = torch.cat([stats, count])
+                collective.allreduce_sum_(packed)
+                stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+            track = bn.track_running_stats
+            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None,
+                                      bn.running_var if track else None, bn.num_batches_tracked if track else None)
+            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
+        else:
+            sync = False
+            invstd = torch.rsqrt(bn.running_var + bn.eps)
+            mean = bn.running_mean
+            scale = (gamma * invstd).contiguous()
+            shift = (beta - mean * scale).contiguous()
+        out = torch.empty((p, 64), dtype=torch.float32, device=dev)
+        arg = torch.empty((p, 64), dtype=torch.uint8, device=dev)
+        _lib.check(lib.s2d_pfn_apply_max_f32(_ptr(voxels), _ptr(num_points), _ptr(coors), _ptr(weight), _ptr(scale), _ptr(shift), *args, _ptr(out),
+                                             _ptr(arg), _stream()), "s2d_pfn_apply_max_f32")
+        ctx.save_for_backward(voxels, num_points, coors, weight, gamma, mean, invstd, count, out, arg)
+        ctx.args, ctx.training, ctx.sync = args, training, sync
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib, collective
+        from . import hip_ops as H
+        from .dense2d import _ptr, _stream
+        lib = _lib.load()
+        voxels, num_points, coors, weight, gamma, mean, invstd, count, out, arg = ctx.saved_tensors
+        p = voxels.shape[0]
+        g = (dout * (out > 0)).contiguous()      # relu'(0) = 0, as torch
+        cols = lib.s2d_pfn_bwd_cols()
+        partial = torch.empty((lib.s2d_pfn_blocks(p), cols), dtype=torch.float32, device=voxels.device)
+        _lib.check(lib.s2d_pfn_bwd_f32(_ptr(voxels), _ptr(num_points), _ptr(coors), _ptr(weight), _ptr(g), _ptr(arg), *ctx.args, _ptr(partial), _stream()),
+                   "s2d_pfn_bwd_f32")
+        row = partial.sum(0)
+        sums = row[:128].contiguous()                     # sum g | sum g*h per channel
+        m1, m2, m3 = row[128:768].view(10, 64).t(), row[768:1408].view(10, 64).t(), row[1408:1418]
+        if ctx.training:
+            sums_all = sums
+            if ctx.sync:
+                sums_all = sums.clone()
+                collective.allreduce_sum_(sums_all)
+            fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+            dgamma, dbeta, a, b, d = fin[0], fin[1], fin[2], fin[3], fin[4]
+            dw = a[:, None] * m1 + b[:, None] * m2 + d[:, None] * m3[None, :]
+        else:
+            dbeta = sums[:64]
+            dgamma = invstd * (sums[64:] - mean * sums[:64])
+            dw = (gamma * invstd)[:, None] * m1
+        return None, None, None, dw.contiguous(), dgamma, dbeta, None, None
+
+
 class PFNLayer(nn.Module):
     def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
         super().__init__()
@@ -115,8 +194,24 @@ class PillarFeatureNet(nn.Module):
         self.x_offset = self.vx / 2 + pc_range[0]
         self.y_offset = self.vy / 2 + pc_range[1]
 
+    def _fused_ok(self, features):
+        """one PFN layer 10 -> 64 on fp32 device pillars: the fused kernels (S2D_PFN_FUSED=0 keeps the layer-by-layer path)"""
+        import os
+        if os.environ.get("S2D_PFN_FUSED", "1") == "0" or len(self.pfn_layers) != 1 or self._with_distance:
+            return False
+        lyr = self.pfn_layers[0]
+        if not (features.is_cuda and features.dtype == torch.float32 and features.dim() == 3 and features.shape[0] > 0
+                and isinstance(lyr.norm, FeatureBatchNorm1d) and lyr.norm.momentum is not None and not torch.is_autocast_enabled()):
+            return False
+        from . import _lib
+        return bool(_lib.load().s2d_pfn_supported(features.shape[2], features.shape[1], lyr.linear.in_features, lyr.units))
+
     def forward(self, features, num_voxels, coors):
         dtype = features.dtype
+        if self._fused_ok(features):
+            lyr = self.pfn_layers[0]
+            return _FusedPfnFn.apply(features, num_voxels, coors, lyr.linear.weight, lyr.norm.weight, lyr.norm.bias, lyr.norm,
+                                     (self.vx, self.vy, self.x_offset, self.y_offset)).squeeze()
         mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_voxels.type_as(features).view(-1, 1, 1)
         f_cluster = features[:, :, :3] - mean
         f_center = torch.zeros_like(features[:, :, :2])
