@@ -715,6 +715,26 @@ int s2d_comm_ranks(void);
 int s2d_comm_shutdown(void);
 int s2d_comm_allreduce_sum_f32(float *buf, int64_t count, s2d_stream_t stream);
 
+/* ---- r04: bf16 storage of the raw PCR up-sampler outputs ---------------------------------------------------------------------
+ * (det3d/models/necks/rpn.py:263-296: the outputs of the two ConvTranspose3d layers, 724 MB and 543 MB in fp32 at batch 4, are read by
+ * four passes of the fused level each).  Same contracts as the fp32 entries named alike; only the element type of that tensor changes:
+ * `out_bf16` / `y` / `in_bf16` are bf16 [B][C][cells]; every other tensor, the statistics and all accumulation stay fp32. */
+int s2d_convt3d_mfma_fwd_stats_y16(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h, int w,
+                                   void *out_bf16, float *stats_partial, s2d_stream_t stream);
+int s2d_pointwise_conv_wgrad_norm_x16(const void *in_bf16, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
+                                      int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_fwd_y16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                          const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
+                          float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_bwd_sums_y16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors, const float *feats,
+                               int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8, const float *go_mask,
+                               const float *go_offset, const float *dz, const float *w2, int co, float *grads, float *bn_sums, void *ws,
+                               size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_bwd_apply_y16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors, const float *feats,
+                                int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8, const float *go_mask,
+                                const float *go_offset, const float *dz, const float *w2, int co, const float *abd, float *dy,
+                                s2d_stream_t stream);
+
 /* ---- fused PointPillars feature net (r04) ----------------------------------------------------------------------------------
  * One PFN layer of det3d/models/readers/pillar_encoder.py:41-56,114-154 (decorate -> Linear(10 -> 64) -> BatchNorm1d -> ReLU -> max over
  * the slots) from the raw pillars voxels[P][slots][5], num_points[P], coors[P][4] (b,z,y,x), recomputing the per-row products in every

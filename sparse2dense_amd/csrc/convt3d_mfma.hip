@@ -117,9 +117,31 @@ static inline int ct_chunk_rows(int64_t row_bytes, int rows_per_y, int halo, int
 
 // waves_per_eu(3): the 32 -> 32 instantiation otherwise takes 176 registers (2 waves per SIMD); at 156 a third workgroup per CU overlaps
 // its staging round trip with the others' MFMA / store phases (372 -> 347 us)
-template <int CIN, int NT, int YR>
+// r04: TO = float or __bf16 - the element type of the written output.  The 724 / 543 MB raw outputs of the two up-samplers are read by
+// four passes of the fused PCR level each (losses.hip): stored as bf16 they cost half the bytes; the statistics of the batch norm
+// that follows are taken from the ROUNDED values, like the dense conv epilogue does.
+template <typename TO> struct CtStore;
+template <> struct CtStore<float> {
+    static __device__ __forceinline__ float4 rnd(float4 v) { return v; }
+    static __device__ __forceinline__ float rnd1(float v) { return v; }
+    static __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ void st1(float *p, float v) { *p = v; }
+};
+template <> struct CtStore<__bf16> {
+    static __device__ __forceinline__ float rnd1(float v) { return (float)(__bf16)v; }
+    static __device__ __forceinline__ float4 rnd(float4 v) { return float4{rnd1(v.x), rnd1(v.y), rnd1(v.z), rnd1(v.w)}; }
+    static __device__ __forceinline__ void st4(__bf16 *p, float4 v) {   // v already rounded: the conversions are exact
+        typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+        bf16x4s o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4s *>(p) = o;
+    }
+    static __device__ __forceinline__ void st1(__bf16 *p, float v) { *p = (__bf16)v; }
+};
+
+template <int CIN, int NT, int YR, typename TO = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
-                                                          CtDims s, int xtiles, CtTileMap map, float *__restrict__ out,
+                                                          CtDims s, int xtiles, CtTileMap map, TO *__restrict__ out,
                                                           float *__restrict__ stats_partial) {
     constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
     constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
@@ -217,7 +239,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int r = lane & 15, q = lane >> 4;
     const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
     const int oz = 2 * hz + pz;
-    float *ob = out + (int64_t)n * s.cout * od * oh * ow;
+    TO *ob = out + (int64_t)n * s.cout * od * oh * ow;
+    using ST = CtStore<TO>;
     float st1[NT], st2[NT];   // per-channel (sum, sum of squares) of this lane's outputs: the batch norm that follows skips its statistics pass
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -286,7 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
                     float4 v = *reinterpret_cast<const float4 *>(dst + co * 2 * CT_TX + 4 * x4);
                     const float bv = bias ? bias[co] : 0.f;
                     v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                    *reinterpret_cast<float4 *>(ob + (((int64_t)co * od + oz) * oh + oy) * ow + 2 * x0 + 4 * x4) = v;
+                    v = ST::rnd(v);
+                    ST::st4(ob + (((int64_t)co * od + oz) * oh + oy) * ow + 2 * x0 + 4 * x4, v);
                     na[k] += (v.x + v.y) + (v.z + v.w);
                     nb[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
@@ -299,24 +323,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const int co = nt * 16 + r;
             if (co >= s.cout) continue;
             const float bv = bias ? bias[co] : 0.f;
-            float *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
+            TO *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int c0 = x0 + mt * 16 + 4 * q;
                 if (c0 + 3 < s.w && (ow & 3) == 0) {
-                    float4 lo{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv};
-                    float4 hi{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv};
-                    *reinterpret_cast<float4 *>(orow + 2 * c0) = lo;
-                    *reinterpret_cast<float4 *>(orow + 2 * c0 + 4) = hi;
+                    const float4 lo = ST::rnd(float4{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv});
+                    const float4 hi = ST::rnd(float4{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv});
+                    ST::st4(orow + 2 * c0, lo);
+                    ST::st4(orow + 2 * c0 + 4, hi);
                     st1[nt] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
                     st2[nt] += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c0 + j < s.w) {
-                            const float v0 = acc[0][mt][nt][j] + bv, v1 = acc[1][mt][nt][j] + bv;
-                            orow[2 * (c0 + j)] = v0;
-                            orow[2 * (c0 + j) + 1] = v1;
+                            const float v0 = ST::rnd1(acc[0][mt][nt][j] + bv), v1 = ST::rnd1(acc[1][mt][nt][j] + bv);
+                            ST::st1(orow + 2 * (c0 + j), v0);
+                            ST::st1(orow + 2 * (c0 + j) + 1, v1);
                             st1[nt] += v0 + v1;
                             st2[nt] += v0 * v0 + v1 * v1;
                         }
@@ -987,8 +1011,9 @@ extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h
 
 /* stats_partial (optional, [s2d_convt3d_mfma_stats_tiles][2][cout]): per-block (sum, sum of squares) per output channel of the written
  * output - the statistics pass of the BatchNorm3d that follows (s2d_bn_partials_sum_f32 folds them) */
-extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
-                                          int w, float *out, float *stats_partial, s2d_stream_t stream) {
+template <typename TO>
+static int ct_fwd_launch(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h, int w, TO *out,
+                         float *stats_partial, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && packed && out && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_fwd: bad argument");
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
     CtDims s{batch, d, h, w, cin, cout};
@@ -1002,12 +1027,22 @@ extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, c
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *wp = (const __bf16 *)packed;
     const int nt = (cout + 15) / 16;
-    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
+                                          int w, float *out, float *stats_partial, s2d_stream_t stream) {
+    return ct_fwd_launch<float>(in, packed, bias, batch, cin, cout, d, h, w, out, stats_partial, stream);
+}
+/* r04: the same forward writing its output as bf16 [B][cout][2d][2h][2w] (read by s2d_pcr_level_*_y16) */
+extern "C" int s2d_convt3d_mfma_fwd_stats_y16(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
+                                              int w, void *out_bf16, float *stats_partial, s2d_stream_t stream) {
+    return ct_fwd_launch<__bf16>(in, packed, bias, batch, cin, cout, d, h, w, (__bf16 *)out_bf16, stats_partial, stream);
 }
 
 extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
@@ -1182,8 +1217,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
 // channels: 2.9 GB for the 32 -> 16 layer at [4,32,10,376,376], 0.76 ms).  A lane's 8 K-elements are the two 4-float chunks at
 // p0 + 4q and p0 + 16 + 4q of its plane (the same position permutation on both operands, so the products pair up correctly):
 // every load instruction reads 64 contiguous bytes per plane.  db = the VALU sum of the lane's own dy values.
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ bnp,
+template <int MT, int NT, typename TX = float>
+__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const TX *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ bnp,
                                                             int64_t positions, int batch, int cin, int cout, int steps_per_block,
                                                             float *__restrict__ partial) {
     __shared__ float red[MT * NT * 4 + MT][64];
@@ -1207,9 +1242,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restr
     const int64_t steps = (positions + 31) / 32;
     const int64_t s0 = (int64_t)blockIdx.x * steps_per_block;
     const int64_t s1 = s0 + steps_per_block < steps ? s0 + steps_per_block : steps;
-    const unsigned plane = (unsigned)(positions * 4);
+    const unsigned plane = (unsigned)(positions * 4), xplane = (unsigned)(positions * sizeof(TX));
     for (int b = 0; b < batch; ++b) {
-        const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)b * cin * positions, (unsigned)cin * plane);
+        const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)b * cin * positions, (unsigned)cin * xplane);
         const __amdgpu_buffer_rsrc_t yr = ct_rsrc(dy + (int64_t)b * cout * positions, (unsigned)cout * plane);
         for (int64_t st = s0 + wid; st < s1; st += 4) {
             const int64_t p0 = st * 32 + 4 * q;
@@ -1225,9 +1260,21 @@ __global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const float *__restr
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const unsigned base = (unsigned)(n * 16 + r) * plane + (unsigned)p0 * 4u;
-                lo[MT + n] = ct_load4(xr, ok0 ? base : CT_OOB, 0);
-                hi[MT + n] = ct_load4(xr, ok1 ? base : CT_OOB, 64);
+                if constexpr (sizeof(TX) == 4) {
+                    const unsigned base = (unsigned)(n * 16 + r) * plane + (unsigned)p0 * 4u;
+                    lo[MT + n] = ct_load4(xr, ok0 ? base : CT_OOB, 0);
+                    hi[MT + n] = ct_load4(xr, ok1 ? base : CT_OOB, 64);
+                } else {   // bf16 planes: the lane's two 4-element chunks are 8-byte loads
+                    const unsigned base = (unsigned)(n * 16 + r) * xplane + (unsigned)p0 * 2u;
+                    // (the 8 bytes as ONE 64-bit integer: element access on the float-pair view of a pair of bf16 pairs returned element 0 twice)
+                    const uint64_t l2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(xr, ok0 ? base : CT_OOB, 0, 0));
+                    const uint64_t h2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(xr, ok1 ? base : CT_OOB, 32, 0));
+                    const uint32_t la = (uint32_t)l2, lb = (uint32_t)(l2 >> 32), ha = (uint32_t)h2, hb = (uint32_t)(h2 >> 32);
+                    lo[MT + n] = f32x4m{__builtin_bit_cast(float, la << 16), __builtin_bit_cast(float, la & 0xFFFF0000u),
+                                        __builtin_bit_cast(float, lb << 16), __builtin_bit_cast(float, lb & 0xFFFF0000u)};
+                    hi[MT + n] = f32x4m{__builtin_bit_cast(float, ha << 16), __builtin_bit_cast(float, ha & 0xFFFF0000u),
+                                        __builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xFFFF0000u)};
+                }
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -1336,9 +1383,9 @@ extern "C" int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout,
 }
 
 /* ... with x = relu(in*scale + shift) applied on the fly: in_scale_shift (device, 2*cin) = scale[cin] | shift[cin], or NULL */
-extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
-                                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
-                                                  s2d_stream_t stream) {
+template <typename TX>
+static int pw_wgrad_norm_launch(const TX *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout, int64_t positions,
+                                float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && dout && dweight && batch > 0, "pointwise_conv_wgrad_bf16: bad argument");
     if (!s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, positions)) {
         s2d::set_error("pointwise_conv_wgrad_bf16: unsupported %d -> %d over %lld positions", cin, cout, (long long)positions);
@@ -1355,13 +1402,24 @@ extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)ws;
     if (cin == 128)
-        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8, TX>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
                            partial);
     else
-        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2, TX>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
                            partial);
     hipLaunchKernelGGL(s2d::pw_wgrad_reduce_kernel, dim3((unsigned)s2d::ceil_div((int64_t)cout * (cin + 1), 16)), dim3(256), 0, st, partial, chunks,
                        cin, cout, dweight, dbias);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
+                                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes,
+                                                  s2d_stream_t stream) {
+    return pw_wgrad_norm_launch<float>(in, in_scale_shift, dout, batch, cin, cout, positions, dweight, dbias, ws, ws_bytes, stream);
+}
+/* r04: the same with the input operand stored as bf16 [B][cin][positions] (the bf16 up-sampler output) */
+extern "C" int s2d_pointwise_conv_wgrad_norm_x16(const void *in_bf16, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
+                                                 int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pw_wgrad_norm_launch<__bf16>((const __bf16 *)in_bf16, in_scale_shift, dout, batch, cin, cout, positions, dweight, dbias, ws, ws_bytes, stream);
 }

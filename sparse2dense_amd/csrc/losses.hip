@@ -289,6 +289,53 @@ template <int V> __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_
     }
 }
 
+// r04: the RAW up-sampler outputs y (724 MB / 543 MB in fp32 at batch 4, read by four passes per level) may be stored in bf16: the level
+// kernels take the element type of y as a template parameter; everything they write (z, dy, sums) stays fp32
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __builtin_bit_cast(float, hi16 << 16); }
+template <int V, typename T> __device__ __forceinline__ void buf_load_t(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float (&v)[V]) {
+    if constexpr (sizeof(T) == 4) {
+        buf_load<V>(r, voff, soff, v);
+    } else if constexpr (V == 2) {
+        const uint32_t t = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        v[0] = bf16_bits_to_f32(t & 0xFFFFu); v[1] = bf16_bits_to_f32(t >> 16);
+    } else {
+        const uint64_t t2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        const uint32_t a = (uint32_t)t2, b = (uint32_t)(t2 >> 32);
+        v[0] = bf16_bits_to_f32(a & 0xFFFFu); v[1] = bf16_bits_to_f32(a >> 16);
+        v[2] = bf16_bits_to_f32(b & 0xFFFFu); v[3] = bf16_bits_to_f32(b >> 16);
+    }
+}
+// the V consecutive elements of C planes held the way they were loaded: fp32 as floats, bf16 PACKED (two per register) and unpacked at
+// every use - unpacking at the load kept both forms live and cost the 32-channel backward kernels their occupancy (166 -> 257 registers)
+template <int C, int V, typename T> struct YPack;
+template <int C, int V> struct YPack<C, V, float> {
+    float v[C][V];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int c) { buf_load<V>(r, voff, soff, v[c]); }
+    __device__ __forceinline__ float get(int c, int k) const { return v[c][k]; }
+};
+template <int C, int V> struct YPack<C, V, __bf16> {
+    uint32_t w[C][V / 2];
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int c) {
+        if constexpr (V == 2) {
+            w[c][0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        } else {
+            const uint64_t t2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+            w[c][0] = (uint32_t)t2;
+            w[c][1] = (uint32_t)(t2 >> 32);
+        }
+    }
+    __device__ __forceinline__ float get(int c, int k) const {
+        uint32_t x = w[c][k >> 1];
+        asm volatile("" : "+v"(x));   // opaque: the unpack is redone at each use instead of being hoisted next to the load
+        return __builtin_bit_cast(float, (k & 1) ? (x & 0xFFFF0000u) : (x << 16));
+    }
+};
+
+template <typename T> __device__ __forceinline__ float plane_elem(const T *p) {
+    if constexpr (sizeof(T) == 4) return *p;
+    else return (float)*p;
+}
+
 template <int K>
 __device__ __forceinline__ void block_sums_n(float (&v)[K], float *out) {
     __shared__ float red[4][K];
@@ -671,8 +718,8 @@ __device__ __forceinline__ void pcr_load_norm(const float *__restrict__ bnp, Pcr
     __syncthreads();
 }
 
-template <int C, int CO, int V>
-__global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *__restrict__ y, const float *__restrict__ bnp, const float *__restrict__ hp,
+template <int C, int CO, int V, typename TY = float>
+__global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__restrict__ y, const float *__restrict__ bnp, const float *__restrict__ hp,
                                                                   const float *__restrict__ w2, const float *__restrict__ b2, int64_t cells, int batch,
                                                                   float *__restrict__ z, float *__restrict__ partial,
                                                                   float *__restrict__ zstat_partial) {
@@ -698,16 +745,16 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *_
 #pragma unroll
     for (int q = 0; q < (CO > 0 ? 2 * CO : 1); ++q) zs[q] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
-    const unsigned plane = (unsigned)cells * 4u;
+    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY);
     for (int b = 0; b < batch; ++b) {
-        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * plane);
-        const __amdgpu_buffer_rsrc_t zr = planes_rsrc(CO > 0 ? z + (int64_t)b * CO * cells : y, (CO > 0 ? CO : C) * plane);
+        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * yplane);
+        const __amdgpu_buffer_rsrc_t zr = CO > 0 ? planes_rsrc(z + (int64_t)b * CO * cells, CO * plane) : yr;
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
             asm volatile("" ::: "memory");
-            const unsigned voff = j * (V * 4u);
-            float yv[C][V];
+            const unsigned voff = j * (V * 4u), yoff = j * (V * (unsigned)sizeof(TY));
+            YPack<C, V, TY> yv;
 #pragma unroll
-            for (int c = 0; c < C; ++c) buf_load<V>(yr, voff, c * plane, yv[c]);
+            for (int c = 0; c < C; ++c) yv.load(yr, yoff, c * yplane, c);
             float x[V], za[CO > 0 ? CO : 1][V];
 #pragma unroll
             for (int k = 0; k < V; ++k) x[k] = hw.bm;
@@ -723,7 +770,7 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const float *_
                 float g[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    g[k] = fmaxf(fmaf(yv[c][k], sc, sh), 0.f);
+                    g[k] = fmaxf(fmaf(yv.get(c, k), sc, sh), 0.f);
                     x[k] = fmaf(wc, g[k], x[k]);
                 }
                 if (CO > 0) {
@@ -770,14 +817,14 @@ __global__ __launch_bounds__(64) void pcr_zstats_fold_kernel(const float *__rest
 }
 
 // the site's raw values, post-norm values, logit and offsets
-template <int C>
-__device__ __forceinline__ void pcr_site_eval_norm(const float *__restrict__ y, const PcrHeadW<C> &hw, const PcrNorm<C> &nm, int64_t cells, int b,
+template <int C, typename TY = float>
+__device__ __forceinline__ void pcr_site_eval_norm(const TY *__restrict__ y, const PcrHeadW<C> &hw, const PcrNorm<C> &nm, int64_t cells, int b,
                                                    int64_t cell, float (&yv)[C], float (&gv)[C], float &x, float (&off)[3]) {
     x = hw.bm;
     off[0] = hw.bo[0]; off[1] = hw.bo[1]; off[2] = hw.bo[2];
-    const float *base = y + (int64_t)b * C * cells + cell;
+    const TY *base = y + (int64_t)b * C * cells + cell;
 #pragma unroll
-    for (int c = 0; c < C; ++c) yv[c] = base[(int64_t)c * cells];
+    for (int c = 0; c < C; ++c) yv[c] = plane_elem<TY>(base + (int64_t)c * cells);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         gv[c] = fmaxf(fmaf(yv[c], nm.sc[c], nm.sh[c]), 0.f);
@@ -787,9 +834,9 @@ __device__ __forceinline__ void pcr_site_eval_norm(const float *__restrict__ y, 
     }
 }
 
-template <int C>
+template <int C, typename TY = float>
 __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
-                                                                   PcrGeo geo, const float *__restrict__ y, const float *__restrict__ bnp,
+                                                                   PcrGeo geo, const TY *__restrict__ y, const float *__restrict__ bnp,
                                                                    const float *__restrict__ hp, float *__restrict__ partial) {
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
@@ -808,7 +855,7 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t
         const bool pos = s != 0.f;
         const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
         float yv[C], gv[C], x, off[3];
-        pcr_site_eval_norm<C>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        pcr_site_eval_norm<C, TY>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
         if (pos) {
             acc[0] += 1.f;
             acc[1] += softplusf(-x);
@@ -830,8 +877,8 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t
 
 // pass A (APPLY = false): partial[block][3C+1] = dw_mask(C) | db_mask | sum dG*m (C) | sum dG*m*y (C), nothing written;
 // pass B (APPLY = true):  dy = a*dG*m + b*y + d
-template <int C, int CO, int V, bool APPLY>
-__global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *__restrict__ y, const float *__restrict__ dz, const float *__restrict__ bnp,
+template <int C, int CO, int V, bool APPLY, typename TY = float>
+__global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__restrict__ y, const float *__restrict__ dz, const float *__restrict__ bnp,
                                                                   const float *__restrict__ w2, const float *__restrict__ hp,
                                                                   const float *__restrict__ go_mask, const float *__restrict__ fin,
                                                                   const float *__restrict__ abd, int64_t cells, int batch, float *__restrict__ dy,
@@ -856,17 +903,17 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
 #pragma unroll
     for (int c = 0; c < (APPLY ? 1 : 3 * C + 1); ++c) pw[c] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
-    const unsigned plane = (unsigned)cells * 4u;
+    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY);
     for (int b = 0; b < batch; ++b) {
-        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * plane);
-        const __amdgpu_buffer_rsrc_t dyr = planes_rsrc(APPLY ? dy + (int64_t)b * C * cells : y, C * plane);
-        const __amdgpu_buffer_rsrc_t zr = planes_rsrc(CO > 0 ? dz + (int64_t)b * CO * cells : y, (CO > 0 ? CO : C) * plane);
+        const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * yplane);
+        const __amdgpu_buffer_rsrc_t dyr = APPLY ? planes_rsrc(dy + (int64_t)b * C * cells, C * plane) : yr;
+        const __amdgpu_buffer_rsrc_t zr = CO > 0 ? planes_rsrc(dz + (int64_t)b * CO * cells, CO * plane) : yr;
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
             asm volatile("" ::: "memory");
-            const unsigned voff = j * (V * 4u);
-            float yv[C][V];
+            const unsigned voff = j * (V * 4u), yoff = j * (V * (unsigned)sizeof(TY));
+            YPack<C, V, TY> yv;
 #pragma unroll
-            for (int c = 0; c < C; ++c) buf_load<V>(yr, voff, c * plane, yv[c]);
+            for (int c = 0; c < C; ++c) yv.load(yr, yoff, c * yplane, c);
             float zv[CO > 0 ? CO : 1][V];
             if (CO > 0) {
 #pragma unroll
@@ -879,7 +926,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
             for (int c = 0; c < C; ++c) {
                 const float sc = scv[c], sh = shv[c], wc = wmv[c];
 #pragma unroll
-                for (int k = 0; k < V; ++k) x[k] = fmaf(wc, fmaxf(fmaf(yv[c][k], sc, sh), 0.f), x[k]);
+                for (int k = 0; k < V; ++k) x[k] = fmaf(wc, fmaxf(fmaf(yv.get(c, k), sc, sh), 0.f), x[k]);
             }
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -906,18 +953,18 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
                     float r[V];
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
-                        const float g = fmaf(yv[c][k], sc, sh);
-                        r[k] = fmaf(a, g > 0.f ? o[k] : 0.f, fmaf(bb, yv[c][k], dd));
+                        const float g = fmaf(yv.get(c, k), sc, sh);
+                        r[k] = fmaf(a, g > 0.f ? o[k] : 0.f, fmaf(bb, yv.get(c, k), dd));
                     }
                     buf_store<V>(dyr, voff, c * plane, r);
                 } else {
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
-                        const float g = fmaxf(fmaf(yv[c][k], sc, sh), 0.f);
+                        const float g = fmaxf(fmaf(yv.get(c, k), sc, sh), 0.f);
                         const float om = g > 0.f ? o[k] : 0.f;
                         pw[c] = fmaf(dm[k], g, pw[c]);
                         pw[C + 1 + c] += om;
-                        pw[2 * C + 1 + c] = fmaf(om, yv[c][k], pw[2 * C + 1 + c]);
+                        pw[2 * C + 1 + c] = fmaf(om, yv.get(c, k), pw[2 * C + 1 + c]);
                     }
                 }
             }
@@ -929,9 +976,9 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const float *_
 // sparse pass A (APPLY = false): partial[block][6C+4] = dw_mask(C) | dw_off(3C) | db_mask | db_off(3) | sum corr*m (C) | sum corr*m*y (C);
 //   blockIdx.y selects a group of CG channels whose accumulators the thread keeps (6*CG+4 registers instead of 6*C+4)
 // sparse pass B (APPLY = true):  dy[c][cell] += a[c] * corr[c] * m
-template <int C, int CG, bool APPLY>
+template <int C, int CG, bool APPLY, typename TY = float>
 __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
-                                                                   PcrGeo geo, const float *__restrict__ y, const float *__restrict__ bnp,
+                                                                   PcrGeo geo, const TY *__restrict__ y, const float *__restrict__ bnp,
                                                                    const float *__restrict__ hp, const float *__restrict__ go_mask,
                                                                    const float *__restrict__ go_off, const float *__restrict__ fin,
                                                                    const float *__restrict__ abd, float *__restrict__ dy, float *__restrict__ partial) {
@@ -957,7 +1004,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t
         const bool pos = s != 0.f;
         const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
         float yv[C], gv[C], x, off[3];
-        pcr_site_eval_norm<C>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        pcr_site_eval_norm<C, TY>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
         float dmk = 0.f;
         if (pos) {
             const float sg = sigmoidf(x);
@@ -1051,51 +1098,51 @@ __global__ __launch_bounds__(256) void pcr_level_fold_kernel(const float *__rest
     else bn_sums[t - 4 * C - 4] = r;
 }
 
-template <int C, int CO, int V>
-static int pcr_level_fwd_t(const float *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
+template <int C, int CO, int V, typename TY = float>
+static int pcr_level_fwd_t(const TY *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
                            int64_t m, PcrGeo geo, float *z, float *out8, float *ws, hipStream_t st, float *z_stats = nullptr) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
     float *dense_partial = ws, *sparse_partial = ws + PCRH_DENSE_BLOCKS;
     float *zstat_partial = (CO > 0 && z_stats) ? ws + PCRH_DENSE_BLOCKS + (size_t)PCRH_SPARSE_BLOCKS * 5 : nullptr;   // [nd][2 CO] behind the sparse rows
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
+    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V, TY>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
                        zstat_partial);
     if (zstat_partial) hipLaunchKernelGGL(pcr_zstats_fold_kernel, dim3(2 * CO), dim3(64), 0, st, (const float *)zstat_partial, nd, 2 * CO, z_stats);
-    hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
+    hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C, TY>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
     hipLaunchKernelGGL(pcr_finalize_kernel, dim3(1), dim3(64), 0, st, dense_partial, nd, sparse_partial, ns, (double)n, out8);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
-template <int C, int CO, int V>
-static int pcr_level_bwd_sums_t(const float *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
+template <int C, int CO, int V, typename TY = float>
+static int pcr_level_bwd_sums_t(const TY *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
                                 const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, float *grads,
                                 float *bn_sums, float *ws, hipStream_t st) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
     float *dense_partial = ws, *sparse_partial = ws + (size_t)PCRH_DENSE_BLOCKS * (3 * C + 1);
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false, TY>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
                        geo.batch, nullptr, dense_partial);
     constexpr int CG = C == 32 ? 8 : C;   // channel groups of the sparse pass (accumulator registers)
-    hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask, go_off,
+    hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false, TY>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask, go_off,
                        fin, nullptr, nullptr, sparse_partial);
     hipLaunchKernelGGL((pcr_level_fold_kernel<C>), dim3(6 * C + 4), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, grads, bn_sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
-template <int C, int CO, int V>
-static int pcr_level_bwd_apply_t(const float *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
+template <int C, int CO, int V, typename TY = float>
+static int pcr_level_bwd_apply_t(const TY *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
                                  const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, const float *abd,
                                  float *dy, hipStream_t st) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
     const int nd = (int)std::min<int64_t>(2 * PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true, TY>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
                        dy, nullptr);
     if (m > 0)
-        hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
+        hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true, TY>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
                            coors, feats, m, geo, y, bnp, hp, go_mask, go_off, fin, abd, dy, nullptr);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1112,11 +1159,11 @@ extern "C" size_t s2d_pcr_level_workspace_bytes(int c) {
 
 // y: RAW ConvTranspose3d output [B][C][cells]; bn_scale_shift (device, 2C) = scale[C] | shift[C] of the batch norm that follows it
 // (g = relu(y*scale + shift)); head_params as s2d_pcr_heads_fwd_f32; z[B][co][cells] = w2.g + b2 (co > 0); out8 as s2d_pcr_loss_fwd_f32.
-extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+static int pcr_level_fwd_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
                                      const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
                                      float *z_stats /* [2 co] = sum | sum of squares of z per channel, or NULL */, float *out8, void *ws,
                                      size_t ws_bytes, s2d_stream_t stream) {
-    S2D_CHECK_ARG(y && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
+    S2D_CHECK_ARG(yv && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
                       (co == 0 || (w2 && z)),
                   "pcr_level_fwd: bad argument");
     if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
@@ -1130,18 +1177,37 @@ extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
     float *wsf = (float *)ws;
+    if (y16) {
+        const __bf16 *y = (const __bf16 *)yv;
+        if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2, __bf16>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st, z_stats);
+        if (c == 32) return pcr_level_fwd_t<32, 0, 2, __bf16>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+        return pcr_level_fwd_t<3, 0, 4, __bf16>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
+    }
+    const float *y = (const float *)yv;
     if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st, z_stats);
     if (c == 32) return pcr_level_fwd_t<32, 0, 2>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
     return pcr_level_fwd_t<3, 0, 4>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st);
 }
+extern "C" int s2d_pcr_level_fwd_f32(const float *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                                     const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
+                                     float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_fwd_any(y, 0, bn_scale_shift, head_params, w2, b2, coors, feats, m, batch, c, co, d, h, w, z, z_stats, out8, ws, ws_bytes, stream);
+}
+/* r04: the same level with y stored as bf16 [B][C][cells] (the up-sampler's bf16 output, s2d_convt3d_mfma_fwd_stats_y16) */
+extern "C" int s2d_pcr_level_fwd_y16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                                     const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
+                                     float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_fwd_any(y, 1, bn_scale_shift, head_params, w2, b2, coors, feats, m, batch, c, co, d, h, w, z, z_stats, out8, ws, ws_bytes, stream);
+}
+
 
 // pass A of the backward: grads[4C+4] = dw_mask[C] | dw_off[3][C] | db_mask | db_off[3] and bn_sums[2C] = (sum dG*m, sum dG*m*y) per
 // channel, the batch norm's backward reduction (s2d_bncm_bwd_reduce_f32's output)
-extern "C" int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+static int pcr_level_bwd_sums_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
                                           float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
-    S2D_CHECK_ARG(y && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && grads && bn_sums && batch > 0 && d > 0 && h > 0 && w > 0 &&
+    S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && grads && bn_sums && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_sums: bad argument");
     if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
@@ -1155,21 +1221,43 @@ extern "C" int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
     float *wsf = (float *)ws;
-    if (c == 32 && co == 16)
-        return pcr_level_bwd_sums_t<32, 16, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums,
-                                               wsf, st);
-    if (c == 32)
-        return pcr_level_bwd_sums_t<32, 0, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums, wsf,
-                                              st);
-    return pcr_level_bwd_sums_t<3, 0, 4>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, bn_sums, wsf, st);
+#define S2D_LVL_SUMS(TY_)                                                                                                                       \
+    do {                                                                                                                                         \
+        const TY_ *y = (const TY_ *)yv;                                                                                                          \
+        if (c == 32 && co == 16)                                                                                                                 \
+            return pcr_level_bwd_sums_t<32, 16, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, \
+                                                        grads, bn_sums, wsf, st);                                                                \
+        if (c == 32)                                                                                                                             \
+            return pcr_level_bwd_sums_t<32, 0, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2,  \
+                                                       grads, bn_sums, wsf, st);                                                                 \
+        return pcr_level_bwd_sums_t<3, 0, 4, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, \
+                                                  bn_sums, wsf, st);                                                                             \
+    } while (0)
+    if (y16) S2D_LVL_SUMS(__bf16);
+    S2D_LVL_SUMS(float);
+#undef S2D_LVL_SUMS
+}
+extern "C" int s2d_pcr_level_bwd_sums_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                          const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                          const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
+                                          float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_bwd_sums_any(y, 0, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, grads,
+                                  bn_sums, ws, ws_bytes, stream);
+}
+extern "C" int s2d_pcr_level_bwd_sums_y16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                          const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                          const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
+                                          float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_bwd_sums_any(y, 1, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, grads,
+                                  bn_sums, ws, ws_bytes, stream);
 }
 
 // pass B: dy[B][C][cells] = a*dG*m + b*y + d with abd (device, 3C) = a[C] | b[C] | d[C] from the batch-norm backward finalisation
-extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+static int pcr_level_bwd_apply_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                            const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                            const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
                                            float *dy, s2d_stream_t stream) {
-    S2D_CHECK_ARG(y && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dy && batch > 0 && d > 0 && h > 0 && w > 0 &&
+    S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dy && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_apply: bad argument");
     if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
@@ -1178,11 +1266,35 @@ extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale
     }
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
-    if (c == 32 && co == 16)
-        return pcr_level_bwd_apply_t<32, 16, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
-    if (c == 32)
-        return pcr_level_bwd_apply_t<32, 0, 2>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
-    return pcr_level_bwd_apply_t<3, 0, 4>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, st);
+#define S2D_LVL_APPLY(TY_)                                                                                                                       \
+    do {                                                                                                                                          \
+        const TY_ *y = (const TY_ *)yv;                                                                                                           \
+        if (c == 32 && co == 16)                                                                                                                  \
+            return pcr_level_bwd_apply_t<32, 16, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, \
+                                                         abd, dy, st);                                                                            \
+        if (c == 32)                                                                                                                              \
+            return pcr_level_bwd_apply_t<32, 0, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2,  \
+                                                        abd, dy, st);                                                                             \
+        return pcr_level_bwd_apply_t<3, 0, 4, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, \
+                                                   st);                                                                                           \
+    } while (0)
+    if (y16) S2D_LVL_APPLY(__bf16);
+    S2D_LVL_APPLY(float);
+#undef S2D_LVL_APPLY
+}
+extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
+                                           float *dy, s2d_stream_t stream) {
+    return pcr_level_bwd_apply_any(y, 0, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, abd, dy,
+                                   stream);
+}
+extern "C" int s2d_pcr_level_bwd_apply_y16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
+                                           float *dy, s2d_stream_t stream) {
+    return pcr_level_bwd_apply_any(y, 1, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, abd, dy,
+                                   stream);
 }
 
 // =====================================================================================================================

@@ -40,6 +40,18 @@ def pointwise_conv(x, w2d, bias):
 
 
 def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
+    if x.dtype == torch.bfloat16:   # r04: bf16-stored input operand (the raw up-sampler output): matrix-core kernel only
+        lib = _lib.load()
+        n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
+        pos = x[0, 0].numel()
+        if not lib.s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, pos):
+            return pointwise_conv_wgrad(x.float(), dout, want_db, bf16, norm)
+        dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
+        ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
+        check(lib.s2d_pointwise_conv_wgrad_norm_x16(_ptr(x), _ptr(norm), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                                    _stream()), "s2d_pointwise_conv_wgrad_norm_x16")
+        return dw, db
     """(dW [Cout,Cin], db [Cout] | None) of a 1x1x1 conv over planar fp32 tensors (position count % 4 == 0).  bf16: operands
     rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported.  norm (f32[2*Cin] = scale |
     shift): the conv's input was relu(x*scale + shift), applied on the fly (bf16 route) or materialised (fp32 route)."""
@@ -111,22 +123,26 @@ def _convt_packed(weight):
 
 class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bf16=False, bn_stats=False):
+    def forward(ctx, x, weight, bias, bf16=False, bn_stats=False, out_bf16=False):
         lib = _lib.load()
         x = x.contiguous()
         weight = weight.contiguous()
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
-        out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
         ctx.mfma = bool(bf16 and lib.s2d_convt3d_mfma_supported(cin, cout))
+        # r04: the raw output may be STORED in bf16 (half the bytes for the four passes of the fused PCR level that read it); only with
+        # the matrix-core kernel and the statistics epilogue, i.e. on the fused training path
+        out_bf16 = bool(out_bf16 and ctx.mfma and bn_stats)
+        out = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
         stats = None
         if ctx.mfma:   # bf16 compute mode: operands rounded to bf16 in the kernel, fp32 accumulate (csrc/convt3d_mfma.hip)
             partial = None
             if bn_stats:   # the epilogue also produces the statistics of the batch norm that follows
                 tiles = lib.s2d_convt3d_mfma_stats_tiles(n, cin, d, h, w)
                 partial = torch.empty((tiles, 2, cout), dtype=torch.float32, device=x.device)
-            check(lib.s2d_convt3d_mfma_fwd_stats(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial),
-                                                 _stream()), "s2d_convt3d_mfma_fwd_stats")
+            entry = lib.s2d_convt3d_mfma_fwd_stats_y16 if out_bf16 else lib.s2d_convt3d_mfma_fwd_stats
+            check(entry(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial), _stream()),
+                  "s2d_convt3d_mfma_fwd_stats")
             if bn_stats:
                 stats = torch.empty((2 * cout,), dtype=torch.float32, device=x.device)
                 ws = _ws(lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], cout), x.device)   # one row per tile: two-stage fold
@@ -149,7 +165,7 @@ class _ConvT3dFn(torch.autograd.Function):
     def backward(ctx, dout, *_unused):
         lib = _lib.load()
         x, weight = ctx.saved_tensors
-        dout = dout.contiguous()
+        dout = dout.float().contiguous()   # (the gradient of a bf16-stored output arrives in fp32 from the fused level; a bf16 one is widened)
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
         dx = dw = db = None
@@ -185,7 +201,7 @@ class _ConvT3dFn(torch.autograd.Function):
                 db = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, cout, dout[0, 0].numel(), x.device)[:cout]
             else:
                 db = dout.sum(dim=(0, 2, 3, 4))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def _hip_ok(x):
@@ -211,12 +227,13 @@ class ConvTranspose3dK4S2(nn.ConvTranspose3d):
 
     bf16_compute = False
     emit_bn_stats = False   # set by the owner when a batch norm consumes the output: y._s2d_bn_stats = [sum | sum of squares] per channel
+    out_bf16 = False        # set by the owner for ONE forward whose consumer reads bf16 (the fused PCR level): the raw output is stored in bf16
 
     def forward(self, x, output_size=None):
         if _hip_ok(x) and self.kernel_size == (4, 4, 4) and self.stride == (2, 2, 2) and self.padding == (1, 1, 1) \
                 and self.output_padding == (0, 0, 0) and self.groups == 1 and self.dilation == (1, 1, 1):
             if self.emit_bn_stats and self.training and torch.is_grad_enabled():
-                y, stats = _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute, True)
+                y, stats = _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute, True, self.out_bf16)
                 y._s2d_bn_stats = stats
                 return y
             return _ConvT3dFn.apply(x, self.weight, self.bias, self.bf16_compute)

@@ -327,7 +327,10 @@ class _PcrLevelNormFn(torch.autograd.Function):
         b, c, d, h, w = y.shape
         pos, dev = d * h * w, y.device
         sync = _collective.sync_on()
+        y16 = y.dtype == torch.bfloat16   # r04: bf16-stored raw up-sampler output (dense3d._ConvT3dFn, out_bf16)
         if stats is None or stats.numel() != 2 * c:   # (else: reduced in the epilogue of the kernel that produced y)
+            if y16:
+                y, y16 = y.float(), False
             stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(y),), b, c, pos, dev)
         count = torch.full((1,), float(b * pos), device=dev)
         if sync:
@@ -350,8 +353,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         # the kernel that writes z also reduces its per-channel (sum, sum of squares): the statistics of the BatchNorm3d behind the conv
         zst = torch.empty(2 * co, dtype=torch.float32, device=dev) if (z_stats_out is not None and c == 32 and co == 16) else None
-        _lib.check(lib.s2d_pcr_level_fwd_f32(_ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h,
-                                             w, _ptr(z), _ptr(zst), _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd_f32")
+        _lib.check((lib.s2d_pcr_level_fwd_y16 if y16 else lib.s2d_pcr_level_fwd_f32)(
+            _ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h, w, _ptr(z), _ptr(zst), _ptr(out),
+            _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd")
         if zst is not None:
             z_stats_out.append(zst)
         ctx.save_for_backward(y, norm, hp, coors, feats, out, w2d, gamma, mean, invstd, count)
@@ -380,7 +384,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         args = (_ptr(y), _ptr(norm), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(go_mask), _ptr(go_off),
                 _ptr(dz) if co else None, _ptr(w2d) if co else None, co)
-        _lib.check(lib.s2d_pcr_level_bwd_sums_f32(*args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums_f32")
+        y16 = y.dtype == torch.bfloat16
+        _lib.check((lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(*args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(),
+                                                                                                _stream()), "s2d_pcr_level_bwd_sums")
         sums_all = sums
         if ctx.sync:
             sums_all = sums.clone()
@@ -388,8 +394,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
         fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
         dgamma, dbeta = fin[0], fin[1]
         abd = torch.cat([fin[2].reshape(-1), fin[3].reshape(-1), fin[4].reshape(-1)]).contiguous()
-        dy = torch.empty_like(y)
-        _lib.check(lib.s2d_pcr_level_bwd_apply_f32(*args, _ptr(abd), _ptr(dy), _stream()), "s2d_pcr_level_bwd_apply_f32")
+        dy = torch.empty(y.shape, dtype=torch.float32, device=dev)
+        _lib.check((lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32)(*args, _ptr(abd), _ptr(dy), _stream()),
+                   "s2d_pcr_level_bwd_apply")
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None
         if co:
@@ -414,9 +421,82 @@ def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
     return out
 
 
+class _SubCtx:
+    """the slice of an autograd context that the two composed Functions below use"""
+
+    def __init__(self, needs):
+        self.needs_input_grad = tuple(needs)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def mark_non_differentiable(self, *ts):
+        pass
+
+    def set_materialize_grads(self, flag):
+        pass
+
+
+class _UpsampleLevelFn(torch.autograd.Function):
+    """ConvTranspose3d(4,2,1) + the fused PCR level behind it as ONE autograd node (r04): the raw up-sampler output y lives only inside
+    the node, stored in bf16 (half the bytes for the four level passes that read it), and its gradient goes from the level's backward
+    to the up-sampler's in fp32 without crossing an autograd edge - autograd casts a gradient to the dtype of the tensor it belongs
+    to, which put three 0.1 ms conversion passes over the 362-724 MB gradients into the step when y was a bf16 graph tensor.
+    forward = dense3d._ConvT3dFn.forward -> _PcrLevelNormFn.forward, backward the reverse; same kernels, same results."""
+
+    @staticmethod
+    def forward(ctx, x, ct_w, ct_b, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, z_stats_out, y16):
+        from .dense3d import _ConvT3dFn
+        c1 = _SubCtx((ctx.needs_input_grad[0], ctx.needs_input_grad[1], ct_b is not None and ctx.needs_input_grad[2], False, False, False))
+        y, stats = _ConvT3dFn.forward(c1, x, ct_w, ct_b, True, True, y16)
+        c2 = _SubCtx((True,) * 3 + (False,) * 12)
+        ml, ol, z = _PcrLevelNormFn.forward(c2, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, stats, z_stats_out)
+        ctx.c1, ctx.c2 = c1, c2
+        ctx.has_z = z is not None
+        return (ml, ol, z) if z is not None else (ml, ol)
+
+    @staticmethod
+    def backward(ctx, go_mask, go_off, dz=None):
+        from .dense3d import _ConvT3dFn
+        g2 = _PcrLevelNormFn.backward(ctx.c2, go_mask, go_off, dz)
+        dy, dgamma, dbeta, dwm, dbm, dwo, dbo, _, _, dw2, db2 = g2[:11]
+        dx, dw, db = _ConvT3dFn.backward(ctx.c1, dy)[:3]
+        return dx, dw, db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, dw2, db2, None, None, None, None
+
+
+def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True):
+    """`pcr_level_norm(ct(x), bn, ...)` as one node (see _UpsampleLevelFn); ct = dense3d.ConvTranspose3dK4S2 in its bf16-compute mode"""
+    assert bn.training and bn.affine and getattr(bn, "fused_relu", False) and bn.momentum is not None
+    coors = coors if coors.dtype == torch.int32 else coors.int()
+    holder = []
+    out = _UpsampleLevelFn.apply(x, ct.weight, ct.bias, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias,
+                                 coors, feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
+                                 bn, bool(getattr(next_conv, "bf16_compute", False)), holder, bool(y16))
+    z = out[2] if len(out) > 2 else None
+    if holder and z is not None:
+        z._s2d_bn_stats = holder[0]
+    return out[0], out[1], z
+
+
+def upsample_level_supported(ct, in_dhw, next_conv=None):
+    """the one-node form needs the matrix-core up-sampler (bf16 compute mode, 32 -> 32 / 16 -> 3 channels) and a level shape the fused
+    kernels cover; in_dhw = the (D, H, W) extent of the up-sampler's INPUT"""
+    from . import _lib
+    from .dense3d import ConvTranspose3dK4S2
+    if not (isinstance(ct, ConvTranspose3dK4S2) and ct.bf16_compute and ct.weight.is_cuda and ct.kernel_size == (4, 4, 4)
+            and ct.stride == (2, 2, 2) and ct.padding == (1, 1, 1) and ct.output_padding == (0, 0, 0)):
+        return False
+    lib = _lib.load()
+    cin, cout = ct.weight.shape[0], ct.weight.shape[1]
+    co = 0 if next_conv is None else next_conv.weight.shape[0]
+    cells = 8 * int(in_dhw[0]) * int(in_dhw[1]) * int(in_dhw[2])
+    return bool(lib.s2d_convt3d_mfma_supported(cin, cout) and lib.s2d_pcr_heads_supported(cout, co, cells))
+
+
 def pcr_level_supported(g, next_conv=None):
     """the fused level (heads + losses [+ next 1x1x1 conv]) runs on CUDA fp32 volumes of 32 or 3 channels"""
-    if not (torch.is_tensor(g) and g.is_cuda and g.dtype == torch.float32 and g.dim() == 5):
+    if not (torch.is_tensor(g) and g.is_cuda and g.dtype in (torch.float32, torch.bfloat16) and g.dim() == 5):
         return False
     from . import _lib
     co = 0 if next_conv is None else next_conv.weight.shape[0]

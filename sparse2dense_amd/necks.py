@@ -10,6 +10,8 @@ Under bf16 autocast on NHWC inputs the layers run on the hand-written kernels be
 whole-map LayerNorm, the PCR head with its fused levels, ConvTranspose2d(4,2,1) and the backward of the stride-2 3x3 convs as
 parity-class convs); fp32 runs and CPU inputs take the stock torch layer.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -18,7 +20,7 @@ from torch import nn
 from .backbones import build_norm_layer
 from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
-from .heads import pcr_level, pcr_level_norm, pcr_level_supported
+from .heads import pcr_level, pcr_level_norm, pcr_level_supported, upsample_level, upsample_level_supported
 from .registry import NECKS
 
 
@@ -262,6 +264,18 @@ class S2D_RPN(RPN):
             bn1, bn2 = self.generator_1[4], self.generator_2[4]
             fold = (tg is not None and gen.is_cuda and isinstance(bn1, FastBatchNorm3d) and isinstance(bn2, FastBatchNorm3d)
                     and bn1.training and bn2.training and bn1.fused_relu and bn2.fused_relu)
+            # r04: on the fused path each up-sampler + its level is ONE autograd node whose raw output is stored in bf16
+            # (heads.upsample_level; S2D_PCR_Y16=0 keeps the r03 two-node fp32 form)
+            one_node = (fold and os.environ.get("S2D_PCR_Y16", "1") != "0"
+                        and upsample_level_supported(self.generator_1[3], (5, h, w), self.generator_2[0])
+                        and upsample_level_supported(self.generator_2[3], (10, 2 * h, 2 * w)))
+            if one_node:
+                mid = self.generator_1[:3](gen)
+                gen_mask_4, gen_offset_4, z = upsample_level(self.generator_1[3], mid, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4],
+                                                              next_conv=self.generator_2[0])
+                mid2 = self.generator_2[1:3](z)
+                gen_mask_2, gen_offset_2, _ = upsample_level(self.generator_2[3], mid2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2])
+                return gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4
             if fold:
                 raw = self.generator_1[:4](gen)   # ... up to the RAW output of the first up-sampler
                 fold = pcr_level_supported(raw, self.generator_2[0])

@@ -215,3 +215,30 @@ def test_partial_sums_fold_of_long_lists(nblocks, c):
     ref = part.double().sum(0)
     assert (outs[0][:2 * c].double() - ref).abs().max() <= 2e-6 * part.abs().sum(0).max()
     assert outs[0][2 * c].item() == 12345.0
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (2, 3, 6, 70)), (16, 3, (2, 4, 7, 376)), (16, 3, (1, 2, 3, 24)), (32, 32, (1, 5, 47, 188))])
+def test_convtranspose3d_bf16_stored_output(cin, cout, shape):
+    """r04 (s2d_convt3d_mfma_fwd_stats_y16): the up-sampler writing bf16 == its fp32 output rounded to bf16, bit for bit; the epilogue
+    statistics are those of the ROUNDED values; the backward (fp32 gradient in) is the fp32-output layer's"""
+    torch.manual_seed(cin * 3 + cout)
+    n, d, h, w = shape
+    m = ConvTranspose3dK4S2(cin, cout, 4, 2, 1).to(DEV).train()
+    m.bf16_compute, m.emit_bn_stats = True, True
+    x = torch.randn(n, cin, d, h, w, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y32 = m(xa)
+    m.out_bf16 = True
+    y16 = m(xb)
+    m.out_bf16 = False
+    assert y16.dtype == torch.bfloat16 and y32.dtype == torch.float32
+    assert torch.equal(y16, y32.detach().to(torch.bfloat16))
+    st = y16._s2d_bn_stats
+    yd = y16.detach().double()
+    s1, s2 = yd.sum(dim=(0, 2, 3, 4)), (yd ** 2).sum(dim=(0, 2, 3, 4))
+    assert (st[:cout].double() - s1).abs().max() <= 1e-5 * s2.sqrt().max() * (yd[0, 0].numel() * n) ** 0.5
+    assert (st[cout:].double() - s2).abs().max() <= 1e-5 * s2.abs().max()
+    g = torch.randn_like(y32)
+    gw32 = torch.autograd.grad(y32, [xa, m.weight], g)
+    gw16 = torch.autograd.grad(y16, [xb, m.weight], g)
+    assert torch.equal(gw32[0], gw16[0]) and torch.equal(gw32[1], gw16[1])

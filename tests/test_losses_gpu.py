@@ -266,3 +266,51 @@ def test_fused_reg_loss_vs_torch_float64(b, c, h, w, m, n_pos):
     (got * wts.cuda()).sum().backward()
     assert (got.cpu().double() - ref.detach()).abs().max() <= 1e-5 * ref.detach().abs().max() + 1e-9
     assert (fc.grad.cpu().double() - fd.grad).abs().max() <= 1e-5 * fd.grad.abs().max() + 1e-12
+
+
+@pytest.mark.parametrize("b,c,co,d,h,w,m", [(2, 32, 16, 6, 20, 24, 300), (2, 3, 0, 6, 20, 24, 300), (3, 32, 16, 10, 94, 94, 20000),
+                                              (2, 3, 0, 20, 188, 188, 30000)])
+def test_pcr_level_with_bf16_stored_up_sampler_output(b, c, co, d, h, w, m):
+    """r04 (s2d_pcr_level_*_y16): the fused level reading its input y as a bf16 tensor == the same level on the fp32 tensor holding the
+    SAME (bf16-representable) values - the storage type changes the bytes moved, not the arithmetic: losses, z, dy and every parameter
+    gradient agree to fp32 round-off, the statistics handed in are used as they are."""
+    import copy
+    from torch import nn
+    from sparse2dense_amd.dense3d import FastBatchNorm3d
+    coors, feats, _, _ = _case(b, d, h, w, m, seed=b * 13 + m + c)
+    gen = torch.Generator().manual_seed(19 + c + m)
+    y0 = (torch.randn(b, c, d, h, w, generator=gen) * 1.5 + 0.2).to(torch.bfloat16)
+    bn = FastBatchNorm3d(c, fused_relu=True)
+    mask_conv, off_conv = nn.Conv3d(c, 1, 1), nn.Conv3d(c, 3, 1)
+    nxt = nn.Conv3d(c, co, 1) if co else None
+    if nxt is not None:
+        nxt.bf16_compute = True
+    r = torch.randn(b, co, d, h, w, generator=gen) / (b * d * h * w) if co else None
+
+    def run(dtype):
+        mods = [None if mm is None else copy.deepcopy(mm).to("cuda") for mm in (bn, mask_conv, off_conv, nxt)]
+        if mods[3] is not None:
+            mods[3].bf16_compute = True
+        mods[0].train()
+        yf = y0.to("cuda").float()
+        stats = torch.cat([yf.double().sum((0, 2, 3, 4)), (yf.double() ** 2).sum((0, 2, 3, 4))]).float()
+        y = y0.to("cuda", dtype).requires_grad_(True)
+        y._s2d_bn_stats = stats
+        ml, ol, z = heads.pcr_level_norm(y, mods[0], mods[1], mods[2], coors.to("cuda"), feats.to("cuda"), next_conv=mods[3])
+        total = 1.7 * ml + 0.6 * ol
+        if co:
+            total = total + (z * r.to("cuda")).sum()
+        total.backward()
+        return ml, ol, z, [y.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+
+    ml_r, ol_r, z_r, gr_r = run(torch.float32)
+    ml, ol, z, gr = run(torch.bfloat16)
+    np.testing.assert_allclose(ml.item(), ml_r.item(), rtol=1e-5)
+    np.testing.assert_allclose(ol.item(), ol_r.item(), rtol=1e-5)
+    if co:
+        assert torch.equal(z, z_r)
+    assert gr[0].dtype == torch.float32 or gr[0].dtype == torch.bfloat16
+    for i, (a, ref) in enumerate(zip(gr, gr_r)):
+        tol = 8e-3 if i == 0 and a.dtype == torch.bfloat16 else 2e-5    # (autograd stores the gradient of a bf16 leaf in bf16)
+        err = float((a.double() - ref.double()).abs().max() / ref.double().abs().max())
+        assert err <= tol, (i, err)
