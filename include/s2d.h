@@ -715,6 +715,13 @@ int s2d_comm_ranks(void);
 int s2d_comm_shutdown(void);
 int s2d_comm_allreduce_sum_f32(float *buf, int64_t count, s2d_stream_t stream);
 
+/* r04: the weight images of up to 64 dense conv layers in ONE launch (the re-pack after an optimizer step; the reference has no such
+ * step - its cuDNN/MIOpen convs read the fp32 parameters directly).  Per layer the arguments of s2d_conv2d{3x3,1x1}_pack_weights[_pair]_bf16;
+ * packed_dgrad[i] = NULL packs a single image (with transpose_flip[i]).  Host arrays of device pointers / ints. */
+int s2d_conv2d_pack_batch_bf16(int n, const float *const *weights, const int32_t *cin, const int32_t *cout, const int32_t *taps,
+                               const int32_t *weight_nhwc, const int32_t *transpose_flip, void *const *packed_fwd, void *const *packed_dgrad,
+                               s2d_stream_t stream);
+
 /* ---- r04: bf16 storage of the raw PCR up-sampler outputs ---------------------------------------------------------------------
  * (det3d/models/necks/rpn.py:263-296: the outputs of the two ConvTranspose3d layers, 724 MB and 543 MB in fp32 at batch 4, are read by
  * four passes of the fused level each).  Same contracts as the fp32 entries named alike; only the element type of that tensor changes:

@@ -34,6 +34,7 @@ SIGNATURES = {
     "s2d_rulebook_conv_fill": (ctypes.c_int, [c_i32p, ctypes.c_int64, ctypes.c_int, _I3, _I3, _I3, _I3, _I3,
                                               ctypes.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, ctypes.c_void_p,
                                               ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_conv2d_pack_batch_bf16": (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 9),
     "s2d_pfn_supported": (ctypes.c_int, [ctypes.c_int] * 4),
     "s2d_pfn_blocks": (ctypes.c_int, [ctypes.c_int64]),
     "s2d_pfn_bwd_cols": (ctypes.c_int, []),

@@ -695,6 +695,61 @@ extern "C" int s2d_conv2d1x1_pack_weights_pair_bf16(const float *weight, int cin
     return conv2d_pack_pair(weight, cin, cout, 0, 1, packed_fwd, packed_dgrad, stream);
 }
 
+// ---- r04: every dense-conv weight image of the model in ONE launch -------------------------------------------------------------------
+// After an optimizer step ~40 layers re-pack their bf16 images (forward + data-gradient operand): 38 launches of ~5 us.  The batch
+// entry takes a host table of the same arguments the single entries take and launches one kernel whose blocks find their layer by a
+// block-uniform scan of the table (the pattern of the fused Adam, optim.hip).
+constexpr int PACK_MAX = 64;
+struct PackTable {
+    const float *w[PACK_MAX];
+    __bf16 *out_f[PACK_MAX];
+    __bf16 *out_d[PACK_MAX];       // null: single image (out_f, built with tf[i])
+    int cin[PACK_MAX], cout[PACK_MAX], taps[PACK_MAX], nhwc[PACK_MAX], tf[PACK_MAX];
+    int first_block[PACK_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(const PackTable tb) {
+    int ti = 0;
+    while (ti + 1 < tb.count && (int)blockIdx.x >= tb.first_block[ti + 1]) ++ti;
+    const int64_t i = (int64_t)((int)blockIdx.x - tb.first_block[ti]) * 256 + threadIdx.x;
+    const int cin = tb.cin[ti], cout = tb.cout[ti];
+    if (tb.out_d[ti]) {   // pair: y = 0 forward [cin -> cout], y = 1 data gradient [cout -> cin], taps mirrored
+        if (blockIdx.y == 0) conv2d_pack_element(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, 0, tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
+        else conv2d_pack_element(tb.w[ti], cout, cin, cin % 128 == 0 ? 128 : 64, 1, tb.nhwc[ti], tb.taps[ti], i, tb.out_d[ti]);
+    } else if (blockIdx.y == 0) {
+        conv2d_pack_element(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, tb.tf[ti], tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
+    }
+}
+
+/* n <= 64 layers; per layer the arguments of s2d_conv2d{3x3,1x1}_pack_weights[_pair]_bf16: weight, (cin, cout) of the PACKED operand for
+ * single images / of the forward conv for pairs, taps (9 or 1), weight_nhwc, transpose_flip (single images), packed_fwd, packed_dgrad
+ * (NULL = single image).  All arrays live on the host. */
+extern "C" int s2d_conv2d_pack_batch_bf16(int n, const float *const *weights, const int32_t *cin, const int32_t *cout, const int32_t *taps,
+                                          const int32_t *weight_nhwc, const int32_t *transpose_flip, void *const *packed_fwd,
+                                          void *const *packed_dgrad, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && n <= PACK_MAX && (n == 0 || (weights && cin && cout && taps && weight_nhwc && transpose_flip && packed_fwd && packed_dgrad)),
+                  "conv2d_pack_batch: 0..%d layers", PACK_MAX);
+    if (n == 0) return S2D_OK;
+    PackTable tb;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        S2D_CHECK_ARG(weights[i] && packed_fwd[i] && (taps[i] == 9 || taps[i] == 1), "conv2d_pack_batch: bad layer %d", i);
+        if (!s2d_conv2d3x3_supported(cin[i], cout[i]) || (packed_dgrad[i] && !s2d_conv2d3x3_supported(cout[i], cin[i]))) {
+            set_error("conv2d_pack_batch: unsupported channels %d <-> %d (layer %d)", cin[i], cout[i], i);
+            return S2D_ERR_UNSUPPORTED;
+        }
+        tb.w[i] = weights[i]; tb.out_f[i] = (__bf16 *)packed_fwd[i]; tb.out_d[i] = (__bf16 *)packed_dgrad[i];
+        tb.cin[i] = cin[i]; tb.cout[i] = cout[i]; tb.taps[i] = taps[i]; tb.nhwc[i] = weight_nhwc[i]; tb.tf[i] = transpose_flip[i];
+        tb.first_block[i] = blocks;
+        blocks += (int)ceil_div((int64_t)taps[i] * cin[i] * cout[i], 256);
+    }
+    tb.first_block[n] = blocks;
+    tb.count = n;
+    hipLaunchKernelGGL(conv2d_pack_batch_kernel, dim3((unsigned)blocks, 2), dim3(256), 0, (hipStream_t)stream, tb);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
 // ---- launch plan --------------------------------------------------------------------------------------------------
 static int conv_env_int(const char *name) {
     const char *e = getenv(name);

@@ -96,14 +96,36 @@ _repack = {}   # (id(weight), variant) -> closure
 _repack_state = dict(sig=None, graph=None, last=None, stable=0)
 
 
-def register_repack(weight, variants, src, launch):
-    """src: the tensor the launch reads (must alias the parameter's storage - a converted / re-laid copy would go stale)"""
+def register_repack(weight, variants, src, launch, conv2d=None):
+    """src: the tensor the launch reads (must alias the parameter's storage - a converted / re-laid copy would go stale).
+    conv2d = (w_ptr_tensor, cin, cout, taps, nhwc, transpose_flip, packed_fwd, packed_dgrad | None): the launch's arguments, for launches
+    that s2d_conv2d_pack_batch_bf16 can serve - refresh_pack_cache() then packs all such layers in ONE launch (r04)"""
     if src.data_ptr() != weight.data_ptr() or src.dtype != weight.dtype:
         return
+    if conv2d is not None:
+        launch.conv2d = conv2d
     for v in variants:
         if _repack.get((id(weight), v)) is not launch:   # a re-packed weight: a captured graph would replay into the OLD image (ADVICE r03)
             _repack_state.update(sig=None, graph=None, last=None, stable=0)
         _repack[(id(weight), v)] = launch
+
+
+def _run_pack_launches(fns):
+    """the registered single-launch re-packs; those that carry conv2d arguments go through the batch entry, 64 layers per launch"""
+    import ctypes
+    batch = [fn for fn in fns if getattr(fn, "conv2d", None) is not None]
+    for fn in fns:
+        if getattr(fn, "conv2d", None) is None:
+            fn()
+    lib = _lib.load() if batch else None
+    for i in range(0, len(batch), 64):
+        part = [fn.conv2d for fn in batch[i:i + 64]]
+        n = len(part)
+        vp, i32 = ctypes.c_void_p * n, ctypes.c_int32 * n
+        check(lib.s2d_conv2d_pack_batch_bf16(n, vp(*[d[0].data_ptr() for d in part]), i32(*[d[1] for d in part]), i32(*[d[2] for d in part]),
+                                             i32(*[d[3] for d in part]), i32(*[int(d[4]) for d in part]), i32(*[int(d[5]) for d in part]),
+                                             vp(*[d[6].data_ptr() for d in part]), vp(*[(None if d[7] is None else d[7].data_ptr()) for d in part]),
+                                             _stream()), "s2d_conv2d_pack_batch_bf16")
 
 
 def refresh_pack_cache():
@@ -135,15 +157,13 @@ def refresh_pack_cache():
     if st["graph"] is not None and st["sig"] == sig:
         st["graph"].replay()
         return
-    for fn in launches.values():
-        fn()
+    _run_pack_launches(list(launches.values()))
     st["stable"] = st["stable"] + 1 if st["last"] == sig else 0
     st["last"] = sig
     if mode != "0" and st["stable"] >= 2 and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for fn in launches.values():
-                fn()
+            _run_pack_launches(list(launches.values()))
         st.update(sig=sig, graph=g)
 
 
@@ -165,7 +185,7 @@ def pack_weights(weight, transpose_flip=False, with_dgrad=False):
             launch()
             cached_pack_put(weight, ("conv3x3", False), pf)
             cached_pack_put(weight, ("conv3x3", True), pd)
-            register_repack(weight, [("conv3x3", False), ("conv3x3", True)], w, launch)
+            register_repack(weight, [("conv3x3", False), ("conv3x3", True)], w, launch, conv2d=(w, cin, cout, 9, nhwc, 0, pf, pd))
     return cached_pack(weight, ("conv3x3", bool(transpose_flip)), lambda: _pack_weights(weight, transpose_flip))
 
 
@@ -181,7 +201,7 @@ def _pack_weights(weight, transpose_flip):
     launch = lambda: check(lib.s2d_conv2d3x3_pack_weights_bf16(_ptr(w), pc_in, pc_out, int(transpose_flip), int(nhwc), _ptr(packed), _stream()),
                            "s2d_conv2d3x3_pack_weights_bf16")
     launch()
-    register_repack(weight, [("conv3x3", bool(transpose_flip))], w, launch)
+    register_repack(weight, [("conv3x3", bool(transpose_flip))], w, launch, conv2d=(w, pc_in, pc_out, 9, nhwc, int(transpose_flip), packed, None))
     return packed
 
 
@@ -354,7 +374,7 @@ def _pack_weights_1x1(weight, transpose, with_dgrad=False):
             launch()
             cached_pack_put(weight, ("conv1x1", False), pf)
             cached_pack_put(weight, ("conv1x1", True), pd)
-            register_repack(weight, [("conv1x1", False), ("conv1x1", True)], w, launch)
+            register_repack(weight, [("conv1x1", False), ("conv1x1", True)], w, launch, conv2d=(w, cin, cout, 1, 0, 0, pf, pd))
 
     def build():
         lib = _lib.load()
@@ -365,7 +385,7 @@ def _pack_weights_1x1(weight, transpose, with_dgrad=False):
         launch = lambda: check(lib.s2d_conv2d1x1_pack_weights_bf16(_ptr(w), pc_in, pc_out, int(transpose), _ptr(packed), _stream()),
                                "s2d_conv2d1x1_pack_weights_bf16")
         launch()
-        register_repack(weight, [("conv1x1", bool(transpose))], w, launch)
+        register_repack(weight, [("conv1x1", bool(transpose))], w, launch, conv2d=(w, pc_in, pc_out, 1, 0, int(transpose), packed, None))
         return packed
     return cached_pack(weight, ("conv1x1", bool(transpose)), build)
 

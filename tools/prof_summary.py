@@ -28,7 +28,7 @@ def main():
         agg[r["Kernel_Name"]][1] += 1
     tot = sum(v[0] for v in agg.values())
     print(f"# last steady-state step: wall {(t1 - t0) / 1e6:.3f} ms, {len(seg)} kernels, sum of kernel time {tot / 1e6:.3f} ms")
-    ours = sum(v[0] for k, v in agg.items() if "s2d::" in k)
+    ours = sum(v[0] for k, v in agg.items() if "s2d::" in k or k.startswith("_ZN3s2d"))
     print(f"# hand-written s2d:: kernels {ours / 1e6:.3f} ms ({100 * ours / tot:.1f} %)")
     print("# share   total_ms  calls  avg_us   kernel")
     for n, (dur, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:220]:
