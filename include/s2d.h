@@ -761,6 +761,29 @@ int s2d_pfn_bwd_f32(const float *voxels, const int32_t *num_points, const int32_
                     const uint8_t *argmax, int64_t pillars, int slots, int ndim, float vx, float vy, float x_offset, float y_offset,
                     float *partial, s2d_stream_t stream);
 
+/* Two PFN layers (configs/waymo/pp/*: num_filters = [64, 64]; layer 1 Linear(10 -> 32) -> BN -> ReLU -> [x | max over slots], layer 2
+ * Linear(64 -> 64) -> BN -> ReLU -> max over slots; pillar_encoder.py:41-56).  scale_shift1 = scale[32] | shift[32] of the first batch
+ * norm, scale_shift2 = scale[64] | shift[64] of the second.  _stats1 / _stats2: per-workgroup partial slabs [s2d_pfn_blocks(P)][2][64]
+ * of (sum h, sum h^2) over the valid rows of layer 1 (columns 32..63 duplicate 0..31) / over all P*slots rows of layer 2.  _apply_max:
+ * out[P][64], the slot of the maximum (first maximum; slot index num_points = an empty slot) and h2 at that slot.  _bwd: abd2 = a | b | d
+ * of the second batch norm's backward (dh2 = a g + b h2 + d), gout = dout with relu' applied; writes s2d_pfn2_bwd_rows() rows of
+ * s2d_pfn2_bwd_cols() floats: dW2[64][64] | sum g1[64] | sum g1 h1[64] | M1[10][64] | M2[10][64] | M3[10] (layer-1 entries in columns
+ * 0..31), to be summed over the rows. */
+int s2d_pfn2_supported(int ndim, int slots, int feats, int c1, int c2);
+int s2d_pfn2_bwd_rows(void);
+int s2d_pfn2_bwd_cols(void);
+int s2d_pfn2_stats1_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *w1, int64_t pillars, int slots,
+                        int ndim, float vx, float vy, float x_offset, float y_offset, float *partial, s2d_stream_t stream);
+int s2d_pfn2_stats2_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *w1, const float *w2,
+                        const float *scale_shift1, int64_t pillars, int slots, int ndim, float vx, float vy, float x_offset,
+                        float y_offset, float *partial, s2d_stream_t stream);
+int s2d_pfn2_apply_max_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *w1, const float *w2,
+                           const float *scale_shift1, const float *scale_shift2, int64_t pillars, int slots, int ndim, float vx, float vy,
+                           float x_offset, float y_offset, float *out, uint8_t *argmax, float *h2_at_max, s2d_stream_t stream);
+int s2d_pfn2_bwd_f32(const float *voxels, const int32_t *num_points, const int32_t *coors, const float *w1, const float *w2,
+                     const float *scale_shift1, const float *abd2, const float *gout, const uint8_t *argmax, int64_t pillars, int slots,
+                     int ndim, float vx, float vy, float x_offset, float y_offset, float *partial, s2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

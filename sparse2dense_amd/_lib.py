@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libs2d_hip.so")
 c_i32p = ctypes.c_void_p
 c_f32p = ctypes.c_void_p
 _I3 = ctypes.c_int32 * 3
+_PFN_GEO = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]   # pillars, slots, ndim, vx, vy, x/y offset
 _F3 = ctypes.c_float * 3
 _F6 = ctypes.c_float * 6
 
@@ -44,6 +45,15 @@ SIGNATURES = {
                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_pfn_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    "s2d_pfn2_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "s2d_pfn2_bwd_rows": (ctypes.c_int, []),
+    "s2d_pfn2_bwd_cols": (ctypes.c_int, []),
+    "s2d_pfn2_stats1_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32p, c_f32p] + _PFN_GEO + [c_f32p, ctypes.c_void_p]),
+    "s2d_pfn2_stats2_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p] + _PFN_GEO + [c_f32p, ctypes.c_void_p]),
+    "s2d_pfn2_apply_max_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p] + _PFN_GEO
+                               + [c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
+    "s2d_pfn2_bwd_f32": (ctypes.c_int, [c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p] + _PFN_GEO
+                         + [c_f32p, ctypes.c_void_p]),
     "s2d_rulebook_chain_supported": (ctypes.c_int, [ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_rulebook_chain_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, _I3, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                              ctypes.c_void_p]),

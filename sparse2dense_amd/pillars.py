@@ -151,6 +151,108 @@ class _FusedPfnFn(torch.autograd.Function):
         return None, None, None, dw.contiguous(), dgamma, dbeta, None, None
 
 
+class _FusedPfn2Fn(torch.autograd.Function):
+    """the two-layer reader of configs/waymo/pp/* (num_filters = [64, 64]: Linear(10 -> 32) -> BN -> ReLU -> [x | max x] -> Linear(64 -> 64)
+    -> BN -> ReLU -> max; pillar_encoder.py:41-56,114-154) on csrc/pfn.hip: three forward passes (statistics of layer 1, statistics of
+    layer 2, apply + max) and one backward pass over the raw pillars - no [P,20,*] tensor exists.  Statistics run over all P*slots rows
+    like the reference's BatchNorm1d; under torch.distributed they are all-reduced like every other batch norm of the path."""
+
+    @staticmethod
+    def _bn_fwd(bn, stats, count, training):
+        from . import collective
+        from . import hip_ops as H
+        gamma, beta = bn.weight, bn.bias
+        if training:
+            sync = collective.sync_on()
+            if sync:
+                packed = torch.cat([stats, count])
+                collective.allreduce_sum_(packed)
+                stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+            track = bn.track_running_stats
+            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, bn.eps, bn.momentum if track else 0.0, bn.running_mean if track else None,
+                                      bn.running_var if track else None, bn.num_batches_tracked if track else None)
+            return fin[0], fin[1], fin[2:4].contiguous().reshape(-1), count, sync
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = gamma * invstd
+        return bn.running_mean, invstd, torch.cat([scale, beta - bn.running_mean * scale]).contiguous(), count, False
+
+    @staticmethod
+    def _bn_bwd(sums, count, gamma, mean, invstd, training, sync):
+        """-> dgamma, dbeta, (a | b | d) with d input = a g + b h + d"""
+        from . import collective
+        from . import hip_ops as H
+        c = gamma.shape[0]
+        if training:
+            sums_all = sums
+            if sync:
+                sums_all = sums.clone()
+                collective.allreduce_sum_(sums_all)
+            fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+            return fin[0], fin[1], fin[2:5].contiguous().reshape(-1)
+        z = torch.zeros(c, dtype=torch.float32, device=gamma.device)
+        return invstd * (sums[c:] - mean * sums[:c]), sums[:c], torch.cat([gamma * invstd, z, z])
+
+    @staticmethod
+    def forward(ctx, voxels, num_points, coors, w1, g1, b1, w2, g2, b2, bn1, bn2, geo):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        lib = _lib.load()
+        voxels, w1, w2 = voxels.contiguous(), w1.contiguous(), w2.contiguous()
+        num_points = num_points.int().contiguous()
+        coors = coors.int().contiguous()
+        p, t, nd = voxels.shape
+        dev = voxels.device
+        vx, vy, xo, yo = geo
+        args = (p, t, nd, float(vx), float(vy), float(xo), float(yo))
+        head = (_ptr(voxels), _ptr(num_points), _ptr(coors), _ptr(w1))
+        training = bn1.training or not bn1.track_running_stats
+        count = torch.full((1,), float(p * t), device=dev)
+        blocks = lib.s2d_pfn_blocks(p)
+        stats1 = None
+        if training:
+            partial = torch.empty((blocks, 2, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.s2d_pfn2_stats1_f32(*head, *args, _ptr(partial), _stream()), "s2d_pfn2_stats1_f32")
+            stats1 = partial.sum(0)[:, :32].reshape(64)
+        mean1, invstd1, ss1, count1, sync = _FusedPfn2Fn._bn_fwd(bn1, stats1, count, training)
+        stats2 = None
+        if training:
+            partial = torch.empty((blocks, 2, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.s2d_pfn2_stats2_f32(*head, _ptr(w2), _ptr(ss1), *args, _ptr(partial), _stream()), "s2d_pfn2_stats2_f32")
+            stats2 = partial.sum(0).reshape(128)
+        mean2, invstd2, ss2, count2, _ = _FusedPfn2Fn._bn_fwd(bn2, stats2, count, training)
+        out = torch.empty((p, 64), dtype=torch.float32, device=dev)
+        arg = torch.empty((p, 64), dtype=torch.uint8, device=dev)
+        h2max = torch.empty((p, 64), dtype=torch.float32, device=dev)
+        _lib.check(lib.s2d_pfn2_apply_max_f32(*head, _ptr(w2), _ptr(ss1), _ptr(ss2), *args, _ptr(out), _ptr(arg), _ptr(h2max), _stream()),
+                   "s2d_pfn2_apply_max_f32")
+        ctx.save_for_backward(voxels, num_points, coors, w1, w2, g1, g2, mean1, invstd1, ss1, mean2, invstd2, count1, count2, out, arg, h2max)
+        ctx.args, ctx.training, ctx.sync = args, training, sync
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _lib
+        from .dense2d import _ptr, _stream
+        lib = _lib.load()
+        voxels, num_points, coors, w1, w2, g1, g2, mean1, invstd1, ss1, mean2, invstd2, count1, count2, out, arg, h2max = ctx.saved_tensors
+        go = (dout * (out > 0)).contiguous()      # relu'(0) = 0, as torch
+        sums2 = torch.cat([go.sum(0), (go * h2max).sum(0)])
+        dgamma2, dbeta2, abd2 = _FusedPfn2Fn._bn_bwd(sums2, count2, g2, mean2, invstd2, ctx.training, ctx.sync)
+        rows, cols = lib.s2d_pfn2_bwd_rows(), lib.s2d_pfn2_bwd_cols()
+        partial = torch.empty((rows, cols), dtype=torch.float32, device=voxels.device)
+        _lib.check(lib.s2d_pfn2_bwd_f32(_ptr(voxels), _ptr(num_points), _ptr(coors), _ptr(w1), _ptr(w2), _ptr(ss1), _ptr(abd2.contiguous()), _ptr(go),
+                                        _ptr(arg), *ctx.args, _ptr(partial), _stream()), "s2d_pfn2_bwd_f32")
+        row = partial.sum(0)
+        dw2 = row[:4096].view(64, 64)
+        r1 = row[4096:]
+        sums1 = torch.cat([r1[:32], r1[64:96]])
+        m1, m2, m3 = r1[128:768].view(10, 64)[:, :32].t(), r1[768:1408].view(10, 64)[:, :32].t(), r1[1408:1418]
+        dgamma1, dbeta1, abd1 = _FusedPfn2Fn._bn_bwd(sums1, count1, g1, mean1, invstd1, ctx.training, ctx.sync)
+        a, b, d = abd1[:32], abd1[32:64], abd1[64:96]
+        dw1 = a[:, None] * m1 + b[:, None] * m2 + d[:, None] * m3[None, :]
+        return None, None, None, dw1.contiguous(), dgamma1, dbeta1, dw2.contiguous(), dgamma2, dbeta2, None, None, None
+
+
 class PFNLayer(nn.Module):
     def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
         super().__init__()
@@ -195,20 +297,35 @@ class PillarFeatureNet(nn.Module):
         self.y_offset = self.vy / 2 + pc_range[1]
 
     def _fused_ok(self, features):
-        """one PFN layer 10 -> 64 on fp32 device pillars: the fused kernels (S2D_PFN_FUSED=0 keeps the layer-by-layer path)"""
+        """one PFN layer 10 -> 64 or the two layers 10 -> 32 | 64 -> 64 on fp32 device pillars: the fused kernels, returns the number
+        of fused layers or 0 (S2D_PFN_FUSED=0 keeps the layer-by-layer path)"""
         import os
-        if os.environ.get("S2D_PFN_FUSED", "1") == "0" or len(self.pfn_layers) != 1 or self._with_distance:
-            return False
-        lyr = self.pfn_layers[0]
+        if os.environ.get("S2D_PFN_FUSED", "1") == "0" or len(self.pfn_layers) not in (1, 2) or self._with_distance:
+            return 0
         if not (features.is_cuda and features.dtype == torch.float32 and features.dim() == 3 and features.shape[0] > 0
-                and isinstance(lyr.norm, FeatureBatchNorm1d) and lyr.norm.momentum is not None and not torch.is_autocast_enabled()):
-            return False
+                and not torch.is_autocast_enabled()):
+            return 0
+        for lyr in self.pfn_layers:
+            if not (isinstance(lyr.norm, FeatureBatchNorm1d) and lyr.norm.momentum is not None):
+                return 0
         from . import _lib
-        return bool(_lib.load().s2d_pfn_supported(features.shape[2], features.shape[1], lyr.linear.in_features, lyr.units))
+        lib = _lib.load()
+        l0 = self.pfn_layers[0]
+        if len(self.pfn_layers) == 1:
+            return 1 if lib.s2d_pfn_supported(features.shape[2], features.shape[1], l0.linear.in_features, l0.units) else 0
+        l1 = self.pfn_layers[1]
+        if l1.linear.in_features != 2 * l0.units or l0.norm.training != l1.norm.training:
+            return 0
+        return 2 if lib.s2d_pfn2_supported(features.shape[2], features.shape[1], l0.linear.in_features, l0.units, l1.units) else 0
 
     def forward(self, features, num_voxels, coors):
         dtype = features.dtype
-        if self._fused_ok(features):
+        fused = self._fused_ok(features)
+        if fused == 2:
+            l0, l1 = self.pfn_layers
+            return _FusedPfn2Fn.apply(features, num_voxels, coors, l0.linear.weight, l0.norm.weight, l0.norm.bias, l1.linear.weight, l1.norm.weight,
+                                      l1.norm.bias, l0.norm, l1.norm, (self.vx, self.vy, self.x_offset, self.y_offset)).squeeze()
+        if fused == 1:
             lyr = self.pfn_layers[0]
             return _FusedPfnFn.apply(features, num_voxels, coors, lyr.linear.weight, lyr.norm.weight, lyr.norm.bias, lyr.norm,
                                      (self.vx, self.vy, self.x_offset, self.y_offset)).squeeze()

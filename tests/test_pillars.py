@@ -267,12 +267,14 @@ DEV = "cuda"
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("filters", [(64,), (64, 64)])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train):
+def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters):
     """csrc/pfn.hip (decorate -> Linear -> BatchNorm1d -> ReLU -> max in two recomputing passes + one backward pass) against the
     layer-by-layer PillarFeatureNet (pillar_encoder.py:41-56,114-154 restated on torch ops; pinned to the reference by
     pillar_*.npz above) evaluated in float64 on the host: output 1e-5, every parameter gradient 1e-4, running statistics 1e-5.
-    Covers pillars whose maximum sits in an EMPTY slot (relu(shift) > every occupied slot: positive bias) and full pillars."""
+    Covers pillars whose maximum sits in an EMPTY slot (relu(shift) > every occupied slot: positive bias) and full pillars, the one-layer
+    reader and the two-layer reader of configs/waymo/pp/* (10 -> 32, [x | max x] -> 64; three forward passes + one backward pass)."""
     import copy
     from sparse2dense_amd.pillars import PillarFeatureNet
     torch.manual_seed(3)
@@ -283,14 +285,19 @@ def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train):
     vox = rs.randn(P, T, 5).astype(np.float32) * np.array([20, 20, 1.5, 0.5, 0.1], np.float32)
     vox *= (np.arange(T)[None, :] < num[:, None])[:, :, None]
     coors = np.stack([rs.randint(0, 2, P), np.zeros(P, np.int64), rs.randint(0, 468, P), rs.randint(0, 468, P)], 1).astype(np.int32)
-    net = PillarFeatureNet(num_input_features=5, num_filters=(64,), voxel_size=(0.32, 0.32, 6.0), pc_range=(-74.88, -74.88, -2, 74.88, 74.88, 4.0))
+    net = PillarFeatureNet(num_input_features=5, num_filters=filters, voxel_size=(0.32, 0.32, 6.0), pc_range=(-74.88, -74.88, -2, 74.88, 74.88, 4.0))
+    assert len(net.pfn_layers) == len(filters)
     with torch.no_grad():
         net.pfn_layers[0].linear.weight.mul_(0.3)
-        net.pfn_layers[0].norm.weight.copy_(torch.rand(64) + 0.5)
-        net.pfn_layers[0].norm.bias.copy_(torch.randn(64) * 0.5)          # half the channels: relu(shift) > 0 in the empty slots
-        net.pfn_layers[0].norm.running_mean.copy_(torch.randn(64) * 0.1)
-        net.pfn_layers[0].norm.running_var.copy_(torch.rand(64) + 0.5)
+        for lyr in net.pfn_layers:
+            c = lyr.units
+            lyr.norm.weight.copy_(torch.rand(c) + 0.5)
+            lyr.norm.bias.copy_(torch.randn(c) * 0.5)          # half the channels: relu(shift) > 0 in the empty slots
+            lyr.norm.running_mean.copy_(torch.randn(c) * 0.1)
+            lyr.norm.running_var.copy_(torch.rand(c) + 0.5)
     net.train(train)
+    assert net.to(DEV)._fused_ok(torch.zeros(1, T, 5, device=DEV)) == len(filters), "the fused reader was not selected"
+    net = net.cpu()
     g = torch.randn(P, 64, generator=torch.Generator().manual_seed(9))
 
     # float64 reference: the same module on the host through torch ops (FeatureBatchNorm1d -> the oracle backend)
@@ -316,6 +323,7 @@ def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train):
         el = ((p.grad.double().cpu() - q.grad).abs() / (q.grad.abs() + 1e-3 * q.grad.abs().max())).flatten()
         assert float(el.median()) <= 1e-4, (n, float(el.median()))
     if train:
-        assert _rel(dev.pfn_layers[0].norm.running_mean, ref.pfn_layers[0].norm.running_mean) <= 1e-5
-        assert _rel(dev.pfn_layers[0].norm.running_var, ref.pfn_layers[0].norm.running_var) <= 1e-5
-        assert int(dev.pfn_layers[0].norm.num_batches_tracked) == 1
+        for a, b in zip(dev.pfn_layers, ref.pfn_layers):
+            assert _rel(a.norm.running_mean, b.norm.running_mean) <= 1e-5
+            assert _rel(a.norm.running_var, b.norm.running_var) <= 1e-5
+            assert int(a.norm.num_batches_tracked) == 1
