@@ -147,6 +147,116 @@ __global__ __launch_bounds__(256) void vox_ksmall_kernel(const int *__restrict__
     }
 }
 
+// ---- dense cells (pillars: max_points = 20, ~14 points per cell on average, hundreds in the cells next to the sensor) --------------
+// The atomicMin cascade above serialises on the 80-byte list of a cell: when the ~1000 points of a dense pillar arrive together each of
+// them walks the whole list (0.42 ms per chain on the Waymo pillar grid, all of it same-line atomics).  For max_points >=
+// VOXSEL_MIN_POINTS the points are instead bucketed per cell - count (one fire-and-forget atomic per point), exclusive scan, ticket
+// scatter (one returning atomic per point) - and a wave per cell picks the max_points smallest indices in index order: cells of <= 64
+// points rank every entry by counting the smaller ones (v_readlane sweep), larger cells extract minima round by round.  The counters
+// start at 0x7F7F7F7F (they live in the workspace's one 0x7F memset) and are read relative to it.
+constexpr int VOXSEL_MIN_POINTS = 8;
+
+__global__ __launch_bounds__(256) void voxsel_count_kernel(const int *__restrict__ pt_slot, const int *__restrict__ vid, int n, unsigned *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = pt_slot[i];
+    if (s < 0) return;
+    const int v = vid[s];
+    if (v < 0) return;
+    __hip_atomic_fetch_add(&cnt[v], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct CellCountIn {
+    const unsigned *cnt;
+    __device__ int operator()(int64_t i) const { return (int)(cnt[i] - VOX_EMPTY); }
+};
+struct CellStartOut {
+    int *start;
+    __device__ void operator()(int64_t i, int, int run) const { start[i] = run; }
+};
+__global__ __launch_bounds__(256) void voxsel_scatter_kernel(const int *__restrict__ pt_slot, const int *__restrict__ vid, int n,
+                                                             const int *__restrict__ start, unsigned *__restrict__ fillc, int *__restrict__ bucket) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = pt_slot[i];
+    if (s < 0) return;
+    const int v = vid[s];
+    if (v < 0) return;
+    const unsigned ticket = atomicAdd(&fillc[v], 1u) - VOX_EMPTY;
+    bucket[start[v] + (int)ticket] = i;
+}
+__global__ __launch_bounds__(256) void voxsel_select_kernel(const unsigned *__restrict__ cnt, const int *__restrict__ start, const int *__restrict__ bucket,
+                                                            int64_t rows, int max_points, int *__restrict__ ksmall) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= rows) return;
+    const int np = (int)(cnt[v] - VOX_EMPTY);
+    if (np <= 0) return;
+    const int *ent = bucket + start[v];
+    int *list = ksmall + v * max_points;
+    if (np <= 64) {
+        const int x = lane < np ? ent[lane] : 0x7FFFFFFF;
+        int rank = 0;
+        for (int j = 0; j < np; ++j) rank += __builtin_amdgcn_readlane(x, j) < x ? 1 : 0;
+        if (lane < np && rank < max_points) list[rank] = x;
+        return;
+    }
+    int prev = -1;
+    const int rounds = np < max_points ? np : max_points;
+    for (int r = 0; r < rounds; ++r) {
+        int m = 0x7FFFFFFF;
+        for (int e = lane; e < np; e += 64) {
+            const int y = ent[e];
+            m = (y > prev && y < m) ? y : m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int y = __shfl_xor(m, o);
+            m = y < m ? y : m;
+        }
+        if (lane == 0) list[r] = m;
+        prev = m;
+    }
+}
+
+struct VoxSelWs {
+    unsigned *cnt, *fillc;        // per cell row, inside the 0x7F clear region
+    unsigned long long *flags;    // scan granules of the per-cell scan, inside the clear region
+    int *start, *bucket;
+};
+// the clear-region part; call between the other clear-region takes
+static void voxsel_carve_clear(Carver &c, VoxSelWs &w, int64_t rows, int max_points) {
+    w.cnt = w.fillc = nullptr; w.flags = nullptr; w.start = w.bucket = nullptr;
+    if (max_points < VOXSEL_MIN_POINTS) return;
+    const size_t r = (size_t)(rows > 0 ? rows : 1);
+    w.cnt = c.take<unsigned>(r);
+    w.fillc = c.take<unsigned>(r);
+    w.flags = c.take<unsigned long long>(scan1_num_blocks((int64_t)r));
+}
+static void voxsel_carve_rest(Carver &c, VoxSelWs &w, int64_t rows, int64_t n_points, int max_points) {
+    if (max_points < VOXSEL_MIN_POINTS) return;
+    w.start = c.take<int>((size_t)(rows > 0 ? rows : 1));
+    w.bucket = c.take<int>((size_t)(n_points > 0 ? n_points : 1));
+}
+// the max_points smallest point indices of every cell, in index order, into ksmall (pre-set to IDX_EMPTY)
+static int vox_select_launch(const int *pt_slot, const int *first, const int *vid, int n, int max_points, int64_t rows, int *ksmall, const VoxSelWs &w,
+                             hipStream_t st) {
+    const dim3 blk(256);
+    if (max_points < VOXSEL_MIN_POINTS) {
+        hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, pt_slot, first, vid, n, max_points, ksmall);
+        S2D_LAUNCH_CHECK();
+        return 0;
+    }
+    hipLaunchKernelGGL(voxsel_count_kernel, dim3((n + 255) / 256), blk, 0, st, pt_slot, vid, n, w.cnt);
+    CellCountIn cin{w.cnt};
+    CellStartOut cout{w.start};
+    int rc = device_exclusive_scan_onepass(cin, cout, rows, w.flags, nullptr, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(voxsel_scatter_kernel, dim3((n + 255) / 256), blk, 0, st, pt_slot, vid, n, w.start, w.fillc, w.bucket);
+    hipLaunchKernelGGL(voxsel_select_kernel, dim3((unsigned)ceil_div(rows, 4)), blk, 0, st, w.cnt, w.start, w.bucket, rows, max_points, ksmall);
+    S2D_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void vox_fill_kernel(const float *__restrict__ points, const int *__restrict__ ksmall,
                                                        const int32_t *__restrict__ out_m, int ndim, int max_points,
                                                        float *__restrict__ voxels, int32_t *__restrict__ num_points) {
@@ -201,6 +311,7 @@ struct VoxWs {
     size_t table_size;
     size_t clear_bytes;          // keys .. flags: one 0x7F memset
     size_t bytes;
+    VoxSelWs sel;
 };
 
 static VoxWs vox_carve(void *ws, int64_t n_points, int max_points, int max_voxels) {
@@ -214,10 +325,12 @@ static VoxWs vox_carve(void *ws, int64_t n_points, int max_points, int max_voxel
     w.first = c.take<int>(t);
     w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
     w.flags = c.take<unsigned long long>(scan1_num_blocks(n_points));
+    voxsel_carve_clear(c, w.sel, rows, max_points);
     w.clear_bytes = c.total();
     w.vid = c.take<int>(t);
     w.pt_slot = c.take<int>(n_points > 0 ? n_points : 1);
     w.total = c.take<int>(2);   // [1] = scan error flag
+    voxsel_carve_rest(c, w.sel, rows, n_points, max_points);
     w.bytes = c.total();
     return w;
 }
@@ -283,7 +396,8 @@ extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim,
     int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_finalize_count_kernel, dim3(1), dim3(1), 0, st, w.total, max_voxels, out_m);
-    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.vid, n, max_points, w.ksmall);
+    rc = vox_select_launch(w.pt_slot, w.first, w.vid, n, max_points, rows, w.ksmall, w.sel, st);
+    if (rc) return rc;
     const int64_t fill_threads = rows * max_points;
     hipLaunchKernelGGL(vox_fill_kernel, dim3((unsigned)ceil_div(fill_threads, 256)), blk, 0, st, points, w.ksmall, out_m,
                        ndim, max_points, voxels, num_points);
@@ -455,6 +569,7 @@ struct VoxbWs {
     size_t table_total;
     size_t clear_bytes;          // keys .. flags: one 0x7F memset
     size_t bytes;
+    VoxSelWs sel;
 };
 
 static size_t voxb_table(int64_t n) {
@@ -479,6 +594,7 @@ static VoxbWs voxb_carve(void *ws, int frames, const int64_t *offsets, int max_p
     w.first = c.take<int>(tt);
     w.ksmall = c.take<int>((size_t)(rows > 0 ? rows : 1) * max_points);
     w.flags = c.take<unsigned long long>(scan1_num_blocks(n));
+    voxsel_carve_clear(c, w.sel, rows, max_points);
     w.clear_bytes = c.total();
     w.vid = c.take<int>(tt);
     w.rank_of_slot = c.take<int>(tt);
@@ -486,6 +602,7 @@ static VoxbWs voxb_carve(void *ws, int frames, const int64_t *offsets, int max_p
     w.total = c.take<int>(2);
     w.frame_start_rank = c.take<int>(frames + 1);
     w.out_base = c.take<int>(frames + 1);
+    voxsel_carve_rest(c, w.sel, rows, n, max_points);
     w.bytes = c.total();
     return w;
 }
@@ -563,7 +680,8 @@ extern "C" int s2d_voxelize_batch_run(const float *points, int frames, const int
     hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base, out_base);
     hipLaunchKernelGGL(voxb_assign_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.keys, w.rank_of_slot, w.frame_start_rank,
                        w.out_base, n, p, vb, w.vid, coors4);
-    hipLaunchKernelGGL(vox_ksmall_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.vid, n, max_points, w.ksmall);
+    rc = vox_select_launch(w.pt_slot, w.first, w.vid, n, max_points, rows, w.ksmall, w.sel, st);
+    if (rc) return rc;
     hipLaunchKernelGGL(voxb_fill_kernel, dim3((unsigned)ceil_div(rows * max_points, 256)), blk, 0, st, points, w.ksmall, w.out_base, frames, ndim,
                        max_points, voxels, num_points);
     if (mean)

@@ -303,8 +303,8 @@ class PillarFeatureNet(nn.Module):
         if os.environ.get("S2D_PFN_FUSED", "1") == "0" or len(self.pfn_layers) not in (1, 2) or self._with_distance:
             return 0
         if not (features.is_cuda and features.dtype == torch.float32 and features.dim() == 3 and features.shape[0] > 0
-                and not torch.is_autocast_enabled()):
-            return 0
+                and not torch.is_autocast_enabled()) or (features.requires_grad and torch.is_grad_enabled()):
+            return 0   # (a gradient w.r.t. the raw points is never needed in training; the layer-by-layer path provides it)
         for lyr in self.pfn_layers:
             if not (isinstance(lyr.norm, FeatureBatchNorm1d) and lyr.norm.momentum is not None):
                 return 0

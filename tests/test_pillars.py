@@ -47,6 +47,14 @@ def _run(golden_dir, dev, chk, rt, at):
     check_digest_norm(gr[0], g, "gvox", max(rt * 5, 2e-3))
     for n, gi in zip(names, gr[1:]):   # sums over ~1.4e5 rows in a different fp32 order
         check_digest_norm(gi, g, "g:" + n, max(rt * 5, 2e-3))
+    if dev != "cpu":
+        # the fused reader (csrc/pfn.hip; taken when no gradient w.r.t. the raw points is asked for) against the same golden file
+        assert pfn._fused_ok(voxels) == 2 and pfn._fused_ok(vin) == 0
+        pfn.zero_grad()
+        ff = pfn(voxels, num, coors)
+        chk(ff, g, "feats", rt, at)
+        for n, gi in zip(names, _grads([ff], [params[n] for n in names], 700)):
+            check_digest_norm(gi, g, "g:" + n, max(rt * 5, 2e-3))
     sc = build_from_cfg(dict(type="PointPillarsScatter", num_input_features=64), BACKBONES)
     canvas = sc(feats.detach(), coors, 1, np.array([468, 468, 1]))
     assert canvas.shape == (1, 64, 468, 468)
