@@ -162,7 +162,8 @@ class _ConvT3dFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout, *_unused):
+    def backward(ctx, dout, *_unused, dout_sum=None):
+        """dout_sum (direct calls from heads._UpsampleLevelFn only): per-channel sums of dout the caller already has = the bias gradient"""
         lib = _lib.load()
         x, weight = ctx.saved_tensors
         dout = dout.float().contiguous()   # (the gradient of a bf16-stored output arrives in fp32 from the fused level; a bf16 one is widened)
@@ -197,7 +198,9 @@ class _ConvT3dFn(torch.autograd.Function):
                             sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
                             dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            if dout[0, 0].numel() % 4 == 0:   # per-channel sums of a planar tensor: the first half of the BN3d statistics pass
+            if dout_sum is not None:
+                db = dout_sum
+            elif dout[0, 0].numel() % 4 == 0:   # per-channel sums of a planar tensor: the first half of the BN3d statistics pass
                 db = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, cout, dout[0, 0].numel(), x.device)[:cout]
             else:
                 db = dout.sum(dim=(0, 2, 3, 4))

@@ -333,6 +333,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
                 y, y16 = y.float(), False
             stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(y),), b, c, pos, dev)
         count = torch.full((1,), float(b * pos), device=dev)
+        ctx.local_ysum, ctx.local_rows = stats[:c], float(b * pos)   # this rank's sum of y per channel (for the up-sampler's bias gradient)
         if sync:
             packed = torch.cat([stats, count])
             _collective.allreduce_sum_(packed)
@@ -394,6 +395,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
         fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
         dgamma, dbeta = fin[0], fin[1]
         abd = torch.cat([fin[2].reshape(-1), fin[3].reshape(-1), fin[4].reshape(-1)]).contiguous()
+        # sum over this rank's rows of dy = a g + b y + d, per channel, from the sums at hand (= the bias gradient of the conv that produced
+        # y; mathematically zero behind a training-mode batch norm, fp32 rounding noise here as in the reference) - no pass over dy
+        ctx.dy_sum = fin[2].reshape(-1) * sums[:c] + fin[3].reshape(-1) * ctx.local_ysum + fin[4].reshape(-1) * ctx.local_rows
         dy = torch.empty(y.shape, dtype=torch.float32, device=dev)
         _lib.check((lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32)(*args, _ptr(abd), _ptr(dy), _stream()),
                    "s2d_pcr_level_bwd_apply")
@@ -461,7 +465,7 @@ class _UpsampleLevelFn(torch.autograd.Function):
         from .dense3d import _ConvT3dFn
         g2 = _PcrLevelNormFn.backward(ctx.c2, go_mask, go_off, dz)
         dy, dgamma, dbeta, dwm, dbm, dwo, dbo, _, _, dw2, db2 = g2[:11]
-        dx, dw, db = _ConvT3dFn.backward(ctx.c1, dy)[:3]
+        dx, dw, db = _ConvT3dFn.backward(ctx.c1, dy, dout_sum=ctx.c2.dy_sum)[:3]
         return dx, dw, db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, dw2, db2, None, None, None, None
 
 
