@@ -533,6 +533,14 @@ int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int
 size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int cout, int d, int h, int w);
 int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int cin, int cout, int d, int h,
                            int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+/* bf16-stored output gradient (r04): the same data / weight gradients from a dout the producer wrote in bf16 - the kernels above round
+ * dout to bf16 on load, so the results are identical and the 0.5-0.7 GB tensor is half as large.  _supported: the layer shapes the
+ * bf16-reading kernels cover (d, h, w = INPUT extents). */
+int s2d_convt3d_mfma_d16_supported(int cin, int cout, int d, int h, int w);
+int s2d_convt3d_mfma_dgrad_d16(const void *dout_bf16, const void *packed, int batch, int cin, int cout, int d, int h, int w, float *din,
+                               s2d_stream_t stream);
+int s2d_convt3d_mfma_wgrad_d16(const float *in, const void *dout_bf16, int batch, int cin, int cout, int d, int h, int w, float *dweight,
+                               void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /* weight (+ bias) gradient of the 1x1x1 Conv3d layers of the PCR head: dweight[cout][cin] = sum_{n,p} dout[n][co][p] in[n][ci][p],
  * dbias[cout] = sum dout (NCDHW fp32 tensors, positions % 4 == 0); deterministic two-stage reduction */
@@ -741,6 +749,11 @@ int s2d_pcr_level_bwd_apply_y16(const void *y, const float *bn_scale_shift, cons
                                 int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8, const float *go_mask,
                                 const float *go_offset, const float *dz, const float *w2, int co, const float *abd, float *dy,
                                 s2d_stream_t stream);
+/* bf16 y AND bf16 dy (the gradient's only readers, s2d_convt3d_mfma_{dgrad,wgrad}_d16, round it to bf16 anyway) */
+int s2d_pcr_level_bwd_apply_y16_d16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors, const float *feats,
+                                    int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8, const float *go_mask,
+                                    const float *go_offset, const float *dz, const float *w2, int co, const float *abd, void *dy_bf16,
+                                    s2d_stream_t stream);
 
 /* ---- fused PointPillars feature net (r04) ----------------------------------------------------------------------------------
  * One PFN layer of det3d/models/readers/pillar_encoder.py:41-56,114-154 (decorate -> Linear(10 -> 64) -> BatchNorm1d -> ReLU -> max over

@@ -111,6 +111,10 @@ SIGNATURES = {
     "s2d_convt3d_mfma_stats_tiles": (ctypes.c_int64, [ctypes.c_int] * 5),
     "s2d_convt3d_mfma_fwd_stats": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_fwd_stats_y16": (ctypes.c_int, [c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_convt3d_mfma_d16_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "s2d_convt3d_mfma_dgrad_d16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
+    "s2d_convt3d_mfma_wgrad_d16": (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                                                                                   ctypes.c_void_p]),
     "s2d_convt3d_mfma_dgrad": (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_convt3d_mfma_wgrad": (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p, ctypes.c_size_t,
@@ -208,6 +212,8 @@ SIGNATURES = {
     "s2d_pcr_level_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
                                     [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_pcr_level_bwd_apply_y16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                                    [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p]),
+    "s2d_pcr_level_bwd_apply_y16_d16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
                                     [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_bev_iou_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p]),
     "s2d_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),

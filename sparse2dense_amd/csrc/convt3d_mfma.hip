@@ -28,6 +28,21 @@ typedef __bf16 bf16x8m __attribute__((ext_vector_type(8)));
 constexpr unsigned CT_OOB = BUF_OOB;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ct_rsrc(const void *base, unsigned bytes) { return buf_rsrc(base, bytes); }
 __device__ __forceinline__ f32x4m ct_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return buf_load4(r, voff, soff); }
+// bf16-stored gradients (r04, the fused PCR levels write dy in bf16): raw dwords, two elements each (low half = the even element)
+typedef uint32_t u32x2m __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3m __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x3m ct_load3u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x3m, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x4m ct_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4m, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x2m ct_load2u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x2m, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint32_t ct_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (a.hi, b.hi)
+__device__ __forceinline__ uint32_t ct_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // (a.lo, b.lo)
 
 struct CtDims {
     int n, d, h, w;   // batch and INPUT extents; output is 2d x 2h x 2w
@@ -479,15 +494,17 @@ __global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restr
 // (L1) feeds MT MFMAs.  The staged kernel above holds 32-64 KB of LDS per block and waits for memory once per staging round
 // (1.9 ms for the 16 -> 3 layer at [4,16,10,376,376] against a 0.2 ms stream); a first direct version with dword loads (one
 // per channel and kx) ran at ~70 clocks per load instruction: 1.9 / 1.5 ms.
-template <int COP, int NT, int MT, bool N4 = false>
-__global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
+template <int COP, int NT, int MT, bool N4 = false, typename TD = float>
+__global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
                                                               CtTileMap map, float *__restrict__ din) {
+    constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the window [2c-1, 2c+2] is elements 1..4 of the three dwords from element 2c-2
+    constexpr unsigned ES = sizeof(TD);
     constexpr int KSTEPS = COP == 32 ? 4 : 1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
     const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
-    const unsigned oplane_b = (unsigned)(oplane * 4), dbytes = (unsigned)(s.cout * oplane * 4), ibytes = (unsigned)(s.cin * cells * 4);
+    const unsigned oplane_b = (unsigned)(oplane * ES), dbytes = (unsigned)(s.cout * oplane * ES), ibytes = (unsigned)(s.cin * cells * 4);
     // Item order (XCD-aware, see ct_fwd_mfma_kernel): an input row reads 4 x 4 (z, y) rows of dout and shares half of them with each
     // neighbour, so every dout row has four readers.  With items dealt to workgroups in plain order those sat on different XCDs and
     // HBM delivered every row up to 4x (PMC: 2.9 GB fetched for a 724 MB gradient - the kernel ran AT the HBM roof).  Here XCD x owns
@@ -519,14 +536,14 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
             const int c = x0 + mt * 16 + r;
             shifted[mt] = c == 0;
             last[mt] = c == s.w - 1;
-            pos[mt] = c < s.w ? (unsigned)((2 * c - (c == 0 ? 0 : 1)) * 4) : CT_OOB;
+            pos[mt] = c < s.w ? (D16 ? (unsigned)((c == 0 ? 0 : 2 * c - 2) * 2) : (unsigned)((2 * c - (c == 0 ? 0 : 1)) * 4)) : CT_OOB;
         }
 #pragma unroll 2
         for (int kzky = 0; kzky < (N4 ? 8 : 16); ++kzky) {
             // N4 (cout <= 4): the lane groups q = (ky of a pair, channel pair) - the row is per lane and goes into the lane offset
             const int z = 2 * hz - 1 + (N4 ? kzky >> 1 : kzky >> 2), y = 2 * hy - 1 + (N4 ? 2 * (kzky & 1) + (q >> 1) : kzky & 3);
             const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform unless N4
-            const unsigned roff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+            const unsigned roff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * ES) : 0u;
             const unsigned soff = N4 ? 0u : roff;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -537,6 +554,27 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
                 const int co0 = N4 ? 2 * (q & 1) : 8 * ks + 2 * q;
                 const unsigned pl0 = (rok && co0 < s.cout) ? (unsigned)co0 * oplane_b + (N4 ? roff : 0u) : CT_OOB;
                 const unsigned pl1 = (rok && co0 + 1 < s.cout) ? (unsigned)(co0 + 1) * oplane_b + (N4 ? roff : 0u) : CT_OOB;
+                if constexpr (D16) {
+                    u32x3m u0[MT], u1[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        u0[mt] = ct_load3u(dr, (pos[mt] | pl0) >= CT_OOB ? CT_OOB : pos[mt] + pl0, soff);
+                        u1[mt] = ct_load3u(dr, (pos[mt] | pl1) >= CT_OOB ? CT_OOB : pos[mt] + pl1, soff);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        // elements 1..4 of the six loaded ones; shifted lanes (cell 0) loaded from element 0: sample kx = element kx - 1, kx = 0 zero
+                        const bool sh = shifted[mt];
+                        const uint32_t a0 = sh ? 0u : u0[mt].x, a1 = sh ? u0[mt].x : u0[mt].y, a2 = sh ? u0[mt].y : u0[mt].z;
+                        const uint32_t b0 = sh ? 0u : u1[mt].x, b1 = sh ? u1[mt].x : u1[mt].y, b2 = sh ? u1[mt].y : u1[mt].z;
+                        const uint32_t lm = last[mt] ? 0x0000FFFFu : 0xFFFFFFFFu;   // position 2w of the last cell belongs to the next row
+                        const u32x4m pk = {__builtin_amdgcn_alignbit(a1, a0, 16), __builtin_amdgcn_alignbit(a2, a1, 16) & lm,
+                                           __builtin_amdgcn_alignbit(b1, b0, 16), __builtin_amdgcn_alignbit(b2, b1, 16) & lm};
+                        const bf16x8m a = __builtin_bit_cast(bf16x8m, pk);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                } else {
                 f32x4m v0[MT], v1[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -561,6 +599,7 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const float *__res
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[nt], acc[mt][nt], 0, 0, 0);
+                }
                 }
             }
         }
@@ -703,10 +742,12 @@ __global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restr
 // [4,32,5,188,188]); the small x tensor is re-read instead.  Per 32-cell step a wave issues all its loads first (five 16-byte
 // pieces of the 20-float dout window = the 4 kx fragments, and the 8 cells of the four input rows), then 16*CIT MFMAs into
 // acc[a][b][kx][ci tile].
-template <int CIT>
-__global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
+template <int CIT, typename TD = float>
+__global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
                                                             int co_tiles, int groups, int n_chunks, float *__restrict__ partial) {
     constexpr int FR = 16 * CIT;
+    constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the 20-element window is ten dwords, the fragments are byte permutes of them
+    constexpr unsigned ES = sizeof(TD);
     __shared__ float red[FR * 4][64];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -733,14 +774,14 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
 #pragma unroll
                 for (int i = 0; i < CIT; ++i) acc[a][b][k][i] = f32x4m{0.f, 0.f, 0.f, 0.f};
     const int steps = (s.w + 31) / 32;
-    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * 4);
+    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * ES);
     const int co = bt * 16 + r;
-    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * 4) : CT_OOB;
+    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * ES) : CT_OOB;
     for (int64_t row = r0 + wid; row < r1; row += 4) {
         const int yy = (int)(row % s.h), zz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
         const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)n * s.cin * cells, xbytes);
         const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
-        const unsigned drow = (unsigned)(((int64_t)(2 * zz + pz) * oh + (2 * yy + py)) * ow * 4);
+        const unsigned drow = (unsigned)(((int64_t)(2 * zz + pz) * oh + (2 * yy + py)) * ow * ES);
         unsigned xrow[2][2];
         bool xok[2][2];
 #pragma unroll
@@ -757,10 +798,17 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
             // dout window: floats [2*c0 - 2, 2*c0 + 18) of the row; tap kx of cell c0 + e = element 1 + kx + 2e.  The first cells'
             // window would start at -2 (out of range as a whole for plane 0): those lanes start at 0 and index two elements earlier.
             const bool shifted = c0 == 0;
-            const unsigned wl = lo_ok ? dlane + (unsigned)((2 * c0 - (shifted ? 0 : 2)) * 4) : CT_OOB;
-            f32x4m wv[5];
+            const unsigned wl = lo_ok ? dlane + (unsigned)((2 * c0 - (shifted ? 0 : 2)) * ES) : CT_OOB;
+            f32x4m wv[D16 ? 1 : 5];
+            uint32_t ww[10];
+            if constexpr (D16) {
+                const u32x4m w0 = ct_load4u(dr, wl, drow), w1 = ct_load4u(dr, wl, drow + 16u);
+                const u32x2m w2 = ct_load2u(dr, wl, drow + 32u);
+                ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w; ww[8] = w2.x; ww[9] = w2.y;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) wv[j] = ct_load4(dr, wl, drow + 16u * j);
+                for (int j = 0; j < 5; ++j) wv[j] = ct_load4(dr, wl, drow + 16u * j);
+            }
             f32x4m xl[2][2][CIT], xh[2][2][CIT];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -773,6 +821,27 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
                         xl[a][b][i] = ct_load4(xr, lo_ok ? base : CT_OOB, xrow[a][b]);
                         xh[a][b][i] = ct_load4(xr, hi_ok ? base : CT_OOB, xrow[a][b] + 16u);
                     }
+            bf16x8m bk[4];
+            if constexpr (D16) {
+                // window element j sits in word j >> 1 (low half = even j); shifted lanes loaded from element 0: word i = loaded word i - 1.
+                // tap kx of cell c0 + e = element 1 + kx + 2e: kx 0 / 2 are the high halves of words e / e + 1, kx 1 / 3 the low halves of
+                // words e + 1 / e + 2; a fragment word holds the samples of two consecutive cells
+                uint32_t ws[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) ws[i] = shifted ? (i ? ww[i - 1] : 0u) : ww[i];
+                const int elast = s.w - 1 - c0;   // the sample of kx = 3 at cell w - 1 is position 2w: it belongs to the next row
+                u32x4m f0, f1, f2, f3;
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    f0[pq] = ct_hi_hi(ws[2 * pq], ws[2 * pq + 1]);
+                    f1[pq] = ct_lo_lo(ws[2 * pq + 1], ws[2 * pq + 2]);
+                    f2[pq] = ct_hi_hi(ws[2 * pq + 1], ws[2 * pq + 2]);
+                    const uint32_t m3 = elast == 2 * pq ? 0xFFFF0000u : (elast == 2 * pq + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+                    f3[pq] = ct_lo_lo(ws[2 * pq + 2], ws[2 * pq + 3]) & m3;
+                }
+                bk[0] = __builtin_bit_cast(bf16x8m, f0); bk[1] = __builtin_bit_cast(bf16x8m, f1);
+                bk[2] = __builtin_bit_cast(bf16x8m, f2); bk[3] = __builtin_bit_cast(bf16x8m, f3);
+            } else {
             float win[20];
 #pragma unroll
             for (int j = 0; j < 20; ++j) {
@@ -780,7 +849,6 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
                 const float early = j >= 2 ? wv[(j - 2) >> 2][(j - 2) & 3] : 0.f;   // shifted lanes: element j of the window = loaded j - 2
                 win[j] = shifted ? early : plain;
             }
-            bf16x8m bk[4];
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
@@ -789,6 +857,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
                     if (kx == 3) v = (c0 + e == s.w - 1) ? 0.f : v;   // position 2w belongs to the next row
                     bk[kx][e] = (__bf16)v;
                 }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -838,10 +907,12 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
 // all 16 (kz,ky) accumulators.  The 16 window loads of four (kz,ky) rows are issued together, branch-free (rows / columns / lanes
 // outside the tensor get an out-of-range buffer offset): the first version waited for memory once per (kz,ky) row with two
 // waves per SIMD (3.5 ms at [4,16,10,376,376]).
-template <int CIT>
-__global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const float *__restrict__ dout, CtDims s, int rows_per_block,
+template <int CIT, typename TD = float>
+__global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
                                                               int n_chunks, float *__restrict__ partial) {
     constexpr int FR = 16 * CIT;
+    constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the 16-element window is eight dwords (two 16-byte loads instead of four)
+    constexpr unsigned ES = sizeof(TD);
     __shared__ float red[FR * 4][64];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -860,12 +931,13 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
 #pragma unroll
         for (int a = 0; a < CIT; ++a) acc[g][a] = f32x4m{0.f, 0.f, 0.f, 0.f};
     const int steps = (s.w + 31) / 32;
-    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * 4);
+    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * ES);
     // window of the lane: floats [base, base + 16) of the dout row with base = 2*c0 - 2 + 2*((kx + 1) >> 1); sample e = element
     // 2e + (kx odd ? 0 : 1), i.e. position 2*(c0 + e) - 1 + kx
     const int wshift = 2 * ((kx + 1) >> 1) - 2;
     const bool odd = kx & 1;
-    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * 4) : CT_OOB;
+    const unsigned dlane = co < s.cout ? (unsigned)(co * oplane * ES) : CT_OOB;
+    const uint32_t half_sel = odd ? 0x05040100u : 0x07060302u;   // bf16 dout: sample e = the low (odd kx) / high (even kx) half of window word e
     for (int64_t row = r0 + wid; row < r1; row += 4) {
         const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
         const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)n * s.cin * cells, xbytes);
@@ -886,23 +958,44 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
             // the window of the row's first cells with kx = 0 would start at position -2: an offset below the plane start is out
             // of range as a whole for plane 0, so those lanes start at 0 and take their samples two elements earlier
             const bool shifted = 2 * c0 + wshift < 0;
-            const unsigned wlane = cok ? dlane + (unsigned)((2 * c0 + wshift + (shifted ? 2 : 0)) * 4) : CT_OOB;
+            const unsigned wlane = cok ? dlane + (unsigned)((2 * c0 + wshift + (shifted ? 2 : 0)) * ES) : CT_OOB;
             const bool first_bad = 2 * c0 - 1 + kx < 0, last_bad = 2 * (c0 + 7) - 1 + kx >= ow;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                f32x4m wv[4][4];
+                f32x4m wv[4][D16 ? 1 : 4];
+                u32x4m wu[4][2];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int z = 2 * hz - 1 + gq, y = 2 * hy - 1 + g4;
                     const bool rok = (unsigned)z < (unsigned)od && (unsigned)y < (unsigned)oh;   // wave-uniform
-                    const unsigned soff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * 4) : 0u;
+                    const unsigned soff = rok ? (unsigned)(((int64_t)z * oh + y) * ow * ES) : 0u;
                     const unsigned wl = rok ? wlane : CT_OOB;   // the range check sees the per-lane offset only
+                    if constexpr (D16) {
+                        wu[g4][0] = ct_load4u(dr, wl, soff);
+                        wu[g4][1] = ct_load4u(dr, wl, soff + 16u);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wv[g4][j] = ct_load4(dr, wl, soff + 16u * j);
+                        for (int j = 0; j < 4; ++j) wv[g4][j] = ct_load4(dr, wl, soff + 16u * j);
+                    }
                 }
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     bf16x8m b;
+                    if constexpr (D16) {
+                        // shifted lanes (kx = 0 at the row start) take element 2e - 1 = the high half of word e - 1; sample 0 is then position -1
+                        uint32_t wsr[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t cur = wu[g4][i >> 2][i & 3], prev = i ? wu[g4][(i - 1) >> 2][(i - 1) & 3] : 0u;
+                            wsr[i] = shifted ? prev : cur;
+                        }
+                        u32x4m f;
+#pragma unroll
+                        for (int pq = 0; pq < 4; ++pq) f[pq] = __builtin_amdgcn_perm(wsr[2 * pq + 1], wsr[2 * pq], half_sel);
+                        f[0] = first_bad ? (f[0] & 0xFFFF0000u) : f[0];   // position -1 of the row belongs to the previous row
+                        f[3] = last_bad ? (f[3] & 0x0000FFFFu) : f[3];    // position ow to the next one
+                        b = __builtin_bit_cast(bf16x8m, f);
+                    } else
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float v = odd ? wv[g4][e >> 1][(2 * e) & 3] : wv[g4][e >> 1][(2 * e + 1) & 3];
@@ -1050,37 +1143,48 @@ extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const f
     return s2d_convt3d_mfma_fwd_stats(in, packed, bias, batch, cin, cout, d, h, w, out, nullptr, stream);
 }
 
+// the direct (LDS-free) data-gradient kernels cover a layer when one sample's fp32 dout stays under 2 GB
+static bool ct_dgrad_is_direct(int cout, int d, int h, int w) { return (int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31); }
+
+template <typename TD>
+static int ct_dgrad_direct_launch(const TD *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w, float *din, hipStream_t st) {
+    CtDims s{batch, d, h, w, cin, cout};
+    const dim3 blk(256);
+    const int nt_f = (cout + 15) / 16;
+    const __bf16 *wp = (const __bf16 *)packed + (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512;
+    const bool narrow = cout <= 8;
+    constexpr int MT = 4;
+    const int tpr = (w + 16 * MT - 1) / (16 * MT);
+    const int64_t items = (int64_t)batch * d * h * tpr;
+    S2D_CHECK_ARG(items < 0x7fffffff, "convt3d_mfma_dgrad: too many tiles");
+    const dim3 g2(xcd_grid(std::min<int64_t>(ceil_div(items, 4), 256 * 16)));
+    // live across a z step: 4 z planes x (2 yc + 2) rows of dout, cout planes each
+    const CtTileMap map = ct_tile_map(d, h, tpr, ct_chunk_rows((int64_t)2 * w * cout * sizeof(TD), 2, 2, 4));
+    const __bf16 *wd = wp + (size_t)16 * (narrow ? 1 : 4) * (cin / 16) * 512;   // the direct kernel's image follows the staged one
+    if (narrow && cout <= 4 && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, true, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    else if (narrow && cout <= 4) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, true, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    else if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, false, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, false, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT, false, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT, false, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
 extern "C" int s2d_convt3d_mfma_dgrad(const float *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w,
                                       float *din, s2d_stream_t stream) {
     S2D_CHECK_ARG(dout && packed && din && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_dgrad: bad argument");
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (ct_dgrad_is_direct(cout, d, h, w)) return ct_dgrad_direct_launch<float>(dout, packed, batch, cin, cout, d, h, w, din, st);
     CtDims s{batch, d, h, w, cin, cout};
     const int xtiles = (w + CT_TX - 1) / CT_TX;
     const int64_t blocks = (int64_t)batch * d * h * xtiles;
     S2D_CHECK_ARG(blocks < 0x7fffffff, "convt3d_mfma_dgrad: grid too large");
     const dim3 grid((unsigned)blocks), blk(256);
-    hipStream_t st = (hipStream_t)stream;
     const int nt_f = (cout + 15) / 16;
     const __bf16 *wp = (const __bf16 *)packed + (size_t)8 * (cin == 32 ? 8 : 4) * nt_f * 512;
     const bool narrow = cout <= 8;
-    if ((int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31)) {   // direct fragments, no LDS staging (one sample's dout < 2 GB)
-        constexpr int MT = 4;
-        const int tpr = (w + 16 * MT - 1) / (16 * MT);
-        const int64_t items = (int64_t)batch * d * h * tpr;
-        S2D_CHECK_ARG(items < 0x7fffffff, "convt3d_mfma_dgrad: too many tiles");
-        const dim3 g2(xcd_grid(std::min<int64_t>(ceil_div(items, 4), 256 * 16)));
-        // live across a z step: 4 z planes x (2 yc + 2) rows of dout, cout planes each
-        const CtTileMap map = ct_tile_map(d, h, tpr, ct_chunk_rows((int64_t)2 * w * cout * 4, 2, 2, 4));
-        const __bf16 *wd = wp + (size_t)16 * (narrow ? 1 : 4) * (cin / 16) * 512;   // the direct kernel's image follows the staged one
-        if (narrow && cout <= 4 && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, true>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        else if (narrow && cout <= 4) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, true>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        else if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        else if (narrow) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 2, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        else hipLaunchKernelGGL((ct_dgrad_direct_kernel<32, 1, MT>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
-        S2D_LAUNCH_CHECK();
-        return S2D_OK;
-    }
     if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 2, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
     else if (narrow) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<8, 1, 16>), grid, blk, 0, st, dout, wp, s, xtiles, din);
     else if (cin == 32) hipLaunchKernelGGL((ct_dgrad_mfma_kernel<32, 2, 2>), grid, blk, 0, st, dout, wp, s, xtiles, din);
@@ -1094,6 +1198,38 @@ extern "C" size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int
     return align_up((size_t)ct_wgrad_blocks_for((int64_t)batch * d * h, cout, w) * cin * cout * 64 * sizeof(float), 256);
 }
 
+// the weight-gradient kernels that read a bf16-stored dout: the narrow one and the output-row-major one
+static bool ct_wgrad_has_d16(int cout, int w) { return ct_wgrad_is_narrow(cout, w) || w % 4 == 0; }
+
+template <typename TD>
+static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, int cout, int d, int h, int w, float *dweight, void *ws, hipStream_t st) {
+    CtDims s{batch, d, h, w, cin, cout};
+    const int64_t rows = (int64_t)batch * d * h;
+    const int bx = ct_wgrad_blocks_for(rows, cout, w);
+    const int rpb = (int)ceil_div(rows, bx);
+    float *partial = (float *)ws;
+    const int cit = cin / 16, cot = (cout + 15) / 16;
+    const bool narrow = ct_wgrad_is_narrow(cout, w);
+    if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
+    else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
+    // both input-channel tiles in one block: dout is read once (measured 0.62 ms against 0.85 ms with one tile per block and two
+    // resident waves per SIMD, 32 -> 32 at [4,32,5,188,188])
+    else if (w % 4 == 0 && cit == 2) hipLaunchKernelGGL((ct_wgrad_rows_kernel<2, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot, bx, partial);
+    else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot * cit)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot * cit, bx, partial);
+    else if constexpr (sizeof(TD) == 4) {
+        if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
+        else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
+        else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
+        else hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 1, 8>), dim3(bx, 2), dim3(256), 0, st, in, dout, s, rpb, partial);
+    } else {
+        return S2D_ERR_UNSUPPORTED;
+    }
+    const int64_t size = (int64_t)cin * cout * 64;
+    hipLaunchKernelGGL(ct_slab_reduce_kernel, dim3((unsigned)ceil_div(size, 16)), dim3(256), 0, st, partial, bx, size, dweight);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
 extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int batch, int cin, int cout, int d, int h, int w,
                                       float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && dout && dweight && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_wgrad: bad argument");
@@ -1103,28 +1239,30 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
         set_error("convt3d_mfma_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
         return S2D_ERR_WORKSPACE;
     }
-    CtDims s{batch, d, h, w, cin, cout};
-    const int64_t rows = (int64_t)batch * d * h;
-    const int bx = ct_wgrad_blocks_for(rows, cout, w);
-    const int rpb = (int)ceil_div(rows, bx);
-    hipStream_t st = (hipStream_t)stream;
-    float *partial = (float *)ws;
-    const int cit = cin / 16, cot = (cout + 15) / 16;
-    const bool narrow = ct_wgrad_is_narrow(cout, w);
-    if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
-    else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
-    // both input-channel tiles in one block: dout is read once (measured 0.62 ms against 0.85 ms with one tile per block and two
-    // resident waves per SIMD, 32 -> 32 at [4,32,5,188,188])
-    else if (w % 4 == 0 && cit == 2) hipLaunchKernelGGL((ct_wgrad_rows_kernel<2>), dim3(xcd_grid((int64_t)bx * 4 * cot)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot, bx, partial);
-    else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1>), dim3(xcd_grid((int64_t)bx * 4 * cot * cit)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot * cit, bx, partial);
-    else if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
-    else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
-    else if (cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 2, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
-    else hipLaunchKernelGGL((ct_wgrad_mfma_kernel<1, 1, 8>), dim3(bx, 2), dim3(256), 0, st, in, dout, s, rpb, partial);
-    const int64_t size = (int64_t)cin * cout * 64;
-    hipLaunchKernelGGL(ct_slab_reduce_kernel, dim3((unsigned)ceil_div(size, 16)), dim3(256), 0, st, partial, bx, size, dweight);
-    S2D_LAUNCH_CHECK();
-    return S2D_OK;
+    return ct_wgrad_launch<float>(in, dout, batch, cin, cout, d, h, w, dweight, ws, (hipStream_t)stream);
+}
+
+/* ---- bf16-stored output gradient (r04): the same data / weight gradients from a dout the producer wrote in bf16 (the kernels round it to
+ * bf16 anyway: identical results, half the bytes on the 0.5-0.7 GB tensor).  _supported: the layer shapes the bf16-reading kernels cover. */
+extern "C" int s2d_convt3d_mfma_d16_supported(int cin, int cout, int d, int h, int w) {
+    return ct_mfma_ok(cin, cout) && d > 0 && h > 0 && w > 0 && ct_dgrad_is_direct(cout, d, h, w) && ct_wgrad_has_d16(cout, w);
+}
+extern "C" int s2d_convt3d_mfma_dgrad_d16(const void *dout_bf16, const void *packed, int batch, int cin, int cout, int d, int h, int w, float *din,
+                                          s2d_stream_t stream) {
+    S2D_CHECK_ARG(dout_bf16 && packed && din && batch > 0, "convt3d_mfma_dgrad_d16: bad argument");
+    if (!s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
+    return ct_dgrad_direct_launch<__bf16>((const __bf16 *)dout_bf16, packed, batch, cin, cout, d, h, w, din, (hipStream_t)stream);
+}
+extern "C" int s2d_convt3d_mfma_wgrad_d16(const float *in, const void *dout_bf16, int batch, int cin, int cout, int d, int h, int w, float *dweight,
+                                          void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && dout_bf16 && dweight && batch > 0, "convt3d_mfma_wgrad_d16: bad argument");
+    if (!s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
+    const size_t need = s2d_convt3d_mfma_wgrad_workspace_bytes(batch, cin, cout, d, h, w);
+    if (!ws || ws_bytes < need) {
+        set_error("convt3d_mfma_wgrad_d16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    return ct_wgrad_launch<__bf16>(in, (const __bf16 *)dout_bf16, batch, cin, cout, d, h, w, dweight, ws, (hipStream_t)stream);
 }
 
 // ---- 1x1x1 Conv3d weight gradient (planar fp32 tensors) ------------------------------------------------------------

@@ -305,6 +305,21 @@ template <int V, typename T> __device__ __forceinline__ void buf_load_t(__amdgpu
         v[2] = bf16_bits_to_f32(b & 0xFFFFu); v[3] = bf16_bits_to_f32(b >> 16);
     }
 }
+// V consecutive elements stored as T (fp32 or round-to-nearest-even bf16, two per dword)
+template <int V, typename T> __device__ __forceinline__ void buf_store_t(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float (&v)[V]) {
+    if constexpr (sizeof(T) == 4) {
+        buf_store<V>(r, voff, soff, v);
+    } else {
+        uint32_t w[V / 2];
+#pragma unroll
+        for (int k = 0; k < V / 2; ++k) {
+            const __bf16 lo = (__bf16)v[2 * k], hi = (__bf16)v[2 * k + 1];
+            w[k] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+        }
+        if constexpr (V == 2) buf_store1(r, voff, soff, __builtin_bit_cast(float, w[0]));
+        else buf_store2(r, voff, soff, __builtin_bit_cast(buf_f32x2, ((uint64_t)w[1] << 32) | w[0]));
+    }
+}
 // the V consecutive elements of C planes held the way they were loaded: fp32 as floats, bf16 PACKED (two per register) and unpacked at
 // every use - unpacking at the load kept both forms live and cost the 32-channel backward kernels their occupancy (166 -> 257 registers)
 template <int C, int V, typename T> struct YPack;
@@ -877,11 +892,11 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t
 
 // pass A (APPLY = false): partial[block][3C+1] = dw_mask(C) | db_mask | sum dG*m (C) | sum dG*m*y (C), nothing written;
 // pass B (APPLY = true):  dy = a*dG*m + b*y + d
-template <int C, int CO, int V, bool APPLY, typename TY = float>
+template <int C, int CO, int V, bool APPLY, typename TY = float, typename TD = float>
 __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__restrict__ y, const float *__restrict__ dz, const float *__restrict__ bnp,
                                                                   const float *__restrict__ w2, const float *__restrict__ hp,
                                                                   const float *__restrict__ go_mask, const float *__restrict__ fin,
-                                                                  const float *__restrict__ abd, int64_t cells, int batch, float *__restrict__ dy,
+                                                                  const float *__restrict__ abd, int64_t cells, int batch, TD *__restrict__ dy,
                                                                   float *__restrict__ partial) {
     __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
     __shared__ float abds[APPLY ? 3 * C : 1];
@@ -903,10 +918,10 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
 #pragma unroll
     for (int c = 0; c < (APPLY ? 1 : 3 * C + 1); ++c) pw[c] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
-    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY);
+    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY), dplane = (unsigned)cells * (unsigned)sizeof(TD);
     for (int b = 0; b < batch; ++b) {
         const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * yplane);
-        const __amdgpu_buffer_rsrc_t dyr = APPLY ? planes_rsrc(dy + (int64_t)b * C * cells, C * plane) : yr;
+        const __amdgpu_buffer_rsrc_t dyr = APPLY ? planes_rsrc(dy + (int64_t)b * C * cells, C * dplane) : yr;
         const __amdgpu_buffer_rsrc_t zr = CO > 0 ? planes_rsrc(dz + (int64_t)b * CO * cells, CO * plane) : yr;
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
             asm volatile("" ::: "memory");
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
                         const float g = fmaf(yv.get(c, k), sc, sh);
                         r[k] = fmaf(a, g > 0.f ? o[k] : 0.f, fmaf(bb, yv.get(c, k), dd));
                     }
-                    buf_store<V>(dyr, voff, c * plane, r);
+                    buf_store_t<V, TD>(dyr, j * (V * (unsigned)sizeof(TD)), c * dplane, r);
                 } else {
 #pragma unroll
                     for (int k = 0; k < V; ++k) {
@@ -976,12 +991,12 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
 // sparse pass A (APPLY = false): partial[block][6C+4] = dw_mask(C) | dw_off(3C) | db_mask | db_off(3) | sum corr*m (C) | sum corr*m*y (C);
 //   blockIdx.y selects a group of CG channels whose accumulators the thread keeps (6*CG+4 registers instead of 6*C+4)
 // sparse pass B (APPLY = true):  dy[c][cell] += a[c] * corr[c] * m
-template <int C, int CG, bool APPLY, typename TY = float>
+template <int C, int CG, bool APPLY, typename TY = float, typename TD = float>
 __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
                                                                    PcrGeo geo, const TY *__restrict__ y, const float *__restrict__ bnp,
                                                                    const float *__restrict__ hp, const float *__restrict__ go_mask,
                                                                    const float *__restrict__ go_off, const float *__restrict__ fin,
-                                                                   const float *__restrict__ abd, float *__restrict__ dy, float *__restrict__ partial) {
+                                                                   const float *__restrict__ abd, TD *__restrict__ dy, float *__restrict__ partial) {
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
     pcr_load_head<C>(hp, hw);
@@ -1019,11 +1034,11 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t
             dk[k] = (t != 0.f) ? (dlt > 0.f ? so : (dlt < 0.f ? -so : 0.f)) : 0.f;
         }
         if constexpr (APPLY) {
-            float *ob = dy + (int64_t)c.x * C * cells + cell;
+            TD *ob = dy + (int64_t)c.x * C * cells + cell;   // (a cell belongs to one recon voxel: a 2-byte read-modify-write of a bf16 dy is private)
 #pragma unroll
             for (int q = 0; q < C; ++q) {
                 const float corr = (hw.wm[q] * dmk + hw.wo[0][q] * dk[0]) + (hw.wo[1][q] * dk[1] + hw.wo[2][q] * dk[2]);
-                if (gv[q] > 0.f) ob[(int64_t)q * cells] += abd[q] * corr;
+                if (gv[q] > 0.f) ob[(int64_t)q * cells] = (TD)((float)ob[(int64_t)q * cells] + abd[q] * corr);
             }
         } else {
 #pragma unroll
@@ -1123,26 +1138,26 @@ static int pcr_level_bwd_sums_t(const TY *y, const float *bnp, const float *hp, 
     float *dense_partial = ws, *sparse_partial = ws + (size_t)PCRH_DENSE_BLOCKS * (3 * C + 1);
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false, TY>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
-                       geo.batch, nullptr, dense_partial);
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false, TY, float>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
+                       geo.batch, (float *)nullptr, dense_partial);
     constexpr int CG = C == 32 ? 8 : C;   // channel groups of the sparse pass (accumulator registers)
-    hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false, TY>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask, go_off,
-                       fin, nullptr, nullptr, sparse_partial);
+    hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false, TY, float>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask,
+                       go_off, fin, nullptr, (float *)nullptr, sparse_partial);
     hipLaunchKernelGGL((pcr_level_fold_kernel<C>), dim3(6 * C + 4), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, grads, bn_sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
 
-template <int C, int CO, int V, typename TY = float>
+template <int C, int CO, int V, typename TY = float, typename TD = float>
 static int pcr_level_bwd_apply_t(const TY *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
                                  const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, const float *abd,
-                                 float *dy, hipStream_t st) {
+                                 TD *dy, hipStream_t st) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
     const int nd = (int)std::min<int64_t>(2 * PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true, TY>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true, TY, TD>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
                        dy, nullptr);
     if (m > 0)
-        hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true, TY>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
+        hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true, TY, TD>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
                            coors, feats, m, geo, y, bnp, hp, go_mask, go_off, fin, abd, dy, nullptr);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1253,11 +1268,11 @@ extern "C" int s2d_pcr_level_bwd_sums_y16(const void *y, const float *bn_scale_s
 }
 
 // pass B: dy[B][C][cells] = a*dG*m + b*y + d with abd (device, 3C) = a[C] | b[C] | d[C] from the batch-norm backward finalisation
-static int pcr_level_bwd_apply_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+static int pcr_level_bwd_apply_any(const void *yv, int y16 /* 0: fp32 y, fp32 dy; 1: bf16 y, fp32 dy; 2: bf16 y, bf16 dy */, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                            const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                            const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
-                                           float *dy, s2d_stream_t stream) {
-    S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dy && batch > 0 && d > 0 && h > 0 && w > 0 &&
+                                           void *dyv, s2d_stream_t stream) {
+    S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dyv && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_apply: bad argument");
     if (!s2d_pcr_heads_supported(c, co, (int64_t)d * h * w)) {
@@ -1266,20 +1281,22 @@ static int pcr_level_bwd_apply_any(const void *yv, int y16, const float *bn_scal
     }
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
-#define S2D_LVL_APPLY(TY_)                                                                                                                       \
+#define S2D_LVL_APPLY(TY_, TD_)                                                                                                                  \
     do {                                                                                                                                          \
         const TY_ *y = (const TY_ *)yv;                                                                                                           \
+        TD_ *dy = (TD_ *)dyv;                                                                                                                     \
         if (c == 32 && co == 16)                                                                                                                  \
-            return pcr_level_bwd_apply_t<32, 16, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, \
+            return pcr_level_bwd_apply_t<32, 16, 2, TY_, TD_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, \
                                                          abd, dy, st);                                                                            \
         if (c == 32)                                                                                                                              \
-            return pcr_level_bwd_apply_t<32, 0, 2, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2,  \
+            return pcr_level_bwd_apply_t<32, 0, 2, TY_, TD_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2,  \
                                                         abd, dy, st);                                                                             \
-        return pcr_level_bwd_apply_t<3, 0, 4, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, \
+        return pcr_level_bwd_apply_t<3, 0, 4, TY_, TD_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, \
                                                    st);                                                                                           \
     } while (0)
-    if (y16) S2D_LVL_APPLY(__bf16);
-    S2D_LVL_APPLY(float);
+    if (y16 == 2) S2D_LVL_APPLY(__bf16, __bf16);
+    if (y16) S2D_LVL_APPLY(__bf16, float);
+    S2D_LVL_APPLY(float, float);
 #undef S2D_LVL_APPLY
 }
 extern "C" int s2d_pcr_level_bwd_apply_f32(const float *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
@@ -1295,6 +1312,14 @@ extern "C" int s2d_pcr_level_bwd_apply_y16(const void *y, const float *bn_scale_
                                            float *dy, s2d_stream_t stream) {
     return pcr_level_bwd_apply_any(y, 1, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, abd, dy,
                                    stream);
+}
+/* bf16 y AND bf16 dy: the gradient's only readers (the up-sampler's data- and weight-gradient kernels) round it to bf16 anyway */
+extern "C" int s2d_pcr_level_bwd_apply_y16_d16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                               const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                               const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co,
+                                               const float *abd, void *dy_bf16, s2d_stream_t stream) {
+    return pcr_level_bwd_apply_any(y, 2, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, abd,
+                                   dy_bf16, stream);
 }
 
 // =====================================================================================================================

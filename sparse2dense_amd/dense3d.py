@@ -166,13 +166,19 @@ class _ConvT3dFn(torch.autograd.Function):
         """dout_sum (direct calls from heads._UpsampleLevelFn only): per-channel sums of dout the caller already has = the bias gradient"""
         lib = _lib.load()
         x, weight = ctx.saved_tensors
-        dout = dout.float().contiguous()   # (the gradient of a bf16-stored output arrives in fp32 from the fused level; a bf16 one is widened)
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
+        # r04: the fused PCR level hands its gradient over in bf16 when the matrix-core kernels cover the layer (they round dout to bf16 on load
+        # anyway); any other bf16 gradient is widened
+        d16 = bool(dout.dtype == torch.bfloat16 and ctx.mfma and lib.s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w))
+        dout = dout.contiguous() if d16 else dout.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if ctx.mfma:
+            if d16:
+                check(lib.s2d_convt3d_mfma_dgrad_d16(_ptr(dout), _ptr(_convt_packed(weight)), n, cin, cout, d, h, w, _ptr(dx), _stream()),
+                      "s2d_convt3d_mfma_dgrad_d16")
+            elif ctx.mfma:
                 check(lib.s2d_convt3d_mfma_dgrad(_ptr(dout), _ptr(_convt_packed(weight)), n, cin, cout, d, h, w, _ptr(dx), _stream()),
                       "s2d_convt3d_mfma_dgrad")
             else:
@@ -180,7 +186,11 @@ class _ConvT3dFn(torch.autograd.Function):
                       "s2d_convt3d_k4s2p1_dgrad_f32")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            if ctx.mfma:
+            if d16:
+                ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
+                check(lib.s2d_convt3d_mfma_wgrad_d16(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(), _stream()),
+                      "s2d_convt3d_mfma_wgrad_d16")
+            elif ctx.mfma:
                 ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
                 check(lib.s2d_convt3d_mfma_wgrad(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(), _stream()),
                       "s2d_convt3d_mfma_wgrad")
@@ -200,6 +210,8 @@ class _ConvT3dFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if dout_sum is not None:
                 db = dout_sum
+            elif d16:
+                db = dout.float().sum(dim=(0, 2, 3, 4))
             elif dout[0, 0].numel() % 4 == 0:   # per-channel sums of a planar tensor: the first half of the BN3d statistics pass
                 db = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, cout, dout[0, 0].numel(), x.device)[:cout]
             else:

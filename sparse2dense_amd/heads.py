@@ -11,6 +11,7 @@ training hot path.
 """
 import copy
 import logging
+import os
 from collections import defaultdict
 
 import torch
@@ -398,9 +399,10 @@ class _PcrLevelNormFn(torch.autograd.Function):
         # sum over this rank's rows of dy = a g + b y + d, per channel, from the sums at hand (= the bias gradient of the conv that produced
         # y; mathematically zero behind a training-mode batch norm, fp32 rounding noise here as in the reference) - no pass over dy
         ctx.dy_sum = fin[2].reshape(-1) * sums[:c] + fin[3].reshape(-1) * ctx.local_ysum + fin[4].reshape(-1) * ctx.local_rows
-        dy = torch.empty(y.shape, dtype=torch.float32, device=dev)
-        _lib.check((lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32)(*args, _ptr(abd), _ptr(dy), _stream()),
-                   "s2d_pcr_level_bwd_apply")
+        dy16 = y16 and getattr(ctx, "dy16", False)   # set by _UpsampleLevelFn: dy never leaves the node and its readers take bf16
+        dy = torch.empty(y.shape, dtype=torch.bfloat16 if dy16 else torch.float32, device=dev)
+        apply = lib.s2d_pcr_level_bwd_apply_y16_d16 if dy16 else (lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32)
+        _lib.check(apply(*args, _ptr(abd), _ptr(dy), _stream()), "s2d_pcr_level_bwd_apply")
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None
         if co:
@@ -456,6 +458,11 @@ class _UpsampleLevelFn(torch.autograd.Function):
         y, stats = _ConvT3dFn.forward(c1, x, ct_w, ct_b, True, True, y16)
         c2 = _SubCtx((True,) * 3 + (False,) * 12)
         ml, ol, z = _PcrLevelNormFn.forward(c2, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, stats, z_stats_out)
+        # the gradient of y goes from the level's backward straight into the up-sampler's: stored in bf16 as well when the up-sampler's
+        # matrix-core kernels read that (they round it to bf16 on load in any case; S2D_PCR_DY16=0 keeps it fp32)
+        from . import _lib
+        c2.dy16 = bool(y16 and os.environ.get("S2D_PCR_DY16", "1") != "0"
+                       and _lib.load().s2d_convt3d_mfma_d16_supported(x.shape[1], ct_w.shape[1], *x.shape[2:]))
         ctx.c1, ctx.c2 = c1, c2
         ctx.has_z = z is not None
         return (ml, ol, z) if z is not None else (ml, ol)

@@ -314,3 +314,66 @@ def test_pcr_level_with_bf16_stored_up_sampler_output(b, c, co, d, h, w, m):
         tol = 8e-3 if i == 0 and a.dtype == torch.bfloat16 else 2e-5    # (autograd stores the gradient of a bf16 leaf in bf16)
         err = float((a.double() - ref.double()).abs().max() / ref.double().abs().max())
         assert err <= tol, (i, err)
+
+
+@pytest.mark.parametrize("cin,cout,co,b,d,h,w,m", [(32, 32, 16, 2, 3, 6, 12, 400), (16, 3, 0, 2, 3, 5, 16, 500), (16, 3, 0, 1, 2, 4, 12, 90),
+                                                   (32, 3, 0, 1, 2, 4, 8, 60), (16, 32, 0, 1, 2, 3, 8, 50)])
+def test_upsample_level_bf16_gradient_storage(cin, cout, co, b, d, h, w, m, monkeypatch):
+    """r04 heads.upsample_level (ConvTranspose3d(4,2,1) + the fused level as one node): with the raw output y stored in bf16 the node also
+    stores dy in bf16 (s2d_pcr_level_bwd_apply_y16_d16 -> s2d_convt3d_mfma_{dgrad,wgrad}_d16).  The up-sampler's matrix-core kernels round
+    dy to bf16 when they load it, so against the same node with an fp32 dy (S2D_PCR_DY16=0) nothing changes except at the <= m recon
+    cells, where the sparse correction is added to an already rounded value (one extra bf16 rounding): forward identical, every gradient
+    produced before dy identical, dx / dW of the up-sampler within 2e-3 of their norm.  All-fp32 storage (y16=False) is the looser
+    reference for the bf16-stored y (bar 6e-2: the level's ReLU and L1-sign decisions move with the rounding of y; 4e-2 seen on the 3-channel level)."""
+    import copy
+    from torch import nn
+    from sparse2dense_amd import dense3d
+    from sparse2dense_amd.dense3d import ConvTranspose3dK4S2, FastBatchNorm3d
+    od, oh, ow = 2 * d, 2 * h, 2 * w
+    coors, feats, _, _ = _case(b, od, oh, ow, m, seed=cin + cout + m)
+    gen = torch.Generator().manual_seed(5 + cin + m)
+    x0 = torch.randn(b, cin, d, h, w, generator=gen)
+    ct = ConvTranspose3dK4S2(cin, cout, 4, 2, 1)
+    ct.bf16_compute = True
+    bn = FastBatchNorm3d(cout, fused_relu=True)
+    mask_conv, off_conv = nn.Conv3d(cout, 1, 1), nn.Conv3d(cout, 3, 1)
+    nxt = nn.Conv3d(cout, co, 1) if co else None
+    r = torch.randn(b, co, od, oh, ow, generator=gen) / (b * od * oh * ow) if co else None
+    seen = []
+    orig = dense3d._ConvT3dFn.backward
+    monkeypatch.setattr(dense3d._ConvT3dFn, "backward", staticmethod(lambda ctx, dout, *a, **k: (seen.append(dout.dtype), orig(ctx, dout, *a, **k))[1]))
+
+    def run(y16, dy16):
+        monkeypatch.setenv("S2D_PCR_DY16", "1" if dy16 else "0")
+        mods = [None if mm is None else copy.deepcopy(mm).to("cuda") for mm in (ct, bn, mask_conv, off_conv, nxt)]
+        mods[0].bf16_compute = True
+        if mods[4] is not None:
+            mods[4].bf16_compute = True
+        mods[1].train()
+        assert heads.upsample_level_supported(mods[0], (d, h, w), mods[4])
+        x = x0.to("cuda").requires_grad_(True)
+        ml, ol, z = heads.upsample_level(mods[0], x, mods[1], mods[2], mods[3], coors.to("cuda"), feats.to("cuda"), next_conv=mods[4], y16=y16)
+        total = 1.7 * ml + 0.6 * ol
+        if co:
+            total = total + (z * r.to("cuda")).sum()
+        total.backward()
+        return ml, ol, z, [x.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+
+    ref = run(False, False)
+    a = run(True, False)
+    bb = run(True, True)
+    assert seen == [torch.float32, torch.float32, torch.bfloat16], seen
+    rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-30))
+    assert bb[0].item() == a[0].item() and bb[1].item() == a[1].item()
+    if co:
+        assert torch.equal(bb[2], a[2])
+    for i, (u, v) in enumerate(zip(bb[3], a[3])):
+        if i in (0, 1):                       # dx and the up-sampler's weight gradient read dy
+            assert rel(u, v) <= 2e-3, (i, rel(u, v))
+        elif i == 2:                          # its bias gradient: analytic, ~0 behind the batch norm (noise against noise)
+            assert float((u - v).abs().max()) <= 1e-4 * float(a[3][1].abs().max()), i
+        else:
+            assert torch.equal(u, v), i
+    for i, (u, v) in enumerate(zip(a[3], ref[3])):
+        if i != 2:
+            assert rel(u, v) <= 6e-2, (i, rel(u, v))
