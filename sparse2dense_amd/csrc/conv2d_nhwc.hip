@@ -48,6 +48,36 @@ __device__ __forceinline__ void conv2d_pack_element(const float *__restrict__ w,
     out[i] = (__bf16)v;
 }
 
+// the eight consecutive packed elements [8 i8, 8 i8 + 8) (the e index: eight consecutive input channels of one (tap, co)): one 16-byte
+// store and one index decomposition instead of eight (the batched re-pack after the optimizer step: 150 -> see DESIGN us per step)
+__device__ __forceinline__ void conv2d_pack_element8(const float *__restrict__ w, int cin, int cout, int bn, int transpose_flip, int w_nhwc, int taps,
+                                                     int64_t i8, __bf16 *__restrict__ out) {
+    const int64_t total8 = (int64_t)taps * cin * cout / 8;
+    if (i8 >= total8) return;
+    const int ntile = bn / 16, per_wave = bn / 32;
+    int64_t r = i8;
+    const int c = r % 16; r /= 16;
+    const int q = r % 4; r /= 4;
+    const int nt = r % ntile; r /= ntile;
+    const int h = r % 2; r /= 2;
+    const int blk = r % (cout / bn); r /= (cout / bn);
+    const int chunk = r % (cin / 64); r /= (cin / 64);
+    const int tap = (int)r;
+    const int ci0 = chunk * 64 + h * 32 + 8 * q;
+    const int co = blk * bn + (nt / per_wave) * (bn / 2) + c * per_wave + (nt % per_wave);
+    const int st = transpose_flip ? taps - 1 - tap : tap;
+    const int src_c = transpose_flip ? cout : cin;
+    typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+    bf16x8p o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = ci0 + e;
+        const int so = transpose_flip ? ci : co, sc = transpose_flip ? co : ci;
+        o[e] = (__bf16)(w_nhwc ? w[((int64_t)so * taps + st) * src_c + sc] : w[((int64_t)so * src_c + sc) * taps + st]);
+    }
+    *reinterpret_cast<bf16x8p *>(out + i8 * 8) = o;
+}
+
 __global__ __launch_bounds__(256) void conv2d_pack_kernel(const float *__restrict__ w, int cin, int cout, int bn,
                                                           int transpose_flip, int w_nhwc, int taps, __bf16 *__restrict__ out) {
     conv2d_pack_element(w, cin, cout, bn, transpose_flip, w_nhwc, taps, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, out);
@@ -714,10 +744,10 @@ __global__ __launch_bounds__(256) void conv2d_pack_batch_kernel(const PackTable 
     const int64_t i = (int64_t)((int)blockIdx.x - tb.first_block[ti]) * 256 + threadIdx.x;
     const int cin = tb.cin[ti], cout = tb.cout[ti];
     if (tb.out_d[ti]) {   // pair: y = 0 forward [cin -> cout], y = 1 data gradient [cout -> cin], taps mirrored
-        if (blockIdx.y == 0) conv2d_pack_element(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, 0, tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
-        else conv2d_pack_element(tb.w[ti], cout, cin, cin % 128 == 0 ? 128 : 64, 1, tb.nhwc[ti], tb.taps[ti], i, tb.out_d[ti]);
+        if (blockIdx.y == 0) conv2d_pack_element8(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, 0, tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
+        else conv2d_pack_element8(tb.w[ti], cout, cin, cin % 128 == 0 ? 128 : 64, 1, tb.nhwc[ti], tb.taps[ti], i, tb.out_d[ti]);
     } else if (blockIdx.y == 0) {
-        conv2d_pack_element(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, tb.tf[ti], tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
+        conv2d_pack_element8(tb.w[ti], cin, cout, cout % 128 == 0 ? 128 : 64, tb.tf[ti], tb.nhwc[ti], tb.taps[ti], i, tb.out_f[ti]);
     }
 }
 
@@ -741,7 +771,7 @@ extern "C" int s2d_conv2d_pack_batch_bf16(int n, const float *const *weights, co
         tb.w[i] = weights[i]; tb.out_f[i] = (__bf16 *)packed_fwd[i]; tb.out_d[i] = (__bf16 *)packed_dgrad[i];
         tb.cin[i] = cin[i]; tb.cout[i] = cout[i]; tb.taps[i] = taps[i]; tb.nhwc[i] = weight_nhwc[i]; tb.tf[i] = transpose_flip[i];
         tb.first_block[i] = blocks;
-        blocks += (int)ceil_div((int64_t)taps[i] * cin[i] * cout[i], 256);
+        blocks += (int)ceil_div((int64_t)taps[i] * cin[i] * cout[i] / 8, 256);   // a thread packs eight consecutive elements
     }
     tb.first_block[n] = blocks;
     tb.count = n;

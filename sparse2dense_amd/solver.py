@@ -19,7 +19,8 @@ single-group state_dict and (b) the reference's: torch.optim.Adam over the TWO p
 `split_bn_bias(get_layer_groups(model))` (fastai_optim.py:17-28, apis/train.py:159-164) - every non-batch-norm leaf module's
 parameters first, then every batch-norm leaf's - which needs the model to rebuild the index map (`reference_param_order`).
 Every moment tensor is shape-checked against its parameter and re-laid to the parameter's strides before the raw-pointer
-kernel may see it; anything else is refused with a ValueError.
+kernel may see it; anything else is refused with a ValueError.  `state_dict` writes layout (b) when the model is attached (the
+reference's torch.optim.Adam resumes from it: tests/test_solver_checkpoint.py), layout (a) otherwise.
 """
 import ctypes
 import math
@@ -119,6 +120,25 @@ class OneCycleAdam:
         return st
 
     def state_dict(self):
+        """With the model attached: the reference's layout - torch.optim.Adam state over the two split_bn_bias groups in
+        `reference_param_order` (standard-layout moments, torch-Adam group keys), which `torch.optim.Adam(groups).load_state_dict` of a
+        reference run resumes from and `load_state_dict` below maps back; the extra top-level keys (`wd`, `step_count`) are ignored
+        by torch.  Without the model (or when the model's leaves do not cover this optimizer's parameters): one group in
+        `self.params` order, this class's own layout."""
+        if self.model is not None:
+            groups = reference_param_order(self.model)
+            order = [q for g in groups for q in g]
+            if len(order) == len(self.params) and {id(q) for q in order} == {id(q) for q in self.params}:
+                pos = {id(q): i for i, q in enumerate(order)}
+                state = {}
+                for p, st in self.state.items():
+                    state[pos[id(p)]] = {k: (v.detach().clone(memory_format=torch.contiguous_format) if torch.is_tensor(v) else v) for k, v in st.items()}
+                pg, k = [], 0
+                for g in groups:
+                    pg.append({"lr": self.lr, "betas": (self.mom, self.beta), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                               "params": list(range(k, k + len(g)))})
+                    k += len(g)
+                return {"state": state, "param_groups": pg, "wd": self.wd, "step_count": self.step_count}
         idx = {p: i for i, p in enumerate(self.params)}
         return {"state": {idx[p]: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.state.items()},
                 "param_groups": [{"lr": self.lr, "betas": (self.mom, self.beta), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
