@@ -282,6 +282,12 @@ int s2d_bncm_bwd_reduce_f32(const float *dy, const float *y, const float *x, int
 int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const float *x, const float *a,
                            const float *b, const float *d, int relu, int batch, int c,
                            int64_t positions, float *dx, s2d_stream_t stream);
+/* the two backward passes with the ReLU mask re-derived from x - y > 0 <=> fma(x, scale[c], shift[c]) > 0, the expression
+ * s2d_bncm_apply_f32 evaluated, hence the same mask bit for bit - instead of reading the output planes a third time */
+int s2d_bncm_bwd_reduce_x_f32(const float *dy, const float *x, const float *scale, const float *shift, int batch, int c, int64_t positions,
+                              float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bncm_bwd_apply_x_f32(const float *dy, const float *x, const float *scale, const float *shift, const float *a, const float *b,
+                             const float *d, int batch, int c, int64_t positions, float *dx, s2d_stream_t stream);
 
 /*
  * Dense 3x3 convolution, stride 1 (or 2: forward only), padding 0 or 1, on NHWC bf16 activations (the BEV neck blocks

@@ -261,12 +261,16 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
 // x[n][c][p], few channels (1..32) and up to 1.1e7 positions per plane.  MIOpen assigns one workgroup
 // per channel to such shapes (1.2 ms per call); here every (channel, position-chunk) gets a block.
 // grid (chunks, C); partial[chunk][2C] is reduced by partial_sum_kernel like the row-major case.
+// relu with y == nullptr (r04): the mask y > 0 is re-derived from x as fma(x, scale, shift) > 0 - the expression the forward apply
+// evaluated, so the same mask bit for bit - instead of reading the 362 MB output plane set a third time
 template <bool BWD>
 __global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                         const float *__restrict__ y, int relu, int n, int c, int64_t p4,
-                                                        int64_t chunk4, float *__restrict__ partial) {
+                                                        int64_t chunk4, float *__restrict__ partial, const float *__restrict__ scale = nullptr,
+                                                        const float *__restrict__ shift = nullptr) {
     __shared__ float lds[2][4];
     const int ch = blockIdx.y;
+    const float msc = (BWD && scale) ? scale[ch] : 0.f, msh = (BWD && shift) ? shift[ch] : 0.f;
     const int64_t q0 = (int64_t)blockIdx.x * chunk4;
     const int64_t q1 = q0 + chunk4 < p4 ? q0 + chunk4 : p4;
     float s0 = 0.f, s1 = 0.f;
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict_
             if (BWD) {
                 float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
                 if (relu) {
-                    const float4 yv = reinterpret_cast<const float4 *>(y)[base + q];
+                    const float4 yv = y ? reinterpret_cast<const float4 *>(y)[base + q]
+                                        : float4{fmaf(xv.x, msc, msh), fmaf(xv.y, msc, msh), fmaf(xv.z, msc, msh), fmaf(xv.w, msc, msh)};
                     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                     g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
                 }
@@ -308,10 +313,12 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                        const float *__restrict__ y, const float *__restrict__ v0,
                                                        const float *__restrict__ v1, const float *__restrict__ v2, int relu,
-                                                       int c, int64_t p4, float *__restrict__ out) {
+                                                       int c, int64_t p4, float *__restrict__ out, const float *__restrict__ scale = nullptr,
+                                                       const float *__restrict__ shift = nullptr) {
     // grid (position blocks, N*C)
     const int plane = blockIdx.y, ch = plane % c;
     const float a = v0[ch], b = v1[ch], d = BWD ? v2[ch] : 0.f;
+    const float msc = (BWD && scale) ? scale[ch] : 0.f, msh = (BWD && shift) ? shift[ch] : 0.f;   // y == nullptr: mask from x (see cm_reduce_kernel)
     const int64_t base = (int64_t)plane * p4;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < p4; q += (int64_t)gridDim.x * 256) {
         const float4 xv = reinterpret_cast<const float4 *>(x)[base + q];
@@ -319,7 +326,8 @@ __global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__
         if (BWD) {
             float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
             if (relu) {
-                const float4 yv = reinterpret_cast<const float4 *>(y)[base + q];
+                const float4 yv = y ? reinterpret_cast<const float4 *>(y)[base + q]
+                                    : float4{fmaf(xv.x, msc, msh), fmaf(xv.y, msc, msh), fmaf(xv.z, msc, msh), fmaf(xv.w, msc, msh)};
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
             }
@@ -840,7 +848,8 @@ extern "C" size_t s2d_bncm_workspace_bytes(int batch, int c, int64_t positions) 
 }
 
 static int bncm_reduce(bool bwd, const float *x, const float *dy, const float *y, int relu, int batch, int c,
-                       int64_t positions, float *sums, void *ws, size_t ws_bytes, hipStream_t st) {
+                       int64_t positions, float *sums, void *ws, size_t ws_bytes, hipStream_t st, const float *scale = nullptr,
+                       const float *shift = nullptr) {
     S2D_CHECK_ARG(batch > 0 && c > 0 && c <= 65535 && positions > 0 && x && sums, "bncm: bad argument");
     if (positions & 3) {
         set_error("bncm: positions per plane (%lld) must be a multiple of 4", (long long)positions);
@@ -853,10 +862,10 @@ static int bncm_reduce(bool bwd, const float *x, const float *dy, const float *y
     }
     if (bwd)
         hipLaunchKernelGGL(cm_reduce_kernel<true>, dim3(pl.chunks, c), dim3(256), 0, st, x, dy, y, relu, batch, c,
-                           positions / 4, pl.chunk4, (float *)ws);
+                           positions / 4, pl.chunk4, (float *)ws, scale, shift);
     else
-        hipLaunchKernelGGL(cm_reduce_kernel<false>, dim3(pl.chunks, c), dim3(256), 0, st, x, nullptr, nullptr, 0, batch, c,
-                           positions / 4, pl.chunk4, (float *)ws);
+        hipLaunchKernelGGL(cm_reduce_kernel<false>, dim3(pl.chunks, c), dim3(256), 0, st, x, (const float *)nullptr, (const float *)nullptr, 0, batch, c,
+                           positions / 4, pl.chunk4, (float *)ws, (const float *)nullptr, (const float *)nullptr);
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, pl.chunks, 2 * c, sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -873,6 +882,13 @@ extern "C" int s2d_bncm_bwd_reduce_f32(const float *dy, const float *y, const fl
     return bncm_reduce(true, x, dy, y, relu, batch, c, positions, sums, ws, ws_bytes, (hipStream_t)stream);
 }
 
+/* the same sums with the ReLU mask re-derived from x: y > 0 <=> fma(x, scale[c], shift[c]) > 0 (what s2d_bncm_apply_f32 evaluated) */
+extern "C" int s2d_bncm_bwd_reduce_x_f32(const float *dy, const float *x, const float *scale, const float *shift, int batch, int c,
+                                         int64_t positions, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(dy && scale && shift, "bncm_bwd_reduce_x: null argument");
+    return bncm_reduce(true, x, dy, nullptr, 1, batch, c, positions, sums, ws, ws_bytes, (hipStream_t)stream, scale, shift);
+}
+
 extern "C" int s2d_bncm_apply_f32(const float *x, const float *scale, const float *shift, int relu, int batch, int c,
                                   int64_t positions, float *y, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && scale && shift && y && batch > 0 && c > 0 && positions > 0 && !(positions & 3) &&
@@ -880,8 +896,8 @@ extern "C" int s2d_bncm_apply_f32(const float *x, const float *scale, const floa
     const int64_t p4 = positions / 4;
     int64_t bx = ceil_div(p4, 256);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(cm_apply_kernel<false>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, nullptr,
-                       nullptr, scale, shift, nullptr, relu, c, p4, y);
+    hipLaunchKernelGGL(cm_apply_kernel<false>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, (const float *)nullptr,
+                       (const float *)nullptr, scale, shift, (const float *)nullptr, relu, c, p4, y, (const float *)nullptr, (const float *)nullptr);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -895,7 +911,21 @@ extern "C" int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const flo
     int64_t bx = ceil_div(p4, 256);
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(cm_apply_kernel<true>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, dy, y, a, b,
-                       d, relu, c, p4, dx);
+                       d, relu, c, p4, dx, (const float *)nullptr, (const float *)nullptr);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* dx = a g + b x + d with g = dy where fma(x, scale, shift) > 0 (the ReLU mask re-derived from x, see s2d_bncm_bwd_reduce_x_f32) */
+extern "C" int s2d_bncm_bwd_apply_x_f32(const float *dy, const float *x, const float *scale, const float *shift, const float *a, const float *b,
+                                        const float *d, int batch, int c, int64_t positions, float *dx, s2d_stream_t stream) {
+    S2D_CHECK_ARG(dy && x && scale && shift && a && b && d && dx && batch > 0 && c > 0 && positions > 0 && !(positions & 3) &&
+                      (int64_t)batch * c <= 65535, "bncm_bwd_apply_x: bad argument");
+    const int64_t p4 = positions / 4;
+    int64_t bx = ceil_div(p4, 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(cm_apply_kernel<true>, dim3((unsigned)bx, batch * c), dim3(256), 0, (hipStream_t)stream, x, dy, (const float *)nullptr, a, b, d, 1, c,
+                       p4, dx, scale, shift);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

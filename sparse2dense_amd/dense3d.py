@@ -302,7 +302,8 @@ class _BNChannelMajorFn(torch.autograd.Function):
         y = torch.empty_like(x)
         check(lib.s2d_bncm_apply_f32(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), int(relu), n, c, pos,
                                      _ptr(y), _stream()), "s2d_bncm_apply_f32")
-        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, count, scale)
+        # the backward re-derives the ReLU mask from x (fma(x, scale, shift) > 0: the expression the apply kernel evaluated) - y is not kept
+        ctx.save_for_backward(x, gamma, mean, invstd, count, scale.contiguous(), shift.contiguous())
         ctx.relu, ctx.sync, ctx.training = relu, sync, training
         return y
 
@@ -311,11 +312,14 @@ class _BNChannelMajorFn(torch.autograd.Function):
         import torch.distributed as dist
         from . import hip_ops as H
         lib = _lib.load()
-        x, y, gamma, mean, invstd, count, scale = ctx.saved_tensors
+        x, gamma, mean, invstd, count, scale, shift = ctx.saved_tensors
         dy = dy.contiguous()
         n, c = x.shape[0], x.shape[1]
         pos = x[0, 0].numel()
-        sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), _ptr(y), _ptr(x), int(ctx.relu)), n, c, pos, x.device)
+        if ctx.relu:
+            sums = _bncm_reduce("s2d_bncm_bwd_reduce_x_f32", (_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift)), n, c, pos, x.device)
+        else:
+            sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), None, _ptr(x), 0), n, c, pos, x.device)
         if ctx.training:
             sums_all = sums
             if ctx.sync:
@@ -330,8 +334,12 @@ class _BNChannelMajorFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(a), _ptr(b), _ptr(d), int(ctx.relu), n, c, pos,
-                                             _ptr(dx), _stream()), "s2d_bncm_bwd_apply_f32")
+            if ctx.relu:
+                check(lib.s2d_bncm_bwd_apply_x_f32(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(a), _ptr(b), _ptr(d), n, c, pos, _ptr(dx), _stream()),
+                      "s2d_bncm_bwd_apply_x_f32")
+            else:
+                check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), None, _ptr(x), _ptr(a), _ptr(b), _ptr(d), 0, n, c, pos, _ptr(dx), _stream()),
+                      "s2d_bncm_bwd_apply_f32")
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
