@@ -547,6 +547,14 @@ int s2d_convt3d_mfma_dgrad_d16(const void *dout_bf16, const void *packed, int ba
                                s2d_stream_t stream);
 int s2d_convt3d_mfma_wgrad_d16(const float *in, const void *dout_bf16, int batch, int cin, int cout, int d, int h, int w, float *dweight,
                                void *ws, size_t ws_bytes, s2d_stream_t stream);
+/* The BatchNorm3d + ReLU in FRONT of the layer folded into its kernels (r04): `in` is the raw tensor, in_scale_shift = scale[cin] |
+ * shift[cin] (device), applied as relu(fma(x, scale, shift)) - the expression of s2d_bncm_apply_f32 - while the forward stages its input
+ * and while the weight gradient loads it; the normalised tensor is never written or read. */
+int s2d_convt3d_mfma_norm_supported(int cin, int cout, int d, int h, int w);   /* the layers it pays on: narrow outputs (cout <= 4, w % 8 == 0) */
+int s2d_convt3d_mfma_fwd_stats_y16_norm(const float *in, const float *in_scale_shift, const void *packed, const float *bias, int batch,
+                                        int cin, int cout, int d, int h, int w, void *out_bf16, float *stats_partial, s2d_stream_t stream);
+int s2d_convt3d_mfma_wgrad_d16_norm(const float *in, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout, int d,
+                                    int h, int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
 /* weight (+ bias) gradient of the 1x1x1 Conv3d layers of the PCR head: dweight[cout][cin] = sum_{n,p} dout[n][co][p] in[n][ci][p],
  * dbias[cout] = sum dout (NCDHW fp32 tensors, positions % 4 == 0); deterministic two-stage reduction */

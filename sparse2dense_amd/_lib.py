@@ -115,6 +115,11 @@ SIGNATURES = {
     "s2d_convt3d_mfma_dgrad_d16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_wgrad_d16": (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p, ctypes.c_size_t,
                                                                                                    ctypes.c_void_p]),
+    "s2d_convt3d_mfma_norm_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "s2d_convt3d_mfma_fwd_stats_y16_norm": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, c_f32p,
+                                                                                                                  ctypes.c_void_p]),
+    "s2d_convt3d_mfma_wgrad_d16_norm": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                                                                                              ctypes.c_void_p]),
     "s2d_convt3d_mfma_dgrad": (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_convt3d_mfma_wgrad": (ctypes.c_int, [c_f32p, c_f32p] + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_void_p, ctypes.c_size_t,

@@ -157,7 +157,10 @@ template <> struct CtStore<__bf16> {
 template <int CIN, int NT, int YR, typename TO = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_mfma_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           CtDims s, int xtiles, CtTileMap map, TO *__restrict__ out,
-                                                          float *__restrict__ stats_partial) {
+                                                          float *__restrict__ stats_partial, const float *__restrict__ in_norm = nullptr) {
+    // in_norm (r04, scale[CIN] | shift[CIN] or null): the input is the RAW tensor in front of a BatchNorm3d + ReLU, applied here while
+    // staging - relu(fma(x, scale[ci], shift[ci])), the expression of s2d_bncm_apply_f32 - so the normalised tensor is never written
+    // or read (cells outside the tensor stay zero: the padding is of the normalised tensor)
     constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
     constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
     constexpr int KSTEPS = CIN == 32 ? 8 : 4;
@@ -206,8 +209,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float val = src[ok ? (int64_t)e * cells : 0];
+                float val = src[ok ? (int64_t)e * cells : 0];
+                if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
                 hv[e] = ok ? val : 0.f;
+            }
+        }
+        // (p >> 4) advances by 16 per iteration, a multiple of GROUPS: a thread's channel group - and its eight scale / shift pairs - is fixed
+        static_assert(16 % GROUPS == 0, "a thread keeps its channel group");
+        float nsc[8], nsh[8];
+        if (in_norm) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                nsc[e] = in_norm[((t >> 4) % GROUPS) * 8 + e];
+                nsh[e] = in_norm[CIN + ((t >> 4) % GROUPS) * 8 + e];
             }
         }
         for (int p = t; p < BODY; p += 256) {
@@ -218,6 +232,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             float4 f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const float4 *>(src + (ok ? (int64_t)e * cells : 0));
+            if (in_norm) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sc = nsc[e], sh = nsh[e];
+                    f[e] = float4{fmaxf(fmaf(f[e].x, sc, sh), 0.f), fmaxf(fmaf(f[e].y, sc, sh), 0.f), fmaxf(fmaf(f[e].z, sc, sh), 0.f),
+                                  fmaxf(fmaf(f[e].w, sc, sh), 0.f)};
+                }
+            }
             bf16x8m v[4];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -241,7 +263,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             if ((unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w) {
                 const float *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[(int64_t)e * cells];
+                for (int e = 0; e < 8; ++e) {
+                    float val = src[(int64_t)e * cells];
+                    if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
+                    v[e] = (__bf16)val;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
@@ -744,7 +770,8 @@ __global__ __launch_bounds__(256) void ct_wgrad_mfma_kernel(const float *__restr
 // acc[a][b][kx][ci tile].
 template <int CIT, typename TD = float>
 __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
-                                                            int co_tiles, int groups, int n_chunks, float *__restrict__ partial) {
+                                                            int co_tiles, int groups, int n_chunks, float *__restrict__ partial,
+                                                            const float *__restrict__ in_norm = nullptr) {
     constexpr int FR = 16 * CIT;
     constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the 20-element window is ten dwords, the fragments are byte permutes of them
     constexpr unsigned ES = sizeof(TD);
@@ -865,6 +892,16 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
 #pragma unroll
                     for (int i = 0; i < CIT; ++i) {
                         bf16x8m av;
+                        if (in_norm) {   // x is the raw tensor in front of a BatchNorm3d + ReLU (see ct_fwd_mfma_kernel); loads outside the tensor stay zero
+                            const int ci = ci_base + i * 16 + r;
+                            const bool cv = xok[a][b] && ci < s.cin;
+                            const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xl[a][b][i][e] = (cv && lo_ok) ? fmaxf(fmaf(xl[a][b][i][e], sc, sh), 0.f) : 0.f;
+                                xh[a][b][i][e] = (cv && hi_ok) ? fmaxf(fmaf(xh[a][b][i][e], sc, sh), 0.f) : 0.f;
+                            }
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { av[e] = (__bf16)xl[a][b][i][e]; av[4 + e] = (__bf16)xh[a][b][i][e]; }
 #pragma unroll
@@ -909,7 +946,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
 // waves per SIMD (3.5 ms at [4,16,10,376,376]).
 template <int CIT, typename TD = float>
 __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
-                                                              int n_chunks, float *__restrict__ partial) {
+                                                              int n_chunks, float *__restrict__ partial, const float *__restrict__ in_norm = nullptr) {
     constexpr int FR = 16 * CIT;
     constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the 16-element window is eight dwords (two 16-byte loads instead of four)
     constexpr unsigned ES = sizeof(TD);
@@ -951,7 +988,16 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
             for (int ai = 0; ai < CIT; ++ai) {
                 const int ci = ai * 16 + r;
                 const unsigned voff = (cok && ci < s.cin) ? (unsigned)(ci * cells * 4) + xrow + (unsigned)c0 * 4u : CT_OOB;
-                const f32x4m lo = ct_load4(xr, voff, 0), hi = ct_load4(xr, voff, 16);
+                f32x4m lo = ct_load4(xr, voff, 0), hi = ct_load4(xr, voff, 16);
+                if (in_norm) {   // x is the raw tensor in front of a BatchNorm3d + ReLU (see ct_fwd_mfma_kernel); loads outside the tensor stay zero
+                    const bool cv = cok && ci < s.cin;
+                    const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = cv ? fmaxf(fmaf(lo[e], sc, sh), 0.f) : 0.f;
+                        hi[e] = cv ? fmaxf(fmaf(hi[e], sc, sh), 0.f) : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { a[ai][e] = (__bf16)lo[e]; a[ai][4 + e] = (__bf16)hi[e]; }
             }
@@ -1106,7 +1152,7 @@ extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h
  * output - the statistics pass of the BatchNorm3d that follows (s2d_bn_partials_sum_f32 folds them) */
 template <typename TO>
 static int ct_fwd_launch(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h, int w, TO *out,
-                         float *stats_partial, s2d_stream_t stream) {
+                         float *stats_partial, s2d_stream_t stream, const float *in_norm = nullptr) {
     S2D_CHECK_ARG(in && packed && out && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_fwd: bad argument");
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
     CtDims s{batch, d, h, w, cin, cout};
@@ -1120,10 +1166,10 @@ static int ct_fwd_launch(const float *in, const void *packed, const float *bias,
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *wp = (const __bf16 *)packed;
     const int nt = (cout + 15) / 16;
-    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
-    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial);
+    if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
+    else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
+    else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
+    else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -1136,6 +1182,15 @@ extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, c
 extern "C" int s2d_convt3d_mfma_fwd_stats_y16(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
                                               int w, void *out_bf16, float *stats_partial, s2d_stream_t stream) {
     return ct_fwd_launch<__bf16>(in, packed, bias, batch, cin, cout, d, h, w, (__bf16 *)out_bf16, stats_partial, stream);
+}
+
+/* r04: ... with the BatchNorm3d + ReLU in FRONT of the layer applied while the input is staged: `in` is the raw tensor, in_scale_shift =
+ * scale[cin] | shift[cin] (device); the normalised tensor is never materialised (see also s2d_convt3d_mfma_wgrad_d16_norm) */
+extern "C" int s2d_convt3d_mfma_fwd_stats_y16_norm(const float *in, const float *in_scale_shift, const void *packed, const float *bias, int batch,
+                                                   int cin, int cout, int d, int h, int w, void *out_bf16, float *stats_partial,
+                                                   s2d_stream_t stream) {
+    S2D_CHECK_ARG(in_scale_shift, "convt3d_mfma_fwd_stats_y16_norm: null scale / shift");
+    return ct_fwd_launch<__bf16>(in, packed, bias, batch, cin, cout, d, h, w, (__bf16 *)out_bf16, stats_partial, stream, in_scale_shift);
 }
 
 extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
@@ -1202,7 +1257,8 @@ extern "C" size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int
 static bool ct_wgrad_has_d16(int cout, int w) { return ct_wgrad_is_narrow(cout, w) || w % 4 == 0; }
 
 template <typename TD>
-static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, int cout, int d, int h, int w, float *dweight, void *ws, hipStream_t st) {
+static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, int cout, int d, int h, int w, float *dweight, void *ws, hipStream_t st,
+                           const float *in_norm = nullptr) {
     CtDims s{batch, d, h, w, cin, cout};
     const int64_t rows = (int64_t)batch * d * h;
     const int bx = ct_wgrad_blocks_for(rows, cout, w);
@@ -1210,12 +1266,13 @@ static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, 
     float *partial = (float *)ws;
     const int cit = cin / 16, cot = (cout + 15) / 16;
     const bool narrow = ct_wgrad_is_narrow(cout, w);
-    if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
-    else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial);
+    if (in_norm && !ct_wgrad_has_d16(cout, w)) return S2D_ERR_UNSUPPORTED;   // the input-norm fold lives in the narrow / row-major kernels
+    if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial, in_norm);
+    else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial, in_norm);
     // both input-channel tiles in one block: dout is read once (measured 0.62 ms against 0.85 ms with one tile per block and two
     // resident waves per SIMD, 32 -> 32 at [4,32,5,188,188])
-    else if (w % 4 == 0 && cit == 2) hipLaunchKernelGGL((ct_wgrad_rows_kernel<2, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot, bx, partial);
-    else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot * cit)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot * cit, bx, partial);
+    else if (w % 4 == 0 && cit == 2) hipLaunchKernelGGL((ct_wgrad_rows_kernel<2, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot, bx, partial, in_norm);
+    else if (w % 4 == 0) hipLaunchKernelGGL((ct_wgrad_rows_kernel<1, TD>), dim3(xcd_grid((int64_t)bx * 4 * cot * cit)), dim3(256), 0, st, in, dout, s, rpb, cot, 4 * cot * cit, bx, partial, in_norm);
     else if constexpr (sizeof(TD) == 4) {
         if (cit == 2 && cot == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 2, 2>), dim3(bx, 8), dim3(256), 0, st, in, dout, s, rpb, partial);
         else if (cit == 2) hipLaunchKernelGGL((ct_wgrad_mfma_kernel<2, 1, 4>), dim3(bx, 4), dim3(256), 0, st, in, dout, s, rpb, partial);
@@ -1247,6 +1304,12 @@ extern "C" int s2d_convt3d_mfma_wgrad(const float *in, const float *dout, int ba
 extern "C" int s2d_convt3d_mfma_d16_supported(int cin, int cout, int d, int h, int w) {
     return ct_mfma_ok(cin, cout) && d > 0 && h > 0 && w > 0 && ct_dgrad_is_direct(cout, d, h, w) && ct_wgrad_has_d16(cout, w);
 }
+/* the input-norm fold (s2d_convt3d_mfma_fwd_stats_y16_norm / _wgrad_d16_norm) pays on the narrow layers only: measured on 32 -> 32 at
+ * [4,32,5,188,188] the output-row-major weight gradient went 0.48 -> 0.77 ms with the normalisation in its load path (it saves a 27 us
+ * apply there); 16 -> 3 at [4,16,10,376,376]: forward 0.53 -> 0.56, weight gradient 0.45 -> 0.47 ms against a 0.12 ms apply pass */
+extern "C" int s2d_convt3d_mfma_norm_supported(int cin, int cout, int d, int h, int w) {
+    return s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w) && ct_wgrad_is_narrow(cout, w);
+}
 extern "C" int s2d_convt3d_mfma_dgrad_d16(const void *dout_bf16, const void *packed, int batch, int cin, int cout, int d, int h, int w, float *din,
                                           s2d_stream_t stream) {
     S2D_CHECK_ARG(dout_bf16 && packed && din && batch > 0, "convt3d_mfma_dgrad_d16: bad argument");
@@ -1263,6 +1326,18 @@ extern "C" int s2d_convt3d_mfma_wgrad_d16(const float *in, const void *dout_bf16
         return S2D_ERR_WORKSPACE;
     }
     return ct_wgrad_launch<__bf16>(in, (const __bf16 *)dout_bf16, batch, cin, cout, d, h, w, dweight, ws, (hipStream_t)stream);
+}
+/* ... with the BatchNorm3d + ReLU in front of the layer applied to `in` on load (see s2d_convt3d_mfma_fwd_stats_y16_norm) */
+extern "C" int s2d_convt3d_mfma_wgrad_d16_norm(const float *in, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout, int d,
+                                               int h, int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in && in_scale_shift && dout_bf16 && dweight && batch > 0, "convt3d_mfma_wgrad_d16_norm: bad argument");
+    if (!s2d_convt3d_mfma_norm_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
+    const size_t need = s2d_convt3d_mfma_wgrad_workspace_bytes(batch, cin, cout, d, h, w);
+    if (!ws || ws_bytes < need) {
+        set_error("convt3d_mfma_wgrad_d16_norm: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    return ct_wgrad_launch<__bf16>(in, (const __bf16 *)dout_bf16, batch, cin, cout, d, h, w, dweight, ws, (hipStream_t)stream, in_scale_shift);
 }
 
 // ---- 1x1x1 Conv3d weight gradient (planar fp32 tensors) ------------------------------------------------------------

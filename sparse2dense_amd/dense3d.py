@@ -123,13 +123,17 @@ def _convt_packed(weight):
 
 class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bf16=False, bn_stats=False, out_bf16=False):
+    def forward(ctx, x, weight, bias, bf16=False, bn_stats=False, out_bf16=False, in_norm=None):
+        """in_norm (direct calls from heads._UpsampleLevelFn only): scale | shift of the BatchNorm3d + ReLU in front of the layer - x is then
+        the RAW tensor and the kernels normalise it on load (forward and weight gradient; bf16-stored output and gradient only)"""
         lib = _lib.load()
         x = x.contiguous()
         weight = weight.contiguous()
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
         ctx.mfma = bool(bf16 and lib.s2d_convt3d_mfma_supported(cin, cout))
+        ctx.in_norm = in_norm
+        assert in_norm is None or (ctx.mfma and bn_stats and out_bf16 and lib.s2d_convt3d_mfma_norm_supported(cin, cout, d, h, w))
         # r04: the raw output may be STORED in bf16 (half the bytes for the four passes of the fused PCR level that read it); only with
         # the matrix-core kernel and the statistics epilogue, i.e. on the fused training path
         out_bf16 = bool(out_bf16 and ctx.mfma and bn_stats)
@@ -140,9 +144,13 @@ class _ConvT3dFn(torch.autograd.Function):
             if bn_stats:   # the epilogue also produces the statistics of the batch norm that follows
                 tiles = lib.s2d_convt3d_mfma_stats_tiles(n, cin, d, h, w)
                 partial = torch.empty((tiles, 2, cout), dtype=torch.float32, device=x.device)
-            entry = lib.s2d_convt3d_mfma_fwd_stats_y16 if out_bf16 else lib.s2d_convt3d_mfma_fwd_stats
-            check(entry(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial), _stream()),
-                  "s2d_convt3d_mfma_fwd_stats")
+            if in_norm is not None:
+                check(lib.s2d_convt3d_mfma_fwd_stats_y16_norm(_ptr(x), _ptr(in_norm), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w,
+                                                              _ptr(out), _ptr(partial), _stream()), "s2d_convt3d_mfma_fwd_stats_y16_norm")
+            else:
+                entry = lib.s2d_convt3d_mfma_fwd_stats_y16 if out_bf16 else lib.s2d_convt3d_mfma_fwd_stats
+                check(entry(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial), _stream()),
+                      "s2d_convt3d_mfma_fwd_stats")
             if bn_stats:
                 stats = torch.empty((2 * cout,), dtype=torch.float32, device=x.device)
                 ws = _ws(lib.s2d_bn_partials_sum_workspace_bytes(partial.shape[0], cout), x.device)   # one row per tile: two-stage fold
@@ -171,6 +179,8 @@ class _ConvT3dFn(torch.autograd.Function):
         # r04: the fused PCR level hands its gradient over in bf16 when the matrix-core kernels cover the layer (they round dout to bf16 on load
         # anyway); any other bf16 gradient is widened
         d16 = bool(dout.dtype == torch.bfloat16 and ctx.mfma and lib.s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w))
+        in_norm = getattr(ctx, "in_norm", None)
+        assert in_norm is None or d16, "the input-norm fold runs with the bf16-stored gradient only"
         dout = dout.contiguous() if d16 else dout.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -186,7 +196,11 @@ class _ConvT3dFn(torch.autograd.Function):
                       "s2d_convt3d_k4s2p1_dgrad_f32")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            if d16:
+            if d16 and in_norm is not None:
+                ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
+                check(lib.s2d_convt3d_mfma_wgrad_d16_norm(_ptr(x), _ptr(in_norm), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
+                                                          _stream()), "s2d_convt3d_mfma_wgrad_d16_norm")
+            elif d16:
                 ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
                 check(lib.s2d_convt3d_mfma_wgrad_d16(_ptr(x), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(), _stream()),
                       "s2d_convt3d_mfma_wgrad_d16")
@@ -270,35 +284,75 @@ def _bncm_reduce(fn_name, args_front, n, c, pos, device):
     return out
 
 
+def bncm_finalize_fwd(x, gamma, beta, eps, sync, module, training, stats=None):
+    """statistics (reduced here unless the producer handed them over) -> SyncBN exchange -> finalisation (running statistics updated):
+    (mean, invstd, scale, shift, count) of a channel-major batch norm over x[n][c][...]"""
+    from . import hip_ops as H
+    n, c = x.shape[0], x.shape[1]
+    pos = x[0, 0].numel()
+    dev = x.device
+    if training:
+        if stats is None:   # (else: the producing kernel's epilogue already reduced them)
+            stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(x),), n, c, pos, dev)
+        count = torch.full((1,), float(n * pos), device=dev)
+        if sync:
+            packed = torch.cat([stats, count])
+            _collective.allreduce_sum_(packed)
+            stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
+        track = module.track_running_stats
+        fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
+                                  module.running_mean if track else None, module.running_var if track else None,
+                                  module.num_batches_tracked if track else None)
+        return fin[0], fin[1], fin[2], fin[3], count
+    invstd = torch.rsqrt(module.running_var + eps)
+    mean = module.running_mean
+    scale = gamma * invstd
+    return mean, invstd, scale, beta - mean * scale, torch.full((1,), float(n * pos), device=dev)
+
+
+def bncm_backward(dy, x, gamma, mean, invstd, count, scale, shift, relu, sync, training, need_dx=True):
+    """backward of y = [relu](x * scale + shift) with batch (training) or running statistics: (dx, dgamma, dbeta); the ReLU mask is
+    re-derived from x (fma(x, scale, shift) > 0: the forward's expression)"""
+    from . import hip_ops as H
+    lib = _lib.load()
+    dy = dy.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    pos = x[0, 0].numel()
+    if relu:
+        sums = _bncm_reduce("s2d_bncm_bwd_reduce_x_f32", (_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift)), n, c, pos, x.device)
+    else:
+        sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), None, _ptr(x), 0), n, c, pos, x.device)
+    if training:
+        sums_all = sums
+        if sync:
+            sums_all = sums.clone()
+            _collective.allreduce_sum_(sums_all)
+        fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
+        dgamma, dbeta, a, b, d = fin[0], fin[1], fin[2], fin[3], fin[4]
+    else:
+        dbeta = sums[:c]
+        dgamma = invstd * (sums[c:] - mean * sums[:c])
+        a, b, d = scale.contiguous(), torch.zeros_like(scale), torch.zeros_like(scale)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        if relu:
+            check(lib.s2d_bncm_bwd_apply_x_f32(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(a), _ptr(b), _ptr(d), n, c, pos, _ptr(dx), _stream()),
+                  "s2d_bncm_bwd_apply_x_f32")
+        else:
+            check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), None, _ptr(x), _ptr(a), _ptr(b), _ptr(d), 0, n, c, pos, _ptr(dx), _stream()),
+                  "s2d_bncm_bwd_apply_f32")
+    return dx, dgamma, dbeta
+
+
 class _BNChannelMajorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, relu, eps, sync, module, training, stats=None):
-        import torch.distributed as dist
-        from . import hip_ops as H
         lib = _lib.load()
         x = x.contiguous()
         n, c = x.shape[0], x.shape[1]
         pos = x[0, 0].numel()
-        dev = x.device
-        if training:
-            if stats is None:   # (else: the producing kernel's epilogue already reduced them)
-                stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(x),), n, c, pos, dev)
-            count = torch.full((1,), float(n * pos), device=dev)
-            if sync:
-                packed = torch.cat([stats, count])
-                _collective.allreduce_sum_(packed)
-                stats, count = packed[:-1].contiguous(), packed[-1:].contiguous()
-            track = module.track_running_stats
-            fin = H.bn1d_finalize_fwd(stats, count, gamma, beta, eps, module.momentum if track else 0.0,
-                                      module.running_mean if track else None, module.running_var if track else None,
-                                      module.num_batches_tracked if track else None)
-            mean, invstd, scale, shift = fin[0], fin[1], fin[2], fin[3]
-        else:
-            invstd = torch.rsqrt(module.running_var + eps)
-            mean = module.running_mean
-            scale = gamma * invstd
-            shift = beta - mean * scale
-            count = torch.full((1,), float(n * pos), device=dev)
+        mean, invstd, scale, shift, count = bncm_finalize_fwd(x, gamma, beta, eps, sync, module, training, stats)
         y = torch.empty_like(x)
         check(lib.s2d_bncm_apply_f32(_ptr(x), _ptr(scale.contiguous()), _ptr(shift.contiguous()), int(relu), n, c, pos,
                                      _ptr(y), _stream()), "s2d_bncm_apply_f32")
@@ -309,37 +363,8 @@ class _BNChannelMajorFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        import torch.distributed as dist
-        from . import hip_ops as H
-        lib = _lib.load()
         x, gamma, mean, invstd, count, scale, shift = ctx.saved_tensors
-        dy = dy.contiguous()
-        n, c = x.shape[0], x.shape[1]
-        pos = x[0, 0].numel()
-        if ctx.relu:
-            sums = _bncm_reduce("s2d_bncm_bwd_reduce_x_f32", (_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift)), n, c, pos, x.device)
-        else:
-            sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), None, _ptr(x), 0), n, c, pos, x.device)
-        if ctx.training:
-            sums_all = sums
-            if ctx.sync:
-                sums_all = sums.clone()
-                _collective.allreduce_sum_(sums_all)
-            fin = H.bn1d_finalize_bwd(sums, sums_all, count, gamma, mean, invstd)
-            dgamma, dbeta, a, b, d = fin[0], fin[1], fin[2], fin[3], fin[4]
-        else:
-            dbeta = sums[:c]
-            dgamma = invstd * (sums[c:] - mean * sums[:c])
-            a, b, d = scale.contiguous(), torch.zeros_like(scale), torch.zeros_like(scale)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            if ctx.relu:
-                check(lib.s2d_bncm_bwd_apply_x_f32(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(a), _ptr(b), _ptr(d), n, c, pos, _ptr(dx), _stream()),
-                      "s2d_bncm_bwd_apply_x_f32")
-            else:
-                check(lib.s2d_bncm_bwd_apply_f32(_ptr(dy), None, _ptr(x), _ptr(a), _ptr(b), _ptr(d), 0, n, c, pos, _ptr(dx), _stream()),
-                      "s2d_bncm_bwd_apply_f32")
+        dx, dgamma, dbeta = bncm_backward(dy, x, gamma, mean, invstd, count, scale, shift, ctx.relu, ctx.sync, ctx.training, ctx.needs_input_grad[0])
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 

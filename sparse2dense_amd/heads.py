@@ -452,42 +452,78 @@ class _UpsampleLevelFn(torch.autograd.Function):
     forward = dense3d._ConvT3dFn.forward -> _PcrLevelNormFn.forward, backward the reverse; same kernels, same results."""
 
     @staticmethod
-    def forward(ctx, x, ct_w, ct_b, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, z_stats_out, y16):
-        from .dense3d import _ConvT3dFn
+    def forward(ctx, x, ct_w, ct_b, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, z_stats_out, y16,
+                pre_gamma=None, pre_beta=None, pre_bn=None, pre_stats=None):
+        from . import _lib, collective as _collective
+        from .dense3d import _ConvT3dFn, bncm_finalize_fwd
         c1 = _SubCtx((ctx.needs_input_grad[0], ctx.needs_input_grad[1], ct_b is not None and ctx.needs_input_grad[2], False, False, False))
-        y, stats = _ConvT3dFn.forward(c1, x, ct_w, ct_b, True, True, y16)
+        # pre_bn: the BatchNorm3d + ReLU in FRONT of the up-sampler is part of the node too - x is its raw input, the up-sampler's kernels
+        # normalise it on load (forward and weight gradient) and the normalised tensor is never written or read
+        in_norm = None
+        if pre_bn is not None:
+            x = x.contiguous()
+            sync = _collective.sync_on()
+            mean, invstd, scale, shift, count = bncm_finalize_fwd(x, pre_gamma, pre_beta, pre_bn.eps, sync, pre_bn, True, pre_stats)
+            in_norm = torch.cat([scale.reshape(-1), shift.reshape(-1)]).contiguous()
+            ctx.pre = (pre_gamma, mean, invstd, count, scale.contiguous(), shift.contiguous(), sync)
+        y, stats = _ConvT3dFn.forward(c1, x, ct_w, ct_b, True, True, y16, in_norm)
         c2 = _SubCtx((True,) * 3 + (False,) * 12)
         ml, ol, z = _PcrLevelNormFn.forward(c2, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, stats, z_stats_out)
         # the gradient of y goes from the level's backward straight into the up-sampler's: stored in bf16 as well when the up-sampler's
         # matrix-core kernels read that (they round it to bf16 on load in any case; S2D_PCR_DY16=0 keeps it fp32)
-        from . import _lib
         c2.dy16 = bool(y16 and os.environ.get("S2D_PCR_DY16", "1") != "0"
                        and _lib.load().s2d_convt3d_mfma_d16_supported(x.shape[1], ct_w.shape[1], *x.shape[2:]))
+        assert in_norm is None or c2.dy16
         ctx.c1, ctx.c2 = c1, c2
         ctx.has_z = z is not None
         return (ml, ol, z) if z is not None else (ml, ol)
 
     @staticmethod
     def backward(ctx, go_mask, go_off, dz=None):
-        from .dense3d import _ConvT3dFn
+        from .dense3d import _ConvT3dFn, bncm_backward
         g2 = _PcrLevelNormFn.backward(ctx.c2, go_mask, go_off, dz)
         dy, dgamma, dbeta, dwm, dbm, dwo, dbo, _, _, dw2, db2 = g2[:11]
         dx, dw, db = _ConvT3dFn.backward(ctx.c1, dy, dout_sum=ctx.c2.dy_sum)[:3]
-        return dx, dw, db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, dw2, db2, None, None, None, None
+        dpg = dpb = None
+        if getattr(ctx, "pre", None) is not None:
+            pre_gamma, mean, invstd, count, scale, shift, sync = ctx.pre
+            x = ctx.c1.saved_tensors[0]
+            dx, dpg, dpb = bncm_backward(dx, x, pre_gamma, mean, invstd, count, scale, shift, True, sync, True, ctx.needs_input_grad[0])
+        return dx, dw, db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, dw2, db2, None, None, None, None, dpg, dpb, None, None
 
 
-def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True):
-    """`pcr_level_norm(ct(x), bn, ...)` as one node (see _UpsampleLevelFn); ct = dense3d.ConvTranspose3dK4S2 in its bf16-compute mode"""
+def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True, pre_bn=None):
+    """`pcr_level_norm(ct(x), bn, ...)` as one node (see _UpsampleLevelFn); ct = dense3d.ConvTranspose3dK4S2 in its bf16-compute mode.
+    pre_bn (a training-mode FastBatchNorm3d with fused ReLU, y16 only): `pcr_level_norm(ct(pre_bn(x)), bn, ...)` - the batch norm in front
+    of the up-sampler joins the node and its output is never materialised."""
     assert bn.training and bn.affine and getattr(bn, "fused_relu", False) and bn.momentum is not None
     coors = coors if coors.dtype == torch.int32 else coors.int()
     holder = []
+    pre = (None, None, None, None)
+    if pre_bn is not None:
+        assert y16 and pre_bn.training and pre_bn.affine and getattr(pre_bn, "fused_relu", False) and pre_bn.momentum is not None
+        stats = getattr(x, "_s2d_bn_stats", None)
+        pre = (pre_bn.weight, pre_bn.bias, pre_bn, stats if stats is not None and stats.numel() == 2 * pre_bn.num_features else None)
     out = _UpsampleLevelFn.apply(x, ct.weight, ct.bias, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias,
                                  coors, feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
-                                 bn, bool(getattr(next_conv, "bf16_compute", False)), holder, bool(y16))
+                                 bn, bool(getattr(next_conv, "bf16_compute", False)), holder, bool(y16), *pre)
     z = out[2] if len(out) > 2 else None
     if holder and z is not None:
         z._s2d_bn_stats = holder[0]
     return out[0], out[1], z
+
+
+def upsample_level_pre_bn_supported(ct, in_dhw, pre_bn):
+    """the batch norm in front of the up-sampler can join the node: a training-mode FastBatchNorm3d + ReLU of the layer's input channels
+    on a layer shape where the fold pays (narrow outputs: the 16 -> 3 up-sampler; S2D_PCR_PRE_BN=0 keeps it a node of its own)"""
+    from . import _lib
+    from .dense3d import FastBatchNorm3d
+    if os.environ.get("S2D_PCR_PRE_BN", "1") == "0" or os.environ.get("S2D_PCR_DY16", "1") == "0":
+        return False
+    if not (isinstance(pre_bn, FastBatchNorm3d) and pre_bn.training and pre_bn.affine and pre_bn.fused_relu and pre_bn.momentum is not None
+            and pre_bn.num_features == ct.weight.shape[0] and (int(in_dhw[0]) * int(in_dhw[1]) * int(in_dhw[2])) % 4 == 0):
+        return False
+    return bool(_lib.load().s2d_convt3d_mfma_norm_supported(ct.weight.shape[0], ct.weight.shape[1], *[int(v) for v in in_dhw]))
 
 
 def upsample_level_supported(ct, in_dhw, next_conv=None):
