@@ -369,6 +369,21 @@ int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const void *y, const
                              const float *shift, int relu, const float *a, const float *b,
                              const float *d, int64_t n, int c, void *dx, void *dres,
                              s2d_stream_t stream);
+/* Leading-dimension variants (r04): y / dy may be a channel slice of a wider row-major bf16 tensor - y_ld / dy_ld = its row stride in
+ * elements (a multiple of 8, >= c; the pointer is the slice's first element).  Lets the RPN's up-sampling branches write their
+ * batch-norm outputs straight into the concatenated tensor and read their gradients out of its gradient: no torch.cat copy, no
+ * contiguous copies of the gradient slices (rpn.py:156-171). */
+int s2d_bnrow_apply_ld_bf16(const void *x, const float *scale, const float *shift, const void *residual, int relu, int64_t n, int c, void *y,
+                            int y_ld, s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift, int relu,
+                                 int64_t n, int c, float *sums, float *sums_copy, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bnrow_bwd_reduce_finalize_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift,
+                                          int relu, int64_t n, int c, const float *gamma, const float *mean, const float *invstd,
+                                          float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws, size_t ws_bytes,
+                                          s2d_stream_t stream);
+int s2d_bnrow_bwd_apply_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift, int relu,
+                                const float *a, const float *b, const float *d, int64_t n, int c, void *dx, void *dres,
+                                s2d_stream_t stream);
 
 /*
  * bf16-storage sparse convolution ("s16" path): features and outputs are bf16 [n][c] in HBM,

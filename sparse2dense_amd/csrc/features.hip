@@ -478,7 +478,9 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
                                                                       const __bf16 *__restrict__ y,
                                                                       const float *__restrict__ scale,
                                                                       const float *__restrict__ shift, int64_t n, int c,
-                                                                      int rows_per_block, float *__restrict__ partial) {
+                                                                      int rows_per_block, float *__restrict__ partial, int dy_ld) {
+    // dy_ld (r04): row stride of dy in elements (>= c, a multiple of 8) - the gradient may be a channel slice of a wider row-major
+    // tensor (the RPN's concatenated deblock outputs: no contiguous copy of the slice is made)
     constexpr bool relu = ACT == 1, gelu = ACT == 2, act = ACT != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [row_lanes][2][C]
     const int c8 = c >> 3;
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
                 const int64_t r = rb + (int64_t)u * lanes < r1 ? rb + (int64_t)u * lanes : rb;
                 xv[u] = reinterpret_cast<const bf16x8r *>(x + r * c)[grp];
                 if constexpr (BWD) {
-                    gv[u] = reinterpret_cast<const bf16x8r *>(dy + r * c)[grp];
+                    gv[u] = reinterpret_cast<const bf16x8r *>(dy + r * dy_ld)[grp];
                     if constexpr (relu && HAS_Y) yv[u] = reinterpret_cast<const bf16x8r *>(y + r * c)[grp];
                 }
             }
@@ -549,7 +551,8 @@ __global__ __launch_bounds__(RED_THREADS) void row_reduce_bf16_kernel(const __bf
 template <bool RES, int ACT>
 __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ scale,
                                                              const float *__restrict__ shift, const __bf16 *__restrict__ res_p,
-                                                             int64_t n, int c8, __bf16 *__restrict__ y) {
+                                                             int64_t n, int c8, __bf16 *__restrict__ y, int y_c8) {
+    // y_c8 (r04): row stride of y in 8-channel groups (>= c8) - y may be a channel slice of a wider row-major tensor
     constexpr bool relu = ACT == 1, gelu = ACT == 2;
     const __bf16 *__restrict__ res = RES ? res_p : nullptr;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256) void row_apply_bf16_kernel(const __bf16 *__res
                 if (gelu) v = gelu_f(v);
                 o[e] = (__bf16)v;
             }
-            reinterpret_cast<bf16x8r *>(y)[r * c8 + g] = o;
+            reinterpret_cast<bf16x8r *>(y)[r * y_c8 + g] = o;
         }
     }
 }
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *_
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  const float *__restrict__ a, const float *__restrict__ b,
                                                                  const float *__restrict__ d, int64_t n, int c8,
-                                                                 __bf16 *__restrict__ dx, __bf16 *__restrict__ dres) {
+                                                                 __bf16 *__restrict__ dx, __bf16 *__restrict__ dres, int dy_c8) {
     constexpr bool relu = ACT == 1, gelu = ACT == 2, act = ACT != 0;
     const int g = threadIdx.x % c8, rl = threadIdx.x / c8, lanes = blockDim.x / c8;
     float sc[8], sh[8], av[8], bv[8], dv[8];
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256) void row_bwd_apply_bf16_kernel(const __bf16 *_
         for (int u = 0; u < ROW_UNROLL; ++u) {
             const int64_t r = r0 + u * stride < n ? r0 + u * stride : r0;
             xv[u] = reinterpret_cast<const bf16x8r *>(x)[r * c8 + g];
-            gv[u] = reinterpret_cast<const bf16x8r *>(dy)[r * c8 + g];
+            gv[u] = reinterpret_cast<const bf16x8r *>(dy)[r * dy_c8 + g];
             if (relu && HAS_Y) yv[u] = reinterpret_cast<const bf16x8r *>(y)[r * c8 + g];
         }
 #pragma unroll
@@ -984,9 +987,11 @@ extern "C" size_t s2d_bnrow_workspace_bytes(int64_t n, int c) {
 // fwd=1: x -> (sum x, sum x^2); fwd=0: (dy, x, scale, shift, relu) -> (sum g, sum g*x).  out: [2c] sums when
 // fin == nullptr-style split mode is wanted (stats != nullptr), else fused finalisation.
 static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, const float *scale, const float *shift, int relu,
-                        int64_t n, int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who) {
+                        int64_t n, int c, void *ws, size_t ws_bytes, hipStream_t st, RedPlan *plan_out, const char *who, int dy_ld = 0) {
     int rc = check_c8(c, who);
     if (rc) return rc;
+    dy_ld = dy_ld ? dy_ld : c;
+    S2D_CHECK_ARG(dy_ld >= c && dy_ld % 8 == 0, "bnrow reduce: the row stride of dy must be a multiple of 8 and >= c");
     S2D_CHECK_ARG(n > 0 && x && (!bwd || dy) && (!(bwd && relu) || (y && relu == 1) || (scale && shift)) && relu >= 0 && relu <= 2,
                   "bnrow reduce: bad argument");
     RedPlan p = row_plan_bf16(n, c);
@@ -996,7 +1001,7 @@ static int bnrow_reduce(bool bwd, const void *x, const void *dy, const void *y, 
     }
 #define S2D_ROW_REDUCE(B, R, Y)                                                                                              \
     hipLaunchKernelGGL((row_reduce_bf16_kernel<B, R, Y>), dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, (const __bf16 *)x, \
-                       (const __bf16 *)dy, (const __bf16 *)y, scale, shift, n, c, p.rows_per_block, (float *)ws)
+                       (const __bf16 *)dy, (const __bf16 *)y, scale, shift, n, c, p.rows_per_block, (float *)ws, dy_ld)
     if (!bwd) S2D_ROW_REDUCE(false, 0, false);
     else if (!relu) S2D_ROW_REDUCE(true, 0, false);
     else if (relu == 2) S2D_ROW_REDUCE(true, 2, false);
@@ -1036,15 +1041,22 @@ extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, co
     return S2D_OK;
 }
 
+/* y_ld: row stride of y in elements (a multiple of 8, >= c): y may be a channel slice of a wider row-major tensor */
+extern "C" int s2d_bnrow_apply_ld_bf16(const void *x, const float *scale, const float *shift, const void *residual, int relu,
+                                       int64_t n, int c, void *y, int y_ld, s2d_stream_t stream);
 extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const float *shift, const void *residual, int relu,
                                     int64_t n, int c, void *y, s2d_stream_t stream) {
+    return s2d_bnrow_apply_ld_bf16(x, scale, shift, residual, relu, n, c, y, c, stream);
+}
+extern "C" int s2d_bnrow_apply_ld_bf16(const void *x, const float *scale, const float *shift, const void *residual, int relu,
+                                       int64_t n, int c, void *y, int y_ld, s2d_stream_t stream) {
     int rc = check_c8(c, "bnrow_apply");
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && x && y && scale && shift, "bnrow_apply: bad argument");
+    S2D_CHECK_ARG(n > 0 && x && y && scale && shift && y_ld >= c && y_ld % 8 == 0, "bnrow_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
 #define S2D_ROW_APPLY(RS, RL)                                                                                                   \
     hipLaunchKernelGGL((row_apply_bf16_kernel<RS, RL>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream, (const __bf16 *)x, \
-                       scale, shift, (const __bf16 *)residual, n, c / 8, (__bf16 *)y)
+                       scale, shift, (const __bf16 *)residual, n, c / 8, (__bf16 *)y, y_ld / 8)
     S2D_CHECK_ARG(relu >= 0 && relu <= 2, "bnrow_apply: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
     if (residual) {
         if (relu == 2) S2D_ROW_APPLY(true, 2); else if (relu) S2D_ROW_APPLY(true, 1); else S2D_ROW_APPLY(true, 0);
@@ -1056,13 +1068,22 @@ extern "C" int s2d_bnrow_apply_bf16(const void *x, const float *scale, const flo
     return S2D_OK;
 }
 
+/* the _ld variants: dy_ld = row stride of dy in elements (a multiple of 8, >= c): dy may be a channel slice of a wider row-major tensor */
+extern "C" int s2d_bnrow_bwd_reduce_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift,
+                                            int relu, int64_t n, int c, float *sums, float *sums_copy, void *ws, size_t ws_bytes,
+                                            s2d_stream_t stream);
 extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const void *y, const float *scale, const float *shift,
                                          int relu, int64_t n, int c, float *sums, float *sums_copy, void *ws, size_t ws_bytes,
                                          s2d_stream_t stream) {
+    return s2d_bnrow_bwd_reduce_ld_bf16(dy, c, x, y, scale, shift, relu, n, c, sums, sums_copy, ws, ws_bytes, stream);
+}
+extern "C" int s2d_bnrow_bwd_reduce_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift,
+                                            int relu, int64_t n, int c, float *sums, float *sums_copy, void *ws, size_t ws_bytes,
+                                            s2d_stream_t stream) {
     S2D_CHECK_ARG(sums, "bnrow_bwd_reduce: null sums");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce");
+    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce", dy_ld);
     if (rc) return rc;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, 2 * c, sums,
                        sums_copy, -1.f, true);
@@ -1070,14 +1091,25 @@ extern "C" int s2d_bnrow_bwd_reduce_bf16(const void *dy, const void *x, const vo
     return S2D_OK;
 }
 
+extern "C" int s2d_bnrow_bwd_reduce_finalize_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale,
+                                                     const float *shift, int relu, int64_t n, int c, const float *gamma, const float *mean,
+                                                     const float *invstd, float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                                     size_t ws_bytes, s2d_stream_t stream);
 extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x, const void *y, const float *scale,
                                                   const float *shift, int relu, int64_t n, int c, const float *gamma, const float *mean, const float *invstd,
                                                   float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
                                                   size_t ws_bytes, s2d_stream_t stream) {
+    return s2d_bnrow_bwd_reduce_finalize_ld_bf16(dy, c, x, y, scale, shift, relu, n, c, gamma, mean, invstd, dgamma, dbeta, a, b, d, ws, ws_bytes,
+                                                 stream);
+}
+extern "C" int s2d_bnrow_bwd_reduce_finalize_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale,
+                                                     const float *shift, int relu, int64_t n, int c, const float *gamma, const float *mean,
+                                                     const float *invstd, float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                                     size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(gamma && mean && invstd && dgamma && dbeta && a && b && d, "bnrow_bwd_reduce_finalize: bad argument");
     hipStream_t st = (hipStream_t)stream;
     RedPlan p;
-    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize");
+    int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize", dy_ld);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, mean, invstd, c, dgamma, dbeta, a, b, d, true);
@@ -1085,18 +1117,26 @@ extern "C" int s2d_bnrow_bwd_reduce_finalize_bf16(const void *dy, const void *x,
     return S2D_OK;
 }
 
+extern "C" int s2d_bnrow_bwd_apply_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift,
+                                           int relu, const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
+                                           void *dres, s2d_stream_t stream);
 extern "C" int s2d_bnrow_bwd_apply_bf16(const void *dy, const void *x, const void *y, const float *scale, const float *shift,
                                         int relu, const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
                                         void *dres, s2d_stream_t stream) {
+    return s2d_bnrow_bwd_apply_ld_bf16(dy, c, x, y, scale, shift, relu, a, b, d, n, c, dx, dres, stream);
+}
+extern "C" int s2d_bnrow_bwd_apply_ld_bf16(const void *dy, int dy_ld, const void *x, const void *y, const float *scale, const float *shift,
+                                           int relu, const float *a, const float *b, const float *d, int64_t n, int c, void *dx,
+                                           void *dres, s2d_stream_t stream) {
     int rc = check_c8(c, "bnrow_bwd_apply");
     if (rc) return rc;
-    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || (y && relu == 1) || (scale && shift)) && relu >= 0 && relu <= 2,
-                  "bnrow_bwd_apply: bad argument");
+    S2D_CHECK_ARG(n > 0 && dy && x && dx && a && b && d && (!relu || (y && relu == 1) || (scale && shift)) && relu >= 0 && relu <= 2 &&
+                      dy_ld >= c && dy_ld % 8 == 0, "bnrow_bwd_apply: bad argument");
     const RowLaunch l = row_launch(n, c / 8);
 #define S2D_ROW_BWD(RL, Y, DR)                                                                                                     \
     hipLaunchKernelGGL((row_bwd_apply_bf16_kernel<RL, Y, DR>), dim3(l.blocks), dim3(l.threads), 0, (hipStream_t)stream,         \
                        (const __bf16 *)dy, (const __bf16 *)x, (const __bf16 *)y, scale, shift, a, b, d, n, c / 8, (__bf16 *)dx,    \
-                       (__bf16 *)dres)
+                       (__bf16 *)dres, dy_ld / 8)
     const bool use_y = relu == 1 && y;
     if (!relu) {
         if (dres) S2D_ROW_BWD(0, false, true); else S2D_ROW_BWD(0, false, false);

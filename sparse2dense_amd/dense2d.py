@@ -751,6 +751,40 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
+def channel_slice_ld(t, c):
+    """row stride (elements) if t is a [N, c, H, W] bf16 channel slice of a WIDER channels_last tensor whose rows the *_ld kernels can
+    address (16-byte aligned start, stride a multiple of 8), else 0"""
+    if not (torch.is_tensor(t) and t.dim() == 4 and t.dtype == torch.bfloat16 and t.is_cuda and t.shape[1] == c):
+        return 0
+    n, _, h, w = t.shape
+    s = t.stride()
+    ld = s[3]
+    if s[1] != 1 or ld <= c or ld % 8 or s[2] != w * ld or (n > 1 and s[0] != h * w * ld) or (t.storage_offset() * 2) % 16:
+        return 0
+    return ld
+
+
+class _CatSlicesFn(torch.autograd.Function):
+    """torch.cat(parts, 1) whose parts were WRITTEN as channel slices of `buf` by their producers (FastBatchNorm2d(out=slice)): the forward
+    hands out the filled buffer, the backward hands every producer its channel slice of the gradient as a strided view - no copy
+    either way (the *_ld batch-norm kernels read it in place)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, dcat):
+        if dcat.dtype != torch.bfloat16 or not dcat.is_contiguous(memory_format=torch.channels_last):
+            dcat = _nhwc_bf16(dcat)
+        outs, off = [], 0
+        for wd in ctx.widths:
+            outs.append(dcat[:, off:off + wd])
+            off += wd
+        return (None, *outs)
+
+
 class _BNRowFn(torch.autograd.Function):
     """Batch norm over the rows of a row-major bf16 matrix: x is bf16 channels_last [N,C,H,W] (rows = N*H*W) or a
     sparse feature matrix [n,C].  y = relu?(bn(x) + residual?).  Training statistics over all rows (of all ranks when
@@ -758,7 +792,9 @@ class _BNRowFn(torch.autograd.Function):
     passed as base pointer + offset (no tensor views on the hot path)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training, partial=None):
+    def forward(ctx, x, gamma, beta, residual, relu, eps, sync, module, training, partial=None, out=None):
+        """out (r04): a channel slice [N, c, H, W] of a wider bf16 channels_last tensor to write y into (`channel_slice_ld`) - the RPN's
+        up-sampling branches fill the concatenated tensor directly; returned as the function's output"""
         lib = _lib.load()
         c = x.shape[1]
         rows = x.numel() // c
@@ -821,15 +857,22 @@ class _BNRowFn(torch.autograd.Function):
                 if frozen:
                     module._s2d_eval_fin = (key, fin)
             fp, rb = fin.data_ptr(), 4 * c
-        y = torch.empty_like(x)   # preserves channels_last
-        check(lib.s2d_bnrow_apply_bf16(x.data_ptr(), fp + 2 * rb, fp + 3 * rb, _ptr(residual), int(relu), rows, c, y.data_ptr(),
-                                       stream), "s2d_bnrow_apply_bf16")
+        if out is not None:
+            y, y_ld = out, channel_slice_ld(out, c)
+            assert y_ld and out.shape == x.shape and not out.requires_grad, "out must be a channel slice of a bf16 channels_last tensor, shaped like x"
+        else:
+            y, y_ld = torch.empty_like(x), c   # preserves channels_last
+        check(lib.s2d_bnrow_apply_ld_bf16(x.data_ptr(), fp + 2 * rb, fp + 3 * rb, _ptr(residual), int(relu), rows, c, y.data_ptr(), y_ld,
+                                          stream), "s2d_bnrow_apply_ld_bf16")
         has_res = residual is not None
         assert not (has_res and int(relu) == 2), "fused GELU behind a residual add is not supported (its derivative needs bn(x)+res)"
         # with a residual the ReLU mask cannot be recomputed from x alone: keep y
+        assert out is None or not (has_res and relu), "a ReLU behind a residual keeps y for its backward: not with a strided destination"
         ctx.save_for_backward(x, gamma, fin, count, y if (has_res and relu) else None)
         ctx.relu, ctx.sync, ctx.training, ctx.has_res = relu, sync, training, has_res
-        return y
+        # (a destination slice is a plain no-grad buffer written in place; the output is a fresh alias of it, so autograd neither sees an
+        # in-place operation on a view - which would put a CopySlices with its copies into the backward - nor an input returned as is)
+        return y if out is None else y.detach()
 
     @staticmethod
     def backward(ctx, dy):
@@ -839,25 +882,28 @@ class _BNRowFn(torch.autograd.Function):
         rows = x.numel() // c
         dev = x.device
         fp, rb = fin.data_ptr(), 4 * c          # mean, invstd, scale, shift
-        if dy.dtype != torch.bfloat16 or not (dy.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4
-                                              else dy.is_contiguous()):
-            dy = _nhwc_bf16(dy) if x.dim() == 4 else dy.to(torch.bfloat16).contiguous()
+        dy_ld = channel_slice_ld(dy, c) if x.dim() == 4 else 0   # a channel slice of the concatenated tensor's gradient is read in place
+        if not dy_ld:
+            dy_ld = c
+            if dy.dtype != torch.bfloat16 or not (dy.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4
+                                                  else dy.is_contiguous()):
+                dy = _nhwc_bf16(dy) if x.dim() == 4 else dy.to(torch.bfloat16).contiguous()
         relu = int(ctx.relu)
         ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, c), dev)
         stream = _stream()
         out = torch.empty((5, c), dtype=torch.float32, device=dev)   # rows: dgamma, dbeta, a, b, d
         op = out.data_ptr()
         if ctx.training and not ctx.sync:
-            check(lib.s2d_bnrow_bwd_reduce_finalize_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows,
-                                                         c, gamma.data_ptr(), fp, fp + rb, op, op + rb, op + 2 * rb, op + 3 * rb,
-                                                         op + 4 * rb, ws.data_ptr(), ws.numel(), stream),
-                  "s2d_bnrow_bwd_reduce_finalize_bf16")
+            check(lib.s2d_bnrow_bwd_reduce_finalize_ld_bf16(dy.data_ptr(), dy_ld, x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows,
+                                                            c, gamma.data_ptr(), fp, fp + rb, op, op + rb, op + 2 * rb, op + 3 * rb,
+                                                            op + 4 * rb, ws.data_ptr(), ws.numel(), stream),
+                  "s2d_bnrow_bwd_reduce_finalize_ld_bf16")
         else:
             sums = torch.empty((2, 2 * c), dtype=torch.float32, device=dev)   # row 0: local sums, row 1: the copy that is all-reduced
             sp = sums.data_ptr()
-            check(lib.s2d_bnrow_bwd_reduce_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows, c, sp,
-                                                sp + 8 * c if ctx.training else None, ws.data_ptr(), ws.numel(), stream),
-                  "s2d_bnrow_bwd_reduce_bf16")
+            check(lib.s2d_bnrow_bwd_reduce_ld_bf16(dy.data_ptr(), dy_ld, x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows, c, sp,
+                                                   sp + 8 * c if ctx.training else None, ws.data_ptr(), ws.numel(), stream),
+                  "s2d_bnrow_bwd_reduce_ld_bf16")
             if ctx.training:
                 import torch.distributed as dist
                 _collective.allreduce_sum_(sums[1])
@@ -875,10 +921,10 @@ class _BNRowFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             if want_res:
                 dres = torch.empty_like(x) if relu else dy   # without a ReLU the residual gradient is dy itself
-            check(lib.s2d_bnrow_bwd_apply_bf16(dy.data_ptr(), x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, op + 2 * rb,
-                                               op + 3 * rb, op + 4 * rb, rows, c, dx.data_ptr(),
-                                               dres.data_ptr() if (want_res and relu) else None, stream), "s2d_bnrow_bwd_apply_bf16")
-        return dx, out[0], out[1], dres, None, None, None, None, None, None
+            check(lib.s2d_bnrow_bwd_apply_ld_bf16(dy.data_ptr(), dy_ld, x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, op + 2 * rb,
+                                                  op + 3 * rb, op + 4 * rb, rows, c, dx.data_ptr(),
+                                                  dres.data_ptr() if (want_res and relu) else None, stream), "s2d_bnrow_bwd_apply_ld_bf16")
+        return dx, out[0], out[1], dres, None, None, None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):
@@ -896,7 +942,8 @@ class FastBatchNorm2d(nn.BatchNorm2d):
                 and self.num_features % 8 == 0 and self.num_features <= 1024 and x.numel() > 0
                 and x.is_contiguous(memory_format=torch.channels_last) and self.momentum is not None)
 
-    def forward(self, x, relu=None):
+    def forward(self, x, relu=None, out=None):
+        """out: see _BNRowFn.forward (only on the HIP path: callers check `_hip_ok` first)"""
         relu = self.fused_relu if relu is None else relu
         training = self.training or not self.track_running_stats
         sync = training and _dist_sync()
@@ -904,7 +951,8 @@ class FastBatchNorm2d(nn.BatchNorm2d):
             partial = getattr(x, "_s2d_bn_partial", None) if training else None
             if partial is not None and partial.shape[2] != self.num_features:
                 partial = None
-            return _BNRowFn.apply(x, self.weight, self.bias, None, relu, self.eps, sync, self, training, partial)
+            return _BNRowFn.apply(x, self.weight, self.bias, None, relu, self.eps, sync, self, training, partial, out)
+        assert out is None, "FastBatchNorm2d(out=...) needs the HIP path"
         if sync and x.is_cuda:
             import torch.distributed as dist
             from torch.nn.modules._functions import SyncBatchNorm as _SyncFn

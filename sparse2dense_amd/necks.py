@@ -105,8 +105,43 @@ class RPN(nn.Module):
                 if relu_between:
                     x = F.relu(x)
             if i - self._upsample_start_idx >= 0:
-                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+                ups.append(self._deblock(i - self._upsample_start_idx, x, ups))
+        if ups and isinstance(ups[0], tuple):   # every branch wrote its slice of the concatenated tensor (see _deblock)
+            from .dense2d import _CatSlicesFn
+            return _CatSlicesFn.apply(ups[0][1], *[u[0] for u in ups])
         return torch.cat(ups, dim=1) if ups else x
+
+    def _deblock(self, j, x, ups):
+        """deblock j of the trunk.  r04: when every deblock ends in a FastBatchNorm2d on the HIP path and the branch outputs have one
+        spatial size, the batch norms write their outputs as channel slices of ONE buffer = the concatenated tensor of rpn.py:171 (no
+        torch.cat pass, no contiguous copies of the gradient slices in the backward); returns (slice, buffer) then, else the plain output.
+        S2D_RPN_CAT=torch keeps the concatenation."""
+        blk = self.deblocks[j]
+        mods = list(blk)
+        while mods and isinstance(mods[-1], nn.Identity):
+            mods.pop()
+        fused = (os.environ.get("S2D_RPN_CAT", "slices") != "torch" and len(self.deblocks) > 1 and mods and isinstance(mods[-1], FastBatchNorm2d)
+                 and all(isinstance(u, tuple) for u in ups) and torch.is_grad_enabled())
+        if not fused:
+            assert not any(isinstance(u, tuple) for u in ups), "mixed concatenation modes"
+            return blk(x)
+        for layer in mods[:-1]:
+            x = layer(x)
+        bn = mods[-1]
+        widths = [list(d)[0].out_channels for d in self.deblocks]
+        total = sum(widths)
+        ok = bn._hip_ok(x) and total % 8 == 0 and all(wd % 8 == 0 for wd in widths)
+        if ups:
+            buf = ups[0][1]
+            ok = ok and buf.shape[0] == x.shape[0] and buf.shape[2:] == x.shape[2:]
+        elif ok:
+            buf = torch.empty((x.shape[0], total, x.shape[2], x.shape[3]), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        if not ok:
+            if ups:   # (cannot happen with the reference's configurations: all branches end at one resolution)
+                raise RuntimeError("RPN deblock outputs differ in shape")
+            return bn(x)
+        off = sum(widths[:j])
+        return bn(x, out=buf[:, off:off + widths[j]]), buf
 
     def forward(self, x):
         return self._trunk(x, relu_between=True)  # rpn.py:156

@@ -329,3 +329,38 @@ def test_losses_cpu_match_reference_golden(golden_dir):
 @pytest.mark.gpu
 def test_losses_gpu_match_reference_golden(golden_dir):
     _loss_checks(golden_dir, "cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RPN", "S2D_RPN"])
+def test_rpn_deblock_outputs_written_as_slices_of_the_concatenated_tensor(kind, monkeypatch):
+    """r04 necks.RPN._deblock: the up-sampling branches' batch norms write their outputs as channel slices of ONE buffer (= the
+    torch.cat of rpn.py:171) and read their gradients out of its gradient in place (s2d_bnrow_*_ld_bf16).  Same kernels, same
+    arithmetic as concatenating: outputs and every gradient are bit-equal to the S2D_RPN_CAT=torch run; no CatArrayBatchedCopy left."""
+    from sparse2dense_amd import dense2d
+    net = fill_params(build_from_cfg(dict(type=kind, **CFG), NECKS)).train().to("cuda:0")
+    x = seeded((2, 256, 64, 48) if kind == "RPN" else (1, 256, 188, 188), 101).to("cuda:0")   # (the S2D module's LayerNorms fix 188 x 188)
+
+    def run(mode):
+        monkeypatch.setenv("S2D_RPN_CAT", mode)
+        net.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        with _bf16_mode(net):
+            og = net(xg)
+        og = [og] if torch.is_tensor(og) else [o for o in og if o is not None]
+        gr = _grads([o.float() for o in og], [xg] + list(net.parameters()), 300)
+        return og, gr
+
+    calls = []
+    orig = dense2d._CatSlicesFn.forward
+    monkeypatch.setattr(dense2d._CatSlicesFn, "forward", staticmethod(lambda ctx, buf, *p: (calls.append(len(p)), orig(ctx, buf, *p))[1]))
+    o_ref, g_ref = run("torch")
+    assert not calls
+    o_new, g_new = run("slices")
+    assert calls == [2], calls
+    for a, b in zip(o_new, o_ref):
+        assert torch.equal(a, b)
+    for a, b in zip(g_new, g_ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
