@@ -614,6 +614,14 @@ int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const i
 int s2d_nhwc_bf16_to_nchw_f32(const void *x, int batch, int c, int64_t hw, float *y, s2d_stream_t stream);
 int s2d_nchw_f32_to_nhwc_bf16(const float *x, int batch, int c, int64_t hw, void *y, s2d_stream_t stream);
 
+/* 2 x 2 resampling of NHWC bf16 maps (r04, the pillar S2D module): nn.Upsample(scale_factor=2, mode="nearest") and nn.MaxPool2d(2, 2) with
+ * their backward passes; c % 8 == 0.  The max-pool backward re-derives the selected window element from x (torch's scan order, NaN
+ * propagating) - no index tensor. */
+int s2d_upsample2x_nhwc_bf16(const void *x, int n, int h, int w, int c, void *y, s2d_stream_t stream);
+int s2d_upsample2x_bwd_nhwc_bf16(const void *dy, int n, int h, int w, int c, void *dx, s2d_stream_t stream);
+int s2d_maxpool2x2_nhwc_bf16(const void *x, int n, int h, int w, int c, void *y, s2d_stream_t stream);
+int s2d_maxpool2x2_bwd_nhwc_bf16(const void *x, const void *dy, int n, int h, int w, int c, void *dx, s2d_stream_t stream);
+
 /*
  * LayerNorm over a whole [C,H,W] map per sample (nn.LayerNorm([256,47,47]) of the S2D ConvNeXt blocks, det3d/models/necks/rpn.py:
  * 210-247): each row is split over many workgroups (two-level fixed-order reduction).  x / y / dy / dx: bf16 [batch][row] in
@@ -803,7 +811,7 @@ int s2d_pfn_bwd_f32(const float *voxels, const int32_t *num_points, const int32_
                     const uint8_t *argmax, int64_t pillars, int slots, int ndim, float vx, float vy, float x_offset, float y_offset,
                     float *partial, s2d_stream_t stream);
 
-/* Two PFN layers (configs/waymo/pp/*: num_filters = [64, 64]; layer 1 Linear(10 -> 32) -> BN -> ReLU -> [x | max over slots], layer 2
+/* Two PFN layers (the configs under configs/waymo/pp: num_filters = [64, 64]; layer 1 Linear(10 -> 32) -> BN -> ReLU -> [x | max over slots], layer 2
  * Linear(64 -> 64) -> BN -> ReLU -> max over slots; pillar_encoder.py:41-56).  scale_shift1 = scale[32] | shift[32] of the first batch
  * norm, scale_shift2 = scale[64] | shift[64] of the second.  _stats1 / _stats2: per-workgroup partial slabs [s2d_pfn_blocks(P)][2][64]
  * of (sum h, sum h^2) over the valid rows of layer 1 (columns 32..63 duplicate 0..31) / over all P*slots rows of layer 2.  _apply_max:

@@ -271,6 +271,10 @@ SIGNATURES = {
                                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bnrow_bwd_apply_ld_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, c_f32p, c_f32p,
                                                    c_f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_upsample2x_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_upsample2x_bwd_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_maxpool2x2_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_maxpool2x2_bwd_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_spconv_s16_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_debug_rg_trace": (None, [ctypes.c_void_p]),
     "s2d_spconv_s16_packed_elems": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),

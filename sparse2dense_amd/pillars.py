@@ -371,11 +371,69 @@ def _cbg(conv, c):
     return fuse_bn_relu([conv, FastBatchNorm2d(c), nn.GELU()])
 
 
-class _UpsampleKeepDtype(nn.Upsample):
-    """nn.Upsample (nearest) that keeps the dtype and memory format of its input under autocast: the autocast policy promotes
-    interpolation to fp32, which turned the NHWC bf16 map of the S2D module into an fp32 one right in front of three consumers"""
+def _nhwc_bf16_ok(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.numel() > 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _Resample2x2Fn(torch.autograd.Function):
+    """nearest up-sampling by 2 (`up=True`) / MaxPool2d(2, 2) of an NHWC bf16 map on csrc/layout.hip (16-byte groups of 8 channels; the
+    max-pool backward re-derives the selected element from x)"""
+
+    @staticmethod
+    def forward(ctx, x, up):
+        from . import _lib
+        from .dense2d import _stream
+        lib = _lib.load()
+        n, c, h, w = x.shape
+        ctx.up = up
+        if up:
+            y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            _lib.check(lib.s2d_upsample2x_nhwc_bf16(x.data_ptr(), n, h, w, c, y.data_ptr(), _stream()), "s2d_upsample2x_nhwc_bf16")
+            ctx.shape = (n, c, h, w)
+        else:
+            y = torch.empty((n, c, h // 2, w // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            _lib.check(lib.s2d_maxpool2x2_nhwc_bf16(x.data_ptr(), n, h, w, c, y.data_ptr(), _stream()), "s2d_maxpool2x2_nhwc_bf16")
+            ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from .dense2d import _nhwc_bf16, _stream
+        lib = _lib.load()
+        if dy.dtype != torch.bfloat16 or not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = _nhwc_bf16(dy)
+        if ctx.up:
+            n, c, h, w = ctx.shape
+            dx = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            _lib.check(lib.s2d_upsample2x_bwd_nhwc_bf16(dy.data_ptr(), n, h, w, c, dx.data_ptr(), _stream()), "s2d_upsample2x_bwd_nhwc_bf16")
+        else:
+            (x,) = ctx.saved_tensors
+            n, c, h, w = x.shape
+            dx = torch.empty_like(x)
+            _lib.check(lib.s2d_maxpool2x2_bwd_nhwc_bf16(x.data_ptr(), dy.data_ptr(), n, h, w, c, dx.data_ptr(), _stream()), "s2d_maxpool2x2_bwd_nhwc_bf16")
+        return dx, None
+
+
+class MaxPool2x2(nn.MaxPool2d):
+    """nn.MaxPool2d(2, 2) (point_pillars.py S2D module, in front of encoder_1); NHWC bf16 CUDA maps run on csrc/layout.hip"""
 
     def forward(self, x):
+        if (_nhwc_bf16_ok(x) and self.kernel_size in (2, (2, 2)) and self.stride in (2, (2, 2)) and self.padding in (0, (0, 0))
+                and self.dilation in (1, (1, 1)) and not self.ceil_mode and not self.return_indices and x.shape[2] >= 2 and x.shape[3] >= 2):
+            return _Resample2x2Fn.apply(x, False)
+        return super().forward(x)
+
+
+class _UpsampleKeepDtype(nn.Upsample):
+    """nn.Upsample (nearest) that keeps the dtype and memory format of its input under autocast: the autocast policy promotes
+    interpolation to fp32, which turned the NHWC bf16 map of the S2D module into an fp32 one right in front of three consumers.
+    scale_factor 2 on an NHWC bf16 map runs on csrc/layout.hip."""
+
+    def forward(self, x):
+        if self.mode == "nearest" and self.size is None and self.scale_factor in (2, 2.0, (2, 2), (2.0, 2.0)) and _nhwc_bf16_ok(x):
+            return _Resample2x2Fn.apply(x, True)
         if x.is_cuda and torch.is_autocast_enabled():
             with torch.autocast("cuda", enabled=False):
                 return super().forward(x)
@@ -396,7 +454,7 @@ class PointPillarsScatter_S2D(nn.Module):
         super().__init__()
         self.name = "PointPillarsScatter"
         self.nchannels = num_input_features
-        self.encoder_1 = nn.Sequential(nn.MaxPool2d(2, 2), *_cbg(nn.Conv2d(64, 32, 1, 1, 0), 32),
+        self.encoder_1 = nn.Sequential(MaxPool2x2(2, 2), *_cbg(nn.Conv2d(64, 32, 1, 1, 0), 32),
                                        *_cbg(nn.Conv2d(32, 32, 2, 2), 32), *_cbg(nn.Conv2d(32, 128, 1, 1, 0), 128))
         self.encoder_2 = nn.Sequential(*_cbg(Conv3x3(128, 128, 3, 2, 1), 128), *_cbg(Conv3x3(128, 256, 3, 1, 1), 256))
         self.convnext_block_1 = _convnext(256, 59)

@@ -335,3 +335,26 @@ def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters):
             assert _rel(a.norm.running_mean, b.norm.running_mean) <= 1e-5
             assert _rel(a.norm.running_var, b.norm.running_var) <= 1e-5
             assert int(a.norm.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 12, 10), (1, 32, 7, 9), (2, 8, 5, 5)])
+def test_2x2_resampling_kernels_match_torch_bit_for_bit(n, c, h, w):
+    """csrc/layout.hip r04: nn.MaxPool2d(2, 2) and nn.Upsample(scale_factor=2) of the pillar S2D module on NHWC bf16 maps - outputs and
+    gradients equal torch's own NHWC kernels bit for bit (odd sizes: the uncovered last row / column gets a zero gradient; ties and a
+    NaN follow torch's window scan)."""
+    from sparse2dense_amd.pillars import MaxPool2x2, _UpsampleKeepDtype
+    g = torch.Generator().manual_seed(n * 100 + c + h)
+    x0 = torch.randn(n, c, h, w, generator=g).to(torch.bfloat16)
+    x0[0, 0, 0, 0] = x0[0, 0, 0, 1] = 3.0          # a tie inside one window: the first element wins
+    x0[0, 1, 1, 1] = float("nan")
+    x0 = x0.to(DEV).contiguous(memory_format=torch.channels_last)
+    for mod, ref in ((MaxPool2x2(2, 2), torch.nn.MaxPool2d(2, 2)), (_UpsampleKeepDtype(scale_factor=2), torch.nn.Upsample(scale_factor=2))):
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        ya, yb = mod(xa), ref(xb)
+        assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last) and ya.shape == yb.shape
+        assert torch.equal(torch.nan_to_num(ya.float(), nan=7.0), torch.nan_to_num(yb.float(), nan=7.0))
+        gy = torch.randn(yb.shape, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+        ya.backward(gy)
+        yb.backward(gy)
+        assert torch.equal(xa.grad, xb.grad), type(mod).__name__
