@@ -237,6 +237,7 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
 # 128->128 / 256->256 BEV layers, 181 vs 224 us on 512->64 - and no SubTensorOp / cast launches or MIOpen host-side
 # solver lookup around it); True / False = all / none
 import os as _os
+from . import side as _side
 WGRAD_HIP = {"0": False, "1": True}.get(_os.environ.get("S2D_WGRAD_HIP", ""), "auto")
 
 
@@ -297,7 +298,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = conv_up(dyb, weight, None, 3)
             if ctx.needs_input_grad[1]:
-                dw = conv_s2_wgrad(dyb, xb, 3).to(weight.dtype)
+                dw = _side.run(weight, lambda: conv_s2_wgrad(dyb, xb, 3).to(weight.dtype), xb, dyb)
         elif stride != 1:   # shapes the kernels above do not take: both gradients through MIOpen
             wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dx, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [stride, stride], [pad, pad], [1, 1], False,
@@ -312,12 +313,14 @@ class _Conv3x3Fn(torch.autograd.Function):
                 else:
                     src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
                 dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
-            if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):
+            if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):   # off the chain to the next layer: second stream when enabled (side.py)
                 if ctx.has_bias and ctx.needs_input_grad[2]:   # the bias gradient rides on the weight-gradient launch
-                    dw, db = conv3x3_wgrad(xb, dyb, pad, want_db=True)
-                    dw = dw.to(weight.dtype)
+                    def both():
+                        dwf, dbf = conv3x3_wgrad(xb, dyb, pad, want_db=True)
+                        return dwf.to(weight.dtype), dbf
+                    dw, db = _side.run(weight, both, xb, dyb)
                 else:
-                    dw = conv3x3_wgrad(xb, dyb, pad).to(weight.dtype)
+                    dw = _side.run(weight, lambda: conv3x3_wgrad(xb, dyb, pad).to(weight.dtype), xb, dyb)
             elif ctx.needs_input_grad[1]:
                 wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 _, dwb, _ = torch.ops.aten.convolution_backward(dyb, xb, wb, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
@@ -493,13 +496,16 @@ class _Conv1x1Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin)
         if ctx.needs_input_grad[1]:
-            dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
-            if ctx.has_bias and ctx.needs_input_grad[2]:   # the bias gradient rides on the weight-gradient launch
-                db = torch.empty((cout,), dtype=torch.float32, device=xb.device)
-            ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
-            check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(db),
-                                                    _ptr(ws), ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
-            dw = dwf.reshape(weight.shape).to(weight.dtype)
+            want_db = bool(ctx.has_bias and ctx.needs_input_grad[2])   # the bias gradient rides on the weight-gradient launch
+
+            def wgrad():
+                dwf = torch.empty((cout, cin), dtype=torch.float32, device=xb.device)
+                dbf = torch.empty((cout,), dtype=torch.float32, device=xb.device) if want_db else None
+                ws = _ws(lib.s2d_conv2d1x1_wgrad_workspace_bytes(n, h, w, cin, cout), xb.device)
+                check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf),
+                                                        _ptr(ws), ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
+                return dwf.reshape(weight.shape).to(weight.dtype), dbf
+            dw, db = _side.run(weight, wgrad, xb, dyb)
         if ctx.has_bias and ctx.needs_input_grad[2] and db is None:   # per-channel sum of dY: the row-reduce kernel's first output half
             rows = n * h * w
             stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)

@@ -607,7 +607,7 @@ def spconv_s16_pack(weight_kio, n_out, transpose=False, flip=False):
     return packed, kvol, cin, cout
 
 
-def spconv_s16_pack_pair(weight_kio, n_out_fwd, n_out_dgrad, flip_dgrad):
+def spconv_s16_pack_pair(weight_kio, n_out_fwd, n_out_dgrad, flip_dgrad, with_launch=False):
     """fp32 [K, cin, cout] -> the forward image AND the data-gradient image ([cout -> cin], offsets mirrored when flip_dgrad) in one
     launch; returns ((packed, kvol, cin, cout), (packed_d, kvol, cout, cin)) as spconv_s16_pack does for each"""
     lib = _lib.load()
@@ -615,8 +615,11 @@ def spconv_s16_pack_pair(weight_kio, n_out_fwd, n_out_dgrad, flip_dgrad):
     w = weight_kio.detach().float().contiguous()
     pf = torch.empty(lib.s2d_spconv_s16_packed_elems(kvol, cin, cout), dtype=torch.bfloat16, device=w.device)
     pd = torch.empty(lib.s2d_spconv_s16_packed_elems(kvol, cout, cin), dtype=torch.bfloat16, device=w.device)
-    check(lib.s2d_spconv_s16_pack_weights_pair(_ptr(w), kvol, cin, cout, int(flip_dgrad), int(n_out_fwd), int(n_out_dgrad), _ptr(pf), _ptr(pd),
-                                               _stream()), "s2d_spconv_s16_pack_weights_pair")
+    launch = lambda: check(lib.s2d_spconv_s16_pack_weights_pair(_ptr(w), kvol, cin, cout, int(flip_dgrad), int(n_out_fwd), int(n_out_dgrad), _ptr(pf),
+                                                                _ptr(pd), _stream()), "s2d_spconv_s16_pack_weights_pair")
+    launch()
+    if with_launch:   # (the launch, the tensor it reads): dense2d.register_repack re-runs it in place after the optimizer step
+        return (pf, kvol, cin, cout), (pd, kvol, cout, cin), launch, w
     return (pf, kvol, cin, cout), (pd, kvol, cout, cin)
 
 

@@ -1,0 +1,141 @@
+"""Weight-gradient launches on a second HIP stream (default; S2D_WGRAD_STREAM=0 turns it off, =dense / =sparse select layer kinds).
+
+In the backward of a conv layer only the data gradient is on the chain to the next layer; the weight gradient (and its
+split-K fold, and the bias gradient that rides on it) is needed by nobody before the optimizer.  On one stream both are
+serialised with the chain's many small kernels (batch-norm finalize launches of ONE workgroup, folds, row passes that
+cannot fill 256 CUs); on a second stream the weight-gradient kernels fill those holes.  The reference gets the same
+overlap from cuDNN / spconv kernels queued behind each other by the autograd engine on a device with concurrent kernel
+execution (/root/reference/det3d/torchie/trainer/trainer.py:775-811 `loss.backward()`); here it is explicit.
+
+Protocol (one side stream per device):
+  * `run(weight, fn, *inputs)` inside an autograd backward: the side stream waits for an event recorded on the current
+    stream (everything `fn` reads has been enqueued there), `fn()` runs with the side stream current (its launches, its
+    workspace - `_ws` is keyed by stream - and its output allocations belong to that stream).  A reference to every input
+    is kept until the side stream has passed an event recorded behind `fn` (or until the join): the caching allocator
+    cannot hand their memory out meanwhile, and the autograd engine cannot accumulate a later gradient INTO one of them in
+    place on the main stream (it does that with a buffered gradient nobody else references - e.g. the gradient of a
+    residual add, which is both the `dy` of the branch's last conv and the buffered gradient of the block input).
+  * the returned gradient is handed to autograd unchanged.  With `weight.grad is None` AccumulateGrad adopts the tensor
+    without launching anything, so no main-stream kernel touches it before the join.  Every other case (accumulation
+    into an existing `.grad`, post-accumulate-grad hooks = the data-parallel buckets, graph capture, the profiling pass of
+    bench.py, double backward) takes the plain path: `fn()` on the current stream.
+  * the join: the first `run` of a backward queues an engine callback that makes the stream `backward()` was called on
+    wait for the side stream; `join()` does the same explicitly (train_step / solver call it before reading gradients).
+"""
+import collections
+import os
+
+import torch
+
+def _parse(v):
+    """"1" / "all": every wired layer kind; a comma list of kinds (dense, sparse) for A/B runs; anything else: off.  (The PCR head's
+    up-samplers were tried too: time-neutral - their weight gradients are chip-filling streams - and not wired.)"""
+    v = (v or "0").strip().lower()
+    if v in ("1", "all"):
+        return {"dense", "sparse"}
+    return {k for k in v.split(",") if k in ("dense", "sparse")}
+
+
+MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "1"))
+
+_streams = {}    # device index -> torch.cuda.Stream
+_pending = {}    # device index -> True while side work has been launched since the last join
+_cb_queued = {}  # device index -> True while a join callback is queued on the running backward
+_events = {}     # device index -> ring of reusable events
+_keep = {}       # device index -> deque of (event recorded on the side stream behind the work, tensors it reads)
+stats = {"side": 0, "plain": 0}
+CHECK = os.environ.get("S2D_WGRAD_STREAM_CHECK", "0") == "1"   # tests: remember what was handed to autograd
+_handed = []
+
+
+def adopted():
+    """(test hook, CHECK mode) True when every gradient produced on the side stream since the last call IS the parameter's .grad"""
+    ok = all(p is None or (w.grad is not None and w.grad.data_ptr() == p) for w, p in _handed)
+    n = len(_handed)
+    _handed.clear()
+    return ok, n
+
+
+def enable(on=True):
+    """True / False or a mode string as in S2D_WGRAD_STREAM"""
+    global MODE
+    MODE = _parse(on) if isinstance(on, str) else _parse("1" if on else "0")
+
+
+def _side(dev):
+    s = _streams.get(dev)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _streams[dev] = s
+        _events[dev] = [[torch.cuda.Event() for _ in range(512)], 0]
+        _keep[dev] = collections.deque()
+    return s
+
+
+def _event(dev):
+    ring = _events[dev]
+    ev = ring[0][ring[1]]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    return ev
+
+
+def usable(weight, kind="dense"):
+    if kind not in MODE or not weight.is_cuda or weight.grad is not None:
+        return False
+    if getattr(weight, "_post_accumulate_grad_hooks", None) or getattr(weight, "_backward_hooks", None):
+        return False
+    if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():   # double backward / capture
+        return False
+    from . import hip_ops as H
+    return H.PROFILE is None
+
+
+def join(device=None):
+    """make the current stream wait for the weight-gradient stream(s)"""
+    for dev, on in list(_pending.items()):
+        if on and (device is None or dev == device):
+            torch.cuda.current_stream(dev).wait_stream(_streams[dev])
+            _pending[dev] = False
+            _keep[dev].clear()   # everything enqueued on this stream from here on is ordered behind the side work
+    for dev in list(_cb_queued):
+        _cb_queued[dev] = False
+
+
+def run(weight, fn, *inputs, kind="dense"):
+    """fn() -> gradient tensor(s) of `weight` (and its bias); on the side stream when the protocol above allows it"""
+    if not usable(weight, kind):
+        stats["plain"] += 1
+        return fn()
+    dev = weight.device.index
+    side = _side(dev)
+    cur = torch.cuda.current_stream(dev)
+    ev = _event(dev)
+    ev.record(cur)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        out = fn()
+        # AccumulateGrad adopts a gradient only if it obeys the parameter's layout; otherwise it CLONES it - a main-stream launch
+        # before the join (and a copy kernel per layer and step on the chain: channels_last conv weights).  The first returned
+        # tensor is the weight gradient: it is re-laid here, on the side stream.
+        dw = out[0] if isinstance(out, (tuple, list)) else out
+        if dw is not None and dw.shape == weight.shape and (dw.stride() != weight.stride() or dw.dtype != weight.dtype):
+            dw = torch.empty_like(weight).copy_(dw)
+            out = (dw,) + tuple(out[1:]) if isinstance(out, (tuple, list)) else dw
+            stats["relaid"] = stats.get("relaid", 0) + 1
+        done = _event(dev)
+        done.record(side)
+    if dw is not None and dw.shape != weight.shape:   # cannot be adopted: the main stream waits here
+        cur.wait_event(done)
+        stats["waited"] = stats.get("waited", 0) + 1
+    elif CHECK:
+        _handed.append((weight, None if dw is None else dw.data_ptr()))
+    keep = _keep[dev]
+    keep.append((done, inputs))
+    while len(keep) > 1 and keep[0][0].query():
+        keep.popleft()
+    _pending[dev] = True
+    if not _cb_queued.get(dev):
+        _cb_queued[dev] = True
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
+    stats["side"] += 1
+    return out

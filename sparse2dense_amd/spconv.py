@@ -112,12 +112,17 @@ class _SparseConvFn(torch.autograd.Function):
         key = ("s16", bool(transpose), bool(flip), int(cin_feat))
         if pair_dgrad is not None and not transpose:
             # training forward: the data-gradient operand of this step is packed in the same launch (pair_dgrad = its (flip, n_out))
-            from .dense2d import cached_pack_has, cached_pack_put
+            from .dense2d import cached_pack_has, cached_pack_put, register_repack
             dkey = ("s16", True, bool(pair_dgrad[0]), int(cin_feat))
             if not cached_pack_has(weight, key) and not cached_pack_has(weight, dkey):
-                pf, pd = H.spconv_s16_pack_pair(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, pair_dgrad[1], pair_dgrad[0])
+                pf, pd, launch, wsrc = H.spconv_s16_pack_pair(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, pair_dgrad[1], pair_dgrad[0],
+                                                              with_launch=True)
                 cached_pack_put(weight, key, pf)
                 cached_pack_put(weight, dkey, pd)
+                # the tile plan (and with it the image layout) does not depend on the row counts (csrc/spconv_s16.hip s16_plan): the same
+                # launch refreshes both images in place after the optimizer step (dense2d.refresh_pack_cache) instead of being re-issued,
+                # with its host work, in the middle of the next forward.  (The 5-channel input layer packs a padded copy: not registered.)
+                register_repack(weight, [key, dkey], wsrc, launch)
         packed, kvol, cin, cout = cached_pack(
             weight, key, lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
         b = None if bias is None else bias.detach().float().contiguous()
@@ -153,9 +158,13 @@ class _SparseConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 nbr = rb.nbr_out if rb.subm else rb.nbr_in
                 dfeat = _SparseConvFn._s16(dout, weight, None, rb, nbr, rb.n_in, True, rb.subm, "dgrad", cin_feat=feat.shape[1])
-            if ctx.needs_input_grad[1]:
-                dw = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
-                dw = dw[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
+            if ctx.needs_input_grad[1]:   # off the chain to the previous layer: second stream when enabled (side.py)
+                from . import side
+
+                def wgrad():
+                    dwf = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
+                    return dwf[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
+                dw = side.run(weight, wgrad, feat, dout, rb.nbr_out, kind="sparse")
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = H.col_sums_bf16(dout)
             return dfeat, dw, db, None, None

@@ -56,7 +56,7 @@ def backward_and_clip(loss, params, max_norm=35.0):
     (dp.wrap_ddp, routes "overlap"/"flat") the gradients are averaged over the ranks by the model's GradBuckets: its
     all-reduces are launched from gradient hooks during the backward and awaited here, before the clip.
     max_norm=None: no clip here (solver.OneCycleAdam.clip_and_step folds it into the update)."""
-    from . import dp
+    from . import dp, side
     params = list(params)
     syncs = dp.bucketers_of(params)
     for g in syncs:
@@ -64,6 +64,7 @@ def backward_and_clip(loss, params, max_norm=35.0):
     for p in params:
         p.grad = None
     loss.backward()
+    side.join()   # weight gradients produced on the second stream (side.py; the engine callback has normally joined already)
     for g in syncs:
         g.finish()
     if max_norm is None:

@@ -1,0 +1,98 @@
+"""Weight gradients on a second HIP stream (sparse2dense_amd/side.py, S2D_WGRAD_STREAM): the same kernels on the same operands in a
+different launch order, so a training run must not depend on the mode - bit-identical losses and parameters - and every gradient
+produced on the side stream must be the tensor autograd adopted as `.grad` (a clone would be a main-stream launch before the join)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mode, steps=5, n_points=12000):
+    from sparse2dense_amd import dense2d, hip_ops, side, waymo_configs
+    from sparse2dense_amd.data import SyntheticFrames
+    from sparse2dense_amd.registry import build_detector
+    from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+    from sparse2dense_amd.train_step import backward_and_step
+    side.enable(mode)
+    side.CHECK = True
+    side._handed.clear()
+    side.stats.update(side=0, plain=0, waited=0)
+    dense2d.clear_pack_cache()
+    hip_ops.set_sparse_compute_dtype("s16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = build_detector(waymo_configs.s2d_student())
+    model.dense_dtype = torch.bfloat16
+    model.use_channels_last()
+    model = model.to(dev).train()
+    frames = SyntheticFrames(1, n_points=n_points, seed=5, distill=True, device=dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = build_one_cycle_optimizer(model, dict(wd=0.01))
+    sch = build_one_cycle_scheduler(opt, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4), total_steps=100)
+    losses, adopted = [], []
+    try:
+        for it in range(steps):
+            out = model(frames.example(), return_loss=True, return_feature=True)
+            loss = sum(out[0]["loss"]) + out[4] + out[5]
+            if it == steps - 1:   # last step by hand: the gradients themselves are compared
+                for p in params:
+                    p.grad = None
+                loss.backward()
+                adopted.append(side.adopted())
+                torch.cuda.synchronize()
+                grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            else:
+                backward_and_step(loss, params, opt, sch, it, 35.0)
+                adopted.append(side.adopted())
+            losses.append(float(loss))
+        final = torch.cat([p.detach().flatten()[:64].double().cpu() for p in params])
+        stats = dict(side.stats)
+    finally:
+        side.enable(False)
+        side.CHECK = False
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+    return losses, final, grads, adopted, stats
+
+
+def test_training_run_is_independent_of_the_weight_gradient_stream():
+    ref_losses, ref_final, ref_grads, _, ref_stats = _run("0")
+    assert ref_stats["side"] == 0
+    for mode in ("dense", "sparse", "1"):
+        losses, final, grads, adopted, stats = _run(mode)
+        assert stats["side"] > 0, (mode, stats)                       # the side stream was used ...
+        assert all(ok and n > 0 for ok, n in adopted), (mode, adopted, stats)   # ... and autograd adopted every gradient it produced
+        assert losses == ref_losses, (mode, losses, ref_losses)
+        assert torch.equal(final, ref_final), mode
+        for g, r in zip(grads, ref_grads):
+            assert (g is None) == (r is None)
+            if g is not None:
+                assert torch.equal(g, r), mode
+    assert ref_losses[-1] != ref_losses[0]
+
+
+def test_accumulating_into_an_existing_gradient_takes_the_plain_path():
+    """`.grad` already set (gradient accumulation over micro-batches): AccumulateGrad adds on the main stream, so the layer must not go
+    to the side stream; the sum equals two plain backward passes"""
+    from sparse2dense_amd import dense2d as D, side
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    conv = D.Conv3x3(64, 64, 3, 1, 1).to(dev)
+    x = torch.randn(2, 64, 24, 24, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+
+    def two_passes():
+        conv.weight.grad = conv.bias.grad = None
+        for _ in range(2):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                conv(x).float().square().sum().backward()
+        torch.cuda.synchronize()
+        return conv.weight.grad.clone(), conv.bias.grad.clone()
+    ref = two_passes()
+    side.enable("1")
+    side.stats.update(side=0, plain=0)
+    try:
+        got = two_passes()
+        assert side.stats["side"] == 1 and side.stats["plain"] == 1, side.stats
+    finally:
+        side.enable(False)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
