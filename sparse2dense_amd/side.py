@@ -19,7 +19,7 @@ Protocol (one side stream per device):
     without launching anything, so no main-stream kernel touches it before the join.  Every other case (accumulation
     into an existing `.grad`, post-accumulate-grad hooks = the data-parallel buckets, graph capture, the profiling pass of
     bench.py, double backward) takes the plain path: `fn()` on the current stream.
-  * the join: the first `run` of a backward queues an engine callback that makes the stream `backward()` was called on
+  * the join: every `run` queues an engine callback that makes the stream `backward()` was called on
     wait for the side stream; `join()` does the same explicitly (train_step / solver call it before reading gradients).
 """
 import collections
@@ -40,7 +40,6 @@ MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "1"))
 
 _streams = {}    # device index -> torch.cuda.Stream
 _pending = {}    # device index -> True while side work has been launched since the last join
-_cb_queued = {}  # device index -> True while a join callback is queued on the running backward
 _events = {}     # device index -> ring of reusable events
 _keep = {}       # device index -> deque of (event recorded on the side stream behind the work, tensors it reads)
 stats = {"side": 0, "plain": 0}
@@ -97,8 +96,6 @@ def join(device=None):
             torch.cuda.current_stream(dev).wait_stream(_streams[dev])
             _pending[dev] = False
             _keep[dev].clear()   # everything enqueued on this stream from here on is ordered behind the side work
-    for dev in list(_cb_queued):
-        _cb_queued[dev] = False
 
 
 def run(weight, fn, *inputs, kind="dense"):
@@ -134,8 +131,8 @@ def run(weight, fn, *inputs, kind="dense"):
     while len(keep) > 1 and keep[0][0].query():
         keep.popleft()
     _pending[dev] = True
-    if not _cb_queued.get(dev):
-        _cb_queued[dev] = True
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
+    # one callback per call, not one per backward: a flag "already queued" would go stale when a backward pass dies before its
+    # callbacks run, and every later pass would go without its join; a join with nothing pending costs a dictionary walk
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
     stats["side"] += 1
     return out
