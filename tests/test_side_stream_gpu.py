@@ -1,4 +1,5 @@
-"""Weight gradients on a second HIP stream (sparse2dense_amd/side.py, S2D_WGRAD_STREAM): the same kernels on the same operands in a
+"""Weight gradients on a second HIP stream (sparse2dense_amd/side.py, S2D_WGRAD_STREAM) and the PCR branch on a third
+(necks._pcr_side_stream, S2D_PCR_STREAM): the same kernels on the same operands in a
 different launch order, so a training run must not depend on the mode - bit-identical losses and parameters - and every gradient
 produced on the side stream must be the tensor autograd adopted as `.grad` (a clone would be a main-stream launch before the join)."""
 import pytest
@@ -7,12 +8,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(mode, steps=5, n_points=12000):
+def _run(mode, steps=5, n_points=12000, pcr_stream="0"):
+    import os
     from sparse2dense_amd import dense2d, hip_ops, side, waymo_configs
     from sparse2dense_amd.data import SyntheticFrames
     from sparse2dense_amd.registry import build_detector
     from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
     from sparse2dense_amd.train_step import backward_and_step
+    old_pcr = os.environ.get("S2D_PCR_STREAM")
+    os.environ["S2D_PCR_STREAM"] = pcr_stream   # necks.S2D_RPN: the PCR branch on its own stream (forward and, through autograd, backward)
     side.enable(mode)
     side.CHECK = True
     side._handed.clear()
@@ -50,6 +54,10 @@ def _run(mode, steps=5, n_points=12000):
     finally:
         side.enable(False)
         side.CHECK = False
+        if old_pcr is None:
+            os.environ.pop("S2D_PCR_STREAM", None)
+        else:
+            os.environ["S2D_PCR_STREAM"] = old_pcr
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
     return losses, final, grads, adopted, stats
@@ -58,8 +66,11 @@ def _run(mode, steps=5, n_points=12000):
 def test_training_run_is_independent_of_the_weight_gradient_stream():
     ref_losses, ref_final, ref_grads, _, ref_stats = _run("0")
     assert ref_stats["side"] == 0
-    for mode in ("dense", "sparse", "1"):
-        losses, final, grads, adopted, stats = _run(mode)
+    for mode, pcr in (("dense", "0"), ("sparse", "1"), ("1", "1"), ("0", "1")):   # also: the PCR branch on its own stream
+        losses, final, grads, adopted, stats = _run(mode, pcr_stream=pcr)
+        if mode == "0":
+            assert stats["side"] == 0 and losses == ref_losses and torch.equal(final, ref_final), (mode, pcr)
+            continue
         assert stats["side"] > 0, (mode, stats)                       # the side stream was used ...
         assert all(ok and n > 0 for ok, n in adopted), (mode, adopted, stats)   # ... and autograd adopted every gradient it produced
         assert losses == ref_losses, (mode, losses, ref_losses)
