@@ -728,7 +728,12 @@ __global__ __launch_bounds__(256) void spconv_wgrad_s16_coop128(const __bf16 *__
     int tail = 0, nbase = r_begin;
     auto load_idx = [&](int base) -> int { return base + lane < r_end ? nk[min(base + lane, n_out - 1)] : -1; };
     int jp0 = load_idx(nbase), jp1 = load_idx(nbase + 64);
-    if (lane == 0) ring[0] = make_int2(0, 0);
+    // the clamp target of an empty ring.  The ring is shared by the four waves, so this store must be ordered before ANY wave's first
+    // top_up: a wave that starts a microsecond late (a second stream's kernel competing for the CU's wave slots - side.py) used to
+    // put (0, 0) over the first real pair between an early wave's top_up and its first gather: one pair of one (offset, split)
+    // replaced by rows (0, 0), found as an intermittent last-digit difference of conv4's weight gradients (r04 stress run)
+    if (t == 0) ring[0] = make_int2(0, 0);
+    __syncthreads();
     auto top_up = [&](int need) {   // every wave appends the same pairs to the same slots
         while (tail < need && nbase < r_end) {
             const int j_l = jp0;

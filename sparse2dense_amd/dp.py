@@ -134,6 +134,8 @@ class GradBuckets:
             self._next += 1
 
     def _launch(self, b):
+        from . import side
+        side.join()   # gradients produced on the weight-gradient stream (side.py): this stream waits for them before it copies any
         src, dst = [], []
         for p, v in zip(b["params"], b["views"]):
             if p.grad is None:

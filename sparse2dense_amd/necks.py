@@ -151,12 +151,14 @@ _PCR_STREAMS = {}
 
 
 def _pcr_side_stream(x):
-    """second stream for the PCR branch, one per device (default; S2D_PCR_STREAM=0 runs it in line); None = in line.  r03 (B=4 S2D
-    student step, parity tests green in both modes): 23.7 / 23.7 ms in line, 23.8 / 23.3 ms on its own stream - within the noise of
-    separate runs.  r04, in-process A/B with tools/ab_step.py (blocks of 40 steps, +-0.03 ms): 20.05 -> 19.78 ms - the branch's HBM-bound
-    streams run beside the trunk's matrix-core convs and their batch-norm chains in both passes."""
+    """second stream for the PCR branch (S2D_PCR_STREAM=1), one per device; None = run it in line (default).  r03 (B=4 S2D student step):
+    23.7 / 23.7 ms in line, 23.8 / 23.3 ms on its own stream - within the noise of separate runs.  r04, in-process A/B with
+    tools/ab_step.py (blocks of 40 steps, +-0.03 ms): 20.05 -> 19.78 ms - the branch's HBM-bound streams run beside the trunk's
+    matrix-core convs in both passes.  NOT the default: a stress run (tools/side_stress.py: 4-step training runs compared bit for bit
+    with the in-line run) showed one run in ~25 whose backbone gradients differed at step 3 with the branch on its own stream - an
+    unordered access somewhere in the branch's backward that has not been found; 1.3 % is not worth a wrong gradient."""
     import os
-    if os.environ.get("S2D_PCR_STREAM", "1") == "0" or not x.is_cuda or torch.cuda.is_current_stream_capturing():
+    if os.environ.get("S2D_PCR_STREAM", "0") != "1" or not x.is_cuda or torch.cuda.is_current_stream_capturing():
         return None
     st = _PCR_STREAMS.get(x.device.index)
     if st is None:
@@ -370,7 +372,7 @@ class S2D_RPN(RPN):
             if side is None:
                 gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4 = self._pcr_head(x, F_S_b)
             else:
-                # the PCR branch (HBM-bound streaming kernels over 0.4-0.7 GB volumes) runs on a second stream beside the
+                # S2D_PCR_STREAM=1: the PCR branch (HBM-bound streaming kernels over 0.4-0.7 GB volumes) runs on a second stream beside the
                 # trunk / CenterHead (matrix-core convs) - forward here, and in the backward too: autograd replays every node on the stream
                 # of its forward.  The branch joins the main stream after the trunk; what it reads from the main stream is marked.
                 cur = torch.cuda.current_stream(x.device)

@@ -16,9 +16,11 @@ Protocol (one side stream per device):
     place on the main stream (it does that with a buffered gradient nobody else references - e.g. the gradient of a
     residual add, which is both the `dy` of the branch's last conv and the buffered gradient of the block input).
   * the returned gradient is handed to autograd unchanged.  With `weight.grad is None` AccumulateGrad adopts the tensor
-    without launching anything, so no main-stream kernel touches it before the join.  Every other case (accumulation
-    into an existing `.grad`, post-accumulate-grad hooks = the data-parallel buckets, graph capture, the profiling pass of
-    bench.py, double backward) takes the plain path: `fn()` on the current stream.
+    without launching anything, so no main-stream kernel touches it before the join.  The data-parallel buckets
+    (dp.GradBuckets) copy gradients into their flat buffers when a bucket is complete: `_launch` joins first (a few joins per
+    backward, each waiting for the weight gradients enqueued so far).  Every other case (accumulation into an existing
+    `.grad`, foreign hooks, graph capture, the profiling pass of bench.py, double backward) takes the plain path: `fn()` on
+    the current stream.
   * the join: every `run` queues an engine callback that makes the stream `backward()` was called on
     wait for the side stream; `join()` does the same explicitly (train_step / solver call it before reading gradients).
 """
@@ -81,8 +83,13 @@ def _event(dev):
 def usable(weight, kind="dense"):
     if kind not in MODE or not weight.is_cuda or weight.grad is not None:
         return False
-    if getattr(weight, "_post_accumulate_grad_hooks", None) or getattr(weight, "_backward_hooks", None):
+    if getattr(weight, "_backward_hooks", None):
         return False
+    hooks = getattr(weight, "_post_accumulate_grad_hooks", None)
+    if hooks:   # the data-parallel buckets' hooks only count arrivals; dp.GradBuckets._launch joins before it copies gradients
+        from . import dp
+        if len(hooks) != 1 or id(weight) not in dp._BUCKETERS:
+            return False
     if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():   # double backward / capture
         return False
     from . import hip_ops as H
