@@ -568,13 +568,14 @@ class _SmallConv3x3Fn(torch.autograd.Function):
             dx = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
             check(lib.s2d_smallconv3x3_dgrad(_ptr(dyf), _ptr(wf), n, h, w, cin, cout, _ptr(dx), _stream()), "s2d_smallconv3x3_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dwf = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xb.device)
-            dbf = torch.empty((cout,), dtype=torch.float32, device=xb.device)
-            ws = _ws(lib.s2d_smallconv3x3_wgrad_workspace_bytes(cin, cout), xb.device)
-            check(lib.s2d_smallconv3x3_wgrad(_ptr(xb), _ptr(dyf), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(), _stream()),
-                  "s2d_smallconv3x3_wgrad")
-            dw = dwf.to(weight.dtype)
-            db = dbf if ctx.has_bias else None
+            def wgrad():
+                dwf = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=xb.device)
+                dbf = torch.empty((cout,), dtype=torch.float32, device=xb.device)
+                ws = _ws(lib.s2d_smallconv3x3_wgrad_workspace_bytes(cin, cout), xb.device)
+                check(lib.s2d_smallconv3x3_wgrad(_ptr(xb), _ptr(dyf), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(), _stream()),
+                      "s2d_smallconv3x3_wgrad")
+                return dwf.to(weight.dtype), (dbf if ctx.has_bias else None)
+            dw, db = _side.run(weight, wgrad, xb, dyf, kind="aux")
         return dx, dw, db
 
 
@@ -639,8 +640,8 @@ class _Conv2x2S2Fn(torch.autograd.Function):
             packed = _pack_matrix_1x1(weight, ("conv2x2s2", "dgrad"), lambda: weight.permute(2, 3, 1, 0).reshape(4 * cin, cout))
             dx = _depth_to_space(conv1x1_nhwc(dyb, packed, None, cout, 4 * cin), cin)
         if ctx.needs_input_grad[1]:
-            dwf = _wgrad_1x1(_space_to_depth(xb), dyb, 4 * cin, cout)   # [cout, (py, px, ci)]
-            dw = dwf.reshape(cout, 2, 2, cin).permute(0, 3, 1, 2).to(weight.dtype)
+            dw = _side.run(weight, lambda: _wgrad_1x1(_space_to_depth(xb), dyb, 4 * cin, cout).reshape(cout, 2, 2, cin).permute(0, 3, 1, 2)
+                           .to(weight.dtype), xb, dyb, kind="aux")   # _wgrad_1x1: [cout, (py, px, ci)]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _channel_sums(dyb)
         return dx, dw, db, None
@@ -698,13 +699,14 @@ class _DwConv7Fn(torch.autograd.Function):
             check(lib.s2d_dwconv7_nhwc_bf16(_ptr(dyb), _ptr(weight.detach().float().contiguous()), None, n, h, w, c, 1, _ptr(dx),
                                             _stream()), "s2d_dwconv7_nhwc_bf16 (data gradient)")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dwf = torch.empty((c, 1, 7, 7), dtype=torch.float32, device=xb.device)
-            dbf = torch.empty((c,), dtype=torch.float32, device=xb.device) if ctx.has_bias else None
-            ws = _ws(lib.s2d_dwconv7_wgrad_workspace_bytes(n, h, w, c), xb.device)
-            check(lib.s2d_dwconv7_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), n, h, w, c, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(),
-                                                  _stream()), "s2d_dwconv7_wgrad_nhwc_bf16")
-            dw = dwf.to(weight.dtype)
-            db = dbf
+            def wgrad():
+                dwf = torch.empty((c, 1, 7, 7), dtype=torch.float32, device=xb.device)
+                dbf = torch.empty((c,), dtype=torch.float32, device=xb.device) if ctx.has_bias else None
+                ws = _ws(lib.s2d_dwconv7_wgrad_workspace_bytes(n, h, w, c), xb.device)
+                check(lib.s2d_dwconv7_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), n, h, w, c, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(),
+                                                      _stream()), "s2d_dwconv7_wgrad_nhwc_bf16")
+                return dwf.to(weight.dtype), dbf
+            dw, db = _side.run(weight, wgrad, xb, dyb, kind="aux")
         return dx, dw, db
 
 
@@ -997,9 +999,9 @@ class _ConvT2x2S2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             packed = _pack_matrix_1x1(weight, ("convt2x2s2", "dgrad"), lambda: weight.permute(2, 3, 1, 0).reshape(4 * cout, cin), transpose=True)
             dx = conv1x1_nhwc(dys, packed, None, 4 * cout, cin)
-        if ctx.needs_input_grad[1]:
-            dwf = _wgrad_1x1(xb, dys, cin, 4 * cout)   # [(py, px, co), ci]
-            dw = dwf.reshape(2, 2, cout, cin).permute(3, 2, 0, 1).to(weight.dtype)
+        if ctx.needs_input_grad[1]:   # (the permuted view is re-laid to the parameter's layout on the side stream: side.run)
+            dw = _side.run(weight, lambda: _wgrad_1x1(xb, dys, cin, 4 * cout).reshape(2, 2, cout, cin).permute(3, 2, 0, 1).to(weight.dtype),
+                           xb, dys, kind="aux")   # _wgrad_1x1: [(py, px, co), ci]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _channel_sums(dyb)
         return dx, dw, db
@@ -1126,9 +1128,11 @@ class _ConvT4x4S2Fn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv4x4s2(dyb, weight)
-        if ctx.needs_input_grad[1]:
-            dw = conv_s2_wgrad(xb, dyb, 4).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        want_db = bool(ctx.has_bias and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[1]:   # weight and bias gradient: off the chain (side.py)
+            dw, db = _side.run(weight, lambda: (conv_s2_wgrad(xb, dyb, 4).to(weight.dtype), _channel_sums(dyb) if want_db else None), xb, dyb,
+                               kind="aux")
+        elif want_db:
             db = _channel_sums(dyb)
         return dx, dw, db, None
 

@@ -29,13 +29,17 @@ import os
 
 import torch
 
+KINDS = ("dense", "sparse", "aux")
+
+
 def _parse(v):
-    """"1" / "all": every wired layer kind; a comma list of kinds (dense, sparse) for A/B runs; anything else: off.  (The PCR head's
-    up-samplers were tried too: time-neutral - their weight gradients are chip-filling streams - and not wired.)"""
+    """"1" / "all": every wired layer kind; a comma list of kinds for A/B runs; anything else: off.  Kinds: dense (3x3 / 1x1 NHWC convs),
+    sparse (sparse convs), aux (the small ones: depth-wise 7x7, CenterHead output convs, 2x2 / 4x4 stride-2 forms, sparse-conv bias sums).
+    (The PCR head's up-samplers were tried too: time-neutral - their weight gradients are chip-filling streams - and not wired.)"""
     v = (v or "0").strip().lower()
     if v in ("1", "all"):
-        return {"dense", "sparse"}
-    return {k for k in v.split(",") if k in ("dense", "sparse")}
+        return set(KINDS)
+    return {k for k in v.split(",") if k in KINDS}
 
 
 MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "1"))

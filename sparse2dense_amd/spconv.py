@@ -161,11 +161,16 @@ class _SparseConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:   # off the chain to the previous layer: second stream when enabled (side.py)
                 from . import side
 
-                def wgrad():
+                want_db = bool(ctx.has_bias and ctx.needs_input_grad[2])
+                db_aside = want_db and "aux" in side.MODE
+
+                def wgrad():   # (+ the bias gradient: a pass over dout nobody on the chain waits for)
                     dwf = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
-                    return dwf[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype)
-                dw = side.run(weight, wgrad, feat, dout, rb.nbr_out, kind="sparse")
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+                    return dwf[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype), (H.col_sums_bf16(dout) if db_aside else None)
+                dw, db = side.run(weight, wgrad, feat, dout, rb.nbr_out, kind="sparse")
+                if want_db and not db_aside:
+                    db = H.col_sums_bf16(dout)
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
                 db = H.col_sums_bf16(dout)
             return dfeat, dw, db, None, None
         dout = dout.contiguous()

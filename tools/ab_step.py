@@ -3,7 +3,7 @@ clock / allocator differences between processes (+-3 % between two `bench.py` ru
 
     python tools/ab_step.py --variants "base" "S2D_PCR_STREAM=1" "side=0" --blocks 6 --steps 20
 
-A variant is a comma list of NAME=VALUE environment settings read at run time by the package (e.g. S2D_PCR_STREAM) and of
+A variant is a ';'-separated list of NAME=VALUE environment settings read at run time by the package (e.g. S2D_PCR_STREAM) and of
 side=<mode> (sparse2dense_amd.side.enable); "base" = nothing set.  Prints ms/step per block and the per-variant median."""
 import argparse
 import os
@@ -42,7 +42,7 @@ def main():
         side.enable(default_side)
         if variant == "base":
             return
-        for item in variant.split(","):
+        for item in variant.split(";"):
             k, v = item.split("=", 1)
             if k == "side":
                 side.enable(v)

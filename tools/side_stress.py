@@ -1,6 +1,6 @@
 """Stress run of the multi-stream modes: 4-step training runs of the S2D student (12 k points) in every stream mode, per-step checksums of
 every parameter gradient compared BIT FOR BIT with the single-stream run; prints the first step and the tensors that differ.
-    python tools/side_stress.py 12        # 12 repetitions of (sparse | all weight gradients on the side stream | + PCR-branch stream)
+    python tools/side_stress.py 12 [mode:pcr,...]   # 12 repetitions of (sparse | all weight gradients on the side stream | + PCR-branch stream)
 r04 findings: `spconv_wgrad_s16_coop128` (shared pair ring initialised without a barrier: one run in ~8 had one conv4 weight gradient off
 in the last digits; fixed, 0 of 36 afterwards); S2D_PCR_STREAM=1: one run in ~25 with differing backbone gradients (left opt-in)."""
 import os, sys, torch
@@ -38,10 +38,11 @@ def run(mode, pcr, steps=4):
     side.enable(False)
     return sums, [n for n, _ in named] + ["loss"]
 
+COMBOS = [tuple(c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [("sparse", "0"), ("1", "0"), ("sparse", "1")]
 ref, names = run("0", "0")
 fails = 0
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-    for mode, pcr in (("sparse", "0"), ("1", "0"), ("sparse", "1")):
+    for mode, pcr in COMBOS:
         got, _ = run(mode, pcr)
         for s, (a, b) in enumerate(zip(got, ref)):
             bad = [names[i] for i, (x, y) in enumerate(zip(a, b)) if x != y]
