@@ -11,7 +11,7 @@ Protocol (one side stream per device):
   * `run(weight, fn, *inputs)` inside an autograd backward: the side stream waits for an event recorded on the current
     stream (everything `fn` reads has been enqueued there), `fn()` runs with the side stream current (its launches, its
     workspace - `_ws` is keyed by stream - and its output allocations belong to that stream).  A reference to every input
-    is kept until the side stream has passed an event recorded behind `fn` (or until the join): the caching allocator
+    is kept until the join: the caching allocator
     cannot hand their memory out meanwhile, and the autograd engine cannot accumulate a later gradient INTO one of them in
     place on the main stream (it does that with a buffered gradient nobody else references - e.g. the gradient of a
     residual add, which is both the `dy` of the branch's last conv and the buffered gradient of the block input).
@@ -21,10 +21,9 @@ Protocol (one side stream per device):
     backward, each waiting for the weight gradients enqueued so far).  Every other case (accumulation into an existing
     `.grad`, foreign hooks, graph capture, the profiling pass of bench.py, double backward) takes the plain path: `fn()` on
     the current stream.
-  * the join: every `run` queues an engine callback that makes the stream `backward()` was called on
+  * the join: the first `run` of a backward pass queues an engine callback that makes the stream `backward()` was called on
     wait for the side stream; `join()` does the same explicitly (train_step / solver call it before reading gradients).
 """
-import collections
 import os
 
 import torch
@@ -46,8 +45,9 @@ MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "1"))
 
 _streams = {}    # device index -> torch.cuda.Stream
 _pending = {}    # device index -> True while side work has been launched since the last join
+_queued_for = {}  # device index -> graph-task id of the backward pass that has its join callback queued
 _events = {}     # device index -> ring of reusable events
-_keep = {}       # device index -> deque of (event recorded on the side stream behind the work, tensors it reads)
+_keep = {}       # device index -> list of the tensors the side stream's work since the last join reads
 stats = {"side": 0, "plain": 0}
 CHECK = os.environ.get("S2D_WGRAD_STREAM_CHECK", "0") == "1"   # tests: remember what was handed to autograd
 _handed = []
@@ -73,7 +73,7 @@ def _side(dev):
         s = torch.cuda.Stream(device=dev)
         _streams[dev] = s
         _events[dev] = [[torch.cuda.Event() for _ in range(512)], 0]
-        _keep[dev] = collections.deque()
+        _keep[dev] = []
     return s
 
 
@@ -120,7 +120,10 @@ def run(weight, fn, *inputs, kind="dense"):
     ev = _event(dev)
     ev.record(cur)
     side.wait_event(ev)
-    with torch.cuda.stream(side):
+    # (host cost matters here - ~135 calls per backward on the thread that also launches the chain: set_stream pairs instead of the
+    # `torch.cuda.stream` context manager, 0.9 vs 5.7 us; no completion event per call, see the keep list below)
+    torch.cuda.set_stream(side)
+    try:
         out = fn()
         # AccumulateGrad adopts a gradient only if it obeys the parameter's layout; otherwise it CLONES it - a main-stream launch
         # before the join (and a copy kernel per layer and step on the chain: channels_last conv weights).  The first returned
@@ -130,20 +133,20 @@ def run(weight, fn, *inputs, kind="dense"):
             dw = torch.empty_like(weight).copy_(dw)
             out = (dw,) + tuple(out[1:]) if isinstance(out, (tuple, list)) else dw
             stats["relaid"] = stats.get("relaid", 0) + 1
-        done = _event(dev)
-        done.record(side)
+    finally:
+        torch.cuda.set_stream(cur)
     if dw is not None and dw.shape != weight.shape:   # cannot be adopted: the main stream waits here
-        cur.wait_event(done)
+        cur.wait_stream(side)
         stats["waited"] = stats.get("waited", 0) + 1
     elif CHECK:
         _handed.append((weight, None if dw is None else dw.data_ptr()))
-    keep = _keep[dev]
-    keep.append((done, inputs))
-    while len(keep) > 1 and keep[0][0].query():
-        keep.popleft()
+    _keep[dev].append(inputs)   # until the join (a few GB of gradient tensors at the benchmark's size; HBM is 288 GB)
     _pending[dev] = True
-    # one callback per call, not one per backward: a flag "already queued" would go stale when a backward pass dies before its
-    # callbacks run, and every later pass would go without its join; a join with nothing pending costs a dictionary walk
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
+    # one join callback per backward pass, keyed on the engine's graph-task id (a flag "already queued" would go stale when a pass dies
+    # before its callbacks run, and every later pass would go without its join)
+    gid = torch._C._current_graph_task_id()
+    if _queued_for.get(dev) != gid or gid < 0:
+        _queued_for[dev] = gid
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
     stats["side"] += 1
     return out

@@ -46,6 +46,15 @@ def main():
             gaps[r["Kernel_Name"]][0] += g
             gaps[r["Kernel_Name"]][1] += 1
         end = max(end, int(r["End_Timestamp"]))
+    # streams (r04: weight gradients and the data pipeline run on their own HIP streams = hardware queues): kernel time per queue
+    if seg and "Queue_Id" in seg[0]:
+        perq = collections.defaultdict(lambda: [0, 0])
+        for r in seg:
+            perq[r["Queue_Id"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            perq[r["Queue_Id"]][1] += 1
+        print("# kernel time per hardware queue (the sum exceeds the wall time when streams overlap): " +
+              ", ".join(f"queue {q}: {v[0] / 1e6:.3f} ms in {v[1]} kernels" for q, v in sorted(perq.items(), key=lambda kv: -kv[1][0])))
+        print(f"# device busy (union of the kernel intervals) {(t1 - t0 - idle) / 1e6:.3f} ms of {(t1 - t0) / 1e6:.3f} ms")
     print(f"# GPU idle inside the step: {idle / 1e6:.3f} ms; largest contributors (gap before the kernel):")
     for n, (dur, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
         print(f"#   {dur / 1e3:8.1f} us over {c:4d} gaps   {n[:110]}")
