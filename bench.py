@@ -586,7 +586,7 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
     torch.set_num_threads(min(effective_cpu_count(), 16))
-    from sparse2dense_amd import dp
+    from sparse2dense_amd import dp, side
     rank, local, world = dp.init_distributed()
     if world != max(args.gpus, 1):   # a launcher that started a different number of ranks than asked for: refuse, do not mislabel
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
@@ -682,6 +682,8 @@ def main():
                        "data_pipeline": ("overlapped as in the reference's DataLoader workers: example k+1 (device voxelization, targets, rulebooks) is "
                                          "built on a second HIP stream by a loader thread while step k runs; one example per timed step"
                                          if prefetching else "example built inside its step on the main stream"),
+                       "streams": ("chain + data pipeline" if prefetching else "chain") +
+                                  (" + weight-gradient stream (sparse2dense_amd/side.py: " + ",".join(sorted(side.MODE)) + ")" if side.MODE else ""),
                        "loss": loss_value, "scene": stats},
             "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "voxelize": voxelize, "cpu_baseline": base,
         }

@@ -134,17 +134,28 @@ class GradBuckets:
             self._next += 1
 
     def _launch(self, b):
+        # Gradients produced on the weight-gradient stream (side.py) are complete only in THAT stream's order.  The bucket's copies and
+        # its all-reduce launch are issued from the side stream (which first waits for an event of the current stream: the gradients the
+        # chain produced itself), so the chain never waits for the side stream's backlog; `finish()` waits for the collective as before.
         from . import side
-        side.join()   # gradients produced on the weight-gradient stream (side.py): this stream waits for them before it copies any
-        src, dst = [], []
-        for p, v in zip(b["params"], b["views"]):
-            if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad); dst.append(v)
-        if src:
-            torch._foreach_copy_(dst, src)
-        b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)   # c10d: ordered after the copies, runs on its own stream
+        dev = b["flat"].device.index if b["flat"].is_cuda else None
+        st = side.stream_after(dev)
+        cur = torch.cuda.current_stream(dev) if st is not None else None
+        if st is not None:
+            torch.cuda.set_stream(st)
+        try:
+            src, dst = [], []
+            for p, v in zip(b["params"], b["views"]):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    src.append(p.grad); dst.append(v)
+            if src:
+                torch._foreach_copy_(dst, src)
+            b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)   # c10d: ordered after the copies, runs on its own stream
+        finally:
+            if st is not None:
+                torch.cuda.set_stream(cur)
         b["launched"] = True
         self.launch_log.append(b["index"])
 
