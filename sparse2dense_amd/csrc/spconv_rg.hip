@@ -401,16 +401,23 @@ static int rg_cus() {
 // rows per workgroup: the fewest whole rounds of one workgroup per CU that cover the tiles, then the tile count per workgroup
 // that spreads them evenly (a 47 890-row stage = 2 994 tiles runs as 250 workgroups of 12 tiles, not 187 of 16)
 RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout) {
-    (void)kvol; (void)cin;
+    (void)kvol;
     const int64_t tiles = ceil_div(n_out, 16);
     // measured on the bench scene (tools/spconv_kernel_bench.py, r03): two waves per SIMD with two tiles each win or tie at every
     // shape with 128 input or output channels (128->128: 51 us vs 54 with one wave of three tiles per SIMD; 64->128: 26 vs 29;
     // 128->64: 55-61 vs 63)
     int mi = 2, waves = 8, tpb = 0;
+    // r04 (end of the round): the <128, 128, MI = 2, WAVES = 8> instantiation computes the SECOND tile slot of a wave wrong - one third of
+    // the rows of a 47 890-row launch, every run, against the float reference (tools/side_stress.py at the benchmark's size led here: NaN
+    // gradients in the whole backbone).  It only shows above 32 768 output rows (more than 8 tiles per workgroup), which no test had: the
+    // benchmark's conv4 stage and extra_conv ran it since r03.  Every other instantiation checks out at the benchmark's shapes
+    // (tests/test_s16_gpu.py::test_rg_kernel_at_benchmark_row_counts); the cause inside the 2 x 8 instantiation has not been found, so
+    // 128 -> 128 runs one wave per SIMD with up to four tiles (66-68 us against 63 us for the wrong answer, Python-timed).
+    if (cin == 128 && cout == 128) { mi = 4; waves = 4; }
     if (const char *ov = getenv("S2D_RG_PLAN")) {   // tuning hook: "mi,waves[,tiles_per_block]"
         int a = 0, b = 0, c = 0;
         const int got = sscanf(ov, "%d,%d,%d", &a, &b, &c);
-        if (got >= 2 && a >= 1 && a <= 4 && (b == 4 || b == 8) && !(b == 8 && a > 2 && cout > 64)) {
+        if (got >= 2 && a >= 1 && a <= 4 && (b == 4 || b == 8) && !(b == 8 && a > 2 && cout > 64) && !(b == 8 && a == 2 && cin == 128 && cout == 128)) {
             mi = a; waves = b;
             if (got == 3 && c >= 1 && c <= a * b) tpb = c;
         }

@@ -202,3 +202,39 @@ def test_sparse_conv_bn_pair_with_epilogue_statistics_matches_the_separate_pass(
         assert (res[0][2] - res[1][2]).abs().max() <= 1e-6 * res[1][2].abs().max() + 1e-8
     finally:
         H.SPARSE_COMPUTE_DTYPE = old
+
+
+@pytest.mark.parametrize("cin,cout,n_in,n_out,kvol,p_empty", [
+    (128, 128, 47890, 47890, 27, 0.44),   # conv4 SubM stage of the 4 x 150 k-point benchmark scene
+    (128, 128, 47890, 38277, 3, 0.4),     # extra_conv
+    (128, 128, 3000, 70000, 27, 0.4),     # more than one round of workgroups
+    (64, 128, 126079, 47890, 27, 0.7),    # conv3 -> conv4
+    (128, 64, 47890, 126079, 27, 0.7),    # its data gradient
+    (64, 64, 126079, 126079, 27, 0.5),    # conv3 SubM stage (LDS-staged kernel)
+])
+def test_rg_kernel_at_benchmark_row_counts(cin, cout, n_in, n_out, kvol, p_empty):
+    """The register-gather kernel deals more than one 16-row tile to a wave only above 32 768 output rows - the benchmark's conv4 /
+    extra_conv row counts, which the small-shape tests above never reach.  r04: the <128,128,MI=2,WAVES=8> instantiation got the second
+    tile of every wave wrong there (a third of the rows); rg_plan no longer selects it.  fp32 reference on the device, every row."""
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(cin + cout)
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    w = torch.randn(kvol, cin, cout, device=DEV) * 0.05
+    nbr = _random_map(kvol, n_in, n_out, p_empty=p_empty, seed=1)
+    ref = torch.zeros(n_out, cout, device=DEV, dtype=torch.float32)
+    fr, wr = feat.float(), w.to(torch.bfloat16).float()
+    for k in range(kvol):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        ref[o] += fr[nbr[k][o].long()] @ wr[k]
+    for with_stats in (False, True):
+        poison = torch.full((n_out, cout), float("nan"), device=DEV, dtype=torch.bfloat16)   # an unwritten row must not look written
+        del poison
+        packed, kv, ci, co = H.spconv_s16_pack(w, n_out)
+        r = H.spconv_s16_run(feat, packed, kv, ci, co, None, nbr, n_out, None, "fwd", bn_stats=with_stats)
+        out = (r[0] if with_stats else r).float()
+        bad = ((out - ref).abs() > 1.2e-2 * ref.abs().max()).any(1) | (~torch.isfinite(out)).any(1)
+        assert int(bad.sum()) == 0, (with_stats, int(bad.sum()), bad.nonzero().flatten()[:8].tolist())
+        if with_stats:   # the statistics rows of the epilogue against the stored output
+            part = r[1].double().sum(0)
+            o64 = r[0].double()
+            assert torch.allclose(part[0], o64.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(part[1], (o64 * o64).sum(0), rtol=1e-4, atol=1e-2)
