@@ -558,3 +558,22 @@ def test_conv_transpose_2x2_stride2_vs_cpu_float64(n, cin, cout, h, w, bias):
         err = float((a.detach().double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
         assert err <= tol, (name, err)
     assert set(m.state_dict()) == set(ref.state_dict())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,pad", [(4, 128, 128, 188, 188, 1), (4, 256, 256, 94, 94, 1), (4, 64, 64, 188, 188, 1)])
+def test_conv3x3_wgrad_at_bev_size(n, cin, cout, h, w, pad):
+    """the weight gradient at the benchmark's BEV maps (1 105 tiles, split-K over the whole map) against a float64 contraction on the device:
+    per tap dW[:, :, ky, kx] = dy^T x_shifted (the small-shape test above stops at 47 x 47)"""
+    from sparse2dense_amd import dense2d as D
+    x, wt, _ = _mk(n, cin, cout, h, w, seed=9)
+    dy = torch.randn(n, cout, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dw, db = D.conv3x3_wgrad(x, dy, pad, want_db=True)
+    xp = F.pad(x.float(), (1, 1, 1, 1)).permute(0, 2, 3, 1)            # [n, h+2, w+2, cin]
+    dyr = dy.float().permute(0, 2, 3, 1).reshape(-1, cout).double()   # [n*h*w, cout]
+    ref = torch.empty(cout, cin, 3, 3, device="cuda", dtype=torch.float64)
+    for ky in range(3):
+        for kx in range(3):
+            ref[:, :, ky, kx] = dyr.t() @ xp[:, ky:ky + h, kx:kx + w, :].reshape(-1, cin).double()
+    assert torch.isfinite(dw).all()
+    assert (dw.double() - ref).abs().max() <= 1e-3 * ref.abs().max()
+    assert (db.double() - dyr.sum(0)).abs().max() <= 1e-3 * dyr.sum(0).abs().max()

@@ -238,3 +238,24 @@ def test_rg_kernel_at_benchmark_row_counts(cin, cout, n_in, n_out, kvol, p_empty
             part = r[1].double().sum(0)
             o64 = r[0].double()
             assert torch.allclose(part[0], o64.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(part[1], (o64 * o64).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cin,cout,n_in,n_out,kvol,p_empty", [
+    (128, 128, 47890, 47890, 27, 0.44), (64, 64, 126079, 126079, 27, 0.5), (64, 128, 126079, 47890, 27, 0.7),
+    (32, 32, 265026, 265026, 27, 0.5), (16, 16, 288892, 288892, 27, 0.75)])
+def test_sparse_weight_gradient_at_benchmark_row_counts(cin, cout, n_in, n_out, kvol, p_empty):
+    """dW of the sparse convs at the row counts of the 4 x 150 k-point benchmark scene (the small-shape test above stops at 3 100 rows):
+    split plans, ring wrap-around and the workgroup-cooperative 128-channel kernel at their real sizes, against fp32 matmuls on the device"""
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(5)
+    feat = torch.randn(n_in, cin, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(n_out, cout, device=DEV).to(torch.bfloat16)
+    nbr = _random_map(kvol, n_in, n_out, p_empty=p_empty, seed=2)
+    dw = H.spconv_s16_wgrad(feat, dout, nbr, kvol)
+    ref = torch.zeros(kvol, cin, cout, device=DEV, dtype=torch.float64)
+    for k in range(kvol):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        ref[k] = (feat[nbr[k][o].long()].double().t() @ dout[o].double())
+    assert torch.isfinite(dw).all()
+    assert (dw.double() - ref).abs().max() <= 2e-3 * ref.abs().max(), float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert torch.equal(dw, H.spconv_s16_wgrad(feat, dout, nbr, kvol))   # fixed-order split reduction: bit-reproducible
