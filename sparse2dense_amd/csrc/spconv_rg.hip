@@ -23,8 +23,9 @@
 //     step s -> ds_write in step s+1 -> read by every wave in step s+2; two LDS stages, one barrier per step.
 //   * no conditional memory operation and no peeled tail: the step count is padded to even with phantom steps (indices -1,
 //     clamped slab), so hipcc's vmcnt bookkeeping sees one straight loop body and keeps every load class in flight.
-//   * the accumulators live in AGPRs and are updated by asm MFMAs ("+a"): with the builtin hipcc kept a second accumulator set
-//     and copied ~120 registers per loop iteration; scheduling barriers pin the ds_read / memory / MFMA interleave.
+//   * r03: the accumulators were updated by asm MFMAs ("+a") because the builtin made hipcc keep a second accumulator set and copy ~120
+//     registers per loop iteration.  End of r04: the asm form is wrong in one instantiation (RG_ASM_MFMA below) and the builtin is no
+//     longer slower; scheduling barriers pin the ds_read / memory / MFMA interleave either way.
 // The epilogue: bias, one bf16 rounding, 2*NJ-byte row stores, optional per-workgroup (sum, sum of squares) rows for the
 // BatchNorm1d that follows.
 #include "s2d_common.h"
@@ -38,6 +39,15 @@ typedef float f32x4r __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 
 constexpr int RG_KSTEP = 128;   // K elements per step
+#ifndef RG_ASM_MFMA
+// 0 (default since the end of r04): the compiler's MFMA builtin.  1: the r03 inline-asm MFMAs with the accumulator tied in place ("+a").  The asm form is WRONG
+// in the <128, 128, MI = 2, WAVES = 8> instantiation: the second tile of every wave comes out wrong above 32 768 output rows (DESIGN rule 31) - an inline asm
+// statement is opaque to hipcc's hazard recognizer, which therefore cannot keep a later write of an operand register (fragment reads, in-place refills) away from
+// an MFMA that is still reading it; the instantiation with the highest register pressure is where it bites.  With the builtin every instantiation is right at
+// the benchmark's row counts and no slower (ROCm 7.2's hipcc no longer copies the accumulator set per iteration, the reason r03 went to asm): 128 -> 128 at
+// 47 890 rows 43.9 us (asm: 45.7 us and wrong), 64 -> 128 26.1 (28.0), 128 -> 64 61.8 (63.6).
+#define RG_ASM_MFMA 0
+#endif
 #ifndef RG_BBURST
 #define RG_BBURST 1   // 1: all weight-slab pieces of a step are stored / re-requested in its first group (all 32 KiB in flight at once)
 #endif
@@ -267,7 +277,12 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
                     for (int n = 0; n < FG; ++n)
                         // in-place accumulate in the AGPR file, written as asm: with the builtin hipcc gave the MFMAs a second
                         // accumulator set (dst != src C) and copied ~120 registers back per loop iteration
+#if RG_ASM_MFMA
                         asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][(g % GPC) * FG + n]) : "v"(a[i][g / GPC]), "v"(b[g & 1][n]));
+#else
+                        acc[i][(g % GPC) * FG + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8r, a[i][g / GPC]), __builtin_bit_cast(bf16x8r, b[g & 1][n]),
+                                                                                               acc[i][(g % GPC) * FG + n], 0, 0, 0);
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -401,23 +416,16 @@ static int rg_cus() {
 // rows per workgroup: the fewest whole rounds of one workgroup per CU that cover the tiles, then the tile count per workgroup
 // that spreads them evenly (a 47 890-row stage = 2 994 tiles runs as 250 workgroups of 12 tiles, not 187 of 16)
 RgPlan rg_plan(int64_t n_out, int kvol, int cin, int cout) {
-    (void)kvol;
+    (void)kvol; (void)cin;
     const int64_t tiles = ceil_div(n_out, 16);
     // measured on the bench scene (tools/spconv_kernel_bench.py, r03): two waves per SIMD with two tiles each win or tie at every
     // shape with 128 input or output channels (128->128: 51 us vs 54 with one wave of three tiles per SIMD; 64->128: 26 vs 29;
     // 128->64: 55-61 vs 63)
     int mi = 2, waves = 8, tpb = 0;
-    // r04 (end of the round): the <128, 128, MI = 2, WAVES = 8> instantiation computes the SECOND tile slot of a wave wrong - one third of
-    // the rows of a 47 890-row launch, every run, against the float reference (tools/side_stress.py at the benchmark's size led here: NaN
-    // gradients in the whole backbone).  It only shows above 32 768 output rows (more than 8 tiles per workgroup), which no test had: the
-    // benchmark's conv4 stage and extra_conv ran it since r03.  Every other instantiation checks out at the benchmark's shapes
-    // (tests/test_s16_gpu.py::test_rg_kernel_at_benchmark_row_counts); the cause inside the 2 x 8 instantiation has not been found, so
-    // 128 -> 128 runs one wave per SIMD with up to four tiles (66-68 us against 63 us for the wrong answer, Python-timed).
-    if (cin == 128 && cout == 128) { mi = 4; waves = 4; }
     if (const char *ov = getenv("S2D_RG_PLAN")) {   // tuning hook: "mi,waves[,tiles_per_block]"
         int a = 0, b = 0, c = 0;
         const int got = sscanf(ov, "%d,%d,%d", &a, &b, &c);
-        if (got >= 2 && a >= 1 && a <= 4 && (b == 4 || b == 8) && !(b == 8 && a > 2 && cout > 64) && !(b == 8 && a == 2 && cin == 128 && cout == 128)) {
+        if (got >= 2 && a >= 1 && a <= 4 && (b == 4 || b == 8) && !(b == 8 && a > 2 && cout > 64)) {
             mi = a; waves = b;
             if (got == 3 && c >= 1 && c <= a * b) tpb = c;
         }
