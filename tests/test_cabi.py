@@ -77,3 +77,20 @@ def test_ops_fail_loudly_on_cpu_tensors():
     from sparse2dense_amd import hip_ops
     with pytest.raises(_lib.S2DError):
         hip_ops.voxelize(torch.zeros(10, 5), [.1, .1, .1], [0, 0, 0, 1, 1, 1], 5, 10)
+
+
+def test_no_kernel_issues_mfmas_through_inline_asm():
+    """DESIGN rule 31: an inline-asm MFMA is opaque to hipcc's hazard recognizer; the one kernel that used them (spconv_rg.hip, r03) computed wrong rows in its
+    highest-pressure instantiation.  The asm form survives only behind RG_ASM_MFMA (default 0) as the record of what was wrong."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sparse2dense_amd", "csrc")
+    hits = []
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        for i, line in enumerate(open(f), 1):
+            if re.search(r"asm[^;]*v_mfma", line):
+                hits.append((os.path.basename(f), i))
+    assert [h[0] for h in hits] in ([], ["spconv_rg.hip"]), hits
+    src = open(os.path.join(root, "spconv_rg.hip")).read()
+    assert re.search(r"#define RG_ASM_MFMA 0\b", src) and "#if RG_ASM_MFMA" in src

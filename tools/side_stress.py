@@ -2,7 +2,8 @@
 every parameter gradient compared BIT FOR BIT with the single-stream run; prints the first step and the tensors that differ.
     python tools/side_stress.py 12 [mode:pcr,...] [points] [frames]   # 12 repetitions of (sparse | all weight gradients on the side stream | + PCR-branch stream)
 r04 findings: `spconv_wgrad_s16_coop128` (shared pair ring initialised without a barrier: one run in ~8 had one conv4 weight gradient off
-in the last digits; fixed, 0 of 36 afterwards); S2D_PCR_STREAM=1: one run in ~25 with differing backbone gradients (left opt-in)."""
+in the last digits; fixed, 0 of 36 afterwards); S2D_PCR_STREAM=1: one run in ~25 with differing backbone gradients (left opt-in); and at the
+benchmark's size (`... 3 0:0,1:0 150000 4`) the single-stream run "differed" from itself: NaN gradients - the wrong `spconv_rg_kernel<128,128,2,8>` (DESIGN rule 31)."""
 import os, sys, torch
 sys.path.insert(0, ".")
 from sparse2dense_amd import dense2d, hip_ops, side, waymo_configs
