@@ -77,6 +77,12 @@ def parse():
     p.add_argument("--sparse-dtype", default=None, choices=["f32", "bf16", "s16"],
                    help="override for the sparse stack: bf16 = fp32 storage / bf16 MFMA inputs, s16 = bf16 storage (default with --dtype bf16)")
     p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
+    p.add_argument("--mode", default="auto", help="execution mode: auto = measure {HIP graphs | eager} x {loader thread | in-step} x {weight-gradient "
+                   "stream on | off} for a few steps each on this box and run the fastest (reported in step_breakdown); or graph|eager:loader|instep:KINDS[:KINDS forked inside the graph], "
+                   "e.g. graph:loader:sparse:dense,aux  eager:instep:0")
+    p.add_argument("--no-breakdown", action="store_true", help="skip the torch.profiler kernel-time pass of step_breakdown")
+    p.add_argument("--no-graph", action="store_true", help="launch the dense segment (neck + head + losses) kernel by kernel from Python "
+                   "instead of replaying it as two HIP graphs per step (sparse2dense_amd/graphed.py)")
     return p.parse_args()
 
 
@@ -106,6 +112,8 @@ def build_models(args, workload, dev):
                 m.dense_dtype = torch.bfloat16
             if not args.nchw and args.dense_dtype == "bf16":   # fp32 MIOpen Winograd prefers NCHW (measured)
                 m.use_channels_last()
+                if not args.no_graph and hasattr(m, "use_hip_graphs"):
+                    m.use_hip_graphs()
     return model.to(dev).train(), teacher
 
 
@@ -129,12 +137,13 @@ def make_step(workload, model, teacher, frames, optimizer, scheduler=None):
         else:
             loss, _ = single_stage_loss(model, ex)
         if optimizer is None:
-            backward_and_clip(loss, params, 35.0)
+            step.last_norm = backward_and_clip(loss, params, 35.0)
         else:   # the reference's optimizer step: OneCycle schedule, clip(35) folded into the fused Adam + true weight decay update
-            backward_and_step(loss, params, optimizer, scheduler, it[0], 35.0)
+            step.last_norm = backward_and_step(loss, params, optimizer, scheduler, it[0], 35.0)   # device scalar: total gradient norm
             it[0] += 1
         return loss
 
+    step.last_norm = None
     return step
 
 
@@ -173,27 +182,118 @@ def setup_workload(args, workload, dev, rank):
     return model, teacher, frames, step
 
 
-def timed(step, steps, warmup, world, dev):
-    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks"""
+def timed(step, steps, warmup, world, dev, detail=None):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks.  detail (dict): filled with the per-step
+    view of the same K steps - an event recorded on the launch stream behind every step (no synchronisation: ~2 us each) gives each step's
+    span on the DEVICE timeline, a host time stamp when step() returns gives the host's enqueue time per step - so that one slow step
+    (a stall of the box, an allocator miss) or a host-bound loop can be told from slow kernels in the line itself."""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if detail is not None else None
+    stamps = []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if marks:
+        marks[0].record()
+    for i in range(steps):
         loss = step()
+        if marks:
+            marks[i + 1].record()
+            stamps.append(time.perf_counter())
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if marks:
+        dev_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        host_ms = sorted((b - a) * 1e3 for a, b in zip([t0] + stamps[:-1], stamps))
+        q = lambda v, f: round(v[min(len(v) - 1, int(f * len(v)))], 3)
+        detail.update(device_ms_per_step=dict(median=q(dev_ms, 0.5), min=round(dev_ms[0], 3), max=round(dev_ms[-1], 3)),
+                      host_enqueue_ms_per_step=dict(median=q(host_ms, 0.5), min=round(host_ms[0], 3), max=round(host_ms[-1], 3)),
+                      host_enqueue_ms_total=round(t_enq * 1e3, 2), wall_ms_total=round(elapsed * 1e3, 2))
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, loss
+
+
+# ------------------------------------------------------------------------------------------------
+# execution-mode selection (the analogue of cudnn.benchmark: measured on THIS box, before the warm-up) and the step breakdown
+# ------------------------------------------------------------------------------------------------
+def set_mode(models, mode):
+    """mode = (graph, prefetch, wgrad): dense segment as HIP graphs | data pipeline on a loader thread | weight-gradient stream kinds"""
+    from sparse2dense_amd import side
+    for m in models:
+        if m is not None and hasattr(m, "graph_dense"):
+            m.graph_dense = bool(mode[0]) and hasattr(m, "_segments")
+    side.enable(mode[2] if mode[2] else False)
+    side.graph_fork(mode[3] if (mode[0] and len(mode) > 3 and mode[3]) else False)
+
+
+def mode_name(mode):
+    return (("graphs" if mode[0] else "eager") + ("[wgrad branches: " + mode[3] + "]" if (mode[0] and len(mode) > 3 and mode[3]) else "") + "+" +
+            ("loader-thread" if mode[1] else "in-step") + "+" + ("wgrad-stream(" + mode[2] + ")" if mode[2] else "one-stream"))
+
+
+def calibrate(models, step, dev, candidates, settle=4, n=8):
+    """run every candidate mode for `settle` + `n` steps in this process (same model, same optimizer state: the modes are bit-equal, see
+    tests/test_graph_gpu.py and tests/test_side_stream_gpu.py) and return (best mode, table).  A step's time = its span between two
+    events on the launch stream; a mode's score = the median over n steps (one stalled step does not decide)."""
+    table = {}
+    for mode in candidates:
+        set_mode(models, mode)
+        fn = step if mode[1] else step.sync_step
+        try:
+            for _ in range(settle):
+                fn()
+            torch.cuda.synchronize()
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            t0 = time.perf_counter()
+            marks[0].record()
+            for i in range(n):
+                fn()
+                marks[i + 1].record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / n * 1e3
+            spans = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n))
+            table[mode_name(mode)] = dict(median_ms=round(spans[n // 2], 3), mean_wall_ms=round(wall, 3), max_ms=round(spans[-1], 3))
+        except Exception as e:   # a mode that does not run on this box is not a candidate
+            table[mode_name(mode)] = dict(error=repr(e)[:200])
+    ok = [m for m in candidates if "median_ms" in table[mode_name(m)]]
+    best = min(ok, key=lambda m: max(table[mode_name(m)]["median_ms"], table[mode_name(m)]["mean_wall_ms"]))
+    return best, table
+
+
+def kernel_time_per_step(fn, n=2):
+    """sum of the device kernels' durations and their count per step, from torch.profiler's kernel records (roctracer) over n steps
+    of the chosen mode - the figure a `rocprofv3 --kernel-trace --stats` run of the same command reports (profiles/)"""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+        us, cnt = 0.0, 0
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and str(ev.device_type).endswith("CUDA") and ev.device_time_total > 0:
+                name = ev.name or ""
+                if name.startswith(("Memcpy", "Memset", "hipMemcpy", "hipMemset")):
+                    continue
+                us += ev.device_time_total
+                cnt += 1
+        if cnt == 0:
+            return None
+        return dict(kernel_ms_per_step=round(us / n / 1e3, 3), kernels_per_step=cnt // n)
+    except Exception as e:
+        return dict(error=repr(e)[:200])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -385,6 +485,14 @@ def stats_top_kernels():
         if m and "%" in line:
             names.append(m.group(1))
     return names, "profiles/" + os.path.basename(files[0])
+
+
+def _build_info():
+    try:
+        from sparse2dense_amd import _lib
+        return _lib.build_info()
+    except Exception as e:
+        return repr(e)
 
 
 def effective_cpu_count():
@@ -604,7 +712,46 @@ def main():
     torch.backends.cudnn.benchmark = False   # MIOpen exhaustive find costs minutes on a fresh box
 
     model, teacher, frames, step = setup_workload(args, args.workload, dev, rank)
-    elapsed, loss = timed(step, args.steps, args.warmup, world, dev)
+    from sparse2dense_amd import graphed
+    models = [getattr(model, "module", model), teacher]
+    prefetch_ok = step.sync_step is not step
+    graph_ok = any(m is not None and getattr(m, "graph_dense", False) for m in models)
+    wg = ",".join(sorted(side.MODE)) if side.MODE else ""
+    mode = (graph_ok, prefetch_ok, wg, ",".join(sorted(side.GRAPH_KINDS)) if graph_ok else "")
+    mode_table = None
+    if args.mode == "auto" and world == 1:
+        # which execution mode is fastest depends on the host (how fast it enqueues) as much as on the device: measure, pick, say so
+        cands = []
+        for g in ([True, False] if graph_ok else [False]):
+            for pf in ([True, False] if prefetch_ok else [False]):
+                if g:   # graphs: the dense weight gradients as branches of the backward graph or in line; the sparse ones on a stream or not
+                    cands += [(g, pf, w, f) for f in ("aux,dense", "") for w in ("sparse", "")]
+                else:
+                    cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
+        mode, mode_table = calibrate(models, step, dev, cands)
+    elif args.mode != "auto":
+        g, pf, w, *f = args.mode.split(":")
+        mode = (g == "graph" and graph_ok, pf == "loader" and prefetch_ok, "" if w in ("0", "") else w, "" if (not f or f[0] in ("0", "")) else f[0])
+    set_mode(models, mode)
+    run_step = step if mode[1] else step.sync_step
+    detail = {}
+    elapsed, loss = timed(run_step, args.steps, args.warmup, world, dev, detail)
+    graph_stats = dict(graphed.stats)
+    grad_norm = None
+    if step.last_norm is not None or run_step.last_norm is not None:
+        ln = run_step.last_norm if run_step.last_norm is not None else step.last_norm
+        grad_norm = float(ln.item())
+        # the reference's step is loss.backward(); clip_grad_norm_(35) (hooks/optimizer.py:15-21): a timed step whose gradients are not
+        # finite is not that step (r03/r04 timed one for a round and a half: DESIGN rule 31)
+        assert np.isfinite(grad_norm), f"bench.py: gradient norm of the last timed step is {grad_norm}"
+    assert np.isfinite(float(loss.item())), "bench.py: loss of the last timed step is not finite"
+    if rank == 0 and world == 1 and not args.no_breakdown:
+        detail.update(kernel_time_per_step(run_step) or {})
+        if "kernel_ms_per_step" in detail:
+            detail["ms_per_step_minus_kernel_ms"] = round(elapsed / args.steps * 1e3 - detail["kernel_ms_per_step"], 3)
+    if mode_table is not None:
+        detail["modes_measured_before_warmup"] = mode_table
+    detail["mode"] = mode_name(mode)
 
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
@@ -618,8 +765,8 @@ def main():
               file=sys.stderr)
 
     single = rank == 0 and world == 1
-    prefetching = hasattr(frames, "close")
-    if prefetching:   # loader thread of the timed run: done (the passes below build their examples inside the step)
+    prefetching = bool(mode[1])
+    if hasattr(frames, "close"):   # loader thread of the timed run: done (the passes below build their examples inside the step)
         frames.close()
         frames = frames.frames
     stats = scene_stats(model, frames) if rank == 0 else {}
@@ -646,11 +793,15 @@ def main():
                     a2.dtype, a2.dense_dtype, a2.sparse_dtype = dt, None, None
                 m2, t2, f2, st2 = setup_workload(a2, wl, dev, rank)
                 k = max(5, min(args.steps, 10))
-                el, _ = timed(st2, k, 3, 1, dev)
+                set_mode([getattr(m2, "module", m2), t2], mode)   # the mode chosen for the headline workload on this box
+                run2 = st2 if (mode[1] and st2.sync_step is not st2) else st2.sync_step
+                d2 = {}
+                el, _ = timed(run2, k, 5 if mode[0] else 3, 1, dev, d2)   # (graphs: 2 eager calls + the capture are part of the warm-up)
                 if hasattr(f2, "close"):
                     f2.close()
                 others[name] = dict(workload=WORKLOAD_NAMES[wl], value=round(args.batch * k / el, 3), unit="frames/s",
-                                    ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=3, frames_per_gpu=args.batch,
+                                    ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=5 if mode[0] else 3, frames_per_gpu=args.batch,
+                                    device_ms_per_step=d2.get("device_ms_per_step"),
                                     dtype=f"dense {a2.dense_dtype}, sparse {a2.sparse_dtype}")
                 del m2, t2, f2, st2
                 torch.cuda.empty_cache()
@@ -683,8 +834,13 @@ def main():
                                          "built on a second HIP stream by a loader thread while step k runs; one example per timed step"
                                          if prefetching else "example built inside its step on the main stream"),
                        "streams": ("chain + data pipeline" if prefetching else "chain") +
-                                  (" + weight-gradient stream (sparse2dense_amd/side.py: " + ",".join(sorted(side.MODE)) + ")" if side.MODE else ""),
+                                  (" + weight-gradient stream (sparse2dense_amd/side.py: " + mode[2] + ")" if mode[2] else ""),
+                       "mode": detail.get("mode"), "grad_norm": grad_norm,
+                       "library": _build_info(),
+                       "dense_segment": ("HIP graphs (sparse2dense_amd/graphed.py): neck + head + losses forward / backward = 2 graph launches per step; "
+                                         + str(graph_stats) if graph_stats and graph_stats.get("replay") else "launched kernel by kernel"),
                        "loss": loss_value, "scene": stats},
+            "step_breakdown": detail,
             "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "voxelize": voxelize, "cpu_baseline": base,
         }
         if others:

@@ -50,6 +50,9 @@ typedef void *s2d_stream_t;
 int s2d_version(void);
 /* copies the calling thread's last error text (NUL terminated) into buf; returns its length */
 int s2d_last_error(char *buf, size_t buf_len);
+/* copies "compiler; HIP runtime headers; target; build date" of this library into buf; returns the text's length (no reference
+ * counterpart: the reference's kernels come prebuilt with spconv / torch, docs/INSTALL.md:12,65-72) */
+int s2d_build_info(char *buf, size_t buf_len);
 
 /* ---- voxelization (hard voxelizer + fused reader mean) ------------------------------------ */
 /*

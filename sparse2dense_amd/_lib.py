@@ -20,6 +20,7 @@ _F6 = ctypes.c_float * 6
 SIGNATURES = {
     "s2d_version": (ctypes.c_int, []),
     "s2d_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "s2d_build_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "s2d_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "s2d_voxelize_run": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, _F6, _F3, ctypes.c_int, ctypes.c_int,
                                         c_f32p, c_i32p, c_i32p, c_f32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t,
@@ -358,6 +359,13 @@ def load():
 def last_error():
     buf = ctypes.create_string_buffer(512)
     load().s2d_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def build_info():
+    """compiler / HIP headers / build date of the loaded library (s2d_build_info)"""
+    buf = ctypes.create_string_buffer(256)
+    load().s2d_build_info(buf, 256)
     return buf.value.decode(errors="replace")
 
 

@@ -174,7 +174,7 @@ extern "C" int s2d_regloss_bwd(const float *feat, const int64_t *ind, const uint
     S2D_CHECK_ARG(feat && ind && mask && target && res && go && dfeat && batch > 0 && channels > 0 && hw > 0 && max_objs > 0,
                   "regloss_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    S2D_HIP(hipMemsetAsync(dfeat, 0, (size_t)batch * channels * hw * sizeof(float), st));
+    if (int rc = zero_async(dfeat, (size_t)batch * channels * hw * sizeof(float), st)) return rc;   // (a kernel, not a memset node: see zero_async)
     hipLaunchKernelGGL(regloss_bwd_kernel, dim3((unsigned)ceil_div(batch * max_objs * channels, 256)), dim3(256), 0, st, feat, ind, mask, target,
                        batch, channels, hw, max_objs, res, go, dfeat);
     S2D_LAUNCH_CHECK();

@@ -458,7 +458,7 @@ extern "C" int s2d_convt3d_k4s2p1_wgrad_f32(const float *in, const float *dout, 
     hipStream_t st = (hipStream_t)stream;
     Dims3 s{d, h, w};
     float *partial = (float *)ws;
-    S2D_HIP(hipMemsetAsync(partial, 0, p.ws_bytes, st));   // (kz,ky) blocks whose rows are all out of range write nothing
+    if (int rc = zero_async(partial, p.ws_bytes, st)) return rc;   // (kz,ky) blocks whose rows are all out of range write nothing
     const dim3 grid(p.blocks_x, 16), blk(256);
 #define S2D_CW(A, B)                                                                                          \
     do {                                                                                                      \

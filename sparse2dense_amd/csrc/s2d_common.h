@@ -32,6 +32,11 @@ void set_error(const char *fmt, ...);
 
 #define S2D_LAUNCH_CHECK() S2D_HIP(hipGetLastError())
 
+// Zero-fill by a KERNEL (csrc/common.hip).  Entry points that can be recorded into a HIP graph (the dense segment, graphed.py) must not
+// use hipMemsetAsync: a memset node followed by an atomically accumulating kernel node stopped being ordered after a few replays of the
+// graph (ROCm 7.2, r05: the regression-loss scatter added onto the previous replay's gradient map from the fourth replay on).
+int zero_async(void *p, size_t bytes, hipStream_t st);
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

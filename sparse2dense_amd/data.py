@@ -208,7 +208,8 @@ class PrefetchLoader:
             if ev is None:
                 return
             try:
-                with torch.cuda.stream(self.side):
+                from .graphed import CAPTURE_LOCK
+                with CAPTURE_LOCK, torch.cuda.stream(self.side):   # (never beside a HIP-graph capture: see graphed.CAPTURE_LOCK)
                     self.side.wait_event(ev)
                     ex = self._build()
                     done = torch.cuda.Event()

@@ -57,6 +57,7 @@ def cached_pack(weight, variant, build):
     """Packed-weight images are rebuilt when the parameter changes (its autograd version counter moves on every in-place
     update such as an optimizer step or load_state_dict, its data_ptr on re-assignment), not on every call.  In-place
     edits through `weight.data` do not move the counter: call clear_pack_cache() after such surgery."""
+    weight = getattr(weight, "_s2d_origin", weight)   # graphed.GraphedSegment captures with leaf aliases of the parameters: one image per parameter
     key = id(weight)
     ent = _pack_cache.get(key)
     if ent is None or ent[0]() is not weight or ent[1] != weight.data_ptr() or ent[2] != weight._version:
@@ -70,6 +71,7 @@ def cached_pack(weight, variant, build):
 
 
 def cached_pack_has(weight, variant):
+    weight = getattr(weight, "_s2d_origin", weight)
     ent = _pack_cache.get(id(weight))
     return (ent is not None and ent[0]() is weight and ent[1] == weight.data_ptr() and ent[2] == weight._version and variant in ent[3])
 
@@ -100,6 +102,7 @@ def register_repack(weight, variants, src, launch, conv2d=None):
     """src: the tensor the launch reads (must alias the parameter's storage - a converted / re-laid copy would go stale).
     conv2d = (w_ptr_tensor, cin, cout, taps, nhwc, transpose_flip, packed_fwd, packed_dgrad | None): the launch's arguments, for launches
     that s2d_conv2d_pack_batch_bf16 can serve - refresh_pack_cache() then packs all such layers in ONE launch (r04)"""
+    weight = getattr(weight, "_s2d_origin", weight)
     if src.data_ptr() != weight.data_ptr() or src.dtype != weight.dtype:
         return
     if conv2d is not None:
@@ -739,11 +742,14 @@ class AbsorbedZeroPad2d(nn.ZeroPad2d):
 # BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
 # --------------------------------------------------------------------------------------------------
 _ws_cache = {}
+WS_PRIVATE = False   # set by graphed.GraphedSegment while it captures: a HIP graph must not reference a buffer that a later, larger request re-allocates
 
 
 def _ws(nbytes, device):
     """reduction workspace: one grow-only buffer per device and stream.  Every user writes it before reading it inside
     one entry point, and launches on a stream are ordered, so consecutive calls can share it."""
+    if WS_PRIVATE:   # graph capture: a plain allocation from the graph's memory pool, owned by the graph
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index, _stream())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -80,6 +80,87 @@ class SingleStageDetector(nn.Module):
             return type(out)(conv)
         return out if keep_first and torch.is_tensor(out) else f32(out)
 
+    # ---- the shape-static dense segment as HIP graphs (graphed.GraphedSegment) ----------------------------------------------------------
+    graph_dense = False   # set by use_hip_graphs()
+
+    def use_hip_graphs(self, on=True):
+        """Replay neck + head (+ losses in training) as HIP graphs: forward and backward of everything behind the BEV map are two graph
+        launches per step instead of ~600 Python-issued kernel launches (sparse2dense_amd/graphed.py).  Needs CUDA inputs; steps whose
+        batch norms synchronise over ranks (SyncBN collectives inside the segment) keep the eager path unless S2D_DENSE_GRAPH_SYNCBN=1."""
+        self.graph_dense = bool(on)
+        self._segments = {}
+        return self
+
+    def _graph_ok(self, x):
+        if not (self.graph_dense and torch.is_tensor(x) and x.is_cuda):
+            return False
+        from . import collective, graphed
+        import os
+        if collective.sync_on() and os.environ.get("S2D_DENSE_GRAPH_SYNCBN", "0") != "1":
+            return False
+        return graphed.enabled()
+
+    def _segment(self, name, fn):
+        from .graphed import GraphedSegment
+        segs = self.__dict__.setdefault("_segments", {})
+        seg = segs.get(name)
+        if seg is None:
+            mods = [self.bbox_head] + ([self.neck] if self.neck is not None else [])
+            seg = segs[name] = GraphedSegment(fn, mods, name=f"{type(self).__name__}.{name}")
+        return seg
+
+    @staticmethod
+    def _flat_targets(example, tasks):
+        """the CenterHead targets of an example as a flat tensor list (task-major)"""
+        return [example[k][t] for t in range(tasks) for k in ("hm", "ind", "mask", "cat", "anno_box")]
+
+    @staticmethod
+    def _unflat_targets(flat, tasks):
+        keys = ("hm", "ind", "mask", "cat", "anno_box")
+        return {k: [flat[t * len(keys) + i] for t in range(tasks)] for i, k in enumerate(keys)}
+
+    @staticmethod
+    def _flat_struct(obj, out, spec_path=()):
+        """flatten nested dict / list / tuple of tensors (and passthrough constants) into `out`; returns a spec to rebuild it"""
+        if torch.is_tensor(obj):
+            out.append(obj)
+            return ("t", len(out) - 1)
+        if isinstance(obj, dict):
+            return ("d", type(obj) if type(obj) is dict else dict, [(k, SingleStageDetector._flat_struct(v, out)) for k, v in obj.items()])
+        if isinstance(obj, (list, tuple)):
+            return ("l", type(obj), [SingleStageDetector._flat_struct(v, out) for v in obj])
+        return ("c", obj)
+
+    @staticmethod
+    def _unflat_struct(spec, flat):
+        kind = spec[0]
+        if kind == "t":
+            return flat[spec[1]]
+        if kind == "d":
+            return spec[1]((k, SingleStageDetector._unflat_struct(v, flat)) for k, v in spec[2])
+        if kind == "l":
+            return spec[1](SingleStageDetector._unflat_struct(v, flat) for v in spec[2])
+        return spec[1]
+
+    def _run_segment(self, name, part, x, side_inputs):
+        """part(x, *side_inputs) -> nested structure of tensors; through the segment's graphs.  The structure is rebuilt around the
+        (static) output tensors of the replay."""
+        holder = {}
+
+        def fn(x_, *side):
+            flat = []
+            holder["spec"] = self._flat_struct(part(x_, *side), flat)
+            return tuple(flat)
+        seg = self._segment(name, fn)
+        seg.fn = fn     # (the closure of THIS call: eager warm-up calls and the capture record the output structure through it)
+        outs = seg(x, *side_inputs)
+        spec = holder.get("spec")
+        if spec is None:
+            spec = seg.__dict__["_spec"]
+        else:
+            seg.__dict__["_spec"] = spec
+        return self._unflat_struct(spec, list(outs))
+
     def _read(self, example, prefix=""):
         mean_key = prefix + "voxel_mean"
         if mean_key in example:
@@ -89,12 +170,32 @@ class SingleStageDetector(nn.Module):
 
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
-    def extract_feat(self, data):
+    def _bev(self, data):
         # the BEV map goes straight to NHWC bf16 in the bf16 mode: the neck reads exactly that, and a caller that asked for the
         # feature (the distillation teacher's F_D_a) gets it in the compute dtype / layout (sparse2dense_loss upcasts per element)
         bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and self.with_neck and data["features"].is_cuda)
-        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"],
-                                         bev_nhwc_bf16=bev)
+        return self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"], bev_nhwc_bf16=bev)
+
+    def _dense_part(self, x, example, return_loss):
+        """everything behind the BEV map: neck -> CenterHead (-> losses).  Shapes depend on the batch size only: this is the segment
+        `use_hip_graphs()` replays as HIP graphs."""
+        neck = self._dense(self.neck, x, keep_first=True) if self.with_neck else x
+        preds = self._dense(self.bbox_head, neck)
+        losses = self.bbox_head.loss(example, preds) if return_loss else None
+        return neck, preds, losses
+
+    def _dense_call(self, x, example, return_loss):
+        if self._graph_ok(x) and self.with_neck:
+            tasks = len(self.bbox_head.tasks)
+            name = f"{'train' if self.training else 'eval'}:{'loss' if return_loss else 'fwd'}:{int(torch.is_grad_enabled())}"
+            if return_loss:
+                return self._run_segment(name, lambda x_, *flat: self._dense_part(x_, self._unflat_targets(flat, tasks), True), x,
+                                         self._flat_targets(example, tasks))
+            return self._run_segment(name, lambda x_: self._dense_part(x_, None, False), x, [])
+        return self._dense_part(x, example, return_loss)
+
+    def extract_feat(self, data):
+        x, voxel_feature = self._bev(data)
         neck = self._dense(self.neck, x, keep_first=True) if self.with_neck else x
         return neck, voxel_feature, x
 
@@ -103,15 +204,14 @@ class VoxelNet(SingleStageDetector):
         batch_size = len(example[prefix + "num_voxels"])
         data = dict(features=self._read(example, prefix), coors=example[prefix + "coordinates"], batch_size=batch_size,
                     input_shape=example["shape"][0], bev_private=not return_feature)
-        x, _, F_D_a = self.extract_feat(data)
+        F_D_a, _ = self._bev(data)
         F_D_b = None
         if return_recon_feature:  # second backbone pass on the object-only cloud (voxelnet.py:73-89)
             bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and data["features"].is_cuda)
             F_D_b, _ = self.backbone(self._read(example, "reconstruction_"), example["reconstruction_coordinates"],
                                      batch_size, example["shape"][0], bev_nhwc_bf16=bev)
-        preds = self._dense(self.bbox_head, x)
+        x, preds, losses = self._dense_call(F_D_a, example, return_loss)
         if return_loss:
-            losses = self.bbox_head.loss(example, preds)
             return losses if not return_feature else (losses, F_D_a, F_D_b)
         if return_feature and return_recon_feature:
             return preds, F_D_a, F_D_b
@@ -136,10 +236,13 @@ class VoxelNet(SingleStageDetector):
 
 @DETECTORS.register_module
 class KD_VoxelNet(VoxelNet):
-    def extract_feat(self, data, train_pcm=True):
-        # the BEV map goes straight to NHWC bf16 when only the bf16 neck reads it (as in VoxelNet.extract_feat)
+    def _bev(self, data):
+        # the BEV map goes straight to NHWC bf16 when only the bf16 neck reads it (as in VoxelNet._bev)
         bev = bool(self.dense_channels_last and self.dense_dtype == torch.bfloat16 and data["features"].is_cuda)
-        x, voxel_feature = self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"], bev_nhwc_bf16=bev)
+        return self.backbone(data["features"], data["coors"], data["batch_size"], data["input_shape"], bev_nhwc_bf16=bev)
+
+    def extract_feat(self, data, train_pcm=True):
+        x, voxel_feature = self._bev(data)
         # F_S_a / F_S_b stay in the neck's compute dtype (sparse2dense_loss upcasts per element)
         x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True, keep=(5, 6))
         return x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, voxel_feature
@@ -159,15 +262,14 @@ class KD_VoxelNet(VoxelNet):
             return example[key]
         return self.reader(example[f"reconstruction_voxels_{scale}"], example[f"reconstruction_num_points_{scale}"])
 
-    def forward(self, example, return_loss=True, return_feature=False, **kwargs):
-        batch_size = len(example["num_voxels"])
-        data = dict(features=self._read(example), coors=example["coordinates"], batch_size=batch_size,
-                    input_shape=example["shape"][0])
-        want_pcr = self.training and return_loss
-        if want_pcr and data["features"].is_cuda and hasattr(self.neck, "pcr_targets"):
+    def _dense_part(self, x, example, return_loss, want_pcr=False):
+        """everything behind the BEV map (S2D module + PCR head + RPN trunk + CenterHead + losses, voxelnet.py:216-265): shapes depend on
+        the batch size only - the segment `use_hip_graphs()` replays as HIP graphs"""
+        batch_size = x.shape[0]
+        if want_pcr and x.is_cuda and hasattr(self.neck, "pcr_targets"):
             # hand the recon voxels to the neck: its PCR levels return their losses directly (heads.pcr_level)
             self.neck.pcr_targets = {s: (example[f"reconstruction_coordinates_{s}"], self._read_scaled(example, s)) for s in (4, 2)}
-        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b, _ = self.extract_feat(data)
+        x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True, keep=(5, 6))
         mask_loss = comp_loss = 0
         if want_pcr:
             if gen_offset_2.dim() == 0:   # fused levels: the slots already hold the losses
@@ -190,8 +292,62 @@ class KD_VoxelNet(VoxelNet):
                 m2, o2 = mask_offset_loss(gen_offset_2, gen_mask_2, recon_gt_2, grid_2)
             mask_loss, comp_loss = m2 + m4, o2 + o4
         preds = self._dense(self.bbox_head, x)
+        losses = self.bbox_head.loss(example, preds) if return_loss else None
+        return losses, F_S_a, F_S_b, preds, mask_loss, comp_loss
+
+    def _padded_recon(self, example, scale):
+        """the recon voxels of one scale in capacity-sized persistent buffers (rows past the list carry batch index -1, which every PCR kernel
+        skips): a static-shaped input for the graph, whatever the cloud's voxel count"""
+        coors = example[f"reconstruction_coordinates_{scale}"]
+        feats = self._read_scaled(example, scale)
+        coors = coors if coors.dtype == torch.int32 else coors.int()
+        feats = feats.float()
+        m = int(coors.shape[0])
+        store = self.__dict__.setdefault("_recon_pad", {})
+        ent = store.get(scale)
+        if ent is None or ent[0].shape[0] < m or ent[0].device != coors.device or ent[1].shape[1] != feats.shape[1]:
+            cap = -(-int(m * 1.5 + 1) // 65536) * 65536
+            cb = torch.full((cap, 4), -1, dtype=torch.int32, device=coors.device)
+            fb = torch.zeros((cap, feats.shape[1]), dtype=torch.float32, device=coors.device)
+            cb._s2d_static = fb._s2d_static = True
+            ent = store[scale] = [cb, fb, 0]
+        cb, fb, prev = ent
+        cb[:m].copy_(coors)
+        fb[:m].copy_(feats)
+        if prev > m:
+            cb[m:prev].fill_(-1)
+        ent[2] = m
+        return cb, fb
+
+    def _dense_call(self, x, example, return_loss, want_pcr=False):
+        fused = want_pcr and return_loss and hasattr(self.neck, "pcr_targets")
+        if self._graph_ok(x) and (fused or not want_pcr):
+            tasks = len(self.bbox_head.tasks)
+            name = f"{'train' if self.training else 'eval'}:{'loss' if return_loss else 'fwd'}:{int(want_pcr)}:{int(torch.is_grad_enabled())}"
+            side = self._flat_targets(example, tasks) if return_loss else []
+            nt = len(side)
+            if want_pcr:
+                for s_ in (4, 2):
+                    side += list(self._padded_recon(example, s_))
+
+            def part(x_, *flat):
+                ex = self._unflat_targets(flat[:nt], tasks) if return_loss else {}
+                if want_pcr:
+                    for k, s_ in enumerate((4, 2)):
+                        ex[f"reconstruction_coordinates_{s_}"] = flat[nt + 2 * k]
+                        ex[f"reconstruction_voxel_mean_{s_}"] = flat[nt + 2 * k + 1]
+                return self._dense_part(x_, ex, return_loss, want_pcr)
+            return self._run_segment(name, part, x, side)
+        return self._dense_part(x, example, return_loss, want_pcr)
+
+    def forward(self, example, return_loss=True, return_feature=False, **kwargs):
+        batch_size = len(example["num_voxels"])
+        data = dict(features=self._read(example), coors=example["coordinates"], batch_size=batch_size,
+                    input_shape=example["shape"][0])
+        want_pcr = self.training and return_loss
+        bev, _ = self._bev(data)
+        losses, F_S_a, F_S_b, preds, mask_loss, comp_loss = self._dense_call(bev, example, return_loss, want_pcr)
         if return_loss:
-            losses = self.bbox_head.loss(example, preds)
             if not return_feature:
                 return losses, preds
             return losses, F_S_a, F_S_b, preds, mask_loss, comp_loss

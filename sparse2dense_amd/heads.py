@@ -652,9 +652,14 @@ class CenterHead(nn.Module):
                 preds["anno_box"] = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["vel"], preds["rot"]), 1)
             else:
                 preds["anno_box"] = torch.cat((preds["reg"], preds["height"], preds["dim"], preds["rot"]), 1)
-                target_box = target_box[..., [0, 1, 2, 3, 4, 5, -2, -1]]  # drop the velocity target
+                # drop the velocity target: columns [0..5, -2, -1] (two slices - an index list would be an H2D copy per step, which a
+                # HIP-graph capture also refuses)
+                target_box = torch.cat((target_box[..., :6], target_box[..., -2:]), -1)
             box_loss = self.crit_reg(preds["anno_box"], example["mask"][task_id], example["ind"][task_id], target_box)
-            loc_loss = (box_loss * box_loss.new_tensor(self.code_weights)).sum()
+            cw = getattr(self, "_code_w", None)   # device copy of the code weights, made once (an H2D copy per step is also not capturable)
+            if cw is None or cw.device != box_loss.device or cw.dtype != box_loss.dtype or cw.numel() != len(self.code_weights):
+                cw = self._code_w = box_loss.new_tensor(self.code_weights)
+            loc_loss = (box_loss * cw).sum()
             loss = hm_loss + self.weight * loc_loss
             # NB: the reference copies the logging scalars to the host here (.detach().cpu(), four
             # blocking syncs per step, center_head.py:283); we keep them on the device.

@@ -1,4 +1,6 @@
-"""Weight-gradient launches on a second HIP stream (default; S2D_WGRAD_STREAM=0 turns it off, =dense / =sparse select layer kinds).
+"""Weight-gradient launches on a second HIP stream (opt-in since r05: S2D_WGRAD_STREAM=1 | dense | sparse | aux, or side.enable(...);
+bench.py measures it against the single-stream run on the box it runs on and keeps it only where it is faster - r04's default-on
+cost 11 ms per step on a slow host for 1.4 ms gained on a fast one).
 
 In the backward of a conv layer only the data gradient is on the chain to the next layer; the weight gradient (and its
 split-K fold, and the bias gradient that rides on it) is needed by nobody before the optimizer.  On one stream both are
@@ -43,7 +45,7 @@ def _parse(v):
     return {k for k in v.split(",") if k in KINDS}
 
 
-MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "1"))
+MODE = _parse(os.environ.get("S2D_WGRAD_STREAM", "0"))
 
 _streams = {}    # device index -> torch.cuda.Stream
 _pending = {}    # device index -> True while side work has been launched since the last join
@@ -123,8 +125,66 @@ def stream_after(dev):
     return side
 
 
+# ---- inside a HIP-graph capture (graphed.GraphedSegment): the same overlap as parallel branches of the backward graph ----------------
+# A weight-gradient launch group forks off the capturing stream (event record / wait = a graph dependency) onto a second capturing
+# stream and is joined once, at the end of the backward capture: in the replayed graph the groups are branches that depend on nothing
+# but their inputs, and the runtime runs them beside the chain - with no host work at all per step.
+GRAPH_KINDS = _parse(os.environ.get("S2D_GRAPH_FORK", "0"))   # layer kinds forked inside a capture (bench.py measures "dense,aux" vs none)
+_cap = {}   # device index -> dict(stream, keep, pending)
+
+
+def graph_fork(kinds):
+    """kinds as in S2D_WGRAD_STREAM; takes effect for captures made afterwards"""
+    global GRAPH_KINDS
+    GRAPH_KINDS = _parse(kinds) if isinstance(kinds, str) else _parse("1" if kinds else "0")
+
+
+def _run_forked(weight, fn, inputs):
+    dev = weight.device.index
+    st = _cap.get(dev)
+    if st is None:
+        st = _cap[dev] = dict(stream=torch.cuda.Stream(device=dev), keep=[], pending=False)
+    cur = torch.cuda.current_stream(dev)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    st["stream"].wait_event(ev)
+    torch.cuda.set_stream(st["stream"])
+    try:
+        out = fn()
+    finally:
+        torch.cuda.set_stream(cur)
+    # the branch reads its inputs while the chain runs on: their blocks of the graph's memory pool must not be handed to a later chain
+    # allocation of the same capture - keep them (and the outputs) referenced until the capture is over
+    st["keep"].append((inputs, out))
+    st["pending"] = True
+    stats["forked"] = stats.get("forked", 0) + 1
+    return out
+
+
+def join_capture():
+    """inside the capture, after the last forked group: the capturing stream waits for the fork stream (an unjoined branch is an error
+    at hipStreamEndCapture)"""
+    for dev, st in _cap.items():
+        if st["pending"]:
+            ev = torch.cuda.Event()
+            ev.record(st["stream"])
+            torch.cuda.current_stream(dev).wait_event(ev)
+            st["pending"] = False
+
+
+def capture_done():
+    """after the capture: the kept tensors may go (their storage stays reserved for the graph by the pool)"""
+    for st in _cap.values():
+        st["keep"].clear()
+
+
 def run(weight, fn, *inputs, kind="dense"):
     """fn() -> gradient tensor(s) of `weight` (and its bias); on the side stream when the protocol above allows it"""
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        if kind in GRAPH_KINDS and not torch.is_grad_enabled():
+            return _run_forked(weight, fn, inputs)
+        stats["plain"] += 1
+        return fn()
     if not usable(weight, kind):
         stats["plain"] += 1
         return fn()

@@ -41,7 +41,10 @@ def distill_loss(T_model, S_model, example):
     t_box = torch.cat((T_preds[0]["reg"], T_preds[0]["height"], T_preds[0]["dim"], T_preds[0]["rot"]), dim=1)
     head = _unwrap(S_model).bbox_head
     kd_reg = distill_reg_loss(S_preds[0]["anno_box"], t_box, mask, ind)
-    kd_reg = (kd_reg * kd_reg.new_tensor(head.code_weights)).sum() * head.weight
+    cw = getattr(head, "_code_w", None)   # device copy made by CenterHead.loss (no H2D copy per step)
+    if cw is None or cw.device != kd_reg.device or cw.dtype != kd_reg.dtype:
+        cw = kd_reg.new_tensor(head.code_weights)
+    kd_reg = (kd_reg * cw).sum() * head.weight
     losses["loss"][0] = losses["loss"][0] + kd_hm + kd_reg + s2d + (mask_loss + offset_loss)
     losses["sparse2dense_loss"] = [s2d.detach()]
     losses["kd_hm_loss"] = [kd_hm.detach()]

@@ -1,0 +1,134 @@
+"""The shape-static dense segment replayed as HIP graphs (sparse2dense_amd/graphed.py, `detector.use_hip_graphs()`): the same kernels on the
+same operands in the same order as the kernel-by-kernel run, so a training run must not depend on the mode - bit-identical losses,
+parameters and gradients - whether the segment is the S2D student's (S2D module + PCR head with padded recon-voxel lists + RPN trunk +
+CenterHead + losses), plain CenterPoint's, or the frozen distillation teacher's forward-only graph.
+Reference loop: /root/reference/det3d/torchie/trainer/trainer.py:775-811, hooks/optimizer.py:15-21."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(kind, dev):
+    from sparse2dense_amd import waymo_configs
+    from sparse2dense_amd.registry import build_detector
+    m = build_detector(getattr(waymo_configs, kind)())
+    m.dense_dtype = torch.bfloat16
+    m.use_channels_last()
+    return m.to(dev)
+
+
+def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False):
+    from sparse2dense_amd import dense2d, graphed, hip_ops, side
+    from sparse2dense_amd.data import SyntheticFrames
+    from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+    from sparse2dense_amd.train_step import backward_and_step
+    side.enable(False)
+    dense2d.clear_pack_cache()
+    hip_ops.set_sparse_compute_dtype("s16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = _model(kind, dev).train()
+    if graph:
+        model.use_hip_graphs()
+    distill = kind == "s2d_student"
+    sets = [SyntheticFrames(batch, n_points=n_points + 1500 * k, seed=5 + 10 * k, distill=distill, device=dev) for k in range(3 if vary else 1)]
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = build_one_cycle_optimizer(model, dict(wd=0.01))
+    sch = build_one_cycle_scheduler(opt, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4), total_steps=100)
+    for k in graphed.stats:
+        graphed.stats[k] = 0
+    losses = []
+    try:
+        for it in range(steps):
+            ex = sets[it % len(sets)].example()
+            if distill:
+                out = model(ex, return_loss=True, return_feature=True)
+                loss = sum(out[0]["loss"]) + out[4] + out[5]
+            else:
+                loss = sum(model(ex, return_loss=True)["loss"])
+            if it == steps - 1:   # last step by hand: the gradients themselves are compared
+                for p in params:
+                    p.grad = None
+                loss.backward()
+                torch.cuda.synchronize()
+                grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            else:
+                backward_and_step(loss, params, opt, sch, it, 35.0)
+            losses.append(float(loss))
+        final = torch.cat([p.detach().flatten()[:64].double().cpu() for p in params])
+        bn = torch.cat([b.detach().flatten()[:16].double().cpu() for b in model.buffers()])
+        st = dict(graphed.stats)
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+    return losses, final, grads, bn, st
+
+
+def _same(a, b, what):
+    la, fa, ga, ba, _ = a
+    lb, fb, gb, bb, _ = b
+    assert la == lb, (what, la, lb)
+    assert torch.equal(fa, fb), what
+    assert torch.equal(ba, bb), what + ": batch-norm running statistics"
+    for g, r in zip(ga, gb):
+        assert (g is None) == (r is None), what
+        if g is not None:
+            assert torch.equal(g, r), what
+
+
+@pytest.mark.parametrize("kind", ["s2d_student", "centerpoint_voxelnet"])
+def test_training_run_is_independent_of_the_graph_replay(kind):
+    ref = _run(False, kind=kind)
+    assert ref[4]["replay"] == 0
+    got = _run(True, kind=kind)
+    assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]    # 2 eager warm-up calls, then capture + replays
+    _same(got, ref, kind)
+    assert ref[0][-1] != ref[0][0]
+
+
+def test_graph_replay_with_recon_lists_of_changing_length():
+    """three point clouds of different sizes in rotation: the sparse stack is eager and re-planned per cloud, the PCR head's recon-voxel lists
+    shrink and grow inside their padded buffers, the dense graphs are captured once"""
+    ref = _run(False, steps=8, vary=True)
+    got = _run(True, steps=8, vary=True)
+    assert got[4]["capture"] == 1 and got[4]["replay"] == 6, got[4]
+    _same(got, ref, "varying clouds")
+
+
+def test_parameter_surgery_drops_the_capture():
+    """load_state_dict (version counters move) behind a captured segment: the next call must not replay a graph that reads stale packed
+    weight images - it re-runs eagerly and captures again"""
+    from sparse2dense_amd import dense2d, graphed, hip_ops
+    from sparse2dense_amd.data import SyntheticFrames
+    hip_ops.set_sparse_compute_dtype("s16")
+    dense2d.clear_pack_cache()
+    dev = torch.device("cuda:0")
+    try:
+        torch.manual_seed(3)
+        model = _model("centerpoint_voxelnet", dev).train().use_hip_graphs()
+        twin = _model("centerpoint_voxelnet", dev).train()
+        frames = SyntheticFrames(1, n_points=9000, seed=2, device=dev)
+        for k in graphed.stats:
+            graphed.stats[k] = 0
+
+        def loss_of(m):
+            return float(sum(m(frames.example(), return_loss=True)["loss"]))
+        for _ in range(4):
+            loss_of(model)
+        assert graphed.stats["capture"] == 1 and graphed.stats["replay"] == 2
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        torch.manual_seed(99)
+        for p in model.parameters():
+            sd_key = [k for k, v in model.named_parameters() if v is p][0]
+            sd[sd_key] = sd[sd_key] + 0.01 * torch.randn_like(p)
+        model.load_state_dict(sd)
+        twin.load_state_dict(sd)
+        a = loss_of(model)
+        assert graphed.stats["dropped"] == 1
+        twin.load_state_dict(model.state_dict())   # (running statistics moved by the calls above)
+        b = loss_of(twin)
+        assert a == b, (a, b)
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
