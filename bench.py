@@ -724,8 +724,10 @@ def main():
         cands = []
         for g in ([True, False] if graph_ok else [False]):
             for pf in ([True, False] if prefetch_ok else [False]):
-                if g:   # graphs: the dense weight gradients as branches of the backward graph or in line; the sparse ones on a stream or not
-                    cands += [(g, pf, w, f) for f in ("aux,dense", "") for w in ("sparse", "")]
+                if g:   # graphs: the sparse weight gradients (eager side of the step) on their stream or not.  The dense ones as BRANCHES of
+                    # the backward graph (--mode graph:loader:0:dense,aux) are not a candidate: -0.4 ms on an idle host, 3x slower when
+                    # the host's cores are busy (the runtime orders graph branches with host-side signal handling), r05 measurement
+                    cands += [(g, pf, w, "") for w in ("sparse", "")]
                 else:
                     cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
         mode, mode_table = calibrate(models, step, dev, cands)

@@ -18,12 +18,13 @@ def _model(kind, dev):
     return m.to(dev)
 
 
-def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False):
+def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False, fork=""):
     from sparse2dense_amd import dense2d, graphed, hip_ops, side
     from sparse2dense_amd.data import SyntheticFrames
     from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
     from sparse2dense_amd.train_step import backward_and_step
     side.enable(False)
+    side.graph_fork(fork if fork else False)
     dense2d.clear_pack_cache()
     hip_ops.set_sparse_compute_dtype("s16")
     dev = torch.device("cuda:0")
@@ -60,6 +61,7 @@ def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False
         bn = torch.cat([b.detach().flatten()[:16].double().cpu() for b in model.buffers()])
         st = dict(graphed.stats)
     finally:
+        side.graph_fork(False)
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
     return losses, final, grads, bn, st
@@ -85,6 +87,18 @@ def test_training_run_is_independent_of_the_graph_replay(kind):
     assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]    # 2 eager warm-up calls, then capture + replays
     _same(got, ref, kind)
     assert ref[0][-1] != ref[0][0]
+
+
+def test_weight_gradients_as_branches_of_the_backward_graph():
+    """side.graph_fork("dense,aux"): inside the capture the weight-gradient launch groups fork onto a second capturing stream and rejoin
+    at the end - parallel branches of the replayed backward graph; same kernels, same operands: bit-equal to the kernel-by-kernel run"""
+    from sparse2dense_amd import side
+    ref = _run(False)
+    side.stats["forked"] = 0
+    got = _run(True, fork="dense,aux")
+    assert side.stats["forked"] > 20, side.stats
+    assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]
+    _same(got, ref, "forked weight gradients")
 
 
 def test_graph_replay_with_recon_lists_of_changing_length():
