@@ -78,7 +78,7 @@ def parse():
                    help="override for the sparse stack: bf16 = fp32 storage / bf16 MFMA inputs, s16 = bf16 storage (default with --dtype bf16)")
     p.add_argument("--nchw", action="store_true", help="keep the dense neck/head in NCHW (default: NHWC when bf16)")
     p.add_argument("--mode", default="auto", help="execution mode: auto = measure {HIP graphs | eager} x {loader thread | in-step} x {weight-gradient "
-                   "stream on | off} for a few steps each on this box and run the fastest (reported in step_breakdown); or graph|eager:loader|instep:KINDS[:KINDS forked inside the graph], "
+                   "stream on | off} for a few steps each on this box and run the fastest (reported in step_breakdown); or graph|eager:loader|instep:KINDS[:KINDS whose weight gradients get a graph of their own on the side stream], "
                    "e.g. graph:loader:sparse:dense,aux  eager:instep:0")
     p.add_argument("--no-breakdown", action="store_true", help="skip the torch.profiler kernel-time pass of step_breakdown")
     p.add_argument("--no-graph", action="store_true", help="launch the dense segment (neck + head + losses) kernel by kernel from Python "
@@ -233,11 +233,11 @@ def set_mode(models, mode):
         if m is not None and hasattr(m, "graph_dense"):
             m.graph_dense = bool(mode[0]) and hasattr(m, "_segments")
     side.enable(mode[2] if mode[2] else False)
-    side.graph_fork(mode[3] if (mode[0] and len(mode) > 3 and mode[3]) else False)
+    side.graph_defer(mode[3] if (mode[0] and len(mode) > 3 and mode[3]) else False)
 
 
 def mode_name(mode):
-    return (("graphs" if mode[0] else "eager") + ("[wgrad branches: " + mode[3] + "]" if (mode[0] and len(mode) > 3 and mode[3]) else "") + "+" +
+    return (("graphs" if mode[0] else "eager") + ("[+wgrad graph on 2nd stream: " + mode[3] + "]" if (mode[0] and len(mode) > 3 and mode[3]) else "") + "+" +
             ("loader-thread" if mode[1] else "in-step") + "+" + ("wgrad-stream(" + mode[2] + ")" if mode[2] else "one-stream"))
 
 
@@ -717,17 +717,18 @@ def main():
     prefetch_ok = step.sync_step is not step
     graph_ok = any(m is not None and getattr(m, "graph_dense", False) for m in models)
     wg = ",".join(sorted(side.MODE)) if side.MODE else ""
-    mode = (graph_ok, prefetch_ok, wg, ",".join(sorted(side.GRAPH_KINDS)) if graph_ok else "")
+    mode = (graph_ok, prefetch_ok, wg, ",".join(sorted(side.GRAPH_DEFER)) if graph_ok else "")
     mode_table = None
     if args.mode == "auto" and world == 1:
         # which execution mode is fastest depends on the host (how fast it enqueues) as much as on the device: measure, pick, say so
         cands = []
         for g in ([True, False] if graph_ok else [False]):
             for pf in ([True, False] if prefetch_ok else [False]):
-                if g:   # graphs: the sparse weight gradients (eager side of the step) on their stream or not.  The dense ones as BRANCHES of
-                    # the backward graph (--mode graph:loader:0:dense,aux) are not a candidate: -0.4 ms on an idle host, 3x slower when
-                    # the host's cores are busy (the runtime orders graph branches with host-side signal handling), r05 measurement
-                    cands += [(g, pf, w, "") for w in ("sparse", "")]
+                if g:   # graphs: the dense weight gradients in a second graph on the side stream (side.GRAPH_DEFER) or inside the chain's
+                    # graph; the sparse ones (eager side of the step) on the side stream or not.  (Weight gradients as BRANCHES of one
+                    # backward graph - S2D_GRAPH_FORK - are not a candidate: -0.4 ms on an idle host, 3x slower when the host's cores are
+                    # busy, r05 measurement: the runtime orders graph branches with host-side signal handling.)
+                    cands += [(g, pf, w, d) for d in ("aux,dense", "") for w in ("sparse", "")]
                 else:
                     cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
         mode, mode_table = calibrate(models, step, dev, cands)

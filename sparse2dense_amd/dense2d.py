@@ -279,6 +279,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.save_for_backward(xb, weight)
         ctx.pad, ctx.stride = pad, stride
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         b = None if bias is None else bias.detach().float().contiguous()
         both = bool(ctx.needs_input_grad[0] and stride == 1)   # this step's backward will ask for the data-gradient operand
         if bn_stats:
@@ -321,7 +322,7 @@ class _Conv3x3Fn(torch.autograd.Function):
                     def both():
                         dwf, dbf = conv3x3_wgrad(xb, dyb, pad, want_db=True)
                         return dwf.to(weight.dtype), dbf
-                    dw, db = _side.run(weight, both, xb, dyb)
+                    dw, db = _side.run(weight, both, xb, dyb, bias=ctx.bias_p, pair=True)
                 else:
                     dw = _side.run(weight, lambda: conv3x3_wgrad(xb, dyb, pad).to(weight.dtype), xb, dyb)
             elif ctx.needs_input_grad[1]:
@@ -337,7 +338,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, dw, db, None, None, None
+        return dx, _side.undefer(dw), _side.undefer(db), None, None, None
 
 
 class Conv3x3(nn.Conv2d):
@@ -480,6 +481,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         b = None if bias is None else bias.detach().float().contiguous()
         if bn_stats:
             y, partial = conv1x1_nhwc(xb, _pack_weights_1x1(weight, False, with_dgrad=ctx.needs_input_grad[0]), b, cin, cout, bn_stats=True)
@@ -508,14 +510,14 @@ class _Conv1x1Fn(torch.autograd.Function):
                 check(lib.s2d_conv2d1x1_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), _ptr(_zero_page(xb.device)), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf),
                                                         _ptr(ws), ws.numel(), _stream()), "s2d_conv2d1x1_wgrad_nhwc_bf16")
                 return dwf.reshape(weight.shape).to(weight.dtype), dbf
-            dw, db = _side.run(weight, wgrad, xb, dyb)
+            dw, db = _side.run(weight, wgrad, xb, dyb, bias=ctx.bias_p, pair=True)
         if ctx.has_bias and ctx.needs_input_grad[2] and db is None:   # per-channel sum of dY: the row-reduce kernel's first output half
             rows = n * h * w
             stats = torch.empty((2 * cout,), dtype=torch.float32, device=dyb.device)
             ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, dw, db, None
+        return dx, _side.undefer(dw), _side.undefer(db), None
 
 
 class Conv1x1(nn.Conv2d):
@@ -556,6 +558,7 @@ class _SmallConv3x3Fn(torch.autograd.Function):
         check(lib.s2d_smallconv3x3_fwd(_ptr(xb), _ptr(wf), _ptr(b), n, h, w, cin, cout, _ptr(y), _stream()), "s2d_smallconv3x3_fwd")
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         return y
 
     @staticmethod
@@ -578,8 +581,8 @@ class _SmallConv3x3Fn(torch.autograd.Function):
                 check(lib.s2d_smallconv3x3_wgrad(_ptr(xb), _ptr(dyf), n, h, w, cin, cout, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(), _stream()),
                       "s2d_smallconv3x3_wgrad")
                 return dwf.to(weight.dtype), (dbf if ctx.has_bias else None)
-            dw, db = _side.run(weight, wgrad, xb, dyf, kind="aux")
-        return dx, dw, db
+            dw, db = _side.run(weight, wgrad, xb, dyf, kind="aux", bias=ctx.bias_p, pair=True)
+        return dx, _side.undefer(dw), _side.undefer(db)
 
 
 class SmallConv3x3(nn.Conv2d):
@@ -626,6 +629,7 @@ class _Conv2x2S2Fn(torch.autograd.Function):
                                             _stream()), "s2d_conv2d2x2s2_nhwc_bf16")
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         if bn_stats:
             ctx.mark_non_differentiable(partial)
             ctx.set_materialize_grads(False)   # no zero-filled gradient tensor for the statistics output in every backward
@@ -647,7 +651,7 @@ class _Conv2x2S2Fn(torch.autograd.Function):
                            .to(weight.dtype), xb, dyb, kind="aux")   # _wgrad_1x1: [cout, (py, px, ci)]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _channel_sums(dyb)
-        return dx, dw, db, None
+        return dx, _side.undefer(dw), _side.undefer(db), None
 
 
 class Conv2x2S2(nn.Conv2d):
@@ -688,6 +692,7 @@ class _DwConv7Fn(torch.autograd.Function):
                                         n, h, w, c, 0, _ptr(y), _stream()), "s2d_dwconv7_nhwc_bf16")
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         return y
 
     @staticmethod
@@ -709,8 +714,8 @@ class _DwConv7Fn(torch.autograd.Function):
                 check(lib.s2d_dwconv7_wgrad_nhwc_bf16(_ptr(xb), _ptr(dyb), n, h, w, c, _ptr(dwf), _ptr(dbf), _ptr(ws), ws.numel(),
                                                       _stream()), "s2d_dwconv7_wgrad_nhwc_bf16")
                 return dwf.to(weight.dtype), dbf
-            dw, db = _side.run(weight, wgrad, xb, dyb, kind="aux")
-        return dx, dw, db
+            dw, db = _side.run(weight, wgrad, xb, dyb, kind="aux", bias=ctx.bias_p, pair=True)
+        return dx, _side.undefer(dw), _side.undefer(db)
 
 
 class DepthwiseConv7(nn.Conv2d):
@@ -993,6 +998,7 @@ class _ConvT2x2S2Fn(torch.autograd.Function):
         y = _depth_to_space(conv1x1_nhwc(xb, packed, b4, cin, 4 * cout), cout)
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         return y
 
     @staticmethod
@@ -1010,7 +1016,7 @@ class _ConvT2x2S2Fn(torch.autograd.Function):
                            xb, dys, kind="aux")   # _wgrad_1x1: [(py, px, co), ci]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _channel_sums(dyb)
-        return dx, dw, db
+        return dx, _side.undefer(dw), _side.undefer(db)
 
 
 class ConvT2x2S2(nn.ConvTranspose2d):
@@ -1119,6 +1125,7 @@ class _ConvT4x4S2Fn(torch.autograd.Function):
         xb = _nhwc_bf16(x)
         ctx.save_for_backward(xb, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         b = None if bias is None else bias.detach().float().contiguous()
         if bn_stats:
             y, partial = conv_up(xb, weight, b, 4, bn_stats=True)
@@ -1137,10 +1144,10 @@ class _ConvT4x4S2Fn(torch.autograd.Function):
         want_db = bool(ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:   # weight and bias gradient: off the chain (side.py)
             dw, db = _side.run(weight, lambda: (conv_s2_wgrad(xb, dyb, 4).to(weight.dtype), _channel_sums(dyb) if want_db else None), xb, dyb,
-                               kind="aux")
+                               kind="aux", bias=ctx.bias_p, pair=True)
         elif want_db:
             db = _channel_sums(dyb)
-        return dx, dw, db, None
+        return dx, _side.undefer(dw), _side.undefer(db), None
 
 
 class ConvT4x4S2(nn.ConvTranspose2d):

@@ -54,7 +54,7 @@ def _static_like(t):
 
 
 class _Capture:
-    __slots__ = ("fwd", "bwd", "s_in", "s_out", "g_idx", "s_gout", "s_gin", "s_gparams", "diff_idx", "params", "pstate", "pool", "stream")
+    __slots__ = ("fwd", "bwd", "bwd2", "keep", "s_in", "s_out", "g_idx", "s_gout", "s_gin", "s_gparams", "diff_idx", "params", "pstate", "pool", "stream")
 
 
 class _Replay(torch.autograd.Function):
@@ -85,6 +85,9 @@ class _Replay(torch.autograd.Function):
                 raise RuntimeError(f"GraphedSegment '{seg.name}': output {i} received a gradient that the captured backward does not cover; "
                                    "call .reset() after changing which losses are used")
         cap.bwd.replay()
+        if cap.bwd2 is not None:   # the weight gradients' graph: on the side stream, beside whatever the caller's backward does next
+            from . import side
+            side.replay_on_side(cap.bwd2, cap.s_in[0].device.index)
         for p, g in zip(cap.params, cap.s_gparams):
             if g is None:
                 continue
@@ -131,7 +134,7 @@ class GraphedSegment:
             return self.fn(*inputs)
         grad_mode = torch.is_grad_enabled()
         from . import side
-        key = (tuple(_sig(t) for t in inputs), grad_mode, torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(), frozenset(side.GRAPH_KINDS))
+        key = (tuple(_sig(t) for t in inputs), grad_mode, torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(), frozenset(side.GRAPH_KINDS), frozenset(side.GRAPH_DEFER))
         cap = self._caps.get(key)
         if cap is not None:
             ps = cap.pstate
@@ -180,7 +183,7 @@ class GraphedSegment:
         """the static buffer input `index` will be copied into at the next replay of the signature `inputs` have (a producer that
         writes there directly saves the copy), or None while that signature has no capture"""
         from . import side
-        key = (tuple(_sig(t) for t in inputs), torch.is_grad_enabled(), torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(), frozenset(side.GRAPH_KINDS))
+        key = (tuple(_sig(t) for t in inputs), torch.is_grad_enabled(), torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype(), frozenset(side.GRAPH_KINDS), frozenset(side.GRAPH_DEFER))
         cap = self._caps.get(key)
         return None if cap is None else cap.s_in[index]
 
@@ -237,20 +240,41 @@ class GraphedSegment:
             outs = tuple(outs)
             cap.s_out = outs
             cap.g_idx = [i for i in g_idx if torch.is_tensor(outs[i]) and outs[i].requires_grad] if grad_mode else []
-            cap.s_gout, cap.s_gin, cap.s_gparams, cap.bwd = [], [], [], None
+            cap.s_gout, cap.s_gin, cap.s_gparams, cap.bwd, cap.bwd2, cap.keep = [], [], [], None, None, None
             if cap.g_idx:
                 cap.s_gout = [torch.zeros_like(outs[i]) for i in cap.g_idx]
                 wrt = [cap.s_in[i] for i in cap.diff_idx] + proxies
                 cap.bwd = torch.cuda.CUDAGraph()
                 from . import side
+                side.take_deferred()
                 with torch.cuda.graph(cap.bwd, pool=cap.pool, stream=cap.stream):
                     grads = torch.autograd.grad([outs[i] for i in cap.g_idx], wrt, cap.s_gout, allow_unused=True)
                     side.join_capture()      # weight-gradient groups forked onto a second capturing stream (side.GRAPH_KINDS) rejoin here
                 side.capture_done()
                 nd = len(cap.diff_idx)
                 cap.s_gin = list(grads[:nd])
-                # a parameter's gradient must obey the parameter's layout (the fused Adam pairs elements by storage offset)
                 cap.s_gparams = list(grads[nd:])
+                # weight-gradient groups the layers queued instead of launching (side.GRAPH_DEFER): a second, linear graph.  Their operands
+                # (layer inputs and output gradients: tensors of the chain's graph) stay referenced by `cap.keep` for the capture's lifetime -
+                # the pool must never hand their blocks to a later capture while this graph can still be replayed.
+                items = side.take_deferred()
+                if items:
+                    slot = {id(q): k for k, q in enumerate(proxies)}
+                    cap.bwd2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cap.bwd2, pool=cap.pool, stream=cap.stream):
+                        for weight, bias, fn, _inputs in items:
+                            out = fn()
+                            dw, db = out if isinstance(out, (tuple, list)) else (out, None)
+                            for prm, g in ((weight, dw), (bias, db)):
+                                if prm is None or g is None or id(prm) not in slot:
+                                    continue
+                                # a parameter's gradient must obey the parameter's layout and dtype (the fused Adam pairs elements by
+                                # storage offset; AccumulateGrad, which would re-lay it, is not in the picture)
+                                if g.shape != prm.shape or g.stride() != prm.stride() or g.dtype != prm.dtype:
+                                    g = torch.empty_like(prm).copy_(g.reshape(prm.shape) if g.shape != prm.shape else g)
+                                assert cap.s_gparams[slot[id(prm)]] is None, "a deferred parameter also received a gradient on the chain"
+                                cap.s_gparams[slot[id(prm)]] = g
+                    cap.keep = items
             cap.s_out = tuple(o.detach() if torch.is_tensor(o) else o for o in outs)
         finally:
             dense2d.WS_PRIVATE = False

@@ -88,10 +88,24 @@ def _event(dev):
     return ev
 
 
-def usable(weight, kind="dense"):
+_pass_ids = {}   # device index -> (graph-task id, ids of the parameters that went to the side stream in that pass)
+
+
+def usable(weight, kind="dense", bias=None):
     if kind not in MODE or not weight.is_cuda or weight.grad is not None:
         return False
     if getattr(weight, "_backward_hooks", None):
+        return False
+    if bias is not None and (bias.grad is not None or getattr(bias, "_backward_hooks", None)):
+        return False   # AccumulateGrad would add into the existing bias.grad in place on the chain, before the join
+    # a parameter that receives a SECOND gradient in one backward pass (a module applied twice, tied weights): the engine sums the two
+    # on the chain's stream without an event from the side stream - the second one takes the plain path behind a join
+    gid = torch._C._current_graph_task_id()
+    ent = _pass_ids.get(weight.device.index)
+    if ent is None or ent[0] != gid:
+        ent = _pass_ids[weight.device.index] = (gid, set())
+    if id(weight) in ent[1]:
+        join(weight.device.index)
         return False
     hooks = getattr(weight, "_post_accumulate_grad_hooks", None)
     if hooks:   # the data-parallel buckets' hooks only count arrivals; dp.GradBuckets._launch joins before it copies gradients
@@ -178,17 +192,82 @@ def capture_done():
         st["keep"].clear()
 
 
-def run(weight, fn, *inputs, kind="dense"):
-    """fn() -> gradient tensor(s) of `weight` (and its bias); on the side stream when the protocol above allows it"""
+# ---- deferral into a graph of their own (r05, the default of the graphed dense segment) -------------------------------------------
+# While graphed.GraphedSegment captures the backward, a weight-gradient group of a kind in GRAPH_DEFER is not launched at all: its
+# closure is queued, the layer's backward returns no gradient for the weight (and bias), and after the chain's graph is closed the
+# queued closures are captured, one after the other, into a SECOND graph.  A step then replays the chain graph on the launch stream -
+# the gradient of the BEV map is out as early as possible - and the weight-gradient graph on the side stream, where it runs beside the
+# eager sparse backward (latency-bound gather kernels next to matrix-core contractions); train_step's side.join() orders the optimizer
+# behind it.  Both graphs are linear chains: no intra-graph branches (see _run_forked: those need host-side signal handling).
+GRAPH_DEFER = _parse(os.environ.get("S2D_GRAPH_DEFER", "dense,aux"))
+_deferred = []          # (weight, bias, fn, inputs) queued by the capture in progress
+_deferred_ids = set()   # id(parameter) queued: a parameter that gets a second gradient in one pass takes the plain path
+
+
+class _Deferred:
+    def __repr__(self):
+        return "<weight gradient deferred to the segment's second graph>"
+
+
+DEFERRED = _Deferred()
+
+
+def undefer(t):
+    """what a layer's backward returns to autograd for a deferred gradient"""
+    return None if t is DEFERRED else t
+
+
+def graph_defer(kinds):
+    """kinds as in S2D_WGRAD_STREAM; takes effect for captures made afterwards"""
+    global GRAPH_DEFER
+    GRAPH_DEFER = _parse(kinds) if isinstance(kinds, str) else _parse("1" if kinds else "0")
+
+
+def take_deferred():
+    items = list(_deferred)
+    _deferred.clear()
+    _deferred_ids.clear()
+    return items
+
+
+def replay_on_side(graph, dev):
+    """launch a captured graph on the side stream behind everything enqueued so far on the current stream; joined like any side work"""
+    side = _side(dev)
+    cur = torch.cuda.current_stream(dev)
+    ev = _event(dev)
+    ev.record(cur)
+    side.wait_event(ev)
+    torch.cuda.set_stream(side)
+    try:
+        graph.replay()
+    finally:
+        torch.cuda.set_stream(cur)
+    _pending[dev] = True
+    gid = torch._C._current_graph_task_id()
+    if gid >= 0 and _queued_for.get(dev) != gid:
+        _queued_for[dev] = gid
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
+
+
+def run(weight, fn, *inputs, kind="dense", bias=None, pair=False):
+    """fn() -> gradient tensor(s) of `weight` (and its bias); on the side stream when the protocol above allows it.
+    bias: the bias parameter when fn returns (dw, db); pair: fn returns a 2-tuple"""
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
-        if kind in GRAPH_KINDS and not torch.is_grad_enabled():
-            return _run_forked(weight, fn, inputs)
+        if not torch.is_grad_enabled():
+            if kind in GRAPH_DEFER and id(weight) not in _deferred_ids:
+                _deferred.append((weight, bias, fn, inputs))
+                _deferred_ids.add(id(weight))
+                stats["deferred"] = stats.get("deferred", 0) + 1
+                return (DEFERRED, DEFERRED) if pair else DEFERRED
+            if kind in GRAPH_KINDS:
+                return _run_forked(weight, fn, inputs)
         stats["plain"] += 1
         return fn()
-    if not usable(weight, kind):
+    if not usable(weight, kind, bias):
         stats["plain"] += 1
         return fn()
     dev = weight.device.index
+    _pass_ids[dev][1].add(id(weight))
     side = _side(dev)
     cur = torch.cuda.current_stream(dev)
     ev = _event(dev)

@@ -133,6 +133,7 @@ class _SparseConvFn(torch.autograd.Function):
         w = weight.reshape(rb.kvol, weight.shape[-2], weight.shape[-1])
         ctx.rb = rb
         ctx.has_bias = bias is not None
+        ctx.bias_p = bias
         ctx.save_for_backward(feat, weight)
         ctx.s16 = feat.dtype == torch.bfloat16
         if ctx.s16:   # bf16 feature storage: gather -> LDS -> MFMA, bf16 out
@@ -167,7 +168,7 @@ class _SparseConvFn(torch.autograd.Function):
                 def wgrad():   # (+ the bias gradient: a pass over dout nobody on the chain waits for)
                     dwf = H.spconv_s16_wgrad(feat, dout, rb.nbr_out, rb.kvol, rb.pair_count)
                     return dwf[:, : weight.shape[-2]].reshape(weight.shape).to(weight.dtype), (H.col_sums_bf16(dout) if db_aside else None)
-                dw, db = side.run(weight, wgrad, feat, dout, rb.nbr_out, kind="sparse")
+                dw, db = side.run(weight, wgrad, feat, dout, rb.nbr_out, kind="sparse", bias=ctx.bias_p if db_aside else None, pair=True)
                 if want_db and not db_aside:
                     db = H.col_sums_bf16(dout)
             elif ctx.has_bias and ctx.needs_input_grad[2]:

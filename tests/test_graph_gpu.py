@@ -18,13 +18,15 @@ def _model(kind, dev):
     return m.to(dev)
 
 
-def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False, fork=""):
+def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False, fork="", defer="dense,aux"):
     from sparse2dense_amd import dense2d, graphed, hip_ops, side
     from sparse2dense_amd.data import SyntheticFrames
     from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
     from sparse2dense_amd.train_step import backward_and_step
     side.enable(False)
     side.graph_fork(fork if fork else False)
+    side.graph_defer(defer if defer else False)
+    side.stats["deferred"] = 0
     dense2d.clear_pack_cache()
     hip_ops.set_sparse_compute_dtype("s16")
     dev = torch.device("cuda:0")
@@ -62,6 +64,7 @@ def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False
         st = dict(graphed.stats)
     finally:
         side.graph_fork(False)
+        side.graph_defer("dense,aux")
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
     return losses, final, grads, bn, st
@@ -80,11 +83,16 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("kind", ["s2d_student", "centerpoint_voxelnet"])
-def test_training_run_is_independent_of_the_graph_replay(kind):
+@pytest.mark.parametrize("defer", ["dense,aux", ""])
+def test_training_run_is_independent_of_the_graph_replay(kind, defer):
+    """defer = the layer kinds whose weight gradients are captured into a second graph that is replayed on the side stream beside the eager
+    sparse backward (side.GRAPH_DEFER, the default); "" = everything in the chain's graph"""
+    from sparse2dense_amd import side
     ref = _run(False, kind=kind)
     assert ref[4]["replay"] == 0
-    got = _run(True, kind=kind)
+    got = _run(True, kind=kind, defer=defer)
     assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]    # 2 eager warm-up calls, then capture + replays
+    assert (side.stats["deferred"] > 20) == bool(defer), side.stats
     _same(got, ref, kind)
     assert ref[0][-1] != ref[0][0]
 
@@ -95,7 +103,7 @@ def test_weight_gradients_as_branches_of_the_backward_graph():
     from sparse2dense_amd import side
     ref = _run(False)
     side.stats["forked"] = 0
-    got = _run(True, fork="dense,aux")
+    got = _run(True, fork="dense,aux", defer="")
     assert side.stats["forked"] > 20, side.stats
     assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]
     _same(got, ref, "forked weight gradients")
