@@ -28,6 +28,7 @@ Outputs are views of static buffers: they are valid until the segment's next cal
 """
 import os
 import threading
+import time
 
 import torch
 
@@ -37,7 +38,7 @@ import torch
 CAPTURE_LOCK = threading.RLock()
 
 WARMUP = int(os.environ.get("S2D_GRAPH_WARMUP", "2"))
-stats = {"eager": 0, "capture": 0, "replay": 0, "dropped": 0}
+stats = {"eager": 0, "capture": 0, "replay": 0, "dropped": 0, "launch_host_ms": 0.0}   # launch_host_ms: host time spent inside hipGraphLaunch calls
 
 
 def enabled():
@@ -64,7 +65,9 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, seg, cap, anchor, *diff_inputs):
         ctx.seg, ctx.cap = seg, cap
+        t0 = time.perf_counter()
         cap.fwd.replay()
+        stats["launch_host_ms"] += (time.perf_counter() - t0) * 1e3
         outs = tuple(o.detach() for o in cap.s_out)
         ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i not in cap.g_idx])
         ctx.set_materialize_grads(False)
@@ -84,7 +87,9 @@ class _Replay(torch.autograd.Function):
                 # an output that received no gradient during the warm-up now has one: this capture cannot deliver it
                 raise RuntimeError(f"GraphedSegment '{seg.name}': output {i} received a gradient that the captured backward does not cover; "
                                    "call .reset() after changing which losses are used")
+        t0 = time.perf_counter()
         cap.bwd.replay()
+        stats["launch_host_ms"] += (time.perf_counter() - t0) * 1e3
         if cap.bwd2 is not None:   # the weight gradients' graph: on the side stream, beside whatever the caller's backward does next
             from . import side
             side.replay_on_side(cap.bwd2, cap.s_in[0].device.index)

@@ -275,9 +275,9 @@ DEV = "cuda"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("filters", [(64,), (64, 64)])
+@pytest.mark.parametrize("filters,P", [((64,), 3000), ((64, 64), 3000), ((64, 64), 128000)])   # 128 000 = the benchmark's 4 x 32 000 pillars (rule 31)
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters):
+def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters, P):
     """csrc/pfn.hip (decorate -> Linear -> BatchNorm1d -> ReLU -> max in two recomputing passes + one backward pass) against the
     layer-by-layer PillarFeatureNet (pillar_encoder.py:41-56,114-154 restated on torch ops; pinned to the reference by
     pillar_*.npz above) evaluated in float64 on the host: output 1e-5, every parameter gradient 1e-4, running statistics 1e-5.
@@ -287,12 +287,12 @@ def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters):
     from sparse2dense_amd.pillars import PillarFeatureNet
     torch.manual_seed(3)
     rs = np.random.RandomState(4)
-    P, T = 3000, 20
+    T = 20
     num = rs.randint(1, T + 1, P).astype(np.int32)
     num[:50] = T
     vox = rs.randn(P, T, 5).astype(np.float32) * np.array([20, 20, 1.5, 0.5, 0.1], np.float32)
     vox *= (np.arange(T)[None, :] < num[:, None])[:, :, None]
-    coors = np.stack([rs.randint(0, 2, P), np.zeros(P, np.int64), rs.randint(0, 468, P), rs.randint(0, 468, P)], 1).astype(np.int32)
+    coors = np.stack([rs.randint(0, 4 if P > 3000 else 2, P), np.zeros(P, np.int64), rs.randint(0, 468, P), rs.randint(0, 468, P)], 1).astype(np.int32)
     net = PillarFeatureNet(num_input_features=5, num_filters=filters, voxel_size=(0.32, 0.32, 6.0), pc_range=(-74.88, -74.88, -2, 74.88, 74.88, 4.0))
     assert len(net.pfn_layers) == len(filters)
     with torch.no_grad():
@@ -329,7 +329,7 @@ def test_fused_pfn_matches_the_layer_by_layer_reader_in_float64(train, filters):
     for (n, p), (_, q) in zip(dev.named_parameters(), ref.named_parameters()):
         assert _rel(p.grad, q.grad) <= 2e-2, (n, _rel(p.grad, q.grad))
         el = ((p.grad.double().cpu() - q.grad).abs() / (q.grad.abs() + 1e-3 * q.grad.abs().max())).flatten()
-        assert float(el.median()) <= 1e-4, (n, float(el.median()))
+        assert float(el.median()) <= (1e-4 if P <= 10000 else 1e-3), (n, float(el.median()))   # (fp32 sums over 2.5 M point rows at 4 x 32 000 pillars)
     if train:
         for a, b in zip(dev.pfn_layers, ref.pfn_layers):
             assert _rel(a.norm.running_mean, b.norm.running_mean) <= 1e-5
