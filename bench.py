@@ -415,7 +415,7 @@ def roofline_pass(step, n_steps=3):
                                         avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1),
                                         frac=round(r["tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4)) for r in sg_rows])
     if not rows:
-        return None, [], rulebook, sparse_gemm, voxelize
+        return None, [], rulebook, sparse_gemm, voxelize, None
 
     # the dominant KERNEL is a device function (what rocprofv3 --stats lists); one template instantiation serves several
     # tensor shapes, so group the per-shape rows by instantiation before ranking
@@ -423,6 +423,20 @@ def roofline_pass(step, n_steps=3):
         if r["kernel"].startswith("conv3x3_"):
             return r["kernel"]
         return f"{r['kernel']}<{r['cin']}, {r['cout']}>"
+    wgrad_rows = [r for r in rows if r["kernel"].startswith("conv3x3_wgrad")]
+    roofline_wgrad = None
+    if wgrad_rows:   # the weight-gradient sibling of the dominant dense kernel: same FLOPs per layer (2 M 9 Cin Cout), its own event-timed figure
+        ms = sum(r["total_ms"] for r in wgrad_rows)
+        fl = sum(r["tflops"] * 1e12 * r["total_ms"] * 1e-3 for r in wgrad_rows)
+        n_l = sum(r["launches"] for r in wgrad_rows)
+        tf = fl / (ms * 1e-3) / 1e12
+        roofline_wgrad = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_BF16_MATRIX_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_MATRIX_TFLOPS, 4),
+                              traffic=None, kernel="s2d::conv3x3_wgrad_kernel<TCO, TCI, 3, 1, 3> + s2d::conv3x3_wgrad_reduce_kernel (one event pair per layer)",
+                              launches_per_step=n_l // n_steps, avg_launch_us=round(ms / n_l * 1e3, 2),
+                              shapes=[dict(cin=r["cin"], cout=r["cout"], rows_out=r["n_out"], launches_per_step=r["launches"] // n_steps,
+                                           avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1)) for r in wgrad_rows],
+                              scope="weight gradients of the stride-1 3x3 convs of the BEV neck / head (transpose-read contraction over the pixels + split-K fold)")
+    rows = [r for r in rows if not r["kernel"].startswith("conv3x3_wgrad")]
     groups = {}
     for r in rows:
         g = groups.setdefault(template_of(r), dict(rows=[], ms=0.0, n=0, flops=0.0, bytes=0.0))
@@ -466,7 +480,7 @@ def roofline_pass(step, n_steps=3):
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), **common)
     else:
         roof = dict(bound="mfma", achieved=round(tflops, 3), peak=peak_tf, unit="TFLOP/s", frac=round(tflops / peak_tf, 4), **common)
-    return roof, rows, rulebook, sparse_gemm, voxelize
+    return roof, rows, rulebook, sparse_gemm, voxelize, roofline_wgrad
 
 
 def stats_top_kernels():
@@ -773,9 +787,9 @@ def main():
         frames.close()
         frames = frames.frames
     stats = scene_stats(model, frames) if rank == 0 else {}
-    roof, rows, rulebook, sparse_gemm, voxelize = (None, [], None, None, None)
+    roof, rows, rulebook, sparse_gemm, voxelize, roofline_wgrad = (None, [], None, None, None, None)
     if single and not args.no_roofline:
-        roof, rows, rulebook, sparse_gemm, voxelize = roofline_pass(step.sync_step)
+        roof, rows, rulebook, sparse_gemm, voxelize, roofline_wgrad = roofline_pass(step.sync_step)
     loss_value = round(float(loss.item()), 4)
 
     others = {}
@@ -812,6 +826,39 @@ def main():
                 others[name] = dict(error=repr(e))
         from sparse2dense_amd import hip_ops as _H
         _H.set_sparse_compute_dtype(args.sparse_dtype)
+        # the whole N>1 route at ONE rank: a one-rank RCCL process group with the data-parallel machinery forced on -
+        # self-synchronising batch norms (an all-reduce of every [2C+1] statistics vector, forward and backward), gradient buckets on their own
+        # process group, fused Adam on the bucket views - i.e. the collective overhead a step carries before any real exchange.  Eager launch
+        # mode (the dense graphs stay off while batch norms issue collectives, graphed.py), data pipeline as chosen above.
+        try:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ["S2D_FORCE_DDP"] = "1"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+            a2 = copy.copy(args)
+            m2, t2, f2, st2 = setup_workload(a2, "s2d_student", dev, rank)
+            ddp_mode = (False, mode[1], "", "")
+            set_mode([getattr(m2, "module", m2), t2], ddp_mode)
+            run2 = st2 if (ddp_mode[1] and st2.sync_step is not st2) else st2.sync_step
+            k, d2 = max(5, min(args.steps, 10)), {}
+            el, _ = timed(run2, k, 3, 1, dev, d2)
+            if hasattr(f2, "close"):
+                f2.close()
+            from sparse2dense_amd import collective
+            others["s2d_student_ddp1"] = dict(workload=WORKLOAD_NAMES["s2d_student"] + " - the N>1 route (SyncBN all-reduces, gradient buckets) on a one-rank RCCL group",
+                                              value=round(args.batch * k / el, 3), unit="frames/s", ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=3,
+                                              frames_per_gpu=args.batch, device_ms_per_step=d2.get("device_ms_per_step"), mode=mode_name(ddp_mode),
+                                              gradient_allreduce=dp.dp_mode(), syncbn_route=("library RCCL communicator" if collective.direct_enabled() else "torch.distributed"))
+            del m2, t2, f2, st2
+            torch.cuda.empty_cache()
+        except Exception as e:
+            others["s2d_student_ddp1"] = dict(error=repr(e)[:300])
+        finally:
+            os.environ.pop("S2D_FORCE_DDP", None)
+            set_mode([], mode)
     base = None
     if single and not args.no_cpu_baseline:
         base = cpu_baseline_subprocess(args)
@@ -844,7 +891,7 @@ def main():
                                          + str(graph_stats) if graph_stats and graph_stats.get("replay") else "launched kernel by kernel"),
                        "loss": loss_value, "scene": stats},
             "step_breakdown": detail,
-            "roofline": roof, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "voxelize": voxelize, "cpu_baseline": base,
+            "roofline": roof, "roofline_wgrad": roofline_wgrad, "sparse_gemm": sparse_gemm, "rulebook": rulebook, "voxelize": voxelize, "cpu_baseline": base,
         }
         if others:
             out["other_workloads"] = others

@@ -262,8 +262,18 @@ def conv3x3_wgrad(x, dy, pad, want_db=False):
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
     ws = _ws(lib.s2d_conv2d3x3_wgrad_workspace_bytes(n, h, w, cin, cout, pad), x.device)
+    from . import hip_ops as H
+    rec = None
+    if H.PROFILE is not None:   # bench.py roofline pass (`roofline_wgrad`): the transpose-read contraction + its split-K fold, one event pair
+        rec = dict(kernel="conv3x3_wgrad", tag="dense_wgrad", cin=cin, cout=cout, n_out=n * dy.shape[2] * dy.shape[3], kvol=9, pairs=None, dense=True,
+                   in_pixels=n * h * w, pad=pad, stride=1, kname="conv3x3_wgrad_kernel + conv3x3_wgrad_reduce_kernel",
+                   start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
     check(lib.s2d_conv2d3x3_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(_zero_page(x.device)), n, h, w, cin, cout, pad, _ptr(dw), _ptr(db), _ptr(ws),
                                             ws.numel(), _stream()), "s2d_conv2d3x3_wgrad_nhwc_bf16")
+    if rec is not None:
+        rec["end"].record()
+        H.PROFILE.append(rec)
     return (dw, db) if want_db else dw
 
 
