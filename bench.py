@@ -742,7 +742,7 @@ def main():
                     # graph; the sparse ones (eager side of the step) on the side stream or not.  (Weight gradients as BRANCHES of one
                     # backward graph - S2D_GRAPH_FORK - are not a candidate: -0.4 ms on an idle host, 3x slower when the host's cores are
                     # busy, r05 measurement: the runtime orders graph branches with host-side signal handling.)
-                    cands += [(g, pf, w, d) for d in ("aux,dense", "") for w in ("sparse", "")]
+                    cands += [(g, pf, w, d) for d in ("aux,dense,pcr", "aux,dense", "") for w in ("sparse", "")]
                 else:
                     cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
         mode, mode_table = calibrate(models, step, dev, cands)

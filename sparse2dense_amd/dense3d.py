@@ -82,6 +82,7 @@ class _PwConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w2d)
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None
+        ctx.weight_p, ctx.bias_p = weight, bias   # (the parameters themselves: side.run hands deferred gradients to them)
         return pointwise_conv(x, w2d, bias)
 
     @staticmethod
@@ -96,8 +97,14 @@ class _PwConvFn(torch.autograd.Function):
             n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
             pos = x[0, 0].numel()
             if pos % 4 == 0:   # streaming reduction over the positions (csrc/convt3d_mfma.hip pw_wgrad_*)
-                dw, db = pointwise_conv_wgrad(x, dout, want_db, ctx.bf16)
-                dw = dw.reshape(ctx.wshape)
+                from . import side
+
+                def wgrad():
+                    dwf, dbf = pointwise_conv_wgrad(x, dout, want_db, ctx.bf16)
+                    return dwf.reshape(ctx.wshape), dbf
+                # kind "pcr": never on the eager weight-gradient stream (r04: not bit-equal there), but part of the graphed segment's second graph
+                dw, db = side.run(ctx.weight_p, wgrad, x, dout, kind="pcr", bias=ctx.bias_p if want_db else None, pair=True)
+                dw, db = side.undefer(dw), side.undefer(db)
             else:
                 dw = torch.matmul(dout.reshape(n, cout, -1), x.reshape(n, cin, -1).transpose(1, 2)).sum(0).reshape(ctx.wshape)
                 db = dout.sum(dim=[0] + list(range(2, dout.dim()))) if want_db else None
@@ -128,6 +135,7 @@ class _ConvT3dFn(torch.autograd.Function):
         the RAW tensor and the kernels normalise it on load (forward and weight gradient; bf16-stored output and gradient only)"""
         lib = _lib.load()
         x = x.contiguous()
+        weight_param = weight
         weight = weight.contiguous()
         n, cin, d, h, w = x.shape
         cout = weight.shape[1]
@@ -161,6 +169,7 @@ class _ConvT3dFn(torch.autograd.Function):
                   "s2d_convt3d_k4s2p1_fwd_f32")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.weight_p = weight_param
         if bn_stats:
             if stats is None:   # fp32 kernels: the separate statistics pass
                 stats = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(out),), n, cout, out[0, 0].numel(), x.device)
@@ -194,7 +203,7 @@ class _ConvT3dFn(torch.autograd.Function):
             else:
                 check(lib.s2d_convt3d_k4s2p1_dgrad_f32(_ptr(dout), _ptr(weight), n, cin, cout, d, h, w, _ptr(dx), _stream()),
                       "s2d_convt3d_k4s2p1_dgrad_f32")
-        if ctx.needs_input_grad[1]:
+        def wgrad():
             dw = torch.empty_like(weight)
             if d16 and in_norm is not None:
                 ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
@@ -221,6 +230,13 @@ class _ConvT3dFn(torch.autograd.Function):
                         for kx in range(4):
                             sl = dp[:, :, kz:kz + 2 * d:2, ky:ky + 2 * h:2, kx:kx + 2 * w:2].reshape(n, cout, -1)
                             dw[:, :, kz, ky, kx] = torch.matmul(xf, sl.transpose(1, 2)).sum(0)
+            return dw
+        if ctx.needs_input_grad[1]:
+            from . import side
+            wp = getattr(ctx, "weight_p", None)
+            # (kind "pcr": deferred into the graphed segment's second graph, never on the eager weight-gradient stream; callers that
+            # compose this backward - heads._UpsampleLevelFn - strip the DEFERRED marker)
+            dw = side.run(wp, wgrad, x, dout, kind="pcr") if wp is not None else wgrad()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if dout_sum is not None:
                 db = dout_sum
@@ -230,7 +246,10 @@ class _ConvT3dFn(torch.autograd.Function):
                 db = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, cout, dout[0, 0].numel(), x.device)[:cout]
             else:
                 db = dout.sum(dim=(0, 2, 3, 4))
-        return dx, dw, db, None, None, None
+        if not isinstance(ctx, torch.autograd.function.FunctionCtx):   # composed by heads._UpsampleLevelFn: it strips the marker itself
+            return dx, dw, db, None, None, None
+        from . import side as _side
+        return dx, _side.undefer(dw), db, None, None, None
 
 
 def _hip_ok(x):

@@ -363,6 +363,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
         ctx.save_for_backward(y, norm, hp, coors, feats, out, w2d, gamma, mean, invstd, count)
         ctx.shapes = (w_mask.shape, w_off.shape, None if w2 is None else w2.shape, b2 is not None)
         ctx.bf16, ctx.sync = bool(bf16), sync
+        ctx.w2_p, ctx.b2_p = w2, b2   # (the parameters themselves: side.run hands deferred gradients to them)
         return out[0], out[1], z
 
     @staticmethod
@@ -406,8 +407,15 @@ class _PcrLevelNormFn(torch.autograd.Function):
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None
         if co:
-            dw2, db2 = pointwise_conv_wgrad(y, dz, has_b2, ctx.bf16, norm=norm)
-            dw2 = dw2.reshape(w2_shape)
+            from . import side
+
+            def wgrad():
+                dwf, dbf = pointwise_conv_wgrad(y, dz, has_b2, ctx.bf16, norm=norm)
+                return dwf.reshape(w2_shape), dbf
+            # kind "pcr": part of the graphed segment's second graph (side.GRAPH_DEFER), never on the eager weight-gradient stream
+            dw2, db2 = side.run(ctx.w2_p, wgrad, y, dz, norm, kind="pcr", bias=ctx.b2_p if has_b2 else None, pair=True)
+            if isinstance(ctx, torch.autograd.function.FunctionCtx):   # (composed by _UpsampleLevelFn otherwise: it strips the marker)
+                dw2, db2 = side.undefer(dw2), side.undefer(db2)
         return (dy, dgamma, dbeta, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:],
                 None, None, dw2, db2, None, None, None, None)
 
@@ -489,7 +497,9 @@ class _UpsampleLevelFn(torch.autograd.Function):
             pre_gamma, mean, invstd, count, scale, shift, sync = ctx.pre
             x = ctx.c1.saved_tensors[0]
             dx, dpg, dpb = bncm_backward(dx, x, pre_gamma, mean, invstd, count, scale, shift, True, sync, True, ctx.needs_input_grad[0])
-        return dx, dw, db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, dw2, db2, None, None, None, None, dpg, dpb, None, None
+        from . import side
+        u = side.undefer
+        return dx, u(dw), db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, u(dw2), u(db2), None, None, None, None, dpg, dpb, None, None
 
 
 def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True, pre_bn=None):

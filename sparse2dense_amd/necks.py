@@ -355,7 +355,20 @@ class S2D_RPN(RPN):
                 gen_offset_2 = self.gen_out_2(gen)
         return gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4
 
-    def forward(self, x):
+    def forward_s2d(self, x):
+        """the S2D module + the PCR head (rpn.py:186-296,300-325): everything of `forward` in front of the RPN trunk ->
+        (gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b).  `forward` = forward_s2d + forward_trunk; the detector's graphed
+        path replays the two halves as separate HIP-graph segments (detectors.KD_VoxelNet._dense_call)."""
+        out = self.forward(x, _stop_before_trunk=True)
+        return out[1:]
+
+    def forward_trunk(self, F_S_a):
+        """the RPN trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)"""
+        if self.trunk_channels_last and F_S_a.is_cuda:
+            F_S_a = F_S_a.contiguous(memory_format=torch.channels_last)
+        return self._trunk(F_S_a, relu_between=False)
+
+    def forward(self, x, _stop_before_trunk=False):
         if self.trunk_channels_last and x.is_cuda:   # NHWC end to end: conv, batch norm and GELU all keep the layout
             x = x.contiguous(memory_format=torch.channels_last)
         y_1 = self.encoder_1(x)
@@ -384,7 +397,7 @@ class S2D_RPN(RPN):
         else:
             gen_offset_2 = gen_mask_2 = gen_offset_4 = gen_mask_4 = None
         # the trunk WITHOUT the outer ReLU of RPN.forward (rpn.py:327-331 vs :156)
-        out = self._trunk(F_S_a, relu_between=False)
+        out = None if _stop_before_trunk else self._trunk(F_S_a, relu_between=False)
         if side is not None:
             cur.wait_stream(side)
             for t in _tensors_in((gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4)):

@@ -32,7 +32,7 @@ import os
 
 import torch
 
-KINDS = ("dense", "sparse", "aux")
+KINDS = ("dense", "sparse", "aux", "pcr")   # pcr: the PCR head's up-sampler / 1x1x1 weight gradients - deferral into the segment's second graph only
 
 
 def _parse(v):
@@ -41,7 +41,7 @@ def _parse(v):
     (The PCR head's up-samplers were tried too: time-neutral - their weight gradients are chip-filling streams - and not wired.)"""
     v = (v or "0").strip().lower()
     if v in ("1", "all"):
-        return set(KINDS)
+        return set(KINDS) - {"pcr"}
     return {k for k in v.split(",") if k in KINDS}
 
 
@@ -125,6 +125,10 @@ def join(device=None):
             torch.cuda.current_stream(dev).wait_stream(_streams[dev])
             _pending[dev] = False
             _keep[dev].clear()   # everything enqueued on this stream from here on is ordered behind the side work
+    for dev, on in list(_gpending.items()):
+        if on and (device is None or dev == device):
+            torch.cuda.current_stream(dev).wait_stream(_gstreams[dev])
+            _gpending[dev] = False
 
 
 def stream_after(dev):
@@ -199,7 +203,7 @@ def capture_done():
 # the gradient of the BEV map is out as early as possible - and the weight-gradient graph on the side stream, where it runs beside the
 # eager sparse backward (latency-bound gather kernels next to matrix-core contractions); train_step's side.join() orders the optimizer
 # behind it.  Both graphs are linear chains: no intra-graph branches (see _run_forked: those need host-side signal handling).
-GRAPH_DEFER = _parse(os.environ.get("S2D_GRAPH_DEFER", "dense,aux"))
+GRAPH_DEFER = _parse(os.environ.get("S2D_GRAPH_DEFER", "dense,aux,pcr"))
 _deferred = []          # (weight, bias, fn, inputs) queued by the capture in progress
 _deferred_ids = set()   # id(parameter) queued: a parameter that gets a second gradient in one pass takes the plain path
 
@@ -230,19 +234,26 @@ def take_deferred():
     return items
 
 
+_gstreams = {}    # device index -> the stream the segment's weight-gradient graph is replayed on (its own: the eager weight-gradient groups of
+_gpending = {}    # the sparse layers keep the side stream to themselves and run beside it)
+
+
 def replay_on_side(graph, dev):
-    """launch a captured graph on the side stream behind everything enqueued so far on the current stream; joined like any side work"""
-    side = _side(dev)
+    """launch a captured graph on the graph stream behind everything enqueued so far on the current stream; joined like any side work"""
+    _side(dev)   # (event ring)
+    gs = _gstreams.get(dev)
+    if gs is None:
+        gs = _gstreams[dev] = torch.cuda.Stream(device=dev)
     cur = torch.cuda.current_stream(dev)
     ev = _event(dev)
     ev.record(cur)
-    side.wait_event(ev)
-    torch.cuda.set_stream(side)
+    gs.wait_event(ev)
+    torch.cuda.set_stream(gs)
     try:
         graph.replay()
     finally:
         torch.cuda.set_stream(cur)
-    _pending[dev] = True
+    _gpending[dev] = True
     gid = torch._C._current_graph_task_id()
     if gid >= 0 and _queued_for.get(dev) != gid:
         _queued_for[dev] = gid

@@ -123,7 +123,7 @@ def test_s2d_student_step_at_benchmark_size_bf16_vs_fp32_and_across_execution_mo
     # the dense segment replayed as HIP graphs: third pass = first replay, fifth = third replay (a memset node inside the graph went
     # out of order from the FOURTH replay on, r05); no optimizer step in between, so every pass must reproduce the eager gradients
     tg, gg, st = _one_step("s2d_student", "bf16", graph=True, passes=7)
-    assert st["capture"] >= 1 and st["replay"] >= 5, st
+    assert st["capture"] >= 1 and st["replay"] >= 5 * st["capture"], st
     assert tg == t16, (tg, t16)
     for n, g in g16.items():
         assert (g is None) == (gg[n] is None) and (g is None or torch.equal(g, gg[n])), ("HIP graphs", n)

@@ -18,11 +18,13 @@ def _model(kind, dev):
     return m.to(dev)
 
 
-def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False, fork="", defer="dense,aux"):
+def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False, fork="", defer="dense,aux,pcr", split="0"):
     from sparse2dense_amd import dense2d, graphed, hip_ops, side
     from sparse2dense_amd.data import SyntheticFrames
     from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
     from sparse2dense_amd.train_step import backward_and_step
+    import os
+    os.environ["S2D_GRAPH_SPLIT"] = split   # "1": the S2D student's dense part as two graphed segments in sequence (detectors.KD_VoxelNet._dense_call)
     side.enable(False)
     side.graph_fork(fork if fork else False)
     side.graph_defer(defer if defer else False)
@@ -63,8 +65,9 @@ def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False
         bn = torch.cat([b.detach().flatten()[:16].double().cpu() for b in model.buffers()])
         st = dict(graphed.stats)
     finally:
+        os.environ.pop("S2D_GRAPH_SPLIT", None)
         side.graph_fork(False)
-        side.graph_defer("dense,aux")
+        side.graph_defer("dense,aux,pcr")
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
     return losses, final, grads, bn, st
@@ -82,16 +85,17 @@ def _same(a, b, what):
             assert torch.equal(g, r), what
 
 
-@pytest.mark.parametrize("kind", ["s2d_student", "centerpoint_voxelnet"])
-@pytest.mark.parametrize("defer", ["dense,aux", ""])
-def test_training_run_is_independent_of_the_graph_replay(kind, defer):
+@pytest.mark.parametrize("kind,split", [("s2d_student", "1"), ("s2d_student", "0"), ("centerpoint_voxelnet", "1")])
+@pytest.mark.parametrize("defer", ["dense,aux,pcr", "dense,aux", ""])
+def test_training_run_is_independent_of_the_graph_replay(kind, split, defer):
     """defer = the layer kinds whose weight gradients are captured into a second graph that is replayed on the side stream beside the eager
     sparse backward (side.GRAPH_DEFER, the default); "" = everything in the chain's graph"""
     from sparse2dense_amd import side
     ref = _run(False, kind=kind)
     assert ref[4]["replay"] == 0
-    got = _run(True, kind=kind, defer=defer)
-    assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]    # 2 eager warm-up calls, then capture + replays
+    got = _run(True, kind=kind, defer=defer, split=split)
+    segs = 2 if (kind == "s2d_student" and split == "1") else 1
+    assert got[4]["capture"] == segs and got[4]["replay"] == 4 * segs, got[4]    # 2 eager warm-up calls, then capture + replays
     assert (side.stats["deferred"] > 20) == bool(defer), side.stats
     _same(got, ref, kind)
     assert ref[0][-1] != ref[0][0]
@@ -103,7 +107,7 @@ def test_weight_gradients_as_branches_of_the_backward_graph():
     from sparse2dense_amd import side
     ref = _run(False)
     side.stats["forked"] = 0
-    got = _run(True, fork="dense,aux", defer="")
+    got = _run(True, fork="dense,aux", defer="", split="0")
     assert side.stats["forked"] > 20, side.stats
     assert got[4]["capture"] == 1 and got[4]["replay"] == 4, got[4]
     _same(got, ref, "forked weight gradients")
