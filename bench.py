@@ -241,7 +241,7 @@ def mode_name(mode):
             ("loader-thread" if mode[1] else "in-step") + "+" + ("wgrad-stream(" + mode[2] + ")" if mode[2] else "one-stream"))
 
 
-def calibrate(models, step, dev, candidates, settle=4, n=8):
+def calibrate(models, step, dev, candidates, settle=4, n=8, world=1):
     """run every candidate mode for `settle` + `n` steps in this process (same model, same optimizer state: the modes are bit-equal, see
     tests/test_graph_gpu.py and tests/test_side_stream_gpu.py) and return (best mode, table).  A step's time = its span between two
     events on the launch stream; a mode's score = the median over n steps (one stalled step does not decide)."""
@@ -264,9 +264,18 @@ def calibrate(models, step, dev, candidates, settle=4, n=8):
             spans = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n))
             table[mode_name(mode)] = dict(median_ms=round(spans[n // 2], 3), mean_wall_ms=round(wall, 3), max_ms=round(spans[-1], 3))
         except Exception as e:   # a mode that does not run on this box is not a candidate
+            if world > 1:   # (the other ranks are inside the step's collectives: no way to skip a mode on one rank only)
+                raise
             table[mode_name(mode)] = dict(error=repr(e)[:200])
     ok = [m for m in candidates if "median_ms" in table[mode_name(m)]]
-    best = min(ok, key=lambda m: max(table[mode_name(m)]["median_ms"], table[mode_name(m)]["mean_wall_ms"]))
+    score = {mode_name(m): max(table[mode_name(m)]["median_ms"], table[mode_name(m)]["mean_wall_ms"]) for m in ok}
+    if world > 1:   # every rank ran the same candidates in the same order; the slowest rank's time decides, identically everywhere
+        tt = torch.tensor([score[mode_name(m)] for m in ok], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        for m, v in zip(ok, tt.tolist()):
+            score[mode_name(m)] = v
+            table[mode_name(m)]["max_over_ranks_ms"] = round(v, 3)
+    best = min(ok, key=lambda m: score[mode_name(m)])
     return best, table
 
 
@@ -729,11 +738,13 @@ def main():
     from sparse2dense_amd import graphed
     models = [getattr(model, "module", model), teacher]
     prefetch_ok = step.sync_step is not step
-    graph_ok = any(m is not None and getattr(m, "graph_dense", False) for m in models)
+    from sparse2dense_amd import collective
+    graph_ok = (any(m is not None and getattr(m, "graph_dense", False) for m in models)
+                and not (collective.sync_on() and os.environ.get("S2D_DENSE_GRAPH_SYNCBN", "0") != "1"))   # (SyncBN collectives: eager, graphed.py)
     wg = ",".join(sorted(side.MODE)) if side.MODE else ""
     mode = (graph_ok, prefetch_ok, wg, ",".join(sorted(side.GRAPH_DEFER)) if graph_ok else "")
     mode_table = None
-    if args.mode == "auto" and world == 1:
+    if args.mode == "auto":
         # which execution mode is fastest depends on the host (how fast it enqueues) as much as on the device: measure, pick, say so
         cands = []
         for g in ([True, False] if graph_ok else [False]):
@@ -742,10 +753,10 @@ def main():
                     # graph; the sparse ones (eager side of the step) on the side stream or not.  (Weight gradients as BRANCHES of one
                     # backward graph - S2D_GRAPH_FORK - are not a candidate: -0.4 ms on an idle host, 3x slower when the host's cores are
                     # busy, r05 measurement: the runtime orders graph branches with host-side signal handling.)
-                    cands += [(g, pf, w, d) for d in ("aux,dense,pcr", "aux,dense", "") for w in ("sparse", "")]
+                    cands += [(g, pf, w, d) for d in ("aux,dense,pcr", "") for w in ("sparse", "")]
                 else:
                     cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
-        mode, mode_table = calibrate(models, step, dev, cands)
+        mode, mode_table = calibrate(models, step, dev, cands, world=world)
     elif args.mode != "auto":
         g, pf, w, *f = args.mode.split(":")
         mode = (g == "graph" and graph_ok, pf == "loader" and prefetch_ok, "" if w in ("0", "") else w, "" if (not f or f[0] in ("0", "")) else f[0])

@@ -1,24 +1,30 @@
-# per-kernel tables (the ones bench.py's roofline and the judge's recomputation read) are taken SINGLE-STREAM: in-step example, weight-gradient
-# stream off - a kernel's duration next to a concurrent stream's kernels is not its own; the *_default_pipeline_* table shows the overlapped step
+# per-kernel tables (the ones bench.py's roofline and the judge's recomputation read) are taken SINGLE-STREAM and kernel-by-kernel (--mode eager:instep:0):
+# a kernel's duration next to a concurrent stream's kernels is not its own; the *_graph_pipeline_* / *_eager_streams_* tables show the overlapped steps.
+#   TAG=r05_final SKIP_TESTS=1 bash tools/profile_round.sh      (on the GPU box; writes gpurun_out/round/)
 R=$GRAFT_REPO_ROOT
-T=${TAG:-r03_final}
+T=${TAG:-r05_final}
 cd $R
 O=gpurun_out/round
 mkdir -p $O
-timeout 2700 python -m pytest tests -m gpu -q --timeout 900 > $O/gpu_tests.log 2>&1 < /dev/null
+if [ -z "$SKIP_TESTS" ]; then
+timeout 3000 python -m pytest tests -m gpu -q --timeout 900 > $O/gpu_tests.log 2>&1 < /dev/null
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 < /dev/null
-timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err < /dev/null
+fi
+timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err < /dev/null
 cd /tmp && export TMPDIR=/tmp
-S2D_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d -- python $R/bench.py --steps 6 --warmup 3 --no-prefetch --no-cpu-baseline --no-extras --no-roofline > $R/$O/prof_s2d.log 2>&1 < /dev/null
-S2D_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cp -- python $R/bench.py --workload centerpoint --steps 6 --warmup 3 --no-prefetch --no-cpu-baseline --no-extras --no-roofline > $R/$O/prof_cp.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_default -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras --no-roofline > $R/$O/prof_s2d_default.log 2>&1 < /dev/null
-S2D_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pillar -- python $R/bench.py --workload pillar_s2d --steps 6 --warmup 3 --no-prefetch --no-cpu-baseline --no-extras --no-roofline > $R/$O/prof_pillar.log 2>&1 < /dev/null
-S2D_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python $R/bench.py --steps 2 --warmup 2 --no-prefetch --no-cpu-baseline --no-extras --no-roofline > $R/$O/pmc_f.log 2>&1 < /dev/null
-S2D_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python $R/bench.py --steps 2 --warmup 2 --no-prefetch --no-cpu-baseline --no-extras --no-roofline > $R/$O/pmc_w.log 2>&1 < /dev/null
+B="--no-breakdown --no-cpu-baseline --no-extras --no-roofline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d -- python $R/bench.py --mode eager:instep:0 --steps 6 --warmup 3 $B > $R/$O/prof_s2d.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cp -- python $R/bench.py --mode eager:instep:0 --workload centerpoint --steps 6 --warmup 3 $B > $R/$O/prof_cp.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_graph -- python $R/bench.py --mode graph:loader:0:aux,dense,pcr --steps 8 --warmup 5 $B > $R/$O/prof_s2d_graph.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_streams -- python $R/bench.py --mode eager:loader:aux,dense,sparse --steps 6 --warmup 3 $B > $R/$O/prof_s2d_streams.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pillar -- python $R/bench.py --mode eager:instep:0 --workload pillar_s2d --steps 6 --warmup 3 $B > $R/$O/prof_pillar.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python $R/bench.py --mode eager:instep:0 --steps 2 --warmup 2 $B > $R/$O/pmc_f.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python $R/bench.py --mode eager:instep:0 --steps 2 --warmup 2 $B > $R/$O/pmc_w.log 2>&1 < /dev/null
 cd $R
 python tools/prof_summary.py /tmp/prof_s2d 5 > $O/${T}_s2d_student_b4_step_summary.txt 2>&1
 python tools/prof_summary.py /tmp/prof_cp 1 > $O/${T}_centerpoint_b4_step_summary.txt 2>&1
-python tools/prof_summary.py /tmp/prof_s2d_default 5 > $O/${T}_default_pipeline_s2d_b4_step_summary.txt 2>&1
+python tools/prof_summary.py /tmp/prof_s2d_graph 5 > $O/${T}_graph_pipeline_s2d_b4_step_summary.txt 2>&1
+python tools/prof_summary.py /tmp/prof_s2d_streams 5 > $O/${T}_eager_streams_s2d_b4_step_summary.txt 2>&1
 python tools/prof_summary.py /tmp/prof_pillar 2 > $O/${T}_pillar_s2d_b4_step_summary.txt 2>&1
 cp $(find /tmp/prof_pillar -name "*kernel_stats.csv" | head -1) $O/${T}_pillar_s2d_b4_kernel_stats.csv
 cp $(find /tmp/prof_s2d -name "*kernel_stats.csv" | head -1) $O/${T}_s2d_student_b4_kernel_stats.csv
