@@ -312,12 +312,20 @@ class KD_VoxelNet(VoxelNet):
             cb._s2d_static = fb._s2d_static = True
             ent = store[scale] = [cb, fb, 0]
         cb, fb, prev = ent
-        cb[:m].copy_(coors)
-        fb[:m].copy_(feats)
+        pend = self.__dict__.setdefault("_recon_pending", ([], []))   # copies of both scales go out in one multi-tensor launch (_flush_recon)
+        pend[0].extend([cb[:m], fb[:m]])
+        pend[1].extend([coors, feats])
         if prev > m:
             cb[m:prev].fill_(-1)
         ent[2] = m
         return cb, fb
+
+    def _flush_recon(self):
+        pend = self.__dict__.pop("_recon_pending", None)
+        if pend and pend[0]:
+            from .graphed import _copy_all
+            with torch.no_grad():
+                _copy_all(pend[0], pend[1])
 
     def _dense_part_s2d(self, x, example, want_pcr):
         """first half of `_dense_part` as a segment of its own: S2D module + PCR head + PCR losses -> (F_S_a, F_S_b, mask_loss, comp_loss)"""
@@ -349,6 +357,7 @@ class KD_VoxelNet(VoxelNet):
             recon = []
             for s_ in (4, 2):
                 recon += list(self._padded_recon(example, s_))
+            self._flush_recon()
 
             def part_a(x_, c4, f4, c2, f2):
                 ex = {"reconstruction_coordinates_4": c4, "reconstruction_voxel_mean_4": f4, "reconstruction_coordinates_2": c2,
@@ -367,6 +376,7 @@ class KD_VoxelNet(VoxelNet):
             if want_pcr:
                 for s_ in (4, 2):
                     side += list(self._padded_recon(example, s_))
+                self._flush_recon()
 
             def part(x_, *flat):
                 ex = self._unflat_targets(flat[:nt], tasks) if return_loss else {}

@@ -92,6 +92,7 @@ def run(case):
         side = []
         for s_ in (4, 2):
             side += list(det._padded_recon(ex, s_))
+        det._flush_recon()
 
         def fn(x_, c4, f4, c2, f2):
             det.neck.pcr_targets = {4: (c4, f4), 2: (c2, f2)}
