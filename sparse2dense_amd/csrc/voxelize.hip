@@ -60,8 +60,9 @@ __device__ __forceinline__ uint32_t vox_table_insert(uint32_t *__restrict__ keys
 
 __global__ __launch_bounds__(256) void vox_insert_kernel(const float *__restrict__ points, int n, VoxParams p,
                                                          uint32_t *__restrict__ keys, int *__restrict__ first,
-                                                         int *__restrict__ pt_slot) {
+                                                         int *__restrict__ pt_slot, int *__restrict__ scan_err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *scan_err = 0;   // the look-back scan that follows sets it on a spin time-out (scan.h); read by the count kernel behind it
     if (i >= n) return;
     const float *pt = points + (int64_t)i * p.ndim;
     int c[3];
@@ -118,7 +119,7 @@ struct AssignVoxelOut {
 
 __global__ void vox_finalize_count_kernel(const int *total, int max_voxels, int32_t *out_m) {
     int t = *total;
-    *out_m = t < max_voxels ? t : max_voxels;
+    *out_m = total[1] == 1 ? -1 : (t < max_voxels ? t : max_voxels);   // total[1]: the scan's time-out flag -> a negative count, the host raises
 }
 
 // list[0] of a voxel is its first point, which vox_insert already knows (first[slot]): that thread stores it; the other points run
@@ -389,11 +390,11 @@ extern "C" int s2d_voxelize_run(const float *points, int64_t n_points, int ndim,
     const int64_t rows = n_points < max_voxels ? n_points : max_voxels;
     S2D_HIP(hipMemsetAsync(w.keys, 0x7F, w.clear_bytes, st));
     const dim3 blk(256);
-    hipLaunchKernelGGL(vox_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, w.keys, w.first, w.pt_slot);
+    hipLaunchKernelGGL(vox_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, w.keys, w.first, w.pt_slot, w.total + 1);
     S2D_LAUNCH_CHECK();
     FirstFlagIn fin{w.pt_slot, w.first};
     AssignVoxelOut fout{w.pt_slot, w.keys, w.vid, coors, p};
-    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, nullptr, st);
+    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, w.total + 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_finalize_count_kernel, dim3(1), dim3(1), 0, st, w.total, max_voxels, out_m);
     rc = vox_select_launch(w.pt_slot, w.first, w.vid, n, max_points, rows, w.ksmall, w.sel, st);
@@ -437,8 +438,10 @@ __device__ __forceinline__ int voxb_frame_of(const VoxBatch &vb, int i) {
 }
 
 __global__ __launch_bounds__(256) void voxb_insert_kernel(const float *__restrict__ points, int n, VoxParams p, VoxBatch vb,
-                                                          uint32_t *__restrict__ keys, int *__restrict__ first, int *__restrict__ pt_slot) {
+                                                          uint32_t *__restrict__ keys, int *__restrict__ first, int *__restrict__ pt_slot,
+                                                          int *__restrict__ scan_err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *scan_err = 0;   // see vox_insert_kernel
     if (i >= n) return;
     const int b = voxb_frame_of(vb, i);
     const float *pt = points + (int64_t)i * p.ndim;
@@ -477,8 +480,15 @@ struct VoxbRankOut {
 
 // one block: per-frame voxel counts (capped), their exclusive prefix (output row base), totals
 __global__ void voxb_frame_counts_kernel(const int *__restrict__ frame_start_rank, VoxBatch vb, int max_voxels, int32_t *__restrict__ out_m /*[frames]*/,
-                                         int *__restrict__ out_base /*[frames + 1]*/, int32_t *__restrict__ out_base_user /*[frames + 1]*/) {
+                                         int *__restrict__ out_base /*[frames + 1]*/, int32_t *__restrict__ out_base_user /*[frames + 1]*/,
+                                         const int *__restrict__ scan_err) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (*scan_err == 1) {   // the look-back scan timed out: its ranks are wrong - no rows, and a negative total that the host turns into an error
+        for (int b = 0; b < vb.frames; ++b) out_m[b] = out_base[b] = out_base_user[b] = 0;
+        out_base[vb.frames] = 0;
+        out_base_user[vb.frames] = -1;
+        return;
+    }
     int base = 0;
     for (int b = 0; b < vb.frames; ++b) {
         // a frame start at or past the last point was never visited by the scan: its rank is the total
@@ -671,13 +681,13 @@ extern "C" int s2d_voxelize_batch_run(const float *points, int frames, const int
     const int n = (int)n_points;
     S2D_HIP(hipMemsetAsync(w.keys, 0x7F, w.clear_bytes, st));
     const dim3 blk(256);
-    hipLaunchKernelGGL(voxb_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, vb, w.keys, w.first, w.pt_slot);
+    hipLaunchKernelGGL(voxb_insert_kernel, dim3((n + 255) / 256), blk, 0, st, points, n, p, vb, w.keys, w.first, w.pt_slot, w.total + 1);
     S2D_LAUNCH_CHECK();
     FirstFlagIn fin{w.pt_slot, w.first};
     VoxbRankOut fout{w.pt_slot, w.rank_of_slot, w.frame_start_rank, vb, n};
-    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, nullptr, st);
+    int rc = device_exclusive_scan_onepass(fin, fout, n_points, w.flags, w.total, w.total + 1, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base, out_base);
+    hipLaunchKernelGGL(voxb_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.frame_start_rank, vb, max_voxels, out_m, w.out_base, out_base, w.total + 1);
     hipLaunchKernelGGL(voxb_assign_kernel, dim3((n + 255) / 256), blk, 0, st, w.pt_slot, w.first, w.keys, w.rank_of_slot, w.frame_start_rank,
                        w.out_base, n, p, vb, w.vid, coors4);
     rc = vox_select_launch(w.pt_slot, w.first, w.vid, n, max_points, rows, w.ksmall, w.sel, st);

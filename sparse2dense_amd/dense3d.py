@@ -40,7 +40,11 @@ def pointwise_conv(x, w2d, bias):
 
 
 def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
-    if x.dtype == torch.bfloat16:   # r04: bf16-stored input operand (the raw up-sampler output): matrix-core kernel only
+    """(dW [Cout,Cin], db [Cout] | None) of a 1x1x1 conv over planar fp32 tensors (position count % 4 == 0).  bf16: operands
+    rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported.  norm (f32[2*Cin] = scale |
+    shift): the conv's input was relu(x*scale + shift), applied on the fly (bf16 route) or materialised (fp32 route).  A bf16-stored x
+    (r04: the raw up-sampler output) takes the matrix-core kernel only."""
+    if x.dtype == torch.bfloat16:
         lib = _lib.load()
         n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
         pos = x[0, 0].numel()
@@ -52,9 +56,6 @@ def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
         check(lib.s2d_pointwise_conv_wgrad_norm_x16(_ptr(x), _ptr(norm), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
                                                     _stream()), "s2d_pointwise_conv_wgrad_norm_x16")
         return dw, db
-    """(dW [Cout,Cin], db [Cout] | None) of a 1x1x1 conv over planar fp32 tensors (position count % 4 == 0).  bf16: operands
-    rounded to bf16 on the matrix cores (one pass over both tensors) where the shape is supported.  norm (f32[2*Cin] = scale |
-    shift): the conv's input was relu(x*scale + shift), applied on the fly (bf16 route) or materialised (fp32 route)."""
     lib = _lib.load()
     n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
     pos = x[0, 0].numel()

@@ -77,6 +77,8 @@ def voxelize(points: torch.Tensor, voxel_size, coors_range, max_points: int, max
     One host read (M) — the same size the reference API returns."""
     voxels, coors, num, mean, out_m = voxelize_async(points, voxel_size, coors_range, max_points, max_voxels, with_mean)
     m = int(out_m.item())
+    if m < 0:
+        raise _lib.S2DError("s2d_voxelize_run: the look-back scan timed out on the device (csrc/scan.h); no voxels were produced")
     return voxels[:m], coors[:m], num[:m], (mean[:m] if with_mean else None)
 
 
@@ -118,6 +120,8 @@ def voxelize_batch_collect(pending, base):
     """trim a voxelize_batch_launch result with its row offsets `base` (B+1 host ints)"""
     voxels, coors, num, mean, out_base = pending
     m = int(base[-1])
+    if m < 0:
+        raise _lib.S2DError("s2d_voxelize_batch_run: the look-back scan timed out on the device (csrc/scan.h); no voxels were produced")
     counts = torch.tensor([int(base[b + 1]) - int(base[b]) for b in range(len(base) - 1)], dtype=torch.int64, device=voxels.device)
     return voxels[:m], coors[:m], num[:m], mean[:m], counts
 

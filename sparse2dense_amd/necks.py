@@ -95,6 +95,7 @@ class RPN(nn.Module):
         if self.trunk_channels_last and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         ups = []
+        slices = self._slices_possible(x)
         for i, blk in enumerate(self.blocks):
             if relu_between and isinstance(blk[-1], FastBatchNorm2d):   # F.relu(block(x)) with the ReLU fused into the last BN
                 for layer in blk[:-1]:
@@ -105,40 +106,49 @@ class RPN(nn.Module):
                 if relu_between:
                     x = F.relu(x)
             if i - self._upsample_start_idx >= 0:
-                ups.append(self._deblock(i - self._upsample_start_idx, x, ups))
-        if ups and isinstance(ups[0], tuple):   # every branch wrote its slice of the concatenated tensor (see _deblock)
+                ups.append(self._deblock(i - self._upsample_start_idx, x, ups, slices))
+        if ups and all(isinstance(u, tuple) for u in ups):   # every branch wrote its slice of the concatenated tensor (see _deblock)
             from .dense2d import _CatSlicesFn
             return _CatSlicesFn.apply(ups[0][1], *[u[0] for u in ups])
-        return torch.cat(ups, dim=1) if ups else x
+        # (a branch that could not write its slice - other spatial size, a layer off the HIP path: plain concatenation of what there is; a slice
+        # that was written is an ordinary tensor aliasing its part of the buffer)
+        return torch.cat([u[0] if isinstance(u, tuple) else u for u in ups], dim=1) if ups else x
 
-    def _deblock(self, j, x, ups):
-        """deblock j of the trunk.  r04: when every deblock ends in a FastBatchNorm2d on the HIP path and the branch outputs have one
-        spatial size, the batch norms write their outputs as channel slices of ONE buffer = the concatenated tensor of rpn.py:171 (no
-        torch.cat pass, no contiguous copies of the gradient slices in the backward); returns (slice, buffer) then, else the plain output.
-        S2D_RPN_CAT=torch keeps the concatenation."""
+    def _slices_possible(self, x):
+        """decided once per forward, for all deblocks: the batch norms of the up-sampling branches write channel slices of one buffer (= the
+        concatenated tensor) when every branch ends in a FastBatchNorm2d that will see an NHWC bf16 map and all widths are multiples of 8"""
+        if (os.environ.get("S2D_RPN_CAT", "slices") == "torch" or len(self.deblocks) < 2 or not torch.is_grad_enabled()
+                or not (x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
+            return False
+        widths = []
+        for d in self.deblocks:
+            mods = [m for m in d if not isinstance(m, nn.Identity)]
+            if not mods or not isinstance(mods[-1], FastBatchNorm2d) or not hasattr(mods[0], "out_channels"):
+                return False
+            widths.append(int(mods[0].out_channels))
+        return sum(widths) % 8 == 0 and all(wd % 8 == 0 for wd in widths)
+
+    def _deblock(self, j, x, ups, slices):
+        """deblock j of the trunk.  r04: when every deblock ends in a FastBatchNorm2d on the HIP path (`slices`, decided up front by
+        `_slices_possible`) and the branch outputs have one spatial size, the batch norms write their outputs as channel slices of ONE buffer
+        = the concatenated tensor of rpn.py:171 (no torch.cat pass, no contiguous copies of the gradient slices in the backward); returns
+        (slice, buffer) then, else the plain output (the trunk then concatenates with torch.cat).  S2D_RPN_CAT=torch keeps the concatenation."""
         blk = self.deblocks[j]
-        mods = list(blk)
-        while mods and isinstance(mods[-1], nn.Identity):
-            mods.pop()
-        fused = (os.environ.get("S2D_RPN_CAT", "slices") != "torch" and len(self.deblocks) > 1 and mods and isinstance(mods[-1], FastBatchNorm2d)
-                 and all(isinstance(u, tuple) for u in ups) and torch.is_grad_enabled())
-        if not fused:
-            assert not any(isinstance(u, tuple) for u in ups), "mixed concatenation modes"
+        if not slices:
             return blk(x)
+        mods = [m for m in blk if not isinstance(m, nn.Identity)]
         for layer in mods[:-1]:
             x = layer(x)
         bn = mods[-1]
-        widths = [list(d)[0].out_channels for d in self.deblocks]
-        total = sum(widths)
-        ok = bn._hip_ok(x) and total % 8 == 0 and all(wd % 8 == 0 for wd in widths)
-        if ups:
-            buf = ups[0][1]
-            ok = ok and buf.shape[0] == x.shape[0] and buf.shape[2:] == x.shape[2:]
+        widths = [int([m for m in d if not isinstance(m, nn.Identity)][0].out_channels) for d in self.deblocks]
+        prev = [u for u in ups if isinstance(u, tuple)]
+        ok = bn._hip_ok(x) and len(prev) == len(ups)
+        if ok and prev:
+            buf = prev[0][1]
+            ok = buf.shape[0] == x.shape[0] and buf.shape[2:] == x.shape[2:]
         elif ok:
-            buf = torch.empty((x.shape[0], total, x.shape[2], x.shape[3]), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            buf = torch.empty((x.shape[0], sum(widths), x.shape[2], x.shape[3]), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         if not ok:
-            if ups:   # (cannot happen with the reference's configurations: all branches end at one resolution)
-                raise RuntimeError("RPN deblock outputs differ in shape")
             return bn(x)
         off = sum(widths[:j])
         return bn(x, out=buf[:, off:off + widths[j]]), buf

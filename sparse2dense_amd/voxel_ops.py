@@ -115,6 +115,8 @@ def voxelize_batch(generator: VoxelGenerator, point_clouds, max_voxels=-1, prefi
                              generator._max_voxels if max_voxels == -1 else max_voxels, with_mean=True)
             for pts in point_clouds]
     counts = torch.cat([p[4] for p in pend]).cpu().tolist()
+    if counts and min(counts) < 0:
+        raise H._lib.S2DError("s2d_voxelize_run: the look-back scan timed out on the device (csrc/scan.h)")
     vs, cs, ns, ms = [], [], [], []
     for b, ((v, c, n, m, _), k) in enumerate(zip(pend, counts)):
         cb = torch.empty((k, 4), dtype=torch.int32, device=c.device)
