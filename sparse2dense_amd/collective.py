@@ -33,8 +33,15 @@ def direct_enabled():
     return _DIRECT and dist.is_initialized() and _DIRECT_PG is dist.group.WORLD
 
 
+_direct_call = None   # test hook: callable(tensor) standing in for s2d_comm_allreduce_sum_f32 - tests/test_dp_gloo.py drives the direct route's
+#                       call sequence at world 2 through a mock communicator (a second gloo group) with it
+
+
 def allreduce_sum_(t: torch.Tensor):
     """In-place sum of `t` over the ranks, ordered on the current stream."""
+    if _direct_call is not None and direct_enabled() and t.is_contiguous():
+        _direct_call(t)
+        return t
     if direct_enabled() and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
         from . import _lib
         lib = _lib.load()

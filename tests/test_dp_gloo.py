@@ -301,3 +301,58 @@ def test_direct_rccl_route_falls_back_on_every_rank_when_unavailable():
     finally:
         dist.destroy_process_group()
     assert not collective.direct_enabled() and not collective.sync_on()
+
+
+def _worker_mock_direct(rank, world, port, out_dir):
+    """the uneven two-rank scenario (empty rank, parameter without gradient) plus the sparse backbone, with the SyncBN vectors going
+    through collective.py's DIRECT route - its communicator replaced by a mock (a second gloo group that logs every call): the call
+    sequence csrc/comm.hip would see at world 2"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), S2D_DP_MODE="overlap", S2D_BUCKET_MB="1")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    from sparse2dense_amd import collective, dp
+    from sparse2dense_amd.train_step import backward_and_clip
+    dp.init_distributed("gloo")
+    net = dp.wrap_ddp(_build())
+    comm = dist.new_group()                      # stands in for the library-owned RCCL communicator
+    log = []
+
+    def mock_allreduce(t):
+        log.append(int(t.numel()))
+        dist.all_reduce(t, group=comm)
+    feats, c = _voxels(rank)
+    coors = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        out, _ = net(feats, coors, 1, np.array([1504, 1504, 40]))
+        loss = (out * _weights(out.shape)).sum()
+        backward_and_clip(loss, list(net.parameters()), max_norm=1e30)
+        return {n: p.grad.clone() for n, p in net.named_parameters()}
+    ref = step()                                 # torch.distributed route
+    collective._DIRECT, collective._DIRECT_PG, collective._direct_call = True, dist.group.WORLD, mock_allreduce
+    try:
+        assert collective.direct_enabled()
+        got = step()
+    finally:
+        collective._DIRECT, collective._DIRECT_PG, collective._direct_call = False, None, None
+    torch.save(dict(log=log, same=all(torch.equal(ref[n], got[n]) for n in ref), n=len(ref)), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_route_call_sequence_at_world_2_through_a_mock_communicator():
+    """`csrc/comm.hip` has never seen two ranks (no multi-GPU box in any round).  What CAN be checked without one is
+    everything above the C entry: at world 2 both ranks issue the same sequence of direct-route all-reduces (sizes and order - a mismatch
+    is a deadlock on a real communicator), interleaved with the gradient buckets' collectives on their own group, and the result equals
+    the torch.distributed route bit for bit."""
+    port = 33900 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_mock_direct, args=(2, port, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    assert r0["log"] == r1["log"] and len(r0["log"]) >= 40, (len(r0["log"]), len(r1["log"]))   # 21 batch norms x (forward + backward)
+    assert r0["same"] and r1["same"]
