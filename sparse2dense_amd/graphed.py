@@ -257,6 +257,14 @@ class GraphedSegment:
         cap.fwd = torch.cuda.CUDAGraph()
         CAPTURE_LOCK.acquire()
         dense2d.WS_PRIVATE = True      # reduction workspaces: plain allocations from the graph's pool while capturing
+        # No cyclic garbage collection while a stream is capturing: a collection that runs in the middle of the capture (it can start at any
+        # allocation, on the autograd thread as well) may finalise an old CUDAGraph / event / tensor of an earlier segment or test, and
+        # destroying those is a runtime call the capture turns into an abort (seen in the full test suite: "Garbage-collecting" inside a
+        # layer's backward, then SIGABRT).  Collect once up front, switch the collector off, restore afterwards.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with contextlib.ExitStack() as stack:
                 for m, repl in swaps:
@@ -303,6 +311,8 @@ class GraphedSegment:
                     cap.keep = items
             cap.s_out = tuple(o.detach() if torch.is_tensor(o) else o for o in outs)
         finally:
+            if gc_was_on:
+                gc.enable()
             dense2d.WS_PRIVATE = False
             CAPTURE_LOCK.release()
         return cap
