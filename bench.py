@@ -195,6 +195,18 @@ def timed(step, steps, warmup, world, dev, detail=None):
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if detail is not None else None
     stamps = []
+    # Python's cyclic garbage collector is kept out of the timed steps (a full collection over the process's module / tensor objects is a
+    # 20-40 ms stop of the launch thread: one of them inside a 20-step timed region is +1.5 ms per step).  What a production training loop does
+    # too: collect before, freeze the survivors, collect again after (S2D_BENCH_GC=1 leaves the collector alone).
+    import gc
+    manage_gc = os.environ.get("S2D_BENCH_GC", "0") != "1"
+    gc_stats = None
+    if manage_gc:
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+    else:
+        gc_stats = [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     if marks:
         marks[0].record()
@@ -209,6 +221,13 @@ def timed(step, steps, warmup, world, dev, detail=None):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if manage_gc:
+        gc.enable()
+        gc.unfreeze()
+    if detail is not None:
+        detail["python_gc"] = ("collected + frozen before, disabled during the timed steps" if manage_gc else
+                               "left on: collections per generation during the timed steps " +
+                               str([g["collections"] - a for g, a in zip(gc.get_stats(), gc_stats)]))
     if marks:
         dev_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         host_ms = sorted((b - a) * 1e3 for a, b in zip([t0] + stamps[:-1], stamps))
@@ -276,6 +295,17 @@ def calibrate(models, step, dev, candidates, settle=4, n=8, world=1):
             score[mode_name(m)] = v
             table[mode_name(m)]["max_over_ranks_ms"] = round(v, 3)
     best = min(ok, key=lambda m: score[mode_name(m)])
+    # Risk-averse pick: a graphed mode is kept unless the best eager mode beat it by more than 5 % HERE.  Measured r05: on a quiet host the eager
+    # step with the weight-gradient stream is 3-4 % faster than the graphed one (18.9 vs 19.6 ms: its weight gradients overlap the whole dense
+    # backward), but its time follows the host - 30 ms under rocprofv3, 32-37 ms in a run beside a busy neighbour on the same pod (the r04 driver
+    # run: 31 ms) - while the graphed step stayed at 19.5-20.4 ms in every run of the round.
+    graphed = [m for m in ok if m[0]]
+    if graphed and not best[0]:
+        g_best = min(graphed, key=lambda m: score[mode_name(m)])
+        if score[mode_name(g_best)] <= 1.05 * score[mode_name(best)]:
+            table["_pick"] = (f"{mode_name(g_best)} ({score[mode_name(g_best)]:.3f} ms) kept over the fastest measured mode {mode_name(best)} "
+                              f"({score[mode_name(best)]:.3f} ms): within 5 %, and host-independent")
+            best = g_best
     return best, table
 
 
