@@ -133,7 +133,16 @@ def attach_geometry(example, backbone, keys=("coordinates", "dense_coordinates",
         if coors is None or not coors.is_cuda or coors.dtype != torch.int32:
             continue
         batch = len(example[key.replace("coordinates", "num_voxels")])
-        coors._s2d_geometry = (tuple(int(s) for s in shape), batch, build_geometry(coors, batch, shape, strided, subm))
+        plan = build_geometry(coors, batch, shape, strided, subm)
+        # The plan hangs on the coordinate tensor; a rulebook of the plan that holds that very tensor object (the SubM layers' out_coors)
+        # would close a reference cycle - tensor -> plan -> rulebook -> tensor - and the example's ~0.75 GB of device memory (gather maps,
+        # voxels) would then live until Python's CYCLIC collector happens to run instead of dying with the step (r05: 15 GB held after 20
+        # steps with the collector off).  The plan gets an alias of the tensor instead (same storage, no attribute dictionary).
+        for rb in plan.values():
+            for name, val in list(vars(rb).items()):
+                if val is coors:
+                    setattr(rb, name, coors.detach())
+        coors._s2d_geometry = (tuple(int(s) for s in shape), batch, plan)
     return example
 
 
