@@ -39,7 +39,7 @@ import torch.distributed as dist
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = ["r04_final_pmc_traffic.json", "r04_mid_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_mid_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
+PMC_TRAFFIC_FILES = ["r05_final_pmc_traffic.json", "r04_final_pmc_traffic.json", "r04_mid_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_mid_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
 
 WORKLOAD_NAMES = {
     "centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
@@ -851,15 +851,23 @@ def main():
                     a2.dtype, a2.dense_dtype, a2.sparse_dtype = dt, None, None
                 m2, t2, f2, st2 = setup_workload(a2, wl, dev, rank)
                 k = max(5, min(args.steps, 10))
-                set_mode([getattr(m2, "module", m2), t2], mode)   # the mode chosen for the headline workload on this box
-                run2 = st2 if (mode[1] and st2.sync_step is not st2) else st2.sync_step
+                # the mode chosen for the headline workload on this box; a workload whose detector has no graphed segment (the pillar path) takes
+                # the fastest EAGER mode of the table measured above instead
+                mode2 = mode
+                if mode[0] and not hasattr(getattr(m2, "module", m2), "_dense_call") and mode_table:
+                    eager = [(v["mean_wall_ms"], k) for k, v in mode_table.items() if k.startswith("eager") and isinstance(v, dict) and "mean_wall_ms" in v]
+                    if eager:
+                        name_e = min(eager)[1]
+                        mode2 = (False, "loader-thread" in name_e, "aux,dense,sparse" if "wgrad-stream" in name_e else "", "")
+                set_mode([getattr(m2, "module", m2), t2], mode2)
+                run2 = st2 if (mode2[1] and st2.sync_step is not st2) else st2.sync_step
                 d2 = {}
-                el, _ = timed(run2, k, 5 if mode[0] else 3, 1, dev, d2)   # (graphs: 2 eager calls + the capture are part of the warm-up)
+                el, _ = timed(run2, k, 5 if mode2[0] else 3, 1, dev, d2)   # (graphs: 2 eager calls + the capture are part of the warm-up)
                 if hasattr(f2, "close"):
                     f2.close()
                 others[name] = dict(workload=WORKLOAD_NAMES[wl], value=round(args.batch * k / el, 3), unit="frames/s",
-                                    ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=5 if mode[0] else 3, frames_per_gpu=args.batch,
-                                    device_ms_per_step=d2.get("device_ms_per_step"),
+                                    ms_per_step=round(el / k * 1e3, 3), steps=k, warmup=5 if mode2[0] else 3, frames_per_gpu=args.batch,
+                                    device_ms_per_step=d2.get("device_ms_per_step"), mode=mode_name(mode2),
                                     dtype=f"dense {a2.dense_dtype}, sparse {a2.sparse_dtype}")
                 del m2, t2, f2, st2
                 torch.cuda.empty_cache()
