@@ -358,6 +358,12 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(const __bf16 *__
 //     once per 288 pixels: 250 MB of LDS-DMA per launch instead of 636 MB): 58-60 us; with all 13 fragment reads of a sub-step issued
 //     up front (hipcc had paired them with lgkmcnt(0) waits) 58 us; with the LDS-DMA pieces interleaved one per MFMA row group 61 us.
 //     Fewer staged bytes and fewer pieces per MFMA did not move the launch: the limit is not the L2 -> LDS byte rate.
+// r05: (a) counters of this instantiation alone (profiles/r05_conv3x3_fwd_wgrad_sq_lds_tcp_counters.txt): matrix pipe 36 % busy, 2.2 resident waves per SIMD
+//     on average, 48 % issue stalls / 25 % parked at s_waitcnt + barrier, no LDS conflicts (LDS array 8 % active), L2 hit rate 92 %: no unit saturates.
+//   (b) tile height (tools/conv_bm_bench.py, back to back): 128 / 96 / 64 rows = 55.9 / 56.7 / 58.8 us - the 1 112-workgroup tail on 768 slots is not it.
+//   (c) register staging instead of LDS-DMA (global_load_dwordx4 -> VGPR -> ds_write_b128, same ring and LDS image, loads of sub-step t+4 issued at
+//     iteration t, 165 VGPRs, bit-identical, built as a template flag and removed again): 60.1 us against 55.4 us - the ~20 B/clk/CU the LDS-DMA path
+//     delivers here (636 MB per launch) is not what holds the kernel either; the vector path only adds four 13-cycle ds_write_b128 per sub-step.
 template <int BN, int MI, int KS = 3, bool UP = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
                                                                     const float *__restrict__ bias,
