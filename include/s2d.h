@@ -616,6 +616,11 @@ int s2d_pcr_loss_bwd_f32(const float *gen_offset, const float *gen_mask, const i
  */
 int s2d_nhwc_bf16_to_nchw_f32(const void *x, int batch, int c, int64_t hw, float *y, s2d_stream_t stream);
 int s2d_nchw_f32_to_nhwc_bf16(const float *x, int batch, int c, int64_t hw, void *y, s2d_stream_t stream);
+/* r05: the same hand-overs against NHWC rows of `ld` >= c channels (the first c are used; the writer zero-fills the rest): the PCR head's first
+ * 1x1x1 conv (necks/rpn.py:263-266 `generator_1[0]` on `out_conv(F_S_b).view(n, 128, 5, h, w)`) runs as ONE 1x1 conv on the NHWC map with a
+ * block-diagonal weight whose output channel count is padded to the tile kernels' multiple of 64 */
+int s2d_nhwc_bf16_to_nchw_f32_ld(const void *x, int batch, int c, int ld, int64_t hw, float *y, s2d_stream_t stream);
+int s2d_nchw_f32_to_nhwc_bf16_ld(const float *x, int batch, int c, int ld, int64_t hw, void *y, s2d_stream_t stream);
 
 /* 2 x 2 resampling of NHWC bf16 maps (r04, the pillar S2D module): nn.Upsample(scale_factor=2, mode="nearest") and nn.MaxPool2d(2, 2) with
  * their backward passes; c % 8 == 0.  The max-pool backward re-derives the selected window element from x (torch's scan order, NaN

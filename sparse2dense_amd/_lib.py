@@ -142,6 +142,8 @@ SIGNATURES = {
                              [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     "s2d_nhwc_bf16_to_nchw_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_nchw_f32_to_nhwc_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_nhwc_bf16_to_nchw_f32_ld": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
+    "s2d_nchw_f32_to_nhwc_bf16_ld": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_conv2d1x1_pack_weights_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_conv2d3x3_pack_weights_pair_bf16": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                             ctypes.c_void_p]),

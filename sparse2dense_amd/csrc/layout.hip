@@ -10,7 +10,9 @@ typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
 constexpr int LT = 64;   // tile: 64 pixels x 64 channels
 
 // grid (pixel tiles, channel tiles, batch).  c % 8 == 0, hw % 4 == 0.
-__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const __bf16 *__restrict__ x, int c, int64_t hw, float *__restrict__ y) {
+// ld = row stride of the NHWC side in elements (>= c, a multiple of 8): the first c channels of ld-wide rows (r05: a 1x1 conv whose output
+// channel count was padded to the tile kernels' multiple of 64 hands its map over without a compaction copy)
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const __bf16 *__restrict__ x, int c, int ld, int64_t hw, float *__restrict__ y) {
     __shared__ float tile[LT][LT + 1];   // [channel][pixel]
     const int64_t p0 = (int64_t)blockIdx.x * LT;
     const int c0 = blockIdx.y * LT;
@@ -20,7 +22,7 @@ __global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const __bf16
     for (int pass = 0; pass < 2; ++pass) {
         const int p = pass * 32 + (t >> 3), g = t & 7;
         if (p0 + p < hw && c0 + 8 * g < c) {
-            const bf16x8t v = *reinterpret_cast<const bf16x8t *>(x + ((b * hw + p0 + p) * c + c0 + 8 * g));
+            const bf16x8t v = *reinterpret_cast<const bf16x8t *>(x + ((b * hw + p0 + p) * ld + c0 + 8 * g));
 #pragma unroll
             for (int e = 0; e < 8; ++e) tile[8 * g + e][p] = (float)v[e];
         }
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const __bf16
     }
 }
 
-__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float *__restrict__ x, int c, int64_t hw, __bf16 *__restrict__ y) {
+// ld >= c: rows of ld channels are written, channels c .. ld-1 as zeros (grid.y covers ld)
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float *__restrict__ x, int c, int ld, int64_t hw, __bf16 *__restrict__ y) {
     __shared__ float tile[LT][LT + 1];
     const int64_t p0 = (int64_t)blockIdx.x * LT;
     const int c0 = blockIdx.y * LT;
@@ -47,17 +50,19 @@ __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float 
         if (c0 + ch < c && p0 + 4 * pq < hw) {
             const float4 v = *reinterpret_cast<const float4 *>(x + ((b * c + c0 + ch) * hw + p0 + 4 * pq));
             tile[ch][4 * pq] = v.x; tile[ch][4 * pq + 1] = v.y; tile[ch][4 * pq + 2] = v.z; tile[ch][4 * pq + 3] = v.w;
+        } else if (c0 + ch >= c) {
+            tile[ch][4 * pq] = 0.f; tile[ch][4 * pq + 1] = 0.f; tile[ch][4 * pq + 2] = 0.f; tile[ch][4 * pq + 3] = 0.f;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int p = pass * 32 + (t >> 3), g = t & 7;
-        if (p0 + p < hw && c0 + 8 * g < c) {
+        if (p0 + p < hw && c0 + 8 * g < ld) {
             bf16x8t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)tile[8 * g + e][p];
-            *reinterpret_cast<bf16x8t *>(y + ((b * hw + p0 + p) * c + c0 + 8 * g)) = o;
+            *reinterpret_cast<bf16x8t *>(y + ((b * hw + p0 + p) * ld + c0 + 8 * g)) = o;
         }
     }
 }
@@ -83,7 +88,18 @@ extern "C" int s2d_nhwc_bf16_to_nchw_f32(const void *x, int batch, int c, int64_
     int rc = layout_check(x, y, batch, c, hw, "nhwc_bf16_to_nchw_f32");
     if (rc) return rc;
     const dim3 grid((unsigned)ceil_div(hw, LT), (unsigned)ceil_div(c, LT), batch);
-    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, c, hw, y);
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, c, c, hw, y);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* the same from rows of `ld` >= c channels (ld % 8 == 0): x bf16 [batch][hw][ld], channels 0 .. c-1 -> y fp32 [batch][c][hw] */
+extern "C" int s2d_nhwc_bf16_to_nchw_f32_ld(const void *x, int batch, int c, int ld, int64_t hw, float *y, s2d_stream_t stream) {
+    int rc = layout_check(x, y, batch, c, hw, "nhwc_bf16_to_nchw_f32_ld");
+    if (rc) return rc;
+    S2D_CHECK_ARG(ld >= c && ld % 8 == 0, "nhwc_bf16_to_nchw_f32_ld: row stride must be a multiple of 8 and >= c");
+    const dim3 grid((unsigned)ceil_div(hw, LT), (unsigned)ceil_div(c, LT), batch);
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, c, ld, hw, y);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -93,7 +109,18 @@ extern "C" int s2d_nchw_f32_to_nhwc_bf16(const float *x, int batch, int c, int64
     int rc = layout_check(x, y, batch, c, hw, "nchw_f32_to_nhwc_bf16");
     if (rc) return rc;
     const dim3 grid((unsigned)ceil_div(hw, LT), (unsigned)ceil_div(c, LT), batch);
-    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, hw, (__bf16 *)y);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, c, hw, (__bf16 *)y);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* the same into rows of `ld` >= c channels (ld % 8 == 0), channels c .. ld-1 zero-filled: y bf16 [batch][hw][ld] */
+extern "C" int s2d_nchw_f32_to_nhwc_bf16_ld(const float *x, int batch, int c, int ld, int64_t hw, void *y, s2d_stream_t stream) {
+    int rc = layout_check(x, y, batch, c, hw, "nchw_f32_to_nhwc_bf16_ld");
+    if (rc) return rc;
+    S2D_CHECK_ARG(ld >= c && ld % 8 == 0, "nchw_f32_to_nhwc_bf16_ld: row stride must be a multiple of 8 and >= c");
+    const dim3 grid((unsigned)ceil_div(hw, LT), (unsigned)ceil_div(ld, LT), batch);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c, ld, hw, (__bf16 *)y);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -112,6 +112,97 @@ class _PwConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+# --------------------------------------------------------------------------------------------------
+# 1x1x1 conv straight from the NHWC bf16 map (r05)
+# --------------------------------------------------------------------------------------------------
+class _PwConvNhwcFn(torch.autograd.Function):
+    """`Conv3d(C, co, 1)(x.view(n, C, depth, h, w))` for x = an NHWC bf16 map [n, C*depth, h, w] (channel index = c*depth + d, the
+    `.view` of necks/rpn.py:283-285), result fp32 planar [n, co, depth, h, w] - WITHOUT the fp32 planar copy of x (362 MB at B = 4) and
+    without its gradient: the conv is ONE 1x1 conv on the NHWC map with the block-diagonal weight W'[(o, d), (c, d')] = W[o, c] [d = d'],
+    output channels padded to the tile kernels' multiple of 64 (5x the FLOPs of the planar form, on the matrix cores: 45 us instead of
+    0.13 ms of fp32 streaming + 0.10 ms of layout hand-over, per direction), followed by the hand-over of the 45 MB result.  Operands are
+    rounded to bf16 (as in every conv of the bf16 mode), the result once more before it is widened."""
+
+    @staticmethod
+    def _expanded(weight, depth, cop):
+        co, c = weight.shape[0], weight.shape[1]
+        w2 = weight.detach().reshape(co, c).float()
+        wp = torch.zeros((cop, c * depth), dtype=torch.float32, device=weight.device)
+        eye = torch.eye(depth, dtype=torch.float32, device=weight.device)
+        wp[:co * depth] = torch.einsum("oc,de->odce", w2, eye).reshape(co * depth, c * depth)
+        return wp
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, depth):
+        from .dense2d import _pack_matrix_1x1, conv1x1_nhwc
+        lib = _lib.load()
+        n, cd, h, w = x.shape
+        co = weight.shape[0]
+        cop = -(-co * depth // 64) * 64
+        packed = _pack_matrix_1x1(weight, ("pw_nhwc", depth, "fwd"), lambda: _PwConvNhwcFn._expanded(weight, depth, cop))
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(cop, dtype=torch.float32, device=x.device)
+            bp[:co * depth] = bias.detach().float().repeat_interleave(depth)
+        y = conv1x1_nhwc(x, packed, bp, cd, cop)
+        out = torch.empty((n, co, depth, h, w), dtype=torch.float32, device=x.device)
+        check(lib.s2d_nhwc_bf16_to_nchw_f32_ld(y.data_ptr(), n, co * depth, cop, h * w, out.data_ptr(), _stream()), "s2d_nhwc_bf16_to_nchw_f32_ld")
+        ctx.save_for_backward(x, weight)
+        ctx.depth, ctx.cop, ctx.has_bias = depth, cop, bias is not None
+        ctx.weight_p, ctx.bias_p = weight, bias
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import side
+        from .dense2d import _pack_matrix_1x1, _wgrad_1x1, conv1x1_nhwc
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        n, cd, h, w = x.shape
+        depth, cop = ctx.depth, ctx.cop
+        co, c = weight.shape[0], weight.shape[1]
+        dout = dout.float().contiguous()
+        dyn = torch.empty((n, cop, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        check(lib.s2d_nchw_f32_to_nhwc_bf16_ld(dout.data_ptr(), n, co * depth, cop, h * w, dyn.data_ptr(), _stream()), "s2d_nchw_f32_to_nhwc_bf16_ld")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            packed_t = _pack_matrix_1x1(weight, ("pw_nhwc", depth, "dgrad"), lambda: _PwConvNhwcFn._expanded(weight, depth, cop), transpose=True)
+            dx = conv1x1_nhwc(dyn, packed_t, None, cop, cd)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_db:
+            def wgrad():
+                dwp = _wgrad_1x1(x, dyn, cd, cop)                                          # [cop, C*depth]
+                dwf = dwp[:co * depth].view(co, depth, c, depth).diagonal(dim1=1, dim2=3).sum(-1)   # the diagonal blocks, summed over depth
+                dbf = None
+                if want_db:   # per-channel sums of the planar gradient
+                    dbf = _bncm_reduce("s2d_bncm_stats_f32", (_ptr(dout),), n, co, dout[0, 0].numel(), x.device)[:co]
+                return dwf.reshape(weight.shape).to(weight.dtype).contiguous(), dbf
+            dw, db = side.run(ctx.weight_p, wgrad, x, dyn, dout, kind="pcr", bias=ctx.bias_p if want_db else None, pair=True)
+            dw, db = side.undefer(dw), side.undefer(db)
+        return dx, dw, db, None
+
+
+def pw_conv_from_nhwc_supported(x, conv, depth):
+    """x: NHWC bf16 [n, C*depth, h, w] map; conv: a PointwiseConv3d in its bf16-compute mode"""
+    import os
+    if os.environ.get("S2D_PCR_PW_NHWC", "1") == "0":
+        return False
+    if not (isinstance(conv, PointwiseConv3d) and conv.bf16_compute and conv.kernel_size == (1, 1, 1) and conv.groups == 1):
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    n, cd, h, w = x.shape
+    co, c = conv.weight.shape[0], conv.weight.shape[1]
+    cop = -(-co * depth // 64) * 64
+    lib = _lib.load()
+    return bool(cd == c * depth and (co * depth) % 8 == 0 and (h * w) % 4 == 0 and n <= 65535
+                and lib.s2d_conv2d3x3_supported(cd, cop) and lib.s2d_conv2d3x3_supported(cop, cd))
+
+
+def pw_conv_from_nhwc(x, conv, depth):
+    return _PwConvNhwcFn.apply(x, conv.weight, conv.bias, depth)
+
+
 def _convt_packed(weight):
     """bf16 weight images (forward + data gradient) of the MFMA ConvTranspose3d kernels, cached per parameter version"""
     from .dense2d import cached_pack

@@ -306,13 +306,19 @@ class S2D_RPN(RPN):
         # PCR head in fp32 / standard layout: its 3-D convs are memory-bound, and MIOpen's
         # BatchNorm3d segfaults on bf16 5-D inputs under autocast (ROCm 7.2)
         with torch.autocast("cuda", enabled=False):
-            if gen.dtype in (torch.bfloat16, torch.float16):
-                gen = _ToPlanarF32.apply(gen)
-            gen = gen.contiguous().view(n, 128, 5, h, w)
+            # r05: when the first 1x1x1 conv can read the NHWC bf16 map directly (dense3d._PwConvNhwcFn) the fp32 planar copy of the
+            # 640-channel map (362 MB at B = 4) and its gradient are never made
+            from .dense3d import pw_conv_from_nhwc, pw_conv_from_nhwc_supported
+            gen_nhwc = gen if (self.pcr_targets is not None and pw_conv_from_nhwc_supported(gen, self.generator_1[0], 5)) else None
+            if gen_nhwc is None:
+                if gen.dtype in (torch.bfloat16, torch.float16):
+                    gen = _ToPlanarF32.apply(gen)
+                gen = gen.contiguous().view(n, 128, 5, h, w)
             tg, self.pcr_targets = self.pcr_targets, None
             bn1, bn2 = self.generator_1[4], self.generator_2[4]
             fold = (tg is not None and gen.is_cuda and isinstance(bn1, FastBatchNorm3d) and isinstance(bn2, FastBatchNorm3d)
                     and bn1.training and bn2.training and bn1.fused_relu and bn2.fused_relu)
+            first = (lambda: pw_conv_from_nhwc(gen_nhwc, self.generator_1[0], 5)) if gen_nhwc is not None else (lambda: self.generator_1[0](gen))
             # r04: on the fused path each up-sampler + its level is ONE autograd node whose raw output is stored in bf16
             # (heads.upsample_level; S2D_PCR_Y16=0 keeps the r03 two-node fp32 form)
             one_node = (fold and os.environ.get("S2D_PCR_Y16", "1") != "0"
@@ -323,18 +329,23 @@ class S2D_RPN(RPN):
                 # 90 / 362 MB tensors are never written (heads.upsample_level, pre_bn)
                 pre1 = self.generator_1[1] if upsample_level_pre_bn_supported(self.generator_1[3], (5, h, w), self.generator_1[1]) else None
                 pre2 = self.generator_2[1] if upsample_level_pre_bn_supported(self.generator_2[3], (10, 2 * h, 2 * w), self.generator_2[1]) else None
-                mid = self.generator_1[0](gen) if pre1 is not None else self.generator_1[:3](gen)
+                mid = first() if pre1 is not None else self.generator_1[1:3](first())
                 gen_mask_4, gen_offset_4, z = upsample_level(self.generator_1[3], mid, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4],
                                                               next_conv=self.generator_2[0], pre_bn=pre1)
                 mid2 = z if pre2 is not None else self.generator_2[1:3](z)
                 gen_mask_2, gen_offset_2, _ = upsample_level(self.generator_2[3], mid2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2], pre_bn=pre2)
                 return gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4
+            if gen_nhwc is not None:   # (the branches below read the planar tensor)
+                gen = self.generator_1[1:3](first())
+                gen_from = 3
+            else:
+                gen_from = 0
             if fold:
-                raw = self.generator_1[:4](gen)   # ... up to the RAW output of the first up-sampler
+                raw = self.generator_1[gen_from:4](gen)   # ... up to the RAW output of the first up-sampler
                 fold = pcr_level_supported(raw, self.generator_2[0])
                 gen = raw if fold else self.generator_1[4:](raw)
             else:
-                gen = self.generator_1(gen)
+                gen = self.generator_1[gen_from:](gen)
             if fold:
                 # the detector handed the recon voxels in and the levels' batch norms are ours: BatchNorm3d + ReLU + mask / offset heads +
                 # losses (+ the next 1x1x1 conv) run from the raw up-sampler outputs (heads.pcr_level_norm); the gen_* slots carry

@@ -242,3 +242,34 @@ def test_convtranspose3d_bf16_stored_output(cin, cout, shape):
     gw32 = torch.autograd.grad(y32, [xa, m.weight], g)
     gw16 = torch.autograd.grad(y16, [xb, m.weight], g)
     assert torch.equal(gw32[0], gw16[0]) and torch.equal(gw32[1], gw16[1])
+
+
+@pytest.mark.parametrize("n,c,co,depth,h,w", [(2, 128, 32, 5, 12, 16), (1, 128, 32, 5, 47, 48), (2, 64, 16, 2, 10, 6)])
+def test_pointwise_conv3d_straight_from_the_nhwc_map(n, c, co, depth, h, w):
+    """r05 `dense3d._PwConvNhwcFn`: `Conv3d(C, co, 1)(x.view(n, C, depth, h, w))` as one block-diagonal 1x1 conv on the NHWC bf16 map (no fp32 planar
+    copy of x, necks/rpn.py:283-285 + 263-266) against the reference formulation in float64 over the same bf16-rounded operands:
+    output / dx one bf16 rounding (6e-3 of max), dW / db 2e-3"""
+    from sparse2dense_amd.dense3d import pw_conv_from_nhwc, pw_conv_from_nhwc_supported
+    torch.manual_seed(n + c + h)
+    conv = PointwiseConv3d(c, co, 1, 1, 0).to(DEV)
+    conv.bf16_compute = True
+    rb = lambda t: t.to(torch.bfloat16).float()
+    with torch.no_grad():
+        conv.weight.copy_(rb(conv.weight))
+    x = rb(torch.randn(n, c * depth, h, w, device=DEV))
+    g = rb(torch.randn(n, co, depth, h, w, device=DEV))
+    xa = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert pw_conv_from_nhwc_supported(xa, conv, depth)
+    ya = pw_conv_from_nhwc(xa, conv, depth)
+    assert ya.shape == (n, co, depth, h, w) and ya.dtype == torch.float32 and ya.is_contiguous()
+    ya.backward(g)
+    ref = nn.Conv3d(c, co, 1).double().to(DEV)
+    ref.load_state_dict(conv.state_dict())
+    xr = x.double().view(n, c, depth, h, w).requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.double())
+    rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(ya.detach(), yr.detach()) <= 6e-3
+    assert rel(xa.grad.float().view(n, c, depth, h, w), xr.grad) <= 6e-3
+    assert rel(conv.weight.grad, ref.weight.grad) <= 2e-3
+    assert rel(conv.bias.grad, ref.bias.grad) <= 2e-3
