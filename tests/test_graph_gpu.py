@@ -158,3 +158,63 @@ def test_parameter_surgery_drops_the_capture():
     finally:
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
+
+
+def _run_distill(graph, steps=6, n_points=12000, batch=2):
+    """the full distillation step (trainer.py:775-811): frozen teacher forward (a forward-only graph under no_grad) + student step whose
+    feature maps and predictions ALSO receive gradients (sparse2dense_loss, kd_hm, kd_reg on top of the detection and PCR losses)"""
+    from sparse2dense_amd import dense2d, graphed, hip_ops, side
+    from sparse2dense_amd.data import SyntheticFrames
+    from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+    from sparse2dense_amd.train_step import backward_and_step, distill_loss
+    side.enable(False)
+    side.graph_defer("dense,aux,pcr")
+    dense2d.clear_pack_cache()
+    hip_ops.set_sparse_compute_dtype("s16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    student = _model("s2d_student", dev).train()
+    teacher = _model("centerpoint_voxelnet", dev).eval()
+    for p in teacher.parameters():
+        p.requires_grad = False
+    if graph:
+        student.use_hip_graphs()
+        teacher.use_hip_graphs()
+    frames = SyntheticFrames(batch, n_points=n_points, seed=8, distill=True, device=dev)
+    params = [p for p in student.parameters() if p.requires_grad]
+    opt = build_one_cycle_optimizer(student, dict(wd=0.01))
+    sch = build_one_cycle_scheduler(opt, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4), total_steps=100)
+    for k in graphed.stats:
+        graphed.stats[k] = 0
+    out = []
+    try:
+        for it in range(steps):
+            loss, terms = distill_loss(teacher, student, frames.example())
+            out.append((float(loss.detach()), float(terms["sparse2dense_loss"][0]), float(terms["kd_hm_loss"][0]), float(terms["kd_reg_loss"][0])))
+            if it == steps - 1:
+                for p in params:
+                    p.grad = None
+                loss.backward()
+                torch.cuda.synchronize()
+                grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            else:
+                backward_and_step(loss, params, opt, sch, it, 35.0)
+        final = torch.cat([p.detach().flatten()[:64].double().cpu() for p in params])
+        st = dict(graphed.stats)
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+    return out, final, grads, st
+
+
+def test_distillation_step_is_independent_of_the_graph_replay():
+    ref_out, ref_final, ref_grads, st0 = _run_distill(False)
+    got_out, got_final, got_grads, st = _run_distill(True)
+    assert st0["replay"] == 0 and st["capture"] == 2 and st["replay"] == 8, st   # teacher (forward only) + student segments, 4 replays each
+    assert got_out == ref_out, (got_out, ref_out)
+    assert torch.equal(got_final, ref_final)
+    for g, r in zip(got_grads, ref_grads):
+        assert (g is None) == (r is None)
+        if g is not None:
+            assert torch.equal(g, r)
+    assert ref_out[-1][0] != ref_out[0][0] and ref_out[0][1] > 0 and ref_out[0][2] > 0
