@@ -860,6 +860,8 @@ def main():
                         name_e = min(eager)[1]
                         mode2 = (False, "loader-thread" in name_e, "aux,dense,sparse" if "wgrad-stream" in name_e else "", "")
                 set_mode([getattr(m2, "module", m2), t2], mode2)
+                if mode2[0] and not getattr(getattr(m2, "module", m2), "graph_dense", False):   # (fp32 mode: no graphed segment) label what ran
+                    mode2 = (False, mode2[1], mode2[2], "")
                 run2 = st2 if (mode2[1] and st2.sync_step is not st2) else st2.sync_step
                 d2 = {}
                 el, _ = timed(run2, k, 5 if mode2[0] else 3, 1, dev, d2)   # (graphs: 2 eager calls + the capture are part of the warm-up)
