@@ -854,7 +854,7 @@ def main():
                 # the mode chosen for the headline workload on this box; a workload whose detector has no graphed segment (the pillar path) takes
                 # the fastest EAGER mode of the table measured above instead
                 mode2 = mode
-                if mode[0] and not hasattr(getattr(m2, "module", m2), "_dense_call") and mode_table:
+                if mode[0] and not getattr(getattr(m2, "module", m2), "graphed_segment", False) and mode_table:
                     eager = [(v["mean_wall_ms"], k) for k, v in mode_table.items() if k.startswith("eager") and isinstance(v, dict) and "mean_wall_ms" in v]
                     if eager:
                         name_e = min(eager)[1]

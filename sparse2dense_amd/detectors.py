@@ -170,6 +170,8 @@ class SingleStageDetector(nn.Module):
 
 @DETECTORS.register_module
 class VoxelNet(SingleStageDetector):
+    graphed_segment = True   # forward() routes everything behind the BEV map through _dense_call (use_hip_graphs)
+
     def _bev(self, data):
         # the BEV map goes straight to NHWC bf16 in the bf16 mode: the neck reads exactly that, and a caller that asked for the
         # feature (the distillation teacher's F_D_a) gets it in the compute dtype / layout (sparse2dense_loss upcasts per element)

@@ -184,7 +184,19 @@ class GraphedSegment:
                         if torch.is_tensor(o) and o.requires_grad:
                             o.register_hook(lambda g, i=i, s=seen[1]: s.add(i))
                 return outs
-            cap = self._capture(inputs, sorted(seen[1]), grad_mode)
+            if self.__dict__.get("_broken"):
+                stats["eager"] += 1
+                return self.fn(*inputs)
+            try:
+                cap = self._capture(inputs, sorted(seen[1]), grad_mode)
+            except Exception as e:   # something inside the segment cannot be recorded (a library call that allocates / synchronises): keep the
+                # eager path for this segment from now on, and say so once
+                import sys
+                self._broken = repr(e)[:300]
+                stats["capture_failed"] = stats.get("capture_failed", 0) + 1
+                print(f"[s2d] GraphedSegment '{self.name}': capture failed, segment stays eager: {self._broken}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                return self.fn(*inputs)
             self._caps[key] = cap
             stats["capture"] += 1
         stats["replay"] += 1

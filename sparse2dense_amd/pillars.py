@@ -488,7 +488,10 @@ class PointPillarsScatter_S2D(nn.Module):
         return F_S_a, F_S_b
 
     def forward(self, voxel_features, coords, batch_size, input_shape):
-        canvas = _scatter_canvas(voxel_features, coords, batch_size, input_shape)
+        return self.dense_forward(_scatter_canvas(voxel_features, coords, batch_size, input_shape))
+
+    def dense_forward(self, canvas):
+        """everything behind the scatter: shapes depend on the batch size only (the detector's graphed segment starts here)"""
         bf16 = self.dense_dtype == torch.bfloat16 and canvas.is_cuda
         if bf16:
             from .necks import _ToNhwcBf16, _ToPlanarF32
@@ -542,6 +545,11 @@ class PointPillars(SingleStageDetector):
 @DETECTORS.register_module
 class KD_PointPillars(PointPillars):
     mask_offset_loss = staticmethod(mask_offset_loss)
+    # S2D_PILLAR_GRAPH=1 routes everything behind the pillar canvas through a GraphedSegment (use_hip_graphs).  OFF: tried in r05 - the capture
+    # succeeds, the replayed step's gradient norm is NaN (bench.py's finite-gradient assertion caught it).  The pillar S2D module still runs
+    # library ops inside the segment (MIOpen 32-channel convs, torch up-sampling / pooling backward): what they record into a HIP graph
+    # (memset / memcpy nodes, rule 32; workspaces) is not under our control.  Until those layers are on our own kernels the pillar step stays eager.
+    graphed_segment = False
 
     def extract_feat(self, data):
         feats = self.reader(data["features"], data["num_voxels"], data["coors"])
@@ -549,6 +557,17 @@ class KD_PointPillars(PointPillars):
         F_S_a, F_S_b, gen_offset, gen_mask = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
         x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
         return x, F_S_a, F_S_b, gen_offset, gen_mask
+
+    def _dense_part(self, canvas, example, recon_gt):
+        """everything behind the pillar canvas (S2D module + 1x1x1 PCR heads + RPN + CenterHead + every loss, point_pillars.py:160-215): the
+        segment `use_hip_graphs()` replays as HIP graphs (graphed.GraphedSegment)"""
+        F_S_a, F_S_b, gen_offset, gen_mask = self.backbone.dense_forward(canvas)
+        x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
+        preds = self._dense(self.bbox_head, x)
+        n, _, d, h, w = gen_offset.shape
+        grid = metric_grid(n, d, h, w, gen_offset)
+        mask_loss, offset_loss = mask_offset_loss(gen_offset, gen_mask, recon_gt, grid)
+        return self.bbox_head.loss(example, preds), F_S_a, F_S_b, preds, mask_loss, offset_loss
 
     def forward(self, example, return_loss=True, **kwargs):
         batch_size = len(example["num_voxels"])
@@ -559,6 +578,17 @@ class KD_PointPillars(PointPillars):
             recon_gt = SparseConvTensor(feat, example["reconstruction_coordinates"].int(), shape, batch_size).dense()
         data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
                     batch_size=batch_size, input_shape=example["shape"][0])
+        import os
+        if return_loss and self.training and self.graph_dense and os.environ.get("S2D_PILLAR_GRAPH", "0") == "1":
+            # graphed path: reader + scatter eager (pillar counts vary), everything behind the canvas through the segment
+            self.backbone.dense_dtype = self.dense_dtype if self.dense_channels_last else torch.float32
+            feats = self.reader(data["features"], data["num_voxels"], data["coors"])
+            canvas = _scatter_canvas(feats, data["coors"], batch_size, data["input_shape"])
+            if self._graph_ok(canvas):
+                tasks = len(self.bbox_head.tasks)
+                return self._run_segment("train:pillar", lambda c_, gt_, *flat: self._dense_part(c_, self._unflat_targets(flat, tasks), gt_), canvas,
+                                         [recon_gt] + self._flat_targets(example, tasks), modules=[self.backbone, self.neck, self.bbox_head])
+            return self._dense_part(canvas, example, recon_gt)
         x, F_S_a, F_S_b, gen_offset, gen_mask = self.extract_feat(data)
         preds = self._dense(self.bbox_head, x)
         if not return_loss:
