@@ -161,6 +161,37 @@ class SingleStageDetector(nn.Module):
             seg.__dict__["_spec"] = spec
         return self._unflat_struct(spec, list(outs))
 
+    def _padded_list(self, key, coors, feats):
+        """a voxel list (coors [M,4] + feats [M,C]) in capacity-sized persistent buffers (rows past the list carry batch index -1, which every
+        PCR kernel skips): a static-shaped input for the graph, whatever the cloud's voxel count.  The copies of all lists of a step go out in
+        one multi-tensor launch (`_flush_recon`)."""
+        coors = coors if coors.dtype == torch.int32 else coors.int()
+        feats = feats.float()
+        m = int(coors.shape[0])
+        store = self.__dict__.setdefault("_recon_pad", {})
+        ent = store.get(key)
+        if ent is None or ent[0].shape[0] < m or ent[0].device != coors.device or ent[1].shape[1] != feats.shape[1]:
+            cap = -(-int(m * 1.5 + 1) // 65536) * 65536
+            cb = torch.full((cap, 4), -1, dtype=torch.int32, device=coors.device)
+            fb = torch.zeros((cap, feats.shape[1]), dtype=torch.float32, device=coors.device)
+            cb._s2d_static = fb._s2d_static = True
+            ent = store[key] = [cb, fb, 0]
+        cb, fb, prev = ent
+        pend = self.__dict__.setdefault("_recon_pending", ([], []))
+        pend[0].extend([cb[:m], fb[:m]])
+        pend[1].extend([coors, feats])
+        if prev > m:
+            cb[m:prev].fill_(-1)
+        ent[2] = m
+        return cb, fb
+
+    def _flush_recon(self):
+        pend = self.__dict__.pop("_recon_pending", None)
+        if pend and pend[0]:
+            from .graphed import _copy_all
+            with torch.no_grad():
+                _copy_all(pend[0], pend[1])
+
     def _read(self, example, prefix=""):
         mean_key = prefix + "voxel_mean"
         if mean_key in example:
@@ -298,36 +329,7 @@ class KD_VoxelNet(VoxelNet):
         return losses, F_S_a, F_S_b, preds, mask_loss, comp_loss
 
     def _padded_recon(self, example, scale):
-        """the recon voxels of one scale in capacity-sized persistent buffers (rows past the list carry batch index -1, which every PCR kernel
-        skips): a static-shaped input for the graph, whatever the cloud's voxel count"""
-        coors = example[f"reconstruction_coordinates_{scale}"]
-        feats = self._read_scaled(example, scale)
-        coors = coors if coors.dtype == torch.int32 else coors.int()
-        feats = feats.float()
-        m = int(coors.shape[0])
-        store = self.__dict__.setdefault("_recon_pad", {})
-        ent = store.get(scale)
-        if ent is None or ent[0].shape[0] < m or ent[0].device != coors.device or ent[1].shape[1] != feats.shape[1]:
-            cap = -(-int(m * 1.5 + 1) // 65536) * 65536
-            cb = torch.full((cap, 4), -1, dtype=torch.int32, device=coors.device)
-            fb = torch.zeros((cap, feats.shape[1]), dtype=torch.float32, device=coors.device)
-            cb._s2d_static = fb._s2d_static = True
-            ent = store[scale] = [cb, fb, 0]
-        cb, fb, prev = ent
-        pend = self.__dict__.setdefault("_recon_pending", ([], []))   # copies of both scales go out in one multi-tensor launch (_flush_recon)
-        pend[0].extend([cb[:m], fb[:m]])
-        pend[1].extend([coors, feats])
-        if prev > m:
-            cb[m:prev].fill_(-1)
-        ent[2] = m
-        return cb, fb
-
-    def _flush_recon(self):
-        pend = self.__dict__.pop("_recon_pending", None)
-        if pend and pend[0]:
-            from .graphed import _copy_all
-            with torch.no_grad():
-                _copy_all(pend[0], pend[1])
+        return self._padded_list(scale, example[f"reconstruction_coordinates_{scale}"], self._read_scaled(example, scale))
 
     def _dense_part_s2d(self, x, example, want_pcr):
         """first half of `_dense_part` as a segment of its own: S2D module + PCR head + PCR losses -> (F_S_a, F_S_b, mask_loss, comp_loss)"""

@@ -22,7 +22,7 @@ from .backbones import build_norm_layer
 from .dense2d import Conv1x1, Conv3x3, ConvT4x4S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import FastBatchNorm3d, PointwiseConv3d
 from .detectors import SingleStageDetector
-from .heads import mask_offset_loss, metric_grid
+from .heads import mask_offset_loss, mask_offset_loss_sparse, metric_grid
 from .registry import BACKBONES, DETECTORS, READERS
 from .spconv import FeatureBatchNorm1d, SparseConvTensor
 
@@ -545,10 +545,17 @@ class PointPillars(SingleStageDetector):
 @DETECTORS.register_module
 class KD_PointPillars(PointPillars):
     mask_offset_loss = staticmethod(mask_offset_loss)
-    # S2D_PILLAR_GRAPH=1 routes everything behind the pillar canvas through a GraphedSegment (use_hip_graphs).  OFF: tried in r05 - the capture
-    # succeeds, the replayed step's gradient norm is NaN (bench.py's finite-gradient assertion caught it).  The pillar S2D module still runs
-    # library ops inside the segment (MIOpen 32-channel convs, torch up-sampling / pooling backward): what they record into a HIP graph
-    # (memset / memcpy nodes, rule 32; workspaces) is not under our control.  Until those layers are on our own kernels the pillar step stays eager.
+    # S2D_PILLAR_GRAPH=1 routes everything behind the pillar canvas through a GraphedSegment (use_hip_graphs).  OFF by default, two r05 findings
+    # (tools/graph_probe_pillar*.py):
+    #  1. with the reference's dense PCR formulation (torch reductions over a [B,5,1,468,468] target) the replayed step went non-finite from
+    #     the SECOND replay on: torch's multi-block reductions zero their semaphores with hipMemsetAsync, and a memset node inside a replayed
+    #     HIP graph goes out of order (DESIGN rule 32) - count_pos / n_sel came back as garbage.  Fixed: the PCR losses now come from the
+    #     sparse recon-pillar list on csrc/losses.hip in every mode (`_pcr_losses`), as in the voxel detector.
+    #  2. with that fixed, small runs replay bit-equal on every layer that runs on our kernels, but at the benchmark's size 3 of 7 runs still
+    #     ended with a non-finite gradient norm (bench.py's assertion): the segment keeps MIOpen calls - encoder_1's three 32-channel convs,
+    #     the backward of encoder_2's stride-2 conv at 117 -> 59, the RPN's stride-4 transposed conv - whose atomics-based weight gradients
+    #     zero their outputs the same way.  And there is nothing to win yet: the pillar step is GPU-bound (23.1 ms graphed, 23.2 ms kernel by
+    #     kernel at B = 4).  Until those layers are on our own kernels the pillar step stays kernel by kernel.
     graphed_segment = False
 
     def extract_feat(self, data):
@@ -558,24 +565,34 @@ class KD_PointPillars(PointPillars):
         x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
         return x, F_S_a, F_S_b, gen_offset, gen_mask
 
-    def _dense_part(self, canvas, example, recon_gt):
+    @staticmethod
+    def _recon_list(example):
+        """the object-only pillars as a sparse list: coordinates + mean of the first five point features (point_pillars.py:180-187)"""
+        rv, rn = example["reconstruction_voxels"], example["reconstruction_num_points"]
+        feat = (rv[:, :, :5].sum(dim=1) / rn.type_as(rv).view(-1, 1)).contiguous()
+        return example["reconstruction_coordinates"].int(), feat
+
+    def _pcr_losses(self, gen_offset, gen_mask, coors, feat, example, batch_size):
+        if gen_offset.is_cuda and gen_offset.dtype == torch.float32 and gen_mask.dtype == torch.float32:
+            # the target stays sparse (csrc/losses.hip: both losses at the recon pillars + one dense reduction over the occupancy logits)
+            return mask_offset_loss_sparse(gen_offset, gen_mask, coors, feat)
+        # the reference's formulation on the dense target (point_pillars.py:188-215): the CPU oracle stack
+        shape = np.array(example["shape"][0][::-1]).astype("int64")
+        recon_gt = SparseConvTensor(feat, coors, shape, batch_size).dense()
+        n, _, d, h, w = gen_offset.shape
+        return mask_offset_loss(gen_offset, gen_mask, recon_gt, metric_grid(n, d, h, w, gen_offset))
+
+    def _dense_part(self, canvas, example, coors, feat):
         """everything behind the pillar canvas (S2D module + 1x1x1 PCR heads + RPN + CenterHead + every loss, point_pillars.py:160-215): the
         segment `use_hip_graphs()` replays as HIP graphs (graphed.GraphedSegment)"""
         F_S_a, F_S_b, gen_offset, gen_mask = self.backbone.dense_forward(canvas)
         x = self._dense(self.neck, F_S_a, keep_first=True) if self.with_neck else F_S_a
         preds = self._dense(self.bbox_head, x)
-        n, _, d, h, w = gen_offset.shape
-        grid = metric_grid(n, d, h, w, gen_offset)
-        mask_loss, offset_loss = mask_offset_loss(gen_offset, gen_mask, recon_gt, grid)
+        mask_loss, offset_loss = self._pcr_losses(gen_offset, gen_mask, coors, feat, example, canvas.shape[0])
         return self.bbox_head.loss(example, preds), F_S_a, F_S_b, preds, mask_loss, offset_loss
 
     def forward(self, example, return_loss=True, **kwargs):
         batch_size = len(example["num_voxels"])
-        if return_loss:   # dense reconstruction target from the object-only pillars (point_pillars.py:180-190)
-            rv, rn = example["reconstruction_voxels"], example["reconstruction_num_points"]
-            feat = (rv[:, :, :5].sum(dim=1) / rn.type_as(rv).view(-1, 1)).contiguous()
-            shape = np.array(example["shape"][0][::-1]).astype("int64")
-            recon_gt = SparseConvTensor(feat, example["reconstruction_coordinates"].int(), shape, batch_size).dense()
         data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
                     batch_size=batch_size, input_shape=example["shape"][0])
         import os
@@ -584,16 +601,18 @@ class KD_PointPillars(PointPillars):
             self.backbone.dense_dtype = self.dense_dtype if self.dense_channels_last else torch.float32
             feats = self.reader(data["features"], data["num_voxels"], data["coors"])
             canvas = _scatter_canvas(feats, data["coors"], batch_size, data["input_shape"])
+            coors, feat = self._recon_list(example)
             if self._graph_ok(canvas):
                 tasks = len(self.bbox_head.tasks)
-                return self._run_segment("train:pillar", lambda c_, gt_, *flat: self._dense_part(c_, self._unflat_targets(flat, tasks), gt_), canvas,
-                                         [recon_gt] + self._flat_targets(example, tasks), modules=[self.backbone, self.neck, self.bbox_head])
-            return self._dense_part(canvas, example, recon_gt)
+                cb, fb = self._padded_list("pillar", coors, feat)
+                self._flush_recon()
+                return self._run_segment("train:pillar", lambda c_, cb_, fb_, *flat: self._dense_part(c_, self._unflat_targets(flat, tasks), cb_, fb_),
+                                         canvas, [cb, fb] + self._flat_targets(example, tasks), modules=[self.backbone, self.neck, self.bbox_head])
+            return self._dense_part(canvas, example, coors, feat)
         x, F_S_a, F_S_b, gen_offset, gen_mask = self.extract_feat(data)
         preds = self._dense(self.bbox_head, x)
         if not return_loss:
             return self.bbox_head.predict(example, preds, self.test_cfg)
-        n, _, d, h, w = gen_offset.shape
-        grid = metric_grid(n, d, h, w, gen_offset)
-        mask_loss, offset_loss = mask_offset_loss(gen_offset, gen_mask, recon_gt, grid)
+        coors, feat = self._recon_list(example)
+        mask_loss, offset_loss = self._pcr_losses(gen_offset, gen_mask, coors, feat, example, batch_size)
         return self.bbox_head.loss(example, preds), F_S_a, F_S_b, preds, mask_loss, offset_loss

@@ -55,6 +55,30 @@ def test_conv1x1_at_bev_size(cin, cout):
     assert (part[:, 1].sum(0) - s2).abs().max() <= 1e-3 * s2.abs().max()
 
 
+@pytest.mark.parametrize("n,ca,cb,h,w", [(4, 256, 128, 188, 188), (4, 128, 64, 468, 468), (2, 128, 128, 234, 234)])
+def test_stride2_weight_gradient_at_bev_size_reads_nothing_outside_its_operands(n, ca, cb, h, w):
+    """the stride-2 contraction (csrc/conv2d_wgrad.hip STRIDE = 2: backward of the RPN blocks' first conv) at the voxel and pillar BEV sizes
+    against a float64 contraction, with both operands embedded in NaN-filled buffers: a tile tail that reads past a row or past the tensor
+    shows up as a non-finite or changed result"""
+    from sparse2dense_amd import dense2d as D
+
+    def embedded(shape, fill, seed):
+        nn_, c, hh, ww = shape
+        numel = nn_ * c * hh * ww
+        buf = torch.full((numel + 2 * 65536,), fill, dtype=torch.bfloat16, device=DEV)
+        t = buf[65536:65536 + numel].view(nn_, hh, ww, c).permute(0, 3, 1, 2)
+        t.copy_(torch.randn(shape, device=DEV, generator=torch.Generator(DEV).manual_seed(seed)))
+        return t
+    res = []
+    for fill in (0.0, float("nan")):
+        a, b = embedded((n, ca, h // 2, w // 2), fill, 1), embedded((n, cb, h, w), fill, 2)
+        res.append(D.conv_s2_wgrad(a, b, 3))
+    assert bool(torch.isfinite(res[1]).all()) and torch.equal(res[0], res[1])
+    ref = torch.ops.aten.convolution_backward(a.double(), b.double(), torch.zeros(ca, cb, 3, 3, dtype=torch.float64, device=DEV), None, [2, 2], [1, 1],
+                                              [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert float((res[0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 def _pcr_run(neck, bf16, F_S_b, targets):
     """S2D_RPN._pcr_head as the detector calls it (SingleStageDetector._dense): under bf16 autocast on the NHWC map, or plain fp32"""
     neck.pcr_targets = {s: (c, f) for s, (c, f) in targets.items()}

@@ -218,4 +218,3 @@ def test_distillation_step_is_independent_of_the_graph_replay():
         if g is not None:
             assert torch.equal(g, r)
     assert ref_out[-1][0] != ref_out[0][0] and ref_out[0][1] > 0 and ref_out[0][2] > 0
-

@@ -27,8 +27,9 @@ def _case(b, d, h, w, m, seed, special=True):
     return coors, feats, gen_off, gen_mask
 
 
-@pytest.mark.parametrize("b,d,h,w,m", [(2, 6, 20, 24, 300), (1, 5, 17, 9, 40), (4, 10, 94, 94, 20000)])
-def test_pcr_sparse_losses_match_dense_formulation(b, d, h, w, m):
+@pytest.mark.parametrize("b,d,h,w,m,pad", [(2, 6, 20, 24, 300, 0), (1, 5, 17, 9, 40, 0), (4, 10, 94, 94, 20000, 0),
+                                             (4, 1, 468, 468, 9000, 3000)])   # last: the pillar grid (point_pillars.py:180-215) with a padded list
+def test_pcr_sparse_losses_match_dense_formulation(b, d, h, w, m, pad):
     coors, feats, gen_off, gen_mask = _case(b, d, h, w, m, seed=b * 7 + m)
     # reference: dense target + metric grid, float64, host
     gt = torch.zeros(b, d, h, w, 5, dtype=torch.float64)
@@ -42,6 +43,9 @@ def test_pcr_sparse_losses_match_dense_formulation(b, d, h, w, m):
     (1.7 * ml_ref + 0.6 * ol_ref).backward()
     go = gen_off.cuda().requires_grad_(True)
     gm = gen_mask.cuda().requires_grad_(True)
+    if pad:   # rows past the list: batch index -1, skipped by the kernels (the capacity-sized static buffers of the graphed segment)
+        coors = torch.cat([coors, torch.full((pad, 4), -1, dtype=torch.int32)])
+        feats = torch.cat([feats, torch.randn(pad, 5)])
     ml, ol = heads.mask_offset_loss_sparse(go, gm, coors.cuda(), feats.cuda())
     (1.7 * ml + 0.6 * ol).backward()
     np.testing.assert_allclose(ml.item(), ml_ref.item(), rtol=1e-5)
