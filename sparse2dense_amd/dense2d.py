@@ -757,6 +757,7 @@ class AbsorbedZeroPad2d(nn.ZeroPad2d):
 # BatchNorm2d (+ReLU) on NHWC bf16 (csrc/features.hip, s2d_bnrow_*)
 # --------------------------------------------------------------------------------------------------
 _ws_cache = {}
+_WS_POISON = None if not _os.environ.get("S2D_WS_POISON") else float(_os.environ["S2D_WS_POISON"])
 WS_PRIVATE = False   # set by graphed.GraphedSegment while it captures: a HIP graph must not reference a buffer that a later, larger request re-allocates
 
 
@@ -770,6 +771,8 @@ def _ws(nbytes, device):
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+    if _WS_POISON is not None:   # debugging aid (S2D_WS_POISON=<float>): a kernel that reads workspace words it did not write shows up in the results
+        buf.view(torch.float32).fill_(_WS_POISON)
     return buf
 
 

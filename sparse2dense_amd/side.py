@@ -260,6 +260,10 @@ def replay_on_side(graph, dev):
         torch.autograd.Variable._execution_engine.queue_callback(lambda: join(dev))
 
 
+_PCR_ONLY = None if not os.environ.get("S2D_SIDE_PCR_ONLY") else {int(v) for v in os.environ["S2D_SIDE_PCR_ONLY"].split(",")}
+_pcr_count = [None, 0]
+
+
 def run(weight, fn, *inputs, kind="dense", bias=None, pair=False):
     """fn() -> gradient tensor(s) of `weight` (and its bias); on the side stream when the protocol above allows it.
     bias: the bias parameter when fn returns (dw, db); pair: fn returns a 2-tuple"""
@@ -277,6 +281,15 @@ def run(weight, fn, *inputs, kind="dense", bias=None, pair=False):
     if not usable(weight, kind, bias):
         stats["plain"] += 1
         return fn()
+    if kind == "pcr" and _PCR_ONLY is not None:   # debugging aid: only the listed pcr-kind calls of a backward pass (in call order) leave the chain
+        gid = torch._C._current_graph_task_id()
+        if _pcr_count[0] != gid:
+            _pcr_count[:] = [gid, 0]
+        k = _pcr_count[1]
+        _pcr_count[1] += 1
+        if k not in _PCR_ONLY:
+            stats["plain"] += 1
+            return fn()
     dev = weight.device.index
     _pass_ids[dev][1].add(id(weight))
     side = _side(dev)
@@ -299,6 +312,8 @@ def run(weight, fn, *inputs, kind="dense", bias=None, pair=False):
             stats["relaid"] = stats.get("relaid", 0) + 1
     finally:
         torch.cuda.set_stream(cur)
+    if os.environ.get("S2D_SIDE_DEBUG_SYNC") == "1":   # debugging aid: same streams and allocation pattern, no concurrency
+        torch.cuda.synchronize()
     if dw is not None and dw.shape != weight.shape:   # cannot be adopted: the main stream waits here
         cur.wait_stream(side)
         stats["waited"] = stats.get("waited", 0) + 1
