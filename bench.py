@@ -892,10 +892,12 @@ def main():
             a2 = copy.copy(args)
             m2, t2, f2, st2 = setup_workload(a2, "s2d_student", dev, rank)
             ddp_mode = (False, mode[1], "", "")
+            if os.environ.get("S2D_DENSE_GRAPH_SYNCBN", "0") == "1":   # opt-in: the dense graphs WITH the batch norms' collectives captured inside (direct RCCL route)
+                ddp_mode = (True, mode[1], "", "aux,dense,pcr")
             set_mode([getattr(m2, "module", m2), t2], ddp_mode)
             run2 = st2 if (ddp_mode[1] and st2.sync_step is not st2) else st2.sync_step
             k, d2 = max(5, min(args.steps, 10)), {}
-            el, _ = timed(run2, k, 3, 1, dev, d2)
+            el, _ = timed(run2, k, 5 if ddp_mode[0] else 3, 1, dev, d2)
             if hasattr(f2, "close"):
                 f2.close()
             from sparse2dense_amd import collective

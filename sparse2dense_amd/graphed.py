@@ -45,6 +45,18 @@ def enabled():
     return os.environ.get("S2D_DENSE_GRAPH", "1") != "0"
 
 
+def _capture_mode():
+    """hipStreamBeginCapture mode.  "global" (torch's default): an unsafe runtime call on ANY thread invalidates the capture - right while this
+    process is the only one talking to the device.  With a process group up, c10d's watchdog thread polls its work events (hipEventQuery)
+    whenever it likes: under "global" that aborted the process in the middle of a capture (r05); "thread_local" confines the check to the
+    capturing thread.  S2D_GRAPH_CAPTURE_MODE overrides."""
+    mode = os.environ.get("S2D_GRAPH_CAPTURE_MODE")
+    if mode:
+        return mode
+    import torch.distributed as dist
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def _sig(t):
     return (tuple(t.shape), t.dtype, tuple(t.stride()), bool(t.requires_grad))
 
@@ -281,7 +293,7 @@ class GraphedSegment:
             with contextlib.ExitStack() as stack:
                 for m, repl in swaps:
                     stack.enter_context(_reparametrize_module(m, repl))
-                with torch.cuda.graph(cap.fwd, pool=cap.pool, stream=cap.stream):
+                with torch.cuda.graph(cap.fwd, pool=cap.pool, stream=cap.stream, capture_error_mode=_capture_mode()):
                     outs = self.fn(*cap.s_in)
             outs = tuple(outs)
             cap.s_out = outs
@@ -293,7 +305,7 @@ class GraphedSegment:
                 cap.bwd = torch.cuda.CUDAGraph()
                 from . import side
                 side.take_deferred()
-                with torch.cuda.graph(cap.bwd, pool=cap.pool, stream=cap.stream):
+                with torch.cuda.graph(cap.bwd, pool=cap.pool, stream=cap.stream, capture_error_mode=_capture_mode()):
                     grads = torch.autograd.grad([outs[i] for i in cap.g_idx], wrt, cap.s_gout, allow_unused=True)
                     side.join_capture()      # weight-gradient groups forked onto a second capturing stream (side.GRAPH_KINDS) rejoin here
                 side.capture_done()
@@ -307,7 +319,7 @@ class GraphedSegment:
                 if items:
                     slot = {id(q): k for k, q in enumerate(proxies)}
                     cap.bwd2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cap.bwd2, pool=cap.pool, stream=cap.stream):
+                    with torch.cuda.graph(cap.bwd2, pool=cap.pool, stream=cap.stream, capture_error_mode=_capture_mode()):
                         for weight, bias, fn, _inputs in items:
                             out = fn()
                             dw, db = out if isinstance(out, (tuple, list)) else (out, None)

@@ -132,15 +132,24 @@ def join(device=None):
 
 
 def stream_after(dev):
-    """The side stream of device `dev`, made to wait for everything enqueued so far on the current stream - or None when it has no work
-    pending.  For consumers of the gradients that need not be on the chain either (dp.GradBuckets: bucket copies + all-reduce launch)."""
-    if dev is None or not _pending.get(dev):
+    """A stream on which every weight gradient launched off the chain so far is complete in stream order - the eager side stream, or the stream
+    the graphed segment's weight-gradient graph was replayed on (`replay_on_side`) - made to wait for everything enqueued so far on the current
+    stream; None when no such work is pending.  For consumers of the gradients that need not be on the chain either (dp.GradBuckets: bucket
+    copies + all-reduce launch)."""
+    if dev is None:
         return None
-    side = _streams[dev]
+    sp, gp = bool(_pending.get(dev)), bool(_gpending.get(dev))
+    if not (sp or gp):
+        return None
+    target = _gstreams[dev] if gp else _streams[dev]
     ev = _event(dev)
     ev.record(torch.cuda.current_stream(dev))
-    side.wait_event(ev)
-    return side
+    target.wait_event(ev)
+    if gp and sp:   # both kinds of side work pending: the graph stream also waits for the eager side stream
+        ev = _event(dev)
+        ev.record(_streams[dev])
+        target.wait_event(ev)
+    return target
 
 
 # ---- inside a HIP-graph capture (graphed.GraphedSegment): the same overlap as parallel branches of the backward graph ----------------

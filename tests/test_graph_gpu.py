@@ -218,3 +218,66 @@ def test_distillation_step_is_independent_of_the_graph_replay():
         if g is not None:
             assert torch.equal(g, r)
     assert ref_out[-1][0] != ref_out[0][0] and ref_out[0][1] > 0 and ref_out[0][2] > 0
+
+
+def test_graph_replay_with_the_batch_norm_collectives_captured_inside_on_one_rank(monkeypatch):
+    """the N>1 route at world_size 1 over RCCL (dp.wrap_ddp -> gradient buckets, self-synchronising batch norms on the library's own RCCL
+    communicator, collective.init_direct) with S2D_DENSE_GRAPH_SYNCBN=1: every batch-norm all-reduce of the dense segment is a node of the
+    forward / backward HIP graph (capture mode thread_local: c10d's watchdog thread polls its events while the capture runs), the gradient
+    buckets fire from the hooks `_Replay.backward` runs - and the run equals the kernel-by-kernel one bit for bit.
+    Reference: /root/reference/det3d/torchie/apis/train.py:360-391 (SyncBN + DistributedDataParallel)."""
+    import torch.distributed as dist
+    from sparse2dense_amd import _lib, collective, dense2d, dp, graphed, hip_ops, side, waymo_configs
+    from sparse2dense_amd.data import SyntheticFrames
+    from sparse2dense_amd.registry import build_detector
+    from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+    from sparse2dense_amd.train_step import backward_and_step
+    if dist.is_initialized():
+        pytest.skip("a process group is already up")
+    monkeypatch.setenv("S2D_FORCE_DDP", "1")
+    monkeypatch.setenv("S2D_BUCKET_MB", "4")
+    monkeypatch.setenv("S2D_DENSE_GRAPH_SYNCBN", "1")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29593", rank=0, world_size=1)
+    dev = torch.device("cuda:0")
+
+    def run(graph, steps=6):
+        side.enable(False)
+        side.graph_defer("dense,aux,pcr")
+        dense2d.clear_pack_cache()
+        hip_ops.set_sparse_compute_dtype("s16")
+        torch.manual_seed(11)
+        model = build_detector(waymo_configs.s2d_student())
+        model.dense_dtype = torch.bfloat16
+        model.use_channels_last()
+        model = dp.wrap_ddp(model.to(dev).train(), 0)
+        assert collective.sync_on() and collective.direct_enabled()
+        if graph:
+            getattr(model, "module", model).use_hip_graphs()
+        frames = SyntheticFrames(2, n_points=12000, seed=5, distill=True, device=dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = build_one_cycle_optimizer(model, dict(wd=0.01))
+        sch = build_one_cycle_scheduler(opt, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4), total_steps=100)
+        for k in graphed.stats:
+            graphed.stats[k] = 0
+        losses = []
+        for it in range(steps):
+            out = model(frames.example(), return_loss=True, return_feature=True)
+            loss = sum(out[0]["loss"]) + out[4] + out[5]
+            backward_and_step(loss, params, opt, sch, it, 35.0)
+            losses.append(float(loss.detach()))
+        final = torch.cat([p.detach().flatten()[:64].double().cpu() for p in params])
+        model._s2d_grad_buckets.remove()
+        return losses, final, dict(graphed.stats)
+    try:
+        ref = run(False)
+        got = run(True)
+        assert ref[2]["replay"] == 0 and got[2]["capture"] == 1 and got[2]["replay"] == 4, (ref[2], got[2])
+        assert got[0] == ref[0], (got[0], ref[0])
+        assert torch.equal(got[1], ref[1])
+        assert ref[0][-1] != ref[0][0]
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+        collective._DIRECT = False
+        _lib.load().s2d_comm_shutdown()
+        dist.destroy_process_group()
