@@ -53,6 +53,9 @@ int s2d_last_error(char *buf, size_t buf_len);
 /* copies "compiler; HIP runtime headers; target; build date" of this library into buf; returns the text's length (no reference
  * counterpart: the reference's kernels come prebuilt with spconv / torch, docs/INSTALL.md:12,65-72) */
 int s2d_build_info(char *buf, size_t buf_len);
+/* debugging aid (no reference counterpart): `blocks` workgroups fill 64 KB of LDS each with `value`, `spin` + 1 times; sink may be NULL.
+ * tools/side_stress.py uses it to look for kernels that read LDS they did not write. */
+int s2d_debug_lds_fill(float value, int blocks, int spin, float *sink, s2d_stream_t stream);
 
 /* ---- voxelization (hard voxelizer + fused reader mean) ------------------------------------ */
 /*

@@ -21,6 +21,7 @@ SIGNATURES = {
     "s2d_version": (ctypes.c_int, []),
     "s2d_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "s2d_build_info": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "s2d_debug_lds_fill": (ctypes.c_int, [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "s2d_voxelize_run": (ctypes.c_int, [c_f32p, ctypes.c_int64, ctypes.c_int, _F6, _F3, ctypes.c_int, ctypes.c_int,
                                         c_f32p, c_i32p, c_i32p, c_f32p, c_i32p, ctypes.c_void_p, ctypes.c_size_t,

@@ -17,6 +17,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-fast-math", "-ffp-contract=off"]
 
 
+# per-file flags (also part of the staleness test: an object built with other flags is rebuilt)
+EXTRA = {}
+if os.environ.get("S2D_BUILD_LOSSES_NOSLP") == "1":
+    EXTRA["losses.hip"] = ["-fno-slp-vectorize"]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -36,7 +42,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             procs.append((s, subprocess.Popen(cmd)))

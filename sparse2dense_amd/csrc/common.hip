@@ -48,7 +48,25 @@ int zero_async(void *p, size_t bytes, hipStream_t st) {
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
+
+// debugging aid: every resident workgroup fills 64 KB of LDS with `value` (two workgroups per CU cover 128 of the 160 KB) and spins for
+// `spin` rounds - a kernel that reads LDS words it did not write picks the value up when it lands on that CU next
+__global__ __launch_bounds__(256) void lds_fill_kernel(float value, int spin, float *sink) {
+    __shared__ float buf[16384];
+    for (int r = 0; r <= spin; ++r) {
+        for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = value;
+        __syncthreads();
+    }
+    if (sink && buf[(threadIdx.x * 61) & 16383] == 12345.678f) sink[0] = 1.f;   // (keeps the stores alive)
+}
 }  // namespace s2d
+
+extern "C" int s2d_debug_lds_fill(float value, int blocks, int spin, float *sink, s2d_stream_t stream) {
+    S2D_CHECK_ARG(blocks > 0 && spin >= 0, "debug_lds_fill: bad argument");
+    hipLaunchKernelGGL(s2d::lds_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, value, spin, sink);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
 
 extern "C" int s2d_version(void) { return 100; }
 

@@ -197,6 +197,9 @@ def sparse2dense_loss(F_S_a, F_D_a, F_S_b, F_D_b):
     return masked_mse_pair(F_S_a, F_D_a, 10.0, 20.0) + masked_mse_pair(F_S_b, F_D_b, 5.0, 20.0)
 
 
+DEBUG_SUMS = []
+
+
 def mask_offset_loss(gen_offset, gen_mask, gt, grid):
     """PCR losses (voxelnet.py:171-185): BCE-with-logits on occupancy with pos_weight=neg/pos and L1
     on offsets at the non-zero GT entries."""
@@ -390,6 +393,11 @@ class _PcrLevelNormFn(torch.autograd.Function):
         y16 = y.dtype == torch.bfloat16
         _lib.check((lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(*args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(),
                                                                                                 _stream()), "s2d_pcr_level_bwd_sums")
+        if os.environ.get("S2D_DEBUG_SUMS2") == "1":   # debugging aid (tools/side_stress.py): the same launch again, results kept for a comparison after the pass
+            grads2, sums2 = torch.empty_like(grads), torch.empty_like(sums)
+            _lib.check((lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(*args, _ptr(grads2), _ptr(sums2), _ptr(ws), ws.numel(),
+                                                                                                    _stream()), "s2d_pcr_level_bwd_sums")
+            DEBUG_SUMS.append((c, co, sums, sums2, grads, grads2))
         sums_all = sums
         if ctx.sync:
             sums_all = sums.clone()

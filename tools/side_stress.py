@@ -4,14 +4,18 @@ every parameter gradient compared BIT FOR BIT with the single-stream run; prints
 r04 findings: `spconv_wgrad_s16_coop128` (shared pair ring initialised without a barrier: one run in ~8 had one conv4 weight gradient off
 in the last digits; fixed, 0 of 36 afterwards); S2D_PCR_STREAM=1: one run in ~25 with differing backbone gradients (left opt-in); and at the
 benchmark's size (`... 3 0:0,1:0 150000 4`) the single-stream run "differed" from itself: NaN gradients - the wrong `spconv_rg_kernel<128,128,2,8>` (DESIGN rule 31).
-r05 findings: S2D_PCR_STREAM=1 (`sparse:1`): 0 mismatches in 140 runs since the dense kernels' accumulators are cleared by a
-kernel instead of hipMemsetAsync (rule 32).  Mode `pcr` (the PCR head's weight gradients on the eager side stream): 68 of 70 runs differ, and
-S2D_SIDE_PCR_ONLY=<k> (only the k-th pcr-kind call of a pass leaves the chain) pins it to call 0 = the 16 -> 3 up-sampler's weight gradient
-(`ct_wgrad_narrow` with the input-norm fold) - a kernel that only READS chain data and whose own result agrees; the chain's first differing value is
-the next level's batch-norm sums.  It needs real concurrency (S2D_SIDE_DEBUG_SYNC=1: 0 of 5), the caching allocator (PYTORCH_NO_CUDA_MEMORY_CACHING=1:
-0 of 4) and the normal lifetimes of the level's small outputs (S2D_STRESS_HOOKS=1 holding level.out.* until the end of the step: 0 of 7; any single
-one of them held: still 3-4 of 4); workspaces are not involved (STRESS_WS_POISON=nan in single-stream mode: bit-equal), nor uninitialised
-allocations (tools/pcr_side_probe.py POISON=nan).  S2D_STRESS_PTRS=1 logs the storage addresses of the pass."""
+r05 findings (rule 36): S2D_PCR_STREAM=1 (`sparse:1`): 0 mismatches in 140 runs since the dense kernels' accumulators are cleared by a
+kernel instead of hipMemsetAsync (rule 32).  Mode `pcr` (the PCR head's weight gradients on the eager side stream): 68 of 70 runs differ; root cause found with the
+switches below - not a data hazard but packed-FP32 code of the NEXT level's statistics kernel (`pcr_level_bwd_dense_kernel<32,16,2>`, 544 v_pk_fma_f32) whose high lanes
+become timing-dependent while the 16 -> 3 up-sampler's MFMA weight-gradient kernel runs beside it:
+  S2D_SIDE_PCR_ONLY=k        only the k-th pcr-kind call of a backward pass leaves the chain (k = 0 alone reproduces it)
+  S2D_DEBUG_CT_WGRAD=...     stand-ins for that call: zeros | read | long | lds | ldsfill[:v] (none perturbs) | privws | clone | clone_main (the real kernel on private
+                             copies of everything: still perturbs)
+  S2D_DEBUG_SUMS2=1          the statistics kernel launched twice back to back: differing sums (odd channels only) are printed per step
+  S2D_BUILD_LOSSES_NOSLP=1   (at build time) losses.hip without the SLP vectoriser: no v_pk_*, 0 mismatches, single-stream results bit-identical to the packed build (STRESS_DUMP=file)
+  S2D_SIDE_DEBUG_SYNC=1, PYTORCH_NO_CUDA_MEMORY_CACHING=1, S2D_STRESS_HOOKS=1 [S2D_STRESS_HOLD=tags | S2D_STRESS_PTRS=1], STRESS_WS_POISON=v: the dead ends (serialisation
+  effects, workspace poison, held references / address log)
+"""
 import os, sys, torch
 sys.path.insert(0, ".")
 from sparse2dense_amd import dense2d, hip_ops, side, waymo_configs
@@ -98,6 +102,14 @@ def run(mode, pcr, steps=4):
                 print(f"   ptr {ptr:#x} {nb:>10d} B {tag}" + (f"   <-- same block as {prev}" if prev else ""), flush=True)
                 seen[ptr] = tag
             PTRLOG.clear()
+        if os.environ.get("S2D_DEBUG_SUMS2") == "1":
+            from sparse2dense_amd import heads as _heads
+            for c_, co_, s1, s2, g1, g2 in _heads.DEBUG_SUMS:
+                if not (torch.equal(s1, s2) and torch.equal(g1, g2)):
+                    print(f"   step {it}: level C={c_} CO={co_}: two back-to-back launches of pcr_level_bwd_sums differ: sums {int((s1 != s2).sum())} of {s1.numel()}, grads {int((g1 != g2).sum())} of {g1.numel()}", flush=True)
+                    idx = (s1 != s2).nonzero().flatten().tolist()
+                    print("      indices", idx, "first", [float(s1[i]) for i in idx[:6]], "second", [float(s2[i]) for i in idx[:6]], flush=True)
+            _heads.DEBUG_SUMS.clear()
         extra = [float(t.double().abs().sum()) for _, t in REC]
         if it == 0 and REC and len(named) == len(params):
             named += [(f"rec{i}:{tag}", None) for i, (tag, _) in enumerate(REC)]
@@ -113,6 +125,10 @@ COMBOS = [tuple(c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) 
 REF_DONE = False
 ref, names = run("0", "0")
 REF_DONE = True
+if os.environ.get("STRESS_DUMP"):   # the single-stream run's checksums, for comparisons between builds
+    import json
+    with open(os.environ["STRESS_DUMP"], "w") as f:
+        json.dump({"names": names, "sums": ref}, f)
 fails = 0
 PREV = []
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
