@@ -360,7 +360,7 @@ static CmPlan cm_plan(int n, int c, int64_t p4) {
 
 
 // ---- single-GPU fast path: reduction of the per-block partials fused with the finalisation ------
-// one wave per channel: lanes stride over the partials of (sum, sumsq) resp. (sum g, sum g*x).
+// one workgroup per channel: its lanes stride over the partials of (sum, sumsq) resp. (sum g, sum g*x).
 __global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float *__restrict__ partial, int nblocks, float n,
                                                                      const float *__restrict__ gamma,
                                                                      const float *__restrict__ beta, float eps, float momentum,
@@ -369,12 +369,14 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float
                                                                      float *__restrict__ shift, float *__restrict__ running_mean,
                                                                      float *__restrict__ running_var,
                                                                      long long *__restrict__ batches_tracked, bool cm = false) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    // one workgroup per channel (r05; one wave per channel before): the four waves stride over the partial rows together - four times the
+    // loads in flight for a launch whose duration is the latency of its ~18 dependent-free load rounds - and fold in a fixed order
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (i >= c) return;
-    if (i == 0 && lane == 0 && batches_tracked) *batches_tracked += 1;
+    if (i == 0 && threadIdx.x == 0 && batches_tracked) *batches_tracked += 1;
     float s0 = 0.f, s1 = 0.f;
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
         s0 += cm ? partial[(size_t)i * nblocks + b] : partial[(size_t)b * 2 * c + i];
         s1 += cm ? partial[(size_t)(c + i) * nblocks + b] : partial[(size_t)b * 2 * c + c + i];
     }
@@ -383,7 +385,15 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_fwd_kernel(const float
         s0 += __shfl_xor(s0, d, 64);
         s1 += __shfl_xor(s1, d, 64);
     }
-    if (lane != 0) return;
+    __shared__ float red[2][4];
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float mean = s0 / n;
     float var = s1 / n - mean * mean;
     var = var > 0.f ? var : 0.f;
@@ -407,11 +417,11 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_bwd_kernel(const float
                                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                                      float *__restrict__ a, float *__restrict__ b,
                                                                      float *__restrict__ d, bool cm = false) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x;   // one workgroup per channel, as in the forward kernel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (i >= c) return;
     float sg = 0.f, sgx = 0.f;
-    for (int k = lane; k < nblocks; k += 64) {
+    for (int k = threadIdx.x; k < nblocks; k += 256) {
         sg += cm ? partial[(size_t)i * nblocks + k] : partial[(size_t)k * 2 * c + i];
         sgx += cm ? partial[(size_t)(c + i) * nblocks + k] : partial[(size_t)k * 2 * c + c + i];
     }
@@ -420,7 +430,15 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_bwd_kernel(const float
         sg += __shfl_xor(sg, s, 64);
         sgx += __shfl_xor(sgx, s, 64);
     }
-    if (lane != 0) return;
+    __shared__ float red[2][4];
+    if (lane == 0) {
+        red[0][wave] = sg;
+        red[1][wave] = sgx;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    sg = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sgx = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float m = mean[i], is = invstd[i];
     const float dg = is * (sgx - m * sg);
     dbeta[i] = sg;
@@ -949,7 +967,7 @@ extern "C" int s2d_bn1d_stats_finalize_f32(const float *x, int64_t n, int c, con
     }
     hipLaunchKernelGGL(col_reduce_kernel<false>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, nullptr, nullptr, 0, n, c,
                        p.rows_per_block, nullptr, (float *)ws);
-    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3(c), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
                        (long long *)batches_tracked);
     S2D_LAUNCH_CHECK();
@@ -972,7 +990,7 @@ extern "C" int s2d_bn1d_bwd_reduce_finalize_f32(const float *dy, const float *y,
     }
     hipLaunchKernelGGL(col_reduce_kernel<true>, dim3(p.nblocks), dim3(RED_THREADS), p.lds, st, x, dy, y, relu, n, c,
                        p.rows_per_block, g_out, (float *)ws);
-    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3(c), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, mean, invstd, c, dgamma, dbeta, a, b, d);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1034,7 +1052,7 @@ extern "C" int s2d_bnrow_stats_finalize_bf16(const void *x, int64_t n, int c, co
     RedPlan p;
     int rc = bnrow_reduce(false, x, nullptr, nullptr, nullptr, nullptr, 0, n, c, ws, ws_bytes, st, &p, "bnrow_stats_finalize");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3(c), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, beta, eps, momentum, c, mean, invstd, scale, shift, running_mean, running_var,
                        (long long *)batches_tracked, true);
     S2D_LAUNCH_CHECK();
@@ -1111,7 +1129,7 @@ extern "C" int s2d_bnrow_bwd_reduce_finalize_ld_bf16(const void *dy, int dy_ld, 
     RedPlan p;
     int rc = bnrow_reduce(true, x, dy, y, scale, shift, relu, n, c, ws, ws_bytes, st, &p, "bnrow_bwd_reduce_finalize", dy_ld);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
+    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3(c), dim3(256), 0, st, (const float *)ws, p.nblocks, (float)n,
                        gamma, mean, invstd, c, dgamma, dbeta, a, b, d, true);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1180,7 +1198,7 @@ extern "C" int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks
                   "bn_partials_finalize: bad argument");
     hipStream_t st = (hipStream_t)stream;
     nblocks = partials_prefold(partial, nblocks, c, ws, ws_bytes, st);
-    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3((c + 3) / 4), dim3(256), 0, st, partial, nblocks, (float)n, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3(c), dim3(256), 0, st, partial, nblocks, (float)n, gamma, beta, eps,
                        momentum, c, mean, invstd, scale, shift, running_mean, running_var, (long long *)batches_tracked);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
