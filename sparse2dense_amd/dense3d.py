@@ -76,6 +76,9 @@ def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
     return dw, db
 
 
+_DEBUG_CT_WGRAD = os.environ.get("S2D_DEBUG_CT_WGRAD", "")
+
+
 class _PwConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bf16=False):
@@ -299,49 +302,9 @@ class _ConvT3dFn(torch.autograd.Function):
                       "s2d_convt3d_k4s2p1_dgrad_f32")
         def wgrad():
             dw = torch.empty_like(weight)
-            dbg = os.environ.get("S2D_DEBUG_CT_WGRAD")   # debugging aid (tools/side_stress.py): stand-ins for the narrow layer's weight-gradient launch
-            if dbg and in_norm is not None:
-                if dbg == "zeros":       # no read of chain data at all, one tiny kernel
-                    return dw.zero_()
-                if dbg.startswith("ldsfill"):   # a concurrent kernel that only writes LDS (value after the colon, default NaN)
-                    dw.zero_()
-                    val = float(dbg.split(":")[1]) if ":" in dbg else float("nan")
-                    check(lib.s2d_debug_lds_fill(val, 1024, 2000, None, _stream()), "s2d_debug_lds_fill")
-                    return dw
-                if dbg == "lds":         # a concurrent load that leaves data in LDS: block reductions / softmax over the same operand
-                    dw.zero_()
-                    t = x.view(-1, x.shape[-1])
-                    acc = None
-                    for _ in range(8):
-                        t2 = torch.softmax(t, -1)
-                        acc = t2.sum(-1) if acc is None else acc + t2.sum(-1)
-                    dw.view(-1)[0] = acc.sum()
-                    return dw
-                if dbg == "long":        # a generic concurrent load: ~0.3 ms of chip-filling torch kernels over the same operands
-                    dw.zero_()
-                    t = x
-                    for _ in range(12):
-                        t = t * 1.0001
-                    dw.view(-1)[0] = t.sum()
-                    return dw
-                if dbg in ("clone", "clone_main"):   # the real kernels on private copies of every operand (made on the side / on the main stream)
-                    if dbg == "clone":
-                        xc, dc, nc = x.clone(), dout.clone(), in_norm.clone()
-                    else:
-                        xc, dc, nc = getattr(ctx, "_dbg_clones")
-                    ws = torch.empty(max(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), 256), dtype=torch.uint8, device=x.device)
-                    check(lib.s2d_convt3d_mfma_wgrad_d16_norm(_ptr(xc), _ptr(nc), _ptr(dc), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
-                                                              _stream()), "s2d_convt3d_mfma_wgrad_d16_norm")
-                    return dw
-                if dbg == "privws":      # the real kernels with a workspace of their own instead of the cached per-stream one
-                    ws = torch.empty(max(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), 256), dtype=torch.uint8, device=x.device)
-                    check(lib.s2d_convt3d_mfma_wgrad_d16_norm(_ptr(x), _ptr(in_norm), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
-                                                              _stream()), "s2d_convt3d_mfma_wgrad_d16_norm")
-                    return dw
-                if dbg == "read":        # reads the same operands with torch kernels, result unused
-                    dw.zero_()
-                    dw.view(-1)[0] = x.sum() + dout.float().sum() + in_norm.sum()
-                    return dw
+            if _DEBUG_CT_WGRAD and in_norm is not None:   # debugging aid (S2D_DEBUG_CT_WGRAD, tools/side_stress.py): stand-ins for this launch
+                from . import _debug
+                return _debug.ct_wgrad_stand_in(_DEBUG_CT_WGRAD, dw, x, dout, in_norm, (n, cin, cout, d, h, w), getattr(ctx, "_dbg_clones", None))
             if d16 and in_norm is not None:
                 ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
                 check(lib.s2d_convt3d_mfma_wgrad_d16_norm(_ptr(x), _ptr(in_norm), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
@@ -371,7 +334,7 @@ class _ConvT3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             from . import side
             wp = getattr(ctx, "weight_p", None)
-            if os.environ.get("S2D_DEBUG_CT_WGRAD") == "clone_main" and in_norm is not None:
+            if _DEBUG_CT_WGRAD == "clone_main" and in_norm is not None:
                 ctx._dbg_clones = (x.clone(), dout.clone(), in_norm.clone())
             # (kind "pcr": deferred into the graphed segment's second graph, never on the eager weight-gradient stream; callers that
             # compose this backward - heads._UpsampleLevelFn - strip the DEFERRED marker)
