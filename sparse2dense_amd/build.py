@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-fast-math", "-ffp-contract=off"]
 
 
-# per-file extra flags (NOT part of the staleness test: touch the source or pass --force after changing them).
+# per-file extra flags; the flags an object was built with are kept beside it (<name>.flags) and are part of the staleness test.
 # S2D_BUILD_LOSSES_NOSLP=1: losses.hip without the SLP vectoriser, i.e. without packed-FP32 code (DESIGN rule 36; +0.1 ms per step)
 EXTRA = {}
 if os.environ.get("S2D_BUILD_LOSSES_NOSLP") == "1":
@@ -42,8 +42,13 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        flags = FLAGS + EXTRA.get(os.path.basename(s), [])
+        stamp = o[:-2] + ".flags"
+        built_with = open(stamp).read() if os.path.exists(stamp) else " ".join(FLAGS)   # (objects from before the stamps: the default flags)
+        if force or _stale(o, [s] + hdrs) or built_with != " ".join(flags):
+            with open(stamp, "w") as f:
+                f.write(" ".join(flags))
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             procs.append((s, subprocess.Popen(cmd)))
