@@ -21,6 +21,11 @@ spconv v1.x semantics restated here:
   * kernel offset index = row-major over (kz,ky,kx); weight layout [kD,kH,kW,Cin,Cout];
   * out[o] = sum_k W[k]^T in[j] over pairs (j -> o, k) where pos(j) = pos(o)*s - p + k*d (+bias);
   * .dense(): zeros[B,D,H,W,C] scatter rows, permute to [B,C,D,H,W].
+
+Device: rulebooks are numpy on the host, always.  The feature arithmetic is plain torch (index_select / mm /
+index_add) and runs wherever the feature tensor lives: the CPU by default; the GPU parity tests also run it in
+float64 on the device through torch's own kernels (no s2d kernel can be reached: tests/cpu_backend.py guards the
+library loader while the oracle runs), with tests/test_oracle_device.py holding device == CPU.
 """
 import itertools
 
@@ -192,8 +197,8 @@ def sparse_conv(features, weight, bias, pairs, n_out):
     for k, (i_in, i_out) in enumerate(pairs):
         if len(i_in) == 0:
             continue
-        i_in = torch.as_tensor(i_in, dtype=torch.long)
-        i_out = torch.as_tensor(i_out, dtype=torch.long)
+        i_in = torch.as_tensor(i_in, dtype=torch.long, device=features.device)
+        i_out = torch.as_tensor(i_out, dtype=torch.long, device=features.device)
         out = out.index_add(0, i_out, features.index_select(0, i_in) @ w[k])
     if bias is not None:
         out = out + bias
@@ -202,7 +207,7 @@ def sparse_conv(features, weight, bias, pairs, n_out):
 
 def densify(features, coors, shape, batch_size):
     """SparseConvTensor.dense(): [B,C,D,H,W]."""
-    c = torch.as_tensor(np.asarray(coors), dtype=torch.long)
+    c = torch.as_tensor(np.asarray(coors), dtype=torch.long, device=features.device)
     out = features.new_zeros((batch_size, shape[0], shape[1], shape[2], features.shape[1]))
     out[c[:, 0], c[:, 1], c[:, 2], c[:, 3]] = features
     return out.permute(0, 4, 1, 2, 3).contiguous()

@@ -17,10 +17,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-fast-math", "-ffp-contract=off"]
 
 
-# per-file extra flags; the flags an object was built with are kept beside it (<name>.flags) and are part of the staleness test.
-# S2D_BUILD_LOSSES_NOSLP=1: losses.hip without the SLP vectoriser, i.e. without packed-FP32 code (DESIGN rule 36; +0.1 ms per step)
+# per-file extra flags; the flags an object was built with are kept beside it (<name>.flags, written only after hipcc succeeded) and are
+# part of the staleness test.
+# losses.hip is built WITHOUT the SLP vectoriser, i.e. without packed-FP32 code: `pcr_level_bwd_dense_kernel`'s compiler-generated
+# `v_pk_fma_f32` returned different high-lane sums while another queue's MFMA kernel shared the SIMDs (DESIGN rule 36), and the default
+# graphed mode does run weight-gradient MFMA kernels on a second queue.  Costs 0.1 ms per step.  S2D_BUILD_LOSSES_SLP=1 restores the
+# vectorised build for A/B runs.
 EXTRA = {}
-if os.environ.get("S2D_BUILD_LOSSES_NOSLP") == "1":
+if os.environ.get("S2D_BUILD_LOSSES_SLP") != "1":
     EXTRA["losses.hip"] = ["-fno-slp-vectorize"]
 
 
@@ -46,15 +50,22 @@ def build(force=False, verbose=True):
         stamp = o[:-2] + ".flags"
         built_with = open(stamp).read() if os.path.exists(stamp) else " ".join(FLAGS)   # (objects from before the stamps: the default flags)
         if force or _stale(o, [s] + hdrs) or built_with != " ".join(flags):
-            with open(stamp, "w") as f:
-                f.write(" ".join(flags))
+            for stale in (o, stamp):   # a failed or interrupted compile must not leave an object that looks current
+                if os.path.exists(stale):
+                    os.remove(stale)
             cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            procs.append((s, subprocess.Popen(cmd), stamp, " ".join(flags)))
+    failed = []
+    for s, p, stamp, flag_line in procs:
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {s}")
+            failed.append(s)
+            continue
+        with open(stamp, "w") as f:
+            f.write(flag_line)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     if force or procs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -51,6 +51,7 @@ def supported(cin, cout):
 import weakref
 
 _pack_cache = {}   # id(weight) -> [weakref(weight), data_ptr, version, {variant: packed}]
+CAPTURE_PACKS = None   # set by graphed.GraphedSegment._capture for the duration of a capture: {(id(weight), variant): image built inside it}
 
 
 def cached_pack(weight, variant, build):
@@ -64,9 +65,20 @@ def cached_pack(weight, variant, build):
         ent = [weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)), weight.data_ptr(), weight._version, {}]
         _pack_cache[key] = ent
     hit = ent[3].get(variant)
+    if hit is not None and CAPTURE_PACKS is not None and (key, variant) not in _repack:
+        # A capture is recording and this image has no registered in-place refresh: refresh_pack_cache() FREES it after the next optimizer
+        # step (the fused Adam writes through raw pointers, so the capture's staleness check cannot see that), while the graph would go on
+        # reading its address.  Only an image built inside this very capture (graph-pool memory, rebuilt by every replay) may be baked in:
+        # a forward-only capture taken with a warm cache - eval / teacher calls between optimizer steps - builds its own.  ADVICE r05.
+        own = CAPTURE_PACKS.get((key, variant))
+        if own is None:
+            own = CAPTURE_PACKS[(key, variant)] = build()
+        return own
     if hit is None:
         hit = build()
         ent[3][variant] = hit
+        if CAPTURE_PACKS is not None:
+            CAPTURE_PACKS[(key, variant)] = hit
     return hit
 
 
@@ -1275,7 +1287,8 @@ class WideLayerNorm(nn.LayerNorm):
         row = 1
         for d in self.normalized_shape:
             row *= int(d)
-        big = x.is_cuda and row >= (1 << 16) and x.numel() // row <= 64 and self.elementwise_affine
+        big = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and row >= (1 << 16) and x.numel() // row <= 64
+               and self.elementwise_affine)
         if big and ENABLED and x.dtype == torch.bfloat16 and nd == 3 and x.dim() == 4 and row % 8 == 0 and self.bias is not None and (
                 x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
             return _WideLNFn.apply(x, self.weight, self.bias, self.eps)

@@ -299,7 +299,7 @@ class KD_VoxelNet(VoxelNet):
         """everything behind the BEV map (S2D module + PCR head + RPN trunk + CenterHead + losses, voxelnet.py:216-265): shapes depend on
         the batch size only - the segment `use_hip_graphs()` replays as HIP graphs"""
         batch_size = x.shape[0]
-        if want_pcr and x.is_cuda and hasattr(self.neck, "pcr_targets"):
+        if want_pcr and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and hasattr(self.neck, "pcr_targets"):   # (the kernels' dtypes)
             # hand the recon voxels to the neck: its PCR levels return their losses directly (heads.pcr_level)
             self.neck.pcr_targets = {s: (example[f"reconstruction_coordinates_{s}"], self._read_scaled(example, s)) for s in (4, 2)}
         x, gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4, F_S_a, F_S_b = self._dense(self.neck, x, keep_first=True, keep=(5, 6))
@@ -333,7 +333,7 @@ class KD_VoxelNet(VoxelNet):
 
     def _dense_part_s2d(self, x, example, want_pcr):
         """first half of `_dense_part` as a segment of its own: S2D module + PCR head + PCR losses -> (F_S_a, F_S_b, mask_loss, comp_loss)"""
-        if want_pcr and x.is_cuda and hasattr(self.neck, "pcr_targets"):
+        if want_pcr and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and hasattr(self.neck, "pcr_targets"):   # (the kernels' dtypes)
             self.neck.pcr_targets = {s: (example[f"reconstruction_coordinates_{s}"], self._read_scaled(example, s)) for s in (4, 2)}
         go2, gm2, go4, gm4, F_S_a, F_S_b = self._dense(self.neck.forward_s2d, x, keep=(4, 5))
         mask_loss = comp_loss = 0

@@ -19,8 +19,9 @@ Protocol.
     `torch.autograd.grad(outputs that get gradients, differentiable inputs + parameters)` into a second graph, both in one memory pool;
   * afterwards a call = copy the inputs into the static buffers + replay; an autograd node (`_Replay`) hands the static outputs to
     the caller, and in the backward pass copies the incoming gradients, replays the backward graph, binds each parameter's static
-    gradient buffer as its `.grad` (accumulating when one is already there, running the parameter's post-accumulate hooks as
-    AccumulateGrad would) and returns the static input gradients.
+    gradient buffer as its `.grad` (accumulating out of place when one is already there - a `.grad` that is the static buffer itself is
+    copied out before the replay overwrites it -, running the parameter's post-accumulate hooks as AccumulateGrad would) and returns
+    the static input gradients.
   * a replay is refused - the capture dropped, the eager path taken and a new warm-up started - when a parameter's version counter,
     storage or `requires_grad` changed since the capture (load_state_dict, manual surgery: the packed images the graph reads would be
     stale), when the gradient pattern differs, or under the per-launch profiling pass of bench.py.
@@ -120,12 +121,26 @@ class _Replay(torch.autograd.Function):
                 # an output that received no gradient during the warm-up now has one: this capture cannot deliver it
                 raise RuntimeError(f"GraphedSegment '{seg.name}': output {i} received a gradient that the captured backward does not cover; "
                                    "call .reset() after changing which losses are used")
+        # Gradient accumulation (a second backward before the gradients were cleared, zero_grad(set_to_none=False)): a `.grad` that IS one of
+        # this capture's static buffers - bound by the previous backward - is about to be overwritten by the replay: its values move to a
+        # private copy first (enqueued ahead of both replays), and the sums below wait for the weight-gradient graph's stream.  ADVICE r05.
+        accumulate = False
+        for p, g in zip(cap.params, cap.s_gparams):
+            if g is not None and p.grad is not None:
+                accumulate = True
+                if p.grad.data_ptr() == g.data_ptr():
+                    p.grad = p.grad.clone()
         t0 = time.perf_counter()
         cap.bwd.replay()
         stats["launch_host_ms"] += (time.perf_counter() - t0) * 1e3
+        dev = cap.s_in[0].device.index
+        joined = cap.bwd2 is None
         if cap.bwd2 is not None:   # the weight gradients' graph: on the side stream, beside whatever the caller's backward does next
             from . import side
-            side.replay_on_side(cap.bwd2, cap.s_in[0].device.index)
+            side.replay_on_side(cap.bwd2, dev)
+            if accumulate:
+                side.join(dev)
+                joined = True
         for p, g in zip(cap.params, cap.s_gparams):
             if g is None:
                 continue
@@ -135,6 +150,11 @@ class _Replay(torch.autograd.Function):
                 p.grad = p.grad + g      # (never in place: p.grad may be another segment's static buffer)
             hooks = getattr(p, "_post_accumulate_grad_hooks", None)
             if hooks:
+                if not joined:   # only the data-parallel buckets' hooks order themselves behind the side stream (dp.GradBuckets._launch);
+                    from . import dp, side   # any other hook reads p.grad on this stream: it must see the finished gradient
+                    if len(hooks) != 1 or id(p) not in dp._BUCKETERS:
+                        side.join(dev)
+                        joined = True
                 for h in list(hooks.values()):
                     h(p)
         return (None, None, None) + tuple(cap.s_gin)
@@ -281,6 +301,7 @@ class GraphedSegment:
         cap.fwd = torch.cuda.CUDAGraph()
         CAPTURE_LOCK.acquire()
         dense2d.WS_PRIVATE = True      # reduction workspaces: plain allocations from the graph's pool while capturing
+        dense2d.CAPTURE_PACKS = {}     # packed-weight images without an in-place refresh: built inside this capture (dense2d.cached_pack)
         # No cyclic garbage collection while a stream is capturing: a collection that runs in the middle of the capture (it can start at any
         # allocation, on the autograd thread as well) may finalise an old CUDAGraph / event / tensor of an earlier segment or test, and
         # destroying those is a runtime call the capture turns into an abort (seen in the full test suite: "Garbage-collecting" inside a
@@ -297,6 +318,11 @@ class GraphedSegment:
                     outs = self.fn(*cap.s_in)
             outs = tuple(outs)
             cap.s_out = outs
+            # outputs whose gradient the backward graph covers: those that received one during the warm-up; when the warm-up calls never ran
+            # a backward (forward-only sanity / timing calls in train mode) every output that requires one - a superset whose unused
+            # entries replay with zero-filled gradients - instead of a capture that silently detaches its outputs
+            if grad_mode and not g_idx:
+                g_idx = [i for i, o in enumerate(outs) if torch.is_tensor(o) and o.requires_grad]
             cap.g_idx = [i for i in g_idx if torch.is_tensor(outs[i]) and outs[i].requires_grad] if grad_mode else []
             cap.s_gout, cap.s_gin, cap.s_gparams, cap.bwd, cap.bwd2, cap.keep = [], [], [], None, None, None
             if cap.g_idx:
@@ -338,5 +364,6 @@ class GraphedSegment:
             if gc_was_on:
                 gc.enable()
             dense2d.WS_PRIVATE = False
+            dense2d.CAPTURE_PACKS = None
             CAPTURE_LOCK.release()
         return cap

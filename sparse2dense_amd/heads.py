@@ -182,7 +182,8 @@ def masked_mse_pair(student, teacher, w_pos, w_neg):
             teacher = torch.empty_like(student, dtype=teacher.dtype).copy_(teacher.detach())
         if _dense_same_layout(student, teacher):
             return _MaskedMseFn.apply(student, teacher.detach(), w_pos, w_neg)
-    student, teacher = student.float(), teacher.float()   # bf16 feature maps: differences and sums in fp32
+    if student.dtype != torch.float64:   # bf16 feature maps: differences and sums in fp32 (a float64 run keeps its precision)
+        student, teacher = student.float(), teacher.float()
     pos = teacher > 0
     d2 = (student - teacher) ** 2
     n_pos = pos.sum()

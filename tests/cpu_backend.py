@@ -1,11 +1,21 @@
 """TEST INFRASTRUCTURE ONLY — an oracle-backed stand-in for `sparse2dense_amd.hip_ops`.
 
-`install(monkeypatch)` swaps every HIP launcher for a torch-CPU implementation built from
+`install(monkeypatch)` swaps every HIP launcher for a plain-torch implementation built from
 `oracle/` so that the HOST logic of the product (module wiring, autograd functions, rulebook
 caching/planning, SyncBN + DDP data-parallel path over gloo) can be exercised by `-m "not gpu"`
 tests in a container without a GPU.  Nothing under sparse2dense_amd/ imports this file; the
 product path itself has no CPU fallback.
+
+Device: every stand-in here is device-agnostic torch (rulebooks / voxelization: numpy on the host, results
+moved to the tensors' device).  The GPU parity tests run this "oracle stack" in float64 ON the MI355X
+(`oracle_stack(device="cuda:0")`): torch's own float64 kernels do the arithmetic - a 169 s host run becomes
+seconds - and for the whole time the stack runs `sparse2dense_amd._lib.load` RAISES, so no s2d kernel can take
+part in its own reference (a product dispatch that would reach one fails the test loudly).
+tests/test_oracle_device.py holds device run == host run.
 """
+import contextlib
+import sys
+
 import numpy as np
 import torch
 
@@ -38,31 +48,36 @@ def _pairs_to_maps(pairs, n_in, n_out, want_in):
     return nbr_out, nbr_in, cnt
 
 
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
 def voxelize(points, voxel_size, coors_range, max_points, max_voxels, with_mean=True):
-    v, c, n = OV.points_to_voxel(points.numpy(), voxel_size, coors_range, max_points, max_voxels)
-    mean = torch.from_numpy(OV.voxel_mean(v, n)) if with_mean else None
-    return torch.from_numpy(v), torch.from_numpy(c), torch.from_numpy(n), mean
+    dev = points.device
+    v, c, n = OV.points_to_voxel(_np(points), voxel_size, coors_range, max_points, max_voxels)
+    mean = torch.from_numpy(OV.voxel_mean(v, n)).to(dev) if with_mean else None
+    return torch.from_numpy(v).to(dev), torch.from_numpy(c).to(dev), torch.from_numpy(n).to(dev), mean
 
 
 def voxelize_async(points, voxel_size, coors_range, max_points, max_voxels, with_mean=True):
     v, c, n, m = voxelize(points, voxel_size, coors_range, max_points, max_voxels, with_mean)
-    return v, c, n, m, torch.tensor([c.shape[0]], dtype=torch.int32)
+    return v, c, n, m, torch.tensor([c.shape[0]], dtype=torch.int32, device=points.device)
 
 
 def build_subm_rulebook(coors, batch, shape, ksize, dilation=(1, 1, 1)):
-    c = coors.numpy()
+    c, dev = _np(coors), coors.device
     pairs = R.rulebook_subm(c, tuple(shape), ksize, dilation)
     nbr_out, _, cnt = _pairs_to_maps(pairs, c.shape[0], c.shape[0], False)
-    return H.Rulebook(True, len(pairs), c.shape[0], c.shape[0], torch.from_numpy(nbr_out), None, torch.from_numpy(cnt),
+    return H.Rulebook(True, len(pairs), c.shape[0], c.shape[0], torch.from_numpy(nbr_out).to(dev), None, torch.from_numpy(cnt).to(dev),
                       None, tuple(int(s) for s in shape))
 
 
 def build_conv_rulebook(coors, batch, shape, ksize, stride, padding, dilation=(1, 1, 1)):
-    c = coors.numpy()
+    c, dev = _np(coors), coors.device
     oc, oshape, pairs = R.rulebook_conv(c, tuple(shape), ksize, stride, padding, dilation)
     nbr_out, nbr_in, cnt = _pairs_to_maps(pairs, c.shape[0], oc.shape[0], True)
-    return H.Rulebook(False, len(pairs), c.shape[0], oc.shape[0], torch.from_numpy(nbr_out), torch.from_numpy(nbr_in),
-                      torch.from_numpy(cnt), torch.from_numpy(oc), oshape)
+    return H.Rulebook(False, len(pairs), c.shape[0], oc.shape[0], torch.from_numpy(nbr_out).to(dev), torch.from_numpy(nbr_in).to(dev),
+                      torch.from_numpy(cnt).to(dev), torch.from_numpy(oc).to(dev), oshape)
 
 
 def spconv_gather_gemm(feat, weight_kio, bias, nbr, n_out, pair_count=None, tag="fwd", transpose=False, flip=False):
@@ -123,13 +138,13 @@ def bn1d_finalize_bwd(sums_local, sums_global, count, gamma, mean, invstd):
 
 
 def bn1d_stats_finalize(x, gamma, beta, eps, momentum, running_mean=None, running_var=None, batches_tracked=None):
-    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype)
+    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype, device=x.device)
     return bn1d_finalize_fwd(bn1d_stats(x), count, gamma, beta, eps, momentum, running_mean, running_var, batches_tracked)
 
 
 def bn1d_bwd_reduce_finalize(dy, y, x, relu, gamma, mean, invstd):
     g, sums = bn1d_bwd_reduce(dy, y, x, relu)
-    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype)
+    count = torch.full((1,), float(x.shape[0]), dtype=x.dtype, device=x.device)
     return g, bn1d_finalize_bwd(sums, sums, count, gamma, mean, invstd)
 
 
@@ -150,11 +165,11 @@ def bn1d_bwd_apply(g, x, a, b, d):
 
 
 def densify(feat, coors, batch, shape):
-    return R.densify(feat, coors.numpy(), tuple(shape), batch)
+    return R.densify(feat, _np(coors), tuple(shape), batch)
 
 
 def densify_bwd(dout, coors, batch, shape, c):
-    i = coors.long()
+    i = coors.long().to(dout.device)
     return dout[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]].contiguous()
 
 
@@ -162,9 +177,21 @@ _NAMES = ["voxelize", "voxelize_async", "build_subm_rulebook", "build_conv_ruleb
           "bn1d_finalize_fwd", "bn1d_finalize_bwd", "bn1d_stats_finalize", "bn1d_bwd_reduce_finalize", "bn1d_apply", "bn1d_bwd_reduce", "bn1d_bwd_apply", "densify", "densify_bwd"]
 
 
-def install(monkeypatch=None):
-    """Patch sparse2dense_amd.hip_ops (and the CUDA-only guard of FeatureBatchNorm1d) in place."""
+class OracleReachedHip(AssertionError):
+    pass
+
+
+def _no_hip_library():
+    raise OracleReachedHip("the oracle stack reached a HIP launcher (sparse2dense_amd._lib.load): a product dispatch took the device path "
+                           "for a tensor of the float64 reference run - its predicate must name the dtypes the kernel supports")
+
+
+def install(monkeypatch=None, guard=False):
+    """Patch sparse2dense_amd.hip_ops (and the CUDA-only guard of FeatureBatchNorm1d) in place.  guard=True (the device runs of the
+    oracle stack): additionally make the library loader raise and report the rulebook chain as unsupported, so that every
+    route into an s2d kernel is closed while the reference is computed."""
     import sparse2dense_amd.spconv as sp
+    from sparse2dense_amd import _lib
     g = globals()
     for n in _NAMES:
         if monkeypatch is not None:
@@ -175,3 +202,33 @@ def install(monkeypatch=None):
         monkeypatch.setattr(sp.FeatureBatchNorm1d, "_REQUIRE_CUDA", False)
     else:
         sp.FeatureBatchNorm1d._REQUIRE_CUDA = False
+    if guard:
+        assert monkeypatch is not None, "the guarded installation must be undone: pass a MonkeyPatch"
+        monkeypatch.setattr(_lib, "load", _no_hip_library)
+        monkeypatch.setattr(H, "rulebook_chain_supported", lambda *a, **k: False)
+
+
+@contextlib.contextmanager
+def oracle_stack(device="cpu", storage_bf16=False):
+    """`with oracle_stack("cuda:0"):` - the product's host code computes with the oracle's launchers inside the block; on a GPU device
+    no s2d kernel can be reached (see the module docstring).  Everything is restored on exit."""
+    import pytest
+    mp = pytest.MonkeyPatch()
+    try:
+        install(mp, guard=torch.device(device).type == "cuda")
+        if storage_bf16:
+            mp.setattr(sys.modules[__name__], "STORAGE_BF16", [True])
+        yield mp
+    finally:
+        mp.undo()
+
+
+def to_device(obj, device, dtype=None):
+    """an example dict / list / tensor moved to `device`; floating tensors cast to `dtype` when given"""
+    if torch.is_tensor(obj):
+        return obj.to(device=device, dtype=dtype) if (dtype is not None and obj.is_floating_point()) else obj.to(device)
+    if isinstance(obj, dict):
+        return {k: to_device(v, device, dtype) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_device(v, device, dtype) for v in obj)
+    return obj

@@ -93,8 +93,8 @@ class _RoundBf16STE(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
-def bf16_emulation_copy(module):
-    """Float64 host copy of a 2-D neck / head whose leaf layers (convs, transposed convs, batch norms incl. their fused
+def bf16_emulation_copy(module, device="cpu"):
+    """Float64 copy (on `device`: torch's own float64 kernels) of a 2-D neck / head whose leaf layers (convs, transposed convs, batch norms incl. their fused
     ReLU, activations, layer norms) round their OUTPUT - and the gradient flowing back through it - to bf16, and whose
     conv weights are rounded to bf16: the storage roundings of the product's bf16 NHWC mode with exact accumulation in
     between.  3-D (PCR) layers stay unrounded: the product runs them in fp32."""
@@ -106,7 +106,7 @@ def bf16_emulation_copy(module):
             if isinstance(mod, (nn.Conv2d, nn.ConvTranspose2d)):
                 mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
     add_bf16_storage_hooks(m)
-    return m
+    return m.to(device)
 
 
 def add_bf16_storage_hooks(m):

@@ -2,6 +2,8 @@
 sparse convs -> fused BN -> densify [-> neck -> head -> loss]) against the CPU oracle stack with
 the same name-seeded weights.  fp32 tolerance end-to-end through 21 sparse convs + 21 batch-stat
 BNs: rtol 2e-3 / atol 2e-4 on features, rtol 1e-3 on scalar losses."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +17,9 @@ from sparse2dense_amd import backbones, scene, waymo_configs
 from sparse2dense_amd.registry import build_backbone, build_detector
 
 DEV = "cuda:0"
+# the float64 / fp32 oracle modules (oracle/spconv_ref.py: torch index_select / mm / index_add, numpy rulebooks) run on ODEV: the device by
+# default (seconds instead of minutes; tests/test_oracle_device.py holds device == host), "cpu" with S2D_ORACLE_DEVICE=cpu
+ODEV = os.environ.get("S2D_ORACLE_DEVICE", DEV)
 
 
 def _scene_voxels(n_points, seed, batch=1):
@@ -34,6 +39,7 @@ def _rel_errors(grads, exact):
         if a is None or b is None:
             assert a is None and b is None, name
             continue
+        b = b.cpu()
         out[name] = ((a.double().cpu() - b).norm() / (b.norm() + 1e-30)).item()
     return out
 
@@ -69,30 +75,30 @@ def _compare_grads(net, ref64, tol, ref32=None, slack=3.0):
 def test_backbone_forward_backward_vs_oracle(kind, ref_cls, channels):
     feats, coors = _scene_voxels(8000, seed=7, batch=2)   # BASELINE config 1 scene ("second8k"), B=2
     net = fill_params(build_backbone(dict(type=kind, num_input_features=5, ds_factor=8))).train()
-    ref = fill_params(ref_cls(5)).double().train()   # float64 oracle = exact arithmetic for our purposes
-    ref32 = fill_params(ref_cls(5)).train()           # fp32 oracle: calibrates the conditioning of the backward
+    ref = fill_params(ref_cls(5)).double().train().to(ODEV)   # float64 oracle = exact arithmetic for our purposes
+    ref32 = fill_params(ref_cls(5)).train().to(ODEV)           # fp32 oracle: calibrates the conditioning of the backward
     assert sorted(net.state_dict()) == sorted(ref.state_dict())
     grid = np.array([1504, 1504, 40])
-    bev_ref, ms_ref = ref(torch.from_numpy(feats).double(), coors, 2, grid)
-    bev32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
+    bev_ref, ms_ref = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)
+    bev32, _ = ref32(torch.from_numpy(feats).to(ODEV), coors, 2, grid)
     net = net.to(DEV)
     bev, ms = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
     assert bev.shape == (2, channels, 188, 188) == bev_ref.shape
-    torch.testing.assert_close(bev.cpu().double(), bev_ref, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(bev.cpu().double(), bev_ref.detach().cpu(), rtol=1e-3, atol=1e-4)
     if kind == "SpMiddleResNetFHD":
         for k in ["conv1", "conv2", "conv3", "conv4"]:
             assert np.array_equal(ms[k].indices.cpu().numpy(), ms_ref[k].indices), k
-            torch.testing.assert_close(ms[k].features.cpu().double(), ms_ref[k].features, rtol=1e-3, atol=1e-4)
+            torch.testing.assert_close(ms[k].features.cpu().double(), ms_ref[k].features.detach().cpu(), rtol=1e-3, atol=1e-4)
     # running statistics updated identically (momentum 0.01, unbiased variance)
     sd, sr = net.state_dict(), ref.state_dict()
     for k in sd:
         if "running" in k:
-            torch.testing.assert_close(sd[k].cpu().double(), sr[k], rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(sd[k].cpu().double(), sr[k].cpu(), rtol=1e-4, atol=1e-6)
         if k.endswith("num_batches_tracked"):
             assert int(sd[k]) == int(sr[k]) == 1
     g = torch.randn(bev_ref.shape, generator=torch.Generator().manual_seed(5))
-    (bev_ref * g.double()).sum().backward()
-    (bev32 * g).sum().backward()
+    (bev_ref * g.double().to(ODEV)).sum().backward()
+    (bev32 * g.to(ODEV)).sum().backward()
     (bev * g.to(DEV)).sum().backward()
     _compare_grads(net, ref, tol=5e-3, ref32=ref32)
 
@@ -101,13 +107,13 @@ def test_backbone_eval_mode_forward_backward_matches_oracle():
     """Running-stat BN (the teacher's mode) is well conditioned: tight tolerance on every gradient."""
     feats, coors = _scene_voxels(8000, seed=11)
     net = fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).eval().to(DEV)
-    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().eval()
+    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().eval().to(ODEV)
     grid = np.array([1504, 1504, 40])
     a, _ = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 1, grid)
-    b, _ = ref(torch.from_numpy(feats).double(), coors, 1, grid)
-    torch.testing.assert_close(a.cpu().double(), b, rtol=1e-3, atol=1e-4)
+    b, _ = ref(torch.from_numpy(feats).double().to(ODEV), coors, 1, grid)
+    torch.testing.assert_close(a.cpu().double(), b.detach().cpu(), rtol=1e-3, atol=1e-4)
     g = torch.randn(b.shape, generator=torch.Generator().manual_seed(6))
-    (b * g.double()).sum().backward()
+    (b * g.double().to(ODEV)).sum().backward()
     (a * g.to(DEV)).sum().backward()
     _compare_grads(net, ref, tol=5e-4)
 
@@ -122,20 +128,22 @@ def test_detector_loss_vs_oracle_stack():
     model = fill_params(build_detector(waymo_configs.centerpoint_voxelnet())).train()
     ref_bb = R.RefSpMiddleResNetFHD(5)
     ref_bb.load_state_dict(model.backbone.state_dict())
-    ref_bb.double().train()
+    ref_bb.double().train().to(ODEV)
     import copy
-    cpu_neck, cpu_head = copy.deepcopy(model.neck).double().train(), copy.deepcopy(model.bbox_head).double().train()
+    import cpu_backend
+    cpu_neck, cpu_head = copy.deepcopy(model.neck).double().train().to(ODEV), copy.deepcopy(model.bbox_head).double().train().to(ODEV)
     # oracle side: CPU voxelizer + oracle backbone + torch-CPU neck/head
     pts = frames.points[0].cpu().numpy()
     v, c, n = OV.points_to_voxel(pts, scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
     assert np.array_equal(ex["coordinates"][:, 1:].cpu().numpy(), c)
     coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
-    bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double(), coors, 1, np.array([1504, 1504, 40]))
-    preds = cpu_head(cpu_neck(bev))
-    ex_cpu = {k: [t.cpu().double() if t.is_floating_point() else t.cpu() for t in ex[k]]
-              for k in ["hm", "anno_box", "ind", "mask", "cat"]}
-    loss_ref = sum(cpu_head.loss(ex_cpu, preds)["loss"])
-    loss_ref.backward()
+    with cpu_backend.oracle_stack(ODEV):   # (the neck / head are the product's torch modules: no s2d kernel may serve the float64 run)
+        bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double().to(ODEV), coors, 1, np.array([1504, 1504, 40]))
+        preds = cpu_head(cpu_neck(bev))
+        ex_cpu = {k: [t.to(ODEV).double() if t.is_floating_point() else t.to(ODEV) for t in ex[k]]
+                  for k in ["hm", "anno_box", "ind", "mask", "cat"]}
+        loss_ref = sum(cpu_head.loss(ex_cpu, preds)["loss"])
+        loss_ref.backward()
     model = model.to(DEV)
     losses = model(ex, return_loss=True)
     loss = sum(losses["loss"])
@@ -152,9 +160,10 @@ def test_bf16_mode_within_stated_tolerance():
     from sparse2dense_amd.data import SyntheticFrames
     feats, coors = _scene_voxels(8000, seed=7, batch=2)
     net = fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).train().to(DEV)
-    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().train()
+    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().train().to(ODEV)
     grid = np.array([1504, 1504, 40])
-    b, _ = ref(torch.from_numpy(feats).double(), coors, 2, grid)
+    with torch.no_grad():
+        b = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)[0].cpu()
     H.set_sparse_compute_dtype("bf16")
     try:
         a, _ = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
@@ -184,9 +193,10 @@ def test_s16_storage_mode_within_stated_tolerance():
     from sparse2dense_amd.data import SyntheticFrames
     feats, coors = _scene_voxels(8000, seed=7, batch=2)
     net = fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5))).train().to(DEV)
-    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().train()
+    ref = fill_params(R.RefSpMiddleResNetFHD(5)).double().train().to(ODEV)
     grid = np.array([1504, 1504, 40])
-    b, _ = ref(torch.from_numpy(feats).double(), coors, 2, grid)
+    with torch.no_grad():
+        b = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)[0].cpu()
     H.set_sparse_compute_dtype("s16")
     try:
         a, aux = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
@@ -238,15 +248,16 @@ def test_s16_backbone_gradients_vs_bf16_storage_oracle(train):
     grid = np.array([1504, 1504, 40])
     mk = lambda m: (m.train() if train else m.eval())
     net = mk(_round_conv_weights_to_bf16(fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5)))))
-    ref = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5))).double())
-    ref32 = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5)))) if train else None
+    ref = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5))).double()).to(ODEV)
+    ref32 = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5)))).to(ODEV) if train else None
     g = torch.randn((2, 256, 188, 188), generator=torch.Generator().manual_seed(5))
     with R.bf16_storage():
-        b, ms_ref = ref(torch.from_numpy(feats).double(), coors, 2, grid)
-        (b * g.double()).sum().backward()
+        b, ms_ref = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)
+        (b * g.double().to(ODEV)).sum().backward()
         if train:
-            b32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
-            (b32 * g).sum().backward()
+            b32, _ = ref32(torch.from_numpy(feats).to(ODEV), coors, 2, grid)
+            (b32 * g.to(ODEV)).sum().backward()
+    b = b.detach().cpu()
     net = net.to(DEV)
     H.set_sparse_compute_dtype("s16")
     try:
@@ -256,11 +267,12 @@ def test_s16_backbone_gradients_vs_bf16_storage_oracle(train):
         H.set_sparse_compute_dtype("f32")
     assert ms["conv4"].features.dtype == torch.bfloat16
     err = ((a.cpu().double() - b).norm() / b.norm()).item()
-    e32 = ((b32.double() - b).norm() / b.norm()).item() if train else 0.0
+    e32 = ((b32.detach().double().cpu() - b).norm() / b.norm()).item() if train else 0.0
     print(f"s16 vs bf16-storage oracle (train={train}): forward {err:.2e} (fp32 oracle {e32:.2e})")
     assert err <= max(5e-3, 3 * e32), err
     for k in ["conv1", "conv2", "conv3", "conv4"]:
-        fe = ((ms[k].features.double().cpu() - ms_ref[k].features).norm() / ms_ref[k].features.norm()).item()
+        fr = ms_ref[k].features.detach().cpu()
+        fe = ((ms[k].features.double().cpu() - fr).norm() / fr.norm()).item()
         assert fe <= max(5e-3, 3 * e32), (k, fe)
     errs = _rel_errors(_grad_dict(net), _grad_dict(ref))
     print("  gradient errors:", {k: f"{v:.1e}" for k, v in sorted(errs.items()) if k.endswith("weight") and "conv" in k})
@@ -277,14 +289,16 @@ def test_second_config1_forward_vs_cpu_reference_path():
     model = fill_params(build_detector(waymo_configs.second_voxelnet())).eval()
     ref_bb = R.RefSpMiddleFHD(5)
     ref_bb.load_state_dict(model.backbone.state_dict())
-    ref_bb.double().eval()
-    neck, head = copy.deepcopy(model.neck).double().eval(), copy.deepcopy(model.bbox_head).double().eval()
+    ref_bb.double().eval().to(ODEV)
+    import cpu_backend
+    neck, head = copy.deepcopy(model.neck).double().eval().to(ODEV), copy.deepcopy(model.bbox_head).double().eval().to(ODEV)
     pts = frames.points[0].cpu().numpy()
     v, c, n = OV.points_to_voxel(pts, scene.WAYMO_VOXEL, scene.WAYMO_RANGE, 5, 150000)
     coors = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
     with torch.no_grad():
-        bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double(), coors, 1, np.array([1504, 1504, 40]))
-        ref = head(neck(bev))[0]
+        with cpu_backend.oracle_stack(ODEV):
+            bev, _ = ref_bb(torch.from_numpy(OV.voxel_mean(v, n)).double().to(ODEV), coors, 1, np.array([1504, 1504, 40]))
+            ref = {k: t.cpu() for k, t in head(neck(bev))[0].items()}
         out = model.to(DEV)(ex, return_loss=False, raw_preds=True)[0]
     assert out["box_preds"].shape == (1, 188, 188, 42) and out["cls_preds"].shape == (1, 188, 188, 18)
     assert out["dir_cls_preds"].shape == (1, 188, 188, 12)

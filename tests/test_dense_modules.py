@@ -29,6 +29,8 @@ def _chk(dev):
 
 import contextlib
 
+ODEV = os.environ.get("S2D_ORACLE_DEVICE", "cuda:0")   # where the float64 emulation runs of the GPU tests execute (guarded: tests/cpu_backend.py)
+
 
 def _bf16_mode(net):
     """what SingleStageDetector.use_channels_last() + its bf16 autocast do for a bare neck / head: NHWC weights and
@@ -210,14 +212,16 @@ def test_s2d_rpn_bf16_hip_kernels_match_reference_golden(golden_dir):
 def test_bf16_hip_necks_match_float64_run_with_the_same_roundings(kind):
     from golden_util import bf16_emulation_copy, rel_err
     net = fill_params(build_from_cfg(dict(type=kind, **CFG), NECKS)).train()
-    emu = bf16_emulation_copy(net)
+    import cpu_backend
+    emu = bf16_emulation_copy(net, ODEV)
     x = seeded((1, 256, 188, 188), 100).abs_().to(torch.bfloat16).float()
-    xe = x.double().requires_grad_(True)
-    oe = emu(xe)
-    oe = [oe] if torch.is_tensor(oe) else [o for o in oe]
+    xe = x.double().to(ODEV).requires_grad_(True)
     names = ["blocks.0.1.weight", "blocks.1.16.weight", "deblocks.1.0.weight"] + (["encoder_1.3.weight", "decoder_2.0.weight"] if kind == "S2D_RPN" else [])
-    pe = dict(emu.named_parameters())
-    ge = _grads(oe, [xe] + [pe[n] for n in names], 200)
+    with cpu_backend.oracle_stack(ODEV):
+        oe = emu(xe)
+        oe = [oe] if torch.is_tensor(oe) else [o for o in oe]
+        pe = dict(emu.named_parameters())
+        ge = _grads(oe, [xe] + [pe[n] for n in names], 200)
     net = net.to("cuda:0")
     xg = x.to("cuda:0").requires_grad_(True)
     with _bf16_mode(net):
@@ -253,14 +257,16 @@ def test_bf16_hip_necks_well_conditioned_within_the_stated_tolerance(kind):
     random-weight variant above stays as the record of how far batch-statistics normalisation amplifies the same roundings.)"""
     from golden_util import bf16_emulation_copy, rel_err
     net = _bn_eval(fill_params(build_from_cfg(dict(type=kind, **CFG), NECKS)).train())
-    emu = _bn_eval(bf16_emulation_copy(net).train())
+    import cpu_backend
+    emu = _bn_eval(bf16_emulation_copy(net, ODEV).train())
     x = seeded((1, 256, 188, 188), 100).abs_().to(torch.bfloat16).float()
-    xe = x.double().requires_grad_(True)
-    oe = emu(xe)
-    oe = [oe] if torch.is_tensor(oe) else [o for o in oe if o is not None]
-    pe = dict(emu.named_parameters())
-    names = sorted(pe)
-    ge = _grads(oe, [xe] + [pe[n] for n in names], 200, coherent=True)
+    xe = x.double().to(ODEV).requires_grad_(True)
+    with cpu_backend.oracle_stack(ODEV):
+        oe = emu(xe)
+        oe = [oe] if torch.is_tensor(oe) else [o for o in oe if o is not None]
+        pe = dict(emu.named_parameters())
+        names = sorted(pe)
+        ge = _grads(oe, [xe] + [pe[n] for n in names], 200, coherent=True)
     net = net.to("cuda:0")
     xg = x.to("cuda:0").requires_grad_(True)
     with _bf16_mode(net):

@@ -8,6 +8,7 @@ fp32 parity mode: features / loss terms within 2e-3 (the same bar as the single-
 algorithms differ from the CPU's direct sums by ~1e-3 per layer).  The benchmarked mode (bf16 sparse storage + bf16 NHWC
 dense kernels) is then held to the stated bf16 tolerance against the same oracle numbers: 5e-2 on every loss term."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -50,27 +51,50 @@ def setup():
     return ex, teacher, student
 
 
-@pytest.fixture(scope="module")
-def oracle_run(setup):
-    """the oracle stack, float64, on the host"""
+def _bn_eval(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.eval()
+    return m
+
+
+ORACLE_DEV = os.environ.get("S2D_ORACLE_DEVICE", DEV)   # "cpu": the host run of r01-r05 (minutes); default: float64 on the device, guarded
+
+
+def _oracle_step(setup, bn_eval=False, storage_bf16=False):
+    """one teacher + student distillation step of the float64 ORACLE STACK (tests/cpu_backend.py) on ORACLE_DEV"""
     import cpu_backend
+    from golden_util import add_bf16_storage_hooks
     ex, teacher, student = setup
-    mp = pytest.MonkeyPatch()
-    try:
-        cpu_backend.install(mp)
+    with cpu_backend.oracle_stack(ORACLE_DEV, storage_bf16=storage_bf16):
         t64, s64 = copy.deepcopy(teacher).double(), copy.deepcopy(student).double().train()
-        ex64 = _to(ex, "cpu", torch.float64)
+        if bn_eval:
+            _bn_eval(s64)
+        if storage_bf16:
+            with torch.no_grad():
+                for m in (t64, s64):
+                    for mod in list(m.neck.modules()) + list(m.bbox_head.modules()):
+                        if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                            mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
+            for m in (t64, s64):
+                add_bf16_storage_hooks(m.neck)
+                add_bf16_storage_hooks(m.bbox_head)
+        t64, s64 = t64.to(ORACLE_DEV), s64.to(ORACLE_DEV)
+        ex64 = cpu_backend.to_device(ex, ORACLE_DEV, torch.float64)
         feats = {}
-        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
+        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach().cpu(), F_S_b=o[6].detach().cpu()))
         total, losses = distill_loss(t64, s64, ex64)
         total.backward()
         hook.remove()
-        res = dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS},
-                   F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
-                   grads={n: p.grad.clone() for n, p in s64.named_parameters() if p.grad is not None})
-    finally:
-        mp.undo()
-    return res
+        assert total.dtype == torch.float64
+        return dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS}, F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
+                    grads={n: p.grad.detach().cpu() for n, p in s64.named_parameters() if p.grad is not None})
+
+
+@pytest.fixture(scope="module")
+def oracle_run(setup):
+    """the oracle stack, float64"""
+    return _oracle_step(setup)
 
 
 def _rel(a, b):
@@ -122,33 +146,10 @@ def test_distill_step_benchmarked_bf16_mode_within_stated_tolerance(setup, oracl
     # gradients of the benchmarked mode is held by the well-conditioned variant below
 
 
-def _bn_eval(m):
-    for mod in m.modules():
-        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
-            mod.eval()
-    return m
-
-
 @pytest.fixture(scope="module")
 def oracle_run_bn_eval(setup):
     """the float64 oracle stack with every batch norm on its running statistics (fill_params: var in [0.5, 1.5])"""
-    import cpu_backend
-    ex, teacher, student = setup
-    mp = pytest.MonkeyPatch()
-    try:
-        cpu_backend.install(mp)
-        t64, s64 = copy.deepcopy(teacher).double(), _bn_eval(copy.deepcopy(student).double().train())
-        ex64 = _to(ex, "cpu", torch.float64)
-        feats = {}
-        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
-        total, losses = distill_loss(t64, s64, ex64)
-        total.backward()
-        hook.remove()
-        res = dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS}, F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
-                   grads={n: p.grad.clone() for n, p in s64.named_parameters() if p.grad is not None})
-    finally:
-        mp.undo()
-    return res
+    return _oracle_step(setup, bn_eval=True)
 
 
 @pytest.fixture(scope="module")
@@ -157,33 +158,7 @@ def oracle_run_bn_eval_bf16_storage(setup):
     sparse rows (cpu_backend.STORAGE_BF16: conv outputs forward and backward, fused BN outputs and their gradients, bf16 weight
     images), 2-D neck / head layer outputs and their gradients + bf16 conv weights (golden_util.add_bf16_storage_hooks); accumulation,
     statistics, losses and the 3-D PCR head exact.  Its distance to the exact run is what bf16 storage costs ANY arithmetic."""
-    import cpu_backend
-    from golden_util import add_bf16_storage_hooks
-    ex, teacher, student = setup
-    mp = pytest.MonkeyPatch()
-    try:
-        cpu_backend.install(mp)
-        mp.setattr(cpu_backend, "STORAGE_BF16", [True])
-        t64, s64 = copy.deepcopy(teacher).double(), _bn_eval(copy.deepcopy(student).double().train())
-        with torch.no_grad():
-            for m in (t64, s64):
-                for mod in list(m.neck.modules()) + list(m.bbox_head.modules()):
-                    if isinstance(mod, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
-                        mod.weight.copy_(mod.weight.to(torch.bfloat16).double())
-        for m in (t64, s64):
-            add_bf16_storage_hooks(m.neck)
-            add_bf16_storage_hooks(m.bbox_head)
-        ex64 = _to(ex, "cpu", torch.float64)
-        feats = {}
-        hook = s64.neck.register_forward_hook(lambda m, i, o: feats.update(F_S_a=o[5].detach(), F_S_b=o[6].detach()))
-        total, losses = distill_loss(t64, s64, ex64)
-        total.backward()
-        hook.remove()
-        res = dict(total=total.item(), terms={k: float(losses[k][0]) for k in TERMS}, F_S_a=feats["F_S_a"], F_S_b=feats["F_S_b"],
-                   grads={n: p.grad.clone() for n, p in s64.named_parameters() if p.grad is not None})
-    finally:
-        mp.undo()
-    return res
+    return _oracle_step(setup, bn_eval=True, storage_bf16=True)
 
 
 def test_distill_step_bf16_mode_against_the_bf16_storage_oracle(setup, oracle_run_bn_eval, oracle_run_bn_eval_bf16_storage):

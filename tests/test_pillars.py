@@ -124,11 +124,25 @@ def _bn_eval(net):
     return net
 
 
-def _detectors_step(dev, bf16=False, bn_eval=False):
+ODEV = os.environ.get("S2D_ORACLE_DEVICE", "cuda:0")   # where the oracle path of the GPU tests runs (float64, guarded: tests/cpu_backend.py)
+_ORACLE_RUNS = {}
+
+
+def _oracle_detectors_step(bn_eval=False):
+    """the same host code through the oracle's launchers (tests/cpu_backend.py), in float64 on ODEV - computed once per variant"""
+    if bn_eval not in _ORACLE_RUNS:
+        with cpu_backend.oracle_stack(ODEV):
+            _ORACLE_RUNS[bn_eval] = _detectors_step(ODEV, bn_eval=bn_eval, oracle=True)
+    return _ORACLE_RUNS[bn_eval]
+
+
+def _detectors_step(dev, bf16=False, bn_eval=False, oracle=False):
     torch.manual_seed(0)
-    ex = _pp_example(dev)
+    prep = (lambda m: m.double().to(dev)) if oracle else (lambda m: m.to(dev))
+    # (oracle run: the example is voxelized by the C oracle on the host and handed over in float64)
+    ex = cpu_backend.to_device(_pp_example("cpu"), dev, torch.float64) if oracle else _pp_example(dev)
     assert list(ex["shape"][0]) == [468, 468, 1]
-    teacher = build_detector(_pp_cfg("PointPillars")).to(dev).train()
+    teacher = prep(build_detector(_pp_cfg("PointPillars"))).train()
     if bf16:   # the benchmarked mode: NHWC bf16 neck / head / pillar S2D module under autocast (bench.py build_models)
         teacher.dense_dtype = torch.bfloat16
         teacher.use_channels_last()
@@ -140,7 +154,7 @@ def _detectors_step(dev, bf16=False, bn_eval=False):
     with torch.no_grad():
         preds, F_D_a, F_D_b = teacher(ex, return_loss=False)
     assert F_D_a.shape == (1, 64, 468, 468) == F_D_b.shape and preds[0]["hm"].shape == (1, 3, 468, 468)
-    student = build_detector(_pp_cfg("KD_PointPillars")).to(dev).train()
+    student = prep(build_detector(_pp_cfg("KD_PointPillars"))).train()
     if bf16:
         student.dense_dtype = torch.bfloat16
         student.use_channels_last()
@@ -168,12 +182,7 @@ def test_pointpillars_detectors_gpu_match_the_cpu_oracle_path():
     parameter gradient against the same host code run through the CPU oracle (tests/cpu_backend.py) - same seeds, same weights
     (torch.manual_seed(0) before construction).  Bars: losses 2e-3, features 5e-3 norm-wise (MIOpen fp32 convs vs the CPU's direct
     sums, the bar of the voxel detectors), gradients 5e-2 norm-wise (train-mode batch norms)."""
-    mp = pytest.MonkeyPatch()
-    try:
-        cpu_backend.install(mp)
-        ref = _detectors_step("cpu")
-    finally:
-        mp.undo()
+    ref = _oracle_detectors_step()
     got = _detectors_step("cuda:0")
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
     np.testing.assert_allclose(got["teacher_loss"], ref["teacher_loss"], rtol=2e-3)
@@ -210,13 +219,7 @@ def test_pointpillars_detectors_gpu_bf16_mode_vs_the_cpu_oracle_path():
     layers every rounding flip is re-amplified and the median gradient cosine of this very step drops to 0.76): every student
     parameter gradient by cosine and norm-wise."""
     def both(**kw):
-        mp = pytest.MonkeyPatch()
-        try:
-            cpu_backend.install(mp)
-            ref = _detectors_step("cpu", bn_eval=kw.get("bn_eval", False))
-        finally:
-            mp.undo()
-        return ref, _detectors_step("cuda:0", bf16=True, **kw)
+        return _oracle_detectors_step(bn_eval=kw.get("bn_eval", False)), _detectors_step("cuda:0", bf16=True, **kw)
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
     ref, got = both()
     feats = {k: rel(got[k], ref[k]) for k in ("teacher_hm", "F_D_a", "F_S_a", "F_S_b")}

@@ -12,7 +12,7 @@ become timing-dependent while the 16 -> 3 up-sampler's MFMA weight-gradient kern
   S2D_DEBUG_CT_WGRAD=...     stand-ins for that call: zeros | read | long | lds | ldsfill[:v] (none perturbs) | privws | clone | clone_main (the real kernel on private
                              copies of everything: still perturbs)
   S2D_DEBUG_SUMS2=1          the statistics kernel launched twice back to back: differing sums (odd channels only) are printed per step
-  S2D_BUILD_LOSSES_NOSLP=1   (at build time) losses.hip without the SLP vectoriser: no v_pk_*, 0 mismatches, single-stream results bit-identical to the packed build (STRESS_DUMP=file)
+  (default build since r06; S2D_BUILD_LOSSES_SLP=1 restores the packed build) losses.hip without the SLP vectoriser: no v_pk_*, 0 mismatches, single-stream results bit-identical to the packed build (STRESS_DUMP=file)
   S2D_SIDE_DEBUG_SYNC=1, PYTORCH_NO_CUDA_MEMORY_CACHING=1, S2D_STRESS_HOOKS=1 [S2D_STRESS_HOLD=tags | S2D_STRESS_PTRS=1], STRESS_WS_POISON=v: the dead ends (serialisation
   effects, workspace poison, held references / address log)
 """
