@@ -53,9 +53,6 @@ int s2d_last_error(char *buf, size_t buf_len);
 /* copies "compiler; HIP runtime headers; target; build date" of this library into buf; returns the text's length (no reference
  * counterpart: the reference's kernels come prebuilt with spconv / torch, docs/INSTALL.md:12,65-72) */
 int s2d_build_info(char *buf, size_t buf_len);
-/* debugging aid (no reference counterpart): `blocks` workgroups fill 64 KB of LDS each with `value`, `spin` + 1 times; sink may be NULL.
- * tools/side_stress.py uses it to look for kernels that read LDS they did not write. */
-int s2d_debug_lds_fill(float value, int blocks, int spin, float *sink, s2d_stream_t stream);
 
 /* ---- voxelization (hard voxelizer + fused reader mean) ------------------------------------ */
 /*
@@ -403,9 +400,6 @@ int s2d_bnrow_bwd_apply_ld_bf16(const void *dy, int dy_ld, const void *x, const 
  * zero_page: >= 16 zero bytes of device memory (what a missing neighbour reads in the LDS-staged kernel).
  */
 int s2d_spconv_s16_supported(int cin, int cout);
-/* tuning aid (tools/spconv_kernel_bench.py --trace): device buffer int64[grid][64] that the ablation build of the register-gather
- * kernel (csrc/spconv_rg.hip) fills with per-step s_memtime stamps when S2D_RG_DEBUG has bit 32 set; NULL switches it off */
-void s2d_debug_rg_trace(void *buf);
 size_t s2d_spconv_s16_packed_elems(int kvol, int cin, int cout);
 int s2d_spconv_s16_pack_weights(const float *weight, int kvol, int cin, int cout, int transpose,
                                 int flip, int64_t n_out, void *packed, s2d_stream_t stream);
@@ -429,6 +423,35 @@ int64_t s2d_spconv_s16_stats_tiles(int64_t n_out, int kvol, int cin, int cout);
 int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr,
                              int64_t n_out, int kvol, int cin, int cout, const void *zero_page, void *out_feat, float *stats_partial,
                              s2d_stream_t stream);
+
+/*
+ * r06 - rows of a submanifold rulebook grouped by neighbour mask, and the implicit GEMM over the grouped rows.
+ * (spconv.ops.get_indice_pairs / indice_conv; call sites /root/reference/det3d/models/backbones/scn.py:104-152)
+ * s2d_rulebook_sort_by_mask: from the dense gather map nbr [kvol][n] of a rulebook (kvol <= 27) builds
+ *   pmask [n] u32   neighbour mask (bit k = offset k present) of the rows in ascending mask order per chunk (stable radix sort: deterministic),
+ *   perm  [n] i32   canonical row index of each sorted position,
+ *   nbr_perm [kvol][n] i32 = nbr[k][perm[j]].
+ * s2d_spconv_s16_fwd_sorted: the bf16-storage sparse conv (same packed weight image as s2d_spconv_s16_fwd for the layer) over the sorted
+ * rows: every workgroup multiplies only the kernel offsets present in the union of its rows' masks, every wave only those present in its
+ * 16-row tile; results are stored to the canonical rows perm[j], so out_feat (and stats_partial: the same
+ * [s2d_spconv_s16_stats_tiles][2][cout] layout) are what s2d_spconv_s16_fwd_stats returns, up to the summation order of the statistics.
+ * Supported: kvol 27, 64 -> 64 and 128 -> 128 channels (s2d_spconv_s16_sorted_supported).
+ * OPT-IN: measured on the benchmark scene's rulebooks (profiles/r06_sparse_sorted_rows_ab.txt) the sorted form is 5-10 % SLOWER than the
+ * plain kernel although it issues 37 % fewer MFMAs - the kernel is bound by the gathered rows, which skipping does not reduce.
+ * s2d_spconv_s16_set_sorted_rows(1) (or S2D_RG_SORTED=1 in the environment) switches it on and returns the previous setting; it also
+ * moves 64 -> 64 layers to the register-gather weight image, so packed images made before the switch must be rebuilt.
+ */
+int s2d_spconv_s16_set_sorted_rows(int on);
+size_t s2d_rulebook_sort_workspace_bytes(int64_t n);
+/* the sort stays inside chunks of this many canonical rows (the rows one XCD's workgroups of the consuming kernel process): ascending masks
+ * within a chunk, chunks in canonical order */
+int64_t s2d_rulebook_sort_chunk_rows(int64_t n);
+int s2d_rulebook_sort_by_mask(const int32_t *nbr, int kvol, int64_t n, int32_t *perm, uint32_t *pmask, int32_t *nbr_perm, void *ws,
+                              size_t ws_bytes, s2d_stream_t stream);
+int s2d_spconv_s16_sorted_supported(int kvol, int cin, int cout);
+int s2d_spconv_s16_fwd_sorted(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr_perm,
+                              const int32_t *perm, const uint32_t *pmask, int64_t n_out, int kvol, int cin, int cout, void *out_feat,
+                              float *stats_partial, s2d_stream_t stream);
 
 /*
  * Weight gradient of the dense 3x3 stride-1 convolution above (replaces the cuDNN backward-filter call):

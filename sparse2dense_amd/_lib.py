@@ -293,6 +293,14 @@ SIGNATURES = {
     "s2d_spconv_s16_fwd_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, ctypes.c_int64,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, c_f32p,
                                                 ctypes.c_void_p]),
+    "s2d_rulebook_sort_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "s2d_rulebook_sort_chunk_rows": (ctypes.c_int64, [ctypes.c_int64]),
+    "s2d_rulebook_sort_by_mask": (ctypes.c_int, [c_i32p, ctypes.c_int, ctypes.c_int64, c_i32p, ctypes.c_void_p, c_i32p, ctypes.c_void_p, ctypes.c_size_t,
+                                                 ctypes.c_void_p]),
+    "s2d_spconv_s16_set_sorted_rows": (ctypes.c_int, [ctypes.c_int]),
+    "s2d_spconv_s16_sorted_supported": (ctypes.c_int, [ctypes.c_int] * 3),
+    "s2d_spconv_s16_fwd_sorted": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, c_f32p, c_i32p, c_i32p, ctypes.c_void_p, ctypes.c_int64,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_conv2d3x3_wgrad_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "s2d_conv2d3x3_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "s2d_conv2d3x3_wgrad_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 +

@@ -111,11 +111,17 @@ __global__ __launch_bounds__(256) void rg_pack_pair_kernel(const float *__restri
 
 // The work of one wave with MI valid tile slots (the workgroup's waves may run different instantiations: a workgroup of
 // tiles_per_block < WAVES * MI_max tiles deals its waves unequal tile counts; every instantiation executes the same barriers)
-template <int CIN, int COUT, int MI, int WAVES, int DBG>
+// SORTED (r06): the rows arrive grouped by neighbour mask (csrc/rulebook_sort.hip): `nbr` is the permuted map nbr_perm[k][j], `pmask[j]` the
+// mask of sorted row j, `perm[j]` its canonical row (where the result is stored).  The workgroup multiplies only the kernel offsets that
+// occur in the OR of its rows' masks - its step list is the set bits of that union, walked by two scalar cursors (one for the gather
+// indices, four steps ahead, one for the weight slabs, two steps ahead) - and a wave skips the gathers and MFMAs of a tile whose own
+// 16-row union lacks the step's offset(s).
+template <int CIN, int COUT, int MI, int WAVES, int DBG, bool SORTED>
 __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned in_bytes, const __bf16 *__restrict__ wpack,
                                                         const float *__restrict__ bias, const int32_t *__restrict__ nbr, int n_out, int kvol,
                                                         int tiles_per_block, __bf16 *__restrict__ out, float *__restrict__ stats_partial,
-                                                        int dbg_arg, long long *__restrict__ trace) {
+                                                        int dbg_arg, long long *__restrict__ trace, const int32_t *__restrict__ perm,
+                                                        const uint32_t *__restrict__ pmask) {
     typedef RgCfg<CIN, COUT, MI, WAVES> C;
     const int dbg = DBG == 1 ? dbg_arg : 0;   // DBG: 0 production, 1 ablation switches + stamps, 2 stamps only (the production instruction stream)
     // dbg & 32: wave 0 of every workgroup records s_memtime at kernel entry, after the prologue, after every step and at the end
@@ -137,7 +143,18 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
     const int tile0 = block * tiles_per_block;
     if (tile0 >= total_tiles) return;
     const int tile_end = min(total_tiles, tile0 + tiles_per_block);
-    const int steps = rg_steps(CIN, kvol);
+    // SORTED: the union of the workgroup's row masks (every wave computes it for itself: <= 4 rows per lane, no barrier) and of each of
+    // this wave's tiles; cnt = offsets to multiply
+    uint32_t bmask = 0, tmask[MI];
+    if constexpr (SORTED) {
+        const int r0 = tile0 * 16, r1 = min(tile_end * 16, n_out);
+        for (int rr = r0 + lane; rr < r1; rr += 64) bmask |= pmask[rr];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bmask |= (uint32_t)__shfl_xor((int)bmask, o, 64);
+        bmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)bmask);
+    }
+    const int cnt = SORTED ? __builtin_popcount(bmask) : kvol;
+    const int steps = SORTED ? (cnt + C::OPS - 1) / C::OPS : rg_steps(CIN, kvol);
 
     // this lane's output row per tile slot (-1: no such tile / row past the end); tiles are dealt round-robin to the waves
     int row[MI], rowc[MI];
@@ -147,7 +164,23 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
         const int rw = tl * 16 + r;
         row[i] = (tl < tile_end && rw < n_out) ? rw : -1;
         rowc[i] = row[i] < 0 ? 0 : row[i];
+        if constexpr (SORTED) {
+            uint32_t m = row[i] >= 0 ? pmask[rowc[i]] : 0u;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o, 64);
+            tmask[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        } else {
+            tmask[i] = 0xffffffffu;
+        }
     }
+    // SORTED: the offsets of the step list, handed out in order by two cursors (remaining bits of the union)
+    uint32_t cur_idx = bmask, cur_b = bmask;
+    auto next_off = [&](uint32_t &cur) -> int {   // next offset of the list, -1 past its end (wave-uniform)
+        if (cur == 0u) return -1;
+        const int k = __builtin_ctz(cur);
+        cur &= cur - 1u;
+        return k;
+    };
     const __amdgpu_buffer_rsrc_t rin = buf_rsrc(in, in_bytes);
     // chunk c of a step: which of the step's NIDX index registers it gathers with, its kernel offset, and the byte offset of this
     // lane's 16 bytes inside the gathered row
@@ -158,36 +191,87 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
     };
 
     typedef float f4 __attribute__((ext_vector_type(4)));
-    auto load_idx = [&](int s, int (&idx)[MI][C::NIDX]) {   // unconditional, clamped; masked by mask_idx when consumed
+    // koff[j]: the kernel offset behind index register j of the slot (SORTED; -1 = past the list), kept beside the indices
+    auto load_idx = [&](int s, int (&idx)[MI][C::NIDX], int (&koff)[C::NIDX]) {   // unconditional, clamped; masked by mask_idx when consumed
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int j = 0; j < C::NIDX; ++j) {
+            int k;
+            if constexpr (SORTED) {
+                k = koff[j] = next_off(cur_idx);
+                k = k < 0 ? 0 : k;
+            } else {
+                k = min(idx_off(s, j), kvol - 1);
+            }
 #pragma unroll
-            for (int j = 0; j < C::NIDX; ++j) idx[i][j] = nbr[(int64_t)min(idx_off(s, j), kvol - 1) * n_out + rowc[i]];
+            for (int i = 0; i < MI; ++i) idx[i][j] = nbr[(int64_t)k * n_out + rowc[i]];
+        }
     };
-    auto mask_idx = [&](int s, int (&idx)[MI][C::NIDX]) {
+    auto mask_idx = [&](int s, int (&idx)[MI][C::NIDX], const int (&koff)[C::NIDX]) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < C::NIDX; ++j) {
                 if (dbg & 1) idx[i][j] = rowc[i];   // ablation: sequential rows, every neighbour present
-                if (!(row[i] >= 0 && idx_off(s, j) < kvol)) idx[i][j] = -1;
+                const bool live = SORTED ? koff[j] >= 0 : idx_off(s, j) < kvol;
+                if (!(row[i] >= 0 && live)) idx[i][j] = -1;
             }
     };
-    auto load_a = [&](const int (&idx)[MI][C::NIDX], f4 (&a)[MI][C::KC]) {
+    // does tile slot i need the gathers / MFMAs of K chunk c of a step whose offsets are koff?  (wave-uniform; always for the plain kernel)
+    auto tile_live = [&](int i, int c, const int (&koff)[C::NIDX]) -> bool {
+        if constexpr (!SORTED) return true;
+        const int k = koff[chunk_j(c)];
+        return k >= 0 && ((tmask[i] >> k) & 1u);
+    };
+    if constexpr (SORTED) {
+        if (dbg_arg & 128) {   // A/B switch (S2D_RG_SORTED_DEBUG=128): no per-tile skipping, the workgroup's step list only
+#pragma unroll
+            for (int i = 0; i < MI; ++i) tmask[i] = 0xffffffffu;
+        }
+    }
+    auto load_a = [&](const int (&idx)[MI][C::NIDX], const int (&koff)[C::NIDX], f4 (&a)[MI][C::KC]) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int c = 0; c < C::KC; ++c) {
+                if (!tile_live(i, c, koff)) continue;   // (its MFMAs are skipped as well)
                 const int j = idx[i][chunk_j(c)];
                 const unsigned off = (j >= 0 && !(dbg & 4)) ? (unsigned)j * (unsigned)(CIN * 2) + chunk_byte(c) : BUF_OOB;
                 a[i][c] = buf_load4(rin, off, 0);
             }
     };
+    // weight slab of a step: plain kernel = slab `s` of the image; SORTED = the (half-)slabs of the step's offsets, taken from the slab cursor
+    // (the image is [offset][c][nt][lane][e] for every CIN: a step of OPS offsets is OPS consecutive pieces of B_BYTES / OPS bytes)
+    constexpr int SUB_BYTES = C::B_BYTES / C::OPS, SUB_PIECES = C::B_PIECES / C::OPS;
+    const char *bsub[C::OPS];
+    auto b_sources = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < C::OPS; ++j) {
+            int k;
+            if constexpr (SORTED) {
+                k = next_off(cur_b);
+                k = k < 0 ? 0 : k;
+            } else {
+                k = min(s, steps - 1) * C::OPS + j;
+            }
+            bsub[j] = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? j : k) * SUB_BYTES;
+        }
+    };
+    auto b_piece_src = [&](int u) -> const char * {
+        const int p = t + C::THREADS * u;
+        if constexpr (C::OPS == 1) return bsub[0] + (size_t)p * 16;
+        else {
+            const int j = p / SUB_PIECES;
+            const char *base = bsub[0];
+#pragma unroll
+            for (int jj = 1; jj < C::OPS; ++jj) base = j == jj ? bsub[jj] : base;
+            return base + (size_t)(p - j * SUB_PIECES) * 16;
+        }
+    };
     auto load_b = [&](int s, f4 (&breg)[C::B_LOADS]) {
-        const char *src = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? 0 : min(s, steps - 1)) * C::B_BYTES;
+        b_sources(s);
 #pragma unroll
         for (int u = 0; u < C::B_LOADS; ++u)
-            if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) breg[u] = *reinterpret_cast<const f4 *>(src + (size_t)(t + C::THREADS * u) * 16);
+            if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) breg[u] = *reinterpret_cast<const f4 *>(b_piece_src(u));
     };
     auto store_b = [&](int stage, const f4 (&breg)[C::B_LOADS]) {
 #pragma unroll
@@ -207,22 +291,30 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
     // files per loop iteration).  idx_p holds the gather indices of step s+2 during step s and is reloaded with those of step
     // s+4 after the last refill.  The loop is unrolled by two = the parity of the LDS weight stage.
     int idx0[MI][C::NIDX], idx1[MI][C::NIDX];
+    // offsets behind the slot's CURRENT fragments (kc*) and behind the indices waiting in idx* for the refill (kn*)
+    int kc0[C::NIDX], kc1[C::NIDX], kn0[C::NIDX], kn1[C::NIDX];
+#pragma unroll
+    for (int j = 0; j < C::NIDX; ++j) kc0[j] = kc1[j] = kn0[j] = kn1[j] = 0;
     f4 a0[MI][C::KC], a1[MI][C::KC];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int c = 0; c < C::KC; ++c) a0[i][c] = a1[i][c] = f4{0.f, 0.f, 0.f, 0.f};   // (SORTED: a skipped gather leaves its registers as they are)
     f4 breg[C::B_LOADS];
     const int steps2 = (steps + 1) / 2 * 2;
 
     // prologue: idx(0), idx(1); B(0) -> stage 0; A(0), A(1); B(1) -> registers; idx(2), idx(3)
-    load_idx(0, idx0);
-    load_idx(1, idx1);
+    load_idx(0, idx0, kc0);
+    load_idx(1, idx1, kc1);
     load_b(0, breg);
-    mask_idx(0, idx0);
-    load_a(idx0, a0);
-    mask_idx(1, idx1);
-    load_a(idx1, a1);
+    mask_idx(0, idx0, kc0);
+    load_a(idx0, kc0, a0);
+    mask_idx(1, idx1, kc1);
+    load_a(idx1, kc1, a1);
     store_b(0, breg);
     load_b(1, breg);
-    load_idx(2, idx0);
-    load_idx(3, idx1);
+    load_idx(2, idx0, kn0);
+    load_idx(3, idx1, kn1);
     stamp(1);
 
     // Step s (slot = parity):  barrier | NG groups, group g = { ds_read the weight fragments of group g+1 | its share of the
@@ -233,22 +325,29 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
     // of its first use; the scheduling barriers pin the interleave written here.
     constexpr int FG = C::NJ < 4 ? C::NJ : 4, GPC = C::NJ / FG, NG = C::KC * GPC;
     constexpr int BPER = (C::B_LOADS + NG - 1) / NG;   // B pieces per group
-    auto step = [&](int s, auto parity, f4 (&a)[MI][C::KC], int (&idx)[MI][C::NIDX]) {
+    auto step = [&](int s, auto parity, f4 (&a)[MI][C::KC], int (&idx)[MI][C::NIDX], int (&kc)[C::NIDX], int (&kn)[C::NIDX]) {
         constexpr int stage = decltype(parity)::value;
         __syncthreads();   // B(s) visible in `stage`; every wave is done reading the other stage (step s-1)
-        mask_idx(s + 2, idx);
+        mask_idx(s + 2, idx, kn);
         const char *bs = smem + stage * C::B_BYTES;
         char *bw = smem + (stage ^ 1) * C::B_BYTES;
-        const char *bsrc = reinterpret_cast<const char *>(wpack) + (int64_t)((dbg & 8) ? 0 : min(s + 2, steps - 1)) * C::B_BYTES;
+        b_sources(s + 2);
         auto b_task = [&](int u) {
             if (C::B_FULL || t + C::THREADS * u < C::B_PIECES) {
                 *reinterpret_cast<f4 *>(bw + (size_t)(t + C::THREADS * u) * 16) = breg[u];                 // B(s+1) -> LDS
-                if (!(dbg & 64)) breg[u] = *reinterpret_cast<const f4 *>(bsrc + (size_t)(t + C::THREADS * u) * 16);   // B(s+2) -> registers
+                if (!(dbg & 64)) breg[u] = *reinterpret_cast<const f4 *>(b_piece_src(u));                  // B(s+2) -> registers
             }
         };
+        // which (tile, chunk) MFMAs this step issues: decided from the offsets behind the CURRENT fragments, before the refills retarget kc
+        bool live[MI][C::KC];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int c = 0; c < C::KC; ++c) live[i][c] = tile_live(i, c, kc);
         auto refill = [&](int c) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+                if (!tile_live(i, c, kn)) continue;
                 const int j = idx[i][chunk_j(c)];
                 const unsigned off = (j >= 0 && !(dbg & 4)) ? (unsigned)j * (unsigned)(CIN * 2) + chunk_byte(c) : BUF_OOB;
                 a[i][c] = buf_load4(rin, off, 0);
@@ -273,6 +372,7 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
             if (!(dbg & 2)) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
+                    if (SORTED && !live[i][g / GPC]) continue;   // wave-uniform: this tile has no neighbour at the chunk's offset
 #pragma unroll
                     for (int n = 0; n < FG; ++n)
                         // in-place accumulate in the AGPR file, written as asm: with the builtin hipcc gave the MFMAs a second
@@ -288,12 +388,14 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
             __builtin_amdgcn_sched_barrier(0);
         }
         refill(C::KC - 1);
-        load_idx(s + 4, idx);
+#pragma unroll
+        for (int j = 0; j < C::NIDX; ++j) kc[j] = kn[j];   // the slot's fragments now belong to step s + 2
+        load_idx(s + 4, idx, kn);
         if (s + 2 < 60) stamp(s + 2);
     };
     for (int s = 0; s < steps2; s += 2) {
-        step(s, std::integral_constant<int, 0>{}, a0, idx0);
-        step(s + 1, std::integral_constant<int, 1>{}, a1, idx1);
+        step(s, std::integral_constant<int, 0>{}, a0, idx0, kc0, kn0);
+        step(s + 1, std::integral_constant<int, 1>{}, a1, idx1, kc1, kn1);
     }
 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the accumulators were written by asm MFMAs: no hazard bookkeeping by the compiler
@@ -321,7 +423,8 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
                     s1[n] += f;
                     s2[n] += f * f;
                 }
-                __bf16 *dst = out + (int64_t)rw * COUT + r * C::NJ;
+                const int64_t orow = SORTED ? (int64_t)perm[rw] : (int64_t)rw;   // sorted position -> canonical row
+                __bf16 *dst = out + orow * COUT + r * C::NJ;
                 if constexpr (C::NJ == 8) {
                     bf16x8r o;
 #pragma unroll
@@ -371,11 +474,13 @@ __device__ __forceinline__ void rg_wave(const __bf16 *__restrict__ in, unsigned 
     stamp(63);
 }
 
-template <int CIN, int COUT, int MI, int WAVES, int DBG>
+template <int CIN, int COUT, int MI, int WAVES, int DBG, bool SORTED = false>
 __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__restrict__ in, unsigned in_bytes, const __bf16 *__restrict__ wpack,
                                                                const float *__restrict__ bias, const int32_t *__restrict__ nbr, int n_out,
                                                                int kvol, int tiles_per_block, __bf16 *__restrict__ out,
-                                                               float *__restrict__ stats_partial, int dbg_arg, long long *__restrict__ trace) {
+                                                               float *__restrict__ stats_partial, int dbg_arg, long long *__restrict__ trace,
+                                                               const int32_t *__restrict__ perm, const uint32_t *__restrict__ pmask) {
+    static_assert(!SORTED || RgCfg<CIN, COUT, MI, WAVES>::NIDX == RgCfg<CIN, COUT, MI, WAVES>::OPS, "sorted rows: 64 / 128 input channels");
     // valid tile slots of this wave (tiles are dealt round-robin: slot i = tile0 + wave + WAVES * i)
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total_tiles = (n_out + 15) >> 4;
@@ -386,11 +491,11 @@ __global__ __launch_bounds__(WAVES * 64) void spconv_rg_kernel(const __bf16 *__r
 #pragma unroll
     for (int i = 0; i < MI; ++i) nt += (tile0 + wid + WAVES * i < tile_end) ? 1 : 0;
     nt = __builtin_amdgcn_readfirstlane(nt);
-#define RG_ARGS in, in_bytes, wpack, bias, nbr, n_out, kvol, tiles_per_block, out, stats_partial, dbg_arg, trace
-    if constexpr (MI >= 4) { if (nt == 4) { rg_wave<CIN, COUT, 4, WAVES, DBG>(RG_ARGS); return; } }
-    if constexpr (MI >= 3) { if (nt == 3) { rg_wave<CIN, COUT, 3, WAVES, DBG>(RG_ARGS); return; } }
-    if constexpr (MI >= 2) { if (nt == 2) { rg_wave<CIN, COUT, 2, WAVES, DBG>(RG_ARGS); return; } }
-    rg_wave<CIN, COUT, 1, WAVES, DBG>(RG_ARGS);   // also a wave without a tile: one phantom slot, same barriers
+#define RG_ARGS in, in_bytes, wpack, bias, nbr, n_out, kvol, tiles_per_block, out, stats_partial, dbg_arg, trace, perm, pmask
+    if constexpr (MI >= 4) { if (nt == 4) { rg_wave<CIN, COUT, 4, WAVES, DBG, SORTED>(RG_ARGS); return; } }
+    if constexpr (MI >= 3) { if (nt == 3) { rg_wave<CIN, COUT, 3, WAVES, DBG, SORTED>(RG_ARGS); return; } }
+    if constexpr (MI >= 2) { if (nt == 2) { rg_wave<CIN, COUT, 2, WAVES, DBG, SORTED>(RG_ARGS); return; } }
+    rg_wave<CIN, COUT, 1, WAVES, DBG, SORTED>(RG_ARGS);   // also a wave without a tile: one phantom slot, same barriers
 #undef RG_ARGS
 }
 
@@ -455,7 +560,27 @@ static int rg_launch(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf
         attr_done[dbg != 0] = true;
     }
     hipLaunchKernelGGL(kern, dim3(xcd_grid(p.grid)), dim3(C::THREADS), C::LDS, st, in, (unsigned)(n_in * CIN * 2), wpack, bias, nbr, n_out, kvol,
-                       p.tiles_per_block, out, stats, dbg, g_rg_trace);
+                       p.tiles_per_block, out, stats, dbg, g_rg_trace, (const int32_t *)nullptr, (const uint32_t *)nullptr);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+// rows grouped by neighbour mask (csrc/rulebook_sort.hip): one plan shape (two tiles per wave, eight waves), 64 -> 64 and 128 -> 128 - the
+// submanifold layers of the two wide stages
+template <int CIN, int COUT>
+static int rg_launch_sorted(const RgPlan &p, const __bf16 *in, int64_t n_in, const __bf16 *wpack, const float *bias, const int32_t *nbr_perm,
+                            const int32_t *perm, const uint32_t *pmask, int n_out, int kvol, __bf16 *out, float *stats, hipStream_t st) {
+    typedef RgCfg<CIN, COUT, 2, 8> C;
+    auto kern = spconv_rg_kernel<CIN, COUT, 2, 8, 0, true>;
+    static bool attr_done = false;
+    if (!attr_done && C::LDS > 48 * 1024) {
+        S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        attr_done = true;
+    }
+    static int sdbg = -1;
+    if (sdbg < 0) sdbg = getenv("S2D_RG_SORTED_DEBUG") ? atoi(getenv("S2D_RG_SORTED_DEBUG")) : 0;
+    hipLaunchKernelGGL(kern, dim3(xcd_grid(p.grid)), dim3(C::THREADS), C::LDS, st, in, (unsigned)(n_in * CIN * 2), wpack, bias, nbr_perm, n_out, kvol,
+                       p.tiles_per_block, out, stats, sdbg, (long long *)nullptr, perm, pmask);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -504,6 +629,20 @@ int rg_run(const void *in_feat, int64_t n_in, const void *packed_weight, const f
         case 64: return rg_dispatch_cout<64>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
         case 128: return rg_dispatch_cout<128>(cout, plan, in, n_in, wp, bias, nbr, (int)n_out, kvol, out, stats_partial, st);
     }
+    return S2D_ERR_UNSUPPORTED;
+}
+
+bool rg_sorted_supported(int kvol, int cin, int cout) { return kvol == 27 && cin == cout && (cin == 64 || cin == 128); }
+
+// the sorted-row launch: the plan is rg_plan's tile count with the fixed (2, 8) shape, so stats_partial has rg_plan(...).grid rows as usual
+int rg_run_sorted(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr_perm, const int32_t *perm,
+                  const uint32_t *pmask, int64_t n_out, int kvol, int cin, int cout, void *out_feat, float *stats_partial, hipStream_t st) {
+    RgPlan plan = rg_plan(n_out, kvol, cin, cout);
+    if (plan.mi != 2 || plan.waves != 8) return S2D_ERR_UNSUPPORTED;   // (S2D_RG_PLAN tuning override in force)
+    const __bf16 *in = (const __bf16 *)in_feat, *wp = (const __bf16 *)packed_weight;
+    __bf16 *out = (__bf16 *)out_feat;
+    if (cin == 64 && cout == 64) return rg_launch_sorted<64, 64>(plan, in, n_in, wp, bias, nbr_perm, perm, pmask, (int)n_out, kvol, out, stats_partial, st);
+    if (cin == 128 && cout == 128) return rg_launch_sorted<128, 128>(plan, in, n_in, wp, bias, nbr_perm, perm, pmask, (int)n_out, kvol, out, stats_partial, st);
     return S2D_ERR_UNSUPPORTED;
 }
 

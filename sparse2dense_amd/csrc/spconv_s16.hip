@@ -316,6 +316,11 @@ size_t rg_packed_elems(int kvol, int cin, int cout);
 int rg_pack(const float *weight, int kvol, int cin, int cout, int transpose, int flip, void *packed, hipStream_t st);
 int rg_pack_pair(const float *weight, int kvol, int cin, int cout, int flip_dgrad, void *packed_fwd, void *packed_dgrad, hipStream_t st);
 void rg_set_trace(void *p);
+// sorted-row mode (see use_rg): initial value from S2D_RG_SORTED, changed by s2d_spconv_s16_set_sorted_rows
+static int &g_sorted_rows_mode() {
+    static int mode = (getenv("S2D_RG_SORTED") && atoi(getenv("S2D_RG_SORTED")) != 0) ? 1 : 0;
+    return mode;
+}
 static bool use_rg(int cin, int cout) {
     static int v = -1;
     if (v < 0) {
@@ -325,8 +330,13 @@ static bool use_rg(int cin, int cout) {
     // 64 -> 64 (48 vs 52 us) and narrower stay on the LDS-staged kernel.  r03 experiment: the register-gather template instantiated for
     // 32 channels (four offsets per 128-deep K-step): 32 -> 32 61 vs 56 us, 64 -> 32 62 vs 68 us - no case for it; tile heights of the
     // LDS kernel re-swept at the same time (S2D_S16_PLAN): 64 rows still beat 128 / 256 at every 16...64-channel shape
-    return v != 0 && cin >= 64 && cout >= 64 && (cin == 128 || cout == 128);
+    // r06: with the sorted-row form switched on (s2d_spconv_s16_set_sorted_rows: opt-in, it measured SLOWER - see csrc/rulebook_sort.hip) 64 -> 64
+    // runs on the register-gather kernel too: one weight image must serve the plain and the sorted launch of a layer
+    return v != 0 && cin >= 64 && cout >= 64 && (cin == 128 || cout == 128 || g_sorted_rows_mode() != 0);
 }
+bool rg_sorted_supported(int kvol, int cin, int cout);
+int rg_run_sorted(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr_perm, const int32_t *perm,
+                  const uint32_t *pmask, int64_t n_out, int kvol, int cin, int cout, void *out_feat, float *stats_partial, hipStream_t st);
 
 static int s16_wn(int cout, int bm) { return cout == 128 ? 2 : ((cout == 64 && bm == 64) ? 2 : 1); }
 
@@ -492,4 +502,29 @@ extern "C" int s2d_spconv_s16_fwd_stats(const void *in_feat, int64_t n_in, const
         case 128: return s16_dispatch_cout<128>(cout, plan, in, wp, bias, nbr, zp, (int)n_out, kvol, out, stats_partial, st);
     }
     return S2D_ERR_UNSUPPORTED;
+}
+
+/* rows grouped by neighbour mask (s2d_rulebook_sort_by_mask): see include/s2d.h */
+extern "C" int s2d_spconv_s16_set_sorted_rows(int on) {
+    const int was = g_sorted_rows_mode();
+    g_sorted_rows_mode() = on ? 1 : 0;
+    return was;
+}
+
+extern "C" int s2d_spconv_s16_sorted_supported(int kvol, int cin, int cout) {
+    return g_sorted_rows_mode() != 0 && use_rg(cin, cout) && rg_sorted_supported(kvol, cin, cout);
+}
+
+extern "C" int s2d_spconv_s16_fwd_sorted(const void *in_feat, int64_t n_in, const void *packed_weight, const float *bias, const int32_t *nbr_perm,
+                                         const int32_t *perm, const uint32_t *pmask, int64_t n_out, int kvol, int cin, int cout, void *out_feat,
+                                         float *stats_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(n_in >= 0 && n_out >= 0 && n_out < 0x7fffffff && kvol > 0, "spconv_s16_fwd_sorted: bad sizes");
+    if (!s2d_spconv_s16_sorted_supported(kvol, cin, cout)) {
+        set_error("spconv_s16_fwd_sorted: unsupported layer %d -> %d, kvol %d", cin, cout, kvol);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    if (n_out == 0) return S2D_OK;
+    S2D_CHECK_ARG(in_feat && packed_weight && nbr_perm && perm && pmask && out_feat && n_in > 0, "spconv_s16_fwd_sorted: null argument");
+    S2D_CHECK_ARG(n_in * cin * 2 < (int64_t)BUF_OOB, "spconv_s16_fwd_sorted: feature matrix of %lld rows exceeds the 2 GiB buffer window", (long long)n_in);
+    return rg_run_sorted(in_feat, n_in, packed_weight, bias, nbr_perm, perm, pmask, n_out, kvol, cin, cout, out_feat, stats_partial, (hipStream_t)stream);
 }

@@ -649,6 +649,72 @@ def spconv_s16_run(feat, packed, kvol, cin, cout, bias, nbr, n_out, pair_count=N
     return (out, partial) if bn_stats else out
 
 
+# submanifold 64 -> 64 / 128 -> 128 layers over mask-sorted rows (csrc/rulebook_sort.hip).  OPT-IN (S2D_RG_SORTED=1 / set_sorted_rows): on the
+# benchmark scene it is 5-10 % slower than the plain kernel (profiles/r06_sparse_sorted_rows_ab.txt) - the gathers, not the MFMAs, bound it.
+SORTED_ROWS = os.environ.get("S2D_RG_SORTED", "0") not in ("0", "")
+
+
+def set_sorted_rows(on):
+    """switch the sorted-row form on / off in the library and here; returns the previous setting.  The 64 -> 64 layers change their weight
+    image with it, so every cached image is dropped."""
+    global SORTED_ROWS
+    from .dense2d import clear_pack_cache
+    was = bool(_lib.load().s2d_spconv_s16_set_sorted_rows(int(bool(on))))
+    SORTED_ROWS = bool(on)
+    clear_pack_cache()
+    return was
+
+
+
+def rulebook_sorted_rows(rb):
+    """(perm i32[n], pmask i32[n] (bit pattern of the u32 masks), nbr_perm i32[K, n]) of a submanifold rulebook: its rows grouped by
+    neighbour mask, built once per rulebook (three launches, no host read) and kept on it - every layer and both passes of the stage reuse it"""
+    cached = getattr(rb, "_sorted_rows", None)
+    if cached is not None:
+        return cached
+    lib = _lib.load()
+    nbr = rb.nbr_out
+    n = int(rb.n_out)
+    dev = nbr.device
+    assert rb.subm and nbr.dtype == torch.int32 and nbr.is_contiguous() and nbr.shape == (rb.kvol, n)
+    perm = torch.empty((n,), dtype=torch.int32, device=dev)
+    pmask = torch.empty((n,), dtype=torch.int32, device=dev)
+    nbr_perm = torch.empty_like(nbr)
+    ws = _ws(lib.s2d_rulebook_sort_workspace_bytes(n), dev)
+    check(lib.s2d_rulebook_sort_by_mask(_ptr(nbr), rb.kvol, n, _ptr(perm), _ptr(pmask), _ptr(nbr_perm), _ptr(ws), ws.numel(), _stream()),
+          "s2d_rulebook_sort_by_mask")
+    rb._sorted_rows = (perm, pmask, nbr_perm)
+    return rb._sorted_rows
+
+
+def spconv_s16_sorted_ok(rb, kvol, cin, cout, n_out):
+    return bool(SORTED_ROWS and rb is not None and rb.subm and n_out == rb.n_out and n_out > 0
+                and _lib.load().s2d_spconv_s16_sorted_supported(int(kvol), int(cin), int(cout)))
+
+
+def spconv_s16_run_sorted(feat, packed, kvol, cin, cout, bias, rb, tag="fwd", bn_stats=False):
+    """spconv_s16_run over the mask-sorted rows of the submanifold rulebook `rb` (same packed image, same outputs in the canonical row order)"""
+    lib = _lib.load()
+    n_out = int(rb.n_out)
+    assert feat.dtype == torch.bfloat16 and feat.shape[1] == cin and feat.is_contiguous()
+    perm, pmask, nbr_perm = rulebook_sorted_rows(rb)
+    out = torch.empty((n_out, cout), dtype=torch.bfloat16, device=feat.device)
+    partial = None
+    if bn_stats:
+        partial = torch.empty((lib.s2d_spconv_s16_stats_tiles(n_out, kvol, cin, cout), 2, cout), dtype=torch.float32, device=feat.device)
+    rec = None
+    if PROFILE is not None:
+        rec = dict(kernel="spconv_fwd_s16", tag=tag, cin=cin, cout=cout, n_out=n_out, kvol=kvol, pairs=rb.pair_count, sorted_rows=True,
+                   elem_bytes=2, start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
+        rec["start"].record()
+    check(lib.s2d_spconv_s16_fwd_sorted(_ptr(feat), feat.shape[0], _ptr(packed), _ptr(bias), _ptr(nbr_perm), _ptr(perm), _ptr(pmask), n_out, kvol,
+                                        cin, cout, _ptr(out), _ptr(partial), _stream()), "s2d_spconv_s16_fwd_sorted")
+    if rec is not None:
+        rec["end"].record()
+        PROFILE.append(rec)
+    return (out, partial) if bn_stats else out
+
+
 def col_sums_bf16(x):
     """per-column fp32 sums of a row-major bf16 matrix [n, c] (c % 8 == 0): bias gradients"""
     lib = _lib.load()

@@ -126,6 +126,10 @@ class _SparseConvFn(torch.autograd.Function):
         packed, kvol, cin, cout = cached_pack(
             weight, key, lambda: H.spconv_s16_pack(_SparseConvFn._w_s16(weight, rb, cin_feat), n_out, transpose, flip))
         b = None if bias is None else bias.detach().float().contiguous()
+        if nbr is rb.nbr_out and H.spconv_s16_sorted_ok(rb, kvol, cin, cout, n_out):
+            # r06: submanifold 64 -> 64 / 128 -> 128 layers (forward, and the data gradient = the same map with mirrored weights) run over the
+            # rulebook's rows grouped by neighbour mask: offsets absent from a workgroup / tile are not multiplied (csrc/rulebook_sort.hip)
+            return H.spconv_s16_run_sorted(x.contiguous(), packed, kvol, cin, cout, b, rb, tag, bn_stats=bn_stats)
         return H.spconv_s16_run(x.contiguous(), packed, kvol, cin, cout, b, nbr, n_out, rb.pair_count, tag, bn_stats=bn_stats)
 
     @staticmethod

@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# MIOpen has no pre-built kernel / find database for gfx950 in this image: every new fp32 convolution configuration of the parity
+# ("f32") mode JIT-compiles its solver on a fresh box.  Measured r06 (scratch probe, one pillar step at 4 x 150 k points, first call /
+# second call): all solvers 127 s / 7 s; without the Winograd, direct and FFT families - the implicit-GEMM (pre-built CK instances) and
+# GEMM solvers remain - 38 s / 8 s.  The TEST process therefore restricts MIOpen to those families (set before torch loads the
+# library; a value the caller exported wins).  The product, bench.py and smoke() do not touch these variables.
+for _k in ("MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_CONV_DIRECT", "MIOPEN_DEBUG_CONV_FFT"):
+    os.environ.setdefault(_k, "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -40,3 +48,32 @@ def pytest_collection_modifyitems(config, items):
             return 1000 + _GPU_ORDER_LAST.index(name)
         return 500
     items.sort(key=rank)   # stable: the order inside a file is kept
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _memoised_oracle_rulebooks():
+    """oracle.spconv_ref.rulebook_subm / rulebook_conv are pure numpy functions of (coordinates, geometry); the parity tests call them
+    with the same few clouds over and over (every oracle module builds its own rulebooks: float64 run, fp32 calibration run, storage
+    emulation run ...), ~5 s of host time per backbone pass.  Memoised for the session - same function, same results."""
+    import hashlib
+    import numpy as np
+    from oracle import spconv_ref as R
+    orig_subm, orig_conv = R.rulebook_subm, R.rulebook_conv
+    cache = {}
+
+    def key(coors, *args):
+        c = np.ascontiguousarray(np.asarray(coors))
+        return (hashlib.sha1(c.tobytes()).hexdigest(), c.shape, str(c.dtype), repr(args))
+
+    def memo(fn, name):
+        def wrapped(coors, *args, **kw):
+            k = (name,) + key(coors, *args, tuple(sorted(kw.items())))
+            if k not in cache:
+                if len(cache) >= 96:
+                    cache.pop(next(iter(cache)))
+                cache[k] = fn(coors, *args, **kw)
+            return cache[k]
+        return wrapped
+    R.rulebook_subm, R.rulebook_conv = memo(orig_subm, "subm"), memo(orig_conv, "conv")
+    yield
+    R.rulebook_subm, R.rulebook_conv = orig_subm, orig_conv

@@ -226,7 +226,10 @@ def oracle_stack(device="cpu", storage_bf16=False):
 def to_device(obj, device, dtype=None):
     """an example dict / list / tensor moved to `device`; floating tensors cast to `dtype` when given"""
     if torch.is_tensor(obj):
-        return obj.to(device=device, dtype=dtype) if (dtype is not None and obj.is_floating_point()) else obj.to(device)
+        out = obj.to(device=device, dtype=dtype) if (dtype is not None and obj.is_floating_point()) else obj.to(device)
+        # always a NEW tensor object: python attributes hung on an example's tensors by the product's data pipeline (a pre-built HIP
+        # geometry plan, data.attach_geometry) must not travel into the oracle's run
+        return out.clone() if out is obj else out
     if isinstance(obj, dict):
         return {k: to_device(v, device, dtype) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):

@@ -76,11 +76,12 @@ def test_backbone_forward_backward_vs_oracle(kind, ref_cls, channels):
     feats, coors = _scene_voxels(8000, seed=7, batch=2)   # BASELINE config 1 scene ("second8k"), B=2
     net = fill_params(build_backbone(dict(type=kind, num_input_features=5, ds_factor=8))).train()
     ref = fill_params(ref_cls(5)).double().train().to(ODEV)   # float64 oracle = exact arithmetic for our purposes
-    ref32 = fill_params(ref_cls(5)).train().to(ODEV)           # fp32 oracle: calibrates the conditioning of the backward
+    ref32 = fill_params(ref_cls(5)).train()                    # fp32 oracle ON THE HOST: calibrates the conditioning of the backward (the
+    # bar below was set against the host's fp32 summation order in r01; torch's device kernels happen to land 3x closer to float64)
     assert sorted(net.state_dict()) == sorted(ref.state_dict())
     grid = np.array([1504, 1504, 40])
     bev_ref, ms_ref = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)
-    bev32, _ = ref32(torch.from_numpy(feats).to(ODEV), coors, 2, grid)
+    bev32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
     net = net.to(DEV)
     bev, ms = net(torch.from_numpy(feats).to(DEV), torch.from_numpy(coors).to(DEV), 2, grid)
     assert bev.shape == (2, channels, 188, 188) == bev_ref.shape
@@ -98,7 +99,7 @@ def test_backbone_forward_backward_vs_oracle(kind, ref_cls, channels):
             assert int(sd[k]) == int(sr[k]) == 1
     g = torch.randn(bev_ref.shape, generator=torch.Generator().manual_seed(5))
     (bev_ref * g.double().to(ODEV)).sum().backward()
-    (bev32 * g.to(ODEV)).sum().backward()
+    (bev32 * g).sum().backward()
     (bev * g.to(DEV)).sum().backward()
     _compare_grads(net, ref, tol=5e-3, ref32=ref32)
 
@@ -249,14 +250,14 @@ def test_s16_backbone_gradients_vs_bf16_storage_oracle(train):
     mk = lambda m: (m.train() if train else m.eval())
     net = mk(_round_conv_weights_to_bf16(fill_params(build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5)))))
     ref = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5))).double()).to(ODEV)
-    ref32 = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5)))).to(ODEV) if train else None
+    ref32 = mk(_round_conv_weights_to_bf16(fill_params(R.RefSpMiddleResNetFHD(5)))) if train else None   # (host: see above)
     g = torch.randn((2, 256, 188, 188), generator=torch.Generator().manual_seed(5))
     with R.bf16_storage():
         b, ms_ref = ref(torch.from_numpy(feats).double().to(ODEV), coors, 2, grid)
         (b * g.double().to(ODEV)).sum().backward()
         if train:
-            b32, _ = ref32(torch.from_numpy(feats).to(ODEV), coors, 2, grid)
-            (b32 * g.to(ODEV)).sum().backward()
+            b32, _ = ref32(torch.from_numpy(feats), coors, 2, grid)
+            (b32 * g).sum().backward()
     b = b.detach().cpu()
     net = net.to(DEV)
     H.set_sparse_compute_dtype("s16")

@@ -17,10 +17,14 @@ def lib():
     return _lib.load()
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "s2d.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(s2d_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(headers=("s2d.h", "s2d_debug.h")):
+    """entry points of the boundary header and of the debug header (tools only: include/s2d_debug.h)"""
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(s2d_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported(lib):
@@ -29,6 +33,7 @@ def test_header_symbols_all_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/s2d.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "python binding and header disagree"
+    assert not [n for n in declared_symbols(("s2d.h",)) if n.startswith("s2d_debug_")], "debug entries belong in include/s2d_debug.h"
 
 
 def test_version_and_error_text(lib):

@@ -259,3 +259,131 @@ def test_sparse_weight_gradient_at_benchmark_row_counts(cin, cout, n_in, n_out, 
     assert torch.isfinite(dw).all()
     assert (dw.double() - ref).abs().max() <= 2e-3 * ref.abs().max(), float((dw.double() - ref).abs().max() / ref.abs().max())
     assert torch.equal(dw, H.spconv_s16_wgrad(feat, dout, nbr, kvol))   # fixed-order split reduction: bit-reproducible
+
+
+# ---- r06: rows grouped by neighbour mask (csrc/rulebook_sort.hip) and the implicit GEMM over them (spconv_rg_kernel<..., SORTED>) -------------
+def _shaped_map(n, shapes, seed, p_drop=0.0):
+    """a submanifold-like gather map [27][n] whose rows take their neighbour mask from a small set of `shapes` (bit masks; every mask keeps the
+    centre offset 13, as a real rulebook does), rows in random order - what the sort has to group; p_drop: extra random holes"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    pick = torch.randint(0, len(shapes), (n,), device=DEV, generator=g)
+    masks = torch.tensor(shapes, device=DEV, dtype=torch.int64)[pick] | (1 << 13)
+    bits = ((masks[None, :] >> torch.arange(27, device=DEV)[:, None]) & 1).bool()
+    if p_drop:
+        bits &= torch.rand(27, n, device=DEV, generator=g) >= p_drop
+        bits[13] = True
+    nbr = torch.randint(0, n, (27, n), device=DEV, dtype=torch.int32, generator=g)
+    nbr[~bits] = -1
+    return nbr
+
+
+def _subm_rulebook(nbr):
+    from sparse2dense_amd import hip_ops as H
+    n = nbr.shape[1]
+    return H.Rulebook(True, 27, n, n, nbr.contiguous(), None, (nbr >= 0).sum(1).int(), None, (41, 1504, 1504))
+
+
+_SHAPES = {
+    "plane": [0b000000000_111111111_000000000, 0b000000000_000111000_000000000, 0b010010010_010010010_010010010, 0b000010000_000010000_000010000],
+    "mixed": [int(v) for v in np.random.RandomState(3).randint(1, 1 << 27, 40)],
+    "full": [(1 << 27) - 1],
+    "centre": [1 << 13],
+}
+
+
+@pytest.mark.parametrize("n,kind", [(47890, "mixed"), (126079, "plane"), (1000, "mixed"), (17, "full"), (1, "centre")])
+def test_rulebook_rows_sorted_by_neighbour_mask(n, kind):
+    from sparse2dense_amd import hip_ops as H
+    nbr = _shaped_map(n, _SHAPES[kind], seed=n, p_drop=0.1 if kind == "mixed" else 0.0)
+    perm, pmask, nbr_perm = H.rulebook_sorted_rows(_subm_rulebook(nbr))
+    mask = ((nbr >= 0).long() << torch.arange(27, device=DEV)[:, None]).sum(0)
+    pm = pmask.long() & 0xffffffff
+    from sparse2dense_amd import _lib
+    chunk = int(_lib.load().s2d_rulebook_sort_chunk_rows(n))   # the sort stays inside the rows one XCD's workgroups consume
+    assert chunk >= 1 and -(-n // chunk) <= 8
+    assert torch.equal(torch.sort(perm.long())[0], torch.arange(n, device=DEV))            # a permutation
+    assert torch.equal(perm.long() // chunk, torch.arange(n, device=DEV) // chunk)          # ... of each chunk onto itself
+    key = ((perm.long() // chunk) << 27) | pm
+    assert bool((key[1:] >= key[:-1]).all())                                                # ascending masks inside a chunk
+    assert torch.equal(pm, mask[perm.long()])                                               # ... of the rows they name
+    same = key[1:] == key[:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())                                   # stable: equal masks keep the canonical order
+    assert torch.equal(nbr_perm, nbr[:, perm.long()])
+
+
+@pytest.mark.parametrize("c,n,kind,p_drop", [
+    (128, 47890, "mixed", 0.1),     # conv4 SubM stage of the 4 x 150 k-point benchmark scene (two tiles per wave: above 32 768 rows)
+    (128, 47890, "plane", 0.0),     # few offsets per workgroup: short step lists, odd step counts
+    (64, 126079, "mixed", 0.2),     # conv3 SubM stage
+    (64, 126079, "plane", 0.0),
+    (128, 70000, "full", 0.0),      # nothing to skip: every offset in every tile
+    (64, 3000, "centre", 0.0),      # one offset: a single (padded) step
+    (128, 333, "mixed", 0.3), (64, 1, "centre", 0.0), (64, 40, "full", 0.5),
+])
+def test_rg_kernel_over_mask_sorted_rows_matches_fp32_at_benchmark_row_counts(c, n, kind, p_drop):
+    """the sorted-row instantiations against an fp32 restatement on the device, every row, with and without the statistics epilogue,
+    and against the plain kernel's output (same packed image): the stored rows must be in the CANONICAL order"""
+    from sparse2dense_amd import hip_ops as H
+    torch.manual_seed(c + n)
+    nbr = _shaped_map(n, _SHAPES[kind], seed=7 * n + c, p_drop=p_drop)
+    rb = _subm_rulebook(nbr)
+    was = H.set_sorted_rows(True)
+    try:
+        assert H.spconv_s16_sorted_ok(rb, 27, c, c, n)
+        _check_sorted_kernel(H, c, n, nbr, rb)
+    finally:
+        H.set_sorted_rows(was)
+
+
+def _check_sorted_kernel(H, c, n, nbr, rb):
+    feat = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+    w = torch.randn(27, c, c, device=DEV) * 0.05
+    bias = torch.randn(c, device=DEV)
+    ref = torch.zeros(n, c, device=DEV, dtype=torch.float32) + bias
+    fr, wr = feat.float(), w.to(torch.bfloat16).float()
+    for k in range(27):
+        o = torch.nonzero(nbr[k] >= 0).squeeze(1)
+        ref[o] += fr[nbr[k][o].long()] @ wr[k]
+    packed, kv, ci, co = H.spconv_s16_pack(w, n)
+    plain = H.spconv_s16_run(feat, packed, kv, ci, co, bias, nbr, n, None, "fwd").float()
+    for with_stats in (False, True):
+        r = H.spconv_s16_run_sorted(feat, packed, kv, ci, co, bias, rb, "fwd", bn_stats=with_stats)
+        out = (r[0] if with_stats else r).float()
+        bad = ((out - ref).abs() > 1.2e-2 * ref.abs().max()).any(1) | (~torch.isfinite(out)).any(1)
+        assert int(bad.sum()) == 0, (with_stats, int(bad.sum()), bad.nonzero().flatten()[:8].tolist())
+        # same products, same fp32 accumulation order per row (offsets ascending in both kernels): the two kernels agree to the last bf16 ulp
+        assert float((out - plain).abs().max()) <= 8e-3 * float(ref.abs().max())
+        if with_stats:
+            part = r[1].double().sum(0)
+            o64 = r[0].double()
+            assert torch.allclose(part[0], o64.sum(0), rtol=1e-4, atol=1e-2) and torch.allclose(part[1], (o64 * o64).sum(0), rtol=1e-4, atol=1e-2)
+
+
+def test_sparse_conv_layer_uses_the_sorted_rows_and_matches_the_plain_kernel():
+    """spconv.SubMConv3d in the bf16-storage mode: forward and data gradient through the sorted-row kernel == through the plain one
+    (S2D_RG_SORTED=0 path), 64 channels"""
+    from sparse2dense_amd import hip_ops as H
+    from sparse2dense_amd.spconv import _SparseConvFn
+    n, c = 20000, 64
+    nbr = _shaped_map(n, _SHAPES["mixed"], seed=5, p_drop=0.1)
+    rb = _subm_rulebook(nbr)
+    torch.manual_seed(1)
+    w = (torch.randn(3, 3, 3, c, c, device=DEV) * 0.05).requires_grad_(True)
+    x = torch.randn(n, c, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(n, c, device=DEV).to(torch.bfloat16)
+    res = {}
+    old = H.SORTED_ROWS
+    try:
+        for mode in (True, False):
+            H.set_sorted_rows(mode)
+            if hasattr(rb, "_sorted_rows"):
+                del rb._sorted_rows
+            x.grad = w.grad = None
+            y = _SparseConvFn.apply(x, w, None, rb)
+            y.backward(g)
+            res[mode] = (y.detach().float(), x.grad.float(), w.grad.clone())
+            assert hasattr(rb, "_sorted_rows") == mode
+    finally:
+        H.set_sorted_rows(old)
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 8e-3 * float(b.abs().max())
