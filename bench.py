@@ -422,7 +422,7 @@ def roofline_pass(step, n_steps=3):
             else:
                 kname = "conv3x3_k32_nhwc_bf16_kernel<64, 4, 3, false>"
         key = (kname, r["cin"], r["cout"], r["n_out"], r.get("tag", ""))
-        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, tile_rows=r.get("tile_rows", 128)))
+        a = agg.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, issued=0.0, tile_rows=r.get("tile_rows", 128)))
         a["ms"] += ms
         a["n"] += 1
         if r.get("dense"):   # dense 3x3 conv, NHWC bf16: 2*M*9*cin*cout flops; every input / output / weight byte once
@@ -430,6 +430,7 @@ def roofline_pass(step, n_steps=3):
             a["bytes"] += 2.0 * (r["in_pixels"] * r["cin"] + r["n_out"] * r["cout"] + r["kvol"] * r["cin"] * r["cout"])
             continue
         a["flops"] += 2.0 * pairs * r["cin"] * r["cout"]
+        a["issued"] += 2.0 * r["kvol"] * r["n_out"] * r["cin"] * r["cout"]   # what the kernels ISSUE: every offset for every output row
         eb = float(r.get("elem_bytes", 4))   # feature storage: fp32, or bf16 on the s16 path (its weight image is bf16 too)
         a["bytes"] += eb * (pairs * r["cin"] + r["n_out"] * r["cout"]) + 8.0 * pairs + eb * r["kvol"] * r["cin"] * r["cout"]
     rulebook = None
@@ -454,6 +455,7 @@ def roofline_pass(step, n_steps=3):
         avg_ms = a["ms"] / a["n"]
         rows.append(dict(kernel=kern, tag=tag, cin=cin, cout=cout, n_out=n_out, tile_rows=a["tile_rows"], launches=a["n"],
                          avg_us=avg_ms * 1e3, total_ms=a["ms"], tflops=a["flops"] / a["n"] / (avg_ms * 1e-3) / 1e12,
+                         issued_tflops=a["issued"] / a["n"] / (avg_ms * 1e-3) / 1e12,
                          gbs=a["bytes"] / a["n"] / (avg_ms * 1e-3) / 1e9))
     rows.sort(key=lambda r: -r["total_ms"])
 
@@ -467,9 +469,18 @@ def roofline_pass(step, n_steps=3):
         sparse_gemm = dict(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_MATRIX_TFLOPS, unit="TFLOP/s",
                            frac=round(tf / PEAK_BF16_MATRIX_TFLOPS, 4), scope="sparse-conv gather implicit GEMM launches with "
                            "Cin, Cout >= 64 (forward + data gradient), algorithmic FLOPs 2 R Cin Cout",
+                           # two effects, separated per shape: occupancy_bound = R / (K N) - the kernels multiply every kernel
+                           # offset for every output row and a missing neighbour reads zero, so `frac` cannot exceed it; matrix_issue_frac =
+                           # the MFMA work actually issued (2 K N Cin Cout) over the peak = frac / occupancy_bound.  Skipping the empty
+                           # (tile, offset) work was built and measured in r06 (rows sorted by neighbour mask, csrc/rulebook_sort.hip): 37 %
+                           # fewer MFMAs, 5-10 % SLOWER - the gathered rows bound these kernels (profiles/r06_sparse_sorted_rows_ab.txt)
+                           occupancy_note="frac <= occupancy_bound = R/(K*N); matrix_issue_frac = frac / occupancy_bound; offset skipping measured slower (r06)",
                            shapes=[dict(cin=r["cin"], cout=r["cout"], rows_out=r["n_out"], pass_=r["tag"], launches_per_step=r["launches"] // n_steps,
                                         avg_us=round(r["avg_us"], 1), tflops=round(r["tflops"], 1),
-                                        frac=round(r["tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4)) for r in sg_rows])
+                                        frac=round(r["tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4),
+                                        occupancy_bound=round(r["tflops"] / r["issued_tflops"], 4) if r.get("issued_tflops") else None,
+                                        matrix_issue_frac=round(r["issued_tflops"] / PEAK_BF16_MATRIX_TFLOPS, 4) if r.get("issued_tflops") else None)
+                                   for r in sg_rows])
     if not rows:
         return None, [], rulebook, sparse_gemm, voxelize, None
 

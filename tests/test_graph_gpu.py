@@ -73,6 +73,17 @@ def _run(graph, steps=6, n_points=12000, batch=2, kind="s2d_student", vary=False
     return losses, final, grads, bn, st
 
 
+_REF_RUNS = {}
+
+
+def _eager_ref(kind="s2d_student"):
+    """the kernel-by-kernel run of the default settings, computed once per detector kind (every parametrisation compares against the same run)"""
+    if kind not in _REF_RUNS:
+        _REF_RUNS[kind] = _run(False, kind=kind)
+        assert _REF_RUNS[kind][4]["replay"] == 0
+    return _REF_RUNS[kind]
+
+
 def _same(a, b, what):
     la, fa, ga, ba, _ = a
     lb, fb, gb, bb, _ = b
@@ -91,8 +102,7 @@ def test_training_run_is_independent_of_the_graph_replay(kind, split, defer):
     """defer = the layer kinds whose weight gradients are captured into a second graph that is replayed on the side stream beside the eager
     sparse backward (side.GRAPH_DEFER, the default); "" = everything in the chain's graph"""
     from sparse2dense_amd import side
-    ref = _run(False, kind=kind)
-    assert ref[4]["replay"] == 0
+    ref = _eager_ref(kind)
     got = _run(True, kind=kind, defer=defer, split=split)
     segs = 2 if (kind == "s2d_student" and split == "1") else 1
     assert got[4]["capture"] == segs and got[4]["replay"] == 4 * segs, got[4]    # 2 eager warm-up calls, then capture + replays
@@ -105,7 +115,7 @@ def test_weight_gradients_as_branches_of_the_backward_graph():
     """side.graph_fork("dense,aux"): inside the capture the weight-gradient launch groups fork onto a second capturing stream and rejoin
     at the end - parallel branches of the replayed backward graph; same kernels, same operands: bit-equal to the kernel-by-kernel run"""
     from sparse2dense_amd import side
-    ref = _run(False)
+    ref = _eager_ref()
     side.stats["forked"] = 0
     got = _run(True, fork="dense,aux", defer="", split="0")
     assert side.stats["forked"] > 20, side.stats
@@ -281,3 +291,118 @@ def test_graph_replay_with_the_batch_norm_collectives_captured_inside_on_one_ran
         collective._DIRECT = False
         _lib.load().s2d_comm_shutdown()
         dist.destroy_process_group()
+
+
+def _eval_between_training_steps(graph):
+    """train 2 steps -> eval x 4 (graph: 2 eager warm-up calls, capture, replay) -> train 1 step -> eval x 2 (replays): the evaluation outputs"""
+    from sparse2dense_amd import dense2d, graphed, hip_ops, side
+    from sparse2dense_amd.data import SyntheticFrames
+    from sparse2dense_amd.solver import build_one_cycle_optimizer, build_one_cycle_scheduler
+    from sparse2dense_amd.train_step import backward_and_step
+    side.enable(False)
+    dense2d.clear_pack_cache()
+    hip_ops.set_sparse_compute_dtype("s16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = _model("s2d_student", dev).train()
+    if graph:
+        model.use_hip_graphs()
+    frames = SyntheticFrames(2, n_points=12000, seed=5, distill=True, device=dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = build_one_cycle_optimizer(model, dict(wd=0.01))
+    sch = build_one_cycle_scheduler(opt, dict(type="one_cycle", lr_max=0.003, moms=[0.95, 0.85], div_factor=10.0, pct_start=0.4), total_steps=100)
+    for k in graphed.stats:
+        graphed.stats[k] = 0
+    outs, it = [], 0
+
+    def train(n):
+        nonlocal it
+        model.train()
+        for _ in range(n):
+            out = model(frames.example(), return_loss=True, return_feature=True)
+            backward_and_step(sum(out[0]["loss"]) + out[4] + out[5], params, opt, sch, it, 35.0)
+            it += 1
+
+    def evaluate(n):
+        model.eval()
+        with torch.no_grad():
+            for _ in range(n):
+                _, F_S_a, F_S_b = model(frames.example(), return_loss=False, return_feature=True)
+                outs.append((F_S_a.float().clone(), F_S_b.float().clone()))
+    try:
+        train(2)
+        evaluate(4)
+        train(1)
+        evaluate(2)
+        torch.cuda.synchronize()
+        st = dict(graphed.stats)
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+    return outs, st
+
+
+def test_forward_only_capture_with_a_warm_pack_cache_survives_optimizer_steps():
+    """an evaluation capture taken with a WARM packed-weight cache baked in the addresses of images that have no in-place refresh
+    (layer-norm / 1x1 matrices); the next optimizer step freed them (the fused Adam writes through raw pointers: the capture's staleness check
+    sees nothing) and the replay read freed memory.  The capture now builds such images inside itself (dense2d.CAPTURE_PACKS)."""
+    ref, st0 = _eval_between_training_steps(False)
+    got, st = _eval_between_training_steps(True)
+    assert st0["replay"] == 0 and st["replay"] >= 4 and st["capture"] >= 2, st
+    for k, ((a1, b1), (a0, b0)) in enumerate(zip(got, ref)):
+        assert torch.equal(a1, a0) and torch.equal(b1, b0), f"evaluation call {k} differs from the kernel-by-kernel run"
+    assert not torch.equal(ref[3][0], ref[5][0])   # the training step in between did move the weights
+
+
+def _two_backwards(graph):
+    from sparse2dense_amd import dense2d, graphed, hip_ops, side
+    from sparse2dense_amd.data import SyntheticFrames
+    side.enable(False)
+    dense2d.clear_pack_cache()
+    hip_ops.set_sparse_compute_dtype("s16")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    model = _model("s2d_student", dev).train()
+    if graph:
+        model.use_hip_graphs()
+    sets = [SyntheticFrames(2, n_points=12000, seed=5 + 10 * k, distill=True, device=dev) for k in range(2)]
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def loss_of(k):
+        out = model(sets[k].example(), return_loss=True, return_feature=True)
+        return sum(out[0]["loss"]) + out[4] + out[5]
+    try:
+        for _ in range(3):   # warm-up calls + capture, one backward each
+            for p in params:
+                p.grad = None
+            loss_of(0).backward()
+        for p in params:
+            p.grad = None
+        loss_of(0).backward()
+        loss_of(1).backward()          # second micro-batch: accumulates onto the first
+        side.join()
+        torch.cuda.synchronize()
+        grads = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        for p in params:               # ... and the zero_grad(set_to_none=False) pattern: .grad stays bound and is zeroed in place
+            if p.grad is not None:
+                p.grad.zero_()
+        loss_of(1).backward()
+        side.join()
+        torch.cuda.synchronize()
+        grads2 = [None if p.grad is None else p.grad.detach().clone() for p in params]
+    finally:
+        hip_ops.set_sparse_compute_dtype("f32")
+        dense2d.clear_pack_cache()
+    return grads, grads2
+
+
+def test_gradient_accumulation_over_two_backward_passes_matches_the_eager_run():
+    """the first backward binds p.grad to the capture's static buffer; a second backward replayed into that very buffer and then
+    added it to itself (2 x the second gradient, the first lost).  Now: the bound values are copied out before the replay."""
+    ref, ref2 = _two_backwards(False)
+    got, got2 = _two_backwards(True)
+    for pair in ((got, ref), (got2, ref2)):
+        for g, r in zip(*pair):
+            assert (g is None) == (r is None)
+            if g is not None:   # eager accumulates in place (a + b), the graph path out of place (a + b): the same fp32 sum
+                assert torch.equal(g, r)
