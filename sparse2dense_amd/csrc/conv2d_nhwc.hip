@@ -552,6 +552,191 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
                               (int)(m0 / BM) + (UP ? (int)(blockIdx.z * ((m_total + BM - 1) / BM)) : 0), H, W, up_p, up_q);
 }
 
+// ---- warp-specialised form of the kernel above (r06 experiment) ------------------------------------------------------
+// Same tiles, same LDS images, same 3-slot ring of 32-deep sub-steps, same MFMA order (bit-identical results) - but the staging has a wave of
+// its own: a workgroup is FIVE (or six: NP = 2) waves, waves 0-3 (consumers: 2 x 2 tiles) only read fragments and issue MFMAs, wave 4 (and 5) issues every
+// LDS-DMA piece of the workgroup (A: BM * 4 / 64 pieces, B: B_HALF / 1024 pieces per sub-step) and nothing else.  The consumers' instruction
+// stream then holds no address arithmetic, no VMEM issue and no vmcnt wait: what r04's ablation showed "adding up instead of overlapping"
+// (MFMAs only 32 us, + fragment reads 41, staging only 42, all together 56-59) sits in different waves.  Price on gfx950: registers are
+// allocated per KERNEL, so the producer wave holds a consumer's ~130 VGPRs as well, and 5-wave workgroups fit two per CU where the 4-wave
+// form fits three.  Ring protocol per iteration t (slot of sub-step k = k % 3):
+//   producer:  wait vmcnt(pieces of one sub-step): sub-step t+1 has landed, t+2 in flight;  barrier;  stage t+3 into the slot of t
+//   consumer:  wait lgkmcnt(0): own fragment reads of t+1 are done...;                        barrier;  read fragments of t+1; MFMAs of t
+// Measured: see tools/conv_bm_bench.py (S2D_CONV_WS=1) and profiles/r06_conv3x3_warp_specialised_ab.txt.
+template <int BN, int MI, int NP>   // NP producer waves (1 or 2): the pieces of a sub-step are dealt round-robin to them
+__global__ __launch_bounds__(256 + 64 * NP, 2) void conv3x3_k32ws_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wpack,
+                                                                        const float *__restrict__ bias, const __bf16 *__restrict__ zero_page,
+                                                                        int n_img, int H, int W, int cin, int cout, int pad, int stride,
+                                                                        __bf16 *__restrict__ y, float *__restrict__ stats_partial) {
+    constexpr int KS = 3;
+    constexpr int NT = BN / 32;
+    constexpr int BM = 32 * MI;
+    constexpr int A_BYTES = BM * 32 * 2;
+    constexpr int B_HALF = 32 * BN * 2;
+    constexpr int A_PIECES = BM * 4 / 64;        // 1 KiB LDS-DMA pieces (64 lanes x 16 B) of the A tile of a sub-step
+    constexpr int B_PIECES = B_HALF / 1024;
+    static_assert(A_PIECES % NP == 0 && B_PIECES % NP == 0, "equal shares per producer wave");
+    constexpr int LPS = (A_PIECES + B_PIECES) / NP;   // one producer wave's loads per sub-step (16 / NP at BN = 128, MI = 4)
+    static_assert(2 * LPS <= 63, "vmcnt is six bits");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto abuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF); };
+    auto bbuf = [&](int b) -> char * { return smem + b * (A_BYTES + B_HALF) + A_BYTES; };
+
+    const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+    const int64_t m_total = (int64_t)n_img * Ho * Wo;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t m0 = (int64_t)xcd_tile(blockIdx.x, gridDim.x) * BM;
+    if (m0 >= m_total) return;
+    const int blk_n = blockIdx.y;
+    const int chunks = cin / 64;
+    const int T = 2 * KS * KS * chunks;   // sub-steps: (tap, 64-channel chunk, half)
+
+    if (wid >= 4) {
+        // ---------------- producer(s) ----------------
+        const int pw = wid - 4;   // this producer's pieces: u = pw, pw + NP, ...
+        const __bf16 *a_base[A_PIECES / NP];
+        unsigned a_mask[A_PIECES / NP];
+#pragma unroll
+        for (int uu = 0; uu < A_PIECES / NP; ++uu) {
+            const int u = pw + NP * uu;
+            const int id = lane + 64 * u;
+            const int row = id >> 2;
+            const int part = (id & 3) ^ ((row >> 1) & 3);
+            const int64_t m = m0 + row;
+            const bool ok = m < m_total;
+            const int64_t mm = ok ? m : 0;
+            const int ix0 = (int)(mm % Wo) * stride - pad;
+            const int iy0 = (int)((mm / Wo) % Ho) * stride - pad;
+            const int img = (int)(mm / ((int64_t)Wo * Ho));
+            a_base[uu] = x + (((int64_t)img * H + iy0) * W + ix0) * cin + part * 8;
+            unsigned mask = 0;
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap)
+                if (ok && (unsigned)(iy0 + tap / KS) < (unsigned)H && (unsigned)(ix0 + tap % KS) < (unsigned)W) mask |= 1u << tap;
+            a_mask[uu] = mask;
+        }
+        const int64_t wstep = (int64_t)(cout / BN) * (2 * B_HALF);
+        const char *st_w = reinterpret_cast<const char *>(wpack) + (int64_t)blk_n * (2 * B_HALF);
+        int st_tap = 0, st_kx = 0, st_coff = 0, st_off = 0, st_h = 0;
+        auto stage_next = [&](int buf) {
+#pragma unroll
+            for (int uu = 0; uu < A_PIECES / NP; ++uu) {
+                const int u = pw + NP * uu;
+                const bool ok = (a_mask[uu] >> st_tap) & 1u;
+                const __bf16 *src = ok ? a_base[uu] + (st_off + st_coff) : zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(abuf(buf) + (size_t)u * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int uu = 0; uu < B_PIECES / NP; ++uu) {
+                const int u = pw + NP * uu;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st_w + u * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(bbuf(buf) + u * 1024), 16, 0, 0);
+            }
+            st_w += st_h ? wstep - B_HALF : (int64_t)B_HALF;
+            st_h ^= 1;
+            st_coff += 32;
+            if (st_coff == cin) {
+                st_coff = 0;
+                ++st_tap;
+                ++st_kx;
+                st_off += cin;
+                if (st_kx == KS) {
+                    st_kx = 0;
+                    st_off += (W - KS) * cin;
+                }
+            }
+        };
+        int st = 0;
+        stage_next(0);
+        stage_next(1);
+        stage_next(2);
+        wait_vmcnt<2 * LPS>();             // sub-step 0 landed
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t + 3 < T; ++t) {  // iterations 0 .. T-4: the last stages sub-step T-1
+            wait_vmcnt<LPS>();
+            __builtin_amdgcn_s_barrier();
+            stage_next(st);
+            st = st == 2 ? 0 : st + 1;
+        }
+        wait_vmcnt<LPS>();                 // T-2 landed, T-1 in flight
+        __builtin_amdgcn_s_barrier();
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (stats_partial) {               // the statistics fold of conv_epilogue: two workgroup barriers
+            __syncthreads();
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- consumers ----------------
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    f32x4c acc[MI][NT];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4c{0.f, 0.f, 0.f, 0.f};
+    const int a_rd = ((16 * MI * wm + r) * 4 + (q ^ ((r >> 1) & 3))) * 16;
+    const int b_rd = (wn * NT * 64 + lane) * 16;
+    auto read_frags = [&](int slot, bf16x8c (&a)[MI], bf16x8c (&b)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8c *>(abuf(slot) + a_rd + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8c *>(bbuf(slot) + b_rd + j * 1024);
+    };
+    auto mfmas = [&](const bf16x8c (&a)[MI], const bf16x8c (&b)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): own fragment reads done (no vector-memory loads in this wave)
+        __builtin_amdgcn_s_barrier();
+    };
+    int rd = 1;
+    auto rot = [&]() { rd = rd == 2 ? 0 : rd + 1; };
+    bf16x8c fa[2][MI], fb[2][NT];
+    __builtin_amdgcn_s_barrier();            // sub-step 0 landed (the producer waited for it)
+    read_frags(0, fa[0], fb[0]);
+    int t = 0;
+    for (; t + 4 < T; t += 2) {
+        sync();
+        read_frags(rd, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rot();
+        sync();
+        read_frags(rd, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rot();
+    }
+    sync();                                  // t = T-4
+    read_frags(rd, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    rot();
+    sync();                                  // t = T-3
+    read_frags(rd, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    rot();
+    sync();                                  // t = T-2: everything landed
+    read_frags(rd, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(fa[0], fb[0]);
+    mfmas(fa[1], fb[1]);
+    conv_epilogue<BN, MI, false>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial, (int)(m0 / BM), H, W, 0, 0);
+}
+
 // ---- pad = 1 variant with the A tile shared by the three kx taps ------------------------------------------------------
 // With padding 1 the input pixel of output pixel m at tap (ky, kx) is the ky-row centre
 // pixel of output pixel m + kx - 1, so one [130 px][64 ch] tile per (ky, channel chunk) serves all three kx taps: the tap
@@ -899,7 +1084,24 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<BN_, MI_>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn), blk,         \
                        3 * (size_t)(32 * MI_ * 64 + 64 * BN_), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,      \
                        (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial)
-        if (bn == 128) {
+        static const int ws_env = conv_env_int("S2D_CONV_WS");   // r06 experiment: the warp-specialised form, 1 or 2 producer waves (stride 1, 128-wide blocks)
+        if (bn == 128 && (ws_env == 1 || ws_env == 2) && stride == 1) {
+            const int rows = conv_k32_rows(m, cout / bn);
+#define S2D_CONV_K32WS(MI_, NP_)                                                                                                      \
+    hipLaunchKernelGGL((conv3x3_k32ws_nhwc_bf16_kernel<128, MI_, NP_>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn),             \
+                       dim3(256 + 64 * NP_), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight, \
+                       bias, (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial)
+            if (ws_env == 2) {
+                if (rows == 128) S2D_CONV_K32WS(4, 2);
+                else if (rows == 96) S2D_CONV_K32WS(3, 2);
+                else S2D_CONV_K32WS(2, 2);
+            } else {
+                if (rows == 128) S2D_CONV_K32WS(4, 1);
+                else if (rows == 96) S2D_CONV_K32WS(3, 1);
+                else S2D_CONV_K32WS(2, 1);
+            }
+#undef S2D_CONV_K32WS
+        } else if (bn == 128) {
             const int rows = conv_k32_rows(m, cout / bn);
             if (rows == 128) S2D_CONV_K32(128, 4);
             else if (rows == 96) S2D_CONV_K32(128, 3);

@@ -85,7 +85,8 @@ def _copy_all(dst, src):
 
 
 class _Capture:
-    __slots__ = ("fwd", "bwd", "bwd2", "keep", "s_in", "s_out", "g_idx", "s_gout", "s_gin", "s_gparams", "diff_idx", "params", "pstate", "pool", "stream")
+    __slots__ = ("fwd", "bwd", "bwd2", "keep", "s_in", "s_out", "g_idx", "s_gout", "s_gin", "s_gparams", "diff_idx", "params", "pstate", "pool", "stream",
+                 "bound")
 
 
 class _Replay(torch.autograd.Function):
@@ -141,6 +142,7 @@ class _Replay(torch.autograd.Function):
             if accumulate:
                 side.join(dev)
                 joined = True
+        cap.bound = True   # static buffers are (about to be) somebody's .grad: see GraphedSegment.__call__
         for p, g in zip(cap.params, cap.s_gparams):
             if g is None:
                 continue
@@ -232,6 +234,15 @@ class GraphedSegment:
             self._caps[key] = cap
             stats["capture"] += 1
         stats["replay"] += 1
+        if getattr(cap, "bound", False):
+            # The previous backward bound static gradient buffers as `.grad`.  A training step clears them before the next forward; when it
+            # did not (gradient accumulation over micro-batches, zero_grad(set_to_none=False)) the values must leave the graph's memory pool
+            # BEFORE this forward replays: forward and backward graph share the pool, a block that holds a gradient in the backward graph
+            # may be a temporary of the forward graph (r06: a second backward accumulated onto garbage - tests/test_graph_gpu.py).
+            for p, g in zip(cap.params, cap.s_gparams):
+                if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                    p.grad = p.grad.clone()
+            cap.bound = False
         with torch.no_grad():   # ONE multi-tensor copy kernel for all inputs (a hipMemcpyAsync per tensor costs the host ~60 us each under load)
             pairs = [(s, t) for s, t in zip(cap.s_in, inputs) if s.data_ptr() != t.data_ptr()]
             if pairs:
@@ -360,6 +371,7 @@ class GraphedSegment:
                                 cap.s_gparams[slot[id(prm)]] = g
                     cap.keep = items
             cap.s_out = tuple(o.detach() if torch.is_tensor(o) else o for o in outs)
+            cap.bound = False
         finally:
             if gc_was_on:
                 gc.enable()

@@ -327,8 +327,8 @@ def _eval_between_training_steps(graph):
         model.eval()
         with torch.no_grad():
             for _ in range(n):
-                _, F_S_a, F_S_b = model(frames.example(), return_loss=False, return_feature=True)
-                outs.append((F_S_a.float().clone(), F_S_b.float().clone()))
+                out = model(frames.example(), return_loss=True, return_feature=True)   # eval mode: no PCR branch, forward-only segment
+                outs.append((out[1].float().clone(), out[2].float().clone()))
     try:
         train(2)
         evaluate(4)
@@ -371,11 +371,19 @@ def _two_backwards(graph):
     def loss_of(k):
         out = model(sets[k].example(), return_loss=True, return_feature=True)
         return sum(out[0]["loss"]) + out[4] + out[5]
+    singles = []
     try:
         for _ in range(3):   # warm-up calls + capture, one backward each
             for p in params:
                 p.grad = None
             loss_of(0).backward()
+        for k in (0, 1):     # each micro-batch on its own (diagnostics: which sum did a wrong accumulation produce?)
+            for p in params:
+                p.grad = None
+            loss_of(k).backward()
+            side.join()
+            torch.cuda.synchronize()
+            singles.append([None if p.grad is None else p.grad.detach().clone() for p in params])
         for p in params:
             p.grad = None
         loss_of(0).backward()
@@ -393,16 +401,21 @@ def _two_backwards(graph):
     finally:
         hip_ops.set_sparse_compute_dtype("f32")
         dense2d.clear_pack_cache()
-    return grads, grads2
+    return grads, grads2, singles, [n for n, p in model.named_parameters() if p.requires_grad]
 
 
 def test_gradient_accumulation_over_two_backward_passes_matches_the_eager_run():
     """the first backward binds p.grad to the capture's static buffer; a second backward replayed into that very buffer and then
     added it to itself (2 x the second gradient, the first lost).  Now: the bound values are copied out before the replay."""
-    ref, ref2 = _two_backwards(False)
-    got, got2 = _two_backwards(True)
-    for pair in ((got, ref), (got2, ref2)):
-        for g, r in zip(*pair):
-            assert (g is None) == (r is None)
-            if g is not None:   # eager accumulates in place (a + b), the graph path out of place (a + b): the same fp32 sum
-                assert torch.equal(g, r)
+    ref, ref2, ref_single, names = _two_backwards(False)
+    got, got2, got_single, _ = _two_backwards(True)
+    for k in (0, 1):   # the single passes agree (what the other graph tests hold) ...
+        for n, g, r in zip(names, got_single[k], ref_single[k]):
+            assert (g is None) == (r is None) and (g is None or torch.equal(g, r)), ("single backward", k, n)
+    for what, pair in (("two backwards", (got, ref)), ("zeroed in place + one backward", (got2, ref2))):
+        for i, (n, g, r) in enumerate(zip(names, *pair)):
+            assert (g is None) == (r is None), n
+            if g is not None and not torch.equal(g, r):   # eager accumulates in place (a += b), the graph path out of place (a + b): the same fp32 sum
+                rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+                s0, s1 = ref_single[0][i], ref_single[1][i]
+                raise AssertionError((what, n, "vs eager sum", rel(g, r), "vs 2 x second", rel(g, 2 * s1), "vs second", rel(g, s1), "vs first", rel(g, s0)))

@@ -1,5 +1,6 @@
 """Forward time of the dense 3x3 tile kernel per tile height (S2D_CONV_BM = 128 / 96 / 64 forces it; unset = the library's choice) at the
-benchmark's layer shapes.   S2D_CONV_BM=96 python tools/conv_bm_bench.py"""
+benchmark's layer shapes.   S2D_CONV_BM=96 python tools/conv_bm_bench.py
+S2D_CONV_WS=1: the warp-specialised form (r06 experiment, csrc/conv2d_nhwc.hip conv3x3_k32ws_nhwc_bf16_kernel); the checksum column must not move."""
 import os
 import sys
 
@@ -27,8 +28,10 @@ def main():
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / n * 1e3
+        out = D.conv3x3_nhwc(x, packed, None, cin, cout, 1)
+        chk = f"{float(out.double().sum()):.6e}/{float(out.double().abs().max()):.4e}"
         fl = 2.0 * 4 * h * h * 9 * cin * cout
-        print(f"BM={os.environ.get('S2D_CONV_BM', 'auto'):>4s} {cin:3d}->{cout:3d} @4x{h}^2 rows/tile {lib.s2d_conv2d3x3_tile_rows(4, h, h, cin, cout, 1, 1)}: {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+        print(f"BM={os.environ.get('S2D_CONV_BM', 'auto'):>4s} {cin:3d}->{cout:3d} @4x{h}^2 rows/tile {lib.s2d_conv2d3x3_tile_rows(4, h, h, cin, cout, 1, 1)}: {us:7.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  ws={os.environ.get('S2D_CONV_WS', '0')} checksum {chk}", flush=True)
 
 
 if __name__ == "__main__":
