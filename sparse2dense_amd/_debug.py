@@ -1,4 +1,4 @@
-"""Debugging stand-ins used by tools/side_stress.py (rule 36) - nothing here runs unless its environment switch is set.
+"""Debugging stand-ins used by tools/side_stress.py (HISTORY.md section 7 (f), rule 36) - nothing here runs unless its environment switch is set.
 
 S2D_DEBUG_CT_WGRAD=<mode> replaces the weight-gradient launch of the PCR head's narrow up-sampler (the 16 -> 3 ConvTranspose3d with the
 input-norm fold, dense3d._ConvT3dFn.backward) by:

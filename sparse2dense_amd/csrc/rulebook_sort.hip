@@ -6,7 +6,7 @@
 // slabs pulled through L2 and of the gather instructions belong to (tile, offset) pairs with nothing in them.  In voxel order the
 // OR of 16 rows' masks is ~0.9 of 27 - nothing to skip.  Sorted by the 27-bit mask, rows with the same neighbourhood SHAPE (ground
 // plane, wall, isolated column ...) sit next to each other: per 16-row tile the union drops to 0.60-0.64 of 27, per 192-256-row
-// workgroup of a 4-frame batch to ~0.66-0.74 (tools figure: DESIGN.md section 5).
+// workgroup of a 4-frame batch to ~0.66-0.74 (tools/mask_sort_study.py).
 //
 // What is built (once per rulebook, reused by every layer and both passes of the stage):
 //   pmask[j]      u32   neighbour mask of the j-th row in sorted order (bit k: offset k has a neighbour); the order is ascending mask

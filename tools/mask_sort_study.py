@@ -1,6 +1,6 @@
 """Host study (numpy, no GPU): how many (workgroup, K-step) and (16-row MFMA tile, K-step) units of the SubM gather implicit GEMM are
 active when the output rows are processed in natural order vs sorted by their 27-bit neighbour mask (globally or inside chunks that keep
-an XCD-local working set), on the 4-frame bench scene.  Numbers quoted in DESIGN.md section 5 ("sparse_gemm")."""
+an XCD-local working set), on the 4-frame bench scene.  Numbers quoted in HISTORY.md section 5 ("sparse_gemm") and DESIGN.md section 8."""
 import numpy as np, sys, time
 sys.path.insert(0, '/root/repo')
 from sparse2dense_amd import scene

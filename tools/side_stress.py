@@ -4,7 +4,7 @@ every parameter gradient compared BIT FOR BIT with the single-stream run; prints
 r04 findings: `spconv_wgrad_s16_coop128` (shared pair ring initialised without a barrier: one run in ~8 had one conv4 weight gradient off
 in the last digits; fixed, 0 of 36 afterwards); S2D_PCR_STREAM=1: one run in ~25 with differing backbone gradients (left opt-in); and at the
 benchmark's size (`... 3 0:0,1:0 150000 4`) the single-stream run "differed" from itself: NaN gradients - the wrong `spconv_rg_kernel<128,128,2,8>` (DESIGN rule 31).
-r05 findings (rule 36): S2D_PCR_STREAM=1 (`sparse:1`): 0 mismatches in 140 runs since the dense kernels' accumulators are cleared by a
+r05 findings (HISTORY.md section 7 (f), rule 36): S2D_PCR_STREAM=1 (`sparse:1`): 0 mismatches in 140 runs since the dense kernels' accumulators are cleared by a
 kernel instead of hipMemsetAsync (rule 32).  Mode `pcr` (the PCR head's weight gradients on the eager side stream): 68 of 70 runs differ; root cause found with the
 switches below - not a data hazard but packed-FP32 code of the NEXT level's statistics kernel (`pcr_level_bwd_dense_kernel<32,16,2>`, 544 v_pk_fma_f32) whose high lanes
 become timing-dependent while the 16 -> 3 up-sampler's MFMA weight-gradient kernel runs beside it:
