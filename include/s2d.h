@@ -750,6 +750,12 @@ int s2d_bev_iou_f32(const float *boxes_a, int na, const float *boxes_b, int nb, 
 size_t s2d_nms_workspace_bytes(int n);
 int s2d_nms_rotated_bev(const float *boxes_sorted, int n, float iou_threshold, int max_keep, int64_t *keep,
                         int32_t *n_keep, void *ws, size_t ws_bytes, s2d_stream_t stream);
+/* CenterPoint's circle NMS (det3d/core/utils/circle_nms_jit.py:4-31, called from bbox_heads/center_head.py:476-479,499-507): greedy
+ * suppression by centre distance - a later box is removed when (xi - xj)^2 + (yi - yj)^2 <= thresh (the reference compares the squared
+ * distance with test_cfg.min_radius[task] as is).  xy_sorted: [n][2] centres sorted by descending score; same outputs and workspace
+ * (s2d_nms_workspace_bytes) as s2d_nms_rotated_bev. */
+int s2d_nms_circle(const float *xy_sorted, int n, float thresh, int max_keep, int64_t *keep, int32_t *n_keep, void *ws, size_t ws_bytes,
+                   s2d_stream_t stream);
 
 /*
  * CenterPoint training targets on the device = AssignLabel.__call__ (det3d/datasets/pipelines/preprocess.py:489-653, one-task

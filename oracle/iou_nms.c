@@ -91,3 +91,23 @@ int s2d_oracle_nms(const float *boxes, int n, float thresh, int max_keep, int64_
     free(dead);
     return cnt;
 }
+
+/* CenterPoint's circle NMS (/root/reference/det3d/core/utils/circle_nms_jit.py:4-31): centres already sorted by descending score; a later
+ * centre j is suppressed by a kept centre i when (xi - xj)^2 + (yi - yj)^2 <= thresh (squared distance against the threshold as is).
+ * Returns the number kept (the caller truncates to post_max_size, center_head.py:503). */
+int s2d_oracle_circle_nms(const float *xy, int n, float thresh, int64_t *keep) {
+    unsigned char *dead = (unsigned char *)calloc(n > 0 ? n : 1, 1);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[cnt++] = i;
+        for (int j = i + 1; j < n; ++j) {
+            if (dead[j]) continue;
+            const float dx = xy[2 * i] - xy[2 * j], dy = xy[2 * i + 1] - xy[2 * j + 1];
+            const float d0 = dx * dx, d1 = dy * dy;   /* two roundings, then the sum: no fused multiply-add */
+            if (d0 + d1 <= thresh) dead[j] = 1;
+        }
+    }
+    free(dead);
+    return cnt;
+}

@@ -14,6 +14,8 @@ def _lib():
     if not hasattr(lib, "_iou_ready"):
         lib.s2d_oracle_bev_iou_matrix.restype = None
         lib.s2d_oracle_bev_iou_matrix.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.s2d_oracle_circle_nms.restype = ctypes.c_int
+        lib.s2d_oracle_circle_nms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
         lib.s2d_oracle_nms.restype = ctypes.c_int
         lib.s2d_oracle_nms.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
         lib._iou_ready = True
@@ -37,5 +39,16 @@ def rotate_nms(boxes7, scores, thresh, pre_maxsize=None, post_max_size=None):
     b = np.ascontiguousarray(boxes7[order])
     keep = np.zeros((max(len(order), 1),), np.int64)
     n = _lib().s2d_oracle_nms(b.ctypes.data, len(order), float(thresh), len(order), keep.ctypes.data) if len(order) else 0
+    sel = order[keep[:n]]
+    return sel[:post_max_size] if post_max_size is not None else sel
+
+
+def circle_nms(centers_xy, scores, min_radius, post_max_size=83):
+    """indices (into the unsorted input) kept by CenterPoint's circle NMS (center_head.py:499-507, circle_nms_jit.py:4-31)"""
+    xy = np.ascontiguousarray(centers_xy, np.float32)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    b = np.ascontiguousarray(xy[order])
+    keep = np.zeros((max(len(order), 1),), np.int64)
+    n = _lib().s2d_oracle_circle_nms(b.ctypes.data, len(order), float(min_radius), keep.ctypes.data) if len(order) else 0
     sel = order[keep[:n]]
     return sel[:post_max_size] if post_max_size is not None else sel

@@ -228,6 +228,8 @@ SIGNATURES = {
     "s2d_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "s2d_nms_rotated_bev": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_nms_circle": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_assign_label": (ctypes.c_int, [c_f32p, c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_float * 2, ctypes.c_float * 2] + [ctypes.c_int] * 5 +
                          [ctypes.c_double, ctypes.c_int] + [ctypes.c_void_p] * 7),
     "s2d_adam_max_tensors": (ctypes.c_int, []),

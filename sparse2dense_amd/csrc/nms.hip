@@ -128,6 +128,36 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     mask[(int64_t)ri * col_blocks + cb] = bits;
 }
 
+// centre-distance suppression bits (CenterPoint's circle NMS, det3d/core/utils/circle_nms_jit.py:4-31): bit j = (xi - xj)^2 + (yi - yj)^2 <= thresh
+// (the reference compares the SQUARED distance with `min_radius` as is), j > i only
+__global__ __launch_bounds__(64) void circle_mask_kernel(const float *__restrict__ xy, int n, float thresh, unsigned long long *__restrict__ mask) {
+    __shared__ float col[64 * 2];
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    const int col_blocks = (n + 63) / 64;
+    const int t = threadIdx.x;
+    if (cb < rb) {
+        if (rb * 64 + t < n) mask[(int64_t)(rb * 64 + t) * col_blocks + cb] = 0ull;
+        return;
+    }
+    const int cj = cb * 64 + t;
+    if (cj < n) {
+        col[t * 2] = xy[(int64_t)cj * 2];
+        col[t * 2 + 1] = xy[(int64_t)cj * 2 + 1];
+    }
+    __syncthreads();
+    const int ri = rb * 64 + t;
+    if (ri >= n) return;
+    const float x = xy[(int64_t)ri * 2], y = xy[(int64_t)ri * 2 + 1];
+    const int ncol = min(64, n - cb * 64);
+    unsigned long long bits = 0ull;
+    for (int j = (rb == cb ? t + 1 : 0); j < ncol; ++j) {
+        const float dx = x - col[j * 2], dy = y - col[j * 2 + 1];
+        // the reference's expression, evaluated without FMA contraction (the library is built with -ffp-contract=off): (dx)**2 + (dy)**2
+        if (dx * dx + dy * dy <= thresh) bits |= 1ull << j;
+    }
+    mask[(int64_t)ri * col_blocks + cb] = bits;
+}
+
 // greedy walk over the bit matrix in one workgroup: `removed` lives in LDS; box i is kept iff its bit is clear when reached
 __global__ __launch_bounds__(256) void nms_select_kernel(const unsigned long long *__restrict__ mask, int n, int max_keep, int64_t *__restrict__ keep,
                                                          int32_t *__restrict__ n_keep) {
@@ -186,6 +216,28 @@ extern "C" int s2d_nms_rotated_bev(const float *boxes_sorted, int n, float iou_t
     const int cb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)ws;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, st, boxes_sorted, n, iou_threshold, mask);
+    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(256), (size_t)cb * sizeof(unsigned long long), st, mask, n, max_keep, keep, n_keep);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* CenterPoint's circle NMS (see include/s2d.h) */
+extern "C" int s2d_nms_circle(const float *xy_sorted, int n, float thresh, int max_keep, int64_t *keep, int32_t *n_keep, void *ws, size_t ws_bytes,
+                              s2d_stream_t stream) {
+    S2D_CHECK_ARG(n >= 0 && n <= 65536 && max_keep >= 0 && keep && n_keep, "nms_circle: bad argument (n <= 65536)");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0 || max_keep == 0) {
+        S2D_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), st));
+        return S2D_OK;
+    }
+    S2D_CHECK_ARG(xy_sorted, "nms_circle: null centres");
+    if (!ws || ws_bytes < s2d_nms_workspace_bytes(n)) {
+        set_error("nms_circle: workspace too small");
+        return S2D_ERR_WORKSPACE;
+    }
+    const int cb = (n + 63) / 64;
+    unsigned long long *mask = (unsigned long long *)ws;
+    hipLaunchKernelGGL(circle_mask_kernel, dim3(cb, cb), dim3(64), 0, st, xy_sorted, n, thresh, mask);
     hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(256), (size_t)cb * sizeof(unsigned long long), st, mask, n, max_keep, keep, n_keep);
     S2D_LAUNCH_CHECK();
     return S2D_OK;

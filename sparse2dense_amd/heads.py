@@ -690,12 +690,17 @@ class CenterHead(nn.Module):
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
-        """Decode + score / range filter + rotated NMS (center_head.py:293-448,452-495).
-        Returns one dict per sample: box3d_lidar [n, 7 or 9], scores [n], label_preds [n], metadata.  Not supported (not used by
-        the Waymo configs): double-flip test-time augmentation, circular NMS, per-class NMS."""
+        """Decode + score / range filter + NMS (center_head.py:293-448,452-507).
+        Returns one dict per sample: box3d_lidar [n, 7 or 9], scores [n], label_preds [n], metadata.
+        test_cfg.double_flip (r06): the batch holds every sample four times - original, y-flipped, x-flipped, both (center_head.py:318-333) -
+        and the four decoded maps are flipped back and averaged (hm, height, dim, reg with the flipped offsets mirrored, the rotation's
+        sin / cos and the velocities with the flipped components negated) before the boxes are built (center_head.py:343-381,402-412).
+        test_cfg.circular_nms (r06): centre-distance NMS with min_radius[task] instead of the rotated-IoU NMS (center_head.py:476-479).
+        per_class_nms: the reference's branch is `pass` (center_head.py:417-418: no result is produced) - not supported."""
         get = (lambda k, d=None: test_cfg.get(k, d)) if hasattr(test_cfg, "get") else (lambda k, d=None: getattr(test_cfg, k, d))
-        if get("double_flip", False) or get("circular_nms", False) or get("per_class_nms", False):
-            raise NotImplementedError("CenterHead.predict: double_flip / circular_nms / per_class_nms are not on this path")
+        if get("per_class_nms", False):
+            raise NotImplementedError("CenterHead.predict: per_class_nms produces no result in the reference either (center_head.py:417-418)")
+        double_flip, circular = bool(get("double_flip", False)), bool(get("circular_nms", False))
         nms_cfg = get("nms")
         nget = (lambda k: nms_cfg[k]) if isinstance(nms_cfg, dict) else (lambda k: getattr(nms_cfg, k))
         hm0 = preds_dicts[0]["hm"]
@@ -703,24 +708,57 @@ class CenterHead(nn.Module):
         pcr = torch.tensor(pcr, dtype=torch.float32, device=hm0.device) if len(pcr) > 0 else None
         factor, vs, pc0 = get("out_size_factor"), get("voxel_size"), get("pc_range")
         rets = []
-        for preds in preds_dicts:
+        for task_id, preds in enumerate(preds_dicts):
             p = {k: v.float().permute(0, 2, 3, 1).contiguous() for k, v in preds.items()}   # N C H W -> N H W C
             batch, h, w, num_cls = p["hm"].shape
-            hm = torch.sigmoid(p["hm"]).reshape(batch, h * w, num_cls)
-            dim = torch.exp(p["dim"]).reshape(batch, h * w, 3)
-            rot = torch.atan2(p["rot"][..., 0:1], p["rot"][..., 1:2]).reshape(batch, h * w, 1)
-            reg = p["reg"].reshape(batch, h * w, 2)
-            hei = p["height"].reshape(batch, h * w, 1)
+            if double_flip:
+                assert batch % 4 == 0, batch
+                batch //= 4
+                for k in p:   # back to the unflipped frame: [:, 1] was flipped along H (y = -y), [:, 2] along W (x = -x), [:, 3] both
+                    v = p[k].reshape(batch, 4, h, w, -1)
+                    p[k] = torch.stack([v[:, 0], torch.flip(v[:, 1], dims=[1]), torch.flip(v[:, 2], dims=[2]), torch.flip(v[:, 3], dims=[1, 2])], 1)
+            hm, dim = torch.sigmoid(p["hm"]), torch.exp(p["dim"])
+            rots, rotc = p["rot"][..., 0:1], p["rot"][..., 1:2]
+            reg, hei = p["reg"], p["height"]
+            vel = p.get("vel")
+            if double_flip:
+                hm, hei, dim = hm.mean(1), hei.mean(1), dim.mean(1)
+                reg = reg.clone()
+                reg[:, 1, ..., 1] = 1 - reg[:, 1, ..., 1]      # y = -y: the offset inside the cell mirrors
+                reg[:, 2, ..., 0] = 1 - reg[:, 2, ..., 0]
+                reg[:, 3, ..., 0] = 1 - reg[:, 3, ..., 0]
+                reg[:, 3, ..., 1] = 1 - reg[:, 3, ..., 1]
+                reg = reg.mean(1)
+                rots, rotc = rots.clone(), rotc.clone()
+                rotc[:, 1] *= -1                                 # y-flip: theta -> pi - theta
+                rots[:, 2] *= -1                                 # x-flip: theta -> 2 pi - theta
+                rots[:, 3] *= -1
+                rotc[:, 3] *= -1
+                rots, rotc = rots.mean(1), rotc.mean(1)
+                if vel is not None:
+                    vel = vel.clone()
+                    vel[:, 1, ..., 1] *= -1
+                    vel[:, 2, ..., 0] *= -1
+                    vel[:, 3] *= -1
+                    vel = vel.mean(1)
+            hm = hm.reshape(batch, h * w, num_cls)
+            dim = dim.reshape(batch, h * w, 3)
+            rot = torch.atan2(rots, rotc).reshape(batch, h * w, 1)
+            reg = reg.reshape(batch, h * w, 2)
+            hei = hei.reshape(batch, h * w, 1)
             ys, xs = torch.meshgrid(torch.arange(0, h, device=hm.device), torch.arange(0, w, device=hm.device), indexing="ij")
             xs = xs.reshape(1, -1, 1).to(hm) + reg[:, :, 0:1]
             ys = ys.reshape(1, -1, 1).to(hm) + reg[:, :, 1:2]
             xs = xs * factor * vs[0] + pc0[0]
             ys = ys * factor * vs[1] + pc0[1]
-            parts = [xs, ys, hei, dim] + ([p["vel"].reshape(batch, h * w, 2)] if "vel" in p else []) + [rot]
+            parts = [xs, ys, hei, dim] + ([vel.reshape(batch, h * w, 2)] if vel is not None else []) + [rot]
             boxes = torch.cat(parts, dim=2)
+            radius = get("min_radius")[task_id] if circular else None
             rets.append(self.post_processing(boxes, hm, get("score_threshold"), pcr, nget("nms_iou_threshold"),
-                                             nget("nms_pre_max_size"), nget("nms_post_max_size")))
+                                             nget("nms_pre_max_size"), nget("nms_post_max_size"), circle_radius=radius))
         meta = example.get("metadata") if isinstance(example, dict) else None
+        if meta and double_flip:
+            meta = meta[:4 * len(rets[0]):4]
         out = []
         for i in range(len(rets[0])):
             ret, flag = {}, 0
@@ -736,9 +774,10 @@ class CenterHead(nn.Module):
         return out
 
     @torch.no_grad()
-    def post_processing(self, batch_box_preds, batch_hm, score_threshold, post_center_range, iou_threshold, pre_max, post_max):
-        """center_head.py:452-495 per sample: max over classes, score + centre-range mask, rotate_nms_pcdet"""
-        from .nms import rotate_nms
+    def post_processing(self, batch_box_preds, batch_hm, score_threshold, post_center_range, iou_threshold, pre_max, post_max, circle_radius=None):
+        """center_head.py:452-495 per sample: max over classes, score + centre-range mask, rotate_nms_pcdet - or, with circle_radius
+        (test_cfg.circular_nms), `_circle_nms` on the centres (center_head.py:476-479,499-507)"""
+        from .nms import circle_nms, rotate_nms
         res = []
         for box_preds, hm_preds in zip(batch_box_preds, batch_hm):
             scores, labels = torch.max(hm_preds, dim=-1)
@@ -746,7 +785,10 @@ class CenterHead(nn.Module):
             if post_center_range is not None:
                 mask &= (box_preds[..., :3] >= post_center_range[:3]).all(1) & (box_preds[..., :3] <= post_center_range[3:]).all(1)
             box_preds, scores, labels = box_preds[mask], scores[mask], labels[mask]
-            sel = rotate_nms(box_preds[:, [0, 1, 2, 3, 4, 5, -1]].float(), scores.float(), iou_threshold, pre_max, post_max)
+            if circle_radius is not None:
+                sel = circle_nms(box_preds[:, [0, 1]].float(), scores.float(), circle_radius, post_max)
+            else:
+                sel = rotate_nms(box_preds[:, [0, 1, 2, 3, 4, 5, -1]].float(), scores.float(), iou_threshold, pre_max, post_max)
             res.append(dict(box3d_lidar=box_preds[sel], scores=scores[sel], label_preds=labels[sel]))
         return res
 

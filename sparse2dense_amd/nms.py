@@ -40,3 +40,24 @@ def rotate_nms(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
     _lib.check(lib.s2d_nms_rotated_bev(b.data_ptr(), n, float(thresh), max_keep, keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(), ws.numel(),
                                        _stream(b.device)), "s2d_nms_rotated_bev")
     return order[keep[:int(n_keep.item())]]
+
+
+def circle_nms(centers_xy, scores, min_radius, post_max_size=83):
+    """CenterPoint's `_circle_nms` (/root/reference/det3d/models/bbox_heads/center_head.py:499-507 over core/utils/circle_nms_jit.py:4-31):
+    indices into the input kept by the greedy centre-distance suppression, in descending-score order, at most post_max_size of them.
+    (The reference orders equal scores by numpy's reversed argsort; here the sort is stable descending - float scores do not tie.)"""
+    if not centers_xy.is_cuda:
+        raise _lib.S2DError("circle_nms: CUDA tensors expected (no CPU fallback)")
+    lib = _lib.load()
+    order = torch.sort(scores, dim=0, descending=True, stable=True)[1]
+    n = int(order.shape[0])
+    if n == 0:
+        return order
+    xy = centers_xy[order].float().contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device=xy.device)
+    n_keep = torch.empty(1, dtype=torch.int32, device=xy.device)
+    ws = torch.empty(lib.s2d_nms_workspace_bytes(n), dtype=torch.uint8, device=xy.device)
+    max_keep = n if post_max_size is None else min(n, int(post_max_size))
+    _lib.check(lib.s2d_nms_circle(xy.data_ptr(), n, float(min_radius), max_keep, keep.data_ptr(), n_keep.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream(xy.device)), "s2d_nms_circle")
+    return order[keep[:int(n_keep.item())]]

@@ -159,3 +159,20 @@ def reference_param_groups(model):
     l1 = nn.Sequential(*[c for c in leaves if not isinstance(c, bn)])
     l2 = nn.Sequential(*[c for c in leaves if isinstance(c, bn)])
     return [[q for q in l.parameters() if q.requires_grad] for l in (l1, l2)]
+
+
+# inputs of the round-6 predict fixture (tests/golden/make_golden_r06.py generates the expected outputs with the reference; the GPU test
+# feeds the same seeded maps to this package's CenterHead.predict)
+PREDICT_FLIP_CIRCLE_CFG = dict(post_center_limit_range=[-80, -80, -10.0, 80, 80, 10.0],
+                               nms=dict(nms_pre_max_size=4096, nms_post_max_size=83, nms_iou_threshold=0.7), score_threshold=0.1,
+                               pc_range=[-75.2, -75.2], out_size_factor=8, voxel_size=[0.1, 0.1], double_flip=True, circular_nms=True,
+                               min_radius=[2.0])
+
+
+def predict_flip_circle_inputs(h=188, w=188, batch=8):
+    """seeded prediction maps [8, C, H, W] (2 samples x 4 flips); the heat map is biased down so that a few hundred cells pass the threshold"""
+    out = {}
+    for i, (k, c) in enumerate(dict(reg=2, height=1, dim=3, rot=2, hm=3).items()):
+        t = seeded((batch, c, h, w), 900 + i)
+        out[k] = t * 1.5 - 3.0 if k == "hm" else (t * 0.3 + 0.8 if k == "dim" else (torch.sigmoid(t) if k == "reg" else t))
+    return out

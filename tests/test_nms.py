@@ -125,3 +125,63 @@ def test_center_head_predict_matches_restatement():
         np.testing.assert_allclose(got["scores"].cpu().numpy(), scores[m][sel], rtol=1e-5)
         np.testing.assert_allclose(got["box3d_lidar"].cpu().numpy(), boxes[m][sel], rtol=1e-4, atol=1e-4)
         assert np.array_equal(got["label_preds"].cpu().numpy(), labels[m][sel])
+
+
+# ---- r06: CenterPoint's circle NMS and the double-flip decode of CenterHead.predict (center_head.py:301-381,476-479,499-507) --------------
+def _circle_brute(xy, scores, thresh, post_max):
+    """the reference's loop (circle_nms_jit.py:4-31) written out again in plain Python, float32 arithmetic"""
+    order = np.argsort(-scores, kind="stable")
+    dead, keep = np.zeros(len(order), bool), []
+    for a in range(len(order)):
+        if dead[a]:
+            continue
+        i = order[a]
+        keep.append(i)
+        for b in range(a + 1, len(order)):
+            j = order[b]
+            d = np.float32(np.float32(xy[i, 0] - xy[j, 0]) ** 2) + np.float32(np.float32(xy[i, 1] - xy[j, 1]) ** 2)
+            if d <= np.float32(thresh):
+                dead[b] = True
+    return keep[:post_max]
+
+
+def test_oracle_circle_nms_is_the_greedy_centre_distance_loop():
+    rs = np.random.RandomState(12)
+    for n, thr, post in [(400, 4.0, 83), (50, 0.5, 500), (1, 1.0, 83), (0, 1.0, 83)]:
+        xy = (rs.rand(n, 2) * 30).astype(np.float32)
+        sc = rs.rand(n).astype(np.float32)
+        assert list(O.circle_nms(xy, sc, thr, post)) == _circle_brute(xy, sc, thr, post), n
+
+
+@pytest.mark.gpu
+def test_device_circle_nms_matches_oracle():
+    from sparse2dense_amd import nms
+    rs = np.random.RandomState(13)
+    for n, thr, post in [(3000, 2.0, 83), (4097, 0.25, 500), (65, 9.0, 83), (1, 1.0, 5)]:
+        xy = (rs.rand(n, 2) * 60 - 30).astype(np.float32)
+        sc = rs.rand(n).astype(np.float32)
+        sel = nms.circle_nms(torch.from_numpy(xy).cuda(), torch.from_numpy(sc).cuda(), thr, post)
+        assert sel.cpu().numpy().tolist() == O.circle_nms(xy, sc, thr, post).tolist(), n
+    assert nms.circle_nms(torch.zeros(0, 2).cuda(), torch.zeros(0).cuda(), 1.0).numel() == 0
+
+
+@pytest.mark.gpu
+def test_center_head_predict_with_double_flip_and_circle_nms_matches_the_reference_golden(golden_dir):
+    """the REFERENCE's CenterHead.predict(double_flip=True, circular_nms=True) on the same seeded maps (tests/golden/make_golden_r06.py)"""
+    import os
+    from golden_util import PREDICT_FLIP_CIRCLE_CFG as CFG, predict_flip_circle_inputs
+    from sparse2dense_amd import waymo_configs
+    from sparse2dense_amd.registry import build_head
+    g = np.load(os.path.join(golden_dir, "predict_flip_circle.npz"))
+    head = build_head(waymo_configs.centerpoint_voxelnet()["bbox_head"]).cuda().eval()
+    preds = {k: v.cuda() for k, v in predict_flip_circle_inputs().items()}
+    out = head.predict({}, [preds], CFG)
+    assert len(out) == int(g["samples"]) == 2
+    for i, r in enumerate(out):
+        want_b, want_s, want_l = g[f"boxes{i}"], g[f"scores{i}"], g[f"labels{i}"]
+        assert r["box3d_lidar"].shape == want_b.shape == (83, 7)
+        np.testing.assert_allclose(r["scores"].cpu().numpy(), want_s, rtol=1e-5)
+        np.testing.assert_allclose(r["box3d_lidar"].cpu().numpy(), want_b, rtol=1e-4, atol=2e-4)
+        assert np.array_equal(r["label_preds"].cpu().numpy(), want_l)
+    with pytest.raises(NotImplementedError):
+        head.predict({}, [preds], dict(CFG, per_class_nms=True))
