@@ -18,6 +18,7 @@
 //                            straight from the planar tensors (one 18-float window of dout feeds the 4 kx fragments).
 #include "s2d_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace s2d {
 
@@ -389,6 +390,299 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             }
         }
     }
+    if (stats_partial) {   // block partial [2][cout]: lanes of a channel, then the 4 waves (= the 4 (pz,py) classes), fixed order
+        if (NT == 1 && narrow) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float a = na[k], b = nb[k];
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    a += __shfl_xor(a, d, 64);
+                    b += __shfl_xor(b, d, 64);
+                }
+                if ((lane & 31) == 0) {
+                    sred[wid][0][(lane + 64 * k) >> 5] = a;
+                    sred[wid][1][(lane + 64 * k) >> 5] = b;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float a = st1[nt], b = st2[nt];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (q == 0) {
+                    sred[wid][0][nt * 16 + r] = a;
+                    sred[wid][1][nt * 16 + r] = b;
+                }
+            }
+        }
+        __syncthreads();
+        if (t < 2 * NT * 16) {
+            const int which = t / (NT * 16), co = t % (NT * 16);
+            if (co < s.cout)
+                stats_partial[((int64_t)tile * 2 + which) * s.cout + co] =
+                    (sred[0][which][co] + sred[1][which][co]) + (sred[2][which][co] + sred[3][which][co]);
+        }
+    }
+}
+
+// z-sliding form of ct_fwd_mfma_kernel for 16 input channels (r06): the same staging code, MFMA order and epilogue, but a block owns
+// (n, YR rows, x tile) for ALL z and keeps a ring of three staged planes - 1.5 staged rows per produced row instead of 4.5; the wave's
+// weight fragments (its (pz, py) class never changes) stay in registers; the narrow epilogue's LDS transpose is wave-local (no workgroup
+// barriers).  16 -> 3 @ 4 x 10 x 376 x 376, fp32 output: 575 -> 457 us (z ring 526, + weights in registers 470, + wave-local epilogue 457),
+// bit-identical.  Ablation of the 466 us build (template switches, removed again): without the output stores 384, without the MFMAs 413,
+// without the global loads 393, without the A-fragment LDS reads 326, without all four 178 - no single stream dominates; the 32
+// ds_read_b128 per wave and row (4 x redundant: both px classes and both x taps re-read the same cells) are the largest single term.
+template <int CIN, int NT, int YR, typename TO = float>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_zslide_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+                                                          CtDims s, int xtiles, TO *__restrict__ out,
+                                                          float *__restrict__ stats_partial, const float *__restrict__ in_norm = nullptr) {
+    // in_norm (r04, scale[CIN] | shift[CIN] or null): the input is the RAW tensor in front of a BatchNorm3d + ReLU, applied here while
+    // staging - relu(fma(x, scale[ci], shift[ci])), the expression of s2d_bncm_apply_f32 - so the normalised tensor is never written
+    // or read (cells outside the tensor stay zero: the padding is of the normalised tensor)
+    constexpr int GROUPS = CIN / 8;          // 16-byte pieces per staged cell
+    constexpr int XS = CT_TX + 2;            // staged columns: x0-1 .. x0+64
+    constexpr int KSTEPS = CIN == 32 ? 8 : 4;
+    // a block produces YR consecutive input rows y of ONE x tile for EVERY z, walking z with a ring of three staged planes of YR + 2 rows:
+    // each plane is staged once per block instead of three times (by the blocks of z - 1, z, z + 1)
+    constexpr int RY = YR + 2, ROWS = RY;            // rows staged per z step
+    __shared__ __attribute__((aligned(16))) __bf16 xs[3 * RY * XS * CIN];   // [slot * RY + yi][xx][ci], slot of plane z = (z + 3) % 3
+    auto xa = [&](int cell, int g) -> int { return (cell * GROUPS + g) * 8; };
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    // Tile order: (n, group of YR rows, x tile); xcd_tile() gives an XCD a contiguous range of tiles, so the y-halo rows two neighbouring row
+    // groups share are fetched by one XCD's L2
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int hgroups = (s.h + YR - 1) / YR;
+    if (tile >= s.n * hgroups * xtiles) return;
+    const int n = tile / (hgroups * xtiles);
+    const int rem0 = tile - n * (hgroups * xtiles);
+    const int hy0 = (rem0 / xtiles) * YR, xt = rem0 % xtiles;
+    const int x0 = xt * CT_TX;
+    const int64_t cells = (int64_t)s.d * s.h * s.w;
+    const float *xb = x + (int64_t)n * CIN * cells;
+    // stage: the 64-cell body of a row as 16-byte loads (piece = (row9, group, 4 cells): 8 channel planes x float4 -> four 16-byte LDS
+    // stores), the two halo columns (and everything when w % 4 != 0) with one dword per channel.  Strided dword gathers cost ~4x the
+    // issue slots of 16-byte loads (DESIGN rule 7); this staging is what bounds the kernel.
+    const bool vec = (s.w & 3) == 0;
+    auto stage_plane = [&](int zp, int slot) {   // plane zp (zeros outside the tensor) -> rows [slot * RY, slot * RY + RY) of the ring
+    const int rbase = slot * RY;
+    if (vec) {
+        // every thread issues the loads of its halo piece (threads < 18 * GROUPS) and of its first body piece before converting any
+        constexpr int HALO = ROWS * GROUPS * 2, BODY = ROWS * GROUPS * 16;
+        static_assert(HALO <= 256, "one halo piece per thread");
+        float hv[8];
+        const bool has_halo = t < HALO;
+        int h_slot = 0;
+        if (has_halo) {
+            const int c = t & 1, g = (t >> 1) % GROUPS, r9 = (t >> 1) / GROUPS;
+            const int xx = c * (XS - 1);
+            const int z = zp, y = hy0 + r9 - 1, xp = x0 - 1 + xx;
+            h_slot = xa((rbase + r9) * XS + xx, g);
+            const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w;
+            const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float val = src[ok ? (int64_t)e * cells : 0];
+                if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
+                hv[e] = ok ? val : 0.f;
+            }
+        }
+        // (p >> 4) advances by 16 per iteration, a multiple of GROUPS: a thread's channel group - and its eight scale / shift pairs - is fixed
+        static_assert(16 % GROUPS == 0, "a thread keeps its channel group");
+        float nsc[8], nsh[8];
+        if (in_norm) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                nsc[e] = in_norm[((t >> 4) % GROUPS) * 8 + e];
+                nsh[e] = in_norm[CIN + ((t >> 4) % GROUPS) * 8 + e];
+            }
+        }
+        for (int p = t; p < BODY; p += 256) {
+            const int xq = p & 15, g = (p >> 4) % GROUPS, r9 = (p >> 4) / GROUPS;
+            const int z = zp, y = hy0 + r9 - 1, xp = x0 + 4 * xq;
+            const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && xp < s.w;
+            const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
+            float4 f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const float4 *>(src + (ok ? (int64_t)e * cells : 0));
+            if (in_norm) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sc = nsc[e], sh = nsh[e];
+                    f[e] = float4{fmaxf(fmaf(f[e].x, sc, sh), 0.f), fmaxf(fmaf(f[e].y, sc, sh), 0.f), fmaxf(fmaf(f[e].z, sc, sh), 0.f),
+                                  fmaxf(fmaf(f[e].w, sc, sh), 0.f)};
+                }
+            }
+            bf16x8m v[4];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[0][e] = (__bf16)(ok ? f[e].x : 0.f); v[1][e] = (__bf16)(ok ? f[e].y : 0.f);
+                v[2][e] = (__bf16)(ok ? f[e].z : 0.f); v[3][e] = (__bf16)(ok ? f[e].w : 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x8m *>(&xs[xa((rbase + r9) * XS + 1 + 4 * xq + j, g)]) = v[j];
+        }
+        if (has_halo) {
+            bf16x8m v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)hv[e];
+            *reinterpret_cast<bf16x8m *>(&xs[h_slot]) = v;
+        }
+    } else {
+        for (int p = t; p < ROWS * GROUPS * XS; p += 256) {
+            const int xx = p % XS, g = (p / XS) % GROUPS, r9 = p / (XS * GROUPS);
+            const int z = zp, y = hy0 + r9 - 1, xp = x0 - 1 + xx;
+            bf16x8m v;
+            if ((unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w) {
+                const float *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float val = src[(int64_t)e * cells];
+                    if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
+                    v[e] = (__bf16)val;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8m *>(&xs[xa((rbase + r9) * XS + xx, g)]) = v;
+        }
+    }
+    };
+    const int pz = wid >> 1, py = wid & 1;
+    const int r = lane & 15, q = lane >> 4;
+    const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
+    TO *ob = out + (int64_t)n * s.cout * od * oh * ow;
+    using ST = CtStore<TO>;
+    float st1[NT], st2[NT];   // per-channel (sum, sum of squares) of this lane's outputs: the batch norm that follows skips its statistics pass
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        st1[nt] = 0.f;
+        st2[nt] = 0.f;
+    }
+    // <= 4 output channels (the last up-sampler, 16 -> 3): only 4 of 16 column lanes hold outputs, so storing from the accumulator
+    // layout issues 32 store instructions per wave with 12 live lanes each.  The wave transposes its row through LDS instead and
+    // stores whole 512-byte channel rows with every lane (bias and statistics on the float4s).
+    __shared__ __attribute__((aligned(16))) float tr[NT == 1 ? 4 * 4 * 2 * CT_TX : 4];   // [wave][co < 4][2 * CT_TX]
+    const bool narrow = NT == 1 && s.cout <= 4 && (ow & 3) == 0;
+    __shared__ float sred[4][2][NT * 16];
+    float na[2] = {0.f, 0.f}, nb[2] = {0.f, 0.f};   // narrow path: this lane's sums for channel (lane + 64 k) >> 5
+    bf16x8m bw[2][NT == 1 ? KSTEPS : 1];   // NT == 1: the 2 x KSTEPS weight fragments of this wave's (pz, py) classes, loaded once
+    if constexpr (NT == 1) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+                bw[px][ks] = *reinterpret_cast<const bf16x8m *>(wp + (((int64_t)(pz * 4 + py * 2 + px) * KSTEPS + ks) * 64 + lane) * 8);
+    }
+    stage_plane(-1, 2);
+    stage_plane(0, 0);
+    for (int hz = 0; hz < s.d; ++hz) {
+    stage_plane(hz + 1, (hz + 1) % 3);   // overwrites plane hz - 2: every wave left its reads behind at the barrier that closed step hz - 1
+    __syncthreads();
+    const int oz = 2 * hz + pz;
+    const int zslot[3] = {(hz + 2) % 3, hz % 3, (hz + 1) % 3};   // ring slots of the planes hz - 1, hz, hz + 1
+    for (int yy = 0; yy < YR; ++yy) {
+        const int hy = hy0 + yy;
+        if (hy >= s.h) break;   // block-uniform
+        const int oy = 2 * hy + py;
+        f32x4m acc[2][4][NT];
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int cls = pz * 4 + py * 2 + px;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8m b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (NT == 1) b[nt] = bw[px][ks];   // the wave's class never changes: its weight fragments stay in registers
+                    else b[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)cls * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                }
+                const int tap = CIN == 32 ? ks : 2 * ks + (q >> 1);
+                const int g = CIN == 32 ? q : (q & 1);
+                const int ta = tap >> 2, tb = (tap >> 1) & 1, tc = tap & 1;
+                const int r9 = zslot[ct_d(pz, ta) + 1] * RY + (ct_d(py, tb) + 1 + yy);
+                const int dx = ct_d(px, tc);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int xx = mt * 16 + r + 1 + dx;
+                    const bf16x8m a = *reinterpret_cast<const bf16x8m *>(&xs[xa(r9 * XS + xx, g)]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[px][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[px][mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: lane holds column co = nt*16 + r and the 4 cells 4q..4q+3 of every m-tile, both px -> 8 consecutive floats
+        if (NT == 1 && narrow) {
+            // raw accumulators -> tr[wave][co][2 * cell + px] (the wave's own slab: LDS accesses of a wave stay in order)
+            float *dst = tr + wid * 4 * 2 * CT_TX;
+            if (r < s.cout) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int c0 = mt * 16 + 4 * q;
+                    *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0) = float4{acc[0][mt][0][0], acc[1][mt][0][0], acc[0][mt][0][1], acc[1][mt][0][1]};
+                    *reinterpret_cast<float4 *>(dst + r * 2 * CT_TX + 2 * c0 + 4) = float4{acc[0][mt][0][2], acc[1][mt][0][2], acc[0][mt][0][3], acc[1][mt][0][3]};
+                }
+            }
+            // (the slab is this wave's own and a wave's LDS accesses execute in order: no workgroup barrier - r06; the per-z kernel above
+            // still has two per row)
+            __builtin_amdgcn_wave_barrier();
+            const int n4 = (min(CT_TX, s.w - x0) * 2) >> 2;   // float4 per channel row of this tile
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {   // 4 channels x 32 float4: two per lane; a 32-lane half holds one channel
+                const int i = lane + 64 * k, co = i >> 5, x4 = i & 31;
+                if (co < s.cout && x4 < n4) {
+                    float4 v = *reinterpret_cast<const float4 *>(dst + co * 2 * CT_TX + 4 * x4);
+                    const float bv = bias ? bias[co] : 0.f;
+                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                    v = ST::rnd(v);
+                    ST::st4(ob + (((int64_t)co * od + oz) * oh + oy) * ow + 2 * x0 + 4 * x4, v);
+                    na[k] += (v.x + v.y) + (v.z + v.w);
+                    nb[k] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the slab is rewritten by the next row (same wave, in order)
+            continue;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nt * 16 + r;
+            if (co >= s.cout) continue;
+            const float bv = bias ? bias[co] : 0.f;
+            TO *orow = ob + (((int64_t)co * od + oz) * oh + oy) * ow;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int c0 = x0 + mt * 16 + 4 * q;
+                if (c0 + 3 < s.w && (ow & 3) == 0) {
+                    const float4 lo = ST::rnd(float4{acc[0][mt][nt][0] + bv, acc[1][mt][nt][0] + bv, acc[0][mt][nt][1] + bv, acc[1][mt][nt][1] + bv});
+                    const float4 hi = ST::rnd(float4{acc[0][mt][nt][2] + bv, acc[1][mt][nt][2] + bv, acc[0][mt][nt][3] + bv, acc[1][mt][nt][3] + bv});
+                    ST::st4(orow + 2 * c0, lo);
+                    ST::st4(orow + 2 * c0 + 4, hi);
+                    st1[nt] += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+                    st2[nt] += ((lo.x * lo.x + lo.y * lo.y) + (lo.z * lo.z + lo.w * lo.w)) + ((hi.x * hi.x + hi.y * hi.y) + (hi.z * hi.z + hi.w * hi.w));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < s.w) {
+                            const float v0 = ST::rnd1(acc[0][mt][nt][j] + bv), v1 = ST::rnd1(acc[1][mt][nt][j] + bv);
+                            ST::st1(orow + 2 * (c0 + j), v0);
+                            ST::st1(orow + 2 * (c0 + j) + 1, v1);
+                            st1[nt] += v0 + v1;
+                            st2[nt] += v0 * v0 + v1 * v1;
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();   // step hz done: the next step's staging may overwrite the plane behind it
+    }   // hz
     if (stats_partial) {   // block partial [2][cout]: lanes of a channel, then the 4 waves (= the 4 (pz,py) classes), fixed order
         if (NT == 1 && narrow) {
 #pragma unroll
@@ -1143,9 +1437,20 @@ extern "C" int s2d_convt3d_mfma_pack_weights(const float *weight, int cin, int c
 // input channels stay at one row - two rows (50 KB, fewer resident workgroups) measured 0.52 ms against 0.35
 static int ct_fwd_rows(int cin) { return cin == 32 ? 1 : 4; }
 
+// r06: 16-channel inputs take the z-sliding kernel (a block = (n, 4 rows, x tile) for every z: each plane staged once per block instead of three
+// times); S2D_CT_ZSLIDE=0 keeps the per-z blocks for A/B runs
+static bool ct_fwd_zslide(int cin) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("S2D_CT_ZSLIDE");
+        on = !(e && e[0] == '0');
+    }
+    return on && cin == 16;
+}
+
 extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h, int w) {
     const int yr = ct_fwd_rows(cin);
-    return (int64_t)batch * d * ((h + yr - 1) / yr) * ((w + CT_TX - 1) / CT_TX);
+    return (int64_t)batch * (ct_fwd_zslide(cin) ? 1 : d) * ((h + yr - 1) / yr) * ((w + CT_TX - 1) / CT_TX);
 }
 
 /* stats_partial (optional, [s2d_convt3d_mfma_stats_tiles][2][cout]): per-block (sum, sum of squares) per output channel of the written
@@ -1158,14 +1463,21 @@ static int ct_fwd_launch(const float *in, const void *packed, const float *bias,
     CtDims s{batch, d, h, w, cin, cout};
     const int xtiles = (w + CT_TX - 1) / CT_TX;
     const int yr = ct_fwd_rows(cin), hg = (h + yr - 1) / yr;
+    const int nt = (cout + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *wp = (const __bf16 *)packed;
+    if (ct_fwd_zslide(cin)) {
+        const dim3 zgrid(xcd_grid((int64_t)batch * hg * xtiles)), zblk(256);
+        if (nt == 2) hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 2, 4, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        else hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 1, 4, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    }
     const int64_t blocks = (int64_t)batch * d * hg * xtiles;
     S2D_CHECK_ARG(blocks < 0x7fffffff, "convt3d_mfma_fwd: grid too large");
     const dim3 grid(xcd_grid(blocks)), blk(256);
     // 3 z planes x (yc * yr + 2) input rows live per chunk of yc row groups
     const CtTileMap map = ct_tile_map(d, hg, xtiles, ct_chunk_rows((int64_t)w * cin * 4, yr, 2, 3));
-    hipStream_t st = (hipStream_t)stream;
-    const __bf16 *wp = (const __bf16 *)packed;
-    const int nt = (cout + 15) / 16;
     if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 2, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
     else if (cin == 32) hipLaunchKernelGGL((ct_fwd_mfma_kernel<32, 1, 1, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
     else if (nt == 2) hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 2, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
