@@ -834,6 +834,14 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restri
     const int xcd = blockIdx.x % S2D_XCDS, bx = blockIdx.x / S2D_XCDS, bpx = gridDim.x / S2D_XCDS;
     const int per_xcd = (items + S2D_XCDS - 1) / S2D_XCDS;
     const int it_hi = min(items, (xcd + 1) * per_xcd);
+    // r06: the narrow layer's 8 weight fragments (one per (kz, ky pair)) are the same for every item of the wave's sweep: loaded once,
+    // kept in registers (82 -> ~115 VGPRs, still four waves per SIMD), instead of 8 L1 reads in front of every item's MFMAs
+    constexpr bool WREG = N4 && NT == 1 && KSTEPS == 1;
+    bf16x8m wreg[WREG ? 8 : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) wreg[k8] = *reinterpret_cast<const bf16x8m *>(wp + ((int64_t)k8 * 64 + lane) * 8);
+    }
     for (int item = xcd * per_xcd + bx * 4 + wid; item < it_hi; item += bpx * 4) {
         const int n = (int)fastdiv((uint32_t)item, map.per_n);
         int rem = item - n * (int)map.per_n.d;
@@ -858,7 +866,7 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restri
             last[mt] = c == s.w - 1;
             pos[mt] = c < s.w ? (D16 ? (unsigned)((c == 0 ? 0 : 2 * c - 2) * 2) : (unsigned)((2 * c - (c == 0 ? 0 : 1)) * 4)) : CT_OOB;
         }
-#pragma unroll 2
+#pragma unroll (WREG ? 8 : 2)
         for (int kzky = 0; kzky < (N4 ? 8 : 16); ++kzky) {
             // N4 (cout <= 4): the lane groups q = (ky of a pair, channel pair) - the row is per lane and goes into the lane offset
             const int z = 2 * hz - 1 + (N4 ? kzky >> 1 : kzky >> 2), y = 2 * hy - 1 + (N4 ? 2 * (kzky & 1) + (q >> 1) : kzky & 3);
@@ -869,8 +877,10 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restri
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 bf16x8m bfr[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bfr[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (WREG) bfr[nt] = wreg[kzky];   // (the loop is fully unrolled then: a register, not an indexed array)
+                    else bfr[nt] = *reinterpret_cast<const bf16x8m *>(wp + ((((int64_t)kzky * KSTEPS + ks) * NT + nt) * 64 + lane) * 8);
+                }
                 const int co0 = N4 ? 2 * (q & 1) : 8 * ks + 2 * q;
                 const unsigned pl0 = (rok && co0 < s.cout) ? (unsigned)co0 * oplane_b + (N4 ? roff : 0u) : CT_OOB;
                 const unsigned pl1 = (rok && co0 + 1 < s.cout) ? (unsigned)(co0 + 1) * oplane_b + (N4 ? roff : 0u) : CT_OOB;
@@ -1443,9 +1453,9 @@ static bool ct_fwd_zslide(int cin) {
     static int on = -1;
     if (on < 0) {
         const char *e = getenv("S2D_CT_ZSLIDE");
-        on = !(e && e[0] == '0');
+        on = e ? atoi(e) : 1;
     }
-    return on && cin == 16;
+    return on && (cin == 16 || (cin == 32 && on == 2));   // S2D_CT_ZSLIDE=2: the 32-channel layer too (A/B)
 }
 
 extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h, int w) {
@@ -1468,7 +1478,9 @@ static int ct_fwd_launch(const float *in, const void *packed, const float *bias,
     const __bf16 *wp = (const __bf16 *)packed;
     if (ct_fwd_zslide(cin)) {
         const dim3 zgrid(xcd_grid((int64_t)batch * hg * xtiles)), zblk(256);
-        if (nt == 2) hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 2, 4, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_zslide_kernel<32, 2, 1, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        else if (cin == 32) hipLaunchKernelGGL((ct_fwd_zslide_kernel<32, 1, 1, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        else if (nt == 2) hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 2, 4, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
         else hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 1, 4, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
         S2D_LAUNCH_CHECK();
         return S2D_OK;
