@@ -39,7 +39,7 @@ import torch.distributed as dist
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILES = ["r05_final_pmc_traffic.json", "r04_final_pmc_traffic.json", "r04_mid_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_mid_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
+PMC_TRAFFIC_FILES = ["r06_final_pmc_traffic.json", "r05_final_pmc_traffic.json", "r04_final_pmc_traffic.json", "r04_mid_pmc_traffic.json", "r03_final_pmc_traffic.json", "r03_mid_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json"]   # newest first (profiles/)
 
 WORKLOAD_NAMES = {
     "centerpoint": "CenterPoint-voxelnet single-stage (BASELINE configs[1])",
