@@ -39,6 +39,7 @@ import torch
 CAPTURE_LOCK = threading.RLock()
 
 WARMUP = int(os.environ.get("S2D_GRAPH_WARMUP", "2"))
+MAX_CAPTURES = int(os.environ.get("S2D_GRAPH_MAX_CAPTURES", "6"))   # per segment: train / eval x grad modes x a couple of input signatures
 stats = {"eager": 0, "capture": 0, "replay": 0, "dropped": 0, "launch_host_ms": 0.0}   # launch_host_ms: host time spent inside hipGraphLaunch calls
 
 
@@ -232,6 +233,11 @@ class GraphedSegment:
                 torch.cuda.synchronize()
                 return self.fn(*inputs)
             self._caps[key] = cap
+            while len(self._caps) > MAX_CAPTURES:   # signatures that can no longer occur (a padded side input grew its capacity) would only
+                old_key = next(iter(self._caps))    # hold graph-pool memory: the oldest capture goes
+                del self._caps[old_key]
+                self._seen.pop(old_key, None)
+                stats["dropped"] += 1
             stats["capture"] += 1
         stats["replay"] += 1
         if getattr(cap, "bound", False):
