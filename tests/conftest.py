@@ -5,7 +5,7 @@ import sys
 import pytest
 
 # MIOpen has no pre-built kernel / find database for gfx950 in this image: every new fp32 convolution configuration of the parity
-# ("f32") mode JIT-compiles its solver on a fresh box.  Measured r06 (scratch probe, one pillar step at 4 x 150 k points, first call /
+# ("f32") mode JIT-compiles its solver on a fresh box.  Measured r06 (tools/miopen_probe.sh, one pillar step at 4 x 150 k points, first call /
 # second call): all solvers 127 s / 7 s; without the Winograd, direct and FFT families - the implicit-GEMM (pre-built CK instances) and
 # GEMM solvers remain - 38 s / 8 s.  The TEST process therefore restricts MIOpen to those families (set before torch loads the
 # library; a value the caller exported wins).  The product, bench.py and smoke() do not touch these variables.
