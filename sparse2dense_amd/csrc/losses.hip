@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void pcr_heads_bwd_dense_kernel(const float *_
                                                                   const float *__restrict__ w2, const float *__restrict__ hp, const float *__restrict__ go_mask,
                                                                   const float *__restrict__ fin, int64_t cells, int batch, float *__restrict__ dg,
                                                                   float *__restrict__ partial) {
-    __shared__ float w2s[CO > 0 ? CO * C : 1];
+    __shared__ __attribute__((aligned(16))) float w2s[CO > 0 ? CO * C : 4];   // (read as float4 rows)
     __shared__ PcrHeadW<C> hw;
     pcr_load_head<C>(hp, hw);
     if (CO > 0) {
@@ -512,10 +512,22 @@ __global__ __launch_bounds__(256) void pcr_heads_bwd_dense_kernel(const float *_
                 pw[c] = fmaf(dm[k], gv[c][k], pw[c]);
                 o[k] = wc * dm[k];
             }
-            if (CO > 0) {
+            if constexpr (CO > 0 && CO % 4 == 0) {   // four weights per 16-byte LDS broadcast (see pcr_level_bwd_dense_kernel)
+#pragma unroll
+                for (int q4 = 0; q4 < CO / 4; ++q4) {
+                    const float4 wq = *reinterpret_cast<const float4 *>(w2v + c * CO + 4 * q4);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        o[k] = fmaf(wq.x, zv[4 * q4][k], o[k]);
+                        o[k] = fmaf(wq.y, zv[4 * q4 + 1][k], o[k]);
+                        o[k] = fmaf(wq.z, zv[4 * q4 + 2][k], o[k]);
+                        o[k] = fmaf(wq.w, zv[4 * q4 + 3][k], o[k]);
+                    }
+                }
+            } else if (CO > 0) {
 #pragma unroll
                 for (int q = 0; q < CO; ++q) {
-                    const float wq = w2v[c * CO + q];   // transposed image: the CO weights of channel c are contiguous
+                    const float wq = w2v[c * CO + q];
 #pragma unroll
                     for (int k = 0; k < V; ++k) o[k] = fmaf(wq, zv[q][k], o[k]);
                 }
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__re
                                                                   const float *__restrict__ w2, const float *__restrict__ b2, int64_t cells, int batch,
                                                                   float *__restrict__ z, float *__restrict__ partial,
                                                                   float *__restrict__ zstat_partial) {
-    __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
+    __shared__ __attribute__((aligned(16))) float w2s[CO > 0 ? CO * C : 4];   // [C][CO]; read as float4 rows (see pcr_level_bwd_dense_kernel)
     __shared__ float b2s[CO > 0 ? CO : 1];
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
@@ -751,8 +763,12 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__re
     }
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;
-    const float *scv = nm.sc + lane_zero, *shv = nm.sh + lane_zero, *w2v = w2s + lane_zero;
+    const float *w2v = w2s + lane_zero;
+    // per-channel constants (BN scale, BN shift, mask-head weight) as ONE 16-byte LDS broadcast per channel instead of three dword reads
+    __shared__ __attribute__((aligned(16))) float4 cst[C];
+    for (int i = threadIdx.x; i < C; i += 256) cst[i] = float4{nm.sc[i], nm.sh[i], hw.wm[i], 0.f};
+    __syncthreads();
+    const float4 *cstv = cst + lane_zero;
     float acc[1] = {0.f};
     // zstat_partial (block-uniform, CO > 0): per-channel (sum, sum of squares) of the z this kernel writes = the statistics pass of the
     // BatchNorm3d that follows the 1x1x1 conv (generator_2[1], rpn.py:263-296) - one 362 MB read less per step
@@ -781,14 +797,27 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__re
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+                const float4 cc = cstv[c];
+                const float sc = cc.x, sh = cc.y, wc = cc.z;
                 float g[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     g[k] = fmaxf(fmaf(yv.get(c, k), sc, sh), 0.f);
                     x[k] = fmaf(wc, g[k], x[k]);
                 }
-                if (CO > 0) {
+                if constexpr (CO > 0 && CO % 4 == 0) {
+#pragma unroll
+                    for (int q4 = 0; q4 < CO / 4; ++q4) {
+                        const float4 wq = *reinterpret_cast<const float4 *>(w2v + c * CO + 4 * q4);   // one 16-byte LDS broadcast per four weights
+#pragma unroll
+                        for (int k = 0; k < V; ++k) {
+                            za[4 * q4][k] = fmaf(wq.x, g[k], za[4 * q4][k]);
+                            za[4 * q4 + 1][k] = fmaf(wq.y, g[k], za[4 * q4 + 1][k]);
+                            za[4 * q4 + 2][k] = fmaf(wq.z, g[k], za[4 * q4 + 2][k]);
+                            za[4 * q4 + 3][k] = fmaf(wq.w, g[k], za[4 * q4 + 3][k]);
+                        }
+                    }
+                } else if (CO > 0) {
 #pragma unroll
                     for (int q = 0; q < CO; ++q) {
                         const float wq = w2v[c * CO + q];
@@ -898,7 +927,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
                                                                   const float *__restrict__ go_mask, const float *__restrict__ fin,
                                                                   const float *__restrict__ abd, int64_t cells, int batch, TD *__restrict__ dy,
                                                                   float *__restrict__ partial) {
-    __shared__ float w2s[CO > 0 ? CO * C : 1];   // [C][CO]
+    __shared__ __attribute__((aligned(16))) float w2s[CO > 0 ? CO * C : 4];   // [C][CO]; read as float4 rows (r06: a quarter of the LDS instructions)
     __shared__ float abds[APPLY ? 3 * C : 1];
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
@@ -912,8 +941,11 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
     const float scale = go_mask[0] / fin[4];
     int lane_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    const float *wmv = reinterpret_cast<const float *>(&hw) + lane_zero;
-    const float *scv = nm.sc + lane_zero, *shv = nm.sh + lane_zero, *w2v = w2s + lane_zero, *abv = abds + lane_zero;
+    const float *w2v = w2s + lane_zero, *abv = abds + lane_zero;
+    __shared__ __attribute__((aligned(16))) float4 cst[C];   // (BN scale, BN shift, mask-head weight) per channel: one 16-byte LDS broadcast
+    for (int i = threadIdx.x; i < C; i += 256) cst[i] = float4{nm.sc[i], nm.sh[i], hw.wm[i], 0.f};
+    __syncthreads();
+    const float4 *cstv = cst + lane_zero;
     float pw[APPLY ? 1 : 3 * C + 1];
 #pragma unroll
     for (int c = 0; c < (APPLY ? 1 : 3 * C + 1); ++c) pw[c] = 0.f;
@@ -939,7 +971,8 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
             for (int k = 0; k < V; ++k) x[k] = hw.bm;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+                const float4 cc = cstv[c];
+                const float sc = cc.x, sh = cc.y, wc = cc.z;
 #pragma unroll
                 for (int k = 0; k < V; ++k) x[k] = fmaf(wc, fmaxf(fmaf(yv.get(c, k), sc, sh), 0.f), x[k]);
             }
@@ -951,11 +984,27 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
             asm volatile("" ::: "memory");   // re-read the per-channel constants below instead of keeping 3C of them live across both loops
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float sc = scv[c], sh = shv[c], wc = wmv[c];
+                const float4 cc = cstv[c];
+                const float sc = cc.x, sh = cc.y, wc = cc.z;
                 float o[V];
 #pragma unroll
                 for (int k = 0; k < V; ++k) o[k] = wc * dm[k];
-                if (CO > 0) {
+                if constexpr (CO > 0 && CO % 4 == 0) {
+                    // the CO weights of channel c as CO / 4 16-byte LDS reads (wave-uniform address: a broadcast) - with one ds_read_b32 per
+                    // weight the loop issued one LDS instruction per V fused multiply-adds and was bound by them (r06: built without packed
+                    // FP32, rule 36, the kernel went from 299 to 410 us)
+#pragma unroll
+                    for (int q4 = 0; q4 < CO / 4; ++q4) {
+                        const float4 wq = *reinterpret_cast<const float4 *>(w2v + c * CO + 4 * q4);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) {
+                            o[k] = fmaf(wq.x, zv[4 * q4][k], o[k]);
+                            o[k] = fmaf(wq.y, zv[4 * q4 + 1][k], o[k]);
+                            o[k] = fmaf(wq.z, zv[4 * q4 + 2][k], o[k]);
+                            o[k] = fmaf(wq.w, zv[4 * q4 + 3][k], o[k]);
+                        }
+                    }
+                } else if (CO > 0) {
 #pragma unroll
                     for (int q = 0; q < CO; ++q) {
                         const float wq = w2v[c * CO + q];
