@@ -24,10 +24,14 @@ template <bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_nhwc_bf16_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                                 const float *__restrict__ bias, int n, int h, int wd, int c,
                                                                 __bf16 *__restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [49][c]
+    // [49][c + 4]: the row stride is padded by four floats - the transposing store below has consecutive lanes on consecutive TAPS of one
+    // channel, which with stride c (a multiple of 64 words) put all 49 of them on ONE bank (a 49-way conflict in every block's prologue: most
+    // of the r02 kernel's 49 us); with c + 4 they spread over 16 banks (r06)
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int cp = c + 4;
     for (int e = threadIdx.x; e < DW_TAPS * c; e += 256) {
         const int ch = e / DW_TAPS, tap = e - ch * DW_TAPS;      // coalesced read of the torch layout
-        wl[(FLIP ? DW_TAPS - 1 - tap : tap) * c + ch] = w[e];
+        wl[(FLIP ? DW_TAPS - 1 - tap : tap) * cp + ch] = w[e];
     }
     __syncthreads();
     const int groups = c / 8;
@@ -48,23 +52,34 @@ __global__ __launch_bounds__(256) void dwconv7_nhwc_bf16_kernel(const __bf16 *__
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[p][e] = bias ? bias[c0 + e] : 0.f;
 
+    // r06: branch-free.  The r02 form skipped rows / columns outside the map with `continue`: every 16-byte load then sat behind its own
+    // branch, hipcc waited for each before issuing the next (70 dependent L2 round trips per thread: 49 us for a 4.5 MB map).  Now the ten
+    // pieces of a kernel row are buffer loads whose offset is out of range where the pixel is outside the map (reads zero, no branch), all
+    // issued before the first is used.
+    const __amdgpu_buffer_rsrc_t xr = buf_rsrc(x, (unsigned)((int64_t)n * h * wd * c * 2));
+#pragma unroll 1
     for (int ky = 0; ky < DW_K; ++ky) {
         const int iy = oy + ky - DW_R;
-        if ((unsigned)iy >= (unsigned)h) continue;
-        const __bf16 *row = x + (((int64_t)b * h + iy) * wd) * c + c0;
+        const bool rowok = (unsigned)iy < (unsigned)h;
+        const unsigned rowoff = (unsigned)(((((int64_t)b * h + (rowok ? iy : 0)) * wd) * c + c0) * 2);
+        buf_f32x4 raw[DW_XT + DW_K - 1];
+#pragma unroll
+        for (int j = 0; j < DW_XT + DW_K - 1; ++j) {   // input columns x0-3 .. x0+DW_XT+2
+            const int ix = x0 + j - DW_R;
+            const bool ok = rowok && (unsigned)ix < (unsigned)wd;
+            raw[j] = buf_load4(xr, ok ? rowoff + (unsigned)(ix * c * 2) : BUF_OOB, 0);
+        }
         float wk[DW_K][8];
 #pragma unroll
         for (int kx = 0; kx < DW_K; ++kx) {
-            const float4 a = *reinterpret_cast<const float4 *>(&wl[(ky * DW_K + kx) * c + c0]);
-            const float4 bq = *reinterpret_cast<const float4 *>(&wl[(ky * DW_K + kx) * c + c0 + 4]);
+            const float4 a = *reinterpret_cast<const float4 *>(&wl[(ky * DW_K + kx) * cp + c0]);
+            const float4 bq = *reinterpret_cast<const float4 *>(&wl[(ky * DW_K + kx) * cp + c0 + 4]);
             wk[kx][0] = a.x; wk[kx][1] = a.y; wk[kx][2] = a.z; wk[kx][3] = a.w;
             wk[kx][4] = bq.x; wk[kx][5] = bq.y; wk[kx][6] = bq.z; wk[kx][7] = bq.w;
         }
 #pragma unroll
-        for (int j = 0; j < DW_XT + DW_K - 1; ++j) {   // input columns x0-3 .. x0+DW_XT+2
-            const int ix = x0 + j - DW_R;
-            if ((unsigned)ix >= (unsigned)wd) continue;
-            const bf16x8d v = *reinterpret_cast<const bf16x8d *>(row + (int64_t)ix * c);
+        for (int j = 0; j < DW_XT + DW_K - 1; ++j) {
+            const bf16x8d v = __builtin_bit_cast(bf16x8d, raw[j]);
             float f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const __bf16 *__rest
     for (int k = 0; k <= DW_K; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    const __amdgpu_buffer_rsrc_t xr = buf_rsrc(x, (unsigned)(pixels * c * 2));
     if (live) {
         for (int64_t p = p0 + lane; p < min(p0 + DWG_PIX, pixels); p += DWG_LANES) {
             const int ox = (int)(p % wd);
@@ -123,14 +139,19 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const __bf16 *__rest
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[DW_K][e] += gf[e];
             }
+            // r06: branch-free (see dwconv7_nhwc_bf16_kernel): the seven pieces of the kernel row as buffer loads, out of range = zero
             const int iy = oy + ky - DW_R;
-            if ((unsigned)iy >= (unsigned)h) continue;
-            const __bf16 *row = x + (((int64_t)b * h + iy) * wd) * c + c0;
+            const bool rowok = (unsigned)iy < (unsigned)h;
+            const unsigned rowoff = (unsigned)(((((int64_t)b * h + (rowok ? iy : 0)) * wd) * c + c0) * 2);
+            buf_f32x4 raw[DW_K];
 #pragma unroll
             for (int kx = 0; kx < DW_K; ++kx) {
                 const int ix = ox + kx - DW_R;
-                if ((unsigned)ix >= (unsigned)wd) continue;
-                const bf16x8d v = *reinterpret_cast<const bf16x8d *>(row + (int64_t)ix * c);
+                raw[kx] = buf_load4(xr, (rowok && (unsigned)ix < (unsigned)wd) ? rowoff + (unsigned)(ix * c * 2) : BUF_OOB, 0);
+            }
+#pragma unroll
+            for (int kx = 0; kx < DW_K; ++kx) {
+                const bf16x8d v = __builtin_bit_cast(bf16x8d, raw[kx]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[kx][e] = fmaf((float)v[e], gf[e], acc[kx][e]);
             }
@@ -191,7 +212,7 @@ extern "C" int s2d_dwconv7_nhwc_bf16(const void *x, const float *weight, const f
         return S2D_ERR_UNSUPPORTED;
     }
     const int64_t total = (int64_t)n * h * ((w + DW_XT - 1) / DW_XT) * (c / 8);
-    const size_t lds = (size_t)DW_TAPS * c * sizeof(float);
+    const size_t lds = (size_t)DW_TAPS * (c + 4) * sizeof(float);
     const dim3 grid((unsigned)ceil_div(total, 256)), blk(256);
     if (flip) {
         static size_t attr = 48 * 1024;
