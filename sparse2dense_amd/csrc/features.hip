@@ -4,6 +4,7 @@
 //   * SparseConvTensor.dense() scatter and its gather backward (scn.py:173-176)
 // Reductions are two-pass and order-fixed (deterministic; SyncBN all-reduces the [2C] vectors).
 #include "s2d_common.h"
+#include <cstdlib>
 
 namespace s2d {
 
@@ -675,8 +676,17 @@ static RedPlan row_plan_bf16(int64_t n, int c) {
     RedPlan p;
     const int c8 = c / 8;
     const int lanes = RED_THREADS / c8 > 0 ? RED_THREADS / c8 : 1;
-    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * 16);
-    if (nb > 1024) nb = 1024;   // ~4 resident workgroups per CU, each streaming >= 16 rows per thread
+    // rows per thread (S2D_ROW_RPT: A/B hook).  r06: 8 instead of 16 - a 128-channel map of 141 376 pixels then runs as 1 105 workgroups
+    // instead of 553 (two trips of four rows per thread instead of four): the statistics / backward-sum passes are latency-bound at these
+    // sizes, not bandwidth-bound (measured 4 / 6 / 8 / 16 / 32 rows: 14.1 / 13.0 / 13.3 / 16.2 / 23.9 us for the backward sums of that map)
+    static int rpt = 0;
+    if (!rpt) {
+        const char *e = getenv("S2D_ROW_RPT");
+        rpt = e ? atoi(e) : 8;
+        if (rpt < 4 || rpt > 64) rpt = 8;
+    }
+    int64_t nb = ceil_div(n > 0 ? n : 1, (int64_t)lanes * rpt);
+    if (nb > 2048) nb = 2048;
     p.nblocks = (int)nb;
     p.rows_per_block = (int)ceil_div(n > 0 ? n : 1, nb);
     p.lds = (size_t)lanes * 2 * c * sizeof(float);
