@@ -41,7 +41,7 @@ typedef short s16x8w __attribute__((ext_vector_type(8)));
 // = the weight gradient of ConvTranspose2d(4,2,1) (A = its input, B = dY: [Cin][Cout][4][4]) and of a stride-2 3x3 conv (A = dY,
 // B = its input: [Cout][Cin][3][3]).  The B tile holds 31 * 2 + KS pixels and the transpose reads walk it with a two-pixel row stride;
 // its rows are padded by 16 B instead of 32 so that the doubled stride still spreads eight rows over all banks.
-template <int TCO, int TCI, int KS = 3, int STRIDE = 1>
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, bool DEEP = false>
 struct WgCfg {
     static constexpr int WCI = TCI >= 128 ? (TCO >= 128 ? 4 : 8) : 4;   // waves across ci
     static constexpr int WCO = 8 / WCI;                                 // waves across co
@@ -54,8 +54,11 @@ struct WgCfg {
     static constexpr int B_CHUNKS = (NB * CPR_B + 63) / 64 * 64;
     static constexpr int A_BYTES = A_CHUNKS * 16, B_BYTES = B_CHUNKS * 16;
     static constexpr int CHUNKS = A_CHUNKS + B_CHUNKS;
-    static constexpr int NS = 4;                                        // LDS ring depth: 3 K-steps of loads in flight
+    // LDS ring depth: NS - 1 K-steps staged ahead, NS - 2 still in flight behind the wait.  DEEP: as many slots as the 160 KB hold (<= 8)
+    static constexpr int NS_FIT = (160 * 1024) / (A_BYTES + B_BYTES);
+    static constexpr int NS = DEEP ? (NS_FIT > 8 ? 8 : NS_FIT) : 4;
     static constexpr size_t LDS = NS * (size_t)(A_BYTES + B_BYTES);
+    static_assert(NS >= 4, "ring too shallow");
     static_assert(MI >= 1 && NJ >= 1, "bad tiling");
 };
 
@@ -83,12 +86,17 @@ __device__ __forceinline__ bf16x8w tr_pack(const i32x2w &lo, const i32x2w &hi) {
 
 // KS = kernel size: 3, or 1 (the 1x1 convs: one "kernel row", one kx tap, the same transposed-operand pipeline)
 // KXN = kx taps per workgroup (blockIdx.y = ky * (KS / KXN) + kx group): 4x4 kernels run two per workgroup to stay in registers
-template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
+template <int N>
+__device__ __forceinline__ void wg_wait_vm() {   // N younger loads may stay in flight; own LDS reads done
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS, bool DEEP = false>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
                                                             const __bf16 *__restrict__ zero_page, int n_img, int H, int W, int cin,
                                                             int cout, int pad, int steps_per_block, float *__restrict__ partial,
                                                             float *__restrict__ dbias_partial) {
-    typedef WgCfg<TCO, TCI, KS, STRIDE> C;
+    typedef WgCfg<TCO, TCI, KS, STRIDE, DEEP> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto abuf = [&](int b) -> char * { return smem + b * (C::A_BYTES + C::B_BYTES); };
     const unsigned smem_addr = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
@@ -244,10 +252,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_kernel(const __bf16 *__rest
         }
         // step i+1 landed (in every wave after the barrier); the two younger steps stay in flight
         if (more) {
-            if (nl == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if (nl == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else if (nl == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            constexpr int FL = C::NS - 2;   // K-steps left in flight
+            if (nl == 4) wg_wait_vm<4 * FL>();
+            else if (nl == 3) wg_wait_vm<3 * FL>();
+            else if (nl == 2) wg_wait_vm<2 * FL>();
+            else wg_wait_vm<FL>();
         } else {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
@@ -382,11 +391,21 @@ static WgPlan wg_plan(int n_img, int h, int w, int cin, int cout, int pad, int k
     return p;
 }
 
-template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
-static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
+// S2D_WG_RING_DEEP=0: the four-slot ring everywhere (the r01-r05 kernel)
+static bool wg_ring_deep() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("S2D_WG_RING_DEEP");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v != 0;
+}
+
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS, bool DEEP = false>
+static int wg_launch_ring(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
                      int cout, int pad, float *partial, hipStream_t st, float *dbias_partial = nullptr) {
-    typedef WgCfg<TCO, TCI, KS, STRIDE> C;
-    auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS, STRIDE, KXN>;
+    typedef WgCfg<TCO, TCI, KS, STRIDE, DEEP> C;
+    auto kern = conv3x3_wgrad_kernel<TCO, TCI, KS, STRIDE, KXN, DEEP>;
     static bool attr_set = false;   // once per instantiation (idempotent if raced)
     if (C::LDS > 48 * 1024 && !attr_set) {
         S2D_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
@@ -397,6 +416,14 @@ static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const _
                        dbias_partial);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+template <int TCO, int TCI, int KS = 3, int STRIDE = 1, int KXN = KS>
+static int wg_launch(const WgPlan &p, const __bf16 *x, const __bf16 *dy, const __bf16 *zero_page, int n_img, int h, int w, int cin,
+                     int cout, int pad, float *partial, hipStream_t st, float *dbias_partial = nullptr) {
+    if (wg_ring_deep())
+        return wg_launch_ring<TCO, TCI, KS, STRIDE, KXN, true>(p, x, dy, zero_page, n_img, h, w, cin, cout, pad, partial, st, dbias_partial);
+    return wg_launch_ring<TCO, TCI, KS, STRIDE, KXN, false>(p, x, dy, zero_page, n_img, h, w, cin, cout, pad, partial, st, dbias_partial);
 }
 
 }  // namespace s2d
