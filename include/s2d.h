@@ -335,6 +335,26 @@ int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks, int64_t n
                                     float momentum, float *mean, float *invstd, float *scale, float *shift, float *running_mean,
                                     float *running_var, int64_t *batches_tracked, void *ws, size_t ws_bytes, s2d_stream_t stream);
 
+/* Batch-norm backward sums out of the data-gradient conv (r06; rpn.py:126-145 conv -> BatchNorm2d -> ReLU chains, rpn.py:186-253
+ * conv -> BatchNorm2d -> GELU groups; replaces the reduction half of the cuDNN batch-norm backward there).  When the conv being
+ * differentiated reads the output of y = act(z * scale + shift) (act: 0 none, 1 ReLU, 2 exact GELU), its data gradient IS that layer's
+ * dY: the *_bnbwd forms of the conv entries take z (bf16 [n][h][w][cout of this launch]) and the layer's fp32 scale / shift and write,
+ * next to dY, the per-tile sums (sum g, sum g z), g = dY act'(z scale + shift) over the stored bf16 dY, to bn_partial[tiles][2][cout]
+ * (tiles = s2d_conv2d3x3_stats_tiles / s2d_conv2d1x1_stats_tiles of the same launch shape).  s2d_bn_partials_bwd_finalize_ws_f32 folds
+ * them (fixed order) into dgamma, dbeta and the coefficients a, b, d of s2d_bnrow_bwd_apply_ld_bf16 - no pass over (dY, z) in between.
+ * *_supported: the launch plan of the shape takes the kernel that carries the epilogue (stride 1). */
+int s2d_conv2d3x3_bnbwd_supported(int cin, int cout, int pad, int stride);
+int s2d_conv2d3x3_nhwc_bf16_bnbwd(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin, int cout,
+                                  int pad, void *y, const void *bn_z, const float *bn_scale, const float *bn_shift, int bn_act,
+                                  float *bn_partial, s2d_stream_t stream);
+int s2d_conv2d1x1_bnbwd_supported(int cin, int cout);
+int s2d_conv2d1x1_nhwc_bf16_bnbwd(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin, int cout,
+                                  void *y, const void *bn_z, const float *bn_scale, const float *bn_shift, int bn_act, float *bn_partial,
+                                  s2d_stream_t stream);
+int s2d_bn_partials_bwd_finalize_ws_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *mean,
+                                        const float *invstd, float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                        size_t ws_bytes, s2d_stream_t stream);
+
 /*
  * Row-major bf16 batch norm: nn.BatchNorm2d (+ the ReLU that follows it) on NHWC bf16 activations
  * viewed as [n = N*H*W rows][c] (BEV neck and head: rpn.py:126-145, center_head.py:209-232;

@@ -256,6 +256,14 @@ SIGNATURES = {
     "s2d_bn_partials_finalize_ws_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p,
                                                        ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_conv2d3x3_bnbwd_supported": (ctypes.c_int, [ctypes.c_int] * 4),
+    "s2d_conv2d3x3_nhwc_bf16_bnbwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p,
+                                                                                                    ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_conv2d1x1_bnbwd_supported": (ctypes.c_int, [ctypes.c_int] * 2),
+    "s2d_conv2d1x1_nhwc_bf16_bnbwd": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p,
+                                                                                                    ctypes.c_int, c_f32p, ctypes.c_void_p]),
+    "s2d_bn_partials_bwd_finalize_ws_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                           c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bn_partials_sum_f32": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_f32p, ctypes.c_int,
                                                ctypes.c_void_p]),
     "s2d_bn_partials_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -134,15 +134,37 @@ template <int BN, int MI = 4, bool UP = false>
 __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[MI][BN / 32], const float *__restrict__ bias, __bf16 *__restrict__ y,
                                               int64_t m0, int64_t m_total, int cout, int blk_n, int wm, int wn, int r, int q,
                                               char *smem, float *__restrict__ stats_partial, int tile, int up_h = 0, int up_w = 0,
-                                              int up_p = 0, int up_q = 0) {
+                                              int up_p = 0, int up_q = 0, const BnBwd bb = BnBwd{}) {
     constexpr int NT = BN / 32;
     const int co_base = blk_n * BN + wn * (BN / 2);
-    float bv[NT], s1[NT], s2[NT];
+    float bv[NT], s1[NT], s2[NT], bsc[NT], bsh[NT];
+    const bool bnb = bb.z != nullptr;   // block-uniform: the sums are the backward sums of the batch norm whose output gradient this is
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         bv[j] = bias ? bias[co_base + r * NT + j] : 0.f;
         s1[j] = 0.f;
         s2[j] = 0.f;
+        bsc[j] = bnb ? bb.scale[co_base + r * NT + j] : 0.f;
+        bsh[j] = bnb ? bb.shift[co_base + r * NT + j] : 0.f;
+    }
+    // batch-norm backward mode: every z piece of the tile is requested before the first one is used (one load latency, not 4 MI of them:
+    // the first version loaded inside the store loop and a 128 x 128 tile's epilogue went from ~3 to ~20 us)
+    constexpr int ZW = NT / 2;               // 32-bit words of z per (pixel, lane)
+    unsigned zw[MI][4][ZW];
+    if (bnb) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t m = m0 + 16 * MI * wm + 16 * i + 4 * q + reg;
+                const unsigned *zp = reinterpret_cast<const unsigned *>(bb.z + (m < m_total ? m : m_total - 1) * cout + co_base + r * NT);
+                if (ZW == 2) {
+                    const uint2 t2 = *reinterpret_cast<const uint2 *>(zp);
+                    zw[i][reg][0] = t2.x; zw[i][reg][ZW - 1] = t2.y;
+                } else {
+                    zw[i][reg][0] = zp[0];
+                }
+            }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -151,19 +173,34 @@ __device__ __forceinline__ void conv_epilogue(f32x4c (&acc)[MI][BN / 32], const 
             const int64_t m = m0 + 16 * MI * wm + 16 * i + 4 * q + reg;
             if (m < m_total) {
                 __bf16 v[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    v[j] = (__bf16)(acc[i][j][reg] + bv[j]);
-                    const float f = (float)v[j];
-                    s1[j] += f;
-                    s2[j] += f * f;
-                }
                 int64_t mo = m;
                 if (UP) {
                     const int j = (int)(m % up_w);
                     const int64_t t = m / up_w;
                     const int i = (int)(t % up_h);
                     mo = ((t / up_h * 2 * up_h) + 2 * i + up_p) * (2 * up_w) + 2 * j + up_q;
+                }
+                if (bnb) {   // (never with UP: the launchers of the transposed forms pass no BnBwd)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        v[j] = (__bf16)(acc[i][j][reg] + bv[j]);
+                        const unsigned w = zw[i][reg][j / 2];
+                        const float zf = __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));   // bf16 -> fp32
+                        const float pre = fmaf(zf, bsc[j], bsh[j]);
+                        float g = (float)v[j];
+                        if (bb.act == 1) g = pre > 0.f ? g : 0.f;
+                        else if (bb.act == 2) g *= gelu_grad_f(pre);
+                        s1[j] += g;
+                        s2[j] += g * zf;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        v[j] = (__bf16)(acc[i][j][reg] + bv[j]);
+                        const float f = (float)v[j];
+                        s1[j] += f;
+                        s2[j] += f * f;
+                    }
                 }
                 __bf16 *dst = y + mo * cout + co_base + r * NT;
                 if (NT == 4) {
@@ -369,7 +406,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
                                                                     const float *__restrict__ bias,
                                                                     const __bf16 *__restrict__ zero_page, int n_img, int H, int W,
                                                                     int cin, int cout, int pad, int stride, __bf16 *__restrict__ y,
-                                                                    float *__restrict__ stats_partial) {
+                                                                    float *__restrict__ stats_partial, const BnBwd bb) {
     constexpr int NT = BN / 32;
     constexpr int BM = 32 * MI;                // output pixels per workgroup (2 x 2 waves, MI 16-row tiles per wave)
     constexpr int A_BYTES = BM * 32 * 2;       // 8 KiB at MI = 4
@@ -549,7 +586,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_k32_nhwc_bf16_kernel(const __b
     mfmas(fa[1], fb[1]);
 
     conv_epilogue<BN, MI, UP>(acc, bias, y, m0, m_total, cout, blk_n, wm, wn, r, q, smem, stats_partial,
-                              (int)(m0 / BM) + (UP ? (int)(blockIdx.z * ((m_total + BM - 1) / BM)) : 0), H, W, up_p, up_q);
+                              (int)(m0 / BM) + (UP ? (int)(blockIdx.z * ((m_total + BM - 1) / BM)) : 0), H, W, up_p, up_q, bb);
 }
 
 // ---- warp-specialised form of the kernel above (r06 experiment) ------------------------------------------------------
@@ -1036,9 +1073,8 @@ extern "C" int64_t s2d_conv2d3x3_stats_tiles(int n_img, int h, int w, int cin, i
     return ceil_div(m, conv_tile_rows(m, cin, cout, pad, stride));
 }
 
-extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
-                                       int n_img, int h, int w, int cin, int cout, int pad, int stride, void *y,
-                                       float *stats_partial, s2d_stream_t stream) {
+static int conv3x3_run(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h, int w, int cin,
+                       int cout, int pad, int stride, void *y, float *stats_partial, const BnBwd bb, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0 && (pad == 0 || pad == 1) &&
                       (stride == 1 || stride == 2), "conv2d3x3: bad argument");
     if (!s2d_conv2d3x3_supported(cin, cout)) {
@@ -1052,6 +1088,10 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     const int bn = conv_bn(cout);
     const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
     const bool shared_a = conv_use_shared_a(cin, bn, pad, stride);
+    if (bb.z && (shared_a || !conv_use_k32(bn))) {   // (callers ask s2d_conv2d3x3_bnbwd_supported first)
+        set_error("conv2d3x3: the batch-norm backward epilogue needs the 32-deep kernel (%d -> %d, pad %d, stride %d)", cin, cout, pad, stride);
+        return S2D_ERR_UNSUPPORTED;
+    }
     if (shared_a) {
         const size_t lds = 2 * (136 * 64 * 2) + 2 * (size_t)(64 * bn * 2);
         if (bn == 128) {
@@ -1083,9 +1123,9 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
 #define S2D_CONV_K32(BN_, MI_)                                                                                                  \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<BN_, MI_>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn), blk,         \
                        3 * (size_t)(32 * MI_ * 64 + 64 * BN_), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,      \
-                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial)
+                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, pad, stride, (__bf16 *)y, stats_partial, bb)
         static const int ws_env = conv_env_int("S2D_CONV_WS");   // r06 experiment: the warp-specialised form, 1 or 2 producer waves (stride 1, 128-wide blocks)
-        if (bn == 128 && (ws_env == 1 || ws_env == 2) && stride == 1) {
+        if (bn == 128 && (ws_env == 1 || ws_env == 2) && stride == 1 && !bb.z) {
             const int rows = conv_k32_rows(m, cout / bn);
 #define S2D_CONV_K32WS(MI_, NP_)                                                                                                      \
     hipLaunchKernelGGL((conv3x3_k32ws_nhwc_bf16_kernel<128, MI_, NP_>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn),             \
@@ -1135,6 +1175,30 @@ extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight,
     return S2D_OK;
 }
 
+extern "C" int s2d_conv2d3x3_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page,
+                                       int n_img, int h, int w, int cin, int cout, int pad, int stride, void *y,
+                                       float *stats_partial, s2d_stream_t stream) {
+    return conv3x3_run(x, packed_weight, bias, zero_page, n_img, h, w, cin, cout, pad, stride, y, stats_partial, BnBwd{}, stream);
+}
+
+/* The conv as the DATA GRADIENT of the layer behind a batch norm + activation (include/s2d.h): y = dY of that batch norm, and
+   bn_partial[tile][2][cout] receives its backward sums (sum g, sum g z; g = dY act'(z scale + shift)) - the slabs
+   s2d_bn_partials_bwd_finalize_f32 folds.  Tiles as s2d_conv2d3x3_stats_tiles. */
+extern "C" int s2d_conv2d3x3_bnbwd_supported(int cin, int cout, int pad, int stride) {
+    if (!s2d_conv2d3x3_supported(cin, cout) || stride != 1) return 0;
+    const int bn = conv_bn(cout);
+    return !conv_use_shared_a(cin, bn, pad, stride) && conv_use_k32(bn);
+}
+
+extern "C" int s2d_conv2d3x3_nhwc_bf16_bnbwd(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin,
+                                             int cout, int pad, void *y, const void *bn_z, const float *bn_scale, const float *bn_shift,
+                                             int bn_act, float *bn_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(bn_z && bn_scale && bn_shift && bn_partial && bn_act >= 0 && bn_act <= 2, "conv2d3x3_bnbwd: bad argument");
+    BnBwd bb;
+    bb.z = (const __bf16 *)bn_z; bb.scale = bn_scale; bb.shift = bn_shift; bb.act = bn_act;
+    return conv3x3_run(x, packed_weight, nullptr, zero_page, n_img, h, w, cin, cout, pad, 1, y, bn_partial, bb, stream);
+}
+
 
 // ---- stride-2 transposed forms and the 4x4 stride-2 conv on the 32-deep kernel -----------------------------------------------------
 // decoder_1 / decoder_2 of the S2D module (/root/reference/det3d/models/necks/rpn.py:217-231: nn.ConvTranspose2d(256, 256, 4, 2, 1)
@@ -1181,18 +1245,18 @@ extern "C" int s2d_convup_nhwc_bf16(const void *x, const void *packed_weight, co
         if (ks == 4)
             hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 4, true>), dim3(xcd_grid(ceil_div(m, 128)), nc / 64, 4), dim3(256),
                                3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial);
+                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial, BnBwd{});
         else
             hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 3, true>), dim3(xcd_grid(ceil_div(m, 128)), nc / 64, 4), dim3(256),
                                3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,
-                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial);
+                               (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial, BnBwd{});
         S2D_LAUNCH_CHECK();
         return S2D_OK;
     }
 #define S2D_CONVUP(MI_, KS_)                                                                                                       \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, KS_, true>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), nc / 128, 4),     \
                        dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \
-                       bias, (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial)
+                       bias, (const __bf16 *)zero_page, n_img, h, w, kc, nc, 1, 2, (__bf16 *)y, stats_partial, BnBwd{})
     if (ks == 4) {
         if (rows == 128) S2D_CONVUP(4, 4); else if (rows == 96) S2D_CONVUP(3, 4); else S2D_CONVUP(2, 4);
     } else {
@@ -1231,7 +1295,7 @@ extern "C" int s2d_conv2d4x4s2_nhwc_bf16(const void *x, const void *packed_weigh
     if (conv_bn(cout) == 64) {
         hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<64, 4, 4, false>), dim3(xcd_grid(ceil_div(m, 128)), cout / 64), dim3(256),
                            3 * (size_t)(128 * 64 + 64 * 64), st, (const __bf16 *)x, (const __bf16 *)packed_weight, (const float *)nullptr,
-                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr);
+                           (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr, BnBwd{});
         S2D_LAUNCH_CHECK();
         return S2D_OK;
     }
@@ -1239,7 +1303,7 @@ extern "C" int s2d_conv2d4x4s2_nhwc_bf16(const void *x, const void *packed_weigh
 #define S2D_CONV4(MI_)                                                                                                             \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<128, MI_, 4, false>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / 128),       \
                        dim3(256), 3 * (size_t)(32 * MI_ * 64 + 64 * 128), st, (const __bf16 *)x, (const __bf16 *)packed_weight,    \
-                       (const float *)nullptr, (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr)
+                       (const float *)nullptr, (const __bf16 *)zero_page, n_img, h, w, cin, cout, 1, 2, (__bf16 *)y, (float *)nullptr, BnBwd{})
     if (rows == 128) S2D_CONV4(4); else if (rows == 96) S2D_CONV4(3); else S2D_CONV4(2);
 #undef S2D_CONV4
     S2D_LAUNCH_CHECK();
@@ -1282,8 +1346,8 @@ extern "C" int64_t s2d_conv2d1x1_stats_tiles(int n_img, int h, int w, int cin, i
     return ceil_div(m, conv1x1_rows(m, cin, cout));
 }
 
-extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
-                                       int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream) {
+static int conv1x1_run(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h, int w, int cin,
+                       int cout, void *y, float *stats_partial, const BnBwd bb, s2d_stream_t stream) {
     S2D_CHECK_ARG(x && packed_weight && zero_page && y && n_img > 0 && h > 0 && w > 0, "conv2d1x1: bad argument");
     if (!s2d_conv2d3x3_supported(cin, cout)) {
         set_error("conv2d1x1: unsupported channels %d -> %d", cin, cout);
@@ -1294,11 +1358,15 @@ extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight,
     const dim3 grid(xcd_grid(ceil_div(m, 128)), cout / bn), blk(256);
     const size_t lds = (size_t)2 * (128 * 64 * 2 + 64 * bn * 2);
     hipStream_t st = (hipStream_t)stream;
+    if (bb.z && !conv1x1_use_k32(cin)) {
+        set_error("conv2d1x1: the batch-norm backward epilogue needs the 32-deep kernel (%d -> %d)", cin, cout);
+        return S2D_ERR_UNSUPPORTED;
+    }
     if (conv1x1_use_k32(cin)) {
 #define S2D_CONV1_K32(BN_, MI_)                                                                                                    \
     hipLaunchKernelGGL((conv3x3_k32_nhwc_bf16_kernel<BN_, MI_, 1, false>), dim3(xcd_grid(ceil_div(m, 32 * MI_)), cout / bn), blk,   \
                        3 * (size_t)(32 * MI_ * 64 + 64 * BN_), st, (const __bf16 *)x, (const __bf16 *)packed_weight, bias,         \
-                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, 0, 1, (__bf16 *)y, stats_partial)
+                       (const __bf16 *)zero_page, n_img, h, w, cin, cout, 0, 1, (__bf16 *)y, stats_partial, bb)
         if (bn == 128) {
             const int rows = conv1x1_rows(m, cin, cout);
             if (rows == 128) S2D_CONV1_K32(128, 4); else if (rows == 96) S2D_CONV1_K32(128, 3); else S2D_CONV1_K32(128, 2);
@@ -1324,6 +1392,23 @@ extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight,
 #undef S2D_CONV1_LAUNCH
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+extern "C" int s2d_conv2d1x1_nhwc_bf16(const void *x, const void *packed_weight, const float *bias, const void *zero_page, int n_img, int h,
+                                       int w, int cin, int cout, void *y, float *stats_partial, s2d_stream_t stream) {
+    return conv1x1_run(x, packed_weight, bias, zero_page, n_img, h, w, cin, cout, y, stats_partial, BnBwd{}, stream);
+}
+
+extern "C" int s2d_conv2d1x1_bnbwd_supported(int cin, int cout) { return s2d_conv2d3x3_supported(cin, cout) && conv1x1_use_k32(cin); }
+
+/* 1x1 data gradient with the batch-norm backward epilogue (see s2d_conv2d3x3_nhwc_bf16_bnbwd); tiles as s2d_conv2d1x1_stats_tiles */
+extern "C" int s2d_conv2d1x1_nhwc_bf16_bnbwd(const void *x, const void *packed_weight, const void *zero_page, int n_img, int h, int w, int cin,
+                                             int cout, void *y, const void *bn_z, const float *bn_scale, const float *bn_shift, int bn_act,
+                                             float *bn_partial, s2d_stream_t stream) {
+    S2D_CHECK_ARG(bn_z && bn_scale && bn_shift && bn_partial && bn_act >= 0 && bn_act <= 2, "conv2d1x1_bnbwd: bad argument");
+    BnBwd bb;
+    bb.z = (const __bf16 *)bn_z; bb.scale = bn_scale; bb.shift = bn_shift; bb.act = bn_act;
+    return conv1x1_run(x, packed_weight, nullptr, zero_page, n_img, h, w, cin, cout, y, bn_partial, bb, stream);
 }
 
 

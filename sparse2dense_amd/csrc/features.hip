@@ -486,10 +486,7 @@ typedef __bf16 bf16x8r __attribute__((ext_vector_type(8)));
 constexpr int ROW_UNROLL = 4;   // rows per thread and trip in the row-major bf16 kernels
 
 // activation fused behind the normalisation: 0 none, 1 ReLU, 2 exact (erf) GELU = nn.GELU() of the S2D module's conv-BN-GELU groups
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float v) {
-    return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
-}
+// (gelu_f / gelu_grad_f: s2d_common.h - the conv epilogue that emits this layer's backward sums evaluates the same expression)
 
 // ACT / HAS_Y are compile-time: with run-time flags hipcc keeps a uniform branch per element in the unrolled bodies
 template <bool BWD, int ACT, bool HAS_Y>
@@ -1210,6 +1207,22 @@ extern "C" int s2d_bn_partials_finalize_ws_f32(const float *partial, int nblocks
     nblocks = partials_prefold(partial, nblocks, c, ws, ws_bytes, st);
     hipLaunchKernelGGL(bn_reduce_finalize_fwd_kernel, dim3(c), dim3(256), 0, st, partial, nblocks, (float)n, gamma, beta, eps,
                        momentum, c, mean, invstd, scale, shift, running_mean, running_var, (long long *)batches_tracked);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+
+/* Backward counterpart: partial[nblocks][2][c] = per-tile (sum g, sum g x) written by the epilogue of the data-gradient conv that produced
+ * this batch norm's output gradient (s2d_conv2d3x3_nhwc_bf16_bnbwd / s2d_conv2d1x1_nhwc_bf16_bnbwd) -> dgamma, dbeta and the per-channel
+ * coefficients a, b, d of s2d_bnrow_bwd_apply_ld_bf16: the reduction pass over (dY, x) of s2d_bnrow_bwd_reduce_finalize_ld_bf16 is gone. */
+extern "C" int s2d_bn_partials_bwd_finalize_ws_f32(const float *partial, int nblocks, int64_t n, int c, const float *gamma, const float *mean,
+                                                   const float *invstd, float *dgamma, float *dbeta, float *a, float *b, float *d, void *ws,
+                                                   size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(partial && nblocks > 0 && n > 0 && c > 0 && gamma && mean && invstd && dgamma && dbeta && a && b && d,
+                  "bn_partials_bwd_finalize: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    nblocks = partials_prefold(partial, nblocks, c, ws, ws_bytes, st);
+    hipLaunchKernelGGL(bn_reduce_finalize_bwd_kernel, dim3(c), dim3(256), 0, st, partial, nblocks, (float)n, gamma, mean, invstd, c, dgamma,
+                       dbeta, a, b, d, false);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }

@@ -72,6 +72,22 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t x, const FastDiv &f) {
 #endif
 
 #if defined(__HIPCC__)
+// exact (erf) GELU = nn.GELU() and its derivative, as fused behind the row-major batch norm (features.hip) and evaluated by the conv
+// epilogue that produces that batch norm's backward sums (conv2d_nhwc.hip): one definition, the two must agree on every element
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float v) {
+    return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+}
+
+// A data-gradient conv whose output IS the gradient dY of a batch-norm + activation layer y = act(z * scale + shift) (act: 1 ReLU, 2 GELU)
+// emits that layer's two backward sums per tile from its epilogue - sum g and sum g * z with g = dY * act'(z * scale + shift), over the
+// STORED bf16 dY - in the [tile][2][c] slab layout the statistics epilogue uses; z == nullptr: plain epilogue.
+struct BnBwd {
+    const __bf16 *z = nullptr;
+    const float *scale = nullptr, *shift = nullptr;
+    int act = 0;
+};
+
 // Planar (channel-major) tensors through buffer instructions: ONE per-lane 32-bit byte offset plus a scalar offset per access,
 // where flat global pointers cost a 64-bit per-lane address per plane (two VGPRs each: 160 for a 32 + 16 + 32-plane kernel), and
 // a per-lane offset >= num_records reads as zero / drops the store (masked lanes need no branch).  The range check looks at

@@ -220,9 +220,31 @@ def _pack_weights(weight, transpose_flip):
     return packed
 
 
-def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
+BN_BWD_FOLD = 1   # (read from the environment below)
+STATS = {"bn_bwd_folded": 0, "bn_bwd_reduced": 0}   # batch-norm backward passes that took the conv epilogue's sums / their own reduction pass
+
+
+def _bn_src_of(x):
+    """the (z, fin, act) tag a training-mode FastBatchNorm2d leaves on its output (see _BNRowFn.forward), if x still is that tensor"""
+    src = getattr(x, "_s2d_bn_src", None) if BN_BWD_FOLD else None
+    if src is None or src[0].shape != x.shape or src[3] != x._version or (src[2] == 2 and int(BN_BWD_FOLD) < 2):
+        return None
+    return src
+
+
+def _tag_bn_bwd(dx, partial):
+    """dx is the output gradient of a batch norm and `partial` holds that layer's backward sums (conv epilogue): _BNRowFn.backward reads the
+    tag - valid only while dx is the very tensor the kernel wrote (autograd accumulating a second consumer's gradient into it bumps
+    the version, a fresh sum tensor has no tag)"""
+    dx._s2d_bnbwd = (partial, dx._version)
+    return dx
+
+
+def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False, bn_bwd=None):
     """x: bf16 [N,cin,H,W] in channels_last memory -> bf16 [N,cout,Ho,Wo] channels_last.  bn_stats: also returns the
-    per-tile (sum, sumsq) slabs [tiles, 2, cout] of the output (the statistics pass of a following batch norm)."""
+    per-tile (sum, sumsq) slabs [tiles, 2, cout] of the output (the statistics pass of a following batch norm).
+    bn_bwd = (z, fin, act, ...): this launch is the DATA GRADIENT of a conv that read act(bn(z)); returns (y, partial) with the batch norm's
+    backward sums per tile (csrc/conv2d_nhwc.hip `BnBwd`)."""
     lib = _lib.load()
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
     n, _, h, w = x.shape
@@ -238,13 +260,22 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
                    end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
     partial = (torch.empty((lib.s2d_conv2d3x3_stats_tiles(n, h, w, cin, cout, pad, stride), 2, cout), dtype=torch.float32,
-                           device=x.device) if bn_stats else None)
-    check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
-                                      pad, stride, _ptr(y), _ptr(partial), _stream()), "s2d_conv2d3x3_nhwc_bf16")
+                           device=x.device) if (bn_stats or bn_bwd is not None) else None)
+    if bn_bwd is not None:
+        z, fin, act = bn_bwd[0], bn_bwd[1], bn_bwd[2]
+        assert bias is None and not bn_stats and stride == 1 and z.shape == y.shape and z.dtype == torch.bfloat16 \
+            and z.is_contiguous(memory_format=torch.channels_last) and fin.shape == (4, cout)
+        fp = fin.data_ptr()
+        check(lib.s2d_conv2d3x3_nhwc_bf16_bnbwd(_ptr(x), _ptr(packed), _ptr(_zero_page(x.device)), n, h, w, cin, cout, pad, _ptr(y), _ptr(z),
+                                                fp + 8 * cout, fp + 12 * cout, int(act), _ptr(partial), _stream()),
+              "s2d_conv2d3x3_nhwc_bf16_bnbwd")
+    else:
+        check(lib.s2d_conv2d3x3_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout,
+                                          pad, stride, _ptr(y), _ptr(partial), _stream()), "s2d_conv2d3x3_nhwc_bf16")
     if rec is not None:
         rec["end"].record()
         H.PROFILE.append(rec)
-    return (y, partial) if bn_stats else y
+    return (y, partial) if (bn_stats or bn_bwd is not None) else y
 
 
 # which weight gradients take the hand-written transpose-read kernel (csrc/conv2d_wgrad.hip) instead of MIOpen:
@@ -254,6 +285,12 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False):
 import os as _os
 from . import side as _side
 WGRAD_HIP = {"0": False, "1": True}.get(_os.environ.get("S2D_WGRAD_HIP", ""), "auto")
+# r06: the data-gradient conv behind a conv -> BatchNorm2d -> ReLU layer writes that batch norm's backward sums from its epilogue (the
+# reduction pass over (dY, z) of the batch-norm backward is skipped).  Measured on the benchmarked step (4 x 150 k points): the ten ReLU layers
+# of the RPN trunk save 137 us of `row_reduce` for ~90 us of longer conv epilogues (z is read once more, one exposed load latency per tile);
+# behind a GELU the erf / exp per element cost +40 us per launch against the 30 us pass they replace - so "1" (default) folds ReLU / no
+# activation only, "2" also GELU, "0" nothing.
+BN_BWD_FOLD = {"0": 0, "2": 2}.get(_os.environ.get("S2D_BN_BWD_FOLD", "1"), 1)
 
 
 def _wgrad_hip(cin, cout):
@@ -295,11 +332,14 @@ def _nhwc_bf16(t):
 
 class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, stride, bn_stats):
+    def forward(ctx, x, weight, bias, pad, stride, bn_stats, bn_src=None):
         xb = _nhwc_bf16(x)
         cout, cin = weight.shape[0], weight.shape[1]
         ctx.save_for_backward(xb, weight)
         ctx.pad, ctx.stride = pad, stride
+        # x is the output of a training-mode batch norm (+ activation): the data gradient below is that layer's dY
+        ctx.bn_src = bn_src if (bn_src is not None and xb is x and stride == 1
+                                and _lib.load().s2d_conv2d3x3_bnbwd_supported(cout, cin, 1, 1)) else None
         ctx.has_bias = bias is not None
         ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         b = None if bias is None else bias.detach().float().contiguous()
@@ -338,7 +378,10 @@ class _Conv3x3Fn(torch.autograd.Function):
                     src = dyb
                 else:
                     src = torch.nn.functional.pad(dyb, (1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
-                dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
+                if ctx.bn_src is not None:
+                    dx = _tag_bn_bwd(*conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1, bn_bwd=ctx.bn_src))
+                else:
+                    dx = conv3x3_nhwc(src, pack_weights(weight, transpose_flip=True), None, cout, cin, 1)
             if ctx.needs_input_grad[1] and _wgrad_hip(cin, cout):   # off the chain to the next layer: second stream when enabled (side.py)
                 if ctx.has_bias and ctx.needs_input_grad[2]:   # the bias gradient rides on the weight-gradient launch
                     def both():
@@ -360,7 +403,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()),
                   "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, _side.undefer(dw), _side.undefer(db), None, None, None
+        return dx, _side.undefer(dw), _side.undefer(db), None, None, None, None
 
 
 class Conv3x3(nn.Conv2d):
@@ -377,11 +420,12 @@ class Conv3x3(nn.Conv2d):
     def forward(self, x):
         if self._hip_ok(x):
             pad = self.padding[0] + self.absorbed_pad
+            src = _bn_src_of(x) if torch.is_grad_enabled() else None
             if self.emit_bn_stats and self.training and torch.is_grad_enabled():
-                y, partial = _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], True)
+                y, partial = _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], True, src)
                 y._s2d_bn_partial = partial   # read (forward pass only) by the FastBatchNorm2d that follows
                 return y
-            return _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], False)
+            return _Conv3x3Fn.apply(x, self.weight, self.bias, pad, self.stride[0], False, src)
         if self.absorbed_pad:
             x = torch.nn.functional.pad(x, (self.absorbed_pad,) * 4)
         return super().forward(x)
@@ -419,13 +463,15 @@ def _pack_weights_1x1(weight, transpose, with_dgrad=False):
     return cached_pack(weight, ("conv1x1", bool(transpose)), build)
 
 
-def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
-    """x: bf16 [N,cin,H,W] channels_last -> bf16 [N,cout,H,W] channels_last (+ the per-tile batch-norm statistics slabs)"""
+def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False, bn_bwd=None):
+    """x: bf16 [N,cin,H,W] channels_last -> bf16 [N,cout,H,W] channels_last (+ the per-tile batch-norm statistics slabs); bn_bwd: see
+    conv3x3_nhwc"""
     lib = _lib.load()
     assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] == cin
     n, _, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    partial = torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w, cin, cout), 2, cout), dtype=torch.float32, device=x.device) if bn_stats else None
+    partial = (torch.empty((lib.s2d_conv2d1x1_stats_tiles(n, h, w, cin, cout), 2, cout), dtype=torch.float32, device=x.device)
+               if (bn_stats or bn_bwd is not None) else None)
     from . import hip_ops as H
     rec = None
     if H.PROFILE is not None:   # bench.py roofline pass (the one-tap instantiation of the 32-deep tile kernel, or the 64-deep one)
@@ -438,12 +484,21 @@ def conv1x1_nhwc(x, packed, bias, cin, cout, bn_stats=False):
                    kname=(f"conv3x3_k32_nhwc_bf16_kernel<{bn}, {rows // 32}, 1, false>" if k32 else f"conv3x3_nhwc_bf16_kernel<{bn}, 2, 1>"),
                    start=torch.cuda.Event(enable_timing=True), end=torch.cuda.Event(enable_timing=True))
         rec["start"].record()
-    check(lib.s2d_conv2d1x1_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y),
-                                      _ptr(partial), _stream()), "s2d_conv2d1x1_nhwc_bf16")
+    if bn_bwd is not None:
+        z, fin, act = bn_bwd[0], bn_bwd[1], bn_bwd[2]
+        assert bias is None and not bn_stats and z.shape == y.shape and z.dtype == torch.bfloat16 \
+            and z.is_contiguous(memory_format=torch.channels_last) and fin.shape == (4, cout)
+        fp = fin.data_ptr()
+        check(lib.s2d_conv2d1x1_nhwc_bf16_bnbwd(_ptr(x), _ptr(packed), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y), _ptr(z),
+                                                fp + 8 * cout, fp + 12 * cout, int(act), _ptr(partial), _stream()),
+              "s2d_conv2d1x1_nhwc_bf16_bnbwd")
+    else:
+        check(lib.s2d_conv2d1x1_nhwc_bf16(_ptr(x), _ptr(packed), _ptr(bias), _ptr(_zero_page(x.device)), n, h, w, cin, cout, _ptr(y),
+                                          _ptr(partial), _stream()), "s2d_conv2d1x1_nhwc_bf16")
     if rec is not None:
         rec["end"].record()
         H.PROFILE.append(rec)
-    return (y, partial) if bn_stats else y
+    return (y, partial) if (bn_stats or bn_bwd is not None) else y
 
 
 def _pack_matrix_1x1(owner, tag, make, transpose=False):
@@ -498,10 +553,11 @@ def _channel_sums(dyb):
 
 class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_stats):
+    def forward(ctx, x, weight, bias, bn_stats, bn_src=None):
         xb = _nhwc_bf16(x)
         cout, cin = weight.shape[0], weight.shape[1]
         ctx.save_for_backward(xb, weight)
+        ctx.bn_src = bn_src if (bn_src is not None and xb is x and _lib.load().s2d_conv2d1x1_bnbwd_supported(cout, cin)) else None
         ctx.has_bias = bias is not None
         ctx.bias_p = bias   # (the parameter itself: side.run hands a deferred bias gradient to it)
         b = None if bias is None else bias.detach().float().contiguous()
@@ -521,7 +577,10 @@ class _Conv1x1Fn(torch.autograd.Function):
         n, _, h, w = xb.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin)
+            if ctx.bn_src is not None:
+                dx = _tag_bn_bwd(*conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin, bn_bwd=ctx.bn_src))
+            else:
+                dx = conv1x1_nhwc(dyb, _pack_weights_1x1(weight, True), None, cout, cin)
         if ctx.needs_input_grad[1]:
             want_db = bool(ctx.has_bias and ctx.needs_input_grad[2])   # the bias gradient rides on the weight-gradient launch
 
@@ -539,7 +598,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             ws = _ws(lib.s2d_bnrow_workspace_bytes(rows, cout), dyb.device)
             check(lib.s2d_bnrow_stats_bf16(_ptr(dyb), rows, cout, _ptr(stats), 0, _ptr(ws), ws.numel(), _stream()), "s2d_bnrow_stats_bf16")
             db = stats[:cout]
-        return dx, _side.undefer(dw), _side.undefer(db), None
+        return dx, _side.undefer(dw), _side.undefer(db), None, None
 
 
 class Conv1x1(nn.Conv2d):
@@ -557,11 +616,12 @@ class Conv1x1(nn.Conv2d):
 
     def forward(self, x):
         if self._hip_ok(x):
+            src = _bn_src_of(x) if torch.is_grad_enabled() else None
             if self.emit_bn_stats and self.training and torch.is_grad_enabled():
-                y, partial = _Conv1x1Fn.apply(x, self.weight, self.bias, True)
+                y, partial = _Conv1x1Fn.apply(x, self.weight, self.bias, True, src)
                 y._s2d_bn_partial = partial   # read (forward pass only) by the FastBatchNorm2d that follows
                 return y
-            return _Conv1x1Fn.apply(x, self.weight, self.bias, False)
+            return _Conv1x1Fn.apply(x, self.weight, self.bias, False, src)
         return super().forward(x)
 
 
@@ -914,6 +974,9 @@ class _BNRowFn(torch.autograd.Function):
         assert out is None or not (has_res and relu), "a ReLU behind a residual keeps y for its backward: not with a strided destination"
         ctx.save_for_backward(x, gamma, fin, count, y if (has_res and relu) else None)
         ctx.relu, ctx.sync, ctx.training, ctx.has_res = relu, sync, training, has_res
+        if training and not sync and not has_res and out is None and x.dim() == 4 and BN_BWD_FOLD:
+            # read by the conv that consumes y (Conv3x3 / Conv1x1 forward): its data gradient is this layer's dY and can emit our backward sums
+            y._s2d_bn_src = (x, fin, int(relu), y._version)
         # (a destination slice is a plain no-grad buffer written in place; the output is a fresh alias of it, so autograd neither sees an
         # in-place operation on a view - which would put a CopySlices with its copies into the backward - nor an input returned as is)
         return y if out is None else y.detach()
@@ -937,7 +1000,18 @@ class _BNRowFn(torch.autograd.Function):
         stream = _stream()
         out = torch.empty((5, c), dtype=torch.float32, device=dev)   # rows: dgamma, dbeta, a, b, d
         op = out.data_ptr()
-        if ctx.training and not ctx.sync:
+        tag = getattr(dy, "_s2d_bnbwd", None) if (ctx.training and not ctx.sync and not ctx.has_res and dy_ld == c and x.dim() == 4) else None
+        if tag is not None and (tag[1] != dy._version or tag[0].shape[2] != c):
+            tag = None
+        if tag is not None:   # the conv that produced dy summed (g, g x) per tile in its epilogue: fold the slabs, no pass over (dy, x)
+            part = tag[0]
+            pws = _ws(max(lib.s2d_bn_partials_sum_workspace_bytes(part.shape[0], c), 256), dev)
+            check(lib.s2d_bn_partials_bwd_finalize_ws_f32(part.data_ptr(), part.shape[0], rows, c, gamma.data_ptr(), fp, fp + rb, op, op + rb,
+                                                          op + 2 * rb, op + 3 * rb, op + 4 * rb, pws.data_ptr(), pws.numel(), stream),
+                  "s2d_bn_partials_bwd_finalize_ws_f32")
+            STATS["bn_bwd_folded"] += 1
+        elif ctx.training and not ctx.sync:
+            STATS["bn_bwd_reduced"] += 1
             check(lib.s2d_bnrow_bwd_reduce_finalize_ld_bf16(dy.data_ptr(), dy_ld, x.data_ptr(), _ptr(y), fp + 2 * rb, fp + 3 * rb, relu, rows,
                                                             c, gamma.data_ptr(), fp, fp + rb, op, op + rb, op + 2 * rb, op + 3 * rb,
                                                             op + 4 * rb, ws.data_ptr(), ws.numel(), stream),

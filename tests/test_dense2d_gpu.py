@@ -305,6 +305,91 @@ def test_conv_epilogue_bn_statistics_match_the_reduction_kernel(cin, cout, pad, 
         assert err <= (1e-2 if name in ("y", "dx", "dw") else 1e-4), (name, float(err))   # bf16 tensors may flip one rounding
 
 
+@pytest.mark.parametrize("kind,c0,c1,c2,act,hw", [("3x3", 64, 128, 128, "relu", (37, 29)), ("3x3", 128, 128, 64, "gelu", (21, 40)),
+                                                  ("1x1", 128, 256, 128, "gelu", (33, 20)), ("1x1", 256, 128, 256, "relu", (188, 188)),
+                                                  ("3x3", 128, 128, 128, "relu", (188, 188)), ("3x3pad0", 64, 64, 64, "relu", (30, 31))])
+def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(kind, c0, c1, c2, act, hw, monkeypatch):
+    """conv -> BN -> act -> conv -> BN -> act: the second conv's data gradient IS the first batch norm's dY and writes that layer's backward
+    sums (sum g, sum g z per tile) from its epilogue (csrc/conv2d_nhwc.hip `BnBwd`); the batch norm then folds the slabs instead of reading
+    (dY, z) again.  Same sums in a different fp32 order: per-channel results within 1e-4 of the stand-alone reduction pass, bf16 tensors within
+    one rounding; and the float64 CPU chain on the same bf16-rounded weights bounds both.  A batch-norm output with TWO consumers (autograd
+    sums the two gradients) must not take the slabs of either."""
+    import copy
+    from sparse2dense_amd import dense2d as D
+
+    def conv(ci, co):
+        if kind == "1x1":
+            return D.Conv1x1(ci, co, 1, bias=False)
+        return D.Conv3x3(ci, co, 3, padding=0 if kind == "3x3pad0" else 1, bias=False)
+    torch.manual_seed(11)
+    A = torch.nn.GELU if act == "gelu" else torch.nn.ReLU
+    net = torch.nn.Sequential(*D.fuse_bn_relu([conv(c0, c1), D.FastBatchNorm2d(c1, eps=1e-3, momentum=0.01), A(),
+                                               conv(c1, c2), D.FastBatchNorm2d(c2, eps=1e-3, momentum=0.01), A()])).cuda().train()
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, D.FastBatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.5, 0.5)
+    n = 4 if hw == (188, 188) else 3
+    x = torch.randn(n, c0, *hw, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for fold in (True, False):
+        monkeypatch.setattr(D, "BN_BWD_FOLD", 2 if fold else 0)   # 2: also behind a GELU (default 1: ReLU / none only)
+        m = copy.deepcopy(net)
+        for k in D.STATS:
+            D.STATS[k] = 0
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(xi)
+        (y.float() * torch.linspace(-1, 1, y.shape[-1], device="cuda")).sum().backward()
+        assert D.STATS["bn_bwd_folded"] == (1 if fold else 0) and D.STATS["bn_bwd_reduced"] == (1 if fold else 2), (fold, D.STATS)
+        outs[fold] = dict(y=y, dx=xi.grad, dw0=m[0].weight.grad, dw1=m[3].weight.grad, dgamma0=m[1].weight.grad, dbeta0=m[1].bias.grad,
+                          dgamma1=m[4].weight.grad, dbeta1=m[4].bias.grad)
+    for name, u in outs[True].items():
+        v = outs[False][name]
+        err = (u.float() - v.float()).abs().max() / v.float().abs().max().clamp(min=1e-9)
+        assert err <= (1e-2 if name in ("dx", "dw0") else 1e-4), (name, float(err))   # (dx / dw0 sit behind bf16 dz: one rounding may flip)
+    if hw != (188, 188):   # float64 on the CPU, bf16-rounded weights: the documented bf16-storage tolerance for both routes
+        ref = torch.nn.Sequential(*[torch.nn.Conv2d(l.in_channels, l.out_channels, l.kernel_size, padding=l.padding, bias=False)
+                                    if isinstance(l, torch.nn.Conv2d) else torch.nn.BatchNorm2d(l.num_features, eps=1e-3, momentum=0.01)
+                                    if isinstance(l, D.FastBatchNorm2d) else torch.nn.Identity() for l in net]).double()
+        with torch.no_grad():
+            for l, r in zip(net, ref):
+                if isinstance(l, torch.nn.Conv2d):
+                    r.weight.copy_(l.weight.to(torch.bfloat16).double().cpu())
+                elif isinstance(l, D.FastBatchNorm2d):
+                    r.weight.copy_(l.weight.double().cpu()); r.bias.copy_(l.bias.double().cpu())
+        f = torch.nn.functional.gelu if act == "gelu" else torch.relu
+        xr = x.double().cpu().contiguous().requires_grad_(True)
+        yr = f(ref[4](ref[3](f(ref[1](ref[0](xr))))))
+        (yr * torch.linspace(-1, 1, yr.shape[-1], dtype=torch.float64)).sum().backward()
+        for name, r in dict(dgamma0=ref[1].weight.grad, dbeta0=ref[1].bias.grad, dx=xr.grad, dw0=ref[0].weight.grad).items():
+            for fold in (True, False):
+                u = outs[fold][name].double().cpu()
+                # (a ReLU decision flipped by the bf16 rounding of z moves single elements of dx by more: norm-wise there)
+                err = (u - r).norm() / r.norm() if name in ("dx", "dw0") else (u - r).abs().max() / r.abs().max()
+                assert err <= 5e-2, (name, fold, float(err))
+    # two consumers of the first batch norm's output: neither data gradient may stand in for the sum
+    monkeypatch.setattr(D, "BN_BWD_FOLD", 2)
+    m = copy.deepcopy(net)
+    second = copy.deepcopy(net[3])
+    for k in D.STATS:
+        D.STATS[k] = 0
+    xi = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h = m[2](m[1](m[0](xi)))
+        y = m[3](h).float().sum() + second(h).float().square().sum()
+    y.backward()
+    assert D.STATS["bn_bwd_folded"] == 0 and D.STATS["bn_bwd_reduced"] == 1, D.STATS
+    monkeypatch.setattr(D, "BN_BWD_FOLD", 0)
+    m2 = copy.deepcopy(net)
+    xj = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h = m2[2](m2[1](m2[0](xj)))
+        y2 = m2[3](h).float().sum() + second(h).float().square().sum()
+    y2.backward()
+    assert torch.equal(xi.grad, xj.grad) and torch.equal(m[1].weight.grad, m2[1].weight.grad)
+
+
 def test_wide_layernorm_matches_stock():
     from sparse2dense_amd import dense2d as D
     torch.manual_seed(0)
