@@ -835,6 +835,40 @@ int s2d_convt3d_mfma_fwd_stats_y16(const float *in, const void *packed, const fl
                                    void *out_bf16, float *stats_partial, s2d_stream_t stream);
 int s2d_pointwise_conv_wgrad_norm_x16(const void *in_bf16, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
                                       int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream);
+/* r06: the 16-channel volume z between the two PCR levels ([B,16,10,376,376] at the benchmark: 362 MB in fp32), its gradient dz and the second
+ * up-sampler's input gradient dx' STORED IN BF16 (fp32 arithmetic, sums and statistics everywhere): the twelve passes per step that cross one
+ * of the three move half the bytes.  Same contracts as the entries they extend (rpn.py:263-296; replaces the same torch calls):
+ *   s2d_pcr_level_fwd_y16_z16            = s2d_pcr_level_fwd_y16 writing z as bf16 (c = 32, co = 16; z_stats of the stored values)
+ *   s2d_pcr_level_bwd_sums_y16_z16, s2d_pcr_level_bwd_apply_y16_d16_z16 = the level's backward passes reading a bf16 dz
+ *   s2d_pointwise_conv_wgrad_norm_x16_d16 = s2d_pointwise_conv_wgrad_norm_x16 with a bf16 dout (cin = 32)
+ *   s2d_convt3d_mfma_fwd_stats_y16_norm_x16, _wgrad_d16_norm_x16 = the up-sampler's forward / weight gradient reading a bf16 raw input
+ *   s2d_convt3d_mfma_dgrad_d16_x16       = its data gradient written as bf16        (all three: s2d_convt3d_mfma_x16_supported shapes)
+ *   s2d_bncm_bwd_reduce_x_typed / s2d_bncm_bwd_apply_x_typed = s2d_bncm_bwd_reduce_x_f32 / _apply_x_f32 with a storage flag per tensor
+ *     (0 fp32, 1 bf16); combinations (x, dy, dx): all fp32 | (fp32, bf16, fp32) | all bf16 */
+int s2d_pcr_level_fwd_y16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                              const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, void *z_bf16,
+                              float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_bwd_sums_y16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors, const float *feats,
+                                   int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8, const float *go_mask,
+                                   const float *go_offset, const void *dz_bf16, const float *w2, int co, float *grads, float *bn_sums, void *ws,
+                                   size_t ws_bytes, s2d_stream_t stream);
+int s2d_pcr_level_bwd_apply_y16_d16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                        const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                        const float *go_mask, const float *go_offset, const void *dz_bf16, const float *w2, int co,
+                                        const float *abd, void *dy_bf16, s2d_stream_t stream);
+int s2d_pointwise_conv_wgrad_norm_x16_d16(const void *in_bf16, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout,
+                                          int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_convt3d_mfma_x16_supported(int cin, int cout, int d, int h, int w);
+int s2d_convt3d_mfma_fwd_stats_y16_norm_x16(const void *in_bf16, const float *in_scale_shift, const void *packed, const float *bias, int batch,
+                                            int cin, int cout, int d, int h, int w, void *out_bf16, float *stats_partial, s2d_stream_t stream);
+int s2d_convt3d_mfma_wgrad_d16_norm_x16(const void *in_bf16, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout,
+                                        int d, int h, int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_convt3d_mfma_dgrad_d16_x16(const void *dout_bf16, const void *packed, int batch, int cin, int cout, int d, int h, int w, void *din_bf16,
+                                   s2d_stream_t stream);
+int s2d_bncm_bwd_reduce_x_typed(const void *dy, int dy_bf16, const void *x, int x_bf16, const float *scale, const float *shift, int batch, int c,
+                                int64_t positions, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream);
+int s2d_bncm_bwd_apply_x_typed(const void *dy, int dy_bf16, const void *x, int x_bf16, const float *scale, const float *shift, const float *a,
+                               const float *b, const float *d, int batch, int c, int64_t positions, void *dx, int dx_bf16, s2d_stream_t stream);
 int s2d_pcr_level_fwd_y16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
                           const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
                           float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream);

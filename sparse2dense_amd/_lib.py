@@ -333,6 +333,26 @@ SIGNATURES = {
     "s2d_bncm_bwd_reduce_x_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p,
                                                  ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bncm_bwd_apply_x_f32": (ctypes.c_int, [c_f32p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
+    # r06: bf16-stored z / dz / dx' of the PCR head (storage flags: 0 fp32, 1 bf16)
+    "s2d_bncm_bwd_reduce_x_typed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int64, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_bncm_bwd_apply_x_typed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "s2d_convt3d_mfma_x16_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "s2d_convt3d_mfma_dgrad_d16_x16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_convt3d_mfma_fwd_stats_y16_norm_x16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 6 +
+                                                [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
+    "s2d_convt3d_mfma_wgrad_d16_norm_x16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 +
+                                            [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_level_fwd_y16_z16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 6 +
+                                  [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_level_bwd_sums_y16_z16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                                       [c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_int, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.c_void_p]),
+    "s2d_pcr_level_bwd_apply_y16_d16_z16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +
+                                            [c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
+    "s2d_pointwise_conv_wgrad_norm_x16_d16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                              ctypes.c_int64, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_bncm_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_densify_bev_fwd_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_int64, ctypes.c_int, _I3,

@@ -44,6 +44,13 @@ __device__ __forceinline__ u32x2m ct_load2u(__amdgpu_buffer_rsrc_t r, unsigned v
 }
 __device__ __forceinline__ uint32_t ct_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // (a.hi, b.hi)
 __device__ __forceinline__ uint32_t ct_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // (a.lo, b.lo)
+// two fp32 -> one dword of two bf16 (round to nearest even; low half = a): ONE v_cvt_pk_bf16_f32.  hipcc emits the instruction with a dummy second
+// source per value and merges the halves with a v_perm_b32 (three instructions per pair) when the pair is built from two (__bf16) casts.
+__device__ __forceinline__ uint32_t ct_cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 struct CtDims {
     int n, d, h, w;   // batch and INPUT extents; output is 2d x 2h x 2w
@@ -434,8 +441,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 // bit-identical.  Ablation of the 466 us build (template switches, removed again): without the output stores 384, without the MFMAs 413,
 // without the global loads 393, without the A-fragment LDS reads 326, without all four 178 - no single stream dominates; the 32
 // ds_read_b128 per wave and row (4 x redundant: both px classes and both x taps re-read the same cells) are the largest single term.
-template <int CIN, int NT, int YR, typename TO = float>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_zslide_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
+template <int CIN, int NT, int YR, typename TO = float, typename TXI = float>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void ct_fwd_zslide_kernel(const TXI *__restrict__ x, const __bf16 *__restrict__ wp, const float *__restrict__ bias,
                                                           CtDims s, int xtiles, TO *__restrict__ out,
                                                           float *__restrict__ stats_partial, const float *__restrict__ in_norm = nullptr) {
     // in_norm (r04, scale[CIN] | shift[CIN] or null): the input is the RAW tensor in front of a BatchNorm3d + ReLU, applied here while
@@ -460,16 +467,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int hy0 = (rem0 / xtiles) * YR, xt = rem0 % xtiles;
     const int x0 = xt * CT_TX;
     const int64_t cells = (int64_t)s.d * s.h * s.w;
-    const float *xb = x + (int64_t)n * CIN * cells;
+    const TXI *xb = x + (int64_t)n * CIN * cells;   // (TXI = __bf16, r06: the bf16-stored z - a 16-byte load carries 8 cells of a plane, w % 8 == 0)
+    constexpr bool X16 = sizeof(TXI) == 2;
+    constexpr int CPP = X16 ? 8 : 4;             // cells per 16-byte piece of a plane
+    constexpr int PPR = CT_TX / CPP;             // pieces per 64-cell row and plane
     // stage: the 64-cell body of a row as 16-byte loads (piece = (row9, group, 4 cells): 8 channel planes x float4 -> four 16-byte LDS
     // stores), the two halo columns (and everything when w % 4 != 0) with one dword per channel.  Strided dword gathers cost ~4x the
     // issue slots of 16-byte loads (DESIGN rule 7); this staging is what bounds the kernel.
-    const bool vec = (s.w & 3) == 0;
+    const bool vec = (s.w & (CPP - 1)) == 0;
     auto stage_plane = [&](int zp, int slot) {   // plane zp (zeros outside the tensor) -> rows [slot * RY, slot * RY + RY) of the ring
     const int rbase = slot * RY;
     if (vec) {
         // every thread issues the loads of its halo piece (threads < 18 * GROUPS) and of its first body piece before converting any
-        constexpr int HALO = ROWS * GROUPS * 2, BODY = ROWS * GROUPS * 16;
+        constexpr int HALO = ROWS * GROUPS * 2, BODY = ROWS * GROUPS * PPR;
         static_assert(HALO <= 256, "one halo piece per thread");
         float hv[8];
         const bool has_halo = t < HALO;
@@ -480,29 +490,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const int z = zp, y = hy0 + r9 - 1, xp = x0 - 1 + xx;
             h_slot = xa((rbase + r9) * XS + xx, g);
             const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w;
-            const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
+            const TXI *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float val = src[ok ? (int64_t)e * cells : 0];
+                float val = (float)src[ok ? (int64_t)e * cells : 0];
                 if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
                 hv[e] = ok ? val : 0.f;
             }
         }
         // (p >> 4) advances by 16 per iteration, a multiple of GROUPS: a thread's channel group - and its eight scale / shift pairs - is fixed
-        static_assert(16 % GROUPS == 0, "a thread keeps its channel group");
+        static_assert((256 / PPR) % GROUPS == 0, "a thread keeps its channel group");
         float nsc[8], nsh[8];
         if (in_norm) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                nsc[e] = in_norm[((t >> 4) % GROUPS) * 8 + e];
-                nsh[e] = in_norm[CIN + ((t >> 4) % GROUPS) * 8 + e];
+                nsc[e] = in_norm[((t / PPR) % GROUPS) * 8 + e];
+                nsh[e] = in_norm[CIN + ((t / PPR) % GROUPS) * 8 + e];
             }
         }
+        if constexpr (X16) {
+            // bf16 planes: a 16-byte load is 8 cells of one plane; the input is always the raw tensor in front of the batch norm here (in_norm != null:
+            // the launcher's contract).  Per value: one shift / and to widen, half a v_pk_fma_f32 (two channels per instruction), half a
+            // v_cvt_pk_bf16_f32 - packing the channel PAIR (2k, 2k + 1) of a cell, which is the [cell][ci] order of the LDS image: no transposition -
+            // and half a v_pk_max_i16 against zero: the ReLU on the two rounded bf16 values (sign bit set -> 0; rounding keeps the sign, so
+            // relu(round(v)) == round(relu(v)) bit for bit).  The first version did widen / fma / max / narrow per scalar with a run-time in_norm test
+            // per element: 0.47 -> 0.53 ms (the staging is what bounds this kernel).
+            // Two threads per piece (planes 0-3 / 4-7 of the group, an 8-byte half of each cell's LDS slot): 2 BODY = 192 of the 256 threads stage, as on
+            // the fp32 path - with one thread per 8-cell piece only 96 were busy with twice the work each (0.47 -> 0.51 ms).
+            typedef float f32x2x __attribute__((ext_vector_type(2)));
+            typedef short s16x2x __attribute__((ext_vector_type(2)));
+            static_assert((128 / PPR) % GROUPS == 0, "a thread keeps its channel group");
+            const int half = t & 1;
+            f32x2x sc2[2], sh2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c0 = ((t >> 1) / PPR % GROUPS) * 8 + 4 * half + 2 * k;
+                sc2[k] = f32x2x{in_norm[c0], in_norm[c0 + 1]};
+                sh2[k] = f32x2x{in_norm[CIN + c0], in_norm[CIN + c0 + 1]};
+            }
+            for (int p2 = t; p2 < 2 * BODY; p2 += 256) {
+                const int p = p2 >> 1;
+                const int xq = p % PPR, g = (p / PPR) % GROUPS, r9 = (p / PPR) / GROUPS;
+                const int z = zp, y = hy0 + r9 - 1, xp = x0 + 8 * xq;
+                const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && xp < s.w;
+                const TXI *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8 + 4 * half) * cells : xb;
+                u32x4m f[4];   // plane 4 half + e: 8 cells, two per dword (low half = the even cell)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = *reinterpret_cast<const u32x4m *>(src + (ok ? (int64_t)e * cells : 0));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u32x2m o;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint32_t wa = f[2 * k][j >> 1], wb = f[2 * k + 1][j >> 1];
+                        f32x2x val = {__uint_as_float((j & 1) ? (wa & 0xffff0000u) : (wa << 16)),
+                                      __uint_as_float((j & 1) ? (wb & 0xffff0000u) : (wb << 16))};
+                        val = __builtin_elementwise_fma(val, sc2[k], sh2[k]);
+                        const s16x2x r2 = __builtin_elementwise_max(__builtin_bit_cast(s16x2x, ct_cvt_pk_bf16(val[0], val[1])), s16x2x{0, 0});
+                        o[k] = ok ? __builtin_bit_cast(uint32_t, r2) : 0u;
+                    }
+                    *reinterpret_cast<u32x2m *>(&xs[xa((rbase + r9) * XS + 1 + 8 * xq + j, g) + 4 * half]) = o;
+                }
+            }
+        } else
         for (int p = t; p < BODY; p += 256) {
             const int xq = p & 15, g = (p >> 4) % GROUPS, r9 = (p >> 4) / GROUPS;
             const int z = zp, y = hy0 + r9 - 1, xp = x0 + 4 * xq;
             const bool ok = (unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && xp < s.w;
-            const float *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
+            const TXI *src = ok ? xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells : xb;
             float4 f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const float4 *>(src + (ok ? (int64_t)e * cells : 0));
@@ -535,10 +590,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
             const int z = zp, y = hy0 + r9 - 1, xp = x0 - 1 + xx;
             bf16x8m v;
             if ((unsigned)z < (unsigned)s.d && (unsigned)y < (unsigned)s.h && (unsigned)xp < (unsigned)s.w) {
-                const float *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
+                const TXI *src = xb + ((int64_t)z * s.h + y) * s.w + xp + (int64_t)(g * 8) * cells;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float val = src[(int64_t)e * cells];
+                    float val = (float)src[(int64_t)e * cells];
                     if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
                     v[e] = (__bf16)val;
                 }
@@ -814,17 +869,18 @@ __global__ __launch_bounds__(256) void ct_dgrad_mfma_kernel(const float *__restr
 // (L1) feeds MT MFMAs.  The staged kernel above holds 32-64 KB of LDS per block and waits for memory once per staging round
 // (1.9 ms for the 16 -> 3 layer at [4,16,10,376,376] against a 0.2 ms stream); a first direct version with dword loads (one
 // per channel and kx) ran at ~70 clocks per load instruction: 1.9 / 1.5 ms.
-template <int COP, int NT, int MT, bool N4 = false, typename TD = float>
+template <int COP, int NT, int MT, bool N4 = false, typename TD = float, typename TI = float>
 __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restrict__ dout, const __bf16 *__restrict__ wp, CtDims s, int tiles_per_row,
-                                                              CtTileMap map, float *__restrict__ din) {
+                                                              CtTileMap map, TI *__restrict__ din) {
     constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the window [2c-1, 2c+2] is elements 1..4 of the three dwords from element 2c-2
     constexpr unsigned ES = sizeof(TD);
+    constexpr unsigned IS = sizeof(TI);     // r06: din stored in bf16 (w % 4 == 0): a lane's four cells are one 8-byte store
     constexpr int KSTEPS = COP == 32 ? 4 : 1;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int od = 2 * s.d, oh = 2 * s.h, ow = 2 * s.w;
     const int64_t cells = (int64_t)s.d * s.h * s.w, oplane = (int64_t)od * oh * ow;
-    const unsigned oplane_b = (unsigned)(oplane * ES), dbytes = (unsigned)(s.cout * oplane * ES), ibytes = (unsigned)(s.cin * cells * 4);
+    const unsigned oplane_b = (unsigned)(oplane * ES), dbytes = (unsigned)(s.cout * oplane * ES), ibytes = (unsigned)(s.cin * cells * IS);
     // Item order (XCD-aware, see ct_fwd_mfma_kernel): an input row reads 4 x 4 (z, y) rows of dout and shares half of them with each
     // neighbour, so every dout row has four readers.  With items dealt to workgroups in plain order those sat on different XCDs and
     // HBM delivered every row up to 4x (PMC: 2.9 GB fetched for a 724 MB gradient - the kernel ran AT the HBM roof).  Here XCD x owns
@@ -935,15 +991,21 @@ __global__ __launch_bounds__(256) void ct_dgrad_direct_kernel(const TD *__restri
         }
         // C/D layout: row (cell) = 4q + reg, column (ci) = r: a lane stores 4 consecutive cells of its plane
         const __amdgpu_buffer_rsrc_t ir = ct_rsrc(din + (int64_t)n * s.cin * cells, ibytes);
-        const unsigned rowoff = (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4);
+        const unsigned rowoff = (unsigned)(((int64_t)hz * s.h + hy) * s.w * IS);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int c0 = x0 + mt * 16 + 4 * q;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int ci = nt * 16 + r;
-                const unsigned plane = ci < s.cin ? (unsigned)(ci * cells * 4) : CT_OOB;
-                if ((s.w & 3) == 0) {
+                const unsigned plane = ci < s.cin ? (unsigned)(ci * cells * IS) : CT_OOB;
+                if constexpr (IS == 2) {   // (the launcher takes this instantiation for w % 4 == 0 only)
+                    typedef __bf16 bf16x4i __attribute__((ext_vector_type(4)));
+                    bf16x4i o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[mt][nt][j];
+                    buf_store2(ir, (c0 < s.w && ci < s.cin) ? plane + (unsigned)c0 * 2u : CT_OOB, rowoff, __builtin_bit_cast(buf_f32x2, o));
+                } else if ((s.w & 3) == 0) {
                     buf_store4(ir, (c0 < s.w && ci < s.cin) ? plane + (unsigned)c0 * 4u : CT_OOB, rowoff, acc[mt][nt]);
                 } else {
 #pragma unroll
@@ -1248,10 +1310,11 @@ __global__ __launch_bounds__(256) void ct_wgrad_rows_kernel(const float *__restr
 // all 16 (kz,ky) accumulators.  The 16 window loads of four (kz,ky) rows are issued together, branch-free (rows / columns / lanes
 // outside the tensor get an out-of-range buffer offset): the first version waited for memory once per (kz,ky) row with two
 // waves per SIMD (3.5 ms at [4,16,10,376,376]).
-template <int CIT, typename TD = float>
-__global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
+template <int CIT, typename TD = float, typename TXI = float>
+__global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restrict__ x, const TD *__restrict__ dout, CtDims s, int rows_per_block,
                                                               int n_chunks, float *__restrict__ partial, const float *__restrict__ in_norm = nullptr) {
     constexpr int FR = 16 * CIT;
+    constexpr unsigned XS = sizeof(TXI);   // r06: bf16-stored x (the 16-channel z): the lane's 8 cells are ONE 16-byte load
     constexpr bool D16 = sizeof(TD) == 2;   // bf16 dout: the 16-element window is eight dwords (two 16-byte loads instead of four)
     constexpr unsigned ES = sizeof(TD);
     __shared__ float red[FR * 4][64];
@@ -1272,7 +1335,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
 #pragma unroll
         for (int a = 0; a < CIT; ++a) acc[g][a] = f32x4m{0.f, 0.f, 0.f, 0.f};
     const int steps = (s.w + 31) / 32;
-    const unsigned xbytes = (unsigned)(s.cin * cells * 4), dbytes = (unsigned)(s.cout * oplane * ES);
+    const unsigned xbytes = (unsigned)(s.cin * cells * XS), dbytes = (unsigned)(s.cout * oplane * ES);
     // window of the lane: floats [base, base + 16) of the dout row with base = 2*c0 - 2 + 2*((kx + 1) >> 1); sample e = element
     // 2e + (kx odd ? 0 : 1), i.e. position 2*(c0 + e) - 1 + kx
     const int wshift = 2 * ((kx + 1) >> 1) - 2;
@@ -1283,7 +1346,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
         const int hy = (int)(row % s.h), hz = (int)((row / s.h) % s.d), n = (int)(row / ((int64_t)s.h * s.d));
         const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)n * s.cin * cells, xbytes);
         const __amdgpu_buffer_rsrc_t dr = ct_rsrc(dout + (int64_t)n * s.cout * oplane, dbytes);
-        const unsigned xrow = (unsigned)(((int64_t)hz * s.h + hy) * s.w * 4);
+        const unsigned xrow = (unsigned)(((int64_t)hz * s.h + hy) * s.w * XS);
         for (int st = 0; st < steps; ++st) {
             const int c0 = st * 32 + 8 * q;
             const bool cok = c0 < s.w;   // w % 8 == 0: the lane's 8 cells are all inside or all outside
@@ -1291,8 +1354,34 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const float *__res
 #pragma unroll
             for (int ai = 0; ai < CIT; ++ai) {
                 const int ci = ai * 16 + r;
-                const unsigned voff = (cok && ci < s.cin) ? (unsigned)(ci * cells * 4) + xrow + (unsigned)c0 * 4u : CT_OOB;
-                f32x4m lo = ct_load4(xr, voff, 0), hi = ct_load4(xr, voff, 16);
+                const unsigned voff = (cok && ci < s.cin) ? (unsigned)(ci * cells * XS) + xrow + (unsigned)c0 * XS : CT_OOB;
+                f32x4m lo, hi;
+                if constexpr (XS == 2) {
+                    const u32x4m u = ct_load4u(xr, voff, 0);
+                    if (!in_norm) {   // (wave-uniform) the stored bf16 values are the operand
+                        a[ai] = __builtin_bit_cast(bf16x8m, u);
+                        continue;
+                    }
+                    {   // widen, normalise two cells per v_pk_fma_f32, narrow two per v_cvt_pk_bf16_f32, ReLU on the rounded pair (see ct_fwd_zslide_kernel)
+                        typedef float f32x2x __attribute__((ext_vector_type(2)));
+                        typedef short s16x2x __attribute__((ext_vector_type(2)));
+                        const bool cv = cok && ci < s.cin;
+                        const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;   // (lanes outside the tensor loaded 0 and stay 0)
+                        u32x4m o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            f32x2x val = {__uint_as_float(u[e] << 16), __uint_as_float(u[e] & 0xffff0000u)};
+                            val = __builtin_elementwise_fma(val, f32x2x{sc, sc}, f32x2x{sh, sh});
+                            const s16x2x r2 = __builtin_elementwise_max(__builtin_bit_cast(s16x2x, ct_cvt_pk_bf16(val[0], val[1])), s16x2x{0, 0});
+                            o[e] = __builtin_bit_cast(uint32_t, r2);
+                        }
+                        a[ai] = __builtin_bit_cast(bf16x8m, o);
+                        continue;
+                    }
+                } else {
+                    lo = ct_load4(xr, voff, 0);
+                    hi = ct_load4(xr, voff, 16);
+                }
                 if (in_norm) {   // x is the raw tensor in front of a BatchNorm3d + ReLU (see ct_fwd_mfma_kernel); loads outside the tensor stay zero
                     const bool cv = cok && ci < s.cin;
                     const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;
@@ -1465,8 +1554,8 @@ extern "C" int64_t s2d_convt3d_mfma_stats_tiles(int batch, int cin, int d, int h
 
 /* stats_partial (optional, [s2d_convt3d_mfma_stats_tiles][2][cout]): per-block (sum, sum of squares) per output channel of the written
  * output - the statistics pass of the BatchNorm3d that follows (s2d_bn_partials_sum_f32 folds them) */
-template <typename TO>
-static int ct_fwd_launch(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h, int w, TO *out,
+template <typename TO, typename TXI = float>
+static int ct_fwd_launch(const TXI *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h, int w, TO *out,
                          float *stats_partial, s2d_stream_t stream, const float *in_norm = nullptr) {
     S2D_CHECK_ARG(in && packed && out && batch > 0 && d > 0 && h > 0 && w > 0, "convt3d_mfma_fwd: bad argument");
     if (!ct_mfma_ok(cin, cout)) return S2D_ERR_UNSUPPORTED;
@@ -1476,6 +1565,13 @@ static int ct_fwd_launch(const float *in, const void *packed, const float *bias,
     const int nt = (cout + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *wp = (const __bf16 *)packed;
+    if constexpr (sizeof(TXI) == 2) {   // bf16-stored input: the z-sliding kernel of the 16 -> (<= 16) layers (callers: s2d_convt3d_mfma_x16_supported)
+        if (!(cin == 16 && nt == 1 && w % 8 == 0)) return S2D_ERR_UNSUPPORTED;
+        const dim3 zgrid(xcd_grid((int64_t)batch * hg * xtiles)), zblk(256);
+        hipLaunchKernelGGL((ct_fwd_zslide_kernel<16, 1, 4, TO, TXI>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    } else {
     if (ct_fwd_zslide(cin)) {
         const dim3 zgrid(xcd_grid((int64_t)batch * hg * xtiles)), zblk(256);
         if (cin == 32 && nt == 2) hipLaunchKernelGGL((ct_fwd_zslide_kernel<32, 2, 1, TO>), zgrid, zblk, 0, st, in, wp, bias, s, xtiles, out, stats_partial, in_norm);
@@ -1496,6 +1592,7 @@ static int ct_fwd_launch(const float *in, const void *packed, const float *bias,
     else hipLaunchKernelGGL((ct_fwd_mfma_kernel<16, 1, 4, TO>), grid, blk, 0, st, in, wp, bias, s, xtiles, map, out, stats_partial, in_norm);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+    }
 }
 
 extern "C" int s2d_convt3d_mfma_fwd_stats(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
@@ -1517,6 +1614,17 @@ extern "C" int s2d_convt3d_mfma_fwd_stats_y16_norm(const float *in, const float 
     return ct_fwd_launch<__bf16>(in, packed, bias, batch, cin, cout, d, h, w, (__bf16 *)out_bf16, stats_partial, stream, in_scale_shift);
 }
 
+/* r06: ... reading a bf16-STORED raw input (the 16-channel z written in bf16 by s2d_pcr_level_fwd_y16_z16); stats tiles as for the fp32 input
+ * with the z-sliding plan (s2d_convt3d_mfma_stats_tiles counts that plan when S2D_CT_ZSLIDE is on - the x16 path requires it) */
+extern "C" int s2d_convt3d_mfma_fwd_stats_y16_norm_x16(const void *in_bf16, const float *in_scale_shift, const void *packed, const float *bias,
+                                                       int batch, int cin, int cout, int d, int h, int w, void *out_bf16, float *stats_partial,
+                                                       s2d_stream_t stream) {
+    S2D_CHECK_ARG(in_scale_shift, "convt3d_mfma_fwd_stats_y16_norm_x16: null scale / shift");
+    if (!ct_fwd_zslide(cin)) return S2D_ERR_UNSUPPORTED;
+    return ct_fwd_launch<__bf16, __bf16>((const __bf16 *)in_bf16, packed, bias, batch, cin, cout, d, h, w, (__bf16 *)out_bf16, stats_partial, stream,
+                                         in_scale_shift);
+}
+
 extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const float *bias, int batch, int cin, int cout, int d, int h,
                                     int w, float *out, s2d_stream_t stream) {
     return s2d_convt3d_mfma_fwd_stats(in, packed, bias, batch, cin, cout, d, h, w, out, nullptr, stream);
@@ -1525,8 +1633,8 @@ extern "C" int s2d_convt3d_mfma_fwd(const float *in, const void *packed, const f
 // the direct (LDS-free) data-gradient kernels cover a layer when one sample's fp32 dout stays under 2 GB
 static bool ct_dgrad_is_direct(int cout, int d, int h, int w) { return (int64_t)cout * 8 * d * h * w * 4 < ((int64_t)1 << 31); }
 
-template <typename TD>
-static int ct_dgrad_direct_launch(const TD *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w, float *din, hipStream_t st) {
+template <typename TD, typename TI = float>
+static int ct_dgrad_direct_launch(const TD *dout, const void *packed, int batch, int cin, int cout, int d, int h, int w, TI *din, hipStream_t st) {
     CtDims s{batch, d, h, w, cin, cout};
     const dim3 blk(256);
     const int nt_f = (cout + 15) / 16;
@@ -1540,6 +1648,12 @@ static int ct_dgrad_direct_launch(const TD *dout, const void *packed, int batch,
     // live across a z step: 4 z planes x (2 yc + 2) rows of dout, cout planes each
     const CtTileMap map = ct_tile_map(d, h, tpr, ct_chunk_rows((int64_t)2 * w * cout * sizeof(TD), 2, 2, 4));
     const __bf16 *wd = wp + (size_t)16 * (narrow ? 1 : 4) * (cin / 16) * 512;   // the direct kernel's image follows the staged one
+    if constexpr (sizeof(TI) == 2) {   // bf16-stored din: the narrow 16-channel layer (the 16 -> 3 up-sampler behind the bf16-stored z)
+        if (!(narrow && cout <= 4 && cin == 16 && w % 4 == 0)) return S2D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, true, TD, TI>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
+        S2D_LAUNCH_CHECK();
+        return S2D_OK;
+    } else
     if (narrow && cout <= 4 && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, true, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
     else if (narrow && cout <= 4) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 1, MT, true, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
     else if (narrow && cin == 32) hipLaunchKernelGGL((ct_dgrad_direct_kernel<8, 2, MT, false, TD>), g2, blk, 0, st, dout, wd, s, tpr, map, din);
@@ -1580,8 +1694,8 @@ extern "C" size_t s2d_convt3d_mfma_wgrad_workspace_bytes(int batch, int cin, int
 // the weight-gradient kernels that read a bf16-stored dout: the narrow one and the output-row-major one
 static bool ct_wgrad_has_d16(int cout, int w) { return ct_wgrad_is_narrow(cout, w) || w % 4 == 0; }
 
-template <typename TD>
-static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, int cout, int d, int h, int w, float *dweight, void *ws, hipStream_t st,
+template <typename TD, typename TXI = float>
+static int ct_wgrad_launch(const TXI *in, const TD *dout, int batch, int cin, int cout, int d, int h, int w, float *dweight, void *ws, hipStream_t st,
                            const float *in_norm = nullptr) {
     CtDims s{batch, d, h, w, cin, cout};
     const int64_t rows = (int64_t)batch * d * h;
@@ -1591,6 +1705,10 @@ static int ct_wgrad_launch(const float *in, const TD *dout, int batch, int cin, 
     const int cit = cin / 16, cot = (cout + 15) / 16;
     const bool narrow = ct_wgrad_is_narrow(cout, w);
     if (in_norm && !ct_wgrad_has_d16(cout, w)) return S2D_ERR_UNSUPPORTED;   // the input-norm fold lives in the narrow / row-major kernels
+    if constexpr (sizeof(TXI) == 2) {   // bf16-stored input: the narrow 16-channel layer only (s2d_convt3d_mfma_x16_supported)
+        if (!(narrow && cit == 1)) return S2D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1, TD, TXI>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial, in_norm);
+    } else
     if (narrow && cit == 1) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<1, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial, in_norm);
     else if (narrow) hipLaunchKernelGGL((ct_wgrad_narrow_kernel<2, TD>), dim3(xcd_grid(bx)), dim3(256), 0, st, in, dout, s, rpb, bx, partial, in_norm);
     // both input-channel tiles in one block: dout is read once (measured 0.62 ms against 0.85 ms with one tile per block and two
@@ -1640,6 +1758,16 @@ extern "C" int s2d_convt3d_mfma_dgrad_d16(const void *dout_bf16, const void *pac
     if (!s2d_convt3d_mfma_d16_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
     return ct_dgrad_direct_launch<__bf16>((const __bf16 *)dout_bf16, packed, batch, cin, cout, d, h, w, din, (hipStream_t)stream);
 }
+/* r06: ... writing the input gradient in bf16 as well (x16: the layer's input is the bf16-stored z, see s2d_convt3d_mfma_x16_supported) */
+extern "C" int s2d_convt3d_mfma_x16_supported(int cin, int cout, int d, int h, int w) {
+    return s2d_convt3d_mfma_norm_supported(cin, cout, d, h, w) && cin == 16 && cout <= 4 && w % 8 == 0 && ct_fwd_zslide(cin);
+}
+extern "C" int s2d_convt3d_mfma_dgrad_d16_x16(const void *dout_bf16, const void *packed, int batch, int cin, int cout, int d, int h, int w,
+                                              void *din_bf16, s2d_stream_t stream) {
+    S2D_CHECK_ARG(dout_bf16 && packed && din_bf16 && batch > 0, "convt3d_mfma_dgrad_d16_x16: bad argument");
+    if (!s2d_convt3d_mfma_x16_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
+    return ct_dgrad_direct_launch<__bf16, __bf16>((const __bf16 *)dout_bf16, packed, batch, cin, cout, d, h, w, (__bf16 *)din_bf16, (hipStream_t)stream);
+}
 extern "C" int s2d_convt3d_mfma_wgrad_d16(const float *in, const void *dout_bf16, int batch, int cin, int cout, int d, int h, int w, float *dweight,
                                           void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && dout_bf16 && dweight && batch > 0, "convt3d_mfma_wgrad_d16: bad argument");
@@ -1662,6 +1790,20 @@ extern "C" int s2d_convt3d_mfma_wgrad_d16_norm(const float *in, const float *in_
         return S2D_ERR_WORKSPACE;
     }
     return ct_wgrad_launch<__bf16>(in, (const __bf16 *)dout_bf16, batch, cin, cout, d, h, w, dweight, ws, (hipStream_t)stream, in_scale_shift);
+}
+
+/* r06: ... with `in` stored in bf16 (the 16-channel z, see s2d_convt3d_mfma_x16_supported) */
+extern "C" int s2d_convt3d_mfma_wgrad_d16_norm_x16(const void *in_bf16, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout,
+                                                   int d, int h, int w, float *dweight, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    S2D_CHECK_ARG(in_bf16 && in_scale_shift && dout_bf16 && dweight && batch > 0, "convt3d_mfma_wgrad_d16_norm_x16: bad argument");
+    if (!s2d_convt3d_mfma_x16_supported(cin, cout, d, h, w)) return S2D_ERR_UNSUPPORTED;
+    const size_t need = s2d_convt3d_mfma_wgrad_workspace_bytes(batch, cin, cout, d, h, w);
+    if (!ws || ws_bytes < need) {
+        set_error("convt3d_mfma_wgrad_d16_norm_x16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return S2D_ERR_WORKSPACE;
+    }
+    return ct_wgrad_launch<__bf16, __bf16>((const __bf16 *)in_bf16, (const __bf16 *)dout_bf16, batch, cin, cout, d, h, w, dweight, ws,
+                                           (hipStream_t)stream, in_scale_shift);
 }
 
 // ---- 1x1x1 Conv3d weight gradient (planar fp32 tensors) ------------------------------------------------------------
@@ -1754,8 +1896,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
 // channels: 2.9 GB for the 32 -> 16 layer at [4,32,10,376,376], 0.76 ms).  A lane's 8 K-elements are the two 4-float chunks at
 // p0 + 4q and p0 + 16 + 4q of its plane (the same position permutation on both operands, so the products pair up correctly):
 // every load instruction reads 64 contiguous bytes per plane.  db = the VALU sum of the lane's own dy values.
-template <int MT, int NT, typename TX = float>
-__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const TX *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ bnp,
+template <int MT, int NT, typename TX = float, typename TG = float>
+__global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const TX *__restrict__ x, const TG *__restrict__ dy, const float *__restrict__ bnp,
                                                             int64_t positions, int batch, int cin, int cout, int steps_per_block,
                                                             float *__restrict__ partial) {
     __shared__ float red[MT * NT * 4 + MT][64];
@@ -1779,7 +1921,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const TX *__restrict
     const int64_t steps = (positions + 31) / 32;
     const int64_t s0 = (int64_t)blockIdx.x * steps_per_block;
     const int64_t s1 = s0 + steps_per_block < steps ? s0 + steps_per_block : steps;
-    const unsigned plane = (unsigned)(positions * 4), xplane = (unsigned)(positions * sizeof(TX));
+    const unsigned plane = (unsigned)(positions * sizeof(TG)), xplane = (unsigned)(positions * sizeof(TX));   // (TG = __bf16, r06: the bf16-stored dz)
     for (int b = 0; b < batch; ++b) {
         const __amdgpu_buffer_rsrc_t xr = ct_rsrc(x + (int64_t)b * cin * positions, (unsigned)cin * xplane);
         const __amdgpu_buffer_rsrc_t yr = ct_rsrc(dy + (int64_t)b * cout * positions, (unsigned)cout * plane);
@@ -1791,9 +1933,20 @@ __global__ __launch_bounds__(256) void pw_wgrad_mfma_kernel(const TX *__restrict
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int o = m * 16 + r;
-                const unsigned base = o < cout ? (unsigned)o * plane + (unsigned)p0 * 4u : CT_OOB;
-                lo[m] = ct_load4(yr, ok0 ? base : CT_OOB, 0);
-                hi[m] = ct_load4(yr, ok1 ? base : CT_OOB, 64);
+                if constexpr (sizeof(TG) == 4) {
+                    const unsigned base = o < cout ? (unsigned)o * plane + (unsigned)p0 * 4u : CT_OOB;
+                    lo[m] = ct_load4(yr, ok0 ? base : CT_OOB, 0);
+                    hi[m] = ct_load4(yr, ok1 ? base : CT_OOB, 64);
+                } else {
+                    const unsigned base = o < cout ? (unsigned)o * plane + (unsigned)p0 * 2u : CT_OOB;
+                    const uint64_t l2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(yr, ok0 ? base : CT_OOB, 0, 0));
+                    const uint64_t h2 = __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(yr, ok1 ? base : CT_OOB, 32, 0));
+                    const uint32_t la = (uint32_t)l2, lb = (uint32_t)(l2 >> 32), ha = (uint32_t)h2, hb = (uint32_t)(h2 >> 32);
+                    lo[m] = f32x4m{__builtin_bit_cast(float, la << 16), __builtin_bit_cast(float, la & 0xFFFF0000u),
+                                   __builtin_bit_cast(float, lb << 16), __builtin_bit_cast(float, lb & 0xFFFF0000u)};
+                    hi[m] = f32x4m{__builtin_bit_cast(float, ha << 16), __builtin_bit_cast(float, ha & 0xFFFF0000u),
+                                   __builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xFFFF0000u)};
+                }
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -1920,8 +2073,8 @@ extern "C" int s2d_pointwise_conv_wgrad_bf16(const float *in, const float *dout,
 }
 
 /* ... with x = relu(in*scale + shift) applied on the fly: in_scale_shift (device, 2*cin) = scale[cin] | shift[cin], or NULL */
-template <typename TX>
-static int pw_wgrad_norm_launch(const TX *in, const float *in_scale_shift, const float *dout, int batch, int cin, int cout, int64_t positions,
+template <typename TX, typename TG = float>
+static int pw_wgrad_norm_launch(const TX *in, const float *in_scale_shift, const TG *dout, int batch, int cin, int cout, int64_t positions,
                                 float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     S2D_CHECK_ARG(in && dout && dweight && batch > 0, "pointwise_conv_wgrad_bf16: bad argument");
     if (!s2d_pointwise_conv_wgrad_bf16_supported(cin, cout, positions)) {
@@ -1938,6 +2091,11 @@ static int pw_wgrad_norm_launch(const TX *in, const float *in_scale_shift, const
     const int spb = (int)s2d::ceil_div(steps, chunks);
     hipStream_t st = (hipStream_t)stream;
     float *partial = (float *)ws;
+    if constexpr (sizeof(TG) == 2) {   // bf16-stored dout: the 32 -> 16 conv behind the bf16-stored z
+        if (cin != 32) return S2D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<1, 2, TX, TG>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
+                           partial);
+    } else
     if (cin == 128)
         hipLaunchKernelGGL((s2d::pw_wgrad_mfma_kernel<2, 8, TX>), dim3(chunks), dim3(256), 0, st, in, dout, in_scale_shift, positions, batch, cin, cout, spb,
                            partial);
@@ -1959,4 +2117,10 @@ extern "C" int s2d_pointwise_conv_wgrad_norm_bf16(const float *in, const float *
 extern "C" int s2d_pointwise_conv_wgrad_norm_x16(const void *in_bf16, const float *in_scale_shift, const float *dout, int batch, int cin, int cout,
                                                  int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
     return pw_wgrad_norm_launch<__bf16>((const __bf16 *)in_bf16, in_scale_shift, dout, batch, cin, cout, positions, dweight, dbias, ws, ws_bytes, stream);
+}
+/* r06: input AND output gradient stored as bf16 (x = the bf16 up-sampler output, dout = the bf16-stored dz; cin = 32) */
+extern "C" int s2d_pointwise_conv_wgrad_norm_x16_d16(const void *in_bf16, const float *in_scale_shift, const void *dout_bf16, int batch, int cin, int cout,
+                                                     int64_t positions, float *dweight, float *dbias, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pw_wgrad_norm_launch<__bf16, __bf16>((const __bf16 *)in_bf16, in_scale_shift, (const __bf16 *)dout_bf16, batch, cin, cout, positions, dweight,
+                                                dbias, ws, ws_bytes, stream);
 }

@@ -264,8 +264,29 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
 // grid (chunks, C); partial[chunk][2C] is reduced by partial_sum_kernel like the row-major case.
 // relu with y == nullptr (r04): the mask y > 0 is re-derived from x as fma(x, scale, shift) > 0 - the expression the forward apply
 // evaluated, so the same mask bit for bit - instead of reading the 362 MB output plane set a third time
-template <bool BWD>
-__global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+// 4 consecutive positions of a plane as fp32, from an fp32 or a bf16-stored tensor (r06: the 16-channel PCR volume z, its gradient and the
+// up-sampler's input gradient dx' are stored in bf16 - half the bytes of the twelve passes that cross them per step)
+template <typename T> __device__ __forceinline__ float4 cm_load4(const T *p, int64_t i4) {
+    if constexpr (sizeof(T) == 4) {
+        return reinterpret_cast<const float4 *>(p)[i4];
+    } else {
+        const uint2 u = reinterpret_cast<const uint2 *>(p)[i4];
+        return float4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    }
+}
+template <typename T> __device__ __forceinline__ void cm_store4(T *p, int64_t i4, const float4 v) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<float4 *>(p)[i4] = v;
+    } else {
+        typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+        bf16x4s o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4s *>(p)[i4] = o;
+    }
+}
+
+template <bool BWD, typename TX = float, typename TG = float>
+__global__ __launch_bounds__(256) void cm_reduce_kernel(const TX *__restrict__ x, const TG *__restrict__ dy,
                                                         const float *__restrict__ y, int relu, int n, int c, int64_t p4,
                                                         int64_t chunk4, float *__restrict__ partial, const float *__restrict__ scale = nullptr,
                                                         const float *__restrict__ shift = nullptr) {
@@ -278,9 +299,9 @@ __global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict_
     for (int b = 0; b < n; ++b) {
         const int64_t base = ((int64_t)b * c + ch) * p4;
         for (int64_t q = q0 + threadIdx.x; q < q1; q += 256) {
-            const float4 xv = reinterpret_cast<const float4 *>(x)[base + q];
+            const float4 xv = cm_load4(x, base + q);
             if (BWD) {
-                float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
+                float4 g = cm_load4(dy, base + q);
                 if (relu) {
                     const float4 yv = y ? reinterpret_cast<const float4 *>(y)[base + q]
                                         : float4{fmaf(xv.x, msc, msh), fmaf(xv.y, msc, msh), fmaf(xv.z, msc, msh), fmaf(xv.w, msc, msh)};
@@ -310,11 +331,11 @@ __global__ __launch_bounds__(256) void cm_reduce_kernel(const float *__restrict_
 }
 
 // fwd: y = x*scale[c] + shift[c] (relu optional).  bwd (dy given): dx = a[c]*g + b[c]*x + d[c], g = dy*(y>0 if relu)
-template <bool BWD>
-__global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+template <bool BWD, typename TX = float, typename TG = float, typename TO = float>
+__global__ __launch_bounds__(256) void cm_apply_kernel(const TX *__restrict__ x, const TG *__restrict__ dy,
                                                        const float *__restrict__ y, const float *__restrict__ v0,
                                                        const float *__restrict__ v1, const float *__restrict__ v2, int relu,
-                                                       int c, int64_t p4, float *__restrict__ out, const float *__restrict__ scale = nullptr,
+                                                       int c, int64_t p4, TO *__restrict__ out, const float *__restrict__ scale = nullptr,
                                                        const float *__restrict__ shift = nullptr) {
     // grid (position blocks, N*C)
     const int plane = blockIdx.y, ch = plane % c;
@@ -322,10 +343,10 @@ __global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__
     const float msc = (BWD && scale) ? scale[ch] : 0.f, msh = (BWD && shift) ? shift[ch] : 0.f;   // y == nullptr: mask from x (see cm_reduce_kernel)
     const int64_t base = (int64_t)plane * p4;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < p4; q += (int64_t)gridDim.x * 256) {
-        const float4 xv = reinterpret_cast<const float4 *>(x)[base + q];
+        const float4 xv = cm_load4(x, base + q);
         float4 o;
         if (BWD) {
-            float4 g = reinterpret_cast<const float4 *>(dy)[base + q];
+            float4 g = cm_load4(dy, base + q);
             if (relu) {
                 const float4 yv = y ? reinterpret_cast<const float4 *>(y)[base + q]
                                     : float4{fmaf(xv.x, msc, msh), fmaf(xv.y, msc, msh), fmaf(xv.z, msc, msh), fmaf(xv.w, msc, msh)};
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(256) void cm_apply_kernel(const float *__restrict__
             o.x = fmaf(xv.x, a, b); o.y = fmaf(xv.y, a, b); o.z = fmaf(xv.z, a, b); o.w = fmaf(xv.w, a, b);
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         }
-        reinterpret_cast<float4 *>(out)[base + q] = o;
+        cm_store4(out, base + q, o);
     }
 }
 
@@ -942,6 +963,62 @@ extern "C" int s2d_bncm_bwd_apply_f32(const float *dy, const float *y, const flo
                        d, relu, c, p4, dx, (const float *)nullptr, (const float *)nullptr);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
+}
+
+/* r06: the same two passes on bf16-STORED tensors (x_bf16 / dy_bf16 / dx_bf16: 0 = fp32, 1 = bf16 [n][c][positions]; fp32 arithmetic and sums):
+ * the 16-channel PCR volume z [4,16,10,376,376], the up-sampler's input gradient and the batch norm's own output gradient in bf16 halve
+ * the 1.8 GB these two passes move per step.  Supported type combinations: (x, dy, dx) all fp32 | (fp32, bf16, fp32) | all bf16. */
+template <typename TX, typename TG>
+static int bncm_reduce_x_t(const void *dy, const void *x, const float *scale, const float *shift, int batch, int c, int64_t positions, float *sums,
+                           void *ws, size_t ws_bytes, hipStream_t st) {
+    S2D_CHECK_ARG(batch > 0 && c > 0 && c <= 65535 && positions > 0 && x && dy && sums && scale && shift, "bncm_bwd_reduce_x_t: bad argument");
+    if (positions & 3) {
+        set_error("bncm: positions per plane (%lld) must be a multiple of 4", (long long)positions);
+        return S2D_ERR_UNSUPPORTED;
+    }
+    CmPlan pl = cm_plan(batch, c, positions / 4);
+    if (!ws || ws_bytes < pl.ws_bytes) {
+        set_error("bncm: workspace too small (%zu < %zu)", ws_bytes, pl.ws_bytes);
+        return S2D_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL((cm_reduce_kernel<true, TX, TG>), dim3(pl.chunks, c), dim3(256), 0, st, (const TX *)x, (const TG *)dy, (const float *)nullptr, 1,
+                       batch, c, positions / 4, pl.chunk4, (float *)ws, scale, shift);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((2 * c + 3) / 4), dim3(256), 0, st, (const float *)ws, pl.chunks, 2 * c, sums);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+extern "C" int s2d_bncm_bwd_reduce_x_typed(const void *dy, int dy_bf16, const void *x, int x_bf16, const float *scale, const float *shift, int batch,
+                                           int c, int64_t positions, float *sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x_bf16 && !dy_bf16) return bncm_reduce_x_t<float, float>(dy, x, scale, shift, batch, c, positions, sums, ws, ws_bytes, st);
+    if (!x_bf16 && dy_bf16) return bncm_reduce_x_t<float, __bf16>(dy, x, scale, shift, batch, c, positions, sums, ws, ws_bytes, st);
+    if (x_bf16 && dy_bf16) return bncm_reduce_x_t<__bf16, __bf16>(dy, x, scale, shift, batch, c, positions, sums, ws, ws_bytes, st);
+    set_error("bncm_bwd_reduce_x_typed: unsupported storage combination");
+    return S2D_ERR_UNSUPPORTED;
+}
+
+template <typename TX, typename TG, typename TO>
+static int bncm_apply_x_t(const void *dy, const void *x, const float *scale, const float *shift, const float *a, const float *b, const float *d,
+                          int batch, int c, int64_t positions, void *dx, hipStream_t st) {
+    S2D_CHECK_ARG(dy && x && scale && shift && a && b && d && dx && batch > 0 && c > 0 && positions > 0 && !(positions & 3) &&
+                      (int64_t)batch * c <= 65535, "bncm_bwd_apply_x_typed: bad argument");
+    const int64_t p4 = positions / 4;
+    int64_t bx = ceil_div(p4, 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL((cm_apply_kernel<true, TX, TG, TO>), dim3((unsigned)bx, batch * c), dim3(256), 0, st, (const TX *)x, (const TG *)dy,
+                       (const float *)nullptr, a, b, d, 1, c, p4, (TO *)dx, scale, shift);
+    S2D_LAUNCH_CHECK();
+    return S2D_OK;
+}
+extern "C" int s2d_bncm_bwd_apply_x_typed(const void *dy, int dy_bf16, const void *x, int x_bf16, const float *scale, const float *shift,
+                                          const float *a, const float *b, const float *d, int batch, int c, int64_t positions, void *dx, int dx_bf16,
+                                          s2d_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!x_bf16 && !dy_bf16 && !dx_bf16) return bncm_apply_x_t<float, float, float>(dy, x, scale, shift, a, b, d, batch, c, positions, dx, st);
+    if (!x_bf16 && dy_bf16 && !dx_bf16) return bncm_apply_x_t<float, __bf16, float>(dy, x, scale, shift, a, b, d, batch, c, positions, dx, st);
+    if (x_bf16 && dy_bf16 && dx_bf16) return bncm_apply_x_t<__bf16, __bf16, __bf16>(dy, x, scale, shift, a, b, d, batch, c, positions, dx, st);
+    set_error("bncm_bwd_apply_x_typed: unsupported storage combination");
+    return S2D_ERR_UNSUPPORTED;
 }
 
 /* dx = a g + b x + d with g = dy where fma(x, scale, shift) > 0 (the ReLU mask re-derived from x, see s2d_bncm_bwd_reduce_x_f32) */

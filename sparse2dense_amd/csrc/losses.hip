@@ -745,11 +745,12 @@ __device__ __forceinline__ void pcr_load_norm(const float *__restrict__ bnp, Pcr
     __syncthreads();
 }
 
-template <int C, int CO, int V, typename TY = float>
+template <int C, int CO, int V, typename TY = float, typename TZ = float>
 __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__restrict__ y, const float *__restrict__ bnp, const float *__restrict__ hp,
                                                                   const float *__restrict__ w2, const float *__restrict__ b2, int64_t cells, int batch,
-                                                                  float *__restrict__ z, float *__restrict__ partial,
+                                                                  TZ *__restrict__ z, float *__restrict__ partial,
                                                                   float *__restrict__ zstat_partial) {
+    // TZ (r06): z stored in fp32 or bf16 (round to nearest even; its statistics are then those of the STORED values - what the batch norm behind it reads)
     __shared__ __attribute__((aligned(16))) float w2s[CO > 0 ? CO * C : 4];   // [C][CO]; read as float4 rows (see pcr_level_bwd_dense_kernel)
     __shared__ float b2s[CO > 0 ? CO : 1];
     __shared__ PcrHeadW<C> hw;
@@ -776,13 +777,13 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__re
 #pragma unroll
     for (int q = 0; q < (CO > 0 ? 2 * CO : 1); ++q) zs[q] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
-    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY);
+    const unsigned plane = (unsigned)cells * (unsigned)sizeof(TZ), yplane = (unsigned)cells * (unsigned)sizeof(TY);
     for (int b = 0; b < batch; ++b) {
         const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * yplane);
         const __amdgpu_buffer_rsrc_t zr = CO > 0 ? planes_rsrc(z + (int64_t)b * CO * cells, CO * plane) : yr;
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
             asm volatile("" ::: "memory");
-            const unsigned voff = j * (V * 4u), yoff = j * (V * (unsigned)sizeof(TY));
+            const unsigned voff = j * (V * (unsigned)sizeof(TZ)), yoff = j * (V * (unsigned)sizeof(TY));
             YPack<C, V, TY> yv;
 #pragma unroll
             for (int c = 0; c < C; ++c) yv.load(yr, yoff, c * yplane, c);
@@ -830,7 +831,13 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_dense_kernel(const TY *__re
             for (int k = 0; k < V; ++k) acc[0] += softplusf(x[k]);
             if (CO > 0) {
 #pragma unroll
-                for (int q = 0; q < CO; ++q) buf_store<V>(zr, voff, q * plane, za[q]);
+                for (int q = 0; q < CO; ++q) {
+                    if constexpr (sizeof(TZ) == 2) {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) za[q][k] = (float)(__bf16)za[q][k];
+                    }
+                    buf_store_t<V, TZ>(zr, voff, q * plane, za[q]);
+                }
                 if (zstat_partial) {
 #pragma unroll
                     for (int q = 0; q < CO; ++q)
@@ -921,8 +928,8 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t
 
 // pass A (APPLY = false): partial[block][3C+1] = dw_mask(C) | db_mask | sum dG*m (C) | sum dG*m*y (C), nothing written;
 // pass B (APPLY = true):  dy = a*dG*m + b*y + d
-template <int C, int CO, int V, bool APPLY, typename TY = float, typename TD = float>
-__global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__restrict__ y, const float *__restrict__ dz, const float *__restrict__ bnp,
+template <int C, int CO, int V, bool APPLY, typename TY = float, typename TD = float, typename TZ = float>
+__global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__restrict__ y, const TZ *__restrict__ dz, const float *__restrict__ bnp,
                                                                   const float *__restrict__ w2, const float *__restrict__ hp,
                                                                   const float *__restrict__ go_mask, const float *__restrict__ fin,
                                                                   const float *__restrict__ abd, int64_t cells, int batch, TD *__restrict__ dy,
@@ -950,21 +957,23 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
 #pragma unroll
     for (int c = 0; c < (APPLY ? 1 : 3 * C + 1); ++c) pw[c] = 0.f;
     const uint32_t sv = (uint32_t)(cells / V), stride = gridDim.x * 256u;
-    const unsigned plane = (unsigned)cells * 4u, yplane = (unsigned)cells * (unsigned)sizeof(TY), dplane = (unsigned)cells * (unsigned)sizeof(TD);
+    const unsigned plane = (unsigned)cells * (unsigned)sizeof(TZ), yplane = (unsigned)cells * (unsigned)sizeof(TY), dplane = (unsigned)cells * (unsigned)sizeof(TD);
     for (int b = 0; b < batch; ++b) {
         const __amdgpu_buffer_rsrc_t yr = planes_rsrc(y + (int64_t)b * C * cells, C * yplane);
         const __amdgpu_buffer_rsrc_t dyr = APPLY ? planes_rsrc(dy + (int64_t)b * C * cells, C * dplane) : yr;
         const __amdgpu_buffer_rsrc_t zr = CO > 0 ? planes_rsrc(dz + (int64_t)b * CO * cells, CO * plane) : yr;
         for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < sv; j += stride) {
             asm volatile("" ::: "memory");
-            const unsigned voff = j * (V * 4u), yoff = j * (V * (unsigned)sizeof(TY));
+            const unsigned voff = j * (V * (unsigned)sizeof(TZ)), yoff = j * (V * (unsigned)sizeof(TY));   // (voff: dz, r06 fp32 or bf16)
             YPack<C, V, TY> yv;
 #pragma unroll
             for (int c = 0; c < C; ++c) yv.load(yr, yoff, c * yplane, c);
-            float zv[CO > 0 ? CO : 1][V];
+            // dz as loaded (a bf16 dz stays PACKED until the second channel loop: unpacked next to the load, hipcc funnelled the 16 loads through one
+            // register with an s_waitcnt vmcnt(0) behind each - 16 memory latencies in a row, 284 -> 416 us for the sums pass)
+            YPack<(CO > 0 ? CO : 1), V, TZ> zp;
             if (CO > 0) {
 #pragma unroll
-                for (int q = 0; q < CO; ++q) buf_load<V>(zr, voff, q * plane, zv[q]);
+                for (int q = 0; q < CO; ++q) zp.load(zr, voff, q * plane, q);
             }
             float x[V], dm[V];
 #pragma unroll
@@ -982,6 +991,13 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_dense_kernel(const TY *__re
                 if constexpr (!APPLY) pw[C] += dm[k];
             }
             asm volatile("" ::: "memory");   // re-read the per-channel constants below instead of keeping 3C of them live across both loops
+            float zv[CO > 0 ? CO : 1][V];
+            if (CO > 0) {
+#pragma unroll
+                for (int q = 0; q < CO; ++q)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) zv[q][k] = zp.get(q, k);
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float4 cc = cstv[c];
@@ -1162,15 +1178,15 @@ __global__ __launch_bounds__(256) void pcr_level_fold_kernel(const float *__rest
     else bn_sums[t - 4 * C - 4] = r;
 }
 
-template <int C, int CO, int V, typename TY = float>
+template <int C, int CO, int V, typename TY = float, typename TZ = float>
 static int pcr_level_fwd_t(const TY *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
-                           int64_t m, PcrGeo geo, float *z, float *out8, float *ws, hipStream_t st, float *z_stats = nullptr) {
+                           int64_t m, PcrGeo geo, TZ *z, float *out8, float *ws, hipStream_t st, float *z_stats = nullptr) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w, n = cells * geo.batch;
     float *dense_partial = ws, *sparse_partial = ws + PCRH_DENSE_BLOCKS;
     float *zstat_partial = (CO > 0 && z_stats) ? ws + PCRH_DENSE_BLOCKS + (size_t)PCRH_SPARSE_BLOCKS * 5 : nullptr;   // [nd][2 CO] behind the sparse rows
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V, TY>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
+    hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V, TY, TZ>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
                        zstat_partial);
     if (zstat_partial) hipLaunchKernelGGL(pcr_zstats_fold_kernel, dim3(2 * CO), dim3(64), 0, st, (const float *)zstat_partial, nd, 2 * CO, z_stats);
     hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C, TY>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
@@ -1179,15 +1195,15 @@ static int pcr_level_fwd_t(const TY *y, const float *bnp, const float *hp, const
     return S2D_OK;
 }
 
-template <int C, int CO, int V, typename TY = float>
+template <int C, int CO, int V, typename TY = float, typename TZ = float>
 static int pcr_level_bwd_sums_t(const TY *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
-                                const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, float *grads,
+                                const float *fin, const float *go_mask, const float *go_off, const TZ *dz, const float *w2, float *grads,
                                 float *bn_sums, float *ws, hipStream_t st) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
     float *dense_partial = ws, *sparse_partial = ws + (size_t)PCRH_DENSE_BLOCKS * (3 * C + 1);
     const int nd = (int)std::min<int64_t>(PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
     const int ns = (int)std::min<int64_t>(PCRH_SPARSE_BLOCKS, std::max<int64_t>(1, ceil_div(m, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false, TY, float>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, false, TY, float, TZ>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, nullptr, cells,
                        geo.batch, (float *)nullptr, dense_partial);
     constexpr int CG = C == 32 ? 8 : C;   // channel groups of the sparse pass (accumulator registers)
     hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false, TY, float>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask,
@@ -1197,13 +1213,13 @@ static int pcr_level_bwd_sums_t(const TY *y, const float *bnp, const float *hp, 
     return S2D_OK;
 }
 
-template <int C, int CO, int V, typename TY = float, typename TD = float>
+template <int C, int CO, int V, typename TY = float, typename TD = float, typename TZ = float>
 static int pcr_level_bwd_apply_t(const TY *y, const float *bnp, const float *hp, const int32_t *coors, const float *feats, int64_t m, PcrGeo geo,
-                                 const float *fin, const float *go_mask, const float *go_off, const float *dz, const float *w2, const float *abd,
+                                 const float *fin, const float *go_mask, const float *go_off, const TZ *dz, const float *w2, const float *abd,
                                  TD *dy, hipStream_t st) {
     const int64_t cells = (int64_t)geo.d * geo.h * geo.w;
     const int nd = (int)std::min<int64_t>(2 * PCRH_DENSE_BLOCKS, std::max<int64_t>(1, ceil_div(cells / V, 256)));
-    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true, TY, TD>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
+    hipLaunchKernelGGL((pcr_level_bwd_dense_kernel<C, CO, V, true, TY, TD, TZ>), dim3(nd), dim3(256), 0, st, y, dz, bnp, w2, hp, go_mask, fin, abd, cells, geo.batch,
                        dy, nullptr);
     if (m > 0)
         hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true, TY, TD>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
@@ -1226,7 +1242,7 @@ extern "C" size_t s2d_pcr_level_workspace_bytes(int c) {
 static int pcr_level_fwd_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
                                      const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
                                      float *z_stats /* [2 co] = sum | sum of squares of z per channel, or NULL */, float *out8, void *ws,
-                                     size_t ws_bytes, s2d_stream_t stream) {
+                                     size_t ws_bytes, s2d_stream_t stream, int z16 = 0) {
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
                       (co == 0 || (w2 && z)),
                   "pcr_level_fwd: bad argument");
@@ -1241,6 +1257,14 @@ static int pcr_level_fwd_any(const void *yv, int y16, const float *bn_scale_shif
     PcrGeo geo{batch, d, h, w};
     hipStream_t st = (hipStream_t)stream;
     float *wsf = (float *)ws;
+    if (z16) {   // r06: z written in bf16 (the 32 -> 16 level behind a bf16-stored y)
+        if (!(y16 && c == 32 && co == 16)) {
+            set_error("pcr_level_fwd: bf16-stored z is built for the bf16-y 32 -> 16 level only");
+            return S2D_ERR_UNSUPPORTED;
+        }
+        return pcr_level_fwd_t<32, 16, 2, __bf16, __bf16>((const __bf16 *)yv, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, (__bf16 *)z, out8,
+                                                          wsf, st, z_stats);
+    }
     if (y16) {
         const __bf16 *y = (const __bf16 *)yv;
         if (c == 32 && co == 16) return pcr_level_fwd_t<32, 16, 2, __bf16>(y, bn_scale_shift, head_params, w2, b2, coors, feats, m, geo, z, out8, wsf, st, z_stats);
@@ -1264,13 +1288,21 @@ extern "C" int s2d_pcr_level_fwd_y16(const void *y, const float *bn_scale_shift,
     return pcr_level_fwd_any(y, 1, bn_scale_shift, head_params, w2, b2, coors, feats, m, batch, c, co, d, h, w, z, z_stats, out8, ws, ws_bytes, stream);
 }
 
+/* r06: ... and z written as bf16 [B][co][cells] too (c = 32, co = 16): read by s2d_convt3d_mfma_fwd_stats_y16_norm_x16 / _wgrad_d16_norm_x16 and the
+ * typed s2d_bncm_bwd_* passes; z_stats are the sums of the stored (rounded) values */
+extern "C" int s2d_pcr_level_fwd_y16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
+                                         const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, void *z_bf16,
+                                         float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_fwd_any(y, 1, bn_scale_shift, head_params, w2, b2, coors, feats, m, batch, c, co, d, h, w, (float *)z_bf16, z_stats, out8, ws, ws_bytes,
+                             stream, 1);
+}
 
 // pass A of the backward: grads[4C+4] = dw_mask[C] | dw_off[3][C] | db_mask | db_off[3] and bn_sums[2C] = (sum dG*m, sum dG*m*y) per
 // channel, the batch norm's backward reduction (s2d_bncm_bwd_reduce_f32's output)
 static int pcr_level_bwd_sums_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
-                                          float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+                                          float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream, int z16 = 0) {
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && grads && bn_sums && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_sums: bad argument");
@@ -1297,6 +1329,14 @@ static int pcr_level_bwd_sums_any(const void *yv, int y16, const float *bn_scale
         return pcr_level_bwd_sums_t<3, 0, 4, TY_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, grads, \
                                                   bn_sums, wsf, st);                                                                             \
     } while (0)
+    if (z16) {   // r06: dz stored in bf16 (see s2d_pcr_level_fwd_y16_z16)
+        if (!(y16 && c == 32 && co == 16)) {
+            set_error("pcr_level_bwd_sums: bf16-stored dz is built for the bf16-y 32 -> 16 level only");
+            return S2D_ERR_UNSUPPORTED;
+        }
+        return pcr_level_bwd_sums_t<32, 16, 2, __bf16, __bf16>((const __bf16 *)yv, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask,
+                                                               go_offset, (const __bf16 *)dz, w2, grads, bn_sums, wsf, st);
+    }
     if (y16) S2D_LVL_SUMS(__bf16);
     S2D_LVL_SUMS(float);
 #undef S2D_LVL_SUMS
@@ -1315,12 +1355,19 @@ extern "C" int s2d_pcr_level_bwd_sums_y16(const void *y, const float *bn_scale_s
     return pcr_level_bwd_sums_any(y, 1, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, grads,
                                   bn_sums, ws, ws_bytes, stream);
 }
+extern "C" int s2d_pcr_level_bwd_sums_y16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                              const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                              const float *go_mask, const float *go_offset, const void *dz_bf16, const float *w2, int co, float *grads,
+                                              float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream) {
+    return pcr_level_bwd_sums_any(y, 1, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset,
+                                  (const float *)dz_bf16, w2, co, grads, bn_sums, ws, ws_bytes, stream, 1);
+}
 
 // pass B: dy[B][C][cells] = a*dG*m + b*y + d with abd (device, 3C) = a[C] | b[C] | d[C] from the batch-norm backward finalisation
 static int pcr_level_bwd_apply_any(const void *yv, int y16 /* 0: fp32 y, fp32 dy; 1: bf16 y, fp32 dy; 2: bf16 y, bf16 dy */, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                            const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                            const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
-                                           void *dyv, s2d_stream_t stream) {
+                                           void *dyv, s2d_stream_t stream, int z16 = 0) {
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dyv && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_apply: bad argument");
@@ -1343,6 +1390,14 @@ static int pcr_level_bwd_apply_any(const void *yv, int y16 /* 0: fp32 y, fp32 dy
         return pcr_level_bwd_apply_t<3, 0, 4, TY_, TD_>(y, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask, go_offset, dz, w2, abd, dy, \
                                                    st);                                                                                           \
     } while (0)
+    if (z16) {   // r06: dz stored in bf16
+        if (!(y16 == 2 && c == 32 && co == 16)) {
+            set_error("pcr_level_bwd_apply: bf16-stored dz is built for the bf16-y / bf16-dy 32 -> 16 level only");
+            return S2D_ERR_UNSUPPORTED;
+        }
+        return pcr_level_bwd_apply_t<32, 16, 2, __bf16, __bf16, __bf16>((const __bf16 *)yv, bn_scale_shift, head_params, coors, feats, m, geo, fwd_out8, go_mask,
+                                                                        go_offset, (const __bf16 *)dz, w2, abd, (__bf16 *)dyv, st);
+    }
     if (y16 == 2) S2D_LVL_APPLY(__bf16, __bf16);
     if (y16) S2D_LVL_APPLY(__bf16, float);
     S2D_LVL_APPLY(float, float);
@@ -1369,6 +1424,13 @@ extern "C" int s2d_pcr_level_bwd_apply_y16_d16(const void *y, const float *bn_sc
                                                const float *abd, void *dy_bf16, s2d_stream_t stream) {
     return pcr_level_bwd_apply_any(y, 2, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset, dz, w2, co, abd,
                                    dy_bf16, stream);
+}
+extern "C" int s2d_pcr_level_bwd_apply_y16_d16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
+                                                   const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
+                                                   const float *go_mask, const float *go_offset, const void *dz_bf16, const float *w2, int co,
+                                                   const float *abd, void *dy_bf16, s2d_stream_t stream) {
+    return pcr_level_bwd_apply_any(y, 2, bn_scale_shift, head_params, coors, feats, m, batch, c, d, h, w, fwd_out8, go_mask, go_offset,
+                                   (const float *)dz_bf16, w2, co, abd, dy_bf16, stream, 1);
 }
 
 // =====================================================================================================================

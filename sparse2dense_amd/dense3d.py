@@ -55,10 +55,16 @@ def pointwise_conv_wgrad(x, dout, want_db, bf16=False, norm=None):
         dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
         db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_db else None
         ws = _ws(lib.s2d_pointwise_conv_wgrad_workspace_bytes(cin, cout), x.device)
+        if dout.dtype == torch.bfloat16 and cin == 32:   # r06: the bf16-stored gradient of the bf16-stored z
+            check(lib.s2d_pointwise_conv_wgrad_norm_x16_d16(_ptr(x), _ptr(norm), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                                            _stream()), "s2d_pointwise_conv_wgrad_norm_x16_d16")
+            return dw, db
+        dout = dout.float() if dout.dtype != torch.float32 else dout
         check(lib.s2d_pointwise_conv_wgrad_norm_x16(_ptr(x), _ptr(norm), _ptr(dout), n, cin, cout, pos, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
                                                     _stream()), "s2d_pointwise_conv_wgrad_norm_x16")
         return dw, db
     lib = _lib.load()
+    dout = dout.float() if dout.dtype != torch.float32 else dout
     n, cin, cout = dout.shape[0], x.shape[1], dout.shape[1]
     pos = x[0, 0].numel()
     dw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
@@ -239,6 +245,9 @@ class _ConvT3dFn(torch.autograd.Function):
         ctx.mfma = bool(bf16 and lib.s2d_convt3d_mfma_supported(cin, cout))
         ctx.in_norm = in_norm
         assert in_norm is None or (ctx.mfma and bn_stats and out_bf16 and lib.s2d_convt3d_mfma_norm_supported(cin, cout, d, h, w))
+        # r06: a bf16-STORED raw input (direct calls from heads._UpsampleLevelFn only, with in_norm): read by the x16 kernels, gradient returned in bf16
+        x16 = x.dtype == torch.bfloat16
+        assert not x16 or (in_norm is not None and lib.s2d_convt3d_mfma_x16_supported(cin, cout, d, h, w)), "bf16-stored input: the pre-norm x16 form only"
         # r04: the raw output may be STORED in bf16 (half the bytes for the four passes of the fused PCR level that read it); only with
         # the matrix-core kernel and the statistics epilogue, i.e. on the fused training path
         out_bf16 = bool(out_bf16 and ctx.mfma and bn_stats)
@@ -250,8 +259,9 @@ class _ConvT3dFn(torch.autograd.Function):
                 tiles = lib.s2d_convt3d_mfma_stats_tiles(n, cin, d, h, w)
                 partial = torch.empty((tiles, 2, cout), dtype=torch.float32, device=x.device)
             if in_norm is not None:
-                check(lib.s2d_convt3d_mfma_fwd_stats_y16_norm(_ptr(x), _ptr(in_norm), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w,
-                                                              _ptr(out), _ptr(partial), _stream()), "s2d_convt3d_mfma_fwd_stats_y16_norm")
+                fwd_norm = lib.s2d_convt3d_mfma_fwd_stats_y16_norm_x16 if x16 else lib.s2d_convt3d_mfma_fwd_stats_y16_norm
+                check(fwd_norm(_ptr(x), _ptr(in_norm), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w,
+                               _ptr(out), _ptr(partial), _stream()), "s2d_convt3d_mfma_fwd_stats_y16_norm")
             else:
                 entry = lib.s2d_convt3d_mfma_fwd_stats_y16 if out_bf16 else lib.s2d_convt3d_mfma_fwd_stats
                 check(entry(_ptr(x), _ptr(_convt_packed(weight)), _ptr(bias), n, cin, cout, d, h, w, _ptr(out), _ptr(partial), _stream()),
@@ -289,9 +299,14 @@ class _ConvT3dFn(torch.autograd.Function):
         assert in_norm is None or d16, "the input-norm fold runs with the bf16-stored gradient only"
         dout = dout.contiguous() if d16 else dout.float().contiguous()
         dx = dw = db = None
+        x16 = x.dtype == torch.bfloat16   # (forward: the pre-norm x16 form, which implies d16)
+        assert not x16 or d16
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if d16:
+            if x16:
+                check(lib.s2d_convt3d_mfma_dgrad_d16_x16(_ptr(dout), _ptr(_convt_packed(weight)), n, cin, cout, d, h, w, _ptr(dx), _stream()),
+                      "s2d_convt3d_mfma_dgrad_d16_x16")
+            elif d16:
                 check(lib.s2d_convt3d_mfma_dgrad_d16(_ptr(dout), _ptr(_convt_packed(weight)), n, cin, cout, d, h, w, _ptr(dx), _stream()),
                       "s2d_convt3d_mfma_dgrad_d16")
             elif ctx.mfma:
@@ -304,8 +319,13 @@ class _ConvT3dFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             if _DEBUG_CT_WGRAD and in_norm is not None:   # debugging aid (S2D_DEBUG_CT_WGRAD, tools/side_stress.py): stand-ins for this launch
                 from . import _debug
-                return _debug.ct_wgrad_stand_in(_DEBUG_CT_WGRAD, dw, x, dout, in_norm, (n, cin, cout, d, h, w), getattr(ctx, "_dbg_clones", None))
-            if d16 and in_norm is not None:
+                return _debug.ct_wgrad_stand_in(_DEBUG_CT_WGRAD, dw, x.float() if x16 else x, dout, in_norm, (n, cin, cout, d, h, w),
+                                                getattr(ctx, "_dbg_clones", None))
+            if x16:
+                ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
+                check(lib.s2d_convt3d_mfma_wgrad_d16_norm_x16(_ptr(x), _ptr(in_norm), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
+                                                              _stream()), "s2d_convt3d_mfma_wgrad_d16_norm_x16")
+            elif d16 and in_norm is not None:
                 ws = _ws(lib.s2d_convt3d_mfma_wgrad_workspace_bytes(n, cin, cout, d, h, w), x.device)
                 check(lib.s2d_convt3d_mfma_wgrad_d16_norm(_ptr(x), _ptr(in_norm), _ptr(dout), n, cin, cout, d, h, w, _ptr(dw), _ptr(ws), ws.numel(),
                                                           _stream()), "s2d_convt3d_mfma_wgrad_d16_norm")
@@ -439,7 +459,12 @@ def bncm_backward(dy, x, gamma, mean, invstd, count, scale, shift, relu, sync, t
     dy = dy.contiguous()
     n, c = x.shape[0], x.shape[1]
     pos = x[0, 0].numel()
-    if relu:
+    x16, g16 = x.dtype == torch.bfloat16, dy.dtype == torch.bfloat16
+    typed = bool(relu and (x16 or g16))   # r06: bf16-stored x / dy (and then dx): the typed passes (storage flags per tensor)
+    assert (not x16 or g16) and (typed or not (x16 or g16)), "bf16-stored operands: ReLU form, dy in bf16 whenever x is"
+    if typed:
+        sums = _bncm_reduce("s2d_bncm_bwd_reduce_x_typed", (_ptr(dy), int(g16), _ptr(x), int(x16), _ptr(scale), _ptr(shift)), n, c, pos, x.device)
+    elif relu:
         sums = _bncm_reduce("s2d_bncm_bwd_reduce_x_f32", (_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift)), n, c, pos, x.device)
     else:
         sums = _bncm_reduce("s2d_bncm_bwd_reduce_f32", (_ptr(dy), None, _ptr(x), 0), n, c, pos, x.device)
@@ -457,7 +482,10 @@ def bncm_backward(dy, x, gamma, mean, invstd, count, scale, shift, relu, sync, t
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
-        if relu:
+        if typed:
+            check(lib.s2d_bncm_bwd_apply_x_typed(_ptr(dy), int(g16), _ptr(x), int(x16), _ptr(scale), _ptr(shift), _ptr(a), _ptr(b), _ptr(d), n, c, pos,
+                                                 _ptr(dx), int(x16), _stream()), "s2d_bncm_bwd_apply_x_typed")
+        elif relu:
             check(lib.s2d_bncm_bwd_apply_x_f32(_ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(a), _ptr(b), _ptr(d), n, c, pos, _ptr(dx), _stream()),
                   "s2d_bncm_bwd_apply_x_f32")
         else:

@@ -323,7 +323,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
     written.  The batch-norm statistics / finalisation (running stats, SyncBN all-reduces) are the FastBatchNorm3d ones."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16, stats=None, z_stats_out=None):
+    def forward(ctx, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16, stats=None, z_stats_out=None, z16=False):
+        """z16 (r06, direct calls from _UpsampleLevelFn only): z = next_conv(relu(bn(y))) is STORED in bf16 (c = 32 -> co = 16 behind a bf16 y) - its
+        reader is the next up-sampler node in its x16 form, and the gradient that comes back for it is bf16 as well"""
         from . import _lib, collective as _collective, hip_ops as H
         from .dense2d import _ptr, _stream, _ws
         from .dense3d import _bncm_reduce
@@ -355,11 +357,15 @@ class _PcrLevelNormFn(torch.autograd.Function):
         if w2 is not None:
             co = w2.shape[0]
             w2d = w2.reshape(co, c).contiguous()
-            z = torch.empty((b, co, d, h, w), dtype=torch.float32, device=dev)
+            z16 = bool(z16 and y16 and c == 32 and co == 16)
+            z = torch.empty((b, co, d, h, w), dtype=torch.bfloat16 if z16 else torch.float32, device=dev)
+        else:
+            z16 = False
+        ctx.z16 = z16
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         # the kernel that writes z also reduces its per-channel (sum, sum of squares): the statistics of the BatchNorm3d behind the conv
         zst = torch.empty(2 * co, dtype=torch.float32, device=dev) if (z_stats_out is not None and c == 32 and co == 16) else None
-        _lib.check((lib.s2d_pcr_level_fwd_y16 if y16 else lib.s2d_pcr_level_fwd_f32)(
+        _lib.check((lib.s2d_pcr_level_fwd_y16_z16 if z16 else lib.s2d_pcr_level_fwd_y16 if y16 else lib.s2d_pcr_level_fwd_f32)(
             _ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h, w, _ptr(z), _ptr(zst), _ptr(out),
             _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd")
         if zst is not None:
@@ -383,21 +389,28 @@ class _PcrLevelNormFn(torch.autograd.Function):
         go_mask = zero() if go_mask is None else go_mask.float().reshape(1).contiguous()
         go_off = zero() if go_off is None else go_off.float().reshape(1).contiguous()
         co = 0
+        y16 = y.dtype == torch.bfloat16
+        dy16 = y16 and getattr(ctx, "dy16", False)   # set by _UpsampleLevelFn: dy never leaves the node and its readers take bf16
+        z16 = False
         if w2d is not None:
             co = w2d.shape[0]
-            dz = torch.zeros((b, co, d, h, w), dtype=torch.float32, device=dev) if dz is None else dz.contiguous()
+            # r06: the bf16-stored z's gradient arrives in bf16 and is read as such (the level's bf16-y / bf16-dy kernels); anything else is widened
+            z16 = bool(getattr(ctx, "z16", False) and dy16 and (dz is None or dz.dtype == torch.bfloat16))
+            if dz is None:
+                dz = torch.zeros((b, co, d, h, w), dtype=torch.bfloat16 if z16 else torch.float32, device=dev)
+            else:
+                dz = dz.contiguous() if (z16 or dz.dtype == torch.float32) else dz.float().contiguous()
         grads = torch.empty(4 * c + 4, dtype=torch.float32, device=dev)   # dw_mask | dw_off | db_mask | db_off
         sums = torch.empty(2 * c, dtype=torch.float32, device=dev)
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         args = (_ptr(y), _ptr(norm), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(go_mask), _ptr(go_off),
                 _ptr(dz) if co else None, _ptr(w2d) if co else None, co)
-        y16 = y.dtype == torch.bfloat16
-        _lib.check((lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(*args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(),
-                                                                                                _stream()), "s2d_pcr_level_bwd_sums")
+        _lib.check((lib.s2d_pcr_level_bwd_sums_y16_z16 if z16 else lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(
+            *args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums")
         if os.environ.get("S2D_DEBUG_SUMS2") == "1":   # debugging aid (tools/side_stress.py): the same launch again, results kept for a comparison after the pass
             grads2, sums2 = torch.empty_like(grads), torch.empty_like(sums)
-            _lib.check((lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(*args, _ptr(grads2), _ptr(sums2), _ptr(ws), ws.numel(),
-                                                                                                    _stream()), "s2d_pcr_level_bwd_sums")
+            _lib.check((lib.s2d_pcr_level_bwd_sums_y16_z16 if z16 else lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(
+                *args, _ptr(grads2), _ptr(sums2), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums")
             DEBUG_SUMS.append((c, co, sums, sums2, grads, grads2))
         sums_all = sums
         if ctx.sync:
@@ -409,9 +422,9 @@ class _PcrLevelNormFn(torch.autograd.Function):
         # sum over this rank's rows of dy = a g + b y + d, per channel, from the sums at hand (= the bias gradient of the conv that produced
         # y; mathematically zero behind a training-mode batch norm, fp32 rounding noise here as in the reference) - no pass over dy
         ctx.dy_sum = fin[2].reshape(-1) * sums[:c] + fin[3].reshape(-1) * ctx.local_ysum + fin[4].reshape(-1) * ctx.local_rows
-        dy16 = y16 and getattr(ctx, "dy16", False)   # set by _UpsampleLevelFn: dy never leaves the node and its readers take bf16
         dy = torch.empty(y.shape, dtype=torch.bfloat16 if dy16 else torch.float32, device=dev)
-        apply = lib.s2d_pcr_level_bwd_apply_y16_d16 if dy16 else (lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32)
+        apply = (lib.s2d_pcr_level_bwd_apply_y16_d16_z16 if z16 else lib.s2d_pcr_level_bwd_apply_y16_d16 if dy16
+                 else (lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32))
         _lib.check(apply(*args, _ptr(abd), _ptr(dy), _stream()), "s2d_pcr_level_bwd_apply")
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None
@@ -426,7 +439,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
             if isinstance(ctx, torch.autograd.function.FunctionCtx):   # (composed by _UpsampleLevelFn otherwise: it strips the marker)
                 dw2, db2 = side.undefer(dw2), side.undefer(db2)
         return (dy, dgamma, dbeta, grads[:c].reshape(wm_shape), grads[4 * c:4 * c + 1], grads[c:4 * c].reshape(wo_shape), grads[4 * c + 1:],
-                None, None, dw2, db2, None, None, None, None)
+                None, None, dw2, db2, None, None, None, None, None)
 
 
 def pcr_level_norm(y, bn, mask_conv, offset_conv, coors, feats, next_conv=None):
@@ -470,13 +483,16 @@ class _UpsampleLevelFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ct_w, ct_b, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, z_stats_out, y16,
-                pre_gamma=None, pre_beta=None, pre_bn=None, pre_stats=None):
+                pre_gamma=None, pre_beta=None, pre_bn=None, pre_stats=None, z16=False):
         from . import _lib, collective as _collective
         from .dense3d import _ConvT3dFn, bncm_finalize_fwd
         c1 = _SubCtx((ctx.needs_input_grad[0], ctx.needs_input_grad[1], ct_b is not None and ctx.needs_input_grad[2], False, False, False))
         # pre_bn: the BatchNorm3d + ReLU in FRONT of the up-sampler is part of the node too - x is its raw input, the up-sampler's kernels
         # normalise it on load (forward and weight gradient) and the normalised tensor is never written or read
         in_norm = None
+        if x.dtype == torch.bfloat16 and (pre_bn is None or pre_stats is None
+                                          or not _lib.load().s2d_convt3d_mfma_x16_supported(x.shape[1], ct_w.shape[1], *x.shape[2:])):
+            x = x.float()   # (a bf16-stored input is read by the x16 kernels of the pre-norm form only; never on the configured path)
         if pre_bn is not None:
             x = x.contiguous()
             sync = _collective.sync_on()
@@ -485,7 +501,8 @@ class _UpsampleLevelFn(torch.autograd.Function):
             ctx.pre = (pre_gamma, mean, invstd, count, scale.contiguous(), shift.contiguous(), sync)
         y, stats = _ConvT3dFn.forward(c1, x, ct_w, ct_b, True, True, y16, in_norm)
         c2 = _SubCtx((True,) * 3 + (False,) * 12)
-        ml, ol, z = _PcrLevelNormFn.forward(c2, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, stats, z_stats_out)
+        ml, ol, z = _PcrLevelNormFn.forward(c2, y, gamma, beta, w_mask, b_mask, w_off, b_off, coors, feats, w2, b2, bn, bf16_next, stats, z_stats_out,
+                                            bool(z16 and y16))
         # the gradient of y goes from the level's backward straight into the up-sampler's: stored in bf16 as well when the up-sampler's
         # matrix-core kernels read that (they round it to bf16 on load in any case; S2D_PCR_DY16=0 keeps it fp32)
         c2.dy16 = bool(y16 and os.environ.get("S2D_PCR_DY16", "1") != "0"
@@ -508,13 +525,15 @@ class _UpsampleLevelFn(torch.autograd.Function):
             dx, dpg, dpb = bncm_backward(dx, x, pre_gamma, mean, invstd, count, scale, shift, True, sync, True, ctx.needs_input_grad[0])
         from . import side
         u = side.undefer
-        return dx, u(dw), db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, u(dw2), u(db2), None, None, None, None, dpg, dpb, None, None
+        return dx, u(dw), db, dgamma, dbeta, dwm, dbm, dwo, dbo, None, None, u(dw2), u(db2), None, None, None, None, dpg, dpb, None, None, None
 
 
-def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True, pre_bn=None):
+def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=None, y16=True, pre_bn=None, z16=False):
     """`pcr_level_norm(ct(x), bn, ...)` as one node (see _UpsampleLevelFn); ct = dense3d.ConvTranspose3dK4S2 in its bf16-compute mode.
     pre_bn (a training-mode FastBatchNorm3d with fused ReLU, y16 only): `pcr_level_norm(ct(pre_bn(x)), bn, ...)` - the batch norm in front
-    of the up-sampler joins the node and its output is never materialised."""
+    of the up-sampler joins the node and its output is never materialised.
+    z16 (r06): the returned z is stored in bf16 - pass it only to an `upsample_level(..., pre_bn=...)` whose layer is
+    `upsample_level_x16_supported` (it reads a bf16 x and returns a bf16 gradient for it)."""
     assert bn.training and bn.affine and getattr(bn, "fused_relu", False) and bn.momentum is not None
     coors = coors if coors.dtype == torch.int32 else coors.int()
     holder = []
@@ -525,7 +544,7 @@ def upsample_level(ct, x, bn, mask_conv, offset_conv, coors, feats, next_conv=No
         pre = (pre_bn.weight, pre_bn.bias, pre_bn, stats if stats is not None and stats.numel() == 2 * pre_bn.num_features else None)
     out = _UpsampleLevelFn.apply(x, ct.weight, ct.bias, bn.weight, bn.bias, mask_conv.weight, mask_conv.bias, offset_conv.weight, offset_conv.bias,
                                  coors, feats.float(), None if next_conv is None else next_conv.weight, None if next_conv is None else next_conv.bias,
-                                 bn, bool(getattr(next_conv, "bf16_compute", False)), holder, bool(y16), *pre)
+                                 bn, bool(getattr(next_conv, "bf16_compute", False)), holder, bool(y16), *pre, bool(z16))
     z = out[2] if len(out) > 2 else None
     if holder and z is not None:
         z._s2d_bn_stats = holder[0]
@@ -543,6 +562,15 @@ def upsample_level_pre_bn_supported(ct, in_dhw, pre_bn):
             and pre_bn.num_features == ct.weight.shape[0] and (int(in_dhw[0]) * int(in_dhw[1]) * int(in_dhw[2])) % 4 == 0):
         return False
     return bool(_lib.load().s2d_convt3d_mfma_norm_supported(ct.weight.shape[0], ct.weight.shape[1], *[int(v) for v in in_dhw]))
+
+
+def upsample_level_x16_supported(ct, in_dhw, pre_bn):
+    """the up-sampler node can take a bf16-STORED raw input (and return its gradient in bf16): the pre-norm form on the narrow 16-channel
+    layer (S2D_PCR_Z16=0 keeps the volume between the two levels in fp32)"""
+    from . import _lib
+    if os.environ.get("S2D_PCR_Z16", "1") == "0" or not upsample_level_pre_bn_supported(ct, in_dhw, pre_bn):
+        return False
+    return bool(_lib.load().s2d_convt3d_mfma_x16_supported(ct.weight.shape[0], ct.weight.shape[1], *[int(v) for v in in_dhw]))
 
 
 def upsample_level_supported(ct, in_dhw, next_conv=None):

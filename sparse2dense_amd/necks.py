@@ -20,7 +20,7 @@ from torch import nn
 from .backbones import build_norm_layer
 from .dense2d import Conv1x1, Conv2x2S2, Conv3x3, ConvT2x2S2, ConvT4x4S2, DepthwiseConv7, FastBatchNorm2d, WideLayerNorm, fuse_bn_relu
 from .dense3d import ConvTranspose3dK4S2, FastBatchNorm3d, PointwiseConv3d
-from .heads import (pcr_level, pcr_level_norm, pcr_level_supported, upsample_level, upsample_level_pre_bn_supported,
+from .heads import (pcr_level, pcr_level_norm, pcr_level_supported, upsample_level, upsample_level_pre_bn_supported, upsample_level_x16_supported,
                     upsample_level_supported)
 from .registry import NECKS
 
@@ -330,8 +330,11 @@ class S2D_RPN(RPN):
                 pre1 = self.generator_1[1] if upsample_level_pre_bn_supported(self.generator_1[3], (5, h, w), self.generator_1[1]) else None
                 pre2 = self.generator_2[1] if upsample_level_pre_bn_supported(self.generator_2[3], (10, 2 * h, 2 * w), self.generator_2[1]) else None
                 mid = first() if pre1 is not None else self.generator_1[1:3](first())
+                # r06: the 16-channel volume between the two levels (362 MB in fp32 at B = 4), its gradient and the second up-sampler's input gradient
+                # are stored in bf16 when that node reads one (heads.upsample_level_x16_supported; S2D_PCR_Z16=0: fp32)
+                z16 = pre2 is not None and upsample_level_x16_supported(self.generator_2[3], (10, 2 * h, 2 * w), pre2)
                 gen_mask_4, gen_offset_4, z = upsample_level(self.generator_1[3], mid, bn1, self.gen_mask_4[0], self.gen_out_4[0], *tg[4],
-                                                              next_conv=self.generator_2[0], pre_bn=pre1)
+                                                              next_conv=self.generator_2[0], pre_bn=pre1, z16=z16)
                 mid2 = z if pre2 is not None else self.generator_2[1:3](z)
                 gen_mask_2, gen_offset_2, _ = upsample_level(self.generator_2[3], mid2, bn2, self.gen_mask_2[0], self.gen_out_2[0], *tg[2], pre_bn=pre2)
                 return gen_offset_2, gen_mask_2, gen_offset_4, gen_mask_4

@@ -432,3 +432,104 @@ def test_upsample_level_with_the_batch_norm_in_front_folded_in(cin, cout, co, b,
         assert err <= (1e-4 if i == 4 else 1e-6), (i, err)   # (i == 4: the up-sampler's bias gradient, noise around zero)
     assert torch.equal(got[4].running_mean, ref[4].running_mean) and torch.equal(got[4].running_var, ref[4].running_var)
     assert int(got[4].num_batches_tracked) == 1
+
+
+def _level_modules(cin, cout, co, gen, pre=False):
+    from torch import nn
+    from sparse2dense_amd.dense3d import ConvTranspose3dK4S2, FastBatchNorm3d
+    pre_bn = None
+    if pre:
+        pre_bn = FastBatchNorm3d(cin, fused_relu=True)
+        with torch.no_grad():
+            pre_bn.weight.copy_(torch.rand(cin, generator=gen) + 0.5)
+            pre_bn.bias.copy_(torch.randn(cin, generator=gen) * 0.3)
+    ct = ConvTranspose3dK4S2(cin, cout, 4, 2, 1)
+    bn = FastBatchNorm3d(cout, fused_relu=True)
+    return [pre_bn, ct, bn, nn.Conv3d(cout, 1, 1), nn.Conv3d(cout, 3, 1), nn.Conv3d(cout, co, 1) if co else None]
+
+
+def _to_cuda(mods):
+    import copy
+    out = [None if mm is None else copy.deepcopy(mm).to("cuda") for mm in mods]
+    out[1].bf16_compute = True
+    if out[5] is not None:
+        out[5].bf16_compute = True
+    for mm in (out[0], out[2]):
+        if mm is not None:
+            mm.train()
+    return out
+
+
+@pytest.mark.parametrize("b,d,h,w,m", [(2, 2, 3, 8, 700), (1, 3, 5, 16, 900)])
+def test_pcr_level_writes_z_and_reads_its_gradient_in_bf16(b, d, h, w, m):
+    """r06 heads.upsample_level(z16=True) on the 32 -> 32 up-sampler + level + 32 -> 16 conv: z is STORED in bf16 (s2d_pcr_level_fwd_y16_z16) and
+    the gradient that comes back for it is read in bf16 (s2d_pcr_level_bwd_{sums,apply}_*_z16, s2d_pointwise_conv_wgrad_norm_x16_d16).  Against
+    the fp32-z node on the same inputs: losses identical, z == the fp32 z rounded to bf16 bit for bit, the z statistics handed to the next batch
+    norm are those of the STORED values, and with a bf16-representable upstream gradient every gradient is identical bit for bit (the kernels
+    widen bf16 exactly)."""
+    od, oh, ow = 2 * d, 2 * h, 2 * w
+    coors, feats, _, _ = _case(b, od, oh, ow, m, seed=77 + m)
+    gen = torch.Generator().manual_seed(m)
+    x0 = torch.randn(b, 32, d, h, w, generator=gen)
+    mods0 = _level_modules(32, 32, 16, gen)
+    r = (torch.randn(b, 16, od, oh, ow, generator=gen) / (b * od * oh * ow)).to(torch.bfloat16).float()
+
+    def run(z16):
+        mods = _to_cuda(mods0)
+        x = x0.to("cuda").requires_grad_(True)
+        ml, ol, z = heads.upsample_level(mods[1], x, mods[2], mods[3], mods[4], coors.to("cuda"), feats.to("cuda"), next_conv=mods[5], z16=z16)
+        (1.7 * ml + 0.6 * ol + (z.float() * r.to("cuda")).sum()).backward()
+        return ml, ol, z, [x.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+
+    ref = run(False)
+    got = run(True)
+    assert ref[2].dtype == torch.float32 and got[2].dtype == torch.bfloat16
+    assert got[0].item() == ref[0].item() and got[1].item() == ref[1].item()
+    assert torch.equal(got[2], ref[2].to(torch.bfloat16))
+    zs = got[2]._s2d_bn_stats.detach()
+    zf = got[2].detach().double()
+    want = torch.cat([zf.sum(dim=(0, 2, 3, 4)), (zf * zf).sum(dim=(0, 2, 3, 4))])
+    assert float((zs.double() - want).abs().max() / want.abs().max()) <= 1e-5
+    for i, (u, v) in enumerate(zip(got[3], ref[3])):
+        assert torch.equal(u, v), (i, float((u.double() - v.double()).abs().max()))
+
+
+@pytest.mark.parametrize("b,d,h,w,m", [(2, 4, 6, 16, 3000), (1, 2, 5, 24, 1500)])
+def test_upsample_level_reads_a_bf16_stored_input_and_returns_its_gradient_in_bf16(b, d, h, w, m):
+    """r06: the 16 -> 3 up-sampler node with the batch norm in front folded in, fed the bf16-STORED z (s2d_convt3d_mfma_fwd_stats_y16_norm_x16,
+    _wgrad_d16_norm_x16, _dgrad_d16_x16, s2d_bncm_bwd_*_typed).  Against the same node fed the widened fp32 copy: the forward is the same
+    arithmetic on the same values (losses and every gradient that does not pass the input gradient identical); the input gradient dx' is stored
+    in bf16 before the batch norm's backward reads it (one more bf16 rounding, 2^-9 relative per element, over sums that largely cancel on these
+    tiny volumes): the batch norm's dgamma / dbeta and the returned gradient - bf16 itself - within 1e-2 of their norm (measured 1e-3 .. 3e-3)."""
+    from sparse2dense_amd import _lib
+    od, oh, ow = 2 * d, 2 * h, 2 * w
+    coors, feats, _, _ = _case(b, od, oh, ow, m, seed=5 + m)
+    gen = torch.Generator().manual_seed(3 * m)
+    x16 = (torch.randn(b, 16, d, h, w, generator=gen) * 1.3 + 0.4).to(torch.bfloat16)
+    mods0 = _level_modules(16, 3, 0, gen, pre=True)
+    xf = x16.double()
+    stats = torch.cat([xf.sum(dim=(0, 2, 3, 4)), (xf * xf).sum(dim=(0, 2, 3, 4))]).float().to("cuda")
+    assert _lib.load().s2d_convt3d_mfma_x16_supported(16, 3, d, h, w)
+
+    def run(as_bf16):
+        mods = _to_cuda(mods0)
+        x = (x16 if as_bf16 else x16.float()).to("cuda").requires_grad_(True)
+        x._s2d_bn_stats = stats
+        assert heads.upsample_level_x16_supported(mods[1], (d, h, w), mods[0])
+        ml, ol, _ = heads.upsample_level(mods[1], x, mods[2], mods[3], mods[4], coors.to("cuda"), feats.to("cuda"), pre_bn=mods[0])
+        (1.7 * ml + 0.6 * ol).backward()
+        return ml, ol, x.grad, [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)], mods[0]
+
+    ref = run(False)
+    got = run(True)
+    assert got[2].dtype == torch.bfloat16 and ref[2].dtype == torch.float32
+    assert got[0].item() == ref[0].item() and got[1].item() == ref[1].item()
+    rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm().clamp_min(1e-30))
+    assert rel(got[2], ref[2]) <= 1e-2, rel(got[2], ref[2])
+    for i, (u, v) in enumerate(zip(got[3], ref[3])):
+        if i in (0, 1):     # the folded batch norm's dgamma / dbeta: sums over the bf16-stored dx'
+            assert rel(u, v) <= 1e-2, (i, rel(u, v))
+        else:
+            assert torch.equal(u, v), (i, rel(u, v))
+    assert torch.equal(got[4].running_mean, ref[4].running_mean) and torch.equal(got[4].running_var, ref[4].running_var)
+
