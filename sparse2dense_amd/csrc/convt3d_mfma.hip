@@ -462,6 +462,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int hgroups = (s.h + YR - 1) / YR;
     if (tile >= s.n * hgroups * xtiles) return;
+    // the batch norm's scale | shift in LDS: read from global memory inside the staging (8 channel pairs per halo cell, 16 per body thread, every z
+    // step) each pair of dword loads sat between two x loads with an s_waitcnt vmcnt(0) - the halo threads' 8 x loads of a z step went out one
+    // memory latency after the other, in front of the step's barrier
+    __shared__ __attribute__((aligned(16))) float nrm_s[2 * CIN];
+    if (in_norm) {   // block-uniform
+        if (t < 2 * CIN) nrm_s[t] = in_norm[t];
+        __syncthreads();
+    }
     const int n = tile / (hgroups * xtiles);
     const int rem0 = tile - n * (hgroups * xtiles);
     const int hy0 = (rem0 / xtiles) * YR, xt = rem0 % xtiles;
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float val = (float)src[ok ? (int64_t)e * cells : 0];
-                if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
+                if (in_norm) val = fmaxf(fmaf(val, nrm_s[g * 8 + e], nrm_s[CIN + g * 8 + e]), 0.f);
                 hv[e] = ok ? val : 0.f;
             }
         }
@@ -504,8 +512,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         if (in_norm) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                nsc[e] = in_norm[((t / PPR) % GROUPS) * 8 + e];
-                nsh[e] = in_norm[CIN + ((t / PPR) % GROUPS) * 8 + e];
+                nsc[e] = nrm_s[((t / PPR) % GROUPS) * 8 + e];
+                nsh[e] = nrm_s[CIN + ((t / PPR) % GROUPS) * 8 + e];
             }
         }
         if constexpr (X16) {
@@ -525,8 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int c0 = ((t >> 1) / PPR % GROUPS) * 8 + 4 * half + 2 * k;
-                sc2[k] = f32x2x{in_norm[c0], in_norm[c0 + 1]};
-                sh2[k] = f32x2x{in_norm[CIN + c0], in_norm[CIN + c0 + 1]};
+                sc2[k] = f32x2x{nrm_s[c0], nrm_s[c0 + 1]};
+                sh2[k] = f32x2x{nrm_s[CIN + c0], nrm_s[CIN + c0 + 1]};
             }
             for (int p2 = t; p2 < 2 * BODY; p2 += 256) {
                 const int p = p2 >> 1;
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float val = (float)src[(int64_t)e * cells];
-                    if (in_norm) val = fmaxf(fmaf(val, in_norm[g * 8 + e], in_norm[CIN + g * 8 + e]), 0.f);
+                    if (in_norm) val = fmaxf(fmaf(val, nrm_s[g * 8 + e], nrm_s[CIN + g * 8 + e]), 0.f);
                     v[e] = (__bf16)val;
                 }
             } else {
@@ -1335,6 +1343,14 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restr
 #pragma unroll
         for (int a = 0; a < CIT; ++a) acc[g][a] = f32x4m{0.f, 0.f, 0.f, 0.f};
     const int steps = (s.w + 31) / 32;
+    // the lane's scale / shift of the folded batch norm, read once (inside the step loop the two dword loads sat in front of every x load's use)
+    float nsc_l[CIT], nsh_l[CIT];
+#pragma unroll
+    for (int ai = 0; ai < CIT; ++ai) {
+        const int ci = ai * 16 + r;
+        nsc_l[ai] = (in_norm && ci < s.cin) ? in_norm[ci] : 0.f;
+        nsh_l[ai] = (in_norm && ci < s.cin) ? in_norm[s.cin + ci] : 0.f;
+    }
     const unsigned xbytes = (unsigned)(s.cin * cells * XS), dbytes = (unsigned)(s.cout * oplane * ES);
     // window of the lane: floats [base, base + 16) of the dout row with base = 2*c0 - 2 + 2*((kx + 1) >> 1); sample e = element
     // 2e + (kx odd ? 0 : 1), i.e. position 2*(c0 + e) - 1 + kx
@@ -1366,7 +1382,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restr
                         typedef float f32x2x __attribute__((ext_vector_type(2)));
                         typedef short s16x2x __attribute__((ext_vector_type(2)));
                         const bool cv = cok && ci < s.cin;
-                        const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;   // (lanes outside the tensor loaded 0 and stay 0)
+                        const float sc = cv ? nsc_l[ai] : 0.f, sh = cv ? nsh_l[ai] : 0.f;   // (lanes outside the tensor loaded 0 and stay 0)
                         u32x4m o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restr
                 }
                 if (in_norm) {   // x is the raw tensor in front of a BatchNorm3d + ReLU (see ct_fwd_mfma_kernel); loads outside the tensor stay zero
                     const bool cv = cok && ci < s.cin;
-                    const float sc = cv ? in_norm[ci] : 0.f, sh = cv ? in_norm[s.cin + ci] : 0.f;
+                    const float sc = cv ? nsc_l[ai] : 0.f, sh = cv ? nsh_l[ai] : 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         lo[e] = cv ? fmaxf(fmaf(lo[e], sc, sh), 0.f) : 0.f;
