@@ -673,6 +673,11 @@ int s2d_nchw_f32_to_nhwc_bf16_ld(const float *x, int batch, int c, int ld, int64
  * propagating) - no index tensor. */
 int s2d_upsample2x_nhwc_bf16(const void *x, int n, int h, int w, int c, void *y, s2d_stream_t stream);
 int s2d_upsample2x_bwd_nhwc_bf16(const void *dy, int n, int h, int w, int c, void *dx, s2d_stream_t stream);
+/* 2 x 2 space-to-depth on NHWC bf16 (r06): x[n][2h][2w][c] -> y[n][h][w][(py, px, c)] (to_depth != 0), or its inverse (to_depth == 0: x is the
+ * depth image, y the space image); h, w = the extent of the depth image, c % 8 == 0.  The rearrangements around nn.Conv2d(kernel 2, stride 2)
+ * and nn.ConvTranspose2d(kernel 2, stride 2) when those run as 1x1 tile kernels (/root/reference/det3d/models/necks/rpn.py:188 and :92-104;
+ * replaces torch's permute + contiguous copies there). */
+int s2d_space_depth2_nhwc_bf16(const void *x, int n, int h, int w, int c, int to_depth, void *y, s2d_stream_t stream);
 int s2d_maxpool2x2_nhwc_bf16(const void *x, int n, int h, int w, int c, void *y, s2d_stream_t stream);
 int s2d_maxpool2x2_bwd_nhwc_bf16(const void *x, const void *dy, int n, int h, int w, int c, void *dx, s2d_stream_t stream);
 

@@ -353,6 +353,7 @@ SIGNATURES = {
                                             [c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_int, c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_pointwise_conv_wgrad_norm_x16_d16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                               ctypes.c_int64, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_space_depth2_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]),
     "s2d_bncm_bwd_apply_f32": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int64, c_f32p, ctypes.c_void_p]),
     "s2d_densify_bev_fwd_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_i32p, ctypes.c_int64, ctypes.c_int, _I3,

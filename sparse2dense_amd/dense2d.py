@@ -516,9 +516,18 @@ def _pack_matrix_1x1(owner, tag, make, transpose=False):
     return cached_pack(owner, tag, build)
 
 
+def _space_depth_hip(t):
+    return (ENABLED and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[1] % 8 == 0 and t.numel() > 0
+            and t.is_contiguous(memory_format=torch.channels_last) and not (t.requires_grad and torch.is_grad_enabled()))
+
+
 def _space_to_depth(t):
     """NHWC [n, c, 2h, 2w] -> NHWC [n, 4c, h, w], channel = (py, px, c): the four pixels of a 2x2 block side by side"""
     n, c, hh, ww = t.shape
+    if _space_depth_hip(t) and hh % 2 == 0 and ww % 2 == 0:   # one 16-byte-per-lane pass (csrc/layout.hip) instead of torch's strided copy of the view
+        y = torch.empty((n, 4 * c, hh // 2, ww // 2), dtype=torch.bfloat16, device=t.device, memory_format=torch.channels_last)
+        check(_lib.load().s2d_space_depth2_nhwc_bf16(_ptr(t), n, hh // 2, ww // 2, c, 1, _ptr(y), _stream()), "s2d_space_depth2_nhwc_bf16")
+        return y
     v = t.permute(0, 2, 3, 1).reshape(n, hh // 2, 2, ww // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, hh // 2, ww // 2, 4 * c)
     return v.permute(0, 3, 1, 2)
 
@@ -526,6 +535,10 @@ def _space_to_depth(t):
 def _depth_to_space(t, c):
     """inverse of _space_to_depth: NHWC [n, 4c, h, w] -> NHWC [n, c, 2h, 2w]"""
     n, _, h, w = t.shape
+    if _space_depth_hip(t) and t.shape[1] == 4 * c and c % 8 == 0:
+        y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.bfloat16, device=t.device, memory_format=torch.channels_last)
+        check(_lib.load().s2d_space_depth2_nhwc_bf16(_ptr(t), n, h, w, c, 0, _ptr(y), _stream()), "s2d_space_depth2_nhwc_bf16")
+        return y
     v = t.permute(0, 2, 3, 1).reshape(n, h, w, 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, c)
     return v.permute(0, 3, 1, 2)
 

@@ -390,6 +390,25 @@ def test_batch_norm_backward_sums_from_the_data_gradient_epilogue(kind, c0, c1, 
     assert torch.equal(xi.grad, xj.grad) and torch.equal(m[1].weight.grad, m2[1].weight.grad)
 
 
+@pytest.mark.parametrize("n,c,h,w", [(4, 256, 94, 94), (2, 64, 5, 7), (1, 8, 1, 1), (3, 136, 9, 4)])
+def test_space_to_depth_kernel_equals_the_permuted_view(n, c, h, w, monkeypatch):
+    """csrc/layout.hip `space_depth2_kernel` (the rearrangement around the 2x2 / stride-2 conv and the 2x2 transposed conv run as 1x1 tile kernels):
+    a pure permutation - bit-equal to torch's permute + reshape of the same tensor, both directions, and the two are inverses."""
+    from sparse2dense_amd import dense2d as D
+    torch.manual_seed(n + c + h)
+    x = torch.randn(n, c, 2 * h, 2 * w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    got = D._space_to_depth(x)
+    monkeypatch.setattr(D, "ENABLED", False)
+    want = D._space_to_depth(x)
+    monkeypatch.setattr(D, "ENABLED", True)
+    assert got.shape == want.shape == (n, 4 * c, h, w) and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    back = D._depth_to_space(got, c)
+    assert back.is_contiguous(memory_format=torch.channels_last) and torch.equal(back, x)
+    monkeypatch.setattr(D, "ENABLED", False)
+    assert torch.equal(D._depth_to_space(got, c), x)
+
+
 def test_wide_layernorm_matches_stock():
     from sparse2dense_amd import dense2d as D
     torch.manual_seed(0)
