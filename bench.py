@@ -295,16 +295,17 @@ def calibrate(models, step, dev, candidates, settle=4, n=8, world=1):
             score[mode_name(m)] = v
             table[mode_name(m)]["max_over_ranks_ms"] = round(v, 3)
     best = min(ok, key=lambda m: score[mode_name(m)])
-    # Risk-averse pick: a graphed mode is kept unless the best eager mode beat it by more than 5 % HERE.  Measured r05: on a quiet host the eager
+    # Risk-averse pick: a graphed mode is kept unless the best eager mode beat it by more than 3 % HERE (r05: 5 %; r06: the eager step measured
+    # 4.8-7.7 % ahead on the round's boxes - 18.3-18.8 against 19.7-19.9 ms - so the 5 % bar decided by the box).  Measured r05: on a quiet host the eager
     # step with the weight-gradient stream is 3-4 % faster than the graphed one (18.9 vs 19.6 ms: its weight gradients overlap the whole dense
     # backward), but its time follows the host - 30 ms under rocprofv3, 32-37 ms in a run beside a busy neighbour on the same pod (the r04 driver
     # run: 31 ms) - while the graphed step stayed at 19.5-20.4 ms in every run of the round.
     graphed = [m for m in ok if m[0]]
     if graphed and not best[0]:
         g_best = min(graphed, key=lambda m: score[mode_name(m)])
-        if score[mode_name(g_best)] <= 1.05 * score[mode_name(best)]:
+        if score[mode_name(g_best)] <= 1.03 * score[mode_name(best)]:
             table["_pick"] = (f"{mode_name(g_best)} ({score[mode_name(g_best)]:.3f} ms) kept over the fastest measured mode {mode_name(best)} "
-                              f"({score[mode_name(best)]:.3f} ms): within 5 %, and host-independent")
+                              f"({score[mode_name(best)]:.3f} ms): within 3 %, and host-independent")
             best = g_best
     return best, table
 

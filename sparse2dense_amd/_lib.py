@@ -375,6 +375,18 @@ class S2DError(RuntimeError):
     pass
 
 
+def _memoised(fn):
+    cache = {}
+
+    def query(*a):
+        r = cache.get(a)
+        if r is None:
+            r = cache[a] = fn(*a)
+        return r
+    query.__wrapped__ = fn
+    return query
+
+
 def load():
     """dlopen libs2d_hip.so and type every entry point.  Raises if the build is missing."""
     global _lib
@@ -394,6 +406,15 @@ def load():
             raise S2DError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
+    # Pure shape queries (workspace sizes, launch plans, *_supported) are asked again with the same integers by every layer call of every step
+    # - ~150 ctypes round trips of 3-5 us per training step on the launch thread.  They depend on their integer arguments and on
+    # environment switches the library reads once, so the answers are memoised per argument tuple.  (Not the queries that follow a
+    # run-time mode: the sparse bf16-storage kernels' plans change with the sorted-row switch.)
+    _int_types = (ctypes.c_int, ctypes.c_int64, ctypes.c_size_t)
+    for name, (res, args) in SIGNATURES.items():
+        pure = name.endswith(("_workspace_bytes", "_supported", "_stats_tiles", "_tile_rows", "_packed_elems")) and "sort" not in name and "spconv_s16" not in name
+        if pure and args and all(a in _int_types for a in args):
+            setattr(lib, name, _memoised(getattr(lib, name)))
     _lib = lib
     return lib
 

@@ -220,7 +220,7 @@ def _pack_weights(weight, transpose_flip):
     return packed
 
 
-BN_BWD_FOLD = 1   # (read from the environment below)
+BN_BWD_FOLD = 0   # (read from the environment below)
 STATS = {"bn_bwd_folded": 0, "bn_bwd_reduced": 0}   # batch-norm backward passes that took the conv epilogue's sums / their own reduction pass
 
 
@@ -285,12 +285,13 @@ def conv3x3_nhwc(x, packed, bias, cin, cout, pad, stride=1, bn_stats=False, bn_b
 import os as _os
 from . import side as _side
 WGRAD_HIP = {"0": False, "1": True}.get(_os.environ.get("S2D_WGRAD_HIP", ""), "auto")
-# r06: the data-gradient conv behind a conv -> BatchNorm2d -> ReLU layer writes that batch norm's backward sums from its epilogue (the
-# reduction pass over (dY, z) of the batch-norm backward is skipped).  Measured on the benchmarked step (4 x 150 k points): the ten ReLU layers
-# of the RPN trunk save 137 us of `row_reduce` for ~90 us of longer conv epilogues (z is read once more, one exposed load latency per tile);
-# behind a GELU the erf / exp per element cost +40 us per launch against the 30 us pass they replace - so "1" (default) folds ReLU / no
-# activation only, "2" also GELU, "0" nothing.
-BN_BWD_FOLD = {"0": 0, "2": 2}.get(_os.environ.get("S2D_BN_BWD_FOLD", "1"), 1)
+# r06: the data-gradient conv behind a conv -> BatchNorm2d -> ReLU layer can write that batch norm's backward sums from its epilogue (the reduction
+# pass over (dY, z) of the batch-norm backward is skipped): S2D_BN_BWD_FOLD=1 (ReLU / no activation) or 2 (also GELU).  Measured on the benchmarked
+# step (4 x 150 k points): the ten ReLU layers of the RPN trunk save 137 us of `row_reduce` and ten launches for ~90 us of longer conv epilogues (z is
+# read once more, one exposed load latency per tile); behind a GELU the erf / exp per element cost +40 us per launch against the 30 us pass they
+# replace.  The step's wall time does not move (218.4 vs 218.5 frames/s: the eager step is bound by the launch thread, 17.9 ms of enqueue per
+# 18.0 ms step) while the dominant kernel's own launches get 10 % longer, so the default stays the separate pass ("0").
+BN_BWD_FOLD = {"1": 1, "2": 2}.get(_os.environ.get("S2D_BN_BWD_FOLD", "0"), 0)
 
 
 def _wgrad_hip(cin, cout):

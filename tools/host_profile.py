@@ -43,6 +43,7 @@ def main():
     print(f"{steps} steps, host enqueue {1e3 * (t1 - t0) / steps:.2f} ms per step (main thread wall, no sync)")
     st = pstats.Stats(pr)
     st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(40)   # where the launch thread's own time goes (ctypes calls count as the caller's)
     if hasattr(frames, "close"):
         frames.close()
 
