@@ -40,7 +40,7 @@ CAPTURE_LOCK = threading.RLock()
 
 WARMUP = int(os.environ.get("S2D_GRAPH_WARMUP", "2"))
 MAX_CAPTURES = int(os.environ.get("S2D_GRAPH_MAX_CAPTURES", "6"))   # per segment: train / eval x grad modes x a couple of input signatures
-stats = {"eager": 0, "capture": 0, "replay": 0, "dropped": 0, "launch_host_ms": 0.0}   # launch_host_ms: host time spent inside hipGraphLaunch calls
+stats = {"eager": 0, "capture": 0, "replay": 0, "dropped": 0, "parked": 0, "launch_host_ms": 0.0}   # launch_host_ms: host time spent inside hipGraphLaunch calls
 
 
 def enabled():
@@ -163,6 +163,23 @@ class _Replay(torch.autograd.Function):
         return (None, None, None) + tuple(cap.s_gin)
 
 
+_SEGMENTS = None   # weak set of live segments (grads_consumed)
+
+
+def grads_consumed():
+    """Called by a training step AFTER its optimizer has read the gradients (train_step.backward_and_step): the `.grad` tensors that are static
+    buffers of a capture need not survive the next forward replay - the step clears every `.grad` before its next backward anyway.  Without this
+    declaration the next forward replay first moves each of them to a private copy (gradient accumulation must not read a buffer the
+    forward graph reuses) - 164 clones per step for the S2D student (0.64 ms of copy kernels and ~1.6 ms of launch-thread time, r06 profile of the
+    graphed mode: `__amd_rocclr_copyBuffer` 180 launches per step against 16 in r05).  Reading such a `.grad` after the NEXT forward is then
+    undefined; code that accumulates over micro-batches simply does not call this."""
+    if _SEGMENTS is None:
+        return
+    for seg in list(_SEGMENTS):
+        for cap in seg._caps.values():
+            cap.bound = False
+
+
 class GraphedSegment:
     def __init__(self, fn, modules, name="dense"):
         """fn(*tensors) -> tuple of tensors; modules: the nn.Modules whose parameters fn reads (those with requires_grad get their
@@ -174,6 +191,11 @@ class GraphedSegment:
         self._caps = {}       # signature -> _Capture
         self._seen = {}       # signature -> [calls so far, set of output indices that received a gradient]
         self.pool = None
+        global _SEGMENTS
+        if _SEGMENTS is None:
+            import weakref
+            _SEGMENTS = weakref.WeakSet()
+        _SEGMENTS.add(self)
 
     def reset(self):
         self._caps.clear()
@@ -248,6 +270,7 @@ class GraphedSegment:
             for p, g in zip(cap.params, cap.s_gparams):
                 if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
                     p.grad = p.grad.clone()
+                    stats["parked"] += 1   # (a training step that called grads_consumed() never gets here)
             cap.bound = False
         with torch.no_grad():   # ONE multi-tensor copy kernel for all inputs (a hipMemcpyAsync per tensor costs the host ~60 us each under load)
             pairs = [(s, t) for s, t in zip(cap.s_in, inputs) if s.data_ptr() != t.data_ptr()]

@@ -82,4 +82,7 @@ def backward_and_step(loss, params, optimizer, scheduler=None, iteration=None, m
     if scheduler is not None:
         scheduler.step(iteration)
     backward_and_clip(loss, params, None)
-    return optimizer.clip_and_step(max_norm)
+    norm = optimizer.clip_and_step(max_norm)
+    from . import graphed
+    graphed.grads_consumed()   # (the next call clears every .grad before its backward: a graphed segment need not park them over its next forward)
+    return norm
