@@ -850,6 +850,11 @@ int s2d_pointwise_conv_wgrad_norm_x16(const void *in_bf16, const float *in_scale
  *   s2d_convt3d_mfma_dgrad_d16_x16       = its data gradient written as bf16        (all three: s2d_convt3d_mfma_x16_supported shapes)
  *   s2d_bncm_bwd_reduce_x_typed / s2d_bncm_bwd_apply_x_typed = s2d_bncm_bwd_reduce_x_f32 / _apply_x_f32 with a storage flag per tensor
  *     (0 fp32, 1 bf16); combinations (x, dy, dx): all fp32 | (fp32, bf16, fp32) | all bf16 */
+/* r06: per-voxel cache for the NEXT s2d_pcr_level_* call on the calling thread (any storage variant): the forward call fills row i with the c raw
+ * values of y at recon voxel i's cell ([m][c] elements of y's type, [m][4] for c = 3), the level's two backward calls read their voxels from it
+ * instead of c scattered loads per voxel.  buf: >= m * (c == 3 ? 4 : c) * sizeof(y element) bytes of device memory (smaller: ignored); consumed by
+ * the next call, repeat per call; NULL / 0 clears.  (voxelnet.py:171-185: the per-voxel terms of the mask / offset losses.) */
+int s2d_pcr_level_site_cache(void *buf, size_t bytes);
 int s2d_pcr_level_fwd_y16_z16(const void *y, const float *bn_scale_shift, const float *head_params, const float *w2, const float *b2,
                               const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, void *z_bf16,
                               float *z_stats, float *out8, void *ws, size_t ws_bytes, s2d_stream_t stream);

@@ -344,6 +344,7 @@ SIGNATURES = {
                                                 [ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
     "s2d_convt3d_mfma_wgrad_d16_norm_x16": (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_void_p] + [ctypes.c_int] * 6 +
                                             [c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "s2d_pcr_level_site_cache": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "s2d_pcr_level_fwd_y16_z16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 6 +
                                   [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "s2d_pcr_level_bwd_sums_y16_z16": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, ctypes.c_int64] + [ctypes.c_int] * 5 +

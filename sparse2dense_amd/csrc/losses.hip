@@ -867,15 +867,76 @@ __global__ __launch_bounds__(64) void pcr_zstats_fold_kernel(const float *__rest
     if (threadIdx.x == 0) out[col] = (float)v;
 }
 
-// the site's raw values, post-norm values, logit and offsets
+// r06 site cache: the forward's per-voxel pass keeps the C raw values of every recon voxel's cell as one row [site][ROW] (ROW = C, or 4 for C = 3:
+// 64-byte / 8-byte rows in bf16); the two backward passes read the row - one coalesced access - instead of C scattered 2-byte loads from C planes
+// (C lines per site, and the sums pass evaluates every site once per channel group: 139 us for 1.2e5 voxels at C = 32 were line fetches).
+template <int C> struct PcrRow { static constexpr int N = C == 3 ? 4 : C; };
+template <int C, typename TY> __device__ __forceinline__ void pcr_row_load(const TY *__restrict__ row, float (&yv)[C]) {
+    constexpr int N = PcrRow<C>::N;
+    if constexpr (sizeof(TY) == 2) {
+        uint32_t w[N / 2];
+        if constexpr (N % 8 == 0) {
+#pragma unroll
+            for (int q = 0; q < N / 8; ++q) {
+                const uint4 v = reinterpret_cast<const uint4 *>(row)[q];
+                w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+        } else {
+            const uint2 v = *reinterpret_cast<const uint2 *>(row);
+            w[0] = v.x; w[1] = v.y;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) yv[c] = __builtin_bit_cast(float, (c & 1) ? (w[c >> 1] & 0xFFFF0000u) : (w[c >> 1] << 16));
+    } else {
+        float t[N];
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 v = reinterpret_cast<const float4 *>(row)[q];
+            t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) yv[c] = t[c];
+    }
+}
+template <int C, typename TY> __device__ __forceinline__ void pcr_row_store(TY *__restrict__ row, const float (&yv)[C]) {   // (yv holds exact TY values)
+    constexpr int N = PcrRow<C>::N;
+    if constexpr (sizeof(TY) == 2) {
+        uint32_t w[N / 2];
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            const uint32_t lo = 2 * k < C ? (__builtin_bit_cast(uint32_t, yv[2 * k < C ? 2 * k : 0]) >> 16) : 0u;
+            const uint32_t hi = 2 * k + 1 < C ? (__builtin_bit_cast(uint32_t, yv[2 * k + 1 < C ? 2 * k + 1 : 0]) & 0xFFFF0000u) : 0u;
+            w[k] = lo | hi;
+        }
+        if constexpr (N % 8 == 0) {
+#pragma unroll
+            for (int q = 0; q < N / 8; ++q) reinterpret_cast<uint4 *>(row)[q] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+        } else {
+            *reinterpret_cast<uint2 *>(row) = uint2{w[0], w[1]};
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q)
+            reinterpret_cast<float4 *>(row)[q] = float4{yv[4 * q < C ? 4 * q : 0], 4 * q + 1 < C ? yv[4 * q + 1 < C ? 4 * q + 1 : 0] : 0.f,
+                                                        4 * q + 2 < C ? yv[4 * q + 2 < C ? 4 * q + 2 : 0] : 0.f,
+                                                        4 * q + 3 < C ? yv[4 * q + 3 < C ? 4 * q + 3 : 0] : 0.f};
+    }
+}
+
+// the site's raw values, post-norm values, logit and offsets; yrow (optional): the site's row of the site cache instead of the C planes
 template <int C, typename TY = float>
 __device__ __forceinline__ void pcr_site_eval_norm(const TY *__restrict__ y, const PcrHeadW<C> &hw, const PcrNorm<C> &nm, int64_t cells, int b,
-                                                   int64_t cell, float (&yv)[C], float (&gv)[C], float &x, float (&off)[3]) {
+                                                   int64_t cell, float (&yv)[C], float (&gv)[C], float &x, float (&off)[3],
+                                                   const TY *__restrict__ yrow = nullptr) {
     x = hw.bm;
     off[0] = hw.bo[0]; off[1] = hw.bo[1]; off[2] = hw.bo[2];
-    const TY *base = y + (int64_t)b * C * cells + cell;
+    if (yrow) {   // block-uniform
+        pcr_row_load<C, TY>(yrow, yv);
+    } else {
+        const TY *base = y + (int64_t)b * C * cells + cell;
 #pragma unroll
-    for (int c = 0; c < C; ++c) yv[c] = plane_elem<TY>(base + (int64_t)c * cells);
+        for (int c = 0; c < C; ++c) yv[c] = plane_elem<TY>(base + (int64_t)c * cells);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         gv[c] = fmaxf(fmaf(yv[c], nm.sc[c], nm.sh[c]), 0.f);
@@ -888,7 +949,8 @@ __device__ __forceinline__ void pcr_site_eval_norm(const TY *__restrict__ y, con
 template <int C, typename TY = float>
 __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t *__restrict__ coors, const float *__restrict__ feats, int64_t m,
                                                                    PcrGeo geo, const TY *__restrict__ y, const float *__restrict__ bnp,
-                                                                   const float *__restrict__ hp, float *__restrict__ partial) {
+                                                                   const float *__restrict__ hp, float *__restrict__ partial,
+                                                                   TY *__restrict__ ysite = nullptr) {
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
     pcr_load_head<C>(hp, hw);
@@ -907,6 +969,7 @@ __global__ __launch_bounds__(256) void pcr_level_fwd_sparse_kernel(const int32_t
         const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
         float yv[C], gv[C], x, off[3];
         pcr_site_eval_norm<C, TY>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        if (ysite) pcr_row_store<C, TY>(ysite + i * PcrRow<C>::N, yv);   // the site cache row the backward passes read (invalid sites: skipped there too)
         if (pos) {
             acc[0] += 1.f;
             acc[1] += softplusf(-x);
@@ -1061,7 +1124,8 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t
                                                                    PcrGeo geo, const TY *__restrict__ y, const float *__restrict__ bnp,
                                                                    const float *__restrict__ hp, const float *__restrict__ go_mask,
                                                                    const float *__restrict__ go_off, const float *__restrict__ fin,
-                                                                   const float *__restrict__ abd, TD *__restrict__ dy, float *__restrict__ partial) {
+                                                                   const float *__restrict__ abd, TD *__restrict__ dy, float *__restrict__ partial,
+                                                                   const TY *__restrict__ ysite = nullptr) {
     __shared__ PcrHeadW<C> hw;
     __shared__ PcrNorm<C> nm;
     pcr_load_head<C>(hp, hw);
@@ -1084,7 +1148,7 @@ __global__ __launch_bounds__(256) void pcr_level_bwd_sparse_kernel(const int32_t
         const bool pos = s != 0.f;
         const int64_t cell = ((int64_t)c.y * geo.h + c.z) * geo.w + c.w;
         float yv[C], gv[C], x, off[3];
-        pcr_site_eval_norm<C, TY>(y, hw, nm, cells, c.x, cell, yv, gv, x, off);
+        pcr_site_eval_norm<C, TY>(y, hw, nm, cells, c.x, cell, yv, gv, x, off, ysite ? ysite + i * PcrRow<C>::N : nullptr);
         float dmk = 0.f;
         if (pos) {
             const float sg = sigmoidf(x);
@@ -1178,6 +1242,16 @@ __global__ __launch_bounds__(256) void pcr_level_fold_kernel(const float *__rest
     else bn_sums[t - 4 * C - 4] = r;
 }
 
+// the site cache of the NEXT s2d_pcr_level_* call on this thread (s2d_pcr_level_site_cache): consumed (and cleared) by that call
+static thread_local void *g_site_buf = nullptr;
+static thread_local size_t g_site_bytes = 0;
+struct SiteCacheScope {   // one per entry call: whatever was set is gone when the call returns
+    ~SiteCacheScope() { g_site_buf = nullptr; g_site_bytes = 0; }
+};
+template <int C, typename TY> static TY *site_cache(int64_t m) {
+    return (g_site_buf && m > 0 && g_site_bytes >= (size_t)m * PcrRow<C>::N * sizeof(TY)) ? (TY *)g_site_buf : nullptr;
+}
+
 template <int C, int CO, int V, typename TY = float, typename TZ = float>
 static int pcr_level_fwd_t(const TY *y, const float *bnp, const float *hp, const float *w2, const float *b2, const int32_t *coors, const float *feats,
                            int64_t m, PcrGeo geo, TZ *z, float *out8, float *ws, hipStream_t st, float *z_stats = nullptr) {
@@ -1189,7 +1263,8 @@ static int pcr_level_fwd_t(const TY *y, const float *bnp, const float *hp, const
     hipLaunchKernelGGL((pcr_level_fwd_dense_kernel<C, CO, V, TY, TZ>), dim3(nd), dim3(256), 0, st, y, bnp, hp, w2, b2, cells, geo.batch, z, dense_partial,
                        zstat_partial);
     if (zstat_partial) hipLaunchKernelGGL(pcr_zstats_fold_kernel, dim3(2 * CO), dim3(64), 0, st, (const float *)zstat_partial, nd, 2 * CO, z_stats);
-    hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C, TY>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial);
+    hipLaunchKernelGGL((pcr_level_fwd_sparse_kernel<C, TY>), dim3(ns), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, sparse_partial,
+                       site_cache<C, TY>(m));
     hipLaunchKernelGGL(pcr_finalize_kernel, dim3(1), dim3(64), 0, st, dense_partial, nd, sparse_partial, ns, (double)n, out8);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1207,7 +1282,7 @@ static int pcr_level_bwd_sums_t(const TY *y, const float *bnp, const float *hp, 
                        geo.batch, (float *)nullptr, dense_partial);
     constexpr int CG = C == 32 ? 8 : C;   // channel groups of the sparse pass (accumulator registers)
     hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, CG, false, TY, float>), dim3(ns, C / CG), dim3(256), 0, st, coors, feats, m, geo, y, bnp, hp, go_mask,
-                       go_off, fin, nullptr, (float *)nullptr, sparse_partial);
+                       go_off, fin, nullptr, (float *)nullptr, sparse_partial, (const TY *)site_cache<C, TY>(m));
     hipLaunchKernelGGL((pcr_level_fold_kernel<C>), dim3(6 * C + 4), dim3(256), 0, st, dense_partial, nd, sparse_partial, ns, grads, bn_sums);
     S2D_LAUNCH_CHECK();
     return S2D_OK;
@@ -1223,7 +1298,7 @@ static int pcr_level_bwd_apply_t(const TY *y, const float *bnp, const float *hp,
                        dy, nullptr);
     if (m > 0)
         hipLaunchKernelGGL((pcr_level_bwd_sparse_kernel<C, C, true, TY, TD>), dim3((unsigned)std::min<int64_t>(4096, ceil_div(m, 256))), dim3(256), 0, st,
-                           coors, feats, m, geo, y, bnp, hp, go_mask, go_off, fin, abd, dy, nullptr);
+                           coors, feats, m, geo, y, bnp, hp, go_mask, go_off, fin, abd, dy, nullptr, (const TY *)site_cache<C, TY>(m));
     S2D_LAUNCH_CHECK();
     return S2D_OK;
 }
@@ -1243,6 +1318,7 @@ static int pcr_level_fwd_any(const void *yv, int y16, const float *bn_scale_shif
                                      const int32_t *coors, const float *feats, int64_t m, int batch, int c, int co, int d, int h, int w, float *z,
                                      float *z_stats /* [2 co] = sum | sum of squares of z per channel, or NULL */, float *out8, void *ws,
                                      size_t ws_bytes, s2d_stream_t stream, int z16 = 0) {
+    SiteCacheScope site_scope;   // (s2d_pcr_level_site_cache applies to this call only)
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && out8 && batch > 0 && d > 0 && h > 0 && w > 0 && m >= 0 && (m == 0 || (coors && feats)) &&
                       (co == 0 || (w2 && z)),
                   "pcr_level_fwd: bad argument");
@@ -1297,12 +1373,23 @@ extern "C" int s2d_pcr_level_fwd_y16_z16(const void *y, const float *bn_scale_sh
                              stream, 1);
 }
 
+/* r06: a per-voxel cache for the NEXT s2d_pcr_level_* call on this thread (any storage variant).  The forward call fills it - row i = the c raw
+ * values of y at recon voxel i's cell, [m][c] elements of y's type ([m][4] for c = 3) - and the two backward calls of the same level read their
+ * voxels' values from it instead of c scattered loads per voxel.  buf: device memory of at least m * (c == 3 ? 4 : c) * sizeof(y element) bytes
+ * (smaller: ignored); the setting is consumed by the next call and must be repeated per call.  NULL / 0 clears. */
+extern "C" int s2d_pcr_level_site_cache(void *buf, size_t bytes) {
+    g_site_buf = buf;
+    g_site_bytes = buf ? bytes : 0;
+    return S2D_OK;
+}
+
 // pass A of the backward: grads[4C+4] = dw_mask[C] | dw_off[3][C] | db_mask | db_off[3] and bn_sums[2C] = (sum dG*m, sum dG*m*y) per
 // channel, the batch norm's backward reduction (s2d_bncm_bwd_reduce_f32's output)
 static int pcr_level_bwd_sums_any(const void *yv, int y16, const float *bn_scale_shift, const float *head_params, const int32_t *coors,
                                           const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                           const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, float *grads,
                                           float *bn_sums, void *ws, size_t ws_bytes, s2d_stream_t stream, int z16 = 0) {
+    SiteCacheScope site_scope;   // (s2d_pcr_level_site_cache applies to this call only)
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && grads && bn_sums && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_sums: bad argument");
@@ -1368,6 +1455,7 @@ static int pcr_level_bwd_apply_any(const void *yv, int y16 /* 0: fp32 y, fp32 dy
                                            const float *feats, int64_t m, int batch, int c, int d, int h, int w, const float *fwd_out8,
                                            const float *go_mask, const float *go_offset, const float *dz, const float *w2, int co, const float *abd,
                                            void *dyv, s2d_stream_t stream, int z16 = 0) {
+    SiteCacheScope site_scope;   // (s2d_pcr_level_site_cache applies to this call only)
     S2D_CHECK_ARG(yv && bn_scale_shift && head_params && fwd_out8 && go_mask && go_offset && abd && dyv && batch > 0 && d > 0 && h > 0 && w > 0 &&
                       m >= 0 && (m == 0 || (coors && feats)) && (co == 0 || (dz && w2)),
                   "pcr_level_bwd_apply: bad argument");

@@ -365,6 +365,14 @@ class _PcrLevelNormFn(torch.autograd.Function):
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         # the kernel that writes z also reduces its per-channel (sum, sum of squares): the statistics of the BatchNorm3d behind the conv
         zst = torch.empty(2 * co, dtype=torch.float32, device=dev) if (z_stats_out is not None and c == 32 and co == 16) else None
+        # r06 site cache: the forward's per-voxel pass keeps every recon voxel's c raw values as one row; the backward's two per-voxel passes read the
+        # row instead of c scattered loads per voxel (S2D_PCR_SITE_CACHE=0: off)
+        m_sites = coors.shape[0]
+        ysite = None
+        if m_sites > 0 and os.environ.get("S2D_PCR_SITE_CACHE", "1") != "0":
+            ysite = torch.empty((m_sites, 4 if c == 3 else c), dtype=y.dtype, device=dev)
+            lib.s2d_pcr_level_site_cache(_ptr(ysite), ysite.numel() * ysite.element_size())
+        ctx.ysite = ysite
         _lib.check((lib.s2d_pcr_level_fwd_y16_z16 if z16 else lib.s2d_pcr_level_fwd_y16 if y16 else lib.s2d_pcr_level_fwd_f32)(
             _ptr(y), _ptr(norm), _ptr(hp), _ptr(w2d), _ptr(b2), _ptr(coors), _ptr(feats), coors.shape[0], b, c, co, d, h, w, _ptr(z), _ptr(zst), _ptr(out),
             _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_fwd")
@@ -405,10 +413,14 @@ class _PcrLevelNormFn(torch.autograd.Function):
         ws = _ws(lib.s2d_pcr_level_workspace_bytes(c), dev)
         args = (_ptr(y), _ptr(norm), _ptr(hp), _ptr(coors), _ptr(feats), coors.shape[0], b, c, d, h, w, _ptr(out), _ptr(go_mask), _ptr(go_off),
                 _ptr(dz) if co else None, _ptr(w2d) if co else None, co)
+        ysite = getattr(ctx, "ysite", None)
+        site = (lambda: lib.s2d_pcr_level_site_cache(_ptr(ysite), ysite.numel() * ysite.element_size())) if ysite is not None else (lambda: None)
+        site()
         _lib.check((lib.s2d_pcr_level_bwd_sums_y16_z16 if z16 else lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(
             *args, _ptr(grads), _ptr(sums), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums")
         if os.environ.get("S2D_DEBUG_SUMS2") == "1":   # debugging aid (tools/side_stress.py): the same launch again, results kept for a comparison after the pass
             grads2, sums2 = torch.empty_like(grads), torch.empty_like(sums)
+            site()
             _lib.check((lib.s2d_pcr_level_bwd_sums_y16_z16 if z16 else lib.s2d_pcr_level_bwd_sums_y16 if y16 else lib.s2d_pcr_level_bwd_sums_f32)(
                 *args, _ptr(grads2), _ptr(sums2), _ptr(ws), ws.numel(), _stream()), "s2d_pcr_level_bwd_sums")
             DEBUG_SUMS.append((c, co, sums, sums2, grads, grads2))
@@ -425,6 +437,7 @@ class _PcrLevelNormFn(torch.autograd.Function):
         dy = torch.empty(y.shape, dtype=torch.bfloat16 if dy16 else torch.float32, device=dev)
         apply = (lib.s2d_pcr_level_bwd_apply_y16_d16_z16 if z16 else lib.s2d_pcr_level_bwd_apply_y16_d16 if dy16
                  else (lib.s2d_pcr_level_bwd_apply_y16 if y16 else lib.s2d_pcr_level_bwd_apply_f32))
+        site()
         _lib.check(apply(*args, _ptr(abd), _ptr(dy), _stream()), "s2d_pcr_level_bwd_apply")
         wm_shape, wo_shape, w2_shape, has_b2 = ctx.shapes
         dw2 = db2 = None

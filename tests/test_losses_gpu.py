@@ -533,3 +533,40 @@ def test_upsample_level_reads_a_bf16_stored_input_and_returns_its_gradient_in_bf
             assert torch.equal(u, v), (i, rel(u, v))
     assert torch.equal(got[4].running_mean, ref[4].running_mean) and torch.equal(got[4].running_var, ref[4].running_var)
 
+
+@pytest.mark.parametrize("b,c,co,d,h,w,m,dtype", [(2, 32, 16, 6, 20, 24, 300, torch.bfloat16), (2, 3, 0, 6, 20, 24, 300, torch.bfloat16),
+                                                  (3, 32, 16, 10, 94, 94, 20000, torch.bfloat16), (2, 3, 0, 20, 188, 188, 30000, torch.bfloat16),
+                                                  (2, 32, 0, 4, 10, 12, 50, torch.float32), (1, 3, 0, 4, 10, 12, 1, torch.float32)])
+def test_pcr_level_site_cache_changes_nothing_but_the_loads(b, c, co, d, h, w, m, dtype, monkeypatch):
+    """r06 `s2d_pcr_level_site_cache`: the forward's per-voxel pass writes every recon voxel's c raw values as one row, the backward's per-voxel passes
+    read the row instead of c scattered loads - the SAME values, so losses, z and every gradient are bit-equal to the run without the cache."""
+    import copy
+    from torch import nn
+    from sparse2dense_amd.dense3d import FastBatchNorm3d
+    coors, feats, _, _ = _case(b, d, h, w, m, seed=b * 7 + m + c, special=m >= 4)
+    gen = torch.Generator().manual_seed(23 + c + m)
+    y0 = (torch.randn(b, c, d, h, w, generator=gen) * 1.5 + 0.2).to(torch.bfloat16)
+    mods0 = (FastBatchNorm3d(c, fused_relu=True), nn.Conv3d(c, 1, 1), nn.Conv3d(c, 3, 1), nn.Conv3d(c, co, 1) if co else None)
+    r = torch.randn(b, co, d, h, w, generator=gen) / (b * d * h * w) if co else None
+
+    def run(cache):
+        monkeypatch.setenv("S2D_PCR_SITE_CACHE", "1" if cache else "0")
+        mods = [None if mm is None else copy.deepcopy(mm).to("cuda") for mm in mods0]
+        if mods[3] is not None:
+            mods[3].bf16_compute = True
+        mods[0].train()
+        yf = y0.to("cuda").float()
+        y = y0.to("cuda", dtype).requires_grad_(True)
+        y._s2d_bn_stats = torch.cat([yf.double().sum((0, 2, 3, 4)), (yf.double() ** 2).sum((0, 2, 3, 4))]).float()
+        ml, ol, z = heads.pcr_level_norm(y, mods[0], mods[1], mods[2], coors.to("cuda"), feats.to("cuda"), next_conv=mods[3])
+        total = 1.7 * ml + 0.6 * ol
+        if co:
+            total = total + (z * r.to("cuda")).sum()
+        total.backward()
+        return [ml.detach(), ol.detach()] + ([z.detach()] if co else []) + [y.grad] + [p.grad for mm in mods if mm is not None for p in (mm.weight, mm.bias)]
+
+    ref = run(False)
+    got = run(True)
+    for i, (u, v) in enumerate(zip(got, ref)):
+        assert torch.equal(u, v), (i, float((u.double() - v.double()).abs().max()))
+
