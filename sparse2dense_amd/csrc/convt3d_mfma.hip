@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t ct_hi_hi(uint32_t a, uint32_t b) { return __
 __device__ __forceinline__ uint32_t ct_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // (a.lo, b.lo)
 // two fp32 -> one dword of two bf16 (round to nearest even; low half = a): ONE v_cvt_pk_bf16_f32.  hipcc emits the instruction with a dummy second
 // source per value and merges the halves with a v_perm_b32 (three instructions per pair) when the pair is built from two (__bf16) casts.
+// a * b + c as ONE scalar v_fma_f32 the SLP vectoriser cannot pair into v_pk_fma_f32: rule 36 - packed FP32 results were timing-dependent in their high
+// lane when another queue's MFMA kernel ran beside the kernel (r05, `pcr_level_bwd_dense`); the kernels below run beside other streams' MFMA work
+__device__ __forceinline__ float ct_fma_scalar(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t ct_cvt_pk_bf16(float a, float b) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
         }
         if constexpr (X16) {
             // bf16 planes: a 16-byte load is 8 cells of one plane; the input is always the raw tensor in front of the batch norm here (in_norm != null:
-            // the launcher's contract).  Per value: one shift / and to widen, half a v_pk_fma_f32 (two channels per instruction), half a
+            // the launcher's contract).  Per value: one shift / and to widen, one scalar v_fma_f32 (not v_pk_fma_f32: ct_fma_scalar), half a
             // v_cvt_pk_bf16_f32 - packing the channel PAIR (2k, 2k + 1) of a cell, which is the [cell][ci] order of the LDS image: no transposition -
             // and half a v_pk_max_i16 against zero: the ReLU on the two rounded bf16 values (sign bit set -> 0; rounding keeps the sign, so
             // relu(round(v)) == round(relu(v)) bit for bit).  The first version did widen / fma / max / narrow per scalar with a run-time in_norm test
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void c
                         const uint32_t wa = f[2 * k][j >> 1], wb = f[2 * k + 1][j >> 1];
                         f32x2x val = {__uint_as_float((j & 1) ? (wa & 0xffff0000u) : (wa << 16)),
                                       __uint_as_float((j & 1) ? (wb & 0xffff0000u) : (wb << 16))};
-                        val = __builtin_elementwise_fma(val, sc2[k], sh2[k]);
+                        val = f32x2x{ct_fma_scalar(val[0], sc2[k][0], sh2[k][0]), ct_fma_scalar(val[1], sc2[k][1], sh2[k][1])};
                         const s16x2x r2 = __builtin_elementwise_max(__builtin_bit_cast(s16x2x, ct_cvt_pk_bf16(val[0], val[1])), s16x2x{0, 0});
                         o[k] = ok ? __builtin_bit_cast(uint32_t, r2) : 0u;
                     }
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restr
                         a[ai] = __builtin_bit_cast(bf16x8m, u);
                         continue;
                     }
-                    {   // widen, normalise two cells per v_pk_fma_f32, narrow two per v_cvt_pk_bf16_f32, ReLU on the rounded pair (see ct_fwd_zslide_kernel)
+                    {   // widen, normalise (scalar v_fma_f32: ct_fma_scalar), narrow two per v_cvt_pk_bf16_f32, ReLU on the rounded pair (see ct_fwd_zslide_kernel)
                         typedef float f32x2x __attribute__((ext_vector_type(2)));
                         typedef short s16x2x __attribute__((ext_vector_type(2)));
                         const bool cv = cok && ci < s.cin;
@@ -1387,7 +1394,7 @@ __global__ __launch_bounds__(256) void ct_wgrad_narrow_kernel(const TXI *__restr
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             f32x2x val = {__uint_as_float(u[e] << 16), __uint_as_float(u[e] & 0xffff0000u)};
-                            val = __builtin_elementwise_fma(val, f32x2x{sc, sc}, f32x2x{sh, sh});
+                            val = f32x2x{ct_fma_scalar(val[0], sc, sh), ct_fma_scalar(val[1], sc, sh)};
                             const s16x2x r2 = __builtin_elementwise_max(__builtin_bit_cast(s16x2x, ct_cvt_pk_bf16(val[0], val[1])), s16x2x{0, 0});
                             o[e] = __builtin_bit_cast(uint32_t, r2);
                         }
