@@ -814,7 +814,7 @@ def main():
                     # busy, r05 measurement: the runtime orders graph branches with host-side signal handling.)
                     cands += [(g, pf, w, d) for d in ("aux,dense,pcr", "") for w in ("sparse", "")]
                 else:
-                    cands += [(g, pf, w, "") for w in ("aux,dense,sparse", "")]
+                    cands += [(g, pf, w, "") for w in ("aux,dense,pcr,sparse", "")]   # (r06: the PCR weight gradients too - side._parse)
         mode, mode_table = calibrate(models, step, dev, cands, world=world)
     elif args.mode != "auto":
         g, pf, w, *f = args.mode.split(":")
@@ -887,7 +887,7 @@ def main():
                     eager = [(v["mean_wall_ms"], k) for k, v in mode_table.items() if k.startswith("eager") and isinstance(v, dict) and "mean_wall_ms" in v]
                     if eager:
                         name_e = min(eager)[1]
-                        mode2 = (False, "loader-thread" in name_e, "aux,dense,sparse" if "wgrad-stream" in name_e else "", "")
+                        mode2 = (False, "loader-thread" in name_e, "aux,dense,pcr,sparse" if "wgrad-stream" in name_e else "", "")
                 set_mode([getattr(m2, "module", m2), t2], mode2)
                 if mode2[0] and not getattr(getattr(m2, "module", m2), "graph_dense", False):   # (fp32 mode: no graphed segment) label what ran
                     mode2 = (False, mode2[1], mode2[2], "")

@@ -32,16 +32,21 @@ import os
 
 import torch
 
-KINDS = ("dense", "sparse", "aux", "pcr")   # pcr: the PCR head's up-sampler / 1x1x1 weight gradients - deferral into the segment's second graph only
+KINDS = ("dense", "sparse", "aux", "pcr")   # pcr: the PCR head's up-sampler / 1x1x1 weight gradients (r06: on the eager stream too, see _parse)
 
 
 def _parse(v):
     """"1" / "all": every wired layer kind; a comma list of kinds for A/B runs; anything else: off.  Kinds: dense (3x3 / 1x1 NHWC convs),
     sparse (sparse convs), aux (the small ones: depth-wise 7x7, CenterHead output convs, 2x2 / 4x4 stride-2 forms, sparse-conv bias sums).
-    (The PCR head's up-samplers were tried too: time-neutral - their weight gradients are chip-filling streams - and not wired.)"""
+    pcr (the PCR head's up-sampler / 1x1x1 weight gradients): r04 time-neutral, r05 kept off the eager stream - the 16 -> 3 up-sampler's MFMA weight
+    gradient running beside `pcr_level_bwd_dense` made that kernel's packed-FP32 high lanes timing-dependent (rule 36; 68 of 70 stress runs differed).
+    r06 builds losses.hip without packed FP32 by default: 0 of 60 runs at 12 k points, 0 of 8 with the double-launch instrument, 0 of 4 at 4 x 150 k
+    (tools/side_stress.py <n> aux+dense+pcr+sparse:0), and 1.2 ms of weight-gradient kernels leave the chain: 18.0 -> 17.7 ms per eager step."""
     v = (v or "0").strip().lower()
     if v in ("1", "all"):
-        return set(KINDS) - {"pcr"}
+        if os.environ.get("S2D_BUILD_LOSSES_SLP") == "1":   # (the packed-FP32 build of losses.hip: rule 36's victim is back - keep the PCR kinds on the chain)
+            return set(KINDS) - {"pcr"}
+        return set(KINDS)
     return {k for k in v.split(",") if k in KINDS}
 
 

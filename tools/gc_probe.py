@@ -17,7 +17,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     model, teacher, frames, step = bench.setup_workload(args, "s2d_student", dev, 0)
-    bench.set_mode([model, teacher], (mode == "graph", True, "" if mode == "graph" else "aux,dense,sparse", "aux,dense,pcr" if mode == "graph" else ""))
+    bench.set_mode([model, teacher], (mode == "graph", True, "" if mode == "graph" else "aux,dense,pcr,sparse", "aux,dense,pcr" if mode == "graph" else ""))
     for _ in range(6):
         step()
     torch.cuda.synchronize()

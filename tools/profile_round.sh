@@ -16,7 +16,7 @@ B="--no-breakdown --no-cpu-baseline --no-extras --no-roofline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d -- python $R/bench.py --mode eager:instep:0 --steps 6 --warmup 3 $B > $R/$O/prof_s2d.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cp -- python $R/bench.py --mode eager:instep:0 --workload centerpoint --steps 6 --warmup 3 $B > $R/$O/prof_cp.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_graph -- python $R/bench.py --mode graph:loader:0:aux,dense,pcr --steps 8 --warmup 5 $B > $R/$O/prof_s2d_graph.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_streams -- python $R/bench.py --mode eager:loader:aux,dense,sparse --steps 6 --warmup 3 $B > $R/$O/prof_s2d_streams.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s2d_streams -- python $R/bench.py --mode eager:loader:aux,dense,pcr,sparse --steps 6 --warmup 3 $B > $R/$O/prof_s2d_streams.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pillar -- python $R/bench.py --mode eager:instep:0 --workload pillar_s2d --steps 6 --warmup 3 $B > $R/$O/prof_pillar.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python $R/bench.py --mode eager:instep:0 --steps 2 --warmup 2 $B > $R/$O/pmc_f.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python $R/bench.py --mode eager:instep:0 --steps 2 --warmup 2 $B > $R/$O/pmc_w.log 2>&1 < /dev/null

@@ -121,7 +121,8 @@ def run(mode, pcr, steps=4):
 
 POINTS = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
 BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-COMBOS = [tuple(c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [("sparse", "0"), ("1", "0"), ("sparse", "1")]
+# (a mode with several kinds is written with "+": aux+dense+pcr+sparse:0)
+COMBOS = [tuple(v.replace("+", ",") for v in c.split(":")) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [("sparse", "0"), ("1", "0"), ("sparse", "1")]
 REF_DONE = False
 ref, names = run("0", "0")
 REF_DONE = True
